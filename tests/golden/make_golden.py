@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by running the REFERENCE block itself (CPU, this container).
+
+Usage (build container only -- /root/reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports ``CE`` from /root/reference/<task>/model/dagl.py (and the fixed-k
+variant from DN_Gray/model/.ipynb_checkpoints/GReccR2b_3mh_1-checkpoint.py),
+loads weights from ``dagl_amd.synth.make_ce_params`` (numpy PCG64, regenerable
+anywhere), runs ``forward`` under ``torch.no_grad`` and stores only OUTPUT data:
+``tests/golden/<case>.npz`` with
+
+    out      [B,16,H,W] fp32   CE.forward's return value
+    deg      [B,L]  int32      neighbours per query (count of mask != 0)
+    rowsum   [B,L]  fp32       sum_j A_ij  (non-renormalised softmax mass)
+    agg_sub  [B,Ls,784] fp32   aggregated patches of every ``agg_step``-th query
+    meta     json string       case description (seed, variant, mode, k, shapes)
+
+Intermediates are captured with forward hooks / by re-deriving them from the
+reference modules' own sub-layers; no reference source text is stored.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+from dagl_amd.synth import make_ce_params, make_features  # noqa: E402
+
+# (name, task dir, seed, variant, sparse_gain, mode, k, B, H, W)
+CASES = [
+    ("gray_default_16x16",   "DN_Gray",  11, "default", 2.0, "adaptive", 0, 1, 16, 16),
+    ("gray_default_b2_23x30", "DN_Gray", 12, "default", 2.0, "adaptive", 0, 2, 23, 30),
+    ("gray_sparse_63x50",    "DN_Gray",  13, "sparse",  1.6, "adaptive", 0, 1, 63, 50),
+    ("gray_sparse_64x64",    "DN_Gray",  14, "sparse",  1.8, "adaptive", 0, 1, 64, 64),
+    ("gray_sparse_b2_72x72", "DN_Gray",  15, "sparse",  1.8, "adaptive", 0, 2, 72, 72),
+    ("gray_default_64x64",   "DN_Gray",  16, "default", 2.0, "adaptive", 0, 1, 64, 64),
+    ("gray_allpass_20x24",   "DN_Gray",  17, "allpass", 2.0, "adaptive", 0, 1, 20, 24),
+    ("gray_nonepass_20x24",  "DN_Gray",  18, "nonepass", 2.0, "adaptive", 0, 1, 20, 24),
+    ("car_sparse_40x52",     "CAR",      19, "sparse",  1.6, "adaptive", 0, 1, 40, 52),
+    ("demosaic_sparse_33x47", "Demosaic", 20, "sparse", 1.6, "adaptive", 0, 1, 33, 47),
+    ("real_sparse_b3_32x32", "DN_Real",  21, "sparse",  1.5, "adaptive", 0, 3, 32, 32),
+    ("topk4_64x64",          "TOPK",     22, "default", 2.0, "topk",     4, 1, 64, 64),
+    ("topk8_b2_45x38",       "TOPK",     23, "default", 2.0, "topk",     8, 2, 45, 38),
+    ("topk16_72x72",         "TOPK",     24, "default", 2.0, "topk",    16, 1, 72, 72),
+]
+
+
+def _load_module(task: str):
+    """Import the reference module that defines CE for ``task``."""
+    if task == "TOPK":
+        root = os.path.join(REF, "DN_Gray")
+        path = os.path.join(root, "model", ".ipynb_checkpoints", "GReccR2b_3mh_1-checkpoint.py")
+    else:
+        root = os.path.join(REF, task)
+        path = os.path.join(root, "model", "dagl.py")
+    # the reference does ``import model.common``: its task dir must lead sys.path
+    for m in [m for m in sys.modules if m == "model" or m.startswith("model.")]:
+        del sys.modules[m]
+    sys.path.insert(0, root)
+    try:
+        spec = importlib.util.spec_from_file_location(f"ref_{task.lower()}_ce", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(root)
+    return mod
+
+
+def run_case(case, agg_step=7):
+    name, task, seed, variant, gain, mode, k, B, H, W = case
+    mod = _load_module(task)
+    np_params = make_ce_params(seed, variant=variant, sparse_gain=gain)
+    x = torch.from_numpy(make_features(seed, B, 64, H, W))
+    if task == "TOPK":
+        ce = mod.CE(in_channels=64, num_edge=k)
+        sd = {n: torch.from_numpy(a) for n, a in np_params.items()
+              if not n.startswith(("thr_conv", "bias_conv"))}
+        missing = ce.load_state_dict(sd, strict=False)
+        assert set(missing.missing_keys) <= {"conv33.weight", "conv33.bias"}, missing
+    else:
+        ce = mod.CE(in_channels=64)
+        ce.load_state_dict({n: torch.from_numpy(a) for n, a in np_params.items()}, strict=True)
+    ce.eval()
+
+    grabbed = {}
+    if task == "TOPK":
+        # that variant returns b + W(y): take y (the 16-channel block output) at W's input
+        ce.W.register_forward_pre_hook(lambda m, inp: grabbed.__setitem__("y", inp[0].detach().clone()))
+    with torch.no_grad():
+        y = ce(x)
+    out = grabbed["y"] if task == "TOPK" else y
+
+    # intermediates re-derived with the reference module's own layers (dense)
+    degs, rowsums, aggs = [], [], []
+    with torch.no_grad():
+        b1, b2 = ce.g(x), ce.theta(x)
+        q, _ = mod.extract_image_patches(b1, [7, 7], [4, 4], [1, 1], padding="same")
+        kx, _ = mod.extract_image_patches(b1, [7, 7], [1, 1], [1, 1], padding="same")
+        vx, _ = mod.extract_image_patches(b2, [7, 7], [1, 1], [1, 1], padding="same")
+        if task != "TOPK":
+            b4, _ = mod.same_padding(x, [7, 7], [4, 4], [1, 1])
+            thr = ce.thr_conv(b4).view(B, -1)
+            bia = ce.bias_conv(b4).view(B, -1)
+        for n in range(B):
+            wi = ce.fc1(q[n].t())
+            xi = ce.fc2(kx[n].t()).t()
+            S = wi @ xi
+            if task == "TOPK":
+                _, pred = torch.topk(S, min(k, S.shape[1]), dim=1)
+                m = torch.zeros_like(S).scatter_(1, pred, 1.0)
+                mb = m
+            else:
+                m = torch.relu(S - S.mean(dim=1, keepdim=True) * thr[n].unsqueeze(1) + bia[n].unsqueeze(1))
+                mb = (m != 0).float()
+            A = torch.softmax(S * m * 10, dim=1) * mb
+            degs.append(mb.sum(1).to(torch.int32))
+            rowsums.append(A.sum(1))
+            aggs.append((A @ vx[n].t())[::agg_step])
+    meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode,
+                k=k, B=B, C=64, H=H, W=W, agg_step=agg_step,
+                torch=torch.__version__, threads=torch.get_num_threads())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        out=out.numpy().astype(np.float32),
+                        deg=torch.stack(degs).numpy(),
+                        rowsum=torch.stack(rowsums).numpy().astype(np.float32),
+                        agg_sub=torch.stack(aggs).numpy().astype(np.float32),
+                        meta=json.dumps(meta))
+    d = torch.stack(degs).float()
+    print(f"{name:26s} out{tuple(out.shape)} |out|max={out.abs().max():.4f} "
+          f"deg mean={d.mean():.1f} min={d.min():.0f} max={d.max():.0f}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    only = set(sys.argv[1:])
+    for c in CASES:
+        if not only or c[0] in only:
+            run_case(c)
