@@ -1,0 +1,81 @@
+"""ctypes binding of the C-ABI device library (include/dagl_ce.h).
+
+The library is built in-tree by ``dagl_amd.build`` (hipcc, gfx950).  There is no
+CPU or pure-torch fallback: if the shared object is missing or a call fails the
+error is raised to the caller.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
+
+MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
+MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
+MAX_TOPK = 32
+FAST_CAP = 64
+P = 784
+D = 196
+DS = 204
+ERR_WORKSPACE = -2
+
+
+class DaglError(RuntimeError):
+    pass
+
+
+class CeInfo(C.Structure):
+    _fields_ = [("required_bytes", C.c_int64), ("total_edges", C.c_int64),
+                ("max_degree", C.c_int32), ("path", C.c_int32)]
+
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); the one table every declared symbol of include/dagl_ce.h appears in
+SIGNATURES = {
+    "dagl_version": (_i, []),
+    "dagl_last_error": (C.c_char_p, []),
+    "dagl_device_check": (_i, []),
+    "dagl_ce_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dagl_ce_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
+                             C.POINTER(CeInfo)]),
+    "dagl_ce_forward_debug": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
+                                   C.POINTER(CeInfo), _vp, _vp, _vp]),
+    "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
+    "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dagl_feat_rows": (_i, [_i]),
+    "dagl_query_thresholds": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dagl_gather_aggregate": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dagl_unfold_values": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dagl_fold_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dagl_scores_dense": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the device library (once) and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DaglError(
+            f"{LIB_PATH} is missing: build it with `python -m dagl_amd.build` "
+            "(hipcc --offload-arch=gfx950); dagl_amd has no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError => the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().dagl_last_error().decode("utf-8", "replace")
+        raise DaglError(f"{what} failed (code {rc}): {msg}")

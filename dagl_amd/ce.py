@@ -1,0 +1,87 @@
+"""``CE`` -- drop-in replacement of the reference's patch-graph attention head.
+
+Mirrors ``CE`` of /root/reference/DN_Gray/model/dagl.py:174-277 (and its forks in
+CAR/, Demosaic/, DN_Real/): same constructor signature, same parameter names and
+shapes (including the registered-but-unused ``W``, dagl.py:192), same
+``forward(b: [B,in_channels,H,W]) -> [B,inter_channels,H,W]`` -- so ``CES``
+(dagl.py:74-119) accepts it by class substitution and reference checkpoints load
+unchanged.
+
+Only the four prologue convolutions (dagl.py:208-215) stay stock PyTorch-ROCm
+ops; everything from patch extraction to the batch concat (dagl.py:216-274) runs
+in the HIP library behind ``include/dagl_ce.h``.  There is no eager fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import MAX_TOPK, DaglError
+from .synth import same_pad_amounts
+
+
+class CE(nn.Module):
+    def __init__(self, ksize=7, stride_1=4, stride_2=1, softmax_scale=10, shape=64, p_len=64, in_channels=64,
+                 inter_channels=16, use_multiple_size=False, use_topk=False, add_SE=False, num_edge=50):
+        super().__init__()
+        if (ksize, stride_1, stride_2, softmax_scale, inter_channels) != (7, 4, 1, 10, 16):
+            raise DaglError(
+                "dagl_amd.CE implements the hyper-parameters the reference ships and never overrides "
+                "(ksize=7, stride_1=4, stride_2=1, softmax_scale=10, inter_channels=16; dagl.py:175-176)")
+        self.ksize, self.shape, self.p_len = ksize, shape, p_len
+        self.stride_1, self.stride_2 = stride_1, stride_2
+        self.softmax_scale = softmax_scale
+        self.inter_channels, self.in_channels = inter_channels, in_channels
+        self.use_multiple_size, self.use_topk, self.add_SE = use_multiple_size, use_topk, add_SE
+        self.num_edge = num_edge
+        # same registration order and names as dagl.py:190-205
+        self.g = nn.Conv2d(in_channels, inter_channels, kernel_size=3, stride=1, padding=1)
+        self.W = nn.Conv2d(inter_channels, in_channels, kernel_size=1, stride=1, padding=0)   # never applied
+        self.theta = nn.Conv2d(in_channels, inter_channels, kernel_size=1, stride=1, padding=0)
+        feat = ksize ** 2 * inter_channels
+        self.fc1 = nn.Sequential(nn.Linear(feat, feat // 4), nn.ReLU())
+        self.fc2 = nn.Sequential(nn.Linear(feat, feat // 4), nn.ReLU())
+        self.thr_conv = nn.Conv2d(in_channels, 1, kernel_size=ksize, stride=stride_1, padding=0)
+        self.bias_conv = nn.Conv2d(in_channels, 1, kernel_size=ksize, stride=stride_1, padding=0)
+        # Neighbour selection.  The shipped forward ignores use_topk/num_edge (dead arguments,
+        # dagl.py:176,187,189) and always applies the adaptive mask; ``select_mode`` makes the fixed-k
+        # variant (GReccR2b_3mh_1-checkpoint.py:242-250) and the intersection available:
+        #   "adaptive" | "topk" | "adaptive_topk", with k = ``select_k``.
+        self.select_mode = "adaptive"
+        self.select_k = min(num_edge, MAX_TOPK)
+        self._ws = ops.Workspace()
+        self.last_info = None
+
+    def extra_repr(self):
+        return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
+
+    def _prologue(self, b):
+        """The four stock convolutions of dagl.py:208-215 (MIOpen)."""
+        b1 = self.g(b)
+        b2 = self.theta(b)
+        H, W = b.shape[-2:]
+        t, bo = same_pad_amounts(H, self.ksize, self.stride_1)
+        l, r = same_pad_amounts(W, self.ksize, self.stride_1)
+        b4 = F.pad(b, (l, r, t, bo))
+        thr = self.thr_conv(b4).reshape(b.shape[0], -1)
+        bias = self.bias_conv(b4).reshape(b.shape[0], -1)
+        return b1, b2, thr, bias
+
+    def forward(self, b: torch.Tensor) -> torch.Tensor:
+        if b.dim() != 4 or b.shape[1] != self.in_channels:
+            raise DaglError(f"CE.forward: expected [B,{self.in_channels},H,W], got {tuple(b.shape)}")
+        if not b.is_cuda:
+            raise DaglError("CE.forward: input must be on the GPU; dagl_amd has no CPU path")
+        if b.dtype != torch.float32:
+            raise DaglError("CE.forward: fp32 input expected")
+        if torch.is_grad_enabled() and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise DaglError("CE.forward: the HIP block has no backward yet; call under torch.no_grad()")
+        b1, b2, thr, bias = self._prologue(b)
+        out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
+                                   self.fc1[0].weight.contiguous(), self.fc1[0].bias.contiguous(),
+                                   self.fc2[0].weight.contiguous(), self.fc2[0].bias.contiguous(),
+                                   mode=self.select_mode, k=self.select_k, workspace=self._ws, return_info=True)
+        self.last_info = info
+        return out

@@ -1,0 +1,347 @@
+// Edge softmax, neighbour gather + weighted sum, fold/normalise.
+//
+//   edge softmax   A_ij = mask_b * softmax_j(10 * S_ij * m_ij)         (DN_Gray/model/dagl.py:259-261)
+//                  evaluated on the neighbour list only: every non-neighbour contributes exp(0) to the
+//                  denominator (the reference does NOT renormalise after masking), so
+//                  A_ij = e^{l_ij - M} / (sum_nb e^{l - M} + (N - deg) e^{-M}),  M = max(max_nb l, [deg<N] 0)
+//   gather         agg_i = sum_j A_ij * V_j                              (torch.mm(yi, pi), dagl.py:263-264)
+//                  V_j read on the fly from the padded NHWC value map (7 x 448-B segments per neighbour)
+//   fold           out = fold(agg) / fold(unfold(1))                     (dagl.py:265-272)
+#include "dagl_common.h"
+
+namespace dagl {
+
+// ------------------------------------------------------------------------------------------------------
+// edge softmax
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_logit(float s, float mtq, float bsq, bool adaptive) {
+    // l = (S * m) * 10 in fp32, m = relu((S - mean*thr) + bias) or 1  -- the reference's operation order
+    float m = 1.0f;
+    if (adaptive) m = (s - mtq) + bsq;
+    return __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE);
+}
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// MODE 0: adaptive single-pass lists (<= 64 entries, unordered) -> sorted by key index, weights.
+// One wave per query.
+__global__ __launch_bounds__(256) void edge_softmax_fast_kernel(EdgeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ql >= (size_t)a.B * a.L) return;
+    int n = a.cnt[ql];
+    if (n > DAGL_FAST_CAP) n = DAGL_FAST_CAP;                 // overflowing rows are redone by the CSR path
+    int key = 0x7fffffff; float s = 0.f;
+    if (lane < n) { key = a.list_idx[ql * DAGL_FAST_CAP + lane]; s = a.list_val[ql * DAGL_FAST_CAP + lane]; }
+    // bitonic sort (ascending key) across the 64 lanes: the append order of the atomics is not
+    // deterministic, the summation order downstream must be
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const int okey = __shfl_xor(key, j);
+            const float os = __shfl_xor(s, j);
+            const bool up = ((lane & k2) == 0);
+            const bool lower = ((lane & j) == 0);
+            const bool take = (lower == up) ? (okey < key) : (okey > key);
+            if (take) { key = okey; s = os; }
+        }
+    }
+    const float mtq = a.mt[ql], bsq = a.bs[ql];
+    const bool valid = lane < n;
+    const float lg = valid ? edge_logit(s, mtq, bsq, true) : 0.f;
+    double M = wave_max_d(valid ? (double)lg : -1e300);
+    if (n < a.N) M = fmax(M, 0.0);
+    const double e = valid ? exp((double)lg - M) : 0.0;
+    const double sum = wave_sum_d(e) + (double)(a.N - n) * exp(-M);
+    if (valid) {
+        a.nb_idx[ql * a.width + lane] = key;
+        a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+    }
+    if (lane == 0) a.nb_cnt[ql] = n;
+}
+
+// MODE 1: CSR lists of any length (already in deterministic order): weights written at the same offsets.
+__global__ __launch_bounds__(256) void edge_softmax_csr_kernel(EdgeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ql >= (size_t)a.B * a.L) return;
+    const int64_t o0 = a.row_off[ql], o1 = a.row_off[ql + 1];
+    const int n = (int)(o1 - o0);
+    const float mtq = a.mt[ql], bsq = a.bs[ql];
+    double M = -1e300;
+    for (int64_t o = o0 + lane; o < o1; o += 64) M = fmax(M, (double)edge_logit(a.list_val[o], mtq, bsq, true));
+    M = wave_max_d(M);
+    if (n < a.N) M = fmax(M, 0.0);
+    double sum = 0.0;
+    for (int64_t o = o0 + lane; o < o1; o += 64) sum += exp((double)edge_logit(a.list_val[o], mtq, bsq, true) - M);
+    sum = wave_sum_d(sum) + (double)(a.N - n) * exp(-M);
+    for (int64_t o = o0 + lane; o < o1; o += 64) {
+        a.nb_idx[o] = a.list_idx[o];
+        a.nb_wgt[o] = (float)(exp((double)edge_logit(a.list_val[o], mtq, bsq, true) - M) / sum);
+    }
+    if (lane == 0) a.nb_cnt[ql] = n;
+}
+
+// MODE 2/3: merge the per-(chunk, half) k-best candidate lists of a query into its exact k best
+// (value descending, ties -> smaller key index), then weights.  One wave per query; candidates in LDS.
+constexpr int TOPK_MAX_CAND = 1024;
+__global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int kslots) {
+    __shared__ float cv[4][TOPK_MAX_CAND];
+    __shared__ int ci[4][TOPK_MAX_CAND];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t ql = (size_t)blockIdx.x * 4 + w;
+    const bool active = ql < (size_t)a.B * a.L;
+    const int nc = a.splits * 2 * kslots;
+    if (active) {
+        for (int t = lane; t < nc; t += 64) {
+            cv[w][t] = a.cand_val[ql * nc + t];
+            ci[w][t] = a.cand_idx[ql * nc + t];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const bool adaptive = (a.mode == DAGL_MODE_ADAPTIVE_TOPK);
+    const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
+    float my_s = 0.f; int my_key = -1;          // lane r keeps the r-th selected neighbour
+    int n = 0;
+    for (int r = 0; r < a.k; ++r) {
+        float bv = -2.f; int bi = 0x7fffffff, bpos = -1;
+        for (int t = lane; t < nc; t += 64) {
+            const float v = cv[w][t]; const int id = ci[w][t];
+            if (id >= 0 && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; bpos = t; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o); const int op = __shfl_xor(bpos, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
+        }
+        if (bpos < 0) break;                     // fewer than k candidates exist (wave-uniform)
+        if (lane == r) { my_s = bv; my_key = bi; }
+        if (lane == 0) ci[w][bpos] = -1;         // taken
+        __threadfence_block();                   // LDS write visible to the wave's next scan
+        ++n;
+    }
+    const bool valid = lane < n;
+    const float lg = valid ? edge_logit(my_s, mtq, bsq, adaptive) : 0.f;
+    double M = wave_max_d(valid ? (double)lg : -1e300);
+    if (n < a.N) M = fmax(M, 0.0);
+    const double e = valid ? exp((double)lg - M) : 0.0;
+    const double sum = wave_sum_d(e) + (double)(a.N - n) * exp(-M);
+    if (valid) {
+        a.nb_idx[ql * a.width + lane] = my_key;
+        a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+    }
+    if (lane == 0) a.nb_cnt[ql] = n;
+}
+
+// per-query degree and softmax mass (parity tests: the reference's mask_b.sum(1) and A.sum(1))
+__global__ void row_stats_kernel(size_t n_rows, const float* __restrict__ nb_wgt, const int32_t* __restrict__ nb_cnt,
+                                 const int64_t* __restrict__ row_off, int width, int32_t* __restrict__ deg,
+                                 float* __restrict__ rowsum) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int n = nb_cnt[r];
+    const float* w = nb_wgt + (row_off ? (size_t)row_off[r] : r * width);
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += (double)w[j];
+    if (deg) deg[r] = n;
+    if (rowsum) rowsum[r] = (float)s;
+}
+
+int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const int32_t* nb_cnt, const int64_t* row_off,
+                     int width, int32_t* deg, float* rowsum) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, n_rows, nb_wgt,
+                       nb_cnt, row_off, width, deg, rowsum);
+    DAGL_LAUNCH_CHECK("row_stats_kernel");
+    return DAGL_OK;
+}
+
+int launch_edge_softmax(hipStream_t s, const EdgeArgs& a) {
+    const size_t nq = (size_t)a.B * a.L;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (a.mode == DAGL_MODE_ADAPTIVE) {
+        if (a.row_off == nullptr) hipLaunchKernelGGL(edge_softmax_fast_kernel, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(edge_softmax_csr_kernel, grid, block, 0, s, a);
+    } else {
+        const int ks = topk_slots(a.k);
+        if (a.splits * 2 * ks > TOPK_MAX_CAND) {
+            set_error("edge softmax: %d candidates per query exceed %d", a.splits * 2 * ks, TOPK_MAX_CAND);
+            return DAGL_ERR_INVALID;
+        }
+        hipLaunchKernelGGL(edge_softmax_topk_kernel, grid, block, 0, s, a, ks);
+    }
+    DAGL_LAUNCH_CHECK("edge_softmax_kernel");
+    return DAGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gather + weighted sum, value rows read on the fly from the padded NHWC value map
+// ------------------------------------------------------------------------------------------------------
+// thread = (query, float4 column r of the 784-float patch row): r = kh*28 + (kw*4 + c4)
+__global__ __launch_bounds__(256) void aggregate_direct_kernel(AggArgs a) {
+    const int b = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C4 = P / 4;                                      // 196
+    if (t >= (size_t)a.g.L * C4) return;
+    const int q = (int)(t / C4), r = (int)(t % C4);
+    const int kh = r / 28, rem = r % 28;
+    const size_t ql = (size_t)b * a.g.L + q;
+    const int n = a.nb_cnt[ql];
+    const size_t lo = a.row_off ? (size_t)a.row_off[ql] : ql * a.width;
+    const int32_t* ip = a.nb_idx + lo;
+    const float* wp = a.nb_wgt + lo;
+    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH) + rem;
+    const int W = a.g.W, Wp = a.g.Wp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        int id[4]; float w[4]; float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { id[u] = ip[j + u]; w[u] = wp[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jy = id[u] / W, jx = id[u] - jy * W;
+            v[u] = vm[((size_t)(jy + kh) * Wp + jx) * (CH / 4)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+            acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+        }
+    }
+    for (; j < n; ++j) {
+        const int id = ip[j]; const float w = wp[j];
+        const int jy = id / W, jx = id - jy * W;
+        const float4 v = vm[((size_t)(jy + kh) * Wp + jx) * (CH / 4)];
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+    reinterpret_cast<float4*>(a.agg)[ql * C4 + r] = acc;
+}
+
+int launch_aggregate_direct(hipStream_t s, const AggArgs& a) {
+    const size_t items = (size_t)a.g.L * (P / 4);
+    dim3 grid((unsigned)((items + 255) / 256), a.B), block(256);
+    hipLaunchKernelGGL(aggregate_direct_kernel, grid, block, 0, s, a);
+    DAGL_LAUNCH_CHECK("aggregate_direct_kernel");
+    return DAGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stand-alone gather over materialised value rows (the roofline-graded form: k*P*4 + k*8 + P*4 B/query)
+// ------------------------------------------------------------------------------------------------------
+template <int KU>
+__global__ __launch_bounds__(256) void gather_rows_kernel(int L, int k, int P4, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ wgt,
+                                                          const float4* __restrict__ values,
+                                                          float4* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)L * P4) return;
+    const int q = (int)(t / P4), r = (int)(t % P4);
+    const int32_t* ip = idx + (size_t)q * k;
+    const float* wp = wgt + (size_t)q * k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = 0;
+    for (; j + KU <= k; j += KU) {
+        int id[KU]; float w[KU]; float4 v[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { id[u] = ip[j + u]; w[u] = wp[j + u]; }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const bool ok = id[u] >= 0;
+            v[u] = values[(size_t)(ok ? id[u] : 0) * P4 + r];
+            if (!ok) w[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+            acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+        }
+    }
+    for (; j < k; ++j) {
+        const int id = ip[j];
+        if (id < 0) continue;
+        const float w = wp[j];
+        const float4 v = values[(size_t)id * P4 + r];
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+    out[t] = acc;
+}
+
+int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
+                        const float* values, float* out) {
+    const int P4 = P_ / 4;
+    const size_t items = (size_t)L * P4;
+    dim3 grid((unsigned)((items + 255) / 256)), block(256);
+    if (k % 8 == 0)
+        hipLaunchKernelGGL(gather_rows_kernel<8>, grid, block, 0, s, L, k, P4, idx, wgt,
+                           reinterpret_cast<const float4*>(values), reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<4>, grid, block, 0, s, L, k, P4, idx, wgt,
+                           reinterpret_cast<const float4*>(values), reinterpret_cast<float4*>(out));
+    DAGL_LAUNCH_CHECK("gather_rows_kernel");
+    return DAGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fold + overlap normalisation
+// ------------------------------------------------------------------------------------------------------
+// Query (r,c)'s aggregated 7x7 patch lands with its top-left corner at (4r-3, 4c-3) (fold grid: kernel 7,
+// padding 3, stride 4 -- dagl.py:266), i.e. NOT where it was read (SAME grid, top-left 4r-pt).  A pixel is
+// covered by <= 2 x 2 windows; the divisor fold(unfold(1)) (dagl.py:268-270) is that window count.
+__global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restrict__ agg, float* __restrict__ out) {
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= g.W) return;
+    // rows r with 4r-3 <= y <= 4r+3
+    int r0 = (y - 3 + QS - 1) / QS; if (y - 3 < 0) r0 = 0;
+    int r1 = (y + 3) / QS; if (r1 > g.Lh - 1) r1 = g.Lh - 1;
+    int c0 = (x - 3 + QS - 1) / QS; if (x - 3 < 0) c0 = 0;
+    int c1 = (x + 3) / QS; if (c1 > g.Lw - 1) c1 = g.Lw - 1;
+    float4 acc[CH / 4];
+#pragma unroll
+    for (int u = 0; u < CH / 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r <= r1; ++r) {
+        const int kh = y - (QS * r - 3);
+        for (int c = c0; c <= c1; ++c) {
+            const int kw = x - (QS * c - 3);
+            const float4* p = reinterpret_cast<const float4*>(
+                agg + ((size_t)b * g.L + (size_t)r * g.Lw + c) * P + (kh * KS + kw) * CH);
+#pragma unroll
+            for (int u = 0; u < CH / 4; ++u) {
+                const float4 v = p[u];
+                acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            }
+        }
+    }
+    const float cnt = (float)((r1 - r0 + 1) * (c1 - c0 + 1));
+    float* o = out + (size_t)b * CH * g.N + (size_t)y * g.W + x;
+#pragma unroll
+    for (int u = 0; u < CH / 4; ++u) {
+        o[(size_t)(4 * u + 0) * g.N] = acc[u].x / cnt;
+        o[(size_t)(4 * u + 1) * g.N] = acc[u].y / cnt;
+        o[(size_t)(4 * u + 2) * g.N] = acc[u].z / cnt;
+        o[(size_t)(4 * u + 3) * g.N] = acc[u].w / cnt;
+    }
+}
+
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out) {
+    dim3 grid((g.W + 63) / 64, g.H, B), block(64);
+    hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out);
+    DAGL_LAUNCH_CHECK("fold_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

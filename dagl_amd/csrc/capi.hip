@@ -1,0 +1,328 @@
+// extern "C" boundary (include/dagl_ce.h) and the orchestration of one block forward.
+#include <stdarg.h>
+#include <string.h>
+
+#include "dagl_common.h"
+
+namespace dagl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    (void)hipGetLastError();
+    return DAGL_ERR_HIP;
+}
+
+// ---- execution plan: chunking of the key stream + workspace carve ---------------------------------------
+struct Plan {
+    Grid g;
+    int B, mode, k, kslots;
+    int splits, tiles_per_split, n_tiles;
+    int width;                      // neighbour-list width of the fixed-width paths
+    // byte offsets into the workspace
+    size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff, o_deg,
+        o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_end;
+};
+
+static size_t carve(size_t& off, size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+}
+
+static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
+    DAGL_REQUIRE(mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK,
+                 "dagl: unknown mode %d", mode);
+    if (mode != DAGL_MODE_ADAPTIVE)
+        DAGL_REQUIRE(k >= 1 && k <= DAGL_MAX_TOPK, "dagl: k=%d outside [1,%d]", k, DAGL_MAX_TOPK);
+    DAGL_REQUIRE((int64_t)H * W < (1ll << 30), "dagl: image too large");
+    p.g = make_grid(H, W);
+    p.B = B; p.mode = mode; p.k = k;
+    p.kslots = (mode == DAGL_MODE_ADAPTIVE) ? 0 : topk_slots(k);
+    const Grid& g = p.g;
+    p.n_tiles = (g.N + KT - 1) / KT;
+    const int n_qgroups = (g.L + 127) / 128;
+    // enough blocks for ~4 per CU, chunks of at least 8 tiles, candidate merge bounded for top-k
+    int splits = (1024 + n_qgroups * B - 1) / (n_qgroups * B);
+    const int max_by_tiles = (p.n_tiles + 7) / 8;
+    if (splits > max_by_tiles) splits = max_by_tiles;
+    if (p.kslots) { const int cap = 1024 / (2 * p.kslots); if (splits > cap) splits = cap; }
+    if (splits < 1) splits = 1;
+    p.tiles_per_split = (p.n_tiles + splits - 1) / splits;
+    p.splits = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    p.width = (mode == DAGL_MODE_ADAPTIVE) ? DAGL_FAST_CAP : k;
+
+    const size_t BL = (size_t)B * g.L;
+    size_t off = 0;
+    const size_t map_b = (size_t)B * g.Hp * g.Wp * CH * sizeof(float);
+    p.o_b1p = carve(off, map_b);
+    p.o_b2p = carve(off, map_b);
+    p.o_wp1 = carve(off, (size_t)DPAD * P * sizeof(float));
+    p.o_wp2 = carve(off, (size_t)DPAD * P * sizeof(float));
+    p.o_x = carve(off, (size_t)B * feat_rows(g.N) * DS * sizeof(float));
+    p.o_wq = carve(off, (size_t)B * feat_rows(g.L) * DS * sizeof(float));
+    p.o_colsum = carve(off, (size_t)B * DS * sizeof(double));
+    p.o_mt = carve(off, BL * sizeof(float));
+    p.o_cnt = carve(off, BL * sizeof(int32_t));
+    p.o_segcnt = carve(off, BL * p.splits * 2 * sizeof(int32_t));
+    p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int64_t));
+    p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
+    p.o_deg = carve(off, BL * sizeof(int32_t));
+    p.o_stats = carve(off, 2 * sizeof(int64_t));
+    if (mode == DAGL_MODE_ADAPTIVE) {
+        p.o_lidx = carve(off, BL * DAGL_FAST_CAP * sizeof(int32_t));
+        p.o_lval = carve(off, BL * DAGL_FAST_CAP * sizeof(float));
+        p.o_cidx = p.o_cval = 0;
+    } else {
+        p.o_lidx = p.o_lval = 0;
+        p.o_cidx = carve(off, BL * p.splits * 2 * p.kslots * sizeof(int32_t));
+        p.o_cval = carve(off, BL * p.splits * 2 * p.kslots * sizeof(float));
+    }
+    p.o_nbidx = carve(off, BL * p.width * sizeof(int32_t));
+    p.o_nbwgt = carve(off, BL * p.width * sizeof(float));
+    p.o_nbcnt = carve(off, BL * sizeof(int32_t));
+    p.o_agg = carve(off, BL * P * sizeof(float));
+    p.o_end = off;
+    return DAGL_OK;
+}
+
+template <class T>
+static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+static int check_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("dagl: no HIP device"); (void)hipGetLastError(); return DAGL_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("dagl: cannot query device"); (void)hipGetLastError(); return DAGL_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("dagl: device arch %s is not gfx950", prop.gcnArchName);
+        return DAGL_ERR_NO_DEVICE;
+    }
+    return DAGL_OK;
+}
+
+static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
+                           const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                           const float* fc2_b, int mode, int k, float* out, void* ws, size_t ws_bytes,
+                           dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg) {
+    Plan p;
+    int rc = make_plan(B, H, W, mode, k, p);
+    if (rc) return rc;
+    if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = 0; info->max_degree = 0; info->path = 0; }
+    DAGL_REQUIRE(b1 && b2 && fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
+    if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias, "dagl_ce_forward: thr/bias required in adaptive modes");
+    DAGL_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256) == 0, "dagl_ce_forward: workspace must be 256-byte aligned");
+    if (ws_bytes < p.o_end) {
+        set_error("dagl_ce_forward: workspace %zu B < required %zu B", ws_bytes, p.o_end);
+        return DAGL_ERR_WORKSPACE;
+    }
+    const Grid& g = p.g;
+    const size_t BL = (size_t)B * g.L;
+
+    float* b1p = at<float>(ws, p.o_b1p);
+    float* b2p = at<float>(ws, p.o_b2p);
+    float* wp1 = at<float>(ws, p.o_wp1);
+    float* wp2 = at<float>(ws, p.o_wp2);
+    float* X = at<float>(ws, p.o_x);
+    float* Wq = at<float>(ws, p.o_wq);
+    double* colsum = at<double>(ws, p.o_colsum);
+    float* mt = at<float>(ws, p.o_mt);
+    int32_t* cnt = at<int32_t>(ws, p.o_cnt);
+    int32_t* segcnt = at<int32_t>(ws, p.o_segcnt);
+    int64_t* segoff = at<int64_t>(ws, p.o_segoff);
+    int64_t* rowoff = at<int64_t>(ws, p.o_rowoff);
+    int32_t* deg = at<int32_t>(ws, p.o_deg);
+    int64_t* stats = at<int64_t>(ws, p.o_stats);
+    int32_t* nbidx = at<int32_t>(ws, p.o_nbidx);
+    float* nbwgt = at<float>(ws, p.o_nbwgt);
+    int32_t* nbcnt = at<int32_t>(ws, p.o_nbcnt);
+    float* agg = at<float>(ws, p.o_agg);
+
+    // 1. layout: zero-bordered NHWC maps, packed fc weights
+    if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
+    if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
+    if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
+    if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
+
+    // 2. projections (the tail rows / guard tile of the feature matrices must be finite: zero them)
+    {
+        const int rx = feat_rows(g.N), rq = feat_rows(g.L);
+        for (int b = 0; b < B; ++b) {
+            DAGL_HIP_TRY(hipMemsetAsync(X + ((size_t)b * rx + g.N) * DS, 0, (size_t)(rx - g.N) * DS * sizeof(float), s));
+            DAGL_HIP_TRY(hipMemsetAsync(Wq + ((size_t)b * rq + g.L) * DS, 0, (size_t)(rq - g.L) * DS * sizeof(float), s));
+        }
+        DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
+    }
+    if ((rc = launch_project(s, B, g, false, b1p, wp2, fc2_b, X, colsum))) return rc;
+    if ((rc = launch_project(s, B, g, true, b1p, wp1, fc1_b, Wq, nullptr))) return rc;
+
+    // 3. selection
+    SelectArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.B = B; sa.L = g.L; sa.N = g.N; sa.W = g.W; sa.wq = Wq; sa.x = X; sa.mode = mode; sa.k = k;
+    sa.splits = p.splits; sa.tiles_per_split = p.tiles_per_split;
+    EdgeArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.B = B; ea.L = g.L; ea.N = g.N; ea.mode = mode; ea.k = k; ea.splits = p.splits;
+    ea.nb_idx = nbidx; ea.nb_wgt = nbwgt; ea.nb_cnt = nbcnt; ea.width = p.width;
+    AggArgs ag;
+    memset(&ag, 0, sizeof(ag));
+    ag.B = B; ag.g = g; ag.b2p = b2p; ag.nb_idx = nbidx; ag.nb_wgt = nbwgt; ag.nb_cnt = nbcnt; ag.width = p.width;
+    ag.agg = agg;
+
+    if (mode != DAGL_MODE_TOPK) {
+        if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt))) return rc;
+        sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
+    }
+
+    if (mode == DAGL_MODE_ADAPTIVE) {
+        int32_t* lidx = at<int32_t>(ws, p.o_lidx);
+        float* lval = at<float>(ws, p.o_lval);
+        DAGL_HIP_TRY(hipMemsetAsync(cnt, 0, BL * sizeof(int32_t), s));
+        sa.cnt = cnt; sa.seg_cnt = segcnt; sa.list_idx = lidx; sa.list_val = lval;
+        if ((rc = launch_score_select(s, sa, 0))) return rc;
+        if ((rc = launch_csr_offsets(s, (int)BL, p.splits * 2, segcnt, segoff, rowoff, deg, stats))) return rc;
+        int64_t hstats[2] = {0, 0};
+        DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
+        DAGL_HIP_TRY(hipStreamSynchronize(s));
+        if (info) { info->total_edges = hstats[0]; info->max_degree = (int32_t)hstats[1]; }
+        if (hstats[1] <= DAGL_FAST_CAP) {
+            ea.cnt = deg; ea.list_idx = lidx; ea.list_val = lval; ea.row_off = nullptr;
+            if ((rc = launch_edge_softmax(s, ea))) return rc;
+        } else {
+            // two-pass CSR: exact degrees are known, refill deterministically at per-lane cursors
+            size_t off = p.o_end;
+            const size_t e = (size_t)hstats[0];
+            const size_t o_ci = carve(off, e * sizeof(int32_t));
+            const size_t o_cv = carve(off, e * sizeof(float));
+            const size_t o_ni = carve(off, e * sizeof(int32_t));
+            const size_t o_nw = carve(off, e * sizeof(float));
+            if (info) { info->required_bytes = (int64_t)off; info->path = 1; }
+            if (ws_bytes < off) {
+                set_error("dagl_ce_forward: dense neighbourhoods (max degree %lld, %lld edges) need workspace %zu B, have %zu B",
+                          (long long)hstats[1], (long long)hstats[0], off, ws_bytes);
+                return DAGL_ERR_WORKSPACE;
+            }
+            sa.list_idx = at<int32_t>(ws, o_ci); sa.list_val = at<float>(ws, o_cv); sa.seg_off = segoff;
+            if ((rc = launch_score_select(s, sa, 1))) return rc;
+            ea.cnt = deg; ea.list_idx = sa.list_idx; ea.list_val = sa.list_val; ea.row_off = rowoff;
+            ea.nb_idx = at<int32_t>(ws, o_ni); ea.nb_wgt = at<float>(ws, o_nw);
+            if ((rc = launch_edge_softmax(s, ea))) return rc;
+            ag.nb_idx = ea.nb_idx; ag.nb_wgt = ea.nb_wgt; ag.row_off = rowoff;
+        }
+    } else {
+        sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
+        if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
+        ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
+        if ((rc = launch_edge_softmax(s, ea))) return rc;
+        if (info) { info->path = 2; info->max_degree = k; info->total_edges = -1; }
+    }
+
+    // 4. gather + weighted sum, fold
+    if (dbg_deg || dbg_rowsum)
+        if ((rc = launch_row_stats(s, BL, ag.nb_wgt, ag.nb_cnt, ag.row_off, ag.width, dbg_deg, dbg_rowsum))) return rc;
+    if ((rc = launch_aggregate_direct(s, ag))) return rc;
+    if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_fold(s, B, g, agg, out))) return rc;
+    return DAGL_OK;
+}
+
+}  // namespace dagl
+
+using namespace dagl;
+
+extern "C" {
+
+int dagl_version(void) { return 100; }
+
+const char* dagl_last_error(void) { return g_err; }
+
+int dagl_device_check(void) { return check_device(); }
+
+size_t dagl_ce_workspace_bytes(int B, int H, int W, int mode, int k) {
+    Plan p;
+    if (make_plan(B, H, W, mode, k, p)) return 0;
+    return p.o_end;
+}
+
+int dagl_ce_forward(void* stream, int B, int H, int W, const float* b1, const float* b2, const float* thr,
+                    const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                    const float* fc2_b, int mode, int k, float* out, void* workspace, size_t ws_bytes,
+                    dagl_ce_info* info) {
+    return ce_forward_impl((hipStream_t)stream, B, H, W, b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode, k, out,
+                           workspace, ws_bytes, info, nullptr, nullptr, nullptr);
+}
+
+int dagl_ce_forward_debug(void* stream, int B, int H, int W, const float* b1, const float* b2, const float* thr,
+                          const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                          const float* fc2_b, int mode, int k, float* out, void* workspace, size_t ws_bytes,
+                          dagl_ce_info* info, int32_t* deg_out, float* rowsum_out, float* agg_out) {
+    return ce_forward_impl((hipStream_t)stream, B, H, W, b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode, k, out,
+                           workspace, ws_bytes, info, deg_out, rowsum_out, agg_out);
+}
+
+int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && src_nchw && dst_nhwc, "dagl_pad_nhwc: bad argument");
+    return launch_pad_nhwc((hipStream_t)stream, B, H, W, src_nchw, dst_nhwc);
+}
+
+int dagl_pack_fc_weight(void* stream, const float* w, float* w_packed) {
+    DAGL_REQUIRE(w && w_packed, "dagl_pack_fc_weight: null pointer");
+    return launch_pack_fc_weight((hipStream_t)stream, w, w_packed);
+}
+
+int dagl_feat_rows(int rows) { return feat_rows(rows); }
+
+int dagl_project_patches(void* stream, int B, int H, int W, int queries, const float* map_nhwc,
+                         const float* w_packed, const float* fc_bias, float* feat, double* colsum) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && map_nhwc && w_packed && fc_bias && feat,
+                 "dagl_project_patches: bad argument");
+    const Grid g = make_grid(H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = queries ? g.L : g.N, ra = feat_rows(rows);
+    for (int b = 0; b < B; ++b)
+        DAGL_HIP_TRY(hipMemsetAsync(feat + ((size_t)b * ra + rows) * DS, 0, (size_t)(ra - rows) * DS * sizeof(float), s));
+    if (colsum) DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
+    return launch_project(s, B, g, queries != 0, map_nhwc, w_packed, fc_bias, feat, queries ? nullptr : colsum);
+}
+
+int dagl_query_thresholds(void* stream, int B, int L, int N, const float* wq, const double* colsum,
+                          const float* thr, float* mt) {
+    DAGL_REQUIRE(B >= 1 && L >= 1 && N >= 1 && wq && colsum && thr && mt, "dagl_query_thresholds: bad argument");
+    return launch_query_thresholds((hipStream_t)stream, B, L, N, wq, colsum, thr, mt);
+}
+
+int dagl_gather_aggregate(void* stream, int L, int k, int P_, const int32_t* idx, const float* wgt,
+                          const float* values, float* out) {
+    DAGL_REQUIRE(L >= 0 && k >= 1 && P_ >= 4 && (P_ % 4) == 0, "dagl_gather_aggregate: bad shape L=%d k=%d P=%d", L, k, P_);
+    DAGL_REQUIRE(idx && wgt && values && out, "dagl_gather_aggregate: null pointer");
+    DAGL_REQUIRE(((uintptr_t)values % 16) == 0 && ((uintptr_t)out % 16) == 0, "dagl_gather_aggregate: 16-byte alignment required");
+    if (L == 0) return DAGL_OK;
+    return launch_gather_fixed((hipStream_t)stream, L, k, P_, idx, wgt, values, out);
+}
+
+int dagl_unfold_values(void* stream, int B, int H, int W, const float* b2_nhwc, float* rows) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && b2_nhwc && rows, "dagl_unfold_values: bad argument");
+    return launch_unfold_values((hipStream_t)stream, B, make_grid(H, W), b2_nhwc, rows);
+}
+
+int dagl_fold_normalize(void* stream, int B, int H, int W, const float* agg, float* out) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && agg && out, "dagl_fold_normalize: bad argument");
+    return launch_fold((hipStream_t)stream, B, make_grid(H, W), agg, out);
+}
+
+int dagl_scores_dense(void* stream, int B, int L, int N, const float* wq, const float* x, float* sc) {
+    DAGL_REQUIRE(B >= 1 && L >= 1 && N >= 1 && wq && x && sc, "dagl_scores_dense: bad argument");
+    return launch_scores_dense((hipStream_t)stream, B, L, N, wq, x, sc);
+}
+
+}  // extern "C"

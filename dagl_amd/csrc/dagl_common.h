@@ -1,0 +1,142 @@
+// Shared declarations of the device library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dagl_ce.h"
+
+namespace dagl {
+
+constexpr int KS = DAGL_KSIZE;        // 7
+constexpr int QS = DAGL_QSTRIDE;      // 4
+constexpr int CH = DAGL_CH;           // 16 channels of the feature maps
+constexpr int P = DAGL_P;             // 784
+constexpr int D = DAGL_D;             // 196
+constexpr int DS = DAGL_DS;           // 204: feature row stride (floats); 51 16-B slots, odd => conflict-free b128 LDS reads
+constexpr int DPAD = 208;             // fc output columns rounded up to 13 MFMA tiles of 16
+constexpr int PADPIX = DAGL_PADPIX;   // 3
+constexpr int KT = 32;                // keys per streaming tile (one 32x32 MFMA tile)
+constexpr int QT = 32;                // queries per wave
+constexpr float SOFTMAX_SCALE = 10.0f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local error text
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DAGL_HIP_TRY(expr)                                         \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return ::dagl::hip_fail(_e, #expr);  \
+    } while (0)
+
+#define DAGL_LAUNCH_CHECK(name)                                    \
+    do {                                                           \
+        hipError_t _e = hipGetLastError();                         \
+        if (_e != hipSuccess) return ::dagl::hip_fail(_e, name);   \
+    } while (0)
+
+#define DAGL_REQUIRE(cond, ...)                                    \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ::dagl::set_error(__VA_ARGS__);                        \
+            return DAGL_ERR_INVALID;                               \
+        }                                                          \
+    } while (0)
+
+struct Grid {            // geometry of one image
+    int H, W;            // feature map
+    int Hp, Wp;          // padded map (H+6, W+6)
+    int Lh, Lw, L;       // stride-4 query grid
+    int N;               // keys = H*W
+    int pt, pl;          // SAME padding (top, left) of the stride-4 grid  (dagl.py:123-139)
+};
+
+inline Grid make_grid(int H, int W) {
+    Grid g;
+    g.H = H; g.W = W; g.Hp = H + 2 * PADPIX; g.Wp = W + 2 * PADPIX;
+    g.Lh = (H + QS - 1) / QS; g.Lw = (W + QS - 1) / QS; g.L = g.Lh * g.Lw; g.N = H * W;
+    int ph = (g.Lh - 1) * QS + KS - H; if (ph < 0) ph = 0;
+    int pw = (g.Lw - 1) * QS + KS - W; if (pw < 0) pw = 0;
+    g.pt = ph / 2; g.pl = pw / 2;
+    return g;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// rows allocated for a [rows, DS] feature matrix: whole 32-row tiles plus one guard tile so that the
+// 1-KiB LDS-DMA pieces of the last tile stay in bounds.
+inline int feat_rows(int rows) { return round_up(rows, KT) + KT; }
+
+// ---- stage launchers (defined in the .hip files) ------------------------------------------------
+int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
+int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
+int launch_project(hipStream_t s, int B, const Grid& g, bool queries, const float* map, const float* wp,
+                   const float* bias, float* feat, double* colsum);
+int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
+                            const float* thr, float* mt);
+int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
+int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
+                        const float* values, float* out);
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out);
+int launch_scores_dense(hipStream_t s, int B, int L, int N, const float* wq, const float* x, float* sc);
+
+// selection
+struct SelectArgs {
+    int B, L, N, W;                 // W = feature-map width (key index -> pixel)
+    const float* wq;                // [B, feat_rows(L), DS]
+    const float* x;                 // [B, feat_rows(N), DS]
+    const float* mt;                // [B, L]   mean*thr          (adaptive modes)
+    const float* bs;                // [B, L]   bias              (adaptive modes)
+    int mode, k;
+    int splits;                     // key chunks per query tile
+    int tiles_per_split;            // 32-key tiles per chunk
+    // single-pass adaptive lists
+    int32_t* cnt;                   // [B, L] total passing keys per query (atomic)
+    int32_t* seg_cnt;               // [B, L, splits, 2] passing keys per (query, chunk, lane half)
+    int32_t* list_idx;              // [B, L, FAST_CAP]        (fast path)   or CSR array (fill pass)
+    float*   list_val;              // same shape: raw score S
+    const int64_t* seg_off;         // [B, L, splits, 2] CSR cursor starts (fill pass)
+    // top-k candidates
+    int32_t* cand_idx;              // [B, L, splits*2, k]
+    float*   cand_val;
+};
+int launch_score_select(hipStream_t s, const SelectArgs& a, int pass /*0 fast, 1 fill, 2 topk*/);
+
+struct EdgeArgs {
+    int B, L, N, mode, k;
+    const float* mt; const float* bs;
+    // inputs
+    const int32_t* cnt;             // [B,L] degree (adaptive)
+    const int32_t* list_idx; const float* list_val;      // fast lists [B,L,FAST_CAP] or CSR
+    const int64_t* row_off;         // CSR: [B*L+1] offsets (NULL = fast lists)
+    const int32_t* cand_idx; const float* cand_val; int splits;   // top-k candidates
+    // outputs: per-query neighbour lists with softmax weights
+    int32_t* nb_idx; float* nb_wgt; // fast/top-k: [B,L,width] ; CSR: same offsets as input
+    int32_t* nb_cnt;                // [B,L] entries used
+    int width;
+};
+int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
+
+struct AggArgs {
+    int B; Grid g;
+    const float* b2p;               // padded NHWC value map [B,Hp,Wp,16]
+    const int32_t* nb_idx; const float* nb_wgt; const int32_t* nb_cnt;
+    const int64_t* row_off;         // CSR offsets or NULL (fixed width)
+    int width;
+    float* agg;                     // [B,L,784] (kh,kw,c)
+};
+int launch_aggregate_direct(hipStream_t s, const AggArgs& a);
+int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const int32_t* nb_cnt, const int64_t* row_off,
+                     int width, int32_t* deg, float* rowsum);
+
+int launch_csr_offsets(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int64_t* seg_off,
+                       int64_t* row_off, int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);
+int topk_slots(int k);              // per-lane list length used for a requested k (4/8/16/32)
+
+}  // namespace dagl

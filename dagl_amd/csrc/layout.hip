@@ -1,0 +1,60 @@
+// Layout kernels: NCHW -> zero-bordered NHWC maps, fc weight repack, value-row materialisation.
+//
+// The reference extracts patches with ZeroPad2d + Unfold (same_padding / extract_image_patches,
+// DN_Gray/model/dagl.py:123-169) and so writes two 784-float rows per pixel.  Here the maps are
+// re-laid once as channels-last with a 3-pixel zero border; every 7x7x16 patch (stride-1 keys/values
+// AND the stride-4 SAME-padded queries, whose top/left pad is <= 3) is then 7 contiguous 448-byte
+// row segments of that map, addressed on the fly.
+#include "dagl_common.h"
+
+namespace dagl {
+
+__global__ void pad_nhwc_kernel(int H, int W, const float* __restrict__ src, float* __restrict__ dst) {
+    const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
+    const int b = blockIdx.z;
+    const int yp = blockIdx.y;
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xp >= Wp) return;
+    const int y = yp - PADPIX, x = xp - PADPIX;
+    const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+    const float* s = src + (size_t)b * CH * H * W + (size_t)y * W + x;
+    float v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = in ? s[(size_t)c * H * W] : 0.0f;
+    float4* d = reinterpret_cast<float4*>(dst + (((size_t)b * Hp + yp) * Wp + xp) * CH);
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) d[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst) {
+    const int Wp = W + 2 * PADPIX, Hp = H + 2 * PADPIX;
+    dim3 block(128), grid((Wp + 127) / 128, Hp, B);
+    hipLaunchKernelGGL(pad_nhwc_kernel, grid, block, 0, s, H, W, src, dst);
+    DAGL_LAUNCH_CHECK("pad_nhwc_kernel");
+    return DAGL_OK;
+}
+
+// rows[b][n][(kh,kw,c)] = b2p[b][y+kh][x+kw][c]   (n = y*W + x): one float4 per thread.
+__global__ void unfold_values_kernel(int H, int W, const float* __restrict__ mp, float* __restrict__ rows) {
+    const int Wp = W + 2 * PADPIX, Hp = H + 2 * PADPIX;
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index within the image
+    const size_t per_img = (size_t)H * W * (P / 4);
+    if (i >= per_img) return;
+    const int n = (int)(i / (P / 4));
+    const int r = (int)(i % (P / 4));            // float4 within the row: (kh, kw, c4)
+    const int kh = r / (KS * CH / 4), rem = r % (KS * CH / 4);   // 28 float4 per kh
+    const int y = n / W, x = n % W;
+    const float4* src = reinterpret_cast<const float4*>(mp + (((size_t)b * Hp + y + kh) * Wp + x) * CH) + rem;
+    reinterpret_cast<float4*>(rows)[(size_t)b * per_img + i] = *src;
+}
+
+int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows) {
+    const size_t per_img = (size_t)g.N * (P / 4);
+    dim3 grid((unsigned)((per_img + 255) / 256), B);
+    hipLaunchKernelGGL(unfold_values_kernel, grid, dim3(256), 0, s, g.H, g.W, b2p, rows);
+    DAGL_LAUNCH_CHECK("unfold_values_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

@@ -1,0 +1,195 @@
+// Patch projection: feat = relu(patch_rows . W^T + b), the two Linear(784->196)+ReLU layers applied
+// to every 7x7x16 patch (DN_Gray/model/dagl.py:196-203, called at :248 (queries, fc1) and :249 (keys,
+// fc2)) -- computed as an implicit GEMM straight from the zero-bordered NHWC map, so the two
+// [N,784] unfold buffers of dagl.py:224-240 never exist.
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  One wave owns 16 consecutive patches of one
+// grid row x all 208 (=13x16, 196 real) output columns: 13 independent accumulators.
+//   A (patches): read straight from global/L2: for a fixed (kh,kw) the 16 patches x 16 channels are one
+//      contiguous 1-KiB run of the NHWC map (stride-1 grid) -- one coalesced dwordx4 per lane per step.
+//   B (weights): the (kh,kw) slice [208 x 16] = 13 KiB is shared by the 4 waves of a block through LDS,
+//      double buffered, filled by LDS-DMA (global_load_lds_dwordx4) from a pre-swizzled packed copy.
+// K order inside a step is permuted (k-slot g of MFMA t <-> channel 4g+t) so that one 16-byte read per
+// lane feeds 4 MFMAs for both operands; a dot product does not care.
+#include "dagl_common.h"
+
+namespace dagl {
+
+constexpr int PJ_WAVES = 4;
+constexpr int PJ_NT = DPAD / 16;                 // 13 column tiles
+constexpr int PJ_STEPS = KS * KS;                // 49 (kh,kw) steps, 16 channels each
+constexpr int PJ_SLICE = DPAD * CH;              // floats per weight slice (3328)
+
+// Packed weight layout consumed by project_kernel: wp[step][o][slot'][4] with
+// slot' = g ^ (((o>>3)&1)<<1)  (g = channel quad) -- makes the ds_read_b128 of the B fragment conflict-free.
+__global__ void pack_fc_weight_kernel2(const float* __restrict__ w, float* __restrict__ wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PJ_STEPS * PJ_SLICE) return;
+    const int step = i / PJ_SLICE, r = i % PJ_SLICE;
+    const int o = r / CH, sl = (r % CH) / 4, t = r % 4;
+    const int g = sl ^ (((o >> 3) & 1) << 1);
+    const int c = 4 * g + t;
+    wp[i] = (o < D) ? w[(size_t)o * P + c * (KS * KS) + step] : 0.0f;
+}
+
+int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp) {
+    const int n = PJ_STEPS * PJ_SLICE;
+    hipLaunchKernelGGL(pack_fc_weight_kernel2, dim3((n + 255) / 256), dim3(256), 0, s, w, wp);
+    DAGL_LAUNCH_CHECK("pack_fc_weight_kernel");
+    return DAGL_OK;
+}
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <bool QUERIES>
+__global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int segs_per_row,
+                                                      const float* __restrict__ map,
+                                                      const float* __restrict__ wp,
+                                                      const float* __restrict__ fbias,
+                                                      float* __restrict__ feat, int feat_rows_alloc,
+                                                      double* __restrict__ colsum) {
+    __shared__ __attribute__((aligned(16))) float sB[2][PJ_SLICE];       // 26 KiB
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+
+    // work item of this wave: 16 consecutive patches of one grid row
+    int item = blockIdx.x * PJ_WAVES + wave;
+    const bool wave_valid = item < n_items;
+    if (!wave_valid) item = n_items - 1;
+    const int row_len = QUERIES ? gr.Lw : gr.W;
+    const int gy = item / segs_per_row;                       // grid row (query row r or pixel row y)
+    const int gx0 = (item % segs_per_row) * 16;
+    int gx = gx0 + i;
+    const bool row_valid = gx < row_len;
+    if (!row_valid) gx = row_len - 1;
+    // top-left corner of the patch in padded-map coordinates
+    const int py = QUERIES ? (QS * gy - gr.pt + PADPIX) : gy;
+    const int px = QUERIES ? (QS * gx - gr.pl + PADPIX) : gx;
+    const float* abase = map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
+
+    f32x4 acc[PJ_NT];
+#pragma unroll
+    for (int n = 0; n < PJ_NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // B-fragment LDS offsets (floats): row o = n*16 + i, swizzled slot
+    const int bslot = g ^ (((i >> 3) & 1) << 1);
+    const int boff = i * CH + bslot * 4;
+
+    // prologue: slice 0 -> sB[0]
+    for (int p = wave; p < PJ_NT; p += PJ_WAVES)
+        glds16(wp + (size_t)p * 256 + lane * 4, &sB[0][p * 256]);
+    float4 a_cur = *reinterpret_cast<const float4*>(abase);
+    __syncthreads();
+
+    for (int step = 0; step < PJ_STEPS; ++step) {
+        const int cur = step & 1;
+        float4 a_nxt = a_cur;
+        if (step + 1 < PJ_STEPS) {
+            const int ns = step + 1;
+            const float* wsrc = wp + (size_t)ns * PJ_SLICE;
+            for (int p = wave; p < PJ_NT; p += PJ_WAVES)
+                glds16(wsrc + (size_t)p * 256 + lane * 4, &sB[cur ^ 1][p * 256]);
+            const int kh = ns / KS, kw = ns % KS;
+            a_nxt = *reinterpret_cast<const float4*>(abase + ((size_t)kh * gr.Wp + kw) * CH);
+        }
+        const float* sb = &sB[cur][boff];
+#pragma unroll
+        for (int n = 0; n < PJ_NT; ++n) {
+            const float4 bw = *reinterpret_cast<const float4*>(sb + n * 16 * CH);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, bw.x, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, bw.y, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, bw.z, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, bw.w, acc[n], 0, 0, 0);
+        }
+        a_cur = a_nxt;
+        __syncthreads();
+    }
+
+    // epilogue: D[row = 4g + r][col = n*16 + i]; bias + ReLU; zero columns 196..203
+    const int grid_row_base = gy * row_len + gx0;          // linear patch index of row 0 of this wave
+    float* fb = feat + (size_t)b * feat_rows_alloc * DS;
+    float csum[PJ_NT];
+#pragma unroll
+    for (int n = 0; n < PJ_NT; ++n) {
+        const int col = n * 16 + i;
+        const float bv = (col < D) ? fbias[col] : 0.0f;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+            const bool ok = wave_valid && (gx0 + rr < row_len);
+            float v = acc[n][r] + bv;
+            v = v > 0.f ? v : 0.f;
+            if (col >= D) v = 0.f;
+            if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
+            s += ok ? v : 0.f;
+        }
+        csum[n] = s;
+    }
+    if (!QUERIES && colsum != nullptr) {
+        // reduce over the 4 row groups (lanes i, i+16, i+32, i+48), then one fp64 atomic per column per wave
+#pragma unroll
+        for (int n = 0; n < PJ_NT; ++n) {
+            float s = csum[n];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const int col = n * 16 + i;
+            if (g == 0 && col < D && wave_valid) atomicAdd(&colsum[(size_t)b * DS + col], (double)s);
+        }
+    }
+}
+
+int launch_project(hipStream_t s, int B, const Grid& g, bool queries, const float* map, const float* wp,
+                   const float* bias, float* feat, double* colsum) {
+    const int row_len = queries ? g.Lw : g.W;
+    const int n_rows = queries ? g.Lh : g.H;
+    const int segs = (row_len + 15) / 16;
+    const int n_items = segs * n_rows;
+    const int rows_alloc = feat_rows(queries ? g.L : g.N);
+    dim3 grid((n_items + PJ_WAVES - 1) / PJ_WAVES, B), block(256);
+    if (queries)
+        hipLaunchKernelGGL(project_kernel<true>, grid, block, 0, s, g, n_items, segs, map, wp, bias, feat,
+                           rows_alloc, colsum);
+    else
+        hipLaunchKernelGGL(project_kernel<false>, grid, block, 0, s, g, n_items, segs, map, wp, bias, feat,
+                           rows_alloc, colsum);
+    DAGL_LAUNCH_CHECK("project_kernel");
+    return DAGL_OK;
+}
+
+// mt[b,l] = (Wq[l,:] . colsum/N) * thr[b,l]   -- the "mean_j S[l,j] * thr" term of dagl.py:256.
+// The row mean of S is linear in the key features, so it needs no pass over S.
+__global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const float* __restrict__ wq,
+                                        const double* __restrict__ colsum, const float* __restrict__ thr,
+                                        float* __restrict__ mt) {
+    const int b = blockIdx.y;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;     // one wave per query
+    const int lane = threadIdx.x & 63;
+    if (wave >= L) return;
+    const float* q = wq + ((size_t)b * rows_alloc + wave) * DS;
+    const double* cs = colsum + (size_t)b * DS;
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) acc += (double)q[d] * cs[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float mean = (float)(acc / (double)N);
+        mt[(size_t)b * L + wave] = mean * thr[(size_t)b * L + wave];
+    }
+}
+
+int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
+                            const float* thr, float* mt) {
+    dim3 grid((L + 3) / 4, B), block(256);
+    hipLaunchKernelGGL(query_thresholds_kernel, grid, block, 0, s, L, N, feat_rows(L), wq, colsum, thr, mt);
+    DAGL_LAUNCH_CHECK("query_thresholds_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

@@ -1,0 +1,303 @@
+// Similarity + neighbour selection, streamed: S = Wq . X^T is produced 32x32 tile by tile on the fp32
+// matrix cores and consumed in registers; the [L,N] score matrix of the reference
+// (torch.matmul, DN_Gray/model/dagl.py:250: 1 GiB at 256x256) and its ~6 elementwise passes
+// (:256-261) never reach HBM.
+//
+// Per wave: 32 queries held as MFMA B fragments in registers (100 VGPRs), key tiles of 32 rows x 204
+// floats streamed through LDS by LDS-DMA (global_load_lds_dwordx4, double buffered) and shared by the
+// 4 waves (= 4 query tiles) of a block.  Operands are swapped -- D[key][query] = mfma(A = keys,
+// B = queries) -- so that one lane ends up with 16 scores of ONE query: the adaptive threshold / the
+// running k-th best of that query is a lane-local register, no cross-lane traffic in the hot loop.
+//
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (k-ordered), so S here has the same rounding class
+// as the reference's fp32 GEMM.  K order is permuted inside each group of 8 (k-slot h of MFMA m of
+// group t <-> k = 8t + 4h + m) so that one ds_read_b128 per lane feeds 4 MFMAs.
+//
+// Passes (template PASS):
+//   0  adaptive, single pass: keys with relu(S - mean*thr + bias) != 0 (dagl.py:256-257) are appended
+//      to the query's list (<= DAGL_FAST_CAP slots, atomic cursor) and counted per (query, chunk, half)
+//   1  adaptive, CSR fill: same test, written at precomputed per-lane cursors (no atomics, any degree)
+//   2  top-k: per-lane sorted k-best lists (GReccR2b_3mh_1-checkpoint.py:242-246 semantics)
+//   3  adaptive AND top-k
+#include "dagl_common.h"
+
+namespace dagl {
+
+constexpr int SEL_WAVES = 4;
+constexpr int TILE_FLOATS = KT * DS;             // 6528 floats = 26112 B of key features per tile
+constexpr int TILE_PIECES = 26;                  // 1-KiB DMA pieces per tile (the last one is half used)
+constexpr int TILE_LDS = TILE_PIECES * 256;      // floats reserved per LDS buffer
+constexpr int KG = 25;                           // groups of 8 k-values (200 = 196 + 4 zeros)
+
+__device__ __forceinline__ void glds16s(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// XCD-aware, bijective block remap: the blocks an XCD receives (bid % 8 == xcd) form one contiguous
+// range of logical ids, so blocks that stream the same key chunk share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <int K>
+struct TopK {
+    float v[K];
+    int id[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < K; ++t) { v[t] = -1.0f; id[t] = -1; }
+    }
+    __device__ __forceinline__ float kth() const { return v[K - 1]; }
+    // insert (s, j) into the descending list; caller guarantees s > v[K-1]
+    __device__ __forceinline__ void insert(float s, int j) {
+#pragma unroll
+        for (int t = K - 1; t > 0; --t) {
+            const bool up = s > v[t - 1];            // new element goes above slot t-1: shift it down
+            const bool here = !up && (s > v[t]);
+            const float nv = up ? v[t - 1] : (here ? s : v[t]);
+            const int ni = up ? id[t - 1] : (here ? j : id[t]);
+            v[t] = nv; id[t] = ni;
+        }
+        if (s > v[0]) { v[0] = s; id[0] = j; }
+    }
+};
+
+template <int PASS, int K>
+__global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int n_qgroups, int n_tiles,
+                                                              int rows_q, int rows_x) {
+    __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / n_qgroups;
+    const int qg = logical % n_qgroups;
+    const int tile0 = split * a.tiles_per_split;
+    int tile1 = tile0 + a.tiles_per_split;
+    if (tile1 > n_tiles) tile1 = n_tiles;
+
+    const int q = (qg * SEL_WAVES + wave) * QT + i;           // this lane's query
+    const bool qvalid = q < a.L;
+    const int qc = qvalid ? q : a.L - 1;
+
+    // query fragments: qf[t] = Wq[q][8t+4h .. 8t+4h+3]
+    float4 qf[KG];
+    {
+        const float* qp = a.wq + ((size_t)b * rows_q + qc) * DS + 4 * h;
+#pragma unroll
+        for (int t = 0; t < KG; ++t) qf[t] = *reinterpret_cast<const float4*>(qp + 8 * t);
+    }
+    float mtq = 0.f, bsq = 0.f;
+    if (PASS != 2) {
+        mtq = a.mt[(size_t)b * a.L + qc];
+        bsq = a.bs[(size_t)b * a.L + qc];
+    }
+
+    const float* xb = a.x + (size_t)b * rows_x * DS;
+    const size_t qlin = (size_t)b * a.L + qc;                 // linear query id
+    const size_t seg = (qlin * a.splits + split) * 2 + h;     // (query, chunk, half) segment id
+
+    int n_loc = 0;                                            // passing keys seen by this lane
+    int64_t cursor = 0;
+    if (PASS == 1) cursor = a.seg_off[seg];
+    TopK<(PASS >= 2) ? K : 1> best;
+    best.init();
+
+    // prologue: first tile -> buffer 0
+    for (int p = wave; p < TILE_PIECES; p += SEL_WAVES)
+        glds16s(xb + (size_t)tile0 * TILE_FLOATS + p * 256 + lane * 4, &sK[0][p * 256]);
+    __syncthreads();
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        if (tile + 1 < tile1) {
+            for (int p = wave; p < TILE_PIECES; p += SEL_WAVES)
+                glds16s(xb + (size_t)(tile + 1) * TILE_FLOATS + p * 256 + lane * 4, &sK[cur ^ 1][p * 256]);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* kp = &sK[cur][i * DS + 4 * h];
+#pragma unroll
+        for (int t = 0; t < KG; ++t) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, acc, 0, 0, 0);
+        }
+        // acc[r] = S[key = tile*32 + (r&3) + 8*(r>>2) + 4*h][query q]
+        const int kbase = tile * KT + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = acc[r];
+            const int key = kbase + (r & 3) + 8 * (r >> 2);
+            bool pass = qvalid && (key < a.N);
+            if (PASS != 2) {
+                const float m = (s - mtq) + bsq;              // same expression order as dagl.py:256
+                pass = pass && (m > 0.f);
+            }
+            if (PASS == 0) {
+                if (pass) {
+                    ++n_loc;
+                    if (n_loc <= DAGL_FAST_CAP) {
+                        const int pos = atomicAdd(&a.cnt[qlin], 1);
+                        if (pos < DAGL_FAST_CAP) {
+                            a.list_idx[qlin * DAGL_FAST_CAP + pos] = key;
+                            a.list_val[qlin * DAGL_FAST_CAP + pos] = s;
+                        }
+                    }
+                }
+            } else if (PASS == 1) {
+                if (pass) {
+                    a.list_idx[cursor] = key;
+                    a.list_val[cursor] = s;
+                    ++cursor;
+                }
+            } else {
+                pass = pass && (s > best.kth());
+                if (__any(pass)) {
+                    if (pass) best.insert(s, key);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (PASS == 0) {
+        if (qvalid) a.seg_cnt[seg] = n_loc;
+    } else if (PASS >= 2) {
+        if (qvalid) {
+            const size_t o = seg * K;
+#pragma unroll
+            for (int t = 0; t < ((PASS >= 2) ? K : 1); ++t) {
+                a.cand_idx[o + t] = best.id[t];
+                a.cand_val[o + t] = best.v[t];
+            }
+        }
+    }
+}
+
+template <int PASS>
+static int launch_pass(hipStream_t s, const SelectArgs& a, dim3 grid, int n_qgroups, int n_tiles, int rows_q,
+                       int rows_x) {
+    dim3 block(256);
+    if (PASS < 2) {
+        hipLaunchKernelGGL((score_select_kernel<PASS, 1>), grid, block, 0, s, a, n_qgroups, n_tiles, rows_q,
+                           rows_x);
+    } else {
+        switch (a.k <= 4 ? 4 : a.k <= 8 ? 8 : a.k <= 16 ? 16 : 32) {
+            case 4:
+                hipLaunchKernelGGL((score_select_kernel<PASS, 4>), grid, block, 0, s, a, n_qgroups, n_tiles,
+                                   rows_q, rows_x);
+                break;
+            case 8:
+                hipLaunchKernelGGL((score_select_kernel<PASS, 8>), grid, block, 0, s, a, n_qgroups, n_tiles,
+                                   rows_q, rows_x);
+                break;
+            case 16:
+                hipLaunchKernelGGL((score_select_kernel<PASS, 16>), grid, block, 0, s, a, n_qgroups, n_tiles,
+                                   rows_q, rows_x);
+                break;
+            default:
+                hipLaunchKernelGGL((score_select_kernel<PASS, 32>), grid, block, 0, s, a, n_qgroups, n_tiles,
+                                   rows_q, rows_x);
+                break;
+        }
+    }
+    DAGL_LAUNCH_CHECK("score_select_kernel");
+    return DAGL_OK;
+}
+
+int topk_slots(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : 32; }
+
+int launch_score_select(hipStream_t s, const SelectArgs& a, int pass) {
+    const int n_qgroups = (a.L + SEL_WAVES * QT - 1) / (SEL_WAVES * QT);
+    const int n_tiles = (a.N + KT - 1) / KT;
+    dim3 grid(n_qgroups * a.splits, a.B);
+    const int rows_q = feat_rows(a.L), rows_x = feat_rows(a.N);
+    switch (pass) {
+        case 0: return launch_pass<0>(s, a, grid, n_qgroups, n_tiles, rows_q, rows_x);
+        case 1: return launch_pass<1>(s, a, grid, n_qgroups, n_tiles, rows_q, rows_x);
+        case 2: return launch_pass<2>(s, a, grid, n_qgroups, n_tiles, rows_q, rows_x);
+        case 3: return launch_pass<3>(s, a, grid, n_qgroups, n_tiles, rows_q, rows_x);
+    }
+    set_error("launch_score_select: bad pass %d", pass);
+    return DAGL_ERR_INVALID;
+}
+
+// ---- dense scores (tests only): S[b,l,n] = Wq[l,:] . X[n,:] -------------------------------------------
+__global__ void scores_dense_kernel(int L, int N, int rows_q, int rows_x, const float* __restrict__ wq,
+                                    const float* __restrict__ x, float* __restrict__ sc) {
+    const int b = blockIdx.z;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (n >= N) return;
+    const float* qp = wq + ((size_t)b * rows_q + l) * DS;
+    const float* xp = x + ((size_t)b * rows_x + n) * DS;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc = fmaf(qp[d], xp[d], acc);
+    sc[((size_t)b * L + l) * N + n] = acc;
+}
+
+int launch_scores_dense(hipStream_t s, int B, int L, int N, const float* wq, const float* x, float* sc) {
+    dim3 grid((N + 255) / 256, L, B);
+    hipLaunchKernelGGL(scores_dense_kernel, grid, dim3(256), 0, s, L, N, feat_rows(L), feat_rows(N), wq, x, sc);
+    DAGL_LAUNCH_CHECK("scores_dense_kernel");
+    return DAGL_OK;
+}
+
+// ---- CSR offsets: degrees, row offsets, per-(query,chunk,half) cursors ---------------------------------
+// single block; rows are split into contiguous ranges per thread (deterministic).
+__global__ __launch_bounds__(1024) void csr_offsets_kernel(int n_rows, int s2, const int32_t* __restrict__ seg_cnt,
+                                                           int64_t* __restrict__ seg_off,
+                                                           int64_t* __restrict__ row_off,
+                                                           int32_t* __restrict__ deg,
+                                                           int64_t* __restrict__ stats /* total, maxdeg */) {
+    __shared__ int64_t part[1024];
+    __shared__ int32_t pmax[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (n_rows + nt - 1) / nt;
+    const int r0 = t * per, r1 = min(n_rows, r0 + per);
+    int64_t sum = 0; int32_t mx = 0;
+    for (int r = r0; r < r1; ++r) {
+        int32_t d = 0;
+        for (int j = 0; j < s2; ++j) d += seg_cnt[(size_t)r * s2 + j];
+        deg[r] = d; sum += d; mx = max(mx, d);
+    }
+    part[t] = sum; pmax[t] = mx;
+    __syncthreads();
+    if (t == 0) {
+        int64_t run = 0; int32_t m = 0;
+        for (int j = 0; j < nt; ++j) { const int64_t v = part[j]; part[j] = run; run += v; m = max(m, pmax[j]); }
+        stats[0] = run; stats[1] = m;
+        row_off[n_rows] = run;
+    }
+    __syncthreads();
+    int64_t off = part[t];
+    for (int r = r0; r < r1; ++r) {
+        row_off[r] = off;
+        for (int j = 0; j < s2; ++j) {
+            seg_off[(size_t)r * s2 + j] = off;
+            off += seg_cnt[(size_t)r * s2 + j];
+        }
+    }
+}
+
+int launch_csr_offsets(hipStream_t s, int n_rows, int s2, const int32_t* seg_cnt, int64_t* seg_off,
+                       int64_t* row_off, int32_t* deg, int64_t* stats) {
+    hipLaunchKernelGGL(csr_offsets_kernel, dim3(1), dim3(1024), 0, s, n_rows, s2, seg_cnt, seg_off, row_off, deg,
+                       stats);
+    DAGL_LAUNCH_CHECK("csr_offsets_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

@@ -1,0 +1,192 @@
+"""Stage-level host wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+Every function takes contiguous fp32 CUDA(HIP) tensors, enqueues on torch's current stream and returns
+freshly allocated outputs.  They mirror the stages of the reference method one to one
+(DN_Gray/model/dagl.py:216-274); see include/dagl_ce.h for the exact contracts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DS, MODES, P, DaglError, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise DaglError(f"{name}: must live on the GPU (dagl_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise DaglError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise DaglError(f"{name}: must be contiguous")
+    return t
+
+
+def query_grid(H: int, W: int):
+    return -(-H // 4), -(-W // 4)
+
+
+def pad_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[B,16,H,W] -> zero-bordered channels-last [B,H+6,W+6,16]."""
+    _need(x, "x")
+    B, c, H, W = x.shape
+    if c != 16:
+        raise DaglError("pad_nhwc: 16 channels expected")
+    out = torch.empty(B, H + 6, W + 6, 16, device=x.device, dtype=torch.float32)
+    check(_lib.load().dagl_pad_nhwc(_stream(), B, H, W, x.data_ptr(), out.data_ptr()), "dagl_pad_nhwc")
+    return out
+
+
+def pack_fc_weight(w: torch.Tensor) -> torch.Tensor:
+    _need(w, "w")
+    if tuple(w.shape) != (196, 784):
+        raise DaglError("pack_fc_weight: [196,784] expected")
+    out = torch.empty(208 * 784, device=w.device, dtype=torch.float32)
+    check(_lib.load().dagl_pack_fc_weight(_stream(), w.data_ptr(), out.data_ptr()), "dagl_pack_fc_weight")
+    return out
+
+
+def project_patches(map_nhwc: torch.Tensor, w_packed: torch.Tensor, fc_bias: torch.Tensor, H: int, W: int,
+                    queries: bool, want_colsum: bool = False):
+    """relu(Linear(patch)) for every patch -> ([B, rows_alloc, 204] features, optional [B,204] fp64 column sums)."""
+    _need(map_nhwc, "map_nhwc"); _need(w_packed, "w_packed"); _need(fc_bias, "fc_bias")
+    lib = _lib.load()
+    B = map_nhwc.shape[0]
+    Lh, Lw = query_grid(H, W)
+    rows = Lh * Lw if queries else H * W
+    ra = lib.dagl_feat_rows(rows)
+    feat = torch.empty(B, ra, DS, device=map_nhwc.device, dtype=torch.float32)
+    colsum = torch.empty(B, DS, device=map_nhwc.device, dtype=torch.float64) if (want_colsum and not queries) else None
+    check(lib.dagl_project_patches(_stream(), B, H, W, int(queries), map_nhwc.data_ptr(), w_packed.data_ptr(),
+                                   fc_bias.data_ptr(), feat.data_ptr(),
+                                   colsum.data_ptr() if colsum is not None else None), "dagl_project_patches")
+    return feat, colsum
+
+
+def query_thresholds(wq: torch.Tensor, colsum: torch.Tensor, thr: torch.Tensor, L: int, N: int) -> torch.Tensor:
+    _need(wq, "wq"); _need(colsum, "colsum", torch.float64); _need(thr, "thr")
+    B = wq.shape[0]
+    mt = torch.empty(B, L, device=wq.device, dtype=torch.float32)
+    check(_lib.load().dagl_query_thresholds(_stream(), B, L, N, wq.data_ptr(), colsum.data_ptr(), thr.data_ptr(),
+                                            mt.data_ptr()), "dagl_query_thresholds")
+    return mt
+
+
+def scores_dense(wq: torch.Tensor, x: torch.Tensor, L: int, N: int) -> torch.Tensor:
+    _need(wq, "wq"); _need(x, "x")
+    B = wq.shape[0]
+    s = torch.empty(B, L, N, device=wq.device, dtype=torch.float32)
+    check(_lib.load().dagl_scores_dense(_stream(), B, L, N, wq.data_ptr(), x.data_ptr(), s.data_ptr()),
+          "dagl_scores_dense")
+    return s
+
+
+def gather_aggregate(idx: torch.Tensor, wgt: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+    """out[l,:] = sum_k wgt[l,k] * values[idx[l,k],:]   (idx < 0 = empty slot)."""
+    _need(idx, "idx", torch.int32); _need(wgt, "wgt"); _need(values, "values")
+    L, k = idx.shape
+    if wgt.shape != idx.shape or values.dim() != 2:
+        raise DaglError("gather_aggregate: shape mismatch")
+    Pn = values.shape[1]
+    out = torch.empty(L, Pn, device=values.device, dtype=torch.float32)
+    check(_lib.load().dagl_gather_aggregate(_stream(), L, k, Pn, idx.data_ptr(), wgt.data_ptr(), values.data_ptr(),
+                                            out.data_ptr()), "dagl_gather_aggregate")
+    return out
+
+
+def unfold_values(b2_nhwc: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _need(b2_nhwc, "b2_nhwc")
+    B = b2_nhwc.shape[0]
+    rows = torch.empty(B, H * W, P, device=b2_nhwc.device, dtype=torch.float32)
+    check(_lib.load().dagl_unfold_values(_stream(), B, H, W, b2_nhwc.data_ptr(), rows.data_ptr()),
+          "dagl_unfold_values")
+    return rows
+
+
+def fold_normalize(agg: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _need(agg, "agg")
+    B = agg.shape[0]
+    out = torch.empty(B, 16, H, W, device=agg.device, dtype=torch.float32)
+    check(_lib.load().dagl_fold_normalize(_stream(), B, H, W, agg.data_ptr(), out.data_ptr()), "dagl_fold_normalize")
+    return out
+
+
+class Workspace:
+    """Grow-only device scratch buffer reused across calls (allocated through torch's caching allocator, so it
+    is stream-ordered and visible to torch's memory accounting)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != device:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)
+        return self.buf
+
+
+def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
+               workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False):
+    """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W]."""
+    lib = _lib.load()
+    if mode not in MODES:
+        raise DaglError(f"unknown mode {mode!r}")
+    for n, t in (("b1", b1), ("b2", b2), ("fc1_w", fc1_w), ("fc1_b", fc1_b), ("fc2_w", fc2_w), ("fc2_b", fc2_b)):
+        _need(t, n)
+    B, c, H, W = b1.shape
+    if c != 16 or b2.shape != b1.shape:
+        raise DaglError("ce_forward: b1/b2 must both be [B,16,H,W]")
+    if tuple(fc1_w.shape) != (196, 784) or tuple(fc2_w.shape) != (196, 784):
+        raise DaglError("ce_forward: fc weights must be [196,784]")
+    Lh, Lw = query_grid(H, W)
+    if mode != "topk":
+        _need(thr, "thr"); _need(bias, "bias")
+        if thr.numel() != B * Lh * Lw or bias.numel() != B * Lh * Lw:
+            raise DaglError("ce_forward: thr/bias must hold B*L values")
+    ws = workspace if workspace is not None else Workspace()
+    need = lib.dagl_ce_workspace_bytes(B, H, W, MODES[mode], int(k))
+    if need == 0:
+        check(-1, "dagl_ce_workspace_bytes")
+    out = torch.empty(B, 16, H, W, device=b1.device, dtype=torch.float32)
+    info = _lib.CeInfo()
+    rc = 0
+    dbg = None
+    if debug:
+        L = Lh * Lw
+        dbg = dict(deg=torch.empty(B, L, device=b1.device, dtype=torch.int32),
+                   rowsum=torch.empty(B, L, device=b1.device, dtype=torch.float32),
+                   agg=torch.empty(B, L, P, device=b1.device, dtype=torch.float32))
+    for _attempt in range(2):
+        buf = ws.get(need, b1.device)
+        base = buf.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        args = (_stream(), B, H, W, b1.data_ptr(), b2.data_ptr(),
+                thr.data_ptr() if thr is not None else None,
+                bias.data_ptr() if bias is not None else None,
+                fc1_w.data_ptr(), fc1_b.data_ptr(), fc2_w.data_ptr(), fc2_b.data_ptr(),
+                MODES[mode], int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base), C.byref(info))
+        if dbg is None:
+            rc = lib.dagl_ce_forward(*args)
+        else:
+            rc = lib.dagl_ce_forward_debug(*args, dbg["deg"].data_ptr(), dbg["rowsum"].data_ptr(),
+                                           dbg["agg"].data_ptr())
+        if rc == _lib.ERR_WORKSPACE and info.required_bytes > need:
+            need = int(info.required_bytes)      # dense neighbourhoods: the CSR fallback asked for more
+            continue
+        break
+    check(rc, "dagl_ce_forward")
+    meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
+                max_degree=info.max_degree, path=info.path)
+    if dbg is not None:
+        meta.update(dbg)
+    if return_info or debug:
+        return out, meta
+    return out

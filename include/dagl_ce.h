@@ -1,0 +1,164 @@
+/*
+ * dagl_ce.h -- C ABI of the MI355X-native patch-graph attention head.
+ *
+ * One data-parallel hot path is implemented behind this boundary: the body of
+ * the reference method CE.forward (DN_Gray/model/dagl.py:207-275, identical
+ * forks in CAR/, Demosaic/, DN_Real/), i.e. everything after the four stock
+ * prologue convolutions (dagl.py:208-215) up to and including the batch
+ * concatenation (dagl.py:274).
+ *
+ * The reference has no FFI: its boundary is the Python call self.cX_Y(x) in
+ * CES.forward (dagl.py:114,116,118).  The host-side mirror of that call is
+ * dagl_amd.CE (an nn.Module with the reference's constructor, parameter names
+ * and forward signature); it reaches the device code only through the entry
+ * points declared here (ctypes), so that the same library can be bound from
+ * any other host language.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 / int32 data unless stated;
+ *   - buffers are caller-owned; nothing is allocated or freed in here;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     all work is enqueued on it; entry points that must read a device value
+ *     back (noted below) synchronise that stream, nothing else ever does;
+ *   - return value 0 = OK, negative = DAGL_ERR_*; dagl_last_error() gives a
+ *     thread-local message; no entry point aborts the process;
+ *   - the library holds no global mutable state and is re-entrant.
+ *
+ * Fixed hyper-parameters (constructor defaults the reference never overrides,
+ * dagl.py:175-176, CES passes only in_channels, dagl.py:94-109):
+ *   ksize 7, query stride 4, key/value stride 1, inter_channels 16,
+ *   softmax_scale 10, patch length P = 16*7*7 = 784, feature length D = 196.
+ */
+#ifndef DAGL_CE_H
+#define DAGL_CE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAGL_KSIZE      7
+#define DAGL_QSTRIDE    4
+#define DAGL_CH         16            /* inter_channels                         */
+#define DAGL_P          784           /* patch row length  = 16*7*7             */
+#define DAGL_D          196           /* similarity feature length = P/4        */
+#define DAGL_DS         204           /* row stride (floats) of feature rows    */
+#define DAGL_PADPIX     3             /* zero border of the padded NHWC maps    */
+
+/* neighbour-selection modes */
+#define DAGL_MODE_ADAPTIVE       0    /* shipped: relu(S - mean*thr + bias) != 0   (dagl.py:256-257) */
+#define DAGL_MODE_TOPK           1    /* fixed-k variant (GReccR2b_3mh_1-checkpoint.py:242-250)      */
+#define DAGL_MODE_ADAPTIVE_TOPK  2    /* adaptive mask intersected with the k best scores            */
+
+#define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
+#define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path            */
+
+/* error codes */
+#define DAGL_OK                   0
+#define DAGL_ERR_INVALID         -1   /* bad argument (shape, mode, k, null pointer, alignment)      */
+#define DAGL_ERR_WORKSPACE       -2   /* workspace too small; info->required_bytes says how much     */
+#define DAGL_ERR_HIP             -3   /* a HIP call / launch failed (message has hipGetErrorString)  */
+#define DAGL_ERR_NO_DEVICE       -4   /* no gfx950 device visible                                    */
+
+typedef struct dagl_ce_info {
+    int64_t required_bytes;   /* workspace this call needed (valid on OK and on ERR_WORKSPACE)      */
+    int64_t total_edges;      /* sum of degrees over all queries of the batch                       */
+    int32_t max_degree;       /* largest per-query degree                                           */
+    int32_t path;             /* 0 = single-pass lists, 1 = two-pass CSR (some degree > FAST_CAP),
+                                 2 = per-lane top-k lists                                           */
+} dagl_ce_info;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int         dagl_version(void);                 /* 10000*major + 100*minor + patch                  */
+const char* dagl_last_error(void);              /* thread-local, never NULL                         */
+int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
+
+/* ---- whole block: replaces dagl.py:216-274 (CE.forward after its prologue convs) -------------- */
+
+/* Bytes of workspace dagl_ce_forward needs for the single-pass / top-k paths (a two-pass CSR
+ * fallback may ask for more through DAGL_ERR_WORKSPACE + info->required_bytes).                  */
+size_t dagl_ce_workspace_bytes(int B, int H, int W, int mode, int k);
+
+/*
+ * b1   [B,16,H,W]  g(b)      key/query feature map   (dagl.py:208)
+ * b2   [B,16,H,W]  theta(b)  value feature map       (dagl.py:209)
+ * thr  [B,L]       thr_conv(same_pad(b))             (dagl.py:213-214)   L = ceil(H/4)*ceil(W/4)
+ * bias [B,L]       bias_conv(same_pad(b))            (dagl.py:215)
+ *      (thr/bias may be NULL in DAGL_MODE_TOPK)
+ * fc1_w [196,784] fc1_b [196]  query projection  (dagl.py:196-199), element order (c,kh,kw)
+ * fc2_w [196,784] fc2_b [196]  key   projection  (dagl.py:200-203)
+ * out  [B,16,H,W]  the block's return value          (dagl.py:274)
+ * Synchronises `stream` once in the adaptive modes (degree read-back).
+ */
+int dagl_ce_forward(void* stream, int B, int H, int W,
+                    const float* b1, const float* b2, const float* thr, const float* bias,
+                    const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                    int mode, int k, float* out,
+                    void* workspace, size_t ws_bytes, dagl_ce_info* info);
+
+/* Same call with optional per-query read-outs for parity tests (any of them may be NULL):
+ *   deg_out [B,L] int32  neighbours per query     (reference: (mask != 0).sum(1), dagl.py:257)
+ *   rowsum_out [B,L]     sum_j A_ij               (reference: softmax mass left after masking, :261)
+ *   agg_out [B,L,784]    aggregated query patches (reference: torch.mm(yi,pi), :263-264), element
+ *                        order (kh,kw,c)                                                           */
+int dagl_ce_forward_debug(void* stream, int B, int H, int W,
+                          const float* b1, const float* b2, const float* thr, const float* bias,
+                          const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                          int mode, int k, float* out,
+                          void* workspace, size_t ws_bytes, dagl_ce_info* info,
+                          int32_t* deg_out, float* rowsum_out, float* agg_out);
+
+/* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
+
+/* NCHW [B,16,H,W] -> zero-bordered NHWC [B,H+6,W+6,16]  (patch unfold without materialising
+ * patches: replaces same_padding/extract_image_patches, dagl.py:123-169, for all three uses).    */
+int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc);
+
+/* fc weight [196,784] in the reference's (c,kh,kw) column order -> 208*784 floats in the packed
+ * layout the projection kernel streams: [49 (kh,kw)][208 outputs, rows 196.. zero][16 channels,
+ * 16-byte quads XOR-swizzled for conflict-free LDS reads].                                       */
+int dagl_pack_fc_weight(void* stream, const float* w, float* w_packed);
+
+/* Patch projection = Linear(784->196)+ReLU applied to every 7x7x16 patch of the padded map
+ * (dagl.py:248 for queries, :249 for keys), as an implicit GEMM.
+ *   queries != 0 : stride-4 SAME grid (L rows);  0 : stride-1 grid (N = H*W rows)
+ *   feat   [B, rows_alloc, 204]  rows_alloc = dagl_feat_rows(rows); columns 196..203 and the
+ *          rows beyond `rows` are written as zero
+ *   colsum [B,204] (keys only, may be NULL): sum over the N rows of each column (for the row
+ *          mean of the score matrix, dagl.py:256)                                                */
+int dagl_project_patches(void* stream, int B, int H, int W, int queries,
+                         const float* map_nhwc, const float* w_packed, const float* fc_bias,
+                         float* feat, double* colsum);
+int dagl_feat_rows(int rows);          /* rows rounded up to the streaming tile + 1 guard tile     */
+
+/* Per-query threshold pieces of the adaptive mask (dagl.py:256):
+ *   mt[b,l] = mean_j S[l,j] * thr[b,l]   with mean_j S[l,j] = Wq[l,:] . (colsum/N)
+ *   (bias is used as is).                                                                        */
+int dagl_query_thresholds(void* stream, int B, int L, int N, const float* wq, const double* colsum,
+                          const float* thr, float* mt);
+
+/* Gather + weighted sum over fixed-width neighbour lists: the sparse form of torch.mm(yi, pi)
+ * (dagl.py:263-264; the north-star's batched_index_select + weighted sum).
+ *   idx [L,k] int32 (row index into values, <0 = empty slot), wgt [L,k], values [n_rows,P],
+ *   out [L,P];  P must be a multiple of 4, pointers 16-byte aligned.
+ * Algorithmic bytes per query: k*P*4 (rows) + k*8 (idx,wgt) + P*4 (out).                        */
+int dagl_gather_aggregate(void* stream, int L, int k, int P,
+                          const int32_t* idx, const float* wgt, const float* values, float* out);
+
+/* Materialise value rows [B,N,784] (element order (kh,kw,c)) from the padded NHWC value map --
+ * what Unfold does at dagl.py:224-231; only the stand-alone gather benchmark / tests need it.   */
+int dagl_unfold_values(void* stream, int B, int H, int W, const float* b2_nhwc, float* rows);
+
+/* Fold the aggregated query patches back and divide by the overlap count (dagl.py:265-272).
+ *   agg [B,L,784] element order (kh,kw,c);  out [B,16,H,W]                                       */
+int dagl_fold_normalize(void* stream, int B, int H, int W, const float* agg, float* out);
+
+/* Dense score matrix S = Wq . X^T for tests (dagl.py:250): s [B,L,N].                            */
+int dagl_scores_dense(void* stream, int B, int L, int N, const float* wq, const float* x, float* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAGL_CE_H */
