@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the patch-graph attention head on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode topk|adaptive] [--k 8] [--size 256] [--batch 1]
+
+A "step" is one forward of one ``CE`` head (prologue convolutions + the whole HIP block) over one batch
+of synthetic feature maps ``[batch,64,size,size]`` that is already resident in HBM.  Default workload =
+BASELINE.json configs[1]: 256x256x64 features, k=8, fp32, one GPU.  Multi-GPU (launched by
+``python -m torch.distributed.run``) is plain image-batch data parallel: every rank runs the same step
+on its own images (weak scaling), no collective on the data path; timing = barrier + sync on both
+sides, MAX over ranks.
+
+Rank 0 prints ONE JSON line: whole-job query-patches/s, plus
+  roofline      the dominant kernel (streamed similarity + select, fp32 matrix cores): algorithmic FLOP
+                per launch / its mean duration, measured live with hipEvents at the stage boundaries of
+                the very steps that are timed (dagl_profile_*, recorded on the launch stream)
+  roofline_gather  the stand-alone gather/weighted-sum kernel over materialised value rows (HBM bound,
+                algorithmic bytes (k+1)*4P+8k per query) and the fused in-block gather
+  cpu_baseline  the dense CPU oracle (a port of the reference's algorithm) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+D_FEAT, P_ROW = 196, 784
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="topk", choices=["topk", "adaptive", "adaptive_topk"])
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--sparse-gain", type=float, default=2.4, help="adaptive modes: threshold gain of the synthetic thr head")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, params, mode, k):
+    """Dense CPU oracle on the host cores, bounded sample (one forward of the benchmark workload after a small
+    warm-up).  The reference algorithm is dense: its cost does not depend on k."""
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    size = args.cpu_size or args.size
+    x_small = torch.from_numpy(make_features(1, 1, 64, 64, 64))
+    x = torch.from_numpy(make_features(2, 1, 64, size, size))
+    with torch.no_grad():
+        ce_forward_oracle(x_small, params, mode=mode, k=k or None)          # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        ce_forward_oracle(x, params, mode=mode, k=k or None)
+        dt = time.perf_counter() - t0
+    L = ((size + 3) // 4) ** 2
+    return {"value": L / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 forward of oracle/ce_oracle.py (dense torch-CPU restatement of CE.forward) on "
+                      f"[1,64,{size},{size}] fp32, L={L} query patches, {dt:.2f} s, after one 64x64 warm-up"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: used for the barriers/max only
+
+    from dagl_amd import ops
+    from dagl_amd.ce import CE
+    from dagl_amd.shard import rank_seed, reduce_max_seconds
+    from dagl_amd.synth import make_ce_params, make_features
+
+    mode, k = args.mode, (args.k if args.mode != "adaptive" else 0)
+    variant = "default" if mode == "topk" else "sparse"
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(2024, variant=variant, sparse_gain=args.sparse_gain).items()}
+    ce = CE(in_channels=64)
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode = mode
+    if k:
+        ce.select_k = k
+    ce = ce.to(dev).eval()
+
+    B, H, W = args.batch, args.size, args.size
+    x = torch.from_numpy(make_features(rank_seed(100, rank), B, 64, H, W)).to(dev)     # resident in HBM
+    L, N = ((H + 3) // 4) * ((W + 3) // 4), H * W
+
+    prof = ops.StageProfile(max(args.steps, 1))
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            ce(x)
+        ce.profile = prof
+        prof.reset()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ce(x)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ce.profile = None
+    elapsed = reduce_max_seconds(elapsed, dist, dev)
+    stage_ms = prof.read()
+    info = ce.last_info
+
+    # stand-alone gather kernel over materialised value rows (rank 0 only; outside the timed region)
+    gather = None
+    if rank == 0:
+        with torch.no_grad():
+            b1, b2, thr, bias = ce._prologue(x[:1])
+            rows = ops.unfold_values(ops.pad_nhwc(b2.contiguous()), H, W)[0].contiguous()       # [N,784]
+            kk = k or 8
+            g = torch.Generator(device="cpu").manual_seed(5)
+            idx = torch.randint(0, N, (L, kk), generator=g, dtype=torch.int32).to(dev)
+            wgt = torch.rand(L, kk, generator=g).to(dev)
+            for _ in range(5):
+                ops.gather_aggregate(idx, wgt, rows)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                ops.gather_aggregate(idx, wgt, rows)
+            e1.record()
+            e1.synchronize()
+            g_ms = e0.elapsed_time(e1) / reps
+            g_bytes = L * ((kk + 1) * 4 * P_ROW + 8 * kk)
+            gather = {"bound": "hbm", "kernel": "gather_rows_kernel (dagl_gather_aggregate)", "k": kk,
+                      "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                      "bytes_per_launch": g_bytes, "ms_per_launch": g_ms,
+                      "timing": "mean of 50 back-to-back launches (launch gaps included), torch events on the launch stream"}
+            del rows
+
+    if rank == 0:
+        import numpy as np
+        sm = np.asarray(stage_ms, dtype=np.float64)                      # [steps, 8]
+        mean_ms = sm.mean(axis=0) if len(sm) else np.zeros(8)
+        from dagl_amd._lib import STAGE_NAMES
+        sel_ms = float(mean_ms[4])
+        flops = 2.0 * B * L * N * D_FEAT                                 # algorithmic: 2*L*N*D per image
+        ach = flops / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "score_select_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                    "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                    "flop_per_launch": flops, "ms_per_launch": sel_ms}
+        if gather is not None and mean_ms[6] > 0:
+            kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
+            fb = B * L * ((kk + 1) * 4 * P_ROW + 8 * kk)
+            gather["fused_in_block"] = {"kernel": "aggregate_direct_kernel", "ms_per_launch": float(mean_ms[6]),
+                                        "achieved": fb / (mean_ms[6] * 1e-3) / 1e9, "unit": "GB/s",
+                                        "frac": fb / (mean_ms[6] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        total_patches = world * B * L * args.steps
+        line = {
+            "metric": "graph-attn fwd query-patches/s @256x256x64 k=8" if (H, mode, k) == (256, "topk", 8)
+                      else f"graph-attn fwd query-patches/s @{H}x{W}x64 {mode} k={k}",
+            "value": total_patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: one CE head forward, features [{B},64,{H},{W}] fp32 per GPU, "
+                                   f"select mode {mode} k={k}, L={L} queries x N={N} keys per image",
+                       "parallelism": f"dp{world} (independent images per rank, no data-path collective)",
+                       "select_mode": mode, "k": k, "batch_per_gpu": B,
+                       "selection_path": (info or {}).get("path"), "max_degree": (info or {}).get("max_degree")},
+            "roofline": roofline,
+            "roofline_gather": gather,
+            "stage_ms": {STAGE_NAMES[i]: float(mean_ms[i]) for i in range(8)},
+            "hip_block_ms": float(mean_ms.sum()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, params, mode, k)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

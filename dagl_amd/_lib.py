@@ -20,6 +20,8 @@ P = 784
 D = 196
 DS = 204
 ERR_WORKSPACE = -2
+N_STAGES = 8
+STAGE_NAMES = ("layout", "proj_keys", "proj_queries", "thresholds", "select", "edge_softmax", "gather", "fold")
 
 
 class DaglError(RuntimeError):
@@ -43,6 +45,12 @@ SIGNATURES = {
                              C.POINTER(CeInfo)]),
     "dagl_ce_forward_debug": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                    C.POINTER(CeInfo), _vp, _vp, _vp]),
+    "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
+    "dagl_profile_destroy": (_i, [_vp]),
+    "dagl_profile_reset": (_i, [_vp]),
+    "dagl_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), _i]),
+    "dagl_ce_forward_profiled": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
+                                      C.POINTER(CeInfo), _vp]),
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
     "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -62,6 +70,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one this process
+    # initialises, so it is loaded before the device library's DT_NEEDED libamdhip64.so.7 is resolved
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DaglError(
             f"{LIB_PATH} is missing: build it with `python -m dagl_amd.build` "

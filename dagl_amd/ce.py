@@ -53,6 +53,7 @@ class CE(nn.Module):
         self.select_k = min(num_edge, MAX_TOPK)
         self._ws = ops.Workspace()
         self.last_info = None
+        self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
 
     def extra_repr(self):
         return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
@@ -82,6 +83,7 @@ class CE(nn.Module):
         out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
                                    self.fc1[0].weight.contiguous(), self.fc1[0].bias.contiguous(),
                                    self.fc2[0].weight.contiguous(), self.fc2[0].bias.contiguous(),
-                                   mode=self.select_mode, k=self.select_k, workspace=self._ws, return_info=True)
+                                   mode=self.select_mode, k=self.select_k, workspace=self._ws, return_info=True,
+                                   profile=self.profile)
         self.last_info = info
         return out

@@ -21,6 +21,16 @@ int hip_fail(hipError_t e, const char* what) {
     return DAGL_ERR_HIP;
 }
 
+// ---- optional stage profile: hipEvents recorded at stage boundaries on the caller's stream ------------------
+struct Profile {
+    int max_calls = 0, n_calls = 0;
+    hipEvent_t* ev = nullptr;            // [max_calls][DAGL_N_STAGES + 1]
+};
+static inline void prof_mark(Profile* p, hipStream_t s, int stage_boundary) {
+    if (p && p->n_calls < p->max_calls)
+        (void)hipEventRecord(p->ev[(size_t)p->n_calls * (DAGL_N_STAGES + 1) + stage_boundary], s);
+}
+
 // ---- execution plan: chunking of the key stream + workspace carve ---------------------------------------
 struct Plan {
     Grid g;
@@ -113,7 +123,8 @@ static int check_device() {
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
                            const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, int mode, int k, float* out, void* ws, size_t ws_bytes,
-                           dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg) {
+                           dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg,
+                           Profile* prof = nullptr) {
     Plan p;
     int rc = make_plan(B, H, W, mode, k, p);
     if (rc) return rc;
@@ -148,6 +159,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     float* agg = at<float>(ws, p.o_agg);
 
     // 1. layout: zero-bordered NHWC maps, packed fc weights
+    prof_mark(prof, s, 0);
     if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
     if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
@@ -162,8 +174,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
     }
+    prof_mark(prof, s, 1);
     if ((rc = launch_project(s, B, g, false, b1p, wp2, fc2_b, X, colsum))) return rc;
+    prof_mark(prof, s, 2);
     if ((rc = launch_project(s, B, g, true, b1p, wp1, fc1_b, Wq, nullptr))) return rc;
+    prof_mark(prof, s, 3);
 
     // 3. selection
     SelectArgs sa;
@@ -183,6 +198,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt))) return rc;
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
+    prof_mark(prof, s, 4);
 
     if (mode == DAGL_MODE_ADAPTIVE) {
         int32_t* lidx = at<int32_t>(ws, p.o_lidx);
@@ -190,6 +206,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         DAGL_HIP_TRY(hipMemsetAsync(cnt, 0, BL * sizeof(int32_t), s));
         sa.cnt = cnt; sa.seg_cnt = segcnt; sa.list_idx = lidx; sa.list_val = lval;
         if ((rc = launch_score_select(s, sa, 0))) return rc;
+        prof_mark(prof, s, 5);
         if ((rc = launch_csr_offsets(s, (int)BL, p.splits * 2, segcnt, segoff, rowoff, deg, stats))) return rc;
         int64_t hstats[2] = {0, 0};
         DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
@@ -222,6 +239,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     } else {
         sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
         if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
+        prof_mark(prof, s, 5);
         ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
         if ((rc = launch_edge_softmax(s, ea))) return rc;
         if (info) { info->path = 2; info->max_degree = k; info->total_edges = -1; }
@@ -230,9 +248,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // 4. gather + weighted sum, fold
     if (dbg_deg || dbg_rowsum)
         if ((rc = launch_row_stats(s, BL, ag.nb_wgt, ag.nb_cnt, ag.row_off, ag.width, dbg_deg, dbg_rowsum))) return rc;
+    prof_mark(prof, s, 6);
     if ((rc = launch_aggregate_direct(s, ag))) return rc;
+    prof_mark(prof, s, 7);
     if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if ((rc = launch_fold(s, B, g, agg, out))) return rc;
+    prof_mark(prof, s, 8);
+    if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
     return DAGL_OK;
 }
 
@@ -270,6 +292,66 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W, const float* b1, co
                            workspace, ws_bytes, info, deg_out, rowsum_out, agg_out);
 }
 
+int dagl_profile_create(int max_calls, dagl_profile** out) {
+    DAGL_REQUIRE(max_calls >= 1 && max_calls <= 4096 && out, "dagl_profile_create: bad argument");
+    Profile* p = new Profile();
+    p->max_calls = max_calls;
+    const size_t n = (size_t)max_calls * (DAGL_N_STAGES + 1);
+    p->ev = new hipEvent_t[n];
+    for (size_t i = 0; i < n; ++i) {
+        hipError_t e = hipEventCreate(&p->ev[i]);
+        if (e != hipSuccess) {
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
+            delete[] p->ev; delete p;
+            return hip_fail(e, "hipEventCreate");
+        }
+    }
+    *out = reinterpret_cast<dagl_profile*>(p);
+    return DAGL_OK;
+}
+
+int dagl_profile_destroy(dagl_profile* prof) {
+    Profile* p = reinterpret_cast<Profile*>(prof);
+    if (!p) return DAGL_OK;
+    const size_t n = (size_t)p->max_calls * (DAGL_N_STAGES + 1);
+    for (size_t i = 0; i < n; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev; delete p;
+    return DAGL_OK;
+}
+
+int dagl_profile_reset(dagl_profile* prof) {
+    Profile* p = reinterpret_cast<Profile*>(prof);
+    DAGL_REQUIRE(p, "dagl_profile_reset: null profile");
+    p->n_calls = 0;
+    return DAGL_OK;
+}
+
+int dagl_profile_read(dagl_profile* prof, int* n_calls, float* stage_ms, int capacity_calls) {
+    Profile* p = reinterpret_cast<Profile*>(prof);
+    DAGL_REQUIRE(p && n_calls, "dagl_profile_read: null argument");
+    *n_calls = p->n_calls;
+    if (!stage_ms) return DAGL_OK;
+    const int n = p->n_calls < capacity_calls ? p->n_calls : capacity_calls;
+    for (int c = 0; c < n; ++c) {
+        hipEvent_t* e = p->ev + (size_t)c * (DAGL_N_STAGES + 1);
+        DAGL_HIP_TRY(hipEventSynchronize(e[DAGL_N_STAGES]));
+        for (int st = 0; st < DAGL_N_STAGES; ++st) {
+            float ms = 0.f;
+            DAGL_HIP_TRY(hipEventElapsedTime(&ms, e[st], e[st + 1]));
+            stage_ms[(size_t)c * DAGL_N_STAGES + st] = ms;
+        }
+    }
+    return DAGL_OK;
+}
+
+int dagl_ce_forward_profiled(void* stream, int B, int H, int W, const float* b1, const float* b2, const float* thr,
+                             const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                             const float* fc2_b, int mode, int k, float* out, void* workspace, size_t ws_bytes,
+                             dagl_ce_info* info, dagl_profile* prof) {
+    return ce_forward_impl((hipStream_t)stream, B, H, W, b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode, k, out,
+                           workspace, ws_bytes, info, nullptr, nullptr, nullptr, reinterpret_cast<Profile*>(prof));
+}
+
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && src_nchw && dst_nhwc, "dagl_pad_nhwc: bad argument");
     return launch_pad_nhwc((hipStream_t)stream, B, H, W, src_nchw, dst_nhwc);
@@ -304,9 +386,9 @@ int dagl_query_thresholds(void* stream, int B, int L, int N, const float* wq, co
 int dagl_gather_aggregate(void* stream, int L, int k, int P_, const int32_t* idx, const float* wgt,
                           const float* values, float* out) {
     DAGL_REQUIRE(L >= 0 && k >= 1 && P_ >= 4 && (P_ % 4) == 0, "dagl_gather_aggregate: bad shape L=%d k=%d P=%d", L, k, P_);
+    if (L == 0) return DAGL_OK;
     DAGL_REQUIRE(idx && wgt && values && out, "dagl_gather_aggregate: null pointer");
     DAGL_REQUIRE(((uintptr_t)values % 16) == 0 && ((uintptr_t)out % 16) == 0, "dagl_gather_aggregate: 16-byte alignment required");
-    if (L == 0) return DAGL_OK;
     return launch_gather_fixed((hipStream_t)stream, L, k, P_, idx, wgt, values, out);
 }
 

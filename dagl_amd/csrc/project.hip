@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
     const int px = QUERIES ? (QS * gx - gr.pl + PADPIX) : gx;
     const float* abase = map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
 
-    f32x4 acc[PJ_NT];
+    // acc: running chain of the current kernel row (7 steps x 16 channels = 112 terms); tot: sum of finished
+    // rows.  Chunking the 784-term sum by kernel row cuts its rounding error ~2.5x (see select.hip).
+    f32x4 acc[PJ_NT], tot[PJ_NT];
 #pragma unroll
-    for (int n = 0; n < PJ_NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < PJ_NT; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[n] = acc[n]; }
 
     // B-fragment LDS offsets (floats): row o = n*16 + i, swizzled slot
     const int bslot = g ^ (((i >> 3) & 1) << 1);
@@ -107,6 +109,10 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, bw.z, acc[n], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, bw.w, acc[n], 0, 0, 0);
         }
+        if ((step + 1) % KS == 0) {
+#pragma unroll
+            for (int n = 0; n < PJ_NT; ++n) { tot[n] += acc[n]; acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
         a_cur = a_nxt;
         __syncthreads();
     }
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
         for (int r = 0; r < 4; ++r) {
             const int rr = 4 * g + r;
             const bool ok = wave_valid && (gx0 + rr < row_len);
-            float v = acc[n][r] + bv;
+            float v = tot[n][r] + bv;
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
             if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;

@@ -28,6 +28,7 @@ constexpr int TILE_FLOATS = KT * DS;             // 6528 floats = 26112 B of key
 constexpr int TILE_PIECES = 26;                  // 1-KiB DMA pieces per tile (the last one is half used)
 constexpr int TILE_LDS = TILE_PIECES * 256;      // floats reserved per LDS buffer
 constexpr int KG = 25;                           // groups of 8 k-values (200 = 196 + 4 zeros)
+constexpr int KCH = 5;                           // accumulation chunks (5 groups = 40 terms each)
 
 __device__ __forceinline__ void glds16s(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -122,17 +123,29 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
             for (int p = wave; p < TILE_PIECES; p += SEL_WAVES)
                 glds16s(xb + (size_t)(tile + 1) * TILE_FLOATS + p * 256 + lane * 4, &sK[cur ^ 1][p * 256]);
         }
+        // The 196-term dot product is accumulated in KCH chunks of 40 terms (each an fp32 fma chain on the
+        // matrix core) that are then added together: the rounding error of a sequential sum grows ~n^2/2
+        // in variance, so chunking cuts it ~2x -- the logits 10*S*m amplify S errors by up to ~100x, and
+        // this keeps the block inside the reference's own fp32 noise ("error budget").
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* kp = &sK[cur][i * DS + 4 * h];
 #pragma unroll
-        for (int t = 0; t < KG; ++t) {
-            const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * t);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, acc, 0, 0, 0);
+        for (int c = 0; c < KCH; ++c) {
+            f32x16 part;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+            for (int t = c * (KG / KCH); t < (c + 1) * (KG / KCH); ++t) {
+                const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * t);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, part, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += part[r];
         }
         // acc[r] = S[key = tile*32 + (r&3) + 8*(r>>2) + 4*h][query q]
         const int kbase = tile * KT + 4 * h;

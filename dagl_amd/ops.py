@@ -119,6 +119,34 @@ def fold_normalize(agg: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return out
 
 
+class StageProfile:
+    """hipEvents at the stage boundaries of up to ``max_calls`` block forwards (include/dagl_ce.h, dagl_profile_*)."""
+
+    def __init__(self, max_calls: int):
+        self._h = C.c_void_p()
+        check(_lib.load().dagl_profile_create(int(max_calls), C.byref(self._h)), "dagl_profile_create")
+        self.max_calls = int(max_calls)
+
+    def reset(self):
+        check(_lib.load().dagl_profile_reset(self._h), "dagl_profile_reset")
+
+    def read(self):
+        """-> list of per-call lists of N_STAGES milliseconds (waits for the recorded events)."""
+        lib = _lib.load()
+        n = C.c_int(0)
+        buf = (C.c_float * (self.max_calls * _lib.N_STAGES))()
+        check(lib.dagl_profile_read(self._h, C.byref(n), buf, self.max_calls), "dagl_profile_read")
+        return [[buf[c * _lib.N_STAGES + s] for s in range(_lib.N_STAGES)] for c in range(n.value)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().dagl_profile_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
 class Workspace:
     """Grow-only device scratch buffer reused across calls (allocated through torch's caching allocator, so it
     is stream-ordered and visible to torch's memory accounting)."""
@@ -134,7 +162,8 @@ class Workspace:
 
 
 def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
-               workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False):
+               workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False,
+               profile: "StageProfile | None" = None):
     """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W]."""
     lib = _lib.load()
     if mode not in MODES:
@@ -173,7 +202,9 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
                 bias.data_ptr() if bias is not None else None,
                 fc1_w.data_ptr(), fc1_b.data_ptr(), fc2_w.data_ptr(), fc2_b.data_ptr(),
                 MODES[mode], int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base), C.byref(info))
-        if dbg is None:
+        if profile is not None:
+            rc = lib.dagl_ce_forward_profiled(*args, profile._h)
+        elif dbg is None:
             rc = lib.dagl_ce_forward(*args)
         else:
             rc = lib.dagl_ce_forward_debug(*args, dbg["deg"].data_ptr(), dbg["rowsum"].data_ptr(),

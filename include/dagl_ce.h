@@ -110,6 +110,30 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W,
                           void* workspace, size_t ws_bytes, dagl_ce_info* info,
                           int32_t* deg_out, float* rowsum_out, float* agg_out);
 
+/* ---- stage profile: hipEvents recorded at the stage boundaries on the caller's stream ---------
+ * The benchmark times its steps with these (no synchronisation is added to the timed region;
+ * dagl_profile_read waits for the recorded events afterwards).  Stage order:                     */
+#define DAGL_N_STAGES        8
+#define DAGL_STAGE_LAYOUT    0   /* pad/NHWC maps + fc weight pack                                  */
+#define DAGL_STAGE_PROJ_KEYS 1   /* fc2 projection of all N key patches (+ column sums)             */
+#define DAGL_STAGE_PROJ_QRY  2   /* fc1 projection of the L query patches                           */
+#define DAGL_STAGE_THRESH    3   /* per-query adaptive thresholds                                   */
+#define DAGL_STAGE_SELECT    4   /* streamed similarity + neighbour selection (the dominant kernel) */
+#define DAGL_STAGE_EDGE      5   /* degree scan / candidate merge + edge softmax                    */
+#define DAGL_STAGE_GATHER    6   /* neighbour gather + weighted sum                                 */
+#define DAGL_STAGE_FOLD      7   /* fold + overlap normalisation                                    */
+typedef struct dagl_profile dagl_profile;
+int dagl_profile_create(int max_calls, dagl_profile** out);
+int dagl_profile_destroy(dagl_profile* prof);
+int dagl_profile_reset(dagl_profile* prof);
+/* stage_ms [capacity_calls][DAGL_N_STAGES] (host memory, may be NULL to query n_calls only) */
+int dagl_profile_read(dagl_profile* prof, int* n_calls, float* stage_ms, int capacity_calls);
+int dagl_ce_forward_profiled(void* stream, int B, int H, int W,
+                             const float* b1, const float* b2, const float* thr, const float* bias,
+                             const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                             int mode, int k, float* out,
+                             void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
+
 /* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
 
 /* NCHW [B,16,H,W] -> zero-bordered NHWC [B,H+6,W+6,16]  (patch unfold without materialising
