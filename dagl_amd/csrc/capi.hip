@@ -84,7 +84,7 @@ static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
     p.o_mt = carve(off, BL * sizeof(float));
     p.o_cnt = carve(off, BL * sizeof(int32_t));
     p.o_segcnt = carve(off, BL * p.splits * 2 * sizeof(int32_t));
-    p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int64_t));
+    p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int32_t));
     p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
     p.o_deg = carve(off, BL * sizeof(int32_t));
     p.o_stats = carve(off, 2 * sizeof(int64_t));
@@ -149,7 +149,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     float* mt = at<float>(ws, p.o_mt);
     int32_t* cnt = at<int32_t>(ws, p.o_cnt);
     int32_t* segcnt = at<int32_t>(ws, p.o_segcnt);
-    int64_t* segoff = at<int64_t>(ws, p.o_segoff);
+    int32_t* segrel = at<int32_t>(ws, p.o_segoff);
     int64_t* rowoff = at<int64_t>(ws, p.o_rowoff);
     int32_t* deg = at<int32_t>(ws, p.o_deg);
     int64_t* stats = at<int64_t>(ws, p.o_stats);
@@ -175,9 +175,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
     }
     prof_mark(prof, s, 1);
-    if ((rc = launch_project(s, B, g, false, b1p, wp2, fc2_b, X, colsum))) return rc;
+    if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq))) return rc;
     prof_mark(prof, s, 2);
-    if ((rc = launch_project(s, B, g, true, b1p, wp1, fc1_b, Wq, nullptr))) return rc;
     prof_mark(prof, s, 3);
 
     // 3. selection
@@ -207,7 +206,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sa.cnt = cnt; sa.seg_cnt = segcnt; sa.list_idx = lidx; sa.list_val = lval;
         if ((rc = launch_score_select(s, sa, 0))) return rc;
         prof_mark(prof, s, 5);
-        if ((rc = launch_csr_offsets(s, (int)BL, p.splits * 2, segcnt, segoff, rowoff, deg, stats))) return rc;
+        if ((rc = launch_row_degree(s, (int)BL, p.splits * 2, segcnt, segrel, deg, stats))) return rc;
         int64_t hstats[2] = {0, 0};
         DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
         DAGL_HIP_TRY(hipStreamSynchronize(s));
@@ -229,7 +228,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                           (long long)hstats[1], (long long)hstats[0], off, ws_bytes);
                 return DAGL_ERR_WORKSPACE;
             }
-            sa.list_idx = at<int32_t>(ws, o_ci); sa.list_val = at<float>(ws, o_cv); sa.seg_off = segoff;
+            if ((rc = launch_row_scan(s, (int)BL, deg, rowoff))) return rc;
+            sa.list_idx = at<int32_t>(ws, o_ci); sa.list_val = at<float>(ws, o_cv); sa.seg_rel = segrel; sa.row_off = rowoff;
             if ((rc = launch_score_select(s, sa, 1))) return rc;
             ea.cnt = deg; ea.list_idx = sa.list_idx; ea.list_val = sa.list_val; ea.row_off = rowoff;
             ea.nb_idx = at<int32_t>(ws, o_ni); ea.nb_wgt = at<float>(ws, o_nw);
@@ -374,7 +374,8 @@ int dagl_project_patches(void* stream, int B, int H, int W, int queries, const f
     for (int b = 0; b < B; ++b)
         DAGL_HIP_TRY(hipMemsetAsync(feat + ((size_t)b * ra + rows) * DS, 0, (size_t)(ra - rows) * DS * sizeof(float), s));
     if (colsum) DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
-    return launch_project(s, B, g, queries != 0, map_nhwc, w_packed, fc_bias, feat, queries ? nullptr : colsum);
+    if (queries) return launch_project(s, B, g, 2, map_nhwc, nullptr, nullptr, nullptr, nullptr, w_packed, fc_bias, feat);
+    return launch_project(s, B, g, 1, map_nhwc, w_packed, fc_bias, feat, colsum, nullptr, nullptr, nullptr);
 }
 
 int dagl_query_thresholds(void* stream, int B, int L, int N, const float* wq, const double* colsum,

@@ -24,6 +24,25 @@ constexpr float SOFTMAX_SCALE = 10.0f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef __HIPCC__
+// LDS-DMA (global_load_lds_dwordx4): each lane copies 16 B from its own global address to
+// LDS[lds_byte_addr + lane*16]; lds_byte_addr must be wave-uniform.  Issued from inline asm on purpose:
+// hipcc treats its own LDS-DMA builtin as a pending LDS write and drains vmcnt(0) before the next ds_read,
+// which serialises the prefetch of tile t+1 with the reads of tile t.  The caller owns the completion wait
+// (dma_wait_all() before the barrier that publishes the buffer).
+__device__ __forceinline__ void glds16_asm(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+#endif
+
 // thread-local error text
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
@@ -76,8 +95,9 @@ inline int feat_rows(int rows) { return round_up(rows, KT) + KT; }
 // ---- stage launchers (defined in the .hip files) ------------------------------------------------
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
-int launch_project(hipStream_t s, int B, const Grid& g, bool queries, const float* map, const float* wp,
-                   const float* bias, float* feat, double* colsum);
+int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
+                   const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
+                   const float* wp_q, const float* bias_q, float* feat_q);
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
                             const float* thr, float* mt);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
@@ -101,7 +121,8 @@ struct SelectArgs {
     int32_t* seg_cnt;               // [B, L, splits, 2] passing keys per (query, chunk, lane half)
     int32_t* list_idx;              // [B, L, FAST_CAP]        (fast path)   or CSR array (fill pass)
     float*   list_val;              // same shape: raw score S
-    const int64_t* seg_off;         // [B, L, splits, 2] CSR cursor starts (fill pass)
+    const int32_t* seg_rel;         // [B, L, splits, 2] cursor of a segment relative to its row (fill pass)
+    const int64_t* row_off;         // [B*L+1] CSR row offsets (fill pass)
     // top-k candidates
     int32_t* cand_idx;              // [B, L, splits*2, k]
     float*   cand_val;
@@ -135,8 +156,9 @@ int launch_aggregate_direct(hipStream_t s, const AggArgs& a);
 int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const int32_t* nb_cnt, const int64_t* row_off,
                      int width, int32_t* deg, float* rowsum);
 
-int launch_csr_offsets(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int64_t* seg_off,
-                       int64_t* row_off, int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);
+int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
+                      int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);
+int launch_row_scan(hipStream_t s, int n_rows, const int32_t* deg, int64_t* row_off);
 int topk_slots(int k);              // per-lane list length used for a requested k (4/8/16/32)
 
 }  // namespace dagl

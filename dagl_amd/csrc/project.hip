@@ -44,34 +44,52 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <bool QUERIES>
-__global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int segs_per_row,
-                                                      const float* __restrict__ map,
-                                                      const float* __restrict__ wp,
-                                                      const float* __restrict__ fbias,
-                                                      float* __restrict__ feat, int feat_rows_alloc,
-                                                      double* __restrict__ colsum) {
+struct ProjArgs {
+    Grid gr;
+    const float* map;            // padded NHWC key/query feature map
+    const float* wp[2];          // packed weights: [0] keys (fc2), [1] queries (fc1)
+    const float* bias[2];
+    float* feat[2];              // outputs [B, rows_alloc, DS]
+    int rows_alloc[2];
+    int n_items[2];              // 16-patch work items per image
+    int segs[2];                 // work items per grid row
+    int n_blocks_q;              // blocks [0, n_blocks_q) project queries, the rest keys
+    double* colsum;              // [B, DS] key column sums (may be null)
+};
+
+// One launch covers both projections: the few query blocks (stride-4 grid, fc1) are dispatched first and
+// run concurrently with the key blocks (stride-1 grid, fc2) instead of forming a second, under-filled launch.
+__global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
     __shared__ __attribute__((aligned(16))) float sB[2][PJ_SLICE];       // 26 KiB
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
+    const Grid& gr = pa.gr;
+
+    const bool queries = (int)blockIdx.x < pa.n_blocks_q;                // block-uniform
+    const int which = queries ? 1 : 0;
+    const int blk = queries ? blockIdx.x : blockIdx.x - pa.n_blocks_q;
+    const float* __restrict__ wp = pa.wp[which];
+    const int n_items = pa.n_items[which];
+    const int segs_per_row = pa.segs[which];
+    const int stride = queries ? QS : 1;
 
     // work item of this wave: 16 consecutive patches of one grid row
-    int item = blockIdx.x * PJ_WAVES + wave;
+    int item = blk * PJ_WAVES + wave;
     const bool wave_valid = item < n_items;
     if (!wave_valid) item = n_items - 1;
-    const int row_len = QUERIES ? gr.Lw : gr.W;
+    const int row_len = queries ? gr.Lw : gr.W;
     const int gy = item / segs_per_row;                       // grid row (query row r or pixel row y)
     const int gx0 = (item % segs_per_row) * 16;
     int gx = gx0 + i;
-    const bool row_valid = gx < row_len;
-    if (!row_valid) gx = row_len - 1;
+    if (gx >= row_len) gx = row_len - 1;
     // top-left corner of the patch in padded-map coordinates
-    const int py = QUERIES ? (QS * gy - gr.pt + PADPIX) : gy;
-    const int px = QUERIES ? (QS * gx - gr.pl + PADPIX) : gx;
-    const float* abase = map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
+    const int py = queries ? (QS * gy - gr.pt + PADPIX) : gy;
+    const int px = queries ? (QS * gx - gr.pl + PADPIX) : gx;
+    const float* abase = pa.map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
+    (void)stride;
 
     // acc: running chain of the current kernel row (7 steps x 16 channels = 112 terms); tot: sum of finished
     // rows.  Chunking the 784-term sum by kernel row cuts its rounding error ~2.5x (see select.hip).
@@ -84,9 +102,11 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
     const int boff = i * CH + bslot * 4;
 
     // prologue: slice 0 -> sB[0]
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sB[0][0]));
     for (int p = wave; p < PJ_NT; p += PJ_WAVES)
-        glds16(wp + (size_t)p * 256 + lane * 4, &sB[0][p * 256]);
+        glds16_asm(wp + (size_t)p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
     float4 a_cur = *reinterpret_cast<const float4*>(abase);
+    dma_wait_all();
     __syncthreads();
 
     for (int step = 0; step < PJ_STEPS; ++step) {
@@ -95,8 +115,9 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
         if (step + 1 < PJ_STEPS) {
             const int ns = step + 1;
             const float* wsrc = wp + (size_t)ns * PJ_SLICE;
+            const unsigned dst = lds0 + (cur ^ 1) * (PJ_SLICE * 4);
             for (int p = wave; p < PJ_NT; p += PJ_WAVES)
-                glds16(wsrc + (size_t)p * 256 + lane * 4, &sB[cur ^ 1][p * 256]);
+                glds16_asm(wsrc + (size_t)p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(dst + p * 1024));
             const int kh = ns / KS, kw = ns % KS;
             a_nxt = *reinterpret_cast<const float4*>(abase + ((size_t)kh * gr.Wp + kw) * CH);
         }
@@ -114,12 +135,14 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
             for (int n = 0; n < PJ_NT; ++n) { tot[n] += acc[n]; acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
         a_cur = a_nxt;
+        dma_wait_all();
         __syncthreads();
     }
 
     // epilogue: D[row = 4g + r][col = n*16 + i]; bias + ReLU; zero columns 196..203
     const int grid_row_base = gy * row_len + gx0;          // linear patch index of row 0 of this wave
-    float* fb = feat + (size_t)b * feat_rows_alloc * DS;
+    float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
+    const float* __restrict__ fbias = pa.bias[which];
     float csum[PJ_NT];
 #pragma unroll
     for (int n = 0; n < PJ_NT; ++n) {
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
         }
         csum[n] = s;
     }
-    if (!QUERIES && colsum != nullptr) {
+    if (!queries && pa.colsum != nullptr) {
         // reduce over the 4 row groups (lanes i, i+16, i+32, i+48), then one fp64 atomic per column per wave
 #pragma unroll
         for (int n = 0; n < PJ_NT; ++n) {
@@ -146,25 +169,28 @@ __global__ __launch_bounds__(256) void project_kernel(Grid gr, int n_items, int 
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             const int col = n * 16 + i;
-            if (g == 0 && col < D && wave_valid) atomicAdd(&colsum[(size_t)b * DS + col], (double)s);
+            if (g == 0 && col < D && wave_valid) atomicAdd(&pa.colsum[(size_t)b * DS + col], (double)s);
         }
     }
 }
 
-int launch_project(hipStream_t s, int B, const Grid& g, bool queries, const float* map, const float* wp,
-                   const float* bias, float* feat, double* colsum) {
-    const int row_len = queries ? g.Lw : g.W;
-    const int n_rows = queries ? g.Lh : g.H;
-    const int segs = (row_len + 15) / 16;
-    const int n_items = segs * n_rows;
-    const int rows_alloc = feat_rows(queries ? g.L : g.N);
-    dim3 grid((n_items + PJ_WAVES - 1) / PJ_WAVES, B), block(256);
-    if (queries)
-        hipLaunchKernelGGL(project_kernel<true>, grid, block, 0, s, g, n_items, segs, map, wp, bias, feat,
-                           rows_alloc, colsum);
-    else
-        hipLaunchKernelGGL(project_kernel<false>, grid, block, 0, s, g, n_items, segs, map, wp, bias, feat,
-                           rows_alloc, colsum);
+// which: bit 0 = keys, bit 1 = queries
+int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* map, const float* wp_keys,
+                   const float* bias_keys, float* feat_keys, double* colsum, const float* wp_q,
+                   const float* bias_q, float* feat_q) {
+    ProjArgs pa;
+    pa.gr = g; pa.map = map;
+    pa.wp[0] = wp_keys; pa.bias[0] = bias_keys; pa.feat[0] = feat_keys;
+    pa.wp[1] = wp_q; pa.bias[1] = bias_q; pa.feat[1] = feat_q;
+    pa.rows_alloc[0] = feat_rows(g.N); pa.rows_alloc[1] = feat_rows(g.L);
+    pa.segs[0] = (g.W + 15) / 16; pa.segs[1] = (g.Lw + 15) / 16;
+    pa.n_items[0] = pa.segs[0] * g.H; pa.n_items[1] = pa.segs[1] * g.Lh;
+    pa.colsum = colsum;
+    const int nbq = (which & 2) ? (pa.n_items[1] + PJ_WAVES - 1) / PJ_WAVES : 0;
+    const int nbk = (which & 1) ? (pa.n_items[0] + PJ_WAVES - 1) / PJ_WAVES : 0;
+    pa.n_blocks_q = nbq;
+    dim3 grid(nbq + nbk, B), block(256);
+    hipLaunchKernelGGL(project_kernel, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project_kernel");
     return DAGL_OK;
 }

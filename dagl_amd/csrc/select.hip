@@ -95,6 +95,11 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
         const float* qp = a.wq + ((size_t)b * rows_q + qc) * DS + 4 * h;
 #pragma unroll
         for (int t = 0; t < KG; ++t) qf[t] = *reinterpret_cast<const float4*>(qp + 8 * t);
+        // consume the loads here, so that hipcc's lazy vmcnt waits for them sit before the loop and not
+        // between the MFMAs of every tile (where they would also wait for the in-flight LDS-DMA)
+#pragma unroll
+        for (int t = 0; t < KG; ++t)
+            asm volatile("" : "+v"(qf[t].x), "+v"(qf[t].y), "+v"(qf[t].z), "+v"(qf[t].w));
     }
     float mtq = 0.f, bsq = 0.f;
     if (PASS != 2) {
@@ -108,20 +113,25 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
 
     int n_loc = 0;                                            // passing keys seen by this lane
     int64_t cursor = 0;
-    if (PASS == 1) cursor = a.seg_off[seg];
+    if (PASS == 1) cursor = a.row_off[qlin] + a.seg_rel[seg];
     TopK<(PASS >= 2) ? K : 1> best;
     best.init();
 
     // prologue: first tile -> buffer 0
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
     for (int p = wave; p < TILE_PIECES; p += SEL_WAVES)
-        glds16s(xb + (size_t)tile0 * TILE_FLOATS + p * 256 + lane * 4, &sK[0][p * 256]);
+        glds16_asm(xb + (size_t)tile0 * TILE_FLOATS + p * 256 + lane * 4,
+                   __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
+    dma_wait_all();
     __syncthreads();
 
     for (int tile = tile0; tile < tile1; ++tile) {
         const int cur = (tile - tile0) & 1;
         if (tile + 1 < tile1) {
+            const unsigned dst = lds0 + (cur ^ 1) * (TILE_LDS * 4);
             for (int p = wave; p < TILE_PIECES; p += SEL_WAVES)
-                glds16s(xb + (size_t)(tile + 1) * TILE_FLOATS + p * 256 + lane * 4, &sK[cur ^ 1][p * 256]);
+                glds16_asm(xb + (size_t)(tile + 1) * TILE_FLOATS + p * 256 + lane * 4,
+                           __builtin_amdgcn_readfirstlane(dst + p * 1024));
         }
         // The 196-term dot product is accumulated in KCH chunks of 40 terms (each an fp32 fma chain on the
         // matrix core) that are then added together: the rounding error of a sequential sum grows ~n^2/2
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
                 }
             }
         }
+        dma_wait_all();          // next tile landed (it had the whole tile's MFMA time)
         __syncthreads();
     }
 
@@ -268,48 +279,68 @@ int launch_scores_dense(hipStream_t s, int B, int L, int N, const float* wq, con
     return DAGL_OK;
 }
 
-// ---- CSR offsets: degrees, row offsets, per-(query,chunk,half) cursors ---------------------------------
-// single block; rows are split into contiguous ranges per thread (deterministic).
-__global__ __launch_bounds__(1024) void csr_offsets_kernel(int n_rows, int s2, const int32_t* __restrict__ seg_cnt,
-                                                           int64_t* __restrict__ seg_off,
-                                                           int64_t* __restrict__ row_off,
-                                                           int32_t* __restrict__ deg,
-                                                           int64_t* __restrict__ stats /* total, maxdeg */) {
+// ---- degrees and CSR offsets ------------------------------------------------------------------------------
+// row_degree_kernel: one wave per query: deg = sum of its (chunk, half) segment counts, seg_rel = exclusive
+// prefix of the counts inside the row, plus max / total over all rows (integer atomics: order-independent).
+__global__ __launch_bounds__(256) void row_degree_kernel(int n_rows, int s2, const int32_t* __restrict__ seg_cnt,
+                                                         int32_t* __restrict__ seg_rel, int32_t* __restrict__ deg,
+                                                         unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    int run = 0;
+    for (int j0 = 0; j0 < s2; j0 += 64) {
+        const int j = j0 + lane;
+        const int c = (j < s2) ? seg_cnt[(size_t)row * s2 + j] : 0;
+        int incl = c;                                         // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (j < s2) seg_rel[(size_t)row * s2 + j] = run + incl - c;
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+        deg[row] = run;
+        atomicAdd(&stats[0], (unsigned long long)run);
+        atomicMax(&stats[1], (unsigned long long)run);
+    }
+}
+
+// row_scan_kernel: exclusive scan of deg over the rows (single block; only the dense CSR path needs it)
+__global__ __launch_bounds__(1024) void row_scan_kernel(int n_rows, const int32_t* __restrict__ deg,
+                                                        int64_t* __restrict__ row_off) {
     __shared__ int64_t part[1024];
-    __shared__ int32_t pmax[1024];
     const int t = threadIdx.x, nt = blockDim.x;
     const int per = (n_rows + nt - 1) / nt;
-    const int r0 = t * per, r1 = min(n_rows, r0 + per);
-    int64_t sum = 0; int32_t mx = 0;
-    for (int r = r0; r < r1; ++r) {
-        int32_t d = 0;
-        for (int j = 0; j < s2; ++j) d += seg_cnt[(size_t)r * s2 + j];
-        deg[r] = d; sum += d; mx = max(mx, d);
-    }
-    part[t] = sum; pmax[t] = mx;
+    const int r0 = min(n_rows, t * per), r1 = min(n_rows, r0 + per);
+    int64_t sum = 0;
+    for (int r = r0; r < r1; ++r) sum += deg[r];
+    part[t] = sum;
     __syncthreads();
     if (t == 0) {
-        int64_t run = 0; int32_t m = 0;
-        for (int j = 0; j < nt; ++j) { const int64_t v = part[j]; part[j] = run; run += v; m = max(m, pmax[j]); }
-        stats[0] = run; stats[1] = m;
+        int64_t run = 0;
+        for (int j = 0; j < nt; ++j) { const int64_t v = part[j]; part[j] = run; run += v; }
         row_off[n_rows] = run;
     }
     __syncthreads();
     int64_t off = part[t];
-    for (int r = r0; r < r1; ++r) {
-        row_off[r] = off;
-        for (int j = 0; j < s2; ++j) {
-            seg_off[(size_t)r * s2 + j] = off;
-            off += seg_cnt[(size_t)r * s2 + j];
-        }
-    }
+    for (int r = r0; r < r1; ++r) { row_off[r] = off; off += deg[r]; }
 }
 
-int launch_csr_offsets(hipStream_t s, int n_rows, int s2, const int32_t* seg_cnt, int64_t* seg_off,
-                       int64_t* row_off, int32_t* deg, int64_t* stats) {
-    hipLaunchKernelGGL(csr_offsets_kernel, dim3(1), dim3(1024), 0, s, n_rows, s2, seg_cnt, seg_off, row_off, deg,
-                       stats);
-    DAGL_LAUNCH_CHECK("csr_offsets_kernel");
+int launch_row_degree(hipStream_t s, int n_rows, int s2, const int32_t* seg_cnt, int32_t* seg_rel, int32_t* deg,
+                      int64_t* stats) {
+    DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(row_degree_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, s2, seg_cnt, seg_rel, deg,
+                       reinterpret_cast<unsigned long long*>(stats));
+    DAGL_LAUNCH_CHECK("row_degree_kernel");
+    return DAGL_OK;
+}
+
+int launch_row_scan(hipStream_t s, int n_rows, const int32_t* deg, int64_t* row_off) {
+    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_rows, deg, row_off);
+    DAGL_LAUNCH_CHECK("row_scan_kernel");
     return DAGL_OK;
 }
 

@@ -115,8 +115,9 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W,
  * dagl_profile_read waits for the recorded events afterwards).  Stage order:                     */
 #define DAGL_N_STAGES        8
 #define DAGL_STAGE_LAYOUT    0   /* pad/NHWC maps + fc weight pack                                  */
-#define DAGL_STAGE_PROJ_KEYS 1   /* fc2 projection of all N key patches (+ column sums)             */
-#define DAGL_STAGE_PROJ_QRY  2   /* fc1 projection of the L query patches                           */
+#define DAGL_STAGE_PROJ_KEYS 1   /* fc2 projection of the N key patches (+ column sums) and fc1
+                                    projection of the L query patches: one launch                  */
+#define DAGL_STAGE_PROJ_QRY  2   /* (empty: merged into stage 1)                                    */
 #define DAGL_STAGE_THRESH    3   /* per-query adaptive thresholds                                   */
 #define DAGL_STAGE_SELECT    4   /* streamed similarity + neighbour selection (the dominant kernel) */
 #define DAGL_STAGE_EDGE      5   /* degree scan / candidate merge + edge softmax                    */
