@@ -33,6 +33,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 D_FEAT, P_ROW = 196, 784
 
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--sparse-gain", type=float, default=2.4, help="adaptive modes: threshold gain of the synthetic thr head")
+    ap.add_argument("--scan", default="screened", choices=["screened", "exact"],
+                    help="screened: bf16 matrix-core screen + exact refine (default); exact: all scores on the fp32 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
     return ap.parse_args()
@@ -100,6 +103,7 @@ def main():
     ce = CE(in_channels=64)
     ce.load_state_dict(params, strict=True)
     ce.select_mode = mode
+    ce.scan = args.scan
     if k:
         ce.select_k = k
     ce = ce.to(dev).eval()
@@ -165,9 +169,12 @@ def main():
         sel_ms = float(mean_ms[4])
         flops = 2.0 * B * L * N * D_FEAT                                 # algorithmic: 2*L*N*D per image
         ach = flops / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "score_select_kernel (fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+        screened = (info or {}).get("path") == 3
+        peak = PEAK_BF16_MATRIX_TFLOPS if screened else PEAK_F32_MATRIX_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": "screen_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter)" if screened
+                              else "score_select_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
         if gather is not None and mean_ms[6] > 0:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
@@ -185,7 +192,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one CE head forward, features [{B},64,{H},{W}] fp32 per GPU, "
                                    f"select mode {mode} k={k}, L={L} queries x N={N} keys per image",
                        "parallelism": f"dp{world} (independent images per rank, no data-path collective)",
-                       "select_mode": mode, "k": k, "batch_per_gpu": B,
+                       "select_mode": mode, "k": k, "batch_per_gpu": B, "scan": args.scan,
                        "selection_path": (info or {}).get("path"), "max_degree": (info or {}).get("max_degree")},
             "roofline": roofline,
             "roofline_gather": gather,

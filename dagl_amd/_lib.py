@@ -21,7 +21,8 @@ D = 196
 DS = 204
 ERR_WORKSPACE = -2
 N_STAGES = 8
-STAGE_NAMES = ("layout", "proj_keys", "proj_queries", "thresholds", "select", "edge_softmax", "gather", "fold")
+STAGE_NAMES = ("layout", "project", "thresholds", "screen_sample", "select", "edge_softmax", "gather", "fold")
+FLAG_EXACT_SCAN = 0x100
 
 
 class DaglError(RuntimeError):

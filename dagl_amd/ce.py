@@ -51,6 +51,9 @@ class CE(nn.Module):
         #   "adaptive" | "topk" | "adaptive_topk", with k = ``select_k``.
         self.select_mode = "adaptive"
         self.select_k = min(num_edge, MAX_TOPK)
+        # "screened": bf16 matrix-core screen of all L*N scores + exact refinement of the survivors (default);
+        # "exact": every score on the fp32 matrix cores.  Same neighbours either way.
+        self.scan = "screened"
         self._ws = ops.Workspace()
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
@@ -84,6 +87,6 @@ class CE(nn.Module):
                                    self.fc1[0].weight.contiguous(), self.fc1[0].bias.contiguous(),
                                    self.fc2[0].weight.contiguous(), self.fc2[0].bias.contiguous(),
                                    mode=self.select_mode, k=self.select_k, workspace=self._ws, return_info=True,
-                                   profile=self.profile)
+                                   profile=self.profile, exact_scan=(self.scan == "exact"))
         self.last_info = info
         return out

@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int 
     __shared__ int ci[4][TOPK_MAX_CAND];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t ql = (size_t)blockIdx.x * 4 + w;
-    const bool active = ql < (size_t)a.B * a.L;
+    bool active = ql < (size_t)a.B * a.L;
+    if (active && a.run_flags != nullptr) {
+        const size_t b = ql / a.L, qg = (ql - b * a.L) / 128;
+        active = a.run_flags[b * ((a.L + 127) / 128) + qg] != 0;
+    }
     const int nc = a.splits * 2 * kslots;
     if (active) {
         for (int t = lane; t < nc; t += 64) {

@@ -35,11 +35,15 @@ static inline void prof_mark(Profile* p, hipStream_t s, int stage_boundary) {
 struct Plan {
     Grid g;
     int B, mode, k, kslots;
-    int splits, tiles_per_split, n_tiles;
+    bool screen;                    // bf16 screen + exact refine (default) vs. the all-fp32 scan
+    int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
+    int s_splits, s_steps_per_split, s_steps, s_sample;   // bf16 screen (screen.hip)
+    int capseg;
     int width;                      // neighbour-list width of the fixed-width paths
     // byte offsets into the workspace
-    size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff, o_deg,
-        o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_end;
+    size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
+        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
+        o_ssegcnt, o_redo, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -48,10 +52,16 @@ static size_t carve(size_t& off, size_t bytes) {
     return o;
 }
 
-static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
+constexpr int SCREEN_MIN_KEYS = 2048;     // below this the fp32 scan is launch-bound anyway
+constexpr int SCREEN_CAPSEG = 16;
+
+static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
+    const int mode = mode_flags & 0xff;
+    const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE(mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK,
-                 "dagl: unknown mode %d", mode);
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN)) == 0 &&
+                 (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
+                 "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
         DAGL_REQUIRE(k >= 1 && k <= DAGL_MAX_TOPK, "dagl: k=%d outside [1,%d]", k, DAGL_MAX_TOPK);
     DAGL_REQUIRE((int64_t)H * W < (1ll << 30), "dagl: image too large");
@@ -59,9 +69,10 @@ static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
     p.B = B; p.mode = mode; p.k = k;
     p.kslots = (mode == DAGL_MODE_ADAPTIVE) ? 0 : topk_slots(k);
     const Grid& g = p.g;
+    p.screen = !exact && g.N >= SCREEN_MIN_KEYS;
     p.n_tiles = (g.N + KT - 1) / KT;
     const int n_qgroups = (g.L + 127) / 128;
-    // enough blocks for ~4 per CU, chunks of at least 8 tiles, candidate merge bounded for top-k
+    // fp32 scan: enough blocks for ~4 per CU, chunks of at least 8 tiles, candidate merge bounded for top-k
     int splits = (1024 + n_qgroups * B - 1) / (n_qgroups * B);
     const int max_by_tiles = (p.n_tiles + 7) / 8;
     if (splits > max_by_tiles) splits = max_by_tiles;
@@ -70,6 +81,20 @@ static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
     p.tiles_per_split = (p.n_tiles + splits - 1) / splits;
     p.splits = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
     p.width = (mode == DAGL_MODE_ADAPTIVE) ? DAGL_FAST_CAP : k;
+    // bf16 screen: 256 queries per block, chunks of >= 4 steps of 64 keys, <= 64 chunks
+    p.s_steps = (g.N + SKEYS - 1) / SKEYS;
+    {
+        const int nqg = (g.L + 255) / 256;
+        int sp = (768 + nqg * B - 1) / (nqg * B);
+        const int mx = (p.s_steps + 3) / 4;
+        if (sp > mx) sp = mx;
+        if (sp > 64) sp = 64;
+        if (sp < 1) sp = 1;
+        p.s_steps_per_split = (p.s_steps + sp - 1) / sp;
+        p.s_splits = (p.s_steps + p.s_steps_per_split - 1) / p.s_steps_per_split;
+        p.s_sample = p.s_steps_per_split >= 8 ? 4 : (p.s_steps_per_split >= 4 ? 2 : 1);
+    }
+    p.capseg = SCREEN_CAPSEG;
 
     const size_t BL = (size_t)B * g.L;
     size_t off = 0;
@@ -87,7 +112,7 @@ static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
     p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int32_t));
     p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
     p.o_deg = carve(off, BL * sizeof(int32_t));
-    p.o_stats = carve(off, 2 * sizeof(int64_t));
+    p.o_stats = carve(off, 4 * sizeof(int64_t));
     if (mode == DAGL_MODE_ADAPTIVE) {
         p.o_lidx = carve(off, BL * DAGL_FAST_CAP * sizeof(int32_t));
         p.o_lval = carve(off, BL * DAGL_FAST_CAP * sizeof(float));
@@ -101,6 +126,16 @@ static int make_plan(int B, int H, int W, int mode, int k, Plan& p) {
     p.o_nbwgt = carve(off, BL * p.width * sizeof(float));
     p.o_nbcnt = carve(off, BL * sizeof(int32_t));
     p.o_agg = carve(off, BL * P * sizeof(float));
+    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
+    if (p.screen) {
+        p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
+        p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
+        p.o_gmax = carve(off, BL * p.s_splits * 2 * 16 * sizeof(float));
+        p.o_theta = carve(off, BL * sizeof(float));
+        p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int32_t));
+        p.o_ssegcnt = carve(off, BL * p.s_splits * 2 * sizeof(int32_t));
+        p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
+    }
     p.o_end = off;
     return DAGL_OK;
 }
@@ -122,13 +157,14 @@ static int check_device() {
 
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
                            const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
-                           const float* fc2_b, int mode, int k, float* out, void* ws, size_t ws_bytes,
+                           const float* fc2_b, int mode_flags, int k, float* out, void* ws, size_t ws_bytes,
                            dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg,
                            Profile* prof = nullptr) {
     Plan p;
-    int rc = make_plan(B, H, W, mode, k, p);
+    int rc = make_plan(B, H, W, mode_flags, k, p);
     if (rc) return rc;
-    if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = 0; info->max_degree = 0; info->path = 0; }
+    const int mode = p.mode;
+    if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0; }
     DAGL_REQUIRE(b1 && b2 && fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
     if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias, "dagl_ce_forward: thr/bias required in adaptive modes");
     DAGL_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256) == 0, "dagl_ce_forward: workspace must be 256-byte aligned");
@@ -138,6 +174,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     }
     const Grid& g = p.g;
     const size_t BL = (size_t)B * g.L;
+    const int n_qgroups = (g.L + 127) / 128;
 
     float* b1p = at<float>(ws, p.o_b1p);
     float* b2p = at<float>(ws, p.o_b2p);
@@ -145,6 +182,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     float* wp2 = at<float>(ws, p.o_wp2);
     float* X = at<float>(ws, p.o_x);
     float* Wq = at<float>(ws, p.o_wq);
+    uint16_t* Xh = p.screen ? at<uint16_t>(ws, p.o_xh) : nullptr;
+    uint16_t* Wqh = p.screen ? at<uint16_t>(ws, p.o_wqh) : nullptr;
     double* colsum = at<double>(ws, p.o_colsum);
     float* mt = at<float>(ws, p.o_mt);
     int32_t* cnt = at<int32_t>(ws, p.o_cnt);
@@ -158,28 +197,34 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int32_t* nbcnt = at<int32_t>(ws, p.o_nbcnt);
     float* agg = at<float>(ws, p.o_agg);
 
-    // 1. layout: zero-bordered NHWC maps, packed fc weights
+    // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
     if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
     if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
     if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
-
-    // 2. projections (the tail rows / guard tile of the feature matrices must be finite: zero them)
-    {
+    {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
         for (int b = 0; b < B; ++b) {
             DAGL_HIP_TRY(hipMemsetAsync(X + ((size_t)b * rx + g.N) * DS, 0, (size_t)(rx - g.N) * DS * sizeof(float), s));
             DAGL_HIP_TRY(hipMemsetAsync(Wq + ((size_t)b * rq + g.L) * DS, 0, (size_t)(rq - g.L) * DS * sizeof(float), s));
         }
+        if (p.screen) {
+            const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
+            for (int b = 0; b < B; ++b) {
+                DAGL_HIP_TRY(hipMemsetAsync(Xh + ((size_t)b * hx + g.N) * DSH, 0, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), s));
+                DAGL_HIP_TRY(hipMemsetAsync(Wqh + ((size_t)b * hq + g.L) * DSH, 0, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), s));
+            }
+        }
         DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
     }
-    prof_mark(prof, s, 1);
-    if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq))) return rc;
-    prof_mark(prof, s, 2);
-    prof_mark(prof, s, 3);
 
-    // 3. selection
+    // ---- stage 1: both projections, one launch -------------------------------------------------------------
+    prof_mark(prof, s, 1);
+    if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
+
+    // ---- stage 2: adaptive thresholds ----------------------------------------------------------------------
+    prof_mark(prof, s, 2);
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.B = B; sa.L = g.L; sa.N = g.N; sa.W = g.W; sa.wq = Wq; sa.x = X; sa.mode = mode; sa.k = k;
@@ -192,60 +237,109 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     memset(&ag, 0, sizeof(ag));
     ag.B = B; ag.g = g; ag.b2p = b2p; ag.nb_idx = nbidx; ag.nb_wgt = nbwgt; ag.nb_cnt = nbcnt; ag.width = p.width;
     ag.agg = agg;
-
     if (mode != DAGL_MODE_TOPK) {
         if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt))) return rc;
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
-    prof_mark(prof, s, 4);
 
-    if (mode == DAGL_MODE_ADAPTIVE) {
-        int32_t* lidx = at<int32_t>(ws, p.o_lidx);
-        float* lval = at<float>(ws, p.o_lval);
-        DAGL_HIP_TRY(hipMemsetAsync(cnt, 0, BL * sizeof(int32_t), s));
-        sa.cnt = cnt; sa.seg_cnt = segcnt; sa.list_idx = lidx; sa.list_val = lval;
-        if ((rc = launch_score_select(s, sa, 0))) return rc;
+    // ---- stages 3-5: neighbour selection + edge softmax ------------------------------------------------------
+    bool need_exact = !p.screen;
+    int32_t* redo = nullptr;
+    if (p.screen) {
+        ScreenArgs sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.B = B; sc.L = g.L; sc.N = g.N; sc.mode = mode; sc.wqh = Wqh; sc.xh = Xh;
+        sc.rows_qh = feat_rows_h(g.L); sc.rows_xh = feat_rows_h(g.N);
+        sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample;
+        sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
+        sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
+        redo = at<int32_t>(ws, p.o_redo);
+        DAGL_HIP_TRY(hipMemsetAsync(redo, 0, (size_t)B * n_qgroups * sizeof(int32_t), s));
+        DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
+        prof_mark(prof, s, 3);
+        if (mode == DAGL_MODE_TOPK) {
+            if ((rc = launch_screen(s, sc, 0))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 16, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
+        }
+        prof_mark(prof, s, 4);
+        if ((rc = launch_screen(s, sc, 1))) return rc;
         prof_mark(prof, s, 5);
-        if ((rc = launch_row_degree(s, (int)BL, p.splits * 2, segcnt, segrel, deg, stats))) return rc;
-        int64_t hstats[2] = {0, 0};
-        DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
-        DAGL_HIP_TRY(hipStreamSynchronize(s));
-        if (info) { info->total_edges = hstats[0]; info->max_degree = (int32_t)hstats[1]; }
-        if (hstats[1] <= DAGL_FAST_CAP) {
-            ea.cnt = deg; ea.list_idx = lidx; ea.list_val = lval; ea.row_off = nullptr;
-            if ((rc = launch_edge_softmax(s, ea))) return rc;
+        RefineArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.B = B; ra.L = g.L; ra.N = g.N; ra.mode = mode; ra.k = k; ra.splits = p.s_splits; ra.capseg = p.capseg;
+        ra.width = p.width; ra.wq = Wq; ra.x = X; ra.rows_q = feat_rows(g.L); ra.rows_x = feat_rows(g.N);
+        ra.mt = mt; ra.bs = bias; ra.cand_idx = sc.cand_idx; ra.seg_cnt = sc.seg_cnt;
+        ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
+        ra.stats = stats;
+        if ((rc = launch_refine(s, ra))) return rc;
+        if (info) info->path = 3;
+        if (mode == DAGL_MODE_ADAPTIVE) {
+            // dense neighbourhoods need the CSR sizing on the host anyway: read the verdict back
+            int64_t hs[4] = {0, 0, 0, 0};
+            DAGL_HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, s));
+            DAGL_HIP_TRY(hipStreamSynchronize(s));
+            if (hs[2] > 0) need_exact = true;
+            else if (info) { info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1]; }
         } else {
-            // two-pass CSR: exact degrees are known, refill deterministically at per-lane cursors
-            size_t off = p.o_end;
-            const size_t e = (size_t)hstats[0];
-            const size_t o_ci = carve(off, e * sizeof(int32_t));
-            const size_t o_cv = carve(off, e * sizeof(float));
-            const size_t o_ni = carve(off, e * sizeof(int32_t));
-            const size_t o_nw = carve(off, e * sizeof(float));
-            if (info) { info->required_bytes = (int64_t)off; info->path = 1; }
-            if (ws_bytes < off) {
-                set_error("dagl_ce_forward: dense neighbourhoods (max degree %lld, %lld edges) need workspace %zu B, have %zu B",
-                          (long long)hstats[1], (long long)hstats[0], off, ws_bytes);
-                return DAGL_ERR_WORKSPACE;
-            }
-            if ((rc = launch_row_scan(s, (int)BL, deg, rowoff))) return rc;
-            sa.list_idx = at<int32_t>(ws, o_ci); sa.list_val = at<float>(ws, o_cv); sa.seg_rel = segrel; sa.row_off = rowoff;
-            if ((rc = launch_score_select(s, sa, 1))) return rc;
-            ea.cnt = deg; ea.list_idx = sa.list_idx; ea.list_val = sa.list_val; ea.row_off = rowoff;
-            ea.nb_idx = at<int32_t>(ws, o_ni); ea.nb_wgt = at<float>(ws, o_nw);
-            if ((rc = launch_edge_softmax(s, ea))) return rc;
-            ag.nb_idx = ea.nb_idx; ag.nb_wgt = ea.nb_wgt; ag.row_off = rowoff;
+            // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it
+            // exits at once for every other group, so no host round trip is needed
+            sa.run_flags = redo; ea.run_flags = redo;
+            need_exact = true;
         }
     } else {
-        sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
-        if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
-        prof_mark(prof, s, 5);
-        ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
-        if ((rc = launch_edge_softmax(s, ea))) return rc;
-        if (info) { info->path = 2; info->max_degree = k; info->total_edges = -1; }
+        prof_mark(prof, s, 3);
+        prof_mark(prof, s, 4);
     }
 
-    // 4. gather + weighted sum, fold
+    if (need_exact) {
+        if (mode == DAGL_MODE_ADAPTIVE) {
+            int32_t* lidx = at<int32_t>(ws, p.o_lidx);
+            float* lval = at<float>(ws, p.o_lval);
+            DAGL_HIP_TRY(hipMemsetAsync(cnt, 0, BL * sizeof(int32_t), s));
+            sa.cnt = cnt; sa.seg_cnt = segcnt; sa.list_idx = lidx; sa.list_val = lval;
+            if ((rc = launch_score_select(s, sa, 0))) return rc;
+            if (!p.screen) prof_mark(prof, s, 5);
+            if ((rc = launch_row_degree(s, (int)BL, p.splits * 2, segcnt, segrel, deg, stats))) return rc;
+            int64_t hstats[2] = {0, 0};
+            DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
+            DAGL_HIP_TRY(hipStreamSynchronize(s));
+            if (info) { info->total_edges = hstats[0]; info->max_degree = (int32_t)hstats[1]; info->path = 0; }
+            if (hstats[1] <= DAGL_FAST_CAP) {
+                ea.cnt = deg; ea.list_idx = lidx; ea.list_val = lval; ea.row_off = nullptr;
+                if ((rc = launch_edge_softmax(s, ea))) return rc;
+            } else {
+                // two-pass CSR: exact degrees are known, refill deterministically at per-lane cursors
+                size_t off = p.o_end;
+                const size_t e = (size_t)hstats[0];
+                const size_t o_ci = carve(off, e * sizeof(int32_t));
+                const size_t o_cv = carve(off, e * sizeof(float));
+                const size_t o_ni = carve(off, e * sizeof(int32_t));
+                const size_t o_nw = carve(off, e * sizeof(float));
+                if (info) { info->required_bytes = (int64_t)off; info->path = 1; }
+                if (ws_bytes < off) {
+                    set_error("dagl_ce_forward: dense neighbourhoods (max degree %lld, %lld edges) need workspace %zu B, have %zu B",
+                              (long long)hstats[1], (long long)hstats[0], off, ws_bytes);
+                    return DAGL_ERR_WORKSPACE;
+                }
+                if ((rc = launch_row_scan(s, (int)BL, deg, rowoff))) return rc;
+                sa.list_idx = at<int32_t>(ws, o_ci); sa.list_val = at<float>(ws, o_cv); sa.seg_rel = segrel; sa.row_off = rowoff;
+                if ((rc = launch_score_select(s, sa, 1))) return rc;
+                ea.cnt = deg; ea.list_idx = sa.list_idx; ea.list_val = sa.list_val; ea.row_off = rowoff;
+                ea.nb_idx = at<int32_t>(ws, o_ni); ea.nb_wgt = at<float>(ws, o_nw);
+                if ((rc = launch_edge_softmax(s, ea))) return rc;
+                ag.nb_idx = ea.nb_idx; ag.nb_wgt = ea.nb_wgt; ag.row_off = rowoff;
+            }
+        } else {
+            sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
+            if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
+            if (!p.screen) prof_mark(prof, s, 5);
+            ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
+            if ((rc = launch_edge_softmax(s, ea))) return rc;
+            if (info && !p.screen) { info->path = 2; info->max_degree = k; }
+        }
+    }
+
+    // ---- stages 6-7: gather + weighted sum, fold ---------------------------------------------------------------
     if (dbg_deg || dbg_rowsum)
         if ((rc = launch_row_stats(s, BL, ag.nb_wgt, ag.nb_cnt, ag.row_off, ag.width, dbg_deg, dbg_rowsum))) return rc;
     prof_mark(prof, s, 6);

@@ -15,6 +15,8 @@ constexpr int CH = DAGL_CH;           // 16 channels of the feature maps
 constexpr int P = DAGL_P;             // 784
 constexpr int D = DAGL_D;             // 196
 constexpr int DS = DAGL_DS;           // 204: feature row stride (floats); 51 16-B slots, odd => conflict-free b128 LDS reads
+constexpr int DSH = 216;              // bf16 feature row stride (elements): 432 B = 27 16-B slots (odd)
+constexpr int SKEYS = 64;             // keys per step of the bf16 screen
 constexpr int DPAD = 208;             // fc output columns rounded up to 13 MFMA tiles of 16
 constexpr int PADPIX = DAGL_PADPIX;   // 3
 constexpr int KT = 32;                // keys per streaming tile (one 32x32 MFMA tile)
@@ -91,13 +93,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // rows allocated for a [rows, DS] feature matrix: whole 32-row tiles plus one guard tile so that the
 // 1-KiB LDS-DMA pieces of the last tile stay in bounds.
 inline int feat_rows(int rows) { return round_up(rows, KT) + KT; }
+inline int feat_rows_h(int rows) { return round_up(rows, SKEYS) + SKEYS; }   // bf16 copies (64-row steps)
 
 // ---- stage launchers (defined in the .hip files) ------------------------------------------------
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
-                   const float* wp_q, const float* bias_q, float* feat_q);
+                   const float* wp_q, const float* bias_q, float* feat_q,
+                   uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr);
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
                             const float* thr, float* mt);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
@@ -126,6 +130,7 @@ struct SelectArgs {
     // top-k candidates
     int32_t* cand_idx;              // [B, L, splits*2, k]
     float*   cand_val;
+    const int32_t* run_flags;       // optional [B, ceil(L/128)]: only flagged query groups are processed
 };
 int launch_score_select(hipStream_t s, const SelectArgs& a, int pass /*0 fast, 1 fill, 2 topk*/);
 
@@ -141,6 +146,7 @@ struct EdgeArgs {
     int32_t* nb_idx; float* nb_wgt; // fast/top-k: [B,L,width] ; CSR: same offsets as input
     int32_t* nb_cnt;                // [B,L] entries used
     int width;
+    const int32_t* run_flags;       // optional [B, ceil(L/128)] (top-k merge only)
 };
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
 
@@ -155,6 +161,35 @@ struct AggArgs {
 int launch_aggregate_direct(hipStream_t s, const AggArgs& a);
 int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const int32_t* nb_cnt, const int64_t* row_off,
                      int width, int32_t* deg, float* rowsum);
+
+// bf16 screen + exact refine (screen.hip)
+struct ScreenArgs {
+    int B, L, N, mode;
+    const uint16_t* wqh; const uint16_t* xh;        // bf16 features [B, rows_*h, DSH]
+    int rows_qh, rows_xh;
+    int splits, steps_per_split, n_steps, sample;
+    float* gmax;                    // pass 0 out: [B, L, splits*2, 16] group maxima of S~
+    const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
+    const float* mt; const float* bs;               // pass 1 in (adaptive modes)
+    int capseg;
+    int32_t* cand_idx;              // pass 1 out: [B, L, splits*2, capseg]
+    int32_t* seg_cnt;               // pass 1 out: [B, L, splits*2]
+    const int32_t* run_flags;
+};
+int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta);
+
+struct RefineArgs {
+    int B, L, N, mode, k, splits, capseg, width;
+    const float* wq; const float* x; int rows_q, rows_x;     // fp32 features
+    const float* mt; const float* bs;
+    const int32_t* cand_idx; const int32_t* seg_cnt;
+    int32_t* nb_idx; float* nb_wgt; int32_t* nb_cnt;
+    int32_t* redo_flags;            // [B, n_qgroups_exact]: query groups (of 128) the exact kernel must redo
+    int n_qgroups_exact;
+    int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
+};
+int launch_refine(hipStream_t s, const RefineArgs& a);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);

@@ -50,7 +50,9 @@ struct ProjArgs {
     const float* wp[2];          // packed weights: [0] keys (fc2), [1] queries (fc1)
     const float* bias[2];
     float* feat[2];              // outputs [B, rows_alloc, DS]
+    uint16_t* feat_h[2];         // optional bf16 copies [B, rows_alloc_h, DSH] (round to nearest even)
     int rows_alloc[2];
+    int rows_alloc_h[2];
     int n_items[2];              // 16-patch work items per image
     int segs[2];                 // work items per grid row
     int n_blocks_q;              // blocks [0, n_blocks_q) project queries, the rest keys
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
     // epilogue: D[row = 4g + r][col = n*16 + i]; bias + ReLU; zero columns 196..203
     const int grid_row_base = gy * row_len + gx0;          // linear patch index of row 0 of this wave
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
+    uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which];
     float csum[PJ_NT];
 #pragma unroll
@@ -157,6 +160,11 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
             if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
+            if (ok && hb != nullptr) {
+                unsigned u = __float_as_uint(v);
+                u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;            // fp32 -> bf16, round to nearest even
+                hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
+            }
             s += ok ? v : 0.f;
         }
         csum[n] = s;
@@ -177,8 +185,10 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
 // which: bit 0 = keys, bit 1 = queries
 int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* map, const float* wp_keys,
                    const float* bias_keys, float* feat_keys, double* colsum, const float* wp_q,
-                   const float* bias_q, float* feat_q) {
+                   const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16) {
     ProjArgs pa;
+    pa.feat_h[0] = feat_keys_bf16; pa.feat_h[1] = feat_q_bf16;
+    pa.rows_alloc_h[0] = feat_rows_h(g.N); pa.rows_alloc_h[1] = feat_rows_h(g.L);
     pa.gr = g; pa.map = map;
     pa.wp[0] = wp_keys; pa.bias[0] = bias_keys; pa.feat[0] = feat_keys;
     pa.wp[1] = wp_q; pa.bias[1] = bias_q; pa.feat[1] = feat_q;

@@ -1,0 +1,373 @@
+// bf16 screening of the similarity search + exact refinement of the survivors.
+//
+// The score matrix S = Wq . X^T (DN_Gray/model/dagl.py:250) is only ever *used* at the few keys a query
+// keeps (dagl.py:256-261); everything else is compared against a threshold and dropped.  So the O(L*N*D)
+// search runs on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) and only decides
+// which keys MIGHT be kept; the kept scores themselves are then recomputed from the fp32 features with
+// fp64 accumulation (more accurate than an fp32 GEMM) by the refine kernels.  The screen is conservative, not
+// approximate:
+//   all features are >= 0 (post-ReLU), so with q~ = bf16(q), x~ = bf16(x) (round to nearest even, relative
+//   error <= 2^-9 each) every product and therefore the whole sum satisfies
+//        S~ = sum q~ x~  in  [S (1-d), S (1+d)],   d = 2^-8 + 2^-18 + accumulation slack  <  DELTA = 0.004
+//   - adaptive mask:  a key with relu(S - mean*thr + bias) != 0 has S~ (1+DELTA) - mean*thr + bias > 0;
+//   - top-k: split the keys into >= k disjoint groups; the k-th largest group maximum of S~, theta, is
+//     attained by k distinct keys whose true S >= theta/(1+DELTA), hence tau_k(S) >= theta/(1+DELTA) and
+//     every true top-k key has S~ >= theta (1-DELTA)/(1+DELTA).
+// Keys passing these tests are the candidates; a (query, chunk, half) segment that receives more than its
+// slot count raises a flag and that query group is redone by the exact fp32 kernel (select.hip).
+#include "dagl_common.h"
+
+namespace dagl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SCR_WAVES = 8;                     // query tiles (of 32) per block
+constexpr int SK = 64;                           // keys per streaming step (two 32-row MFMA tiles)
+constexpr int STEP_ELEMS = SK * DSH;             // 13824 bf16 = 27648 B = 27 DMA pieces of 1 KiB exactly
+constexpr int STEP_PIECES = 27;
+constexpr int KB = 13;                           // MFMAs (K=16 each) per 32x32 tile: 208 = 196 + 12 zeros
+constexpr float DELTA = 0.004f;
+
+__device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// PASS 0: group maxima over every `sample`-th step (top-k threshold estimation)
+// PASS 1: candidate filter over every step
+template <int PASS>
+__global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[2][STEP_ELEMS];        // 54 KiB
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+
+    const int logical = xcd_remap2(blockIdx.x, gridDim.x);
+    const int split = logical / n_qgroups;
+    const int qg = logical % n_qgroups;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.n_steps) step1 = a.n_steps;
+    const int stride = (PASS == 0) ? a.sample : 1;
+
+    const int q = (qg * SCR_WAVES + wave) * QT + i;
+    const bool qvalid = q < a.L;
+    const int qc = qvalid ? q : a.L - 1;
+    const size_t qlin = (size_t)b * a.L + qc;
+
+    // query fragments: 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
+    bf16x8 qf[KB];
+    {
+        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
+#pragma unroll
+        for (int t = 0; t < KB; ++t)
+            qf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+#pragma unroll
+        for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[t]));
+    }
+
+    float thq = 0.f, mtq = 0.f, bsq = 0.f;
+    if (PASS == 1) {
+        if (a.mode == DAGL_MODE_TOPK) thq = a.theta[qlin];
+        else { mtq = a.mt[qlin]; bsq = a.bs[qlin]; }
+    }
+    const bool adaptive = (a.mode != DAGL_MODE_TOPK);
+
+    float gm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gm[r] = -1.0f;
+    int n_loc = 0;
+    const size_t seg = (qlin * a.splits + split) * 2 + h;
+
+    const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
+    if (step0 < step1) {
+        for (int p = wave; p < STEP_PIECES; p += SCR_WAVES)
+            glds16_asm(reinterpret_cast<const float*>(xb + (size_t)step0 * STEP_ELEMS + p * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
+    }
+    dma_wait_all();
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = step0; step < step1; step += stride) {
+        if (step + stride < step1) {
+            const unsigned dst = lds0 + (cur ^ 1) * (STEP_ELEMS * 2);
+            for (int p = wave; p < STEP_PIECES; p += SCR_WAVES)
+                glds16_asm(reinterpret_cast<const float*>(xb + (size_t)(step + stride) * STEP_ELEMS + p * 512 + lane * 8),
+                           __builtin_amdgcn_readfirstlane(dst + p * 1024));
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const unsigned short* kp = &sK[cur][(rt * 32 + i) * DSH + 8 * h];
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp + 16 * t));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], acc, 0, 0, 0);
+            }
+            const int kbase = step * SK + rt * 32 + 4 * h;
+            if (PASS == 0) {
+                // keys past N are zero rows (S~ = 0): harmless for a lower bound
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] = fmaxf(gm[r], acc[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s = acc[r];
+                    const int key = kbase + (r & 3) + 8 * (r >> 2);
+                    bool cand;
+                    if (adaptive) {
+                        const float su = s * (1.0f + DELTA);
+                        const float m = (su - mtq) + bsq;
+                        cand = m > -1e-5f * (fabsf(mtq) + fabsf(bsq) + su);
+                    } else {
+                        cand = s >= thq;
+                    }
+                    cand = cand && qvalid && (key < a.N);
+                    if (cand) {
+                        if (n_loc < a.capseg) a.cand_idx[seg * a.capseg + n_loc] = key;
+                        ++n_loc;
+                    }
+                }
+            }
+        }
+        dma_wait_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (PASS == 0) {
+        if (qvalid) {
+            float4* o = reinterpret_cast<float4*>(a.gmax + seg * 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = make_float4(gm[4 * u], gm[4 * u + 1], gm[4 * u + 2], gm[4 * u + 3]);
+        }
+    } else {
+        if (qvalid) a.seg_cnt[seg] = n_loc;
+    }
+}
+
+int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
+    const int n_qgroups = (a.L + SCR_WAVES * QT - 1) / (SCR_WAVES * QT);
+    dim3 grid(n_qgroups * a.splits, a.B), block(512);
+    if (pass == 0) hipLaunchKernelGGL(screen_kernel<0>, grid, block, 0, s, a, n_qgroups);
+    else hipLaunchKernelGGL(screen_kernel<1>, grid, block, 0, s, a, n_qgroups);
+    DAGL_LAUNCH_CHECK("screen_kernel");
+    return DAGL_OK;
+}
+
+// ---- theta: k-th largest group maximum per query (one wave per query) ---------------------------------------
+constexpr int THETA_MAX_G = 2048;
+__global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, int k, const float* __restrict__ gmax,
+                                                           float* __restrict__ theta) {
+    __shared__ float v[4][THETA_MAX_G];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t row = (size_t)blockIdx.x * 4 + w;
+    const bool active = row < (size_t)n_rows;
+    if (active)
+        for (int t = lane; t < G; t += 64) v[w][t] = gmax[row * G + t];
+    __syncthreads();
+    if (!active) return;
+    float kth = -1.0f;
+    for (int r = 0; r < k; ++r) {
+        float bv = -2.f; int bp = -1;
+        for (int t = lane; t < G; t += 64) {
+            const float x = v[w][t];
+            if (x > bv) { bv = x; bp = t; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int op = __shfl_xor(bp, o);
+            if (ov > bv || (ov == bv && op >= 0 && (bp < 0 || op < bp))) { bv = ov; bp = op; }
+        }
+        kth = bv;
+        if (bp < 0 || bv < 0.f) { kth = -1.0f; break; }
+        if (lane == 0) v[w][bp] = -3.0f;
+        __threadfence_block();
+    }
+    // fewer than k non-empty groups -> no usable bound: pass everything (theta = 0)
+    if (lane == 0) theta[row] = (kth > 0.f) ? kth * ((1.0f - DELTA) / (1.0f + DELTA)) : 0.0f;
+}
+
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta) {
+    if (G > THETA_MAX_G) { set_error("screen_theta: %d groups exceed %d", G, THETA_MAX_G); return DAGL_ERR_INVALID; }
+    hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta);
+    DAGL_LAUNCH_CHECK("screen_theta_kernel");
+    return DAGL_OK;
+}
+
+// ---- refine: exact scores of the candidates, final selection, edge softmax ---------------------------------------
+// One wave per query.  Candidates are gathered segment by segment (deterministic order: chunk, half, ascending
+// key), their scores recomputed from the fp32 feature rows with fp64 accumulation, then
+//   top-k modes : the k best (score desc, key asc)             (GReccR2b_3mh_1-checkpoint.py:242-246)
+//   adaptive    : those with (S - mean*thr) + bias > 0          (dagl.py:256-257)
+// and the softmax weights of dagl.py:259-261 are formed exactly as in aggregate.hip.
+constexpr int RF_MAX_CAND = 1024;
+
+__device__ __forceinline__ float rf_logit(float s, float mtq, float bsq, bool adaptive) {
+    float m = 1.0f;
+    if (adaptive) m = (s - mtq) + bsq;
+    return __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE);
+}
+
+__global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
+    __shared__ int c_idx[4][RF_MAX_CAND];
+    __shared__ float c_val[4][RF_MAX_CAND];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t ql = (size_t)blockIdx.x * 4 + w;
+    if (ql >= (size_t)a.B * a.L) return;                   // no block-level sync below
+    const int b = (int)(ql / a.L);
+    const int S2 = a.splits * 2;
+    bool overflow = false;
+
+    // 1. gather candidate indices
+    int total = 0;
+    for (int s0 = 0; s0 < S2; s0 += 64) {
+        const int sgi = s0 + lane;
+        int cnt = (sgi < S2) ? a.seg_cnt[ql * S2 + sgi] : 0;
+        if (cnt > a.capseg) { overflow = true; cnt = a.capseg; }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int off = total + incl - cnt;
+        for (int e = 0; e < cnt; ++e) {
+            if (off + e < RF_MAX_CAND) c_idx[w][off + e] = a.cand_idx[(ql * S2 + sgi) * a.capseg + e];
+            else overflow = true;
+        }
+        total += __shfl(incl, 63);
+    }
+    overflow = __any(overflow);
+    if (total > RF_MAX_CAND) total = RF_MAX_CAND;
+    __threadfence_block();
+
+    // 2. exact scores: 4 groups of 16 lanes, one candidate per group per round
+    const int grp = lane >> 4, gl = lane & 15;
+    const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.L)) * DS;
+    float4 qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c4 = gl + 16 * u;
+        qv[u] = (c4 < D / 4) ? *reinterpret_cast<const float4*>(qrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* xb = a.x + (size_t)b * a.rows_x * DS;
+    for (int c0 = 0; c0 < total; c0 += 4) {
+        const int c = c0 + grp;
+        const bool okc = c < total;
+        const int key = okc ? c_idx[w][c] : 0;
+        const float* xrow = xb + (size_t)key * DS;
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c4 = gl + 16 * u;
+            if (c4 < D / 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xrow + 4 * c4);
+                acc += (double)qv[u].x * (double)xv.x + (double)qv[u].y * (double)xv.y +
+                       (double)qv[u].z * (double)xv.z + (double)qv[u].w * (double)xv.w;
+            }
+        }
+        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        if (okc && gl == 0) c_val[w][c] = (float)acc;
+    }
+    __threadfence_block();
+
+    const bool adaptive = (a.mode != DAGL_MODE_TOPK);
+    const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
+    int n = 0;
+    float my_s = 0.f; int my_key = -1;
+
+    if (a.mode == DAGL_MODE_ADAPTIVE) {
+        // keep order, drop candidates failing the exact test; lane j keeps the j-th survivor (<= width)
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int c = c0 + lane;
+            float s = 0.f; int key = -1; bool pass = false;
+            if (c < total) {
+                s = c_val[w][c]; key = c_idx[w][c];
+                pass = ((s - mtq) + bsq) > 0.f;
+            }
+            const unsigned long long bal = __ballot(pass);
+            const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+            // hand survivor #pos to lane pos (pos < 64): via LDS slot reuse
+            if (pass) {
+                if (pos < a.width) { c_val[w][pos] = s; c_idx[w][pos] = key; }   // pos <= c: in-place compaction is safe
+                else overflow = true;
+            }
+            n += __popcll(bal);
+            __threadfence_block();
+        }
+        overflow = __any(overflow);
+        if (n > a.width) n = a.width;
+        if (lane < n) { my_s = c_val[w][lane]; my_key = c_idx[w][lane]; }
+    } else {
+        // top-k (adaptive_topk: among the candidates passing the exact adaptive test)
+        if (a.mode == DAGL_MODE_ADAPTIVE_TOPK) {
+            for (int c = lane; c < total; c += 64)
+                if (!(((c_val[w][c] - mtq) + bsq) > 0.f)) c_idx[w][c] = -1;
+            __threadfence_block();
+        }
+        for (int r = 0; r < a.k; ++r) {
+            float bv = -2.f; int bi = 0x7fffffff, bpos = -1;
+            for (int t = lane; t < total; t += 64) {
+                const float v = c_val[w][t]; const int id = c_idx[w][t];
+                if (id >= 0 && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; bpos = t; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o); const int op = __shfl_xor(bpos, o);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
+            }
+            if (bpos < 0) break;
+            if (lane == r) { my_s = bv; my_key = bi; }
+            if (lane == 0) c_idx[w][bpos] = -1;
+            __threadfence_block();
+            ++n;
+        }
+    }
+
+    // 3. edge softmax over the kept neighbours (non-neighbours contribute exp(0) each to the denominator)
+    const bool valid = lane < n;
+    const float lg = valid ? rf_logit(my_s, mtq, bsq, adaptive) : 0.f;
+    double M = valid ? (double)lg : -1e300;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
+    if (n < a.N) M = fmax(M, 0.0);
+    const double e = valid ? exp((double)lg - M) : 0.0;
+    double sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum += (double)(a.N - n) * exp(-M);
+    if (valid) {
+        a.nb_idx[ql * a.width + lane] = my_key;
+        a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+    }
+    if (lane == 0) {
+        a.nb_cnt[ql] = n;
+        if (overflow) {
+            const size_t qg = (size_t)b * a.n_qgroups_exact + (size_t)(ql - (size_t)b * a.L) / 128;
+            a.redo_flags[qg] = 1;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[2]), 1ull);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[0]), (unsigned long long)n);
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.stats[1]), (unsigned long long)n);
+    }
+}
+
+int launch_refine(hipStream_t s, const RefineArgs& a) {
+    if (a.splits * 2 * a.capseg > RF_MAX_CAND && a.splits * 2 > RF_MAX_CAND) {
+        set_error("refine: too many segments"); return DAGL_ERR_INVALID;
+    }
+    const size_t nq = (size_t)a.B * a.L;
+    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("refine_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

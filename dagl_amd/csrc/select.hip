@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / n_qgroups;
     const int qg = logical % n_qgroups;
+    if (a.run_flags != nullptr && a.run_flags[b * n_qgroups + qg] == 0) return;     // block-uniform
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > n_tiles) tile1 = n_tiles;

@@ -163,7 +163,7 @@ class Workspace:
 
 def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
                workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False,
-               profile: "StageProfile | None" = None):
+               profile: "StageProfile | None" = None, exact_scan: bool = False):
     """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W]."""
     lib = _lib.load()
     if mode not in MODES:
@@ -181,7 +181,8 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
         if thr.numel() != B * Lh * Lw or bias.numel() != B * Lh * Lw:
             raise DaglError("ce_forward: thr/bias must hold B*L values")
     ws = workspace if workspace is not None else Workspace()
-    need = lib.dagl_ce_workspace_bytes(B, H, W, MODES[mode], int(k))
+    mode_flags = MODES[mode] | (_lib.FLAG_EXACT_SCAN if exact_scan else 0)
+    need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
     if need == 0:
         check(-1, "dagl_ce_workspace_bytes")
     out = torch.empty(B, 16, H, W, device=b1.device, dtype=torch.float32)
@@ -201,7 +202,7 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
                 thr.data_ptr() if thr is not None else None,
                 bias.data_ptr() if bias is not None else None,
                 fc1_w.data_ptr(), fc1_b.data_ptr(), fc2_w.data_ptr(), fc2_b.data_ptr(),
-                MODES[mode], int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base), C.byref(info))
+                mode_flags, int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base), C.byref(info))
         if profile is not None:
             rc = lib.dagl_ce_forward_profiled(*args, profile._h)
         elif dbg is None:

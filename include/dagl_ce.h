@@ -52,6 +52,10 @@ extern "C" {
 #define DAGL_MODE_TOPK           1    /* fixed-k variant (GReccR2b_3mh_1-checkpoint.py:242-250)      */
 #define DAGL_MODE_ADAPTIVE_TOPK  2    /* adaptive mask intersected with the k best scores            */
 
+/* OR-ed into `mode`: scan all L*N scores on the fp32 matrix cores instead of screening them in bf16 and
+ * refining the survivors (both give the same neighbours)                             */
+#define DAGL_FLAG_EXACT_SCAN     0x100
+
 #define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
 #define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path            */
 
@@ -66,8 +70,8 @@ typedef struct dagl_ce_info {
     int64_t required_bytes;   /* workspace this call needed (valid on OK and on ERR_WORKSPACE)      */
     int64_t total_edges;      /* sum of degrees over all queries of the batch                       */
     int32_t max_degree;       /* largest per-query degree                                           */
-    int32_t path;             /* 0 = single-pass lists, 1 = two-pass CSR (some degree > FAST_CAP),
-                                 2 = per-lane top-k lists                                           */
+    int32_t path;             /* 0 = fp32 scan, single-pass lists, 1 = fp32 scan, two-pass CSR (some degree >
+                                 FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine */
 } dagl_ce_info;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -115,12 +119,12 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W,
  * dagl_profile_read waits for the recorded events afterwards).  Stage order:                     */
 #define DAGL_N_STAGES        8
 #define DAGL_STAGE_LAYOUT    0   /* pad/NHWC maps + fc weight pack                                  */
-#define DAGL_STAGE_PROJ_KEYS 1   /* fc2 projection of the N key patches (+ column sums) and fc1
+#define DAGL_STAGE_PROJECT   1   /* fc2 projection of the N key patches (+ column sums) and fc1
                                     projection of the L query patches: one launch                  */
-#define DAGL_STAGE_PROJ_QRY  2   /* (empty: merged into stage 1)                                    */
-#define DAGL_STAGE_THRESH    3   /* per-query adaptive thresholds                                   */
-#define DAGL_STAGE_SELECT    4   /* streamed similarity + neighbour selection (the dominant kernel) */
-#define DAGL_STAGE_EDGE      5   /* degree scan / candidate merge + edge softmax                    */
+#define DAGL_STAGE_THRESH    2   /* per-query adaptive thresholds                                   */
+#define DAGL_STAGE_SAMPLE    3   /* top-k screen: sampled group maxima -> per-query threshold       */
+#define DAGL_STAGE_SELECT    4   /* the full L*N scan: bf16 screen filter, or the fp32 select       */
+#define DAGL_STAGE_EDGE      5   /* refine / candidate merge / degree scan + edge softmax           */
 #define DAGL_STAGE_GATHER    6   /* neighbour gather + weighted sum                                 */
 #define DAGL_STAGE_FOLD      7   /* fold + overlap normalisation                                    */
 typedef struct dagl_profile dagl_profile;

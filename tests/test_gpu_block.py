@@ -21,11 +21,12 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _module(params, mode="adaptive", k=0):
+def _module(params, mode="adaptive", k=0, scan="screened"):
     from dagl_amd.ce import CE
     ce = CE(in_channels=64)
     ce.load_state_dict(params, strict=True)
     ce.select_mode = mode
+    ce.scan = scan
     if k:
         ce.select_k = k
     return ce.to(_dev()).eval()
@@ -38,15 +39,16 @@ def _run_debug(ce, x):
         b1, b2, thr, bias = ce._prologue(x)
         out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
                                    ce.fc1[0].weight, ce.fc1[0].bias, ce.fc2[0].weight, ce.fc2[0].bias,
-                                   mode=ce.select_mode, k=ce.select_k, debug=True)
+                                   mode=ce.select_mode, k=ce.select_k, debug=True, exact_scan=(ce.scan == "exact"))
     return out, info
 
 
+@pytest.mark.parametrize("scan", ["screened", "exact"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_block_matches_reference_golden(path):
+def test_block_matches_reference_golden(path, scan):
     meta, g = load_golden(path)
     x, params = case_inputs(meta)
-    ce = _module(params, meta["mode"], meta["k"])
+    ce = _module(params, meta["mode"], meta["k"], scan)
     out, info = _run_debug(ce, x.to(_dev()))
     out = out.cpu().numpy()
     assert out.shape == g["out"].shape
@@ -62,7 +64,9 @@ def test_block_matches_reference_golden(path):
     assert normwise(agg[:, ::meta["agg_step"]].numpy(), g["agg_sub"]) <= TOL_OUT
     if meta["mode"] == "adaptive":
         assert info["total_edges"] == int(g["deg"].sum()) or ndiff > 0
-        assert info["path"] == (1 if g["deg"].max() > 64 else 0)
+        dense = g["deg"].max() > 64
+        screened = scan == "screened" and meta["H"] * meta["W"] >= 2048
+        assert info["path"] == (1 if dense else (3 if screened else 0))
 
 
 @pytest.mark.parametrize("name", ["gray_sparse_64x64", "gray_default_b2_23x30", "topk8_b2_45x38"])
@@ -79,6 +83,39 @@ def test_block_vs_fp64_oracle(name):
     e_hip, e_ref = normwise(out, ref64), normwise(g["out"], ref64)
     assert e_hip <= TOL_OUT
     assert e_hip <= 3 * e_ref + 1e-5, (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("mode,k,variant", [("topk", 8, "default"), ("topk", 16, "default"), ("adaptive", 0, "sparse"),
+                                            ("adaptive_topk", 4, "sparse")])
+@pytest.mark.parametrize("H,W", [(96, 80), (128, 128)])
+def test_screened_scan_selects_the_same_neighbours_as_the_fp32_scan(mode, k, variant, H, W):
+    """bf16 screen + refine vs scanning every score in fp32: identical degrees, outputs equal up to the
+    rounding of the kept scores (fp64-accumulated vs fp32 chain)."""
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(51, variant=variant, sparse_gain=1.8).items()}
+    x = torch.from_numpy(make_features(51, 2, 64, H, W)).to(_dev())
+    outs = {}
+    for scan in ("screened", "exact"):
+        ce = _module(params, mode, k, scan)
+        outs[scan] = _run_debug(ce, x)
+    (o_s, i_s), (o_e, i_e) = outs["screened"], outs["exact"]
+    assert i_s["path"] == 3 and i_e["path"] in (0, 2)
+    assert torch.equal(i_s["deg"], i_e["deg"])
+    assert normwise(o_s.cpu().numpy(), o_e.cpu().numpy()) <= 5e-5
+
+
+def test_screen_overflow_is_redone_by_the_fp32_scan():
+    """A constant feature map makes every interior patch identical: all scores tie, every key is a candidate,
+    the screen's slots overflow and the flagged query groups must come out of the fp32 scan unchanged."""
+    from dagl_amd.synth import make_ce_params
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
+    x = torch.full((1, 64, 64, 64), 0.25).to(_dev())
+    res = {}
+    for scan in ("screened", "exact"):
+        ce = _module(params, "topk", 8, scan)
+        res[scan] = _run_debug(ce, x)
+    assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
+    assert torch.equal(res["screened"][0], res["exact"][0])
 
 
 def test_adaptive_topk_mode_matches_oracle():
