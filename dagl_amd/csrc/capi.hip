@@ -130,7 +130,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
-        p.o_gmax = carve(off, BL * p.s_splits * 2 * 16 * sizeof(float));
+        p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int32_t));
         p.o_ssegcnt = carve(off, BL * p.s_splits * 2 * sizeof(int32_t));
@@ -259,7 +259,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         prof_mark(prof, s, 3);
         if (mode == DAGL_MODE_TOPK) {
             if ((rc = launch_screen(s, sc, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 16, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
         }
         prof_mark(prof, s, 4);
         if ((rc = launch_screen(s, sc, 1))) return rc;

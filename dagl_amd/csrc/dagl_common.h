@@ -168,7 +168,7 @@ struct ScreenArgs {
     const uint16_t* wqh; const uint16_t* xh;        // bf16 features [B, rows_*h, DSH]
     int rows_qh, rows_xh;
     int splits, steps_per_split, n_steps, sample;
-    float* gmax;                    // pass 0 out: [B, L, splits*2, 16] group maxima of S~
+    float* gmax;                    // pass 0 out: [B, L, splits*2, 4] largest group maxima of S~ per segment
     const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
     int capseg;

@@ -28,6 +28,7 @@ constexpr int STEP_ELEMS = SK * DSH;             // 13824 bf16 = 27648 B = 27 DM
 constexpr int STEP_PIECES = 27;
 constexpr int KB = 13;                           // MFMAs (K=16 each) per 32x32 tile: 208 = 196 + 12 zeros
 constexpr float DELTA = 0.004f;
+constexpr int GKEEP = 4;                         // group maxima kept per (query, chunk, half) segment
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     const int xcd = bid & 7, slot = bid >> 3;
@@ -146,11 +147,24 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
     }
 
     if (PASS == 0) {
-        if (qvalid) {
-            float4* o = reinterpret_cast<float4*>(a.gmax + seg * 16);
+        // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
+        // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
+        float top[GKEEP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = make_float4(gm[4 * u], gm[4 * u + 1], gm[4 * u + 2], gm[4 * u + 3]);
+        for (int u = 0; u < GKEEP; ++u) {
+            float m = gm[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[r]);
+            top[u] = m;
+            bool taken = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool hit = !taken && (gm[r] == m);
+                gm[r] = hit ? -1.0f : gm[r];
+                taken = taken || hit;
+            }
         }
+        if (qvalid) *reinterpret_cast<float4*>(a.gmax + seg * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
     } else {
         if (qvalid) a.seg_cnt[seg] = n_loc;
     }
@@ -165,41 +179,46 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     return DAGL_OK;
 }
 
-// ---- theta: k-th largest group maximum per query (one wave per query) ---------------------------------------
-constexpr int THETA_MAX_G = 2048;
+// ---- theta: k-th largest group maximum per query (one wave per query, values in registers) -------------------
+constexpr int THETA_PER_LANE = 8;                // G <= 512
 __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, int k, const float* __restrict__ gmax,
                                                            float* __restrict__ theta) {
-    __shared__ float v[4][THETA_MAX_G];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t row = (size_t)blockIdx.x * 4 + w;
-    const bool active = row < (size_t)n_rows;
-    if (active)
-        for (int t = lane; t < G; t += 64) v[w][t] = gmax[row * G + t];
-    __syncthreads();
-    if (!active) return;
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)n_rows) return;
+    float v[THETA_PER_LANE];
+#pragma unroll
+    for (int u = 0; u < THETA_PER_LANE; ++u) {
+        const int t = lane + 64 * u;
+        v[u] = (t < G) ? gmax[row * G + t] : -1.0f;
+    }
     float kth = -1.0f;
     for (int r = 0; r < k; ++r) {
-        float bv = -2.f; int bp = -1;
-        for (int t = lane; t < G; t += 64) {
-            const float x = v[w][t];
-            if (x > bv) { bv = x; bp = t; }
-        }
+        float lm = v[0];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o); const int op = __shfl_xor(bp, o);
-            if (ov > bv || (ov == bv && op >= 0 && (bp < 0 || op < bp))) { bv = ov; bp = op; }
+        for (int u = 1; u < THETA_PER_LANE; ++u) lm = fmaxf(lm, v[u]);
+        float wm = lm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        kth = wm;
+        if (wm < 0.f) break;                                   // fewer than k non-empty groups (wave-uniform)
+        // the first lane holding the maximum drops one copy of it
+        const unsigned long long bal = __ballot(lm == wm);
+        const int owner = __ffsll((long long)bal) - 1;
+        bool taken = false;
+#pragma unroll
+        for (int u = 0; u < THETA_PER_LANE; ++u) {
+            const bool hit = (lane == owner) && !taken && (v[u] == wm);
+            v[u] = hit ? -1.0f : v[u];
+            taken = taken || hit;
         }
-        kth = bv;
-        if (bp < 0 || bv < 0.f) { kth = -1.0f; break; }
-        if (lane == 0) v[w][bp] = -3.0f;
-        __threadfence_block();
     }
     // fewer than k non-empty groups -> no usable bound: pass everything (theta = 0)
     if (lane == 0) theta[row] = (kth > 0.f) ? kth * ((1.0f - DELTA) / (1.0f + DELTA)) : 0.0f;
 }
 
 int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta) {
-    if (G > THETA_MAX_G) { set_error("screen_theta: %d groups exceed %d", G, THETA_MAX_G); return DAGL_ERR_INVALID; }
+    if (G > 64 * THETA_PER_LANE) { set_error("screen_theta: %d groups exceed %d", G, 64 * THETA_PER_LANE); return DAGL_ERR_INVALID; }
     hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta);
     DAGL_LAUNCH_CHECK("screen_theta_kernel");
     return DAGL_OK;
@@ -219,6 +238,11 @@ __device__ __forceinline__ float rf_logit(float s, float mtq, float bsq, bool ad
     return __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE);
 }
 
+// (value desc, key asc) ordering used everywhere a "k best" is taken
+__device__ __forceinline__ bool rf_before(float va, int ka, float vb, int kb) {
+    return (va > vb) || (va == vb && ka < kb);
+}
+
 __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     __shared__ int c_idx[4][RF_MAX_CAND];
     __shared__ float c_val[4][RF_MAX_CAND];
@@ -229,52 +253,61 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     const int S2 = a.splits * 2;
     bool overflow = false;
 
-    // 1. gather candidate indices
+    // 1. gather candidate indices: lane <-> segment; the first four slots of a segment are fetched together with
+    //    its count (one memory round trip), longer segments are rare and finished in a loop
     int total = 0;
     for (int s0 = 0; s0 < S2; s0 += 64) {
         const int sgi = s0 + lane;
-        int cnt = (sgi < S2) ? a.seg_cnt[ql * S2 + sgi] : 0;
+        const bool sv = sgi < S2;
+        const size_t sg = ql * S2 + (sv ? sgi : 0);
+        int cnt = sv ? a.seg_cnt[sg] : 0;
+        const int4 f4 = *reinterpret_cast<const int4*>(a.cand_idx + sg * a.capseg);
         if (cnt > a.capseg) { overflow = true; cnt = a.capseg; }
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int off = total + incl - cnt;
-        for (int e = 0; e < cnt; ++e) {
-            if (off + e < RF_MAX_CAND) c_idx[w][off + e] = a.cand_idx[(ql * S2 + sgi) * a.capseg + e];
-            else overflow = true;
-        }
+        if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
+        if (cnt > 0) c_idx[w][off] = f4.x;
+        if (cnt > 1) c_idx[w][off + 1] = f4.y;
+        if (cnt > 2) c_idx[w][off + 2] = f4.z;
+        if (cnt > 3) c_idx[w][off + 3] = f4.w;
+        for (int e = 4; e < cnt; ++e) c_idx[w][off + e] = a.cand_idx[sg * a.capseg + e];
         total += __shfl(incl, 63);
     }
     overflow = __any(overflow);
     if (total > RF_MAX_CAND) total = RF_MAX_CAND;
     __threadfence_block();
 
-    // 2. exact scores: 4 groups of 16 lanes, one candidate per group per round
-    const int grp = lane >> 4, gl = lane & 15;
+    // 2. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation
+    const int grp = lane >> 3, gl = lane & 7;
     const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.L)) * DS;
-    float4 qv[4];
+    float4 qv[7];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int c4 = gl + 16 * u;
+    for (int u = 0; u < 7; ++u) {
+        const int c4 = gl + 8 * u;
         qv[u] = (c4 < D / 4) ? *reinterpret_cast<const float4*>(qrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float* xb = a.x + (size_t)b * a.rows_x * DS;
-    for (int c0 = 0; c0 < total; c0 += 4) {
+#pragma unroll 2
+    for (int c0 = 0; c0 < total; c0 += 8) {
         const int c = c0 + grp;
         const bool okc = c < total;
         const int key = okc ? c_idx[w][c] : 0;
         const float* xrow = xb + (size_t)key * DS;
+        float4 xv[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int c4 = gl + 8 * u;                       // c4 <= 55: inside the 51-float4 row stride + next row
+            xv[u] = *reinterpret_cast<const float4*>(xrow + 4 * (c4 < D / 4 ? c4 : 0));
+        }
         double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c4 = gl + 16 * u;
-            if (c4 < D / 4) {
-                const float4 xv = *reinterpret_cast<const float4*>(xrow + 4 * c4);
-                acc += (double)qv[u].x * (double)xv.x + (double)qv[u].y * (double)xv.y +
-                       (double)qv[u].z * (double)xv.z + (double)qv[u].w * (double)xv.w;
-            }
+        for (int u = 0; u < 7; ++u) {
+            acc += (double)qv[u].x * (double)xv[u].x + (double)qv[u].y * (double)xv[u].y +
+                   (double)qv[u].z * (double)xv[u].z + (double)qv[u].w * (double)xv[u].w;
         }
-        acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
         if (okc && gl == 0) c_val[w][c] = (float)acc;
     }
     __threadfence_block();
@@ -295,7 +328,6 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             }
             const unsigned long long bal = __ballot(pass);
             const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
-            // hand survivor #pos to lane pos (pos < 64): via LDS slot reuse
             if (pass) {
                 if (pos < a.width) { c_val[w][pos] = s; c_idx[w][pos] = key; }   // pos <= c: in-place compaction is safe
                 else overflow = true;
@@ -306,8 +338,29 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         overflow = __any(overflow);
         if (n > a.width) n = a.width;
         if (lane < n) { my_s = c_val[w][lane]; my_key = c_idx[w][lane]; }
+    } else if (total <= 64) {
+        // top-k of <= 64 candidates: bitonic sort in registers, (value desc, key asc)
+        float v = -3.0f; int key = 0x7fffffff;
+        if (lane < total) {
+            v = c_val[w][lane]; key = c_idx[w][lane];
+            if (a.mode == DAGL_MODE_ADAPTIVE_TOPK && !(((v - mtq) + bsq) > 0.f)) { v = -3.0f; key = 0x7fffffff; }
+        }
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const float ov = __shfl_xor(v, j); const int ok = __shfl_xor(key, j);
+                const bool first = ((lane & k2) == 0);            // this k2-block sorts "best first"
+                const bool lower = ((lane & j) == 0);
+                const bool other_better = rf_before(ov, ok, v, key);
+                const bool take = (lower == first) ? other_better : (!other_better && (ov != v || ok != key));
+                if (take) { v = ov; key = ok; }
+            }
+        }
+        const unsigned long long valid_mask = __ballot(v > -2.0f);
+        n = min(a.k, (int)__popcll(valid_mask));
+        if (lane < n) { my_s = v; my_key = key; }
     } else {
-        // top-k (adaptive_topk: among the candidates passing the exact adaptive test)
         if (a.mode == DAGL_MODE_ADAPTIVE_TOPK) {
             for (int c = lane; c < total; c += 64)
                 if (!(((c_val[w][c] - mtq) + bsq) > 0.f)) c_idx[w][c] = -1;
@@ -355,8 +408,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             a.redo_flags[qg] = 1;
             atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[2]), 1ull);
         }
-        atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[0]), (unsigned long long)n);
-        atomicMax(reinterpret_cast<unsigned long long*>(&a.stats[1]), (unsigned long long)n);
+        if (a.mode == DAGL_MODE_ADAPTIVE) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[0]), (unsigned long long)n);
+            atomicMax(reinterpret_cast<unsigned long long*>(&a.stats[1]), (unsigned long long)n);
+        }
     }
 }
 

@@ -92,7 +92,7 @@ def test_screened_scan_selects_the_same_neighbours_as_the_fp32_scan(mode, k, var
     """bf16 screen + refine vs scanning every score in fp32: identical degrees, outputs equal up to the
     rounding of the kept scores (fp64-accumulated vs fp32 chain)."""
     from dagl_amd.synth import make_ce_params, make_features
-    params = {n: torch.from_numpy(a) for n, a in make_ce_params(51, variant=variant, sparse_gain=1.8).items()}
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(51, variant=variant, sparse_gain=2.6).items()}
     x = torch.from_numpy(make_features(51, 2, 64, H, W)).to(_dev())
     outs = {}
     for scan in ("screened", "exact"):
