@@ -38,7 +38,9 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
 }
 
 // PASS 0: group maxima over every `sample`-th step (top-k threshold estimation)
-// PASS 1: candidate filter over every step
+// PASS 1: candidate filter over every step: key is a candidate of query q iff S~ >= theta[q]
+//         (theta carries the whole conservative test of either mode; +inf for padding queries).
+// Keys past N are zero rows (S~ = 0): they can only pass a degenerate theta <= 0 and are dropped by refine.
 template <int PASS>
 __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][STEP_ELEMS];        // 54 KiB
@@ -73,18 +75,15 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
         for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[t]));
     }
 
-    float thq = 0.f, mtq = 0.f, bsq = 0.f;
-    if (PASS == 1) {
-        if (a.mode == DAGL_MODE_TOPK) thq = a.theta[qlin];
-        else { mtq = a.mt[qlin]; bsq = a.bs[qlin]; }
-    }
-    const bool adaptive = (a.mode != DAGL_MODE_TOPK);
+    float thq = 0.f;
+    if (PASS == 1) thq = qvalid ? a.theta[qlin] : __builtin_inff();
 
     float gm[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) gm[r] = -1.0f;
     int n_loc = 0;
     const size_t seg = (qlin * a.splits + split) * 2 + h;
+    int32_t* cseg = a.cand_idx + seg * a.capseg;
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
@@ -104,40 +103,44 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
                 glds16_asm(reinterpret_cast<const float*>(xb + (size_t)(step + stride) * STEP_ELEMS + p * 512 + lane * 8),
                            __builtin_amdgcn_readfirstlane(dst + p * 1024));
         }
+        // two 32-key row tiles, MFMA chains interleaved so that no instruction waits on its predecessor
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            f32x16 acc;
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const unsigned short* kp0 = &sK[cur][i * DSH + 8 * h];
+        const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const unsigned short* kp = &sK[cur][(rt * 32 + i) * DSH + 8 * h];
+        for (int t = 0; t < KB; ++t) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], acc1, 0, 0, 0);
+        }
+        if (PASS == 0) {
 #pragma unroll
-            for (int t = 0; t < KB; ++t) {
-                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp + 16 * t));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], acc, 0, 0, 0);
-            }
-            const int kbase = step * SK + rt * 32 + 4 * h;
-            if (PASS == 0) {
-                // keys past N are zero rows (S~ = 0): harmless for a lower bound
+            for (int r = 0; r < 16; ++r) gm[r] = fmaxf(fmaxf(gm[r], acc0[r]), acc1[r]);
+        } else {
+            // common case (no candidate in the whole wave): 16 v_max3 + one compare + one branch
+            float mx = acc0[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gm[r] = fmaxf(gm[r], acc[r]);
-            } else {
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc0[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc1[r]);
+            if (__any(mx >= thq)) {
+                unsigned mask = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float s = acc[r];
-                    const int key = kbase + (r & 3) + 8 * (r >> 2);
-                    bool cand;
-                    if (adaptive) {
-                        const float su = s * (1.0f + DELTA);
-                        const float m = (su - mtq) + bsq;
-                        cand = m > -1e-5f * (fabsf(mtq) + fabsf(bsq) + su);
-                    } else {
-                        cand = s >= thq;
-                    }
-                    cand = cand && qvalid && (key < a.N);
-                    if (cand) {
-                        if (n_loc < a.capseg) a.cand_idx[seg * a.capseg + n_loc] = key;
-                        ++n_loc;
-                    }
+                    mask |= (acc0[r] >= thq ? 1u : 0u) << r;
+                    mask |= (acc1[r] >= thq ? 1u : 0u) << (16 + r);
+                }
+                const int kbase = step * SK + 4 * h;
+                while (mask) {
+                    const int bit = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    const int r = bit & 15;
+                    const int key = kbase + (bit >> 4) * 32 + (r & 3) + 8 * (r >> 2);
+                    if (n_loc < a.capseg) cseg[n_loc] = key;
+                    ++n_loc;
                 }
             }
         }
@@ -168,6 +171,25 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
     } else {
         if (qvalid) a.seg_cnt[seg] = n_loc;
     }
+}
+
+// theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32
+// rounding of either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32).
+__global__ void adaptive_theta_kernel(size_t n, const float* __restrict__ mt, const float* __restrict__ bs,
+                                      float* __restrict__ theta) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = (double)mt[i], bb = (double)bs[i];
+    double t = (m - bb) - 1e-5 * (fabs(m) + fabs(bb) + 1.0);
+    t = t / (1.0 + (double)DELTA);
+    t -= 1e-6 * fabs(t);
+    theta[i] = (float)t - 1e-30f;
+}
+
+int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta) {
+    hipLaunchKernelGGL(adaptive_theta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, mt, bs, theta);
+    DAGL_LAUNCH_CHECK("adaptive_theta_kernel");
+    return DAGL_OK;
 }
 
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
@@ -293,7 +315,9 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     for (int c0 = 0; c0 < total; c0 += 8) {
         const int c = c0 + grp;
         const bool okc = c < total;
-        const int key = okc ? c_idx[w][c] : 0;
+        int key = okc ? c_idx[w][c] : 0;
+        const bool inb = key < a.N;                              // zero rows past N may pass a degenerate theta
+        if (!inb) key = 0;
         const float* xrow = xb + (size_t)key * DS;
         float4 xv[7];
 #pragma unroll
@@ -308,7 +332,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
                    (double)qv[u].z * (double)xv[u].z + (double)qv[u].w * (double)xv[u].w;
         }
         acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
-        if (okc && gl == 0) c_val[w][c] = (float)acc;
+        if (okc && gl == 0) {
+            c_val[w][c] = inb ? (float)acc : -4.0f;
+            if (!inb) c_idx[w][c] = -1;                          // never selected
+        }
     }
     __threadfence_block();
 
@@ -324,7 +351,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             float s = 0.f; int key = -1; bool pass = false;
             if (c < total) {
                 s = c_val[w][c]; key = c_idx[w][c];
-                pass = ((s - mtq) + bsq) > 0.f;
+                pass = (key >= 0) && (((s - mtq) + bsq) > 0.f);
             }
             const unsigned long long bal = __ballot(pass);
             const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         float v = -3.0f; int key = 0x7fffffff;
         if (lane < total) {
             v = c_val[w][lane]; key = c_idx[w][lane];
-            if (a.mode == DAGL_MODE_ADAPTIVE_TOPK && !(((v - mtq) + bsq) > 0.f)) { v = -3.0f; key = 0x7fffffff; }
+            if (key < 0 || (a.mode == DAGL_MODE_ADAPTIVE_TOPK && !(((v - mtq) + bsq) > 0.f))) { v = -3.0f; key = 0x7fffffff; }
         }
 #pragma unroll
         for (int k2 = 2; k2 <= 64; k2 <<= 1) {
