@@ -52,6 +52,8 @@ SIGNATURES = {
     "dagl_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), _i]),
     "dagl_ce_forward_profiled": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                       C.POINTER(CeInfo), _vp]),
+    "dagl_ce_forward_fused": (_i, [_vp, _i, _i, _i] + [_vp] * 13 + [_i, _i, _vp, _vp, _sz, C.POINTER(CeInfo), _vp]),
+    "dagl_ce_prologue": (_i, [_vp, _i, _i, _i] + [_vp] * 13),
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
     "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

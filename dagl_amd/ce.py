@@ -7,9 +7,10 @@ shapes (including the registered-but-unused ``W``, dagl.py:192), same
 (dagl.py:74-119) accepts it by class substitution and reference checkpoints load
 unchanged.
 
-Only the four prologue convolutions (dagl.py:208-215) stay stock PyTorch-ROCm
-ops; everything from patch extraction to the batch concat (dagl.py:216-274) runs
-in the HIP library behind ``include/dagl_ce.h``.  There is no eager fallback.
+The whole method -- the four prologue convolutions (dagl.py:208-215) and
+everything from patch extraction to the batch concat (dagl.py:216-274) -- runs
+in the HIP library behind ``include/dagl_ce.h``; torch only owns the parameters,
+the device memory and the stream.  There is no eager fallback.
 """
 from __future__ import annotations
 
@@ -62,7 +63,8 @@ class CE(nn.Module):
         return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
 
     def _prologue(self, b):
-        """The four stock convolutions of dagl.py:208-215 (MIOpen)."""
+        """The four prologue convolutions of dagl.py:208-215 as stock torch ops (MIOpen) -- kept for the
+        stage-level parity tests; forward() computes them inside the HIP library (prologue.hip)."""
         b1 = self.g(b)
         b2 = self.theta(b)
         H, W = b.shape[-2:]
@@ -82,11 +84,9 @@ class CE(nn.Module):
             raise DaglError("CE.forward: fp32 input expected")
         if torch.is_grad_enabled() and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise DaglError("CE.forward: the HIP block has no backward yet; call under torch.no_grad()")
-        b1, b2, thr, bias = self._prologue(b)
-        out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
-                                   self.fc1[0].weight.contiguous(), self.fc1[0].bias.contiguous(),
-                                   self.fc2[0].weight.contiguous(), self.fc2[0].bias.contiguous(),
-                                   mode=self.select_mode, k=self.select_k, workspace=self._ws, return_info=True,
-                                   profile=self.profile, exact_scan=(self.scan == "exact"))
+        params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
+        out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=self.select_k,
+                                         workspace=self._ws, profile=self.profile,
+                                         exact_scan=(self.scan == "exact"))
         self.last_info = info
         return out

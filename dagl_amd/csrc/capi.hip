@@ -43,7 +43,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_ssegcnt, o_redo, o_end;
+        o_ssegcnt, o_redo, o_thr, o_bias, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -126,6 +126,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.o_nbwgt = carve(off, BL * p.width * sizeof(float));
     p.o_nbcnt = carve(off, BL * sizeof(int32_t));
     p.o_agg = carve(off, BL * P * sizeof(float));
+    p.o_thr = carve(off, BL * sizeof(float));
+    p.o_bias = carve(off, BL * sizeof(float));
     p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
@@ -155,18 +157,30 @@ static int check_device() {
     return DAGL_OK;
 }
 
+struct FusedIn {                 // input of the fused-prologue entry point (all device pointers)
+    const float* x;              // [B,64,H,W]
+    const float *g_w, *g_b, *th_w, *th_b, *thr_w, *thr_b, *bias_w, *bias_b;
+};
+
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
                            const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, int mode_flags, int k, float* out, void* ws, size_t ws_bytes,
                            dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg,
-                           Profile* prof = nullptr) {
+                           Profile* prof = nullptr, const FusedIn* fin = nullptr) {
     Plan p;
     int rc = make_plan(B, H, W, mode_flags, k, p);
     if (rc) return rc;
     const int mode = p.mode;
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0; }
-    DAGL_REQUIRE(b1 && b2 && fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
-    if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias, "dagl_ce_forward: thr/bias required in adaptive modes");
+    DAGL_REQUIRE(fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
+    if (fin) {
+        DAGL_REQUIRE(fin->x && fin->g_w && fin->g_b && fin->th_w && fin->th_b, "dagl_ce_forward_fused: null tensor pointer");
+        if (mode != DAGL_MODE_TOPK)
+            DAGL_REQUIRE(fin->thr_w && fin->thr_b && fin->bias_w && fin->bias_b, "dagl_ce_forward_fused: thr/bias heads required in adaptive modes");
+    } else {
+        DAGL_REQUIRE(b1 && b2, "dagl_ce_forward: null tensor pointer");
+        if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias, "dagl_ce_forward: thr/bias required in adaptive modes");
+    }
     DAGL_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256) == 0, "dagl_ce_forward: workspace must be 256-byte aligned");
     if (ws_bytes < p.o_end) {
         set_error("dagl_ce_forward: workspace %zu B < required %zu B", ws_bytes, p.o_end);
@@ -199,8 +213,17 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
-    if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
-    if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
+    if (fin) {
+        float* thr_ws = at<float>(ws, p.o_thr);
+        float* bias_ws = at<float>(ws, p.o_bias);
+        const bool heads = (mode != DAGL_MODE_TOPK);
+        if ((rc = launch_prologue(s, B, g, fin->x, fin->g_w, fin->g_b, fin->th_w, fin->th_b, fin->thr_w, fin->thr_b,
+                                  fin->bias_w, fin->bias_b, b1p, b2p, heads ? thr_ws : nullptr, bias_ws))) return rc;
+        thr = thr_ws; bias = bias_ws;
+    } else {
+        if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
+        if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
+    }
     if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
     if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
     {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
@@ -446,6 +469,27 @@ int dagl_ce_forward_profiled(void* stream, int B, int H, int W, const float* b1,
                              dagl_ce_info* info, dagl_profile* prof) {
     return ce_forward_impl((hipStream_t)stream, B, H, W, b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode, k, out,
                            workspace, ws_bytes, info, nullptr, nullptr, nullptr, reinterpret_cast<Profile*>(prof));
+}
+
+int dagl_ce_forward_fused(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,
+                          const float* theta_w, const float* theta_b, const float* thr_w, const float* thr_b,
+                          const float* bias_w, const float* bias_b, const float* fc1_w, const float* fc1_b,
+                          const float* fc2_w, const float* fc2_b, int mode, int k, float* out, void* workspace,
+                          size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof) {
+    FusedIn fin{x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b};
+    return ce_forward_impl((hipStream_t)stream, B, H, W, nullptr, nullptr, nullptr, nullptr, fc1_w, fc1_b, fc2_w, fc2_b,
+                           mode, k, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr,
+                           reinterpret_cast<Profile*>(prof), &fin);
+}
+
+int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,
+                     const float* theta_w, const float* theta_b, const float* thr_w, const float* thr_b,
+                     const float* bias_w, const float* bias_b, float* b1_nhwc, float* b2_nhwc, float* thr, float* bias) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && x && g_w && g_b && theta_w && theta_b && b1_nhwc && b2_nhwc,
+                 "dagl_ce_prologue: bad argument");
+    if (thr || bias) DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b, "dagl_ce_prologue: thr/bias heads incomplete");
+    return launch_prologue((hipStream_t)stream, B, make_grid(H, W), x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w,
+                           bias_b, b1_nhwc, b2_nhwc, thr, bias);
 }
 
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {

@@ -98,6 +98,9 @@ inline int feat_rows_h(int rows) { return round_up(rows, SKEYS) + SKEYS; }   // 
 // ---- stage launchers (defined in the .hip files) ------------------------------------------------
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
+int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
+                    const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
+                    const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias);
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                    const float* wp_q, const float* bias_q, float* feat_q,

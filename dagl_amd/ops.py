@@ -222,3 +222,68 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
     if return_info or debug:
         return out, meta
     return out
+
+
+def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None):
+    """The four prologue convolutions (dagl.py:208-215) -> (b1_nhwc, b2_nhwc, thr, bias); heads optional."""
+    for n, t in (("x", x), ("g_w", g_w), ("g_b", g_b), ("theta_w", theta_w), ("theta_b", theta_b)):
+        _need(t, n)
+    B, c, H, W = x.shape
+    if c != 64:
+        raise DaglError("ce_prologue: 64 input channels expected")
+    Lh, Lw = query_grid(H, W)
+    b1p = torch.empty(B, H + 6, W + 6, 16, device=x.device, dtype=torch.float32)
+    b2p = torch.empty_like(b1p)
+    heads = thr_w is not None
+    thr = torch.empty(B, Lh * Lw, device=x.device, dtype=torch.float32) if heads else None
+    bias = torch.empty(B, Lh * Lw, device=x.device, dtype=torch.float32) if heads else None
+    if heads:
+        for n, t in (("thr_w", thr_w), ("thr_b", thr_b), ("bias_w", bias_w), ("bias_b", bias_b)):
+            _need(t, n)
+    p = lambda t: t.data_ptr() if t is not None else None
+    check(_lib.load().dagl_ce_prologue(_stream(), B, H, W, x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(),
+                                       theta_w.data_ptr(), theta_b.data_ptr(), p(thr_w), p(thr_b), p(bias_w), p(bias_b),
+                                       b1p.data_ptr(), b2p.data_ptr(), p(thr), p(bias)), "dagl_ce_prologue")
+    return b1p, b2p, thr, bias
+
+
+def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
+                     profile: "StageProfile | None" = None, exact_scan: bool = False):
+    """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
+    state_dict names to contiguous fp32 GPU tensors.  Returns (out, info)."""
+    lib = _lib.load()
+    if mode not in MODES:
+        raise DaglError(f"unknown mode {mode!r}")
+    _need(x, "x")
+    B, c, H, W = x.shape
+    if c != 64:
+        raise DaglError("ce_forward_fused: 64 input channels expected")
+    names = ["g.weight", "g.bias", "theta.weight", "theta.bias", "thr_conv.weight", "thr_conv.bias",
+             "bias_conv.weight", "bias_conv.bias", "fc1.0.weight", "fc1.0.bias", "fc2.0.weight", "fc2.0.bias"]
+    ptrs = []
+    for n in names:
+        t = params[n]
+        _need(t, n)
+        ptrs.append(t.data_ptr())
+    ws = workspace if workspace is not None else Workspace()
+    mode_flags = MODES[mode] | (_lib.FLAG_EXACT_SCAN if exact_scan else 0)
+    need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
+    if need == 0:
+        check(-1, "dagl_ce_workspace_bytes")
+    out = torch.empty(B, 16, H, W, device=x.device, dtype=torch.float32)
+    info = _lib.CeInfo()
+    rc = 0
+    for _attempt in range(2):
+        buf = ws.get(need, x.device)
+        base = buf.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        rc = lib.dagl_ce_forward_fused(_stream(), B, H, W, x.data_ptr(), *ptrs, mode_flags, int(k), out.data_ptr(),
+                                       aligned, buf.numel() - (aligned - base), C.byref(info),
+                                       profile._h if profile is not None else None)
+        if rc == _lib.ERR_WORKSPACE and info.required_bytes > need:
+            need = int(info.required_bytes)
+            continue
+        break
+    check(rc, "dagl_ce_forward_fused")
+    return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
+                     max_degree=info.max_degree, path=info.path)

@@ -66,6 +66,8 @@ extern "C" {
 #define DAGL_ERR_HIP             -3   /* a HIP call / launch failed (message has hipGetErrorString)  */
 #define DAGL_ERR_NO_DEVICE       -4   /* no gfx950 device visible                                    */
 
+typedef struct dagl_profile dagl_profile;     /* opaque stage profile, see dagl_profile_* below */
+
 typedef struct dagl_ce_info {
     int64_t required_bytes;   /* workspace this call needed (valid on OK and on ERR_WORKSPACE)      */
     int64_t total_edges;      /* sum of degrees over all queries of the batch                       */
@@ -102,6 +104,18 @@ int dagl_ce_forward(void* stream, int B, int H, int W,
                     int mode, int k, float* out,
                     void* workspace, size_t ws_bytes, dagl_ce_info* info);
 
+/* The whole of CE.forward (dagl.py:207-275) from the block's input: the four prologue convolutions are
+ * computed in here too (prologue.hip), so no stock conv runs on the path.
+ *   x [B,64,H,W];  g_w [16,64,3,3] g_b [16];  theta_w [16,64,1,1] theta_b [16];
+ *   thr_w / bias_w [1,64,7,7], thr_b / bias_b [1]  (may be NULL in DAGL_MODE_TOPK)
+ *   prof: optional stage profile (NULL = none)                                                    */
+int dagl_ce_forward_fused(void* stream, int B, int H, int W, const float* x,
+                          const float* g_w, const float* g_b, const float* theta_w, const float* theta_b,
+                          const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
+                          const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                          int mode, int k, float* out,
+                          void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
+
 /* Same call with optional per-query read-outs for parity tests (any of them may be NULL):
  *   deg_out [B,L] int32  neighbours per query     (reference: (mask != 0).sum(1), dagl.py:257)
  *   rowsum_out [B,L]     sum_j A_ij               (reference: softmax mass left after masking, :261)
@@ -127,7 +141,6 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W,
 #define DAGL_STAGE_EDGE      5   /* refine / candidate merge / degree scan + edge softmax           */
 #define DAGL_STAGE_GATHER    6   /* neighbour gather + weighted sum                                 */
 #define DAGL_STAGE_FOLD      7   /* fold + overlap normalisation                                    */
-typedef struct dagl_profile dagl_profile;
 int dagl_profile_create(int max_calls, dagl_profile** out);
 int dagl_profile_destroy(dagl_profile* prof);
 int dagl_profile_reset(dagl_profile* prof);
@@ -140,6 +153,13 @@ int dagl_ce_forward_profiled(void* stream, int B, int H, int W,
                              void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
 
 /* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
+
+/* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
+ * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).                             */
+int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x,
+                     const float* g_w, const float* g_b, const float* theta_w, const float* theta_b,
+                     const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
+                     float* b1_nhwc, float* b2_nhwc, float* thr, float* bias);
 
 /* NCHW [B,16,H,W] -> zero-bordered NHWC [B,H+6,W+6,16]  (patch unfold without materialising
  * patches: replaces same_padding/extract_image_patches, dagl.py:123-169, for all three uses).    */

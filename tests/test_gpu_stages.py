@@ -135,3 +135,23 @@ def test_fold_normalize_matches_fold(B, H, W):
     mine = agg.permute(0, 1, 3, 4, 2).reshape(B, Lh * Lw, 784).contiguous()                   # (kh,kw,c)
     got = ops.fold_normalize(mine.to(d), H, W).cpu()
     assert normwise(got.numpy(), want.numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES + [(1, 5, 9), (1, 72, 200)])
+def test_fused_prologue_matches_stock_convs(B, H, W):
+    """g / theta / thr_conv / bias_conv (dagl.py:208-215) computed by prologue.hip vs torch's CPU convs."""
+    from dagl_amd import ops
+    d = _dev()
+    x, p, _, st = _case(33, B, H, W, variant="default")
+    pd = {n: t.to(d).contiguous() for n, t in p.items()}
+    b1p, b2p, thr, bias = ops.ce_prologue(x.to(d), pd["g.weight"], pd["g.bias"], pd["theta.weight"], pd["theta.bias"],
+                                          pd["thr_conv.weight"], pd["thr_conv.bias"], pd["bias_conv.weight"],
+                                          pd["bias_conv.bias"])
+    want1 = F.pad(st["b1"], (3, 3, 3, 3)).permute(0, 2, 3, 1)
+    want2 = F.pad(st["b2"], (3, 3, 3, 3)).permute(0, 2, 3, 1)
+    assert normwise(b1p.cpu().numpy(), want1.numpy()) <= 2e-6
+    assert normwise(b2p.cpu().numpy(), want2.numpy()) <= 2e-6
+    # zero border exactly zero
+    assert float(b1p[:, :3].abs().max()) == 0.0 and float(b1p[:, :, -3:].abs().max()) == 0.0
+    assert normwise(thr.cpu().numpy(), st["thr"].numpy()) <= 2e-6
+    assert normwise(bias.cpu().numpy(), st["bias"].numpy()) <= 2e-6
