@@ -61,7 +61,11 @@ struct ProjArgs {
 
 // One launch covers both projections: the few query blocks (stride-4 grid, fc1) are dispatched first and
 // run concurrently with the key blocks (stride-1 grid, fc2) instead of forming a second, under-filled launch.
-__global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
+// A wave owns PJ_MT = 2 tiles of 16 consecutive patches: every weight fragment read from LDS feeds 8 MFMAs.
+constexpr int PJ_MT = 2;
+constexpr int PJ_ROWS = 16 * PJ_MT;              // patches per wave
+
+__global__ __launch_bounds__(256, 2) void project_kernel(ProjArgs pa) {
     __shared__ __attribute__((aligned(16))) float sB[2][PJ_SLICE];       // 26 KiB
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,28 +80,32 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
     const float* __restrict__ wp = pa.wp[which];
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
-    const int stride = queries ? QS : 1;
 
-    // work item of this wave: 16 consecutive patches of one grid row
+    // work item of this wave: PJ_ROWS consecutive patches of one grid row
     int item = blk * PJ_WAVES + wave;
     const bool wave_valid = item < n_items;
     if (!wave_valid) item = n_items - 1;
     const int row_len = queries ? gr.Lw : gr.W;
     const int gy = item / segs_per_row;                       // grid row (query row r or pixel row y)
-    const int gx0 = (item % segs_per_row) * 16;
-    int gx = gx0 + i;
-    if (gx >= row_len) gx = row_len - 1;
-    // top-left corner of the patch in padded-map coordinates
-    const int py = queries ? (QS * gy - gr.pt + PADPIX) : gy;
-    const int px = queries ? (QS * gx - gr.pl + PADPIX) : gx;
-    const float* abase = pa.map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
-    (void)stride;
+    const int gx0 = (item % segs_per_row) * PJ_ROWS;
+    const float* abase[PJ_MT];
+#pragma unroll
+    for (int m = 0; m < PJ_MT; ++m) {
+        int gx = gx0 + 16 * m + i;
+        if (gx >= row_len) gx = row_len - 1;
+        // top-left corner of the patch in padded-map coordinates
+        const int py = queries ? (QS * gy - gr.pt + PADPIX) : gy;
+        const int px = queries ? (QS * gx - gr.pl + PADPIX) : gx;
+        abase[m] = pa.map + (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 4 * g;
+    }
 
     // acc: running chain of the current kernel row (7 steps x 16 channels = 112 terms); tot: sum of finished
     // rows.  Chunking the 784-term sum by kernel row cuts its rounding error ~2.5x (see select.hip).
-    f32x4 acc[PJ_NT], tot[PJ_NT];
+    f32x4 acc[PJ_MT][PJ_NT], tot[PJ_MT][PJ_NT];
 #pragma unroll
-    for (int n = 0; n < PJ_NT; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[n] = acc[n]; }
+    for (int m = 0; m < PJ_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < PJ_NT; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[m][n] = acc[m][n]; }
 
     // B-fragment LDS offsets (floats): row o = n*16 + i, swizzled slot
     const int bslot = g ^ (((i >> 3) & 1) << 1);
@@ -107,13 +115,17 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sB[0][0]));
     for (int p = wave; p < PJ_NT; p += PJ_WAVES)
         glds16_asm(wp + (size_t)p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
-    float4 a_cur = *reinterpret_cast<const float4*>(abase);
+    float4 a_cur[PJ_MT];
+#pragma unroll
+    for (int m = 0; m < PJ_MT; ++m) a_cur[m] = *reinterpret_cast<const float4*>(abase[m]);
     dma_wait_all();
     __syncthreads();
 
     for (int step = 0; step < PJ_STEPS; ++step) {
         const int cur = step & 1;
-        float4 a_nxt = a_cur;
+        float4 a_nxt[PJ_MT];
+#pragma unroll
+        for (int m = 0; m < PJ_MT; ++m) a_nxt[m] = a_cur[m];
         if (step + 1 < PJ_STEPS) {
             const int ns = step + 1;
             const float* wsrc = wp + (size_t)ns * PJ_SLICE;
@@ -121,53 +133,66 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs pa) {
             for (int p = wave; p < PJ_NT; p += PJ_WAVES)
                 glds16_asm(wsrc + (size_t)p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(dst + p * 1024));
             const int kh = ns / KS, kw = ns % KS;
-            a_nxt = *reinterpret_cast<const float4*>(abase + ((size_t)kh * gr.Wp + kw) * CH);
+#pragma unroll
+            for (int m = 0; m < PJ_MT; ++m)
+                a_nxt[m] = *reinterpret_cast<const float4*>(abase[m] + ((size_t)kh * gr.Wp + kw) * CH);
         }
         const float* sb = &sB[cur][boff];
 #pragma unroll
         for (int n = 0; n < PJ_NT; ++n) {
             const float4 bw = *reinterpret_cast<const float4*>(sb + n * 16 * CH);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, bw.x, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, bw.y, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, bw.z, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, bw.w, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < PJ_MT; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m].x, bw.x, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m].y, bw.y, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m].z, bw.z, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m].w, bw.w, acc[m][n], 0, 0, 0);
+            }
         }
         if ((step + 1) % KS == 0) {
 #pragma unroll
-            for (int n = 0; n < PJ_NT; ++n) { tot[n] += acc[n]; acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int m = 0; m < PJ_MT; ++m)
+#pragma unroll
+                for (int n = 0; n < PJ_NT; ++n) { tot[m][n] += acc[m][n]; acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
-        a_cur = a_nxt;
+#pragma unroll
+        for (int m = 0; m < PJ_MT; ++m) a_cur[m] = a_nxt[m];
         dma_wait_all();
         __syncthreads();
     }
 
     // epilogue: D[row = 4g + r][col = n*16 + i]; bias + ReLU; zero columns 196..203
-    const int grid_row_base = gy * row_len + gx0;          // linear patch index of row 0 of this wave
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which];
     float csum[PJ_NT];
 #pragma unroll
-    for (int n = 0; n < PJ_NT; ++n) {
-        const int col = n * 16 + i;
-        const float bv = (col < D) ? fbias[col] : 0.0f;
-        float s = 0.f;
+    for (int n = 0; n < PJ_NT; ++n) csum[n] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * g + r;
-            const bool ok = wave_valid && (gx0 + rr < row_len);
-            float v = tot[n][r] + bv;
-            v = v > 0.f ? v : 0.f;
-            if (col >= D) v = 0.f;
-            if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
-            if (ok && hb != nullptr) {
-                unsigned u = __float_as_uint(v);
-                u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;            // fp32 -> bf16, round to nearest even
-                hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
+    for (int m = 0; m < PJ_MT; ++m) {
+        const int grid_row_base = gy * row_len + gx0 + 16 * m;  // linear patch index of row 0 of this tile
+#pragma unroll
+        for (int n = 0; n < PJ_NT; ++n) {
+            const int col = n * 16 + i;
+            const float bv = (col < D) ? fbias[col] : 0.0f;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 4 * g + r;
+                const bool ok = wave_valid && (gx0 + 16 * m + rr < row_len);
+                float v = tot[m][n][r] + bv;
+                v = v > 0.f ? v : 0.f;
+                if (col >= D) v = 0.f;
+                if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
+                if (ok && hb != nullptr) {
+                    unsigned u = __float_as_uint(v);
+                    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;            // fp32 -> bf16, round to nearest even
+                    hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
+                }
+                s += ok ? v : 0.f;
             }
-            s += ok ? v : 0.f;
+            csum[n] += s;
         }
-        csum[n] = s;
     }
     if (!queries && pa.colsum != nullptr) {
         // reduce over the 4 row groups (lanes i, i+16, i+32, i+48), then one fp64 atomic per column per wave
@@ -193,7 +218,7 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* 
     pa.wp[0] = wp_keys; pa.bias[0] = bias_keys; pa.feat[0] = feat_keys;
     pa.wp[1] = wp_q; pa.bias[1] = bias_q; pa.feat[1] = feat_q;
     pa.rows_alloc[0] = feat_rows(g.N); pa.rows_alloc[1] = feat_rows(g.L);
-    pa.segs[0] = (g.W + 15) / 16; pa.segs[1] = (g.Lw + 15) / 16;
+    pa.segs[0] = (g.W + PJ_ROWS - 1) / PJ_ROWS; pa.segs[1] = (g.Lw + PJ_ROWS - 1) / PJ_ROWS;
     pa.n_items[0] = pa.segs[0] * g.H; pa.n_items[1] = pa.segs[1] * g.Lh;
     pa.colsum = colsum;
     const int nbq = (which & 2) ? (pa.n_items[1] + PJ_WAVES - 1) / PJ_WAVES : 0;

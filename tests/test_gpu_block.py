@@ -193,9 +193,12 @@ def test_full_size_properties(H, W, mode, k):
     assert torch.equal(out, out2)
     # linearity in the values: theta scaled by 2 (exact in fp32) doubles the output bit for bit
     with torch.no_grad():
+        out_x1 = ce(x).clone()
         ce.theta.weight.mul_(2.0); ce.theta.bias.mul_(2.0)
         out_x2 = ce(x)
-    assert torch.equal(out_x2, out * 2.0)
+    assert torch.equal(out_x2, out_x1 * 2.0)
+    # fused prologue (module path) vs stock-conv prologue + block entry point: same block, rounding-level difference
+    assert normwise(out_x1.cpu().numpy(), out.cpu().numpy()) <= 2e-5
     # no neighbours -> exact zero
     if mode == "adaptive":
         with torch.no_grad():
