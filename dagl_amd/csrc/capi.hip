@@ -36,6 +36,7 @@ struct Plan {
     Grid g;
     int B, mode, k, kslots;
     bool screen;                    // bf16 screen + exact refine (default) vs. the all-fp32 scan
+    bool split16;                   // fp16 split-operand projection (default) vs. the fp32 MFMA projection
     int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
     int s_splits, s_steps_per_split, s_steps, s_sample;   // bf16 screen (screen.hip)
     int capseg;
@@ -43,7 +44,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_ssegcnt, o_redo, o_thr, o_bias, o_end;
+        o_ssegcnt, o_redo, o_thr, o_bias, o_maphi, o_maplo, o_wp1h, o_wp2h, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -70,6 +71,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.kslots = (mode == DAGL_MODE_ADAPTIVE) ? 0 : topk_slots(k);
     const Grid& g = p.g;
     p.screen = !exact && g.N >= SCREEN_MIN_KEYS;
+    p.split16 = !exact;
     p.n_tiles = (g.N + KT - 1) / KT;
     const int n_qgroups = (g.L + 127) / 128;
     // fp32 scan: enough blocks for ~4 per CU, chunks of at least 8 tiles, candidate merge bounded for top-k
@@ -128,6 +130,13 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.o_agg = carve(off, BL * P * sizeof(float));
     p.o_thr = carve(off, BL * sizeof(float));
     p.o_bias = carve(off, BL * sizeof(float));
+    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = 0;
+    if (!exact) {
+        p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
+        p.o_maplo = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
+        p.o_wp1h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
+        p.o_wp2h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
+    }
     p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
@@ -224,8 +233,17 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     }
-    if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
-    if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
+    uint16_t *map_hi = nullptr, *map_lo = nullptr, *wp1h = nullptr, *wp2h = nullptr;
+    if (p.split16) {
+        map_hi = at<uint16_t>(ws, p.o_maphi); map_lo = at<uint16_t>(ws, p.o_maplo);
+        wp1h = at<uint16_t>(ws, p.o_wp1h); wp2h = at<uint16_t>(ws, p.o_wp2h);
+        if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo))) return rc;
+        if ((rc = launch_pack_fc_weight16(s, fc1_w, wp1h))) return rc;
+        if ((rc = launch_pack_fc_weight16(s, fc2_w, wp2h))) return rc;
+    } else {
+        if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
+        if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
+    }
     {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
         for (int b = 0; b < B; ++b) {
@@ -244,7 +262,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
     prof_mark(prof, s, 1);
-    if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
+    if (p.split16) {
+        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, fc2_b, X, colsum, wp1h, fc1_b, Wq, Xh, Wqh))) return rc;
+    } else {
+        if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
+    }
 
     // ---- stage 2: adaptive thresholds ----------------------------------------------------------------------
     prof_mark(prof, s, 2);

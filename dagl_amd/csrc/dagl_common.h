@@ -105,6 +105,14 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, 
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                    const float* wp_q, const float* bias_q, float* feat_q,
                    uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr);
+// fp16 split-operand projection (project16.hip)
+int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo);
+int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp);
+int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
+                     const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
+                     const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
+                     uint16_t* feat_q_bf16);
+constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216;      // packed fp16 weight size (halfs)
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
                             const float* thr, float* mt);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
