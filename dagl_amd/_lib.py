@@ -30,7 +30,7 @@ class DaglError(RuntimeError):
 
 
 class CeInfo(C.Structure):
-    _fields_ = [("required_bytes", C.c_int64), ("total_edges", C.c_int64),
+    _fields_ = [("required_bytes", C.c_int64), ("total_edges", C.c_int64), ("redone_queries", C.c_int64),
                 ("max_degree", C.c_int32), ("path", C.c_int32)]
 
 

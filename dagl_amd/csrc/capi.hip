@@ -21,6 +21,26 @@ int hip_fail(hipError_t e, const char* what) {
     return DAGL_ERR_HIP;
 }
 
+// 64 bytes of pinned host memory per calling thread for the small device->host read-backs (a pageable
+// destination would make every hipMemcpyAsync a blocking staged copy).  Allocated once, never freed.
+static int64_t* pinned_scratch() {
+    static thread_local int64_t* p = nullptr;
+    if (p == nullptr) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        p = static_cast<int64_t*>(q);
+    }
+    return p;
+}
+static int read_back(hipStream_t s, const int64_t* dev, int n, int64_t* out) {
+    int64_t* pin = pinned_scratch();
+    int64_t* dst = pin ? pin : out;
+    DAGL_HIP_TRY(hipMemcpyAsync(dst, dev, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    DAGL_HIP_TRY(hipStreamSynchronize(s));
+    if (pin) for (int i = 0; i < n; ++i) out[i] = pin[i];
+    return DAGL_OK;
+}
+
 // ---- optional stage profile: hipEvents recorded at stage boundaries on the caller's stream ------------------
 struct Profile {
     int max_calls = 0, n_calls = 0;
@@ -180,7 +200,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int rc = make_plan(B, H, W, mode_flags, k, p);
     if (rc) return rc;
     const int mode = p.mode;
-    if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0; }
+    if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
+                info->redone_queries = -1; }
     DAGL_REQUIRE(fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
     if (fin) {
         DAGL_REQUIRE(fin->x && fin->g_w && fin->g_b && fin->th_w && fin->th_b, "dagl_ce_forward_fused: null tensor pointer");
@@ -287,6 +308,19 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
 
+    auto run_tail = [&](const AggArgs& ag2) -> int {
+        int r;
+        if (dbg_deg || dbg_rowsum)
+            if ((r = launch_row_stats(s, BL, ag2.nb_wgt, ag2.nb_cnt, ag2.row_off, ag2.width, dbg_deg, dbg_rowsum))) return r;
+        prof_mark(prof, s, 6);
+        if ((r = launch_aggregate_direct(s, ag2))) return r;
+        prof_mark(prof, s, 7);
+        if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if ((r = launch_fold(s, B, g, agg, out))) return r;
+        prof_mark(prof, s, 8);
+        return DAGL_OK;
+    };
+
     // ---- stages 3-5: neighbour selection + edge softmax ------------------------------------------------------
     bool need_exact = !p.screen;
     int32_t* redo = nullptr;
@@ -321,17 +355,28 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_refine(s, ra))) return rc;
         if (info) info->path = 3;
         if (mode == DAGL_MODE_ADAPTIVE) {
-            // dense neighbourhoods need the CSR sizing on the host anyway: read the verdict back
+            // Dense neighbourhoods need host-side CSR sizing, so the verdict must be read back -- but only after
+            // the optimistic gather + fold are already queued, so the device does not idle during the round trip.
+            if ((rc = run_tail(ag))) return rc;
             int64_t hs[4] = {0, 0, 0, 0};
-            DAGL_HIP_TRY(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, s));
-            DAGL_HIP_TRY(hipStreamSynchronize(s));
-            if (hs[2] > 0) need_exact = true;
-            else if (info) { info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1]; }
+            if ((rc = read_back(s, stats, 4, hs))) return rc;
+            if (info) info->redone_queries = hs[2];
+            if (hs[2] == 0) {
+                if (info) { info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1]; }
+                if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
+                return DAGL_OK;
+            }
+            need_exact = true;                                   // redo everything with the fp32 scan (CSR capable)
         } else {
             // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it
             // exits at once for every other group, so no host round trip is needed
             sa.run_flags = redo; ea.run_flags = redo;
             need_exact = true;
+            if (info && (dbg_deg || dbg_rowsum || dbg_agg)) {        // debug entry point: report the overflow count
+                int64_t hs[4] = {0, 0, 0, 0};
+                if ((rc = read_back(s, stats, 4, hs))) return rc;
+                info->redone_queries = hs[2];
+            }
         }
     } else {
         prof_mark(prof, s, 3);
@@ -348,8 +393,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if (!p.screen) prof_mark(prof, s, 5);
             if ((rc = launch_row_degree(s, (int)BL, p.splits * 2, segcnt, segrel, deg, stats))) return rc;
             int64_t hstats[2] = {0, 0};
-            DAGL_HIP_TRY(hipMemcpyAsync(hstats, stats, sizeof(hstats), hipMemcpyDeviceToHost, s));
-            DAGL_HIP_TRY(hipStreamSynchronize(s));
+            if ((rc = read_back(s, stats, 2, hstats))) return rc;
             if (info) { info->total_edges = hstats[0]; info->max_degree = (int32_t)hstats[1]; info->path = 0; }
             if (hstats[1] <= DAGL_FAST_CAP) {
                 ea.cnt = deg; ea.list_idx = lidx; ea.list_val = lval; ea.row_off = nullptr;
@@ -387,14 +431,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     }
 
     // ---- stages 6-7: gather + weighted sum, fold ---------------------------------------------------------------
-    if (dbg_deg || dbg_rowsum)
-        if ((rc = launch_row_stats(s, BL, ag.nb_wgt, ag.nb_cnt, ag.row_off, ag.width, dbg_deg, dbg_rowsum))) return rc;
-    prof_mark(prof, s, 6);
-    if ((rc = launch_aggregate_direct(s, ag))) return rc;
-    prof_mark(prof, s, 7);
-    if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if ((rc = launch_fold(s, B, g, agg, out))) return rc;
-    prof_mark(prof, s, 8);
+    if ((rc = run_tail(ag))) return rc;
     if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
     return DAGL_OK;
 }

@@ -216,7 +216,7 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
         break
     check(rc, "dagl_ce_forward")
     meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
-                max_degree=info.max_degree, path=info.path)
+                max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
     if dbg is not None:
         meta.update(dbg)
     if return_info or debug:
@@ -286,4 +286,4 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
         break
     check(rc, "dagl_ce_forward_fused")
     return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
-                     max_degree=info.max_degree, path=info.path)
+                     max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)

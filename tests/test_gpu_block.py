@@ -105,17 +105,20 @@ def test_screened_scan_selects_the_same_neighbours_as_the_fp32_scan(mode, k, var
 
 
 def test_screen_overflow_is_redone_by_the_fp32_scan():
-    """A constant feature map makes every interior patch identical: all scores tie, every key is a candidate,
-    the screen's slots overflow and the flagged query groups must come out of the fp32 scan unchanged."""
+    """A nearly constant feature map makes all patches near-duplicates: every score lies inside the screen's
+    0.8 % band, every key is a candidate, the candidate slots overflow and the flagged query groups must come
+    out of the fp32 scan -- with the same neighbours as scanning everything in fp32 from the start."""
     from dagl_amd.synth import make_ce_params
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
-    x = torch.full((1, 64, 64, 64), 0.25).to(_dev())
+    g = torch.Generator().manual_seed(3)
+    x = (0.25 + 1e-2 * torch.randn(1, 64, 64, 64, generator=g)).to(_dev())
     res = {}
     for scan in ("screened", "exact"):
         ce = _module(params, "topk", 8, scan)
         res[scan] = _run_debug(ce, x)
+    assert res["screened"][1]["path"] == 3 and res["screened"][1]["redone_queries"] > 0
     assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
-    assert torch.equal(res["screened"][0], res["exact"][0])
+    assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
 
 
 def test_adaptive_topk_mode_matches_oracle():
@@ -198,7 +201,7 @@ def test_full_size_properties(H, W, mode, k):
         out_x2 = ce(x)
     assert torch.equal(out_x2, out_x1 * 2.0)
     # fused prologue (module path) vs stock-conv prologue + block entry point: same block, rounding-level difference
-    assert normwise(out_x1.cpu().numpy(), out.cpu().numpy()) <= 2e-5
+    assert normwise(out_x1.cpu().numpy(), out.cpu().numpy()) <= TOL_OUT
     # no neighbours -> exact zero
     if mode == "adaptive":
         with torch.no_grad():
