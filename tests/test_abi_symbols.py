@@ -60,3 +60,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DaglError, match="no fallback"):
         _lib.load()
+
+
+def test_info_struct_layout_matches_header():
+    """ctypes mirror of dagl_ce_info: same field order and size as the C struct (3 x int64 + 2 x int32)."""
+    import ctypes as C
+    from dagl_amd import _lib
+    text = open(os.path.join(REPO, "include", "dagl_ce.h")).read()
+    body = text[text.index("typedef struct dagl_ce_info {"):text.index("} dagl_ce_info;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int64_t|int32_t)\s+(\w+)\s*;", body)
+    assert [n for _, n in fields] == [n for n, _ in _lib.CeInfo._fields_]
+    assert [t for t, _ in fields] == ["int64_t" if f is C.c_int64 else "int32_t" for _, f in _lib.CeInfo._fields_]
+    assert C.sizeof(_lib.CeInfo) == 32
