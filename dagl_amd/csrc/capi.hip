@@ -358,6 +358,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             // Dense neighbourhoods need host-side CSR sizing, so the verdict must be read back -- but only after
             // the optimistic gather + fold are already queued, so the device does not idle during the round trip.
             if ((rc = run_tail(ag))) return rc;
+            if ((rc = launch_degree_stats(s, BL, nbcnt, stats))) return rc;
             int64_t hs[4] = {0, 0, 0, 0};
             if ((rc = read_back(s, stats, 4, hs))) return rc;
             if (info) info->redone_queries = hs[2];

@@ -202,6 +202,7 @@ struct RefineArgs {
     int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);

@@ -435,11 +435,31 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             a.redo_flags[qg] = 1;
             atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[2]), 1ull);
         }
-        if (a.mode == DAGL_MODE_ADAPTIVE) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[0]), (unsigned long long)n);
-            atomicMax(reinterpret_cast<unsigned long long*>(&a.stats[1]), (unsigned long long)n);
-        }
     }
+}
+
+// total / max degree over all queries: one block (a same-address atomic per query would serialise ~12 ns each)
+__global__ __launch_bounds__(1024) void degree_stats_kernel(size_t n_rows, const int32_t* __restrict__ nb_cnt,
+                                                            int64_t* __restrict__ stats) {
+    __shared__ long long ssum[16];
+    __shared__ int smax[16];
+    long long sum = 0; int mx = 0;
+    for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) { const int d = nb_cnt[r]; sum += d; mx = max(mx, d); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0; int m = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); }
+        stats[0] = t; stats[1] = m;
+    }
+}
+
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats) {
+    hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats);
+    DAGL_LAUNCH_CHECK("degree_stats_kernel");
+    return DAGL_OK;
 }
 
 int launch_refine(hipStream_t s, const RefineArgs& a) {
