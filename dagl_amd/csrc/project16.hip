@@ -91,21 +91,22 @@ struct Proj16Args {
     double* colsum;
 };
 
-__global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][P16_SLICE_H];      // 36 KiB
+// NT output tiles starting at tile n0: a block covers 4 x 32 patches x NT x 32 outputs.  The 7 tiles are split
+// 4 + 3 over two blocks so that the accumulators (2 x NT x 16 registers) leave room for two blocks per CU.
+template <int NT>
+__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned short (*sB)[P16_SLICE_H], int n0,
+                                               int blk, bool queries) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const Grid& gr = pa.gr;
-
-    const bool queries = (int)blockIdx.x < pa.n_blocks_q;                // block-uniform
     const int which = queries ? 1 : 0;
-    const int blk = queries ? blockIdx.x : blockIdx.x - pa.n_blocks_q;
-    const unsigned short* __restrict__ wp = pa.wp[which];
+    const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
+    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
 
     int item = blk * P16_WAVES + wave;
     const bool wave_valid = item < n_items;
@@ -121,17 +122,17 @@ __global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
     const unsigned short* ahi = pa.map_hi + aoff;
     const unsigned short* alo = pa.map_lo + aoff;
 
-    f32x16 hh[P16_NT], cx[P16_NT];
+    f32x16 hh[NT], cx[NT];
 #pragma unroll
-    for (int n = 0; n < P16_NT; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { hh[n][r] = 0.f; cx[n][r] = 0.f; }
 
-    // B fragment of tile n: lane (j = i, h) reads row o = n*32 + i: hi at +8h, lo at +16+8h (halfs)
+    // B fragment of local tile n: lane (j = i, h) reads row n*32 + i: hi at +8h, lo at +16+8h (halfs)
     const int boff = i * P16_ROWH + 8 * h;
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sB[0][0]));
-    for (int p = wave; p < P16_PIECES; p += P16_WAVES)
+    for (int p = wave; p < PIECES; p += P16_WAVES)
         glds16_asm(reinterpret_cast<const float*>(wp + (size_t)p * 512 + lane * 8),
                    __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
     s16x8 a_hi = *reinterpret_cast<const s16x8*>(ahi);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
             const int ns = step + 1;
             const unsigned short* wsrc = wp + (size_t)ns * P16_SLICE_H;
             const unsigned dst = lds0 + (cur ^ 1) * (P16_SLICE_H * 2);
-            for (int p = wave; p < P16_PIECES; p += P16_WAVES)
+            for (int p = wave; p < PIECES; p += P16_WAVES)
                 glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
                            __builtin_amdgcn_readfirstlane(dst + p * 1024));
             const int kh = ns / KS, kw = ns % KS;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, a_hi), fa_lo = __builtin_bit_cast(f16x8, a_lo);
         const unsigned short* sb = &sB[cur][boff];
 #pragma unroll
-        for (int n = 0; n < P16_NT; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH));
             const f16x8 w_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH + 16));
             hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi, hh[n], 0, 0, 0);
@@ -169,14 +170,14 @@ __global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
         __syncthreads();
     }
 
-    // epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output n*32 + i]
+    // epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i]
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which];
     const int grid_row_base = gy * row_len + gx0;
 #pragma unroll
-    for (int n = 0; n < P16_NT; ++n) {
-        const int col = n * 32 + i;
+    for (int n = 0; n < NT; ++n) {
+        const int col = (n0 + n) * 32 + i;
         const float bv = (col < D) ? fbias[col] : 0.0f;
         float s = 0.f;
 #pragma unroll
@@ -201,6 +202,17 @@ __global__ __launch_bounds__(256) void project16_kernel(Proj16Args pa) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void project16_kernel(Proj16Args pa) {
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][P16_SLICE_H];      // 36 KiB
+    // blocks: [query blocks x 2 halves][key blocks x 2 halves]; half 0 = output tiles 0..3, half 1 = tiles 4..6
+    const int bid = blockIdx.x;
+    const bool queries = bid < 2 * pa.n_blocks_q;                       // block-uniform
+    const int rel = queries ? bid : bid - 2 * pa.n_blocks_q;
+    const int half = rel & 1, blk = rel >> 1;
+    if (half == 0) project16_body<4>(pa, sB, 0, blk, queries);
+    else project16_body<3>(pa, sB, 4, blk, queries);
+}
+
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                      const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
@@ -217,7 +229,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     const int nbq = (which & 2) ? (pa.n_items[1] + P16_WAVES - 1) / P16_WAVES : 0;
     const int nbk = (which & 1) ? (pa.n_items[0] + P16_WAVES - 1) / P16_WAVES : 0;
     pa.n_blocks_q = nbq;
-    hipLaunchKernelGGL(project16_kernel, dim3(nbq + nbk, B), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(project16_kernel, dim3(2 * (nbq + nbk), B), dim3(256), 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
     return DAGL_OK;
 }
