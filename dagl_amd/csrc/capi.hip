@@ -265,20 +265,31 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
         if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
     }
+    ZeroList zl;
     {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
-        for (int b = 0; b < B; ++b) {
-            DAGL_HIP_TRY(hipMemsetAsync(X + ((size_t)b * rx + g.N) * DS, 0, (size_t)(rx - g.N) * DS * sizeof(float), s));
-            DAGL_HIP_TRY(hipMemsetAsync(Wq + ((size_t)b * rq + g.L) * DS, 0, (size_t)(rq - g.L) * DS * sizeof(float), s));
-        }
-        if (p.screen) {
-            const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
+        const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
+        if (B == 1) {
+            zl.add(X + (size_t)g.N * DS, (size_t)(rx - g.N) * DS * sizeof(float));
+            zl.add(Wq + (size_t)g.L * DS, (size_t)(rq - g.L) * DS * sizeof(float));
+            if (p.screen) {
+                zl.add(Xh + (size_t)g.N * DSH, (size_t)(hx - g.N) * DSH * sizeof(uint16_t));
+                zl.add(Wqh + (size_t)g.L * DSH, (size_t)(hq - g.L) * DSH * sizeof(uint16_t));
+            }
+        } else {
             for (int b = 0; b < B; ++b) {
-                DAGL_HIP_TRY(hipMemsetAsync(Xh + ((size_t)b * hx + g.N) * DSH, 0, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), s));
-                DAGL_HIP_TRY(hipMemsetAsync(Wqh + ((size_t)b * hq + g.L) * DSH, 0, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), s));
+                DAGL_HIP_TRY(hipMemsetAsync(X + ((size_t)b * rx + g.N) * DS, 0, (size_t)(rx - g.N) * DS * sizeof(float), s));
+                DAGL_HIP_TRY(hipMemsetAsync(Wq + ((size_t)b * rq + g.L) * DS, 0, (size_t)(rq - g.L) * DS * sizeof(float), s));
+                if (p.screen) {
+                    DAGL_HIP_TRY(hipMemsetAsync(Xh + ((size_t)b * hx + g.N) * DSH, 0, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), s));
+                    DAGL_HIP_TRY(hipMemsetAsync(Wqh + ((size_t)b * hq + g.L) * DSH, 0, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), s));
+                }
             }
         }
-        DAGL_HIP_TRY(hipMemsetAsync(colsum, 0, (size_t)B * DS * sizeof(double), s));
+        zl.add(colsum, align_up((size_t)B * DS * sizeof(double), 16));
+        zl.add(stats, 4 * sizeof(int64_t));
+        if (p.screen) zl.add(at<int32_t>(ws, p.o_redo), align_up((size_t)B * n_qgroups * sizeof(int32_t), 16));
+        if ((rc = launch_zero_regions(s, zl))) return rc;
     }
 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
@@ -333,8 +344,6 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
         redo = at<int32_t>(ws, p.o_redo);
-        DAGL_HIP_TRY(hipMemsetAsync(redo, 0, (size_t)B * n_qgroups * sizeof(int32_t), s));
-        DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
         prof_mark(prof, s, 3);
         if (mode == DAGL_MODE_TOPK) {
             if ((rc = launch_screen(s, sc, 0))) return rc;

@@ -95,6 +95,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int feat_rows(int rows) { return round_up(rows, KT) + KT; }
 inline int feat_rows_h(int rows) { return round_up(rows, SKEYS) + SKEYS; }   // bf16 copies (64-row steps)
 
+struct ZeroList {                    // small regions cleared by one launch (16-byte granular)
+    int n = 0;
+    void* ptr[12];
+    size_t bytes[12];
+    void add(void* p, size_t b) { if (b) { ptr[n] = p; bytes[n] = b; ++n; } }
+};
+int launch_zero_regions(hipStream_t s, const ZeroList& z);
+int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2);
+
 // ---- stage launchers (defined in the .hip files) ------------------------------------------------
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);

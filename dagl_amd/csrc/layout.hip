@@ -57,4 +57,58 @@ int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, 
     return DAGL_OK;
 }
 
+// ---- zero fills -------------------------------------------------------------------------------------------
+// One launch for all the small regions a call has to clear (tail rows of the feature matrices, column sums,
+// flags, counters): a hipMemsetAsync each costs ~4.5 us of launch + gap.
+__global__ void zero_regions_kernel(ZeroList z) {
+    const int r = blockIdx.y;
+    if (r >= z.n) return;
+    uint4* p = reinterpret_cast<uint4*>(z.ptr[r]);
+    const size_t n16 = z.bytes[r] / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int launch_zero_regions(hipStream_t s, const ZeroList& z) {
+    if (z.n == 0) return DAGL_OK;
+    for (int i = 0; i < z.n; ++i)
+        if ((reinterpret_cast<uintptr_t>(z.ptr[i]) % 16) != 0 || (z.bytes[i] % 16) != 0) {
+            set_error("zero_regions: region %d not 16-byte granular", i);
+            return DAGL_ERR_INVALID;
+        }
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(64, z.n), dim3(256), 0, s, z);
+    DAGL_LAUNCH_CHECK("zero_regions_kernel");
+    return DAGL_OK;
+}
+
+// zero the 3-pixel border of two padded NHWC maps [B,Hp,Wp,16]
+__global__ void zero_borders_kernel(int H, int W, float* __restrict__ m1, float* __restrict__ m2) {
+    const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
+    const int b = blockIdx.y;
+    const int nb = 2 * PADPIX * Wp + 2 * PADPIX * H;                  // border pixels per image
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * 4) return;                                          // 4 float4 per pixel
+    const int pix = t >> 2, q = t & 3;
+    int yp, xp;
+    if (pix < 2 * PADPIX * Wp) {                                      // top / bottom bands
+        const int r = pix / Wp; xp = pix - r * Wp;
+        yp = (r < PADPIX) ? r : (Hp - 2 * PADPIX + r);
+    } else {                                                          // left / right bands of the interior rows
+        const int e = pix - 2 * PADPIX * Wp;
+        const int r = e / (2 * PADPIX), c = e - r * (2 * PADPIX);
+        yp = PADPIX + r; xp = (c < PADPIX) ? c : (Wp - 2 * PADPIX + c);
+    }
+    const size_t o = ((((size_t)b * Hp + yp) * Wp + xp) * CH) / 4 + q;
+    reinterpret_cast<float4*>(m1)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(m2)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2) {
+    const int Wp = W + 2 * PADPIX;
+    const int nb = (2 * PADPIX * Wp + 2 * PADPIX * H) * 4;
+    hipLaunchKernelGGL(zero_borders_kernel, dim3((nb + 255) / 256, B), dim3(256), 0, s, H, W, m1, m2);
+    DAGL_LAUNCH_CHECK("zero_borders_kernel");
+    return DAGL_OK;
+}
+
 }  // namespace dagl

@@ -146,9 +146,8 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, const float* __r
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias) {
-    const size_t map_b = (size_t)B * g.Hp * g.Wp * CH * sizeof(float);
-    DAGL_HIP_TRY(hipMemsetAsync(b1p, 0, map_b, s));              // zero borders
-    DAGL_HIP_TRY(hipMemsetAsync(b2p, 0, map_b, s));
+    int rcz = launch_zero_borders(s, B, g.H, g.W, b1p, b2p);
+    if (rcz) return rcz;
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // ~2 blocks per CU over the whole launch, at least 2 rows per block
     int chunks = (512 + strips * B - 1) / (strips * B);
