@@ -121,7 +121,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                      const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
                      uint16_t* feat_q_bf16);
-constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216;      // packed fp16 weight size (halfs)
+constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216 + 8192; // packed fp16 weights (halfs) + read slack of the last stage
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
                             const float* thr, float* mt);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);

@@ -93,9 +93,21 @@ struct Proj16Args {
 
 // NT output tiles starting at tile n0: a block covers 4 x 32 patches x NT x 32 outputs.  The 7 tiles are split
 // 4 + 3 over two blocks so that the accumulators (2 x NT x 16 registers) leave room for two blocks per CU.
+//
+// Pipeline: every operand of tap t+PD is in flight (LDS-DMA) while tap t is multiplied: a ring of P16_RING
+// stages, each = the block's weight slice (12 KiB: 12 DMA pieces, 3 per wave) + 4 wave-private 2-KiB patch
+// fragments (hi, lo: each lane DMA-copies exactly the 16 bytes it will read back).  All memory operations of the
+// loop are asm LDS-DMAs, 5 per wave per tap, so the landing of tap t+1 is a counted s_waitcnt vmcnt(5*(PD-1)).
+constexpr int P16_RING = 4;
+constexpr int P16_PD = 3;                              // prefetch distance (taps)
+constexpr int P16_STAGE_B = 12 * 1024;                 // bytes: weight slice region (>= NT*32*80)
+constexpr int P16_STAGE = P16_STAGE_B + P16_WAVES * 2048;      // + per-wave patch fragments = 20 KiB
+
+template <int N>
+__device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int NT>
-__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned short (*sB)[P16_SLICE_H], int n0,
-                                               int blk, bool queries) {
+__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk, bool queries) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -106,7 +118,6 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned sh
     const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
-    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
 
     int item = blk * P16_WAVES + wave;
     const bool wave_valid = item < n_items;
@@ -128,45 +139,51 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned sh
 #pragma unroll
         for (int r = 0; r < 16; ++r) { hh[n][r] = 0.f; cx[n][r] = 0.f; }
 
-    // B fragment of local tile n: lane (j = i, h) reads row n*32 + i: hi at +8h, lo at +16+8h (halfs)
-    const int boff = i * P16_ROWH + 8 * h;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    // issue the 5 DMAs of tap `t` (weights: pieces wave, wave+4, wave+8; patches: hi, lo) into ring stage t % RING
+    auto issue = [&](int t) {
+        const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE;
+        const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = wave + 4 * j;
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
+        const int kh = t / KS, kw = t - kh * KS;
+        const size_t o = ((size_t)kh * gr.Wp + kw) * CH;
+        const unsigned sa = st + P16_STAGE_B + wave * 2048;
+        glds16_asm(reinterpret_cast<const float*>(ahi + o), __builtin_amdgcn_readfirstlane(sa));
+        glds16_asm(reinterpret_cast<const float*>(alo + o), __builtin_amdgcn_readfirstlane(sa + 1024));
+    };
 
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sB[0][0]));
-    for (int p = wave; p < PIECES; p += P16_WAVES)
-        glds16_asm(reinterpret_cast<const float*>(wp + (size_t)p * 512 + lane * 8),
-                   __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
-    s16x8 a_hi = *reinterpret_cast<const s16x8*>(ahi);
-    s16x8 a_lo = *reinterpret_cast<const s16x8*>(alo);
-    dma_wait_all();
+#pragma unroll
+    for (int t = 0; t < P16_PD; ++t) issue(t);
+    dma_wait_le<5 * (P16_PD - 1)>();
     __syncthreads();
 
+    // B fragment of local tile n: lane (j = i, h) reads row n*32 + i: hi at +8h, lo at +16+8h (halfs)
+    const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes
     for (int step = 0; step < P16_STEPS; ++step) {
-        const int cur = step & 1;
-        s16x8 n_hi = a_hi, n_lo = a_lo;
-        if (step + 1 < P16_STEPS) {
-            const int ns = step + 1;
-            const unsigned short* wsrc = wp + (size_t)ns * P16_SLICE_H;
-            const unsigned dst = lds0 + (cur ^ 1) * (P16_SLICE_H * 2);
-            for (int p = wave; p < PIECES; p += P16_WAVES)
-                glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
-                           __builtin_amdgcn_readfirstlane(dst + p * 1024));
-            const int kh = ns / KS, kw = ns % KS;
-            const size_t o = ((size_t)kh * gr.Wp + kw) * CH;
-            n_hi = *reinterpret_cast<const s16x8*>(ahi + o);
-            n_lo = *reinterpret_cast<const s16x8*>(alo + o);
-        }
-        const f16x8 fa_hi = __builtin_bit_cast(f16x8, a_hi), fa_lo = __builtin_bit_cast(f16x8, a_lo);
-        const unsigned short* sb = &sB[cur][boff];
+        if (step + P16_PD < P16_STEPS) issue(step + P16_PD);
+        const unsigned char* st = smem + (step % P16_RING) * P16_STAGE;
+        const unsigned char* sa = st + P16_STAGE_B + wave * 2048 + lane * 16;
+        const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
+        const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + 1024));
+        const unsigned char* sb = st + boff;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH));
-            const f16x8 w_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH + 16));
+            const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2));
+            const f16x8 w_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + 32));
             hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi, hh[n], 0, 0, 0);
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo, cx[n], 0, 0, 0);
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi, cx[n], 0, 0, 0);
         }
-        a_hi = n_hi; a_lo = n_lo;
-        dma_wait_all();
+        // tap step+1 must have landed (for every wave) before anyone reads it
+        const int left = P16_STEPS - 1 - step;                          // taps still to compute after this one
+        if (left >= P16_PD) dma_wait_le<5 * (P16_PD - 1)>();
+        else if (left == 2) dma_wait_le<5>();
+        else dma_wait_le<0>();
         __syncthreads();
     }
 
@@ -203,14 +220,14 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned sh
 }
 
 __global__ __launch_bounds__(256, 2) void project16_kernel(Proj16Args pa) {
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][P16_SLICE_H];      // 36 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P16_RING * P16_STAGE];      // 80 KiB
     // blocks: [query blocks x 2 halves][key blocks x 2 halves]; half 0 = output tiles 0..3, half 1 = tiles 4..6
     const int bid = blockIdx.x;
     const bool queries = bid < 2 * pa.n_blocks_q;                       // block-uniform
     const int rel = queries ? bid : bid - 2 * pa.n_blocks_q;
     const int half = rel & 1, blk = rel >> 1;
-    if (half == 0) project16_body<4>(pa, sB, 0, blk, queries);
-    else project16_body<3>(pa, sB, 4, blk, queries);
+    if (half == 0) project16_body<4>(pa, smem, 0, blk, queries);
+    else project16_body<3>(pa, smem, 4, blk, queries);
 }
 
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
