@@ -64,7 +64,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_ssegcnt, o_redo, o_thr, o_bias, o_maphi, o_maplo, o_wp1h, o_wp2h, o_end;
+        o_ssegcnt, o_redo, o_thr, o_bias, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -150,12 +150,13 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.o_agg = carve(off, BL * P * sizeof(float));
     p.o_thr = carve(off, BL * sizeof(float));
     p.o_bias = carve(off, BL * sizeof(float));
-    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = 0;
+    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = p.o_colpart = 0;
     if (!exact) {
         p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_maplo = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_wp1h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
         p.o_wp2h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
+        p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
     p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
@@ -295,7 +296,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
     prof_mark(prof, s, 1);
     if (p.split16) {
-        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, fc2_b, X, colsum, wp1h, fc1_b, Wq, Xh, Wqh))) return rc;
+        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, fc2_b, X, colsum, at<float>(ws, p.o_colpart), wp1h, fc1_b, Wq, Xh, Wqh))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }

@@ -13,6 +13,8 @@
 //   A: hi/lo fp16 NHWC maps, one 16-byte load per lane per tap and part (coalesced, L2 resident)
 //   B: per tap the [224 outs][hi 16 | lo 16 | pad 8] fp16 slice (18 KiB) is shared by the 4 waves of a block
 //      through LDS, double buffered by LDS-DMA; 80-byte rows (5 slots, odd) make the ds_read_b128 conflict-free.
+#include <stdlib.h>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -87,51 +89,50 @@ struct Proj16Args {
     uint16_t* feat_h[2];                                            // optional bf16 copies [B, rows_alloc_h, DSH]
     int rows_alloc[2], rows_alloc_h[2];
     int n_items[2], segs[2];                                        // 32-patch work items per image / per grid row
-    int n_blocks_q;
-    double* colsum;
+    int n_blocks_q, n_blocks_k;
+    float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
 };
 
-// NT output tiles starting at tile n0: a block covers 4 x 32 patches x NT x 32 outputs.  The 7 tiles are split
-// 4 + 3 over two blocks so that the accumulators (2 x NT x 16 registers) leave room for two blocks per CU.
-//
-// Pipeline: every operand of tap t+PD is in flight (LDS-DMA) while tap t is multiplied: a ring of P16_RING
-// stages, each = the block's weight slice (12 KiB: 12 DMA pieces, 3 per wave) + 4 wave-private 2-KiB patch
-// fragments (hi, lo: each lane DMA-copies exactly the 16 bytes it will read back).  All memory operations of the
-// loop are asm LDS-DMAs, 5 per wave per tap, so the landing of tap t+1 is a counted s_waitcnt vmcnt(5*(PD-1)).
+// Block = 8 waves = 8 x 32 consecutive-row patches x NT x 32 outputs (the 7 output tiles are split 4 + 3 over two
+// blocks: accumulators 2 x NT x 16 registers).  All operands arrive by LDS-DMA issued from inline asm and are
+// consumed behind COUNTED s_waitcnt vmcnt(N):
+//   weights  : ring of P16_RING tap slices (NT*32 rows x 80 B), prefetched P16_PD taps ahead, shared by the 8 waves
+//   patches  : keys    -- per wave a 2-row ring of the map rows its 32 patches touch (38 pixels x hi|lo): every input
+//                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
+//              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
+constexpr int P16_BW = 8;                              // waves per block
 constexpr int P16_RING = 4;
 constexpr int P16_PD = 3;                              // prefetch distance (taps)
-constexpr int P16_STAGE_B = 12 * 1024;                 // bytes: weight slice region (>= NT*32*80)
-constexpr int P16_STAGE = P16_STAGE_B + P16_WAVES * 2048;      // + per-wave patch fragments = 20 KiB
+constexpr int P16_STAGE_B = 12 * 1024;                 // bytes per weight stage (>= NT*32*80, whole DMA pieces)
+constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 48 KiB: patch region
+constexpr int P16_AROW = 4096;                         // keys: one staged map row per wave: hi 2 KiB | lo 2 KiB
+constexpr int P16_LDS = P16_OFF_A + P16_BW * 2 * P16_AROW;          // 112 KiB (queries: 48 + 4 stages x 8 x 2 KiB)
 
 template <int N>
 __device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NT>
-__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk, bool queries) {
+template <int NT, bool KEYS, int VAR>
+__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const Grid& gr = pa.gr;
-    const int which = queries ? 1 : 0;
+    constexpr int which = KEYS ? 0 : 1;
     const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
+    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
+    const bool two = wave < (PIECES - P16_BW);                                  // this wave issues 2 weight pieces per tap
 
-    int item = blk * P16_WAVES + wave;
+    int item = blk * P16_BW + wave;
     const bool wave_valid = item < n_items;
     if (!wave_valid) item = n_items - 1;
-    const int row_len = queries ? gr.Lw : gr.W;
+    const int row_len = KEYS ? gr.W : gr.Lw;
     const int gy = item / segs_per_row;
     const int gx0 = (item % segs_per_row) * 32;
-    int gx = gx0 + i;
-    if (gx >= row_len) gx = row_len - 1;
-    const int py = queries ? (QS * gy - gr.pt + PADPIX) : gy;
-    const int px = queries ? (QS * gx - gr.pl + PADPIX) : gx;
-    const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;      // halfs
-    const unsigned short* ahi = pa.map_hi + aoff;
-    const unsigned short* alo = pa.map_lo + aoff;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
     f32x16 hh[NT], cx[NT];
 #pragma unroll
@@ -139,38 +140,73 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 #pragma unroll
         for (int r = 0; r < 16; ++r) { hh[n][r] = 0.f; cx[n][r] = 0.f; }
 
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    // issue the 5 DMAs of tap `t` (weights: pieces wave, wave+4, wave+8; patches: hi, lo) into ring stage t % RING
-    auto issue = [&](int t) {
-        const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE;
+    auto issue_w = [&](int t) {                        // weight slice of tap t -> ring stage t % RING
+        const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
+        glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)wave * 512 + lane * 8),
+                   __builtin_amdgcn_readfirstlane(st + wave * 1024));
+        if (two)
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)(wave + P16_BW) * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(st + (wave + P16_BW) * 1024));
+    };
+
+    // ---- patch operand plumbing -------------------------------------------------------------------------
+    const unsigned short* ahi = nullptr; const unsigned short* alo = nullptr;   // queries: this lane's patch corner
+    size_t krow0 = 0;                                                            // keys: halfs offset of (row py, pixel gx0)
+    if (KEYS) {
+        krow0 = (((size_t)b * gr.Hp + gy) * gr.Wp + gx0) * CH;
+    } else {
+        int gx = gx0 + i; if (gx >= row_len) gx = row_len - 1;
+        const int py = QS * gy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
+        const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
+        ahi = pa.map_hi + aoff; alo = pa.map_lo + aoff;
+    }
+    auto issue_row = [&](int r) {                      // keys: map row gy + r (38 pixels, hi | lo) -> row buffer r & 1
+        const unsigned dst = lds0 + P16_OFF_A + wave * (2 * P16_AROW) + (r & 1) * P16_AROW;
+        const size_t rowoff = krow0 + (size_t)r * gr.Wp * CH;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int p = wave + 4 * j;
-            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
-                       __builtin_amdgcn_readfirstlane(st + p * 1024));
+        for (int j = 0; j < 4; ++j) {                  // pieces: hi px 0-31, hi px 32-63, lo px 0-31, lo px 32-63
+            int p = (j & 1) * 32 + (lane >> 1);
+            if (gx0 + p > gr.Wp - 1) p = gr.Wp - 1 - gx0;                         // stay inside the map row
+            const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + rowoff + (size_t)p * CH + 8 * (lane & 1);
+            glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(dst + j * 1024));
         }
+    };
+    auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back
         const int kh = t / KS, kw = t - kh * KS;
         const size_t o = ((size_t)kh * gr.Wp + kw) * CH;
-        const unsigned sa = st + P16_STAGE_B + wave * 2048;
+        const unsigned sa = lds0 + P16_OFF_A + (unsigned)(t % P16_RING) * (P16_BW * 2048) + wave * 2048;
         glds16_asm(reinterpret_cast<const float*>(ahi + o), __builtin_amdgcn_readfirstlane(sa));
         glds16_asm(reinterpret_cast<const float*>(alo + o), __builtin_amdgcn_readfirstlane(sa + 1024));
     };
+    // landing of tap t+1: its weight pieces (and everything issued before them) are complete once at most the DMAs
+    // issued after them are outstanding.  Patch-row pieces issued in between only make the wait stricter.
+    auto wait_next = [&](int pending_taps) {           // pending_taps = taps issued after tap t+1 (0..PD-1)
+        constexpr int PER_Q = KEYS ? 0 : 2;
+        if (pending_taps >= 2) { if (two) dma_wait_le<2 * (2 + PER_Q)>(); else dma_wait_le<2 * (1 + PER_Q)>(); }
+        else if (pending_taps == 1) { if (two) dma_wait_le<2 + PER_Q>(); else dma_wait_le<1 + PER_Q>(); }
+        else dma_wait_le<0>();
+    };
+    static_assert(P16_PD == 3, "wait_next assumes a prefetch distance of 3 taps");
 
+    if (KEYS) issue_row(0);
 #pragma unroll
-    for (int t = 0; t < P16_PD; ++t) issue(t);
-    dma_wait_le<5 * (P16_PD - 1)>();
+    for (int t = 0; t < P16_PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
+    wait_next(P16_PD - 1);
     __syncthreads();
 
-    // B fragment of local tile n: lane (j = i, h) reads row n*32 + i: hi at +8h, lo at +16+8h (halfs)
-    const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes
+    const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes: B fragment row n*32 + i, half h
     for (int step = 0; step < P16_STEPS; ++step) {
-        if (step + P16_PD < P16_STEPS) issue(step + P16_PD);
-        const unsigned char* st = smem + (step % P16_RING) * P16_STAGE;
-        const unsigned char* sa = st + P16_STAGE_B + wave * 2048 + lane * 16;
+        const int kh = step / KS, kw = step - kh * KS;
+        if (KEYS && kw == 0 && kh + 1 < KS) issue_row(kh + 1);          // one kernel row ahead
+        if (step + P16_PD < P16_STEPS) { issue_w(step + P16_PD); if (!KEYS) issue_q(step + P16_PD); }
+        const unsigned char* sa;
+        int lo_off;
+        if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = 2048; }
+        else { sa = smem + P16_OFF_A + (step % P16_RING) * (P16_BW * 2048) + wave * 2048 + lane * 16; lo_off = 1024; }
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
-        const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + 1024));
-        const unsigned char* sb = st + boff;
+        const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
+        const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE_B + boff;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2));
@@ -179,19 +215,17 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo, cx[n], 0, 0, 0);
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi, cx[n], 0, 0, 0);
         }
-        // tap step+1 must have landed (for every wave) before anyone reads it
         const int left = P16_STEPS - 1 - step;                          // taps still to compute after this one
-        if (left >= P16_PD) dma_wait_le<5 * (P16_PD - 1)>();
-        else if (left == 2) dma_wait_le<5>();
-        else dma_wait_le<0>();
+        wait_next(left >= P16_PD ? P16_PD - 1 : (left >= 1 ? left - 1 : 0));
         __syncthreads();
     }
 
-    // epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i]
+    // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which];
     const int grid_row_base = gy * row_len + gx0;
+    float* csum = reinterpret_cast<float*>(smem);                       // [8 waves][NT*32] (ring is dead now)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = (n0 + n) * 32 + i;
@@ -204,34 +238,63 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             float v = (hh[n][r] + cx[n][r] * (1.0f / P16_LO_SCALE)) + bv;
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
+            if (VAR == 1 && v != 12345.678f) continue;
             if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
-            if (ok && hb != nullptr && col < DPAD) {
+            if (VAR != 3 && ok && hb != nullptr && col < DPAD) {
                 unsigned u = __float_as_uint(v);
                 u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;            // fp32 -> bf16, round to nearest even
                 hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
             }
             s += ok ? v : 0.f;
         }
-        if (!queries && pa.colsum != nullptr) {
+        if (KEYS) {
             s += __shfl_xor(s, 32);                                   // the two row halves of the tile
-            if (h == 0 && col < D && wave_valid) atomicAdd(&pa.colsum[(size_t)b * DS + col], (double)s);
+            if (h == 0) csum[wave * (NT * 32) + n * 32 + i] = s;
+        }
+    }
+    if (KEYS && pa.colpart != nullptr) {
+        // fixed-order block reduction of the key column sums (no atomics: the row mean must be reproducible)
+        __syncthreads();
+        if (tid < NT * 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < P16_BW; ++w) t += csum[w * (NT * 32) + tid];
+            pa.colpart[((size_t)b * pa.n_blocks_k + blk) * P16_OUT + n0 * 32 + tid] = t;
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void project16_kernel(Proj16Args pa) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[P16_RING * P16_STAGE];      // 80 KiB
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void project16_kernel(Proj16Args pa) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];           // 112 KiB
     // blocks: [query blocks x 2 halves][key blocks x 2 halves]; half 0 = output tiles 0..3, half 1 = tiles 4..6
     const int bid = blockIdx.x;
     const bool queries = bid < 2 * pa.n_blocks_q;                       // block-uniform
     const int rel = queries ? bid : bid - 2 * pa.n_blocks_q;
     const int half = rel & 1, blk = rel >> 1;
-    if (half == 0) project16_body<4>(pa, smem, 0, blk, queries);
-    else project16_body<3>(pa, smem, 4, blk, queries);
+    if (queries) {
+        if (half == 0) project16_body<4, false, VAR>(pa, smem, 0, blk);
+        else project16_body<3, false, VAR>(pa, smem, 4, blk);
+    } else {
+        if (half == 0) project16_body<4, true, VAR>(pa, smem, 0, blk);
+        else project16_body<3, true, VAR>(pa, smem, 4, blk);
+    }
 }
 
+// colsum[b][col] = sum over key blocks of colpart[b][blk][col], fixed order, fp64
+__global__ void colsum_reduce_kernel(int n_blocks_k, const float* __restrict__ colpart, double* __restrict__ colsum) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (col >= D) return;
+    double t = 0.0;
+    for (int k = 0; k < n_blocks_k; ++k) t += (double)colpart[((size_t)b * n_blocks_k + k) * P16_OUT + col];
+    colsum[(size_t)b * DS + col] = t;
+}
+
+int project16_key_blocks(const Grid& g) { return (((g.W + 31) / 32) * g.H + P16_BW - 1) / P16_BW; }
+
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
-                     const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
+                     const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
                      uint16_t* feat_q_bf16) {
     Proj16Args pa;
@@ -242,12 +305,20 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.rows_alloc_h[0] = feat_rows_h(g.N); pa.rows_alloc_h[1] = feat_rows_h(g.L);
     pa.segs[0] = (g.W + 31) / 32; pa.segs[1] = (g.Lw + 31) / 32;
     pa.n_items[0] = pa.segs[0] * g.H; pa.n_items[1] = pa.segs[1] * g.Lh;
-    pa.colsum = colsum;
-    const int nbq = (which & 2) ? (pa.n_items[1] + P16_WAVES - 1) / P16_WAVES : 0;
-    const int nbk = (which & 1) ? (pa.n_items[0] + P16_WAVES - 1) / P16_WAVES : 0;
-    pa.n_blocks_q = nbq;
-    hipLaunchKernelGGL(project16_kernel, dim3(2 * (nbq + nbk), B), dim3(256), 0, s, pa);
+    const int nbq = (which & 2) ? (pa.n_items[1] + P16_BW - 1) / P16_BW : 0;
+    const int nbk = (which & 1) ? project16_key_blocks(g) : 0;
+    pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
+    pa.colpart = (colsum != nullptr) ? colpart : nullptr;
+    static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
+    const dim3 grid(2 * (nbq + nbk), B), block(512);
+    if (var == 1) hipLaunchKernelGGL(project16_kernel<1>, grid, block, 0, s, pa);
+    else if (var == 3) hipLaunchKernelGGL(project16_kernel<3>, grid, block, 0, s, pa);
+    else hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
+    if (pa.colpart != nullptr && nbk > 0) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((D + 63) / 64, B), dim3(64), 0, s, nbk, colpart, colsum);
+        DAGL_LAUNCH_CHECK("colsum_reduce_kernel");
+    }
     return DAGL_OK;
 }
 
