@@ -101,12 +101,13 @@ struct Proj16Args {
 //                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
 //              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
 constexpr int P16_BW = 8;                              // waves per block
-constexpr int P16_RING = 4;
-constexpr int P16_PD = 3;                              // prefetch distance (taps)
-constexpr int P16_STAGE_B = 12 * 1024;                 // bytes per weight stage (>= NT*32*80, whole DMA pieces)
-constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 48 KiB: patch region
+constexpr int P16_RING = 6;
+constexpr int P16_PD = 5;                              // prefetch distance (taps): ~50 KiB in flight per CU covers the
+                                                       // ~1.1 us issue->landed latency of an LDS-DMA at 18 B/clk/CU
+constexpr int P16_STAGE_B = 10 * 1024;                 // bytes per weight stage (>= NT*32*80, whole DMA pieces)
+constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 60 KiB: patch region
 constexpr int P16_AROW = 4096;                         // keys: one staged map row per wave: hi 2 KiB | lo 2 KiB
-constexpr int P16_LDS = P16_OFF_A + P16_BW * 2 * P16_AROW;          // 112 KiB (queries: 48 + 4 stages x 8 x 2 KiB)
+constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 156 KiB (keys use 60 + 8 x 2 x 4 KiB = 124)
 
 template <int N>
 __device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -181,25 +182,18 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     };
     // landing of tap t+1: its weight pieces (and everything issued before them) are complete once at most the DMAs
     // issued after them are outstanding.  Patch-row pieces issued in between only make the wait stricter.
-    auto wait_next = [&](int pending_taps) {           // pending_taps = taps issued after tap t+1 (0..PD-1)
-        constexpr int PER_Q = KEYS ? 0 : 2;
-        if (pending_taps >= 2) { if (two) dma_wait_le<2 * (2 + PER_Q)>(); else dma_wait_le<2 * (1 + PER_Q)>(); }
-        else if (pending_taps == 1) { if (two) dma_wait_le<2 + PER_Q>(); else dma_wait_le<1 + PER_Q>(); }
-        else dma_wait_le<0>();
-    };
-    static_assert(P16_PD == 3, "wait_next assumes a prefetch distance of 3 taps");
+    constexpr int PER_Q = KEYS ? 0 : 2;
+#define P16_WAIT(P) do { if (two) dma_wait_le<(P) * (2 + PER_Q)>(); else dma_wait_le<(P) * (1 + PER_Q)>(); } while (0)
 
     if (KEYS) issue_row(0);
 #pragma unroll
     for (int t = 0; t < P16_PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
-    wait_next(P16_PD - 1);
+    P16_WAIT(P16_PD - 1);
     __syncthreads();
 
     const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes: B fragment row n*32 + i, half h
-    for (int step = 0; step < P16_STEPS; ++step) {
+    auto compute = [&](int step) {
         const int kh = step / KS, kw = step - kh * KS;
-        if (KEYS && kw == 0 && kh + 1 < KS) issue_row(kh + 1);          // one kernel row ahead
-        if (step + P16_PD < P16_STEPS) { issue_w(step + P16_PD); if (!KEYS) issue_q(step + P16_PD); }
         const unsigned char* sa;
         int lo_off;
         if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = 2048; }
@@ -215,10 +209,25 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo, cx[n], 0, 0, 0);
             cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi, cx[n], 0, 0, 0);
         }
-        const int left = P16_STEPS - 1 - step;                          // taps still to compute after this one
-        wait_next(left >= P16_PD ? P16_PD - 1 : (left >= 1 ? left - 1 : 0));
+    };
+    // steady state: PD-1 younger taps stay in flight across the barrier
+    for (int step = 0; step < P16_STEPS - P16_PD; ++step) {
+        if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
+        issue_w(step + P16_PD);
+        if (!KEYS) issue_q(step + P16_PD);
+        compute(step);
+        P16_WAIT(P16_PD - 1);
         __syncthreads();
     }
+    // drain: the last PD taps, nothing left to issue
+    compute(P16_STEPS - 5); P16_WAIT(3); __syncthreads();
+    compute(P16_STEPS - 4); P16_WAIT(2); __syncthreads();
+    compute(P16_STEPS - 3); P16_WAIT(1); __syncthreads();
+    compute(P16_STEPS - 2); P16_WAIT(0); __syncthreads();
+    compute(P16_STEPS - 1);
+    __syncthreads();
+#undef P16_WAIT
+    static_assert(P16_PD == 5, "the drain sequence above is written for PD = 5");
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
