@@ -100,14 +100,14 @@ struct Proj16Args {
 //   patches  : keys    -- per wave a 2-row ring of the map rows its 32 patches touch (38 pixels x hi|lo): every input
 //                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
 //              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
-constexpr int P16_BW = 8;                              // waves per block
-constexpr int P16_RING = 6;
-constexpr int P16_PD = 5;                              // prefetch distance (taps): ~50 KiB in flight per CU covers the
-                                                       // ~1.1 us issue->landed latency of an LDS-DMA at 18 B/clk/CU
+constexpr int P16_BW = 4;                              // waves per block (two blocks per CU: independent barriers)
+constexpr int P16_RING = 4;
+constexpr int P16_PD = 3;                              // prefetch distance (taps)
 constexpr int P16_STAGE_B = 10 * 1024;                 // bytes per weight stage (>= NT*32*80, whole DMA pieces)
-constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 60 KiB: patch region
+constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 40 KiB: patch region
 constexpr int P16_AROW = 4096;                         // keys: one staged map row per wave: hi 2 KiB | lo 2 KiB
-constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 156 KiB (keys use 60 + 8 x 2 x 4 KiB = 124)
+constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 72 KiB (keys: 40 + 4 x 2 x 4 KiB = 72)
+static_assert(P16_BW * 2 * P16_AROW <= P16_RING * P16_BW * 2048, "key row rings must fit the patch region");
 
 template <int N>
 __device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -125,7 +125,8 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
     constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
-    const bool two = wave < (PIECES - P16_BW);                                  // this wave issues 2 weight pieces per tap
+    constexpr int PBASE = PIECES / P16_BW;                                      // weight pieces per wave per tap ...
+    const bool extra = wave < (PIECES % P16_BW);                                // ... plus one for the first waves
 
     int item = blk * P16_BW + wave;
     const bool wave_valid = item < n_items;
@@ -142,13 +143,20 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int r = 0; r < 16; ++r) { hh[n][r] = 0.f; cx[n][r] = 0.f; }
 
     auto issue_w = [&](int t) {                        // weight slice of tap t -> ring stage t % RING
+        if (VAR == 6) return;
         const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
-        glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)wave * 512 + lane * 8),
-                   __builtin_amdgcn_readfirstlane(st + wave * 1024));
-        if (two)
-            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)(wave + P16_BW) * 512 + lane * 8),
-                       __builtin_amdgcn_readfirstlane(st + (wave + P16_BW) * 1024));
+#pragma unroll
+        for (int j = 0; j < PBASE; ++j) {
+            const int p = wave + P16_BW * j;
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
+        if (extra) {
+            const int p = wave + P16_BW * PBASE;
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
     };
 
     // ---- patch operand plumbing -------------------------------------------------------------------------
@@ -163,6 +171,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         ahi = pa.map_hi + aoff; alo = pa.map_lo + aoff;
     }
     auto issue_row = [&](int r) {                      // keys: map row gy + r (38 pixels, hi | lo) -> row buffer r & 1
+        if (VAR == 6) return;
         const unsigned dst = lds0 + P16_OFF_A + wave * (2 * P16_AROW) + (r & 1) * P16_AROW;
         const size_t rowoff = krow0 + (size_t)r * gr.Wp * CH;
 #pragma unroll
@@ -183,7 +192,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     // landing of tap t+1: its weight pieces (and everything issued before them) are complete once at most the DMAs
     // issued after them are outstanding.  Patch-row pieces issued in between only make the wait stricter.
     constexpr int PER_Q = KEYS ? 0 : 2;
-#define P16_WAIT(P) do { if (two) dma_wait_le<(P) * (2 + PER_Q)>(); else dma_wait_le<(P) * (1 + PER_Q)>(); } while (0)
+#define P16_WAIT(P) do { if (VAR == 4 || VAR == 6) break; if (extra) dma_wait_le<(P) * (PBASE + 1 + PER_Q)>(); else dma_wait_le<(P) * (PBASE + PER_Q)>(); } while (0)
 
     if (KEYS) issue_row(0);
 #pragma unroll
@@ -191,6 +200,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     P16_WAIT(P16_PD - 1);
     __syncthreads();
 
+    if (VAR == 9) { if (hh[0][0] != 0.f) pa.feat[which][0] = 1.f; return; }
     const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes: B fragment row n*32 + i, half h
     auto compute = [&](int step) {
         const int kh = step / KS, kw = step - kh * KS;
@@ -201,17 +211,28 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
         const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
         const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE_B + boff;
+        // all fragment reads of the tap first (one exposed LDS latency per tap instead of one per tile), then the
+        // MFMAs grouped so that no instruction depends on its predecessor
+        f16x8 w_hi[NT], w_lo[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2));
-            const f16x8 w_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + 32));
-            hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi, hh[n], 0, 0, 0);
-            cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo, cx[n], 0, 0, 0);
-            cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi, cx[n], 0, 0, 0);
+            w_hi[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2));
+            w_lo[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + 32));
         }
+        if (VAR == 5) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(fa_hi), "v"(fa_lo), "v"(w_hi[n]), "v"(w_lo[n]));
+            return;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi[n], hh[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo[n], cx[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi[n], cx[n], 0, 0, 0);
     };
     // steady state: PD-1 younger taps stay in flight across the barrier
-    for (int step = 0; step < P16_STEPS - P16_PD; ++step) {
+    for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 22 : P16_STEPS - P16_PD); ++step) {
         if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
         issue_w(step + P16_PD);
         if (!KEYS) issue_q(step + P16_PD);
@@ -220,14 +241,12 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         __syncthreads();
     }
     // drain: the last PD taps, nothing left to issue
-    compute(P16_STEPS - 5); P16_WAIT(3); __syncthreads();
-    compute(P16_STEPS - 4); P16_WAIT(2); __syncthreads();
     compute(P16_STEPS - 3); P16_WAIT(1); __syncthreads();
     compute(P16_STEPS - 2); P16_WAIT(0); __syncthreads();
     compute(P16_STEPS - 1);
     __syncthreads();
 #undef P16_WAIT
-    static_assert(P16_PD == 5, "the drain sequence above is written for PD = 5");
+    static_assert(P16_PD == 3, "the drain sequence above is written for PD = 3");
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
@@ -274,7 +293,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 }
 
 template <int VAR>
-__global__ __launch_bounds__(512, 2) void project16_kernel(Proj16Args pa) {
+__global__ __launch_bounds__(64 * P16_BW, 2) void project16_kernel(Proj16Args pa) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];           // 112 KiB
     // blocks: [query blocks x 2 halves][key blocks x 2 halves]; half 0 = output tiles 0..3, half 1 = tiles 4..6
     const int bid = blockIdx.x;
@@ -290,14 +309,19 @@ __global__ __launch_bounds__(512, 2) void project16_kernel(Proj16Args pa) {
     }
 }
 
-// colsum[b][col] = sum over key blocks of colpart[b][blk][col], fixed order, fp64
-__global__ void colsum_reduce_kernel(int n_blocks_k, const float* __restrict__ colpart, double* __restrict__ colsum) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+// colsum[b][col] = sum over key blocks of colpart[b][blk][col]: one wave per column, lane-strided partial sums
+// + a fixed-order butterfly (deterministic), fp64
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(int n_blocks_k, const float* __restrict__ colpart,
+                                                            double* __restrict__ colsum) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (col >= D) return;
     double t = 0.0;
-    for (int k = 0; k < n_blocks_k; ++k) t += (double)colpart[((size_t)b * n_blocks_k + k) * P16_OUT + col];
-    colsum[(size_t)b * DS + col] = t;
+    for (int k = lane; k < n_blocks_k; k += 64) t += (double)colpart[((size_t)b * n_blocks_k + k) * P16_OUT + col];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) colsum[(size_t)b * DS + col] = t;
 }
 
 int project16_key_blocks(const Grid& g) { return (((g.W + 31) / 32) * g.H + P16_BW - 1) / P16_BW; }
@@ -319,13 +343,19 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
     pa.colpart = (colsum != nullptr) ? colpart : nullptr;
     static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
-    const dim3 grid(2 * (nbq + nbk), B), block(512);
+    const dim3 grid(2 * (nbq + nbk), B), block(64 * P16_BW);
     if (var == 1) hipLaunchKernelGGL(project16_kernel<1>, grid, block, 0, s, pa);
     else if (var == 3) hipLaunchKernelGGL(project16_kernel<3>, grid, block, 0, s, pa);
+    else if (var == 4) hipLaunchKernelGGL(project16_kernel<4>, grid, block, 0, s, pa);
+    else if (var == 5) hipLaunchKernelGGL(project16_kernel<5>, grid, block, 0, s, pa);
+    else if (var == 6) hipLaunchKernelGGL(project16_kernel<6>, grid, block, 0, s, pa);
+    else if (var == 7) hipLaunchKernelGGL(project16_kernel<7>, grid, block, 0, s, pa);
+    else if (var == 8) hipLaunchKernelGGL(project16_kernel<8>, grid, block, 0, s, pa);
+    else if (var == 9) hipLaunchKernelGGL(project16_kernel<9>, grid, block, 0, s, pa);
     else hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
     if (pa.colpart != nullptr && nbk > 0) {
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((D + 63) / 64, B), dim3(64), 0, s, nbk, colpart, colsum);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((D + 3) / 4, B), dim3(256), 0, s, nbk, colpart, colsum);
         DAGL_LAUNCH_CHECK("colsum_reduce_kernel");
     }
     return DAGL_OK;
