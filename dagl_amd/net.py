@@ -1,0 +1,145 @@
+"""The caller of the block and the inference driver around it, restated so that the
+HIP block can be exercised the way the reference exercises ``CE``: inside the 3-stage x 4-head ``CES`` module
+of the EDSR-style trunk ``RR`` and under the recursive 4-way tiling of ``forward_chop``.
+
+Everything here except ``CE`` is stock PyTorch-ROCm (convs, PReLU).  Module / parameter names and registration order
+follow the reference (``RR`` DN_Gray/model/dagl.py:11-54, ``CES`` :74-119, ``ResBlock`` DN_Gray/model/common.py:59-79),
+so a reference ``state_dict`` loads strictly.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ce import CE
+
+
+def _conv(cin, cout, k):
+    return nn.Conv2d(cin, cout, k, padding=k // 2)       # common.default_conv
+
+
+class ResBlock(nn.Module):
+    """conv3x3 - PReLU - conv3x3 + skip (common.py:59-79, bn=False, res_scale=1)."""
+
+    def __init__(self, n_feats, res_scale=1.0):
+        super().__init__()
+        self.body = nn.Sequential(_conv(n_feats, n_feats, 3), nn.PReLU(), _conv(n_feats, n_feats, 3))
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        return self.body(x).mul(self.res_scale) + x
+
+
+class CES(nn.Module):
+    """Three stages of four patch-graph heads, each stage mixed by a 1x1 conv + residual (dagl.py:74-119)."""
+
+    def __init__(self, in_channels, num=4, ce_cls=CE):
+        super().__init__()
+        self.RBS1 = nn.Sequential(*[ResBlock(in_channels) for _ in range(num)])
+        self.RBS2 = nn.Sequential(*[ResBlock(in_channels) for _ in range(num)])
+        for stage in (1, 2, 3):
+            for head in (1, 2, 3, 4):
+                setattr(self, f"c{stage}_{head}", ce_cls(in_channels=in_channels))
+            setattr(self, f"c{stage}_c", nn.Conv2d(in_channels, in_channels, 1, 1, 0))
+
+    def _stage(self, s, x):
+        heads = [getattr(self, f"c{s}_{h}")(x) for h in (1, 2, 3, 4)]
+        return getattr(self, f"c{s}_c")(torch.cat(heads, dim=1)) + x
+
+    def forward(self, x):
+        out = self._stage(1, x)
+        out = self.RBS1(out)
+        out = self._stage(2, out)
+        out = self.RBS2(out)
+        return self._stage(3, out)
+
+
+class _MeanShift(nn.Conv2d):
+    """Registered by the reference (``add_mean``, dagl.py:41) but never applied; kept for state_dict compatibility."""
+
+    def __init__(self, rgb_range, rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1.0, 1.0, 1.0), sign=1):
+        super().__init__(3, 3, kernel_size=1)
+        std = torch.tensor(rgb_std)
+        self.weight.data = torch.eye(3).view(3, 3, 1, 1) / std.view(3, 1, 1, 1)
+        self.bias.data = sign * rgb_range * torch.tensor(rgb_mean) / std
+        for p in self.parameters():
+            p.requires_grad = False
+
+
+class RR(nn.Module):
+    """head conv - 8 ResBlocks - CES - 8 ResBlocks - conv - tail conv, global residual (dagl.py:11-54)."""
+
+    def __init__(self, n_resblocks=16, n_feats=64, n_colors=1, res_scale=1.0, rgb_range=1.0, ce_cls=CE):
+        super().__init__()
+        body = [ResBlock(n_feats, res_scale) for _ in range(n_resblocks // 2)]
+        body.append(CES(n_feats, ce_cls=ce_cls))
+        body += [ResBlock(n_feats, res_scale) for _ in range(n_resblocks // 2)]
+        body.append(_conv(n_feats, n_feats, 3))
+        self.add_mean = _MeanShift(rgb_range)
+        self.head = nn.Sequential(_conv(n_colors, n_feats, 3))
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(_conv(n_feats, n_colors, 3))
+
+    def forward(self, x):
+        return x + self.tail(self.body(self.head(x)))
+
+
+def seeded_state_dict(template: "OrderedDict[str, torch.Tensor]", seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """Regenerable stand-in for a trained checkpoint (none ships with the reference): every tensor of ``template`` in
+    state_dict order from ONE numpy PCG64 stream -- weights uniform(+-1/sqrt(fan_in)), biases uniform(+-1/sqrt(fan_in)
+    of their layer) approximated by +-0.05, PReLU slopes 0.25, ``add_mean`` left as built."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, t in template.items():
+        if name.startswith("add_mean"):
+            out[name] = t.clone()
+        elif t.dim() >= 2:
+            fan_in = int(np.prod(t.shape[1:]))
+            b = 1.0 / math.sqrt(fan_in)
+            out[name] = torch.from_numpy(rng.uniform(-b, b, size=tuple(t.shape)).astype(np.float32))
+        elif name.endswith("bias"):
+            out[name] = torch.from_numpy(rng.uniform(-0.05, 0.05, size=tuple(t.shape)).astype(np.float32))
+        else:                                             # PReLU slope
+            out[name] = torch.full(tuple(t.shape), 0.25)
+    return out
+
+
+def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4):
+    """Recursive 4-way tiled inference: the reference's ``Model.forward_chop`` for scale 1 without self-ensemble
+    (DN_Gray/model/__init__.py:179-231).  A tile of h x w is split into four overlapping corner tiles of
+    (h//2//4*4 + 24) x (w//2//4*4 + 24) until the corner area drops below ``min_size``; the four leaf tiles of one
+    split form one batch; the outputs' inner quadrants are stitched back."""
+    b, c, h, w = x.shape
+    h_half, w_half = h // 2, w // 2
+    h_size = (h_half // shave_scale) * shave_scale + shave_size_max
+    w_size = (w_half // shave_scale) * shave_scale + shave_size_max
+    tiles = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
+             x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
+    if w_size * h_size < min_size:
+        # the reference runs the four leaves one by one with n_GPUs == 1 (__init__.py:203-209)
+        outs = [model(t.contiguous()) for t in tiles]
+    else:
+        outs = [chop_forward(model, t, min_size, shave_size_max, shave_scale) for t in tiles]
+    out = x.new_empty(b, c, h, w)
+    out[:, :, 0:h_half, 0:w_half] = outs[0][:, :, 0:h_half, 0:w_half]
+    out[:, :, 0:h_half, w_half:w] = outs[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
+    out[:, :, h_half:h, 0:w_half] = outs[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
+    out[:, :, h_half:h, w_half:w] = outs[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
+    return out
+
+
+def psnr(img: torch.Tensor, ref: torch.Tensor, data_range: float = 1.0) -> float:
+    """Per-image PSNR as ``batch_PSNR`` computes it (DN_Gray/utils.py:18-24: skimage compare_psnr on the float images)."""
+    mse = torch.mean((img.double() - ref.double()) ** 2).item()
+    return float("inf") if mse == 0 else 10.0 * math.log10(data_range ** 2 / mse)
+
+
+def set12_protocol_noise(clean: torch.Tensor, sigma: float = 50.0, rgb_range: float = 1.0) -> torch.Tensor:
+    """Noise of the reference test script (DN_Gray/test.py:55-58): torch.manual_seed(1), CPU normal_()."""
+    torch.manual_seed(1)
+    noise = torch.FloatTensor(clean.size()).normal_(mean=0, std=sigma / (255.0 / rgb_range))
+    return clean + noise
