@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--scan", default="screened", choices=["screened", "exact"],
                     help="screened: bf16 matrix-core screen + exact refine (default); exact: all scores on the fp32 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quality", action="store_true", help="skip the Set12 sigma=50 PSNR-delta leg")
     ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
     return ap.parse_args()
 
@@ -74,6 +75,32 @@ def cpu_baseline(args, params, mode, k):
     return {"value": L / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 forward of oracle/ce_oracle.py (dense torch-CPU restatement of CE.forward) on "
                       f"[1,64,{size},{size}] fp32, L={L} query patches, {dt:.2f} s, after one 64x64 warm-up"}
+
+
+def quality_leg(dev):
+    """PSNR on Set12 sigma=50 of the full network (12 HIP heads) vs the reference forward with the same regenerable
+    weights (numbers committed by tests/golden/make_set12_psnr.py, which ran the reference on CPU)."""
+    import numpy as np
+    from dagl_amd.net import RR, chop_forward_batched, psnr, seeded_state_dict, set12_protocol_noise
+    gdir = os.path.join(REPO, "tests", "golden")
+    ref = json.load(open(os.path.join(gdir, "set12_psnr_ref.json")))
+    imgs = np.load(os.path.join(gdir, "set12.npz"))
+    net = RR().eval()
+    net.load_state_dict(seeded_state_dict(net.state_dict(), ref["seed"]), strict=True)
+    net = net.to(dev)
+    deltas, t0 = {}, time.perf_counter()
+    for name in sorted(ref["images"]):
+        clean = torch.from_numpy(imgs[f"img_{name}"].astype(np.float32) / 255.0)[None, None]
+        noisy = set12_protocol_noise(clean, 50.0, 1.0)
+        with torch.no_grad():
+            out = torch.clamp(chop_forward_batched(net, noisy.to(dev)), 0.0, 1.0).cpu()
+        deltas[name] = psnr(out, clean) - ref["images"][name]["psnr_out"]
+    return {"dataset": "Set12 (12 images), sigma=50, reference test protocol (tiled inference, no self-ensemble)",
+            "weights": f"regenerable stand-in checkpoint (numpy PCG64 seed {ref['seed']}); no trained weights ship with the reference",
+            "psnr_delta_db_max_abs": max(abs(v) for v in deltas.values()),
+            "psnr_delta_db_mean": sum(deltas.values()) / len(deltas),
+            "psnr_ref_mean_db": sum(r["psnr_out"] for r in ref["images"].values()) / len(ref["images"]),
+            "bar_db": 0.02, "seconds": time.perf_counter() - t0}
 
 
 def main():
@@ -199,6 +226,8 @@ def main():
             "stage_ms": {STAGE_NAMES[i]: float(mean_ms[i]) for i in range(8)},
             "hip_block_ms": float(mean_ms.sum()),
         }
+        if world == 1 and not args.no_quality:
+            line["quality"] = quality_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, params, mode, k)
         print(json.dumps(line))

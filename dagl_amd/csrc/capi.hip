@@ -270,22 +270,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
         const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
-        if (B == 1) {
-            zl.add(X + (size_t)g.N * DS, (size_t)(rx - g.N) * DS * sizeof(float));
-            zl.add(Wq + (size_t)g.L * DS, (size_t)(rq - g.L) * DS * sizeof(float));
-            if (p.screen) {
-                zl.add(Xh + (size_t)g.N * DSH, (size_t)(hx - g.N) * DSH * sizeof(uint16_t));
-                zl.add(Wqh + (size_t)g.L * DSH, (size_t)(hq - g.L) * DSH * sizeof(uint16_t));
-            }
-        } else {
-            for (int b = 0; b < B; ++b) {
-                DAGL_HIP_TRY(hipMemsetAsync(X + ((size_t)b * rx + g.N) * DS, 0, (size_t)(rx - g.N) * DS * sizeof(float), s));
-                DAGL_HIP_TRY(hipMemsetAsync(Wq + ((size_t)b * rq + g.L) * DS, 0, (size_t)(rq - g.L) * DS * sizeof(float), s));
-                if (p.screen) {
-                    DAGL_HIP_TRY(hipMemsetAsync(Xh + ((size_t)b * hx + g.N) * DSH, 0, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), s));
-                    DAGL_HIP_TRY(hipMemsetAsync(Wqh + ((size_t)b * hq + g.L) * DSH, 0, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), s));
-                }
-            }
+        zl.add(X + (size_t)g.N * DS, (size_t)(rx - g.N) * DS * sizeof(float), B, (size_t)rx * DS * sizeof(float));
+        zl.add(Wq + (size_t)g.L * DS, (size_t)(rq - g.L) * DS * sizeof(float), B, (size_t)rq * DS * sizeof(float));
+        if (p.screen) {
+            zl.add(Xh + (size_t)g.N * DSH, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), B, (size_t)hx * DSH * sizeof(uint16_t));
+            zl.add(Wqh + (size_t)g.L * DSH, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), B, (size_t)hq * DSH * sizeof(uint16_t));
         }
         zl.add(colsum, align_up((size_t)B * DS * sizeof(double), 16));
         zl.add(stats, 4 * sizeof(int64_t));

@@ -95,11 +95,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int feat_rows(int rows) { return round_up(rows, KT) + KT; }
 inline int feat_rows_h(int rows) { return round_up(rows, SKEYS) + SKEYS; }   // bf16 copies (64-row steps)
 
-struct ZeroList {                    // small regions cleared by one launch (16-byte granular)
-    int n = 0;
+struct ZeroList {                    // small regions cleared by one launch (16-byte granular), each repeated
+    int n = 0;                       // `reps` times at a byte stride (one per image of the batch)
     void* ptr[12];
     size_t bytes[12];
-    void add(void* p, size_t b) { if (b) { ptr[n] = p; bytes[n] = b; ++n; } }
+    size_t stride[12];
+    int reps[12];
+    void add(void* p, size_t b, int r = 1, size_t st = 0) {
+        if (b && r > 0) { ptr[n] = p; bytes[n] = b; reps[n] = r; stride[n] = st; ++n; }
+    }
 };
 int launch_zero_regions(hipStream_t s, const ZeroList& z);
 int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2);

@@ -63,20 +63,26 @@ int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, 
 __global__ void zero_regions_kernel(ZeroList z) {
     const int r = blockIdx.y;
     if (r >= z.n) return;
-    uint4* p = reinterpret_cast<uint4*>(z.ptr[r]);
     const size_t n16 = z.bytes[r] / 16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int rep = blockIdx.z; rep < z.reps[r]; rep += gridDim.z) {
+        uint4* p = reinterpret_cast<uint4*>(static_cast<char*>(z.ptr[r]) + (size_t)rep * z.stride[r]);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+            p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 int launch_zero_regions(hipStream_t s, const ZeroList& z) {
     if (z.n == 0) return DAGL_OK;
-    for (int i = 0; i < z.n; ++i)
-        if ((reinterpret_cast<uintptr_t>(z.ptr[i]) % 16) != 0 || (z.bytes[i] % 16) != 0) {
+    int max_reps = 1;
+    for (int i = 0; i < z.n; ++i) {
+        if ((reinterpret_cast<uintptr_t>(z.ptr[i]) % 16) != 0 || (z.bytes[i] % 16) != 0 || (z.stride[i] % 16) != 0) {
             set_error("zero_regions: region %d not 16-byte granular", i);
             return DAGL_ERR_INVALID;
         }
-    hipLaunchKernelGGL(zero_regions_kernel, dim3(64, z.n), dim3(256), 0, s, z);
+        if (z.reps[i] > max_reps) max_reps = z.reps[i];
+    }
+    if (max_reps > 64) max_reps = 64;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(max_reps > 1 ? 8 : 64, z.n, max_reps), dim3(256), 0, s, z);
     DAGL_LAUNCH_CHECK("zero_regions_kernel");
     return DAGL_OK;
 }

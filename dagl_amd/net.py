@@ -132,6 +132,56 @@ def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: 
     return out
 
 
+def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
+                         max_batch: int = 64):
+    """Same tiling and stitching as ``chop_forward``, but all leaf tiles (they share one shape) go through the network in
+    batches of up to ``max_batch`` instead of one by one: tiles are independent, and a batch is just
+    another grid dimension of the HIP block.  Device-side equivalent of the reference's per-leaf loop."""
+    plan = []                                             # (depth-first) leaf views, in the order chop_forward visits them
+
+    def collect(t):
+        b, c, h, w = t.shape
+        h_half, w_half = h // 2, w // 2
+        h_size = (h_half // shave_scale) * shave_scale + shave_size_max
+        w_size = (w_half // shave_scale) * shave_scale + shave_size_max
+        tiles = [t[:, :, 0:h_size, 0:w_size], t[:, :, 0:h_size, (w - w_size):w],
+                 t[:, :, (h - h_size):h, 0:w_size], t[:, :, (h - h_size):h, (w - w_size):w]]
+        if w_size * h_size < min_size:
+            plan.extend(tiles)
+        else:
+            for q in tiles:
+                collect(q)
+
+    collect(x)
+    shapes = {tuple(t.shape) for t in plan}
+    if len(shapes) != 1:                                  # ragged leaves (odd sizes): fall back to the sequential driver
+        return chop_forward(model, x, min_size, shave_size_max, shave_scale)
+    outs = []
+    for i in range(0, len(plan), max_batch):
+        batch = torch.cat([t for t in plan[i:i + max_batch]], dim=0).contiguous()
+        outs.extend(model(batch).split(x.shape[0], dim=0))
+    it = iter(outs)
+
+    def stitch(t):
+        b, c, h, w = t.shape
+        h_half, w_half = h // 2, w // 2
+        h_size = (h_half // shave_scale) * shave_scale + shave_size_max
+        w_size = (w_half // shave_scale) * shave_scale + shave_size_max
+        if w_size * h_size < min_size:
+            o = [next(it) for _ in range(4)]
+        else:
+            o = [stitch(q) for q in (t[:, :, 0:h_size, 0:w_size], t[:, :, 0:h_size, (w - w_size):w],
+                                     t[:, :, (h - h_size):h, 0:w_size], t[:, :, (h - h_size):h, (w - w_size):w])]
+        out = t.new_empty(b, c, h, w)
+        out[:, :, 0:h_half, 0:w_half] = o[0][:, :, 0:h_half, 0:w_half]
+        out[:, :, 0:h_half, w_half:w] = o[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
+        out[:, :, h_half:h, 0:w_half] = o[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
+        out[:, :, h_half:h, w_half:w] = o[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
+        return out
+
+    return stitch(x)
+
+
 def psnr(img: torch.Tensor, ref: torch.Tensor, data_range: float = 1.0) -> float:
     """Per-image PSNR as ``batch_PSNR`` computes it (DN_Gray/utils.py:18-24: skimage compare_psnr on the float images)."""
     mse = torch.mean((img.double() - ref.double()) ** 2).item()

@@ -25,7 +25,7 @@ def net():
 
 @pytest.mark.parametrize("name", ["01", "05", "07", "09", "12"])
 def test_set12_psnr_delta(net, name):
-    from dagl_amd.net import chop_forward, psnr, set12_protocol_noise
+    from dagl_amd.net import chop_forward, chop_forward_batched, psnr, set12_protocol_noise
     model, ref = net
     imgs = np.load(os.path.join(GOLDEN_DIR, "set12.npz"))
     subs = np.load(os.path.join(GOLDEN_DIR, "set12_out_sub.npz"))
@@ -40,3 +40,8 @@ def test_set12_psnr_delta(net, name):
     assert abs(d) <= 0.02
     # and the images themselves agree (every 8th pixel of the reference output is committed)
     assert normwise(out[0, 0, ::8, ::8].numpy(), subs[f"out_{name}"]) <= 2e-3
+    # the batched tile driver gives the same image (tiles are independent)
+    with torch.no_grad():
+        outb = torch.clamp(chop_forward_batched(model, noisy.to("cuda:0")), 0.0, 1.0).cpu()
+    assert abs(psnr(outb, clean) - r["psnr_out"]) <= 0.02
+    assert normwise(outb.numpy(), out.numpy()) <= 2e-3

@@ -68,3 +68,13 @@ def test_trunk_runs_with_stub_heads_and_psnr_helper():
     assert abs(psnr(clean + 0.1, clean) - 20.0) < 1e-4          # fp32 image, 0.1 is not exact
     n1, n2 = set12_protocol_noise(clean), set12_protocol_noise(clean)
     assert torch.equal(n1, n2)
+
+
+def test_batched_chop_equals_sequential_chop():
+    from dagl_amd.net import chop_forward, chop_forward_batched
+    net = nn.Conv2d(1, 1, 5, padding=2).eval()
+    for shape in ((1, 1, 256, 256), (1, 1, 203, 310), (2, 1, 128, 160)):
+        x = torch.rand(*shape)
+        with torch.no_grad():
+            a, b = chop_forward(net, x), chop_forward_batched(net, x, max_batch=16)
+        assert torch.allclose(a, b, atol=1e-6, rtol=0)
