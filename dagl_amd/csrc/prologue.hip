@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
                                                         const float* __restrict__ g_w, const float* __restrict__ g_b,
                                                         const float* __restrict__ th_w, const float* __restrict__ th_b,
                                                         float* __restrict__ b1p, float* __restrict__ b2p) {
-    __shared__ float ring[PRO_ROWS][PC][PRO_LS];                // 69.6 KiB
+    __shared__ __attribute__((aligned(16))) float ring[PRO_ROWS][PC][PRO_LS];                // 69.6 KiB
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -38,14 +38,25 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
     const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
     const float* xb = x + (size_t)b * PC * H * W;
 
-    // weights -> registers.  B fragment of MFMA (tap, T): lane (n = i, k = g) holds w[o = i][c = 4T + g][tap]
+    // weights -> registers, through LDS: a coalesced block copy of g_w / theta_w into the (not yet used) ring, then
+    // every lane picks the 160 values of its B fragments -- lane (n = i, k = g) of MFMA (tap, T) holds
+    // w[o = i][c = 4T + g][tap] -- with LDS reads instead of 160 scattered 4-byte global loads.
     float wg[9][16], wt[16];
+    {
+        float* wl = &ring[0][0][0];                               // 16*64*9 + 16*64 = 10240 floats < ring size
+        for (int e = tid; e < 16 * PC * 9 / 4; e += 256)
+            reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(g_w)[e];
+        for (int e = tid; e < 16 * PC / 4; e += 256)
+            reinterpret_cast<float4*>(wl + 16 * PC * 9)[e] = reinterpret_cast<const float4*>(th_w)[e];
+        __syncthreads();
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int T = 0; T < 16; ++T) wg[tap][T] = g_w[((size_t)i * PC + 4 * T + g) * 9 + tap];
+            for (int T = 0; T < 16; ++T) wg[tap][T] = wl[(i * PC + 4 * T + g) * 9 + tap];
 #pragma unroll
-    for (int T = 0; T < 16; ++T) wt[T] = th_w[(size_t)i * PC + 4 * T + g];
+        for (int T = 0; T < 16; ++T) wt[T] = wl[16 * PC * 9 + i * PC + 4 * T + g];
+        __syncthreads();
+    }
     const float bias1 = g_b[i], bias2 = th_b[i];
 
     // staging: thread handles elements idx = tid + 256*j of a [64 ch][66 px] row
@@ -149,8 +160,8 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     int rcz = launch_zero_borders(s, B, g.H, g.W, b1p, b2p);
     if (rcz) return rcz;
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
-    // ~2 blocks per CU over the whole launch, at least 2 rows per block
-    int chunks = (512 + strips * B - 1) / (strips * B);
+    // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
+    int chunks = (256 + strips * B - 1) / (strips * B);
     if (chunks > (g.H + 1) / 2) chunks = (g.H + 1) / 2;
     if (chunks < 1) chunks = 1;
     const int rows_per_block = (g.H + chunks - 1) / chunks;
