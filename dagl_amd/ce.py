@@ -80,8 +80,13 @@ class CE(nn.Module):
             raise DaglError(f"CE.forward: expected [B,{self.in_channels},H,W], got {tuple(b.shape)}")
         if not b.is_cuda:
             raise DaglError("CE.forward: input must be on the GPU; dagl_amd has no CPU path")
-        if b.dtype != torch.float32:
-            raise DaglError("CE.forward: fp32 input expected")
+        in_dtype = b.dtype
+        if in_dtype in (torch.bfloat16, torch.float16):
+            # reduced-precision feature maps (BASELINE config 3): the block itself computes in fp32 with the bf16
+            # matrix-core screen; I/O is converted at the boundary
+            b = b.float()
+        elif in_dtype != torch.float32:
+            raise DaglError(f"CE.forward: unsupported dtype {in_dtype}")
         if torch.is_grad_enabled() and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise DaglError("CE.forward: the HIP block has no backward yet; call under torch.no_grad()")
         params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
@@ -89,4 +94,4 @@ class CE(nn.Module):
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"))
         self.last_info = info
-        return out
+        return out if in_dtype == torch.float32 else out.to(in_dtype)

@@ -182,6 +182,32 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
     return stitch(x)
 
 
+def forward_x8(forward_fn, x: torch.Tensor) -> torch.Tensor:
+    """Geometric self-ensemble of the reference (``test_x8`` / ``forward_x8``, DN_Gray/model/__init__.py:53-62, :260-293):
+    the 8 flip/transpose variants go through ``forward_fn`` and the back-transformed outputs are averaged.  The reference
+    round-trips every variant through numpy on the host; here the transforms stay on the device."""
+    outs = []
+    for transpose in (False, True):
+        for vflip in (False, True):
+            for hflip in (False, True):
+                t = x
+                if hflip:
+                    t = t.flip(-1)
+                if vflip:
+                    t = t.flip(-2)
+                if transpose:
+                    t = t.transpose(-1, -2)
+                y = forward_fn(t.contiguous())
+                if transpose:
+                    y = y.transpose(-1, -2)
+                if vflip:
+                    y = y.flip(-2)
+                if hflip:
+                    y = y.flip(-1)
+                outs.append(y)
+    return torch.stack(outs, dim=0).mean(dim=0)
+
+
 def psnr(img: torch.Tensor, ref: torch.Tensor, data_range: float = 1.0) -> float:
     """Per-image PSNR as ``batch_PSNR`` computes it (DN_Gray/utils.py:18-24: skimage compare_psnr on the float images)."""
     mse = torch.mean((img.double() - ref.double()) ** 2).item()

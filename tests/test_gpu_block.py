@@ -209,3 +209,56 @@ def test_full_size_properties(H, W, mode, k):
         with torch.no_grad():
             ce.bias_conv.weight.zero_(); ce.bias_conv.bias.fill_(-1e4)
             assert float(ce(x).abs().max()) == 0.0
+
+
+def test_reduced_precision_io_and_large_window_config():
+    """BASELINE configs 3 and 4 run through the same kernels: bf16 feature maps (converted at the boundary) and a
+    1024x1024 whole-image search window with adaptive selection capped at k_max = 16."""
+    from dagl_amd.synth import make_ce_params, make_features
+    d = _dev()
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(61, variant="sparse", sparse_gain=2.6).items()}
+    ce = _module(params, "topk", 8)
+    x = torch.from_numpy(make_features(61, 1, 64, 128, 128)).to(d)
+    with torch.no_grad():
+        y32 = ce(x)
+        y16 = ce(x.to(torch.bfloat16))
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+    with torch.no_grad():
+        ref = ce(x.to(torch.bfloat16).float())
+    assert torch.equal(y16, ref.to(torch.bfloat16))          # same math, only I/O rounding
+    # config 4: 1024x1024, adaptive AND top-16
+    ce4 = _module(params, "adaptive_topk", 16)
+    x4 = torch.from_numpy(make_features(62, 1, 64, 1024, 1024)).to(d)
+    out4, info4 = _run_debug(ce4, x4)
+    assert out4.shape == (1, 16, 1024, 1024) and torch.isfinite(out4).all()
+    deg = info4["deg"].cpu()
+    assert int(deg.max()) <= 16 and int(deg.min()) >= 0
+    assert float(info4["rowsum"].max()) <= 1.0 + 1e-6
+
+
+def test_concurrent_calls_from_two_threads():
+    """nn.DataParallel-style use: two host threads, two streams, two module replicas, at the same time."""
+    import threading
+    path = [p for p in CASES if "gray_sparse_64x64" in p][0]
+    meta, g = load_golden(path)
+    x, params = case_inputs(meta)
+    xd = x.to(_dev())
+    mods = [_module(params), _module(params)]
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(5):
+                    outs[i] = mods[i](xd)
+            s.synchronize()
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert torch.equal(outs[0], outs[1])
+    assert normwise(outs[0].cpu().numpy(), g["out"]) <= TOL_OUT

@@ -78,3 +78,14 @@ def test_batched_chop_equals_sequential_chop():
         with torch.no_grad():
             a, b = chop_forward(net, x), chop_forward_batched(net, x, max_batch=16)
         assert torch.allclose(a, b, atol=1e-6, rtol=0)
+
+
+def test_forward_x8_is_exact_for_an_equivariant_network():
+    """A pointwise network commutes with flips / transposes: the ensemble must return its plain output."""
+    from dagl_amd.net import forward_x8
+    f = lambda t: t * 2.0 + 1.0
+    x = torch.rand(2, 1, 12, 20)
+    assert torch.allclose(forward_x8(f, x), f(x), atol=1e-6)
+    seen = []
+    forward_x8(lambda t: (seen.append(tuple(t.shape[-2:])), t)[1], x)
+    assert len(seen) == 8 and seen.count((12, 20)) == 4 and seen.count((20, 12)) == 4
