@@ -77,6 +77,16 @@ def cpu_baseline(args, params, mode, k):
                       f"[1,64,{size},{size}] fp32, L={L} query patches, {dt:.2f} s, after one 64x64 warm-up"}
 
 
+def committed_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc pass (profiles/r01_traffic.json): PMC
+    counters cannot be read from inside the timed process, so the number comes from the profile of this same command."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+        return t.get(kernel_key)
+    except Exception:
+        return None
+
+
 def quality_leg(dev):
     """PSNR on Set12 sigma=50 of the full network (12 HIP heads) vs the reference forward with the same regenerable
     weights (numbers committed by tests/golden/make_set12_psnr.py, which ran the reference on CPU)."""
@@ -183,7 +193,8 @@ def main():
             g_bytes = L * ((kk + 1) * 4 * P_ROW + 8 * kk)
             gather = {"bound": "hbm", "kernel": "gather_rows_kernel (dagl_gather_aggregate)", "k": kk,
                       "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                      "frac": g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                      "frac": g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                      "traffic": committed_traffic("gather_rows_kernel") if (H, kk) == (256, 8) else None,
                       "bytes_per_launch": g_bytes, "ms_per_launch": g_ms,
                       "timing": "mean of 50 back-to-back launches (launch gaps included), torch events on the launch stream"}
             del rows
@@ -201,7 +212,8 @@ def main():
         roofline = {"bound": "mfma",
                     "kernel": "screen_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter)" if screened
                               else "score_select_kernel (fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": committed_traffic("screen_kernel<1>") if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
         if gather is not None and mean_ms[6] > 0:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
