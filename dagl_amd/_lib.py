@@ -34,6 +34,14 @@ class CeInfo(C.Structure):
                 ("max_degree", C.c_int32), ("path", C.c_int32)]
 
 
+class CeWeights(C.Structure):
+    """dagl_ce_weights: the 12 parameter tensors of one head (device pointers)."""
+    NAMES = ("g.weight", "g.bias", "theta.weight", "theta.bias", "thr_conv.weight", "thr_conv.bias",
+             "bias_conv.weight", "bias_conv.bias", "fc1.0.weight", "fc1.0.bias", "fc2.0.weight", "fc2.0.bias")
+    _fields_ = [(n, C.c_void_p) for n in ("g_w", "g_b", "theta_w", "theta_b", "thr_w", "thr_b", "bias_w", "bias_b",
+                                          "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 
 # name -> (restype, argtypes); the one table every declared symbol of include/dagl_ce.h appears in
@@ -53,6 +61,9 @@ SIGNATURES = {
     "dagl_ce_forward_profiled": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                       C.POINTER(CeInfo), _vp]),
     "dagl_ce_forward_fused": (_i, [_vp, _i, _i, _i] + [_vp] * 13 + [_i, _i, _vp, _vp, _sz, C.POINTER(CeInfo), _vp]),
+    "dagl_ces_stage_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dagl_ces_stage_forward": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(CeWeights), _vp, _vp, _i, _i, _vp, _vp, _sz,
+                                    C.POINTER(CeInfo), _vp]),
     "dagl_ce_prologue": (_i, [_vp, _i, _i, _i] + [_vp] * 13),
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),

@@ -304,7 +304,8 @@ int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx,
 // Query (r,c)'s aggregated 7x7 patch lands with its top-left corner at (4r-3, 4c-3) (fold grid: kernel 7,
 // padding 3, stride 4 -- dagl.py:266), i.e. NOT where it was read (SAME grid, top-left 4r-pt).  A pixel is
 // covered by <= 2 x 2 windows; the divisor fold(unfold(1)) (dagl.py:268-270) is that window count.
-__global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restrict__ agg, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restrict__ agg, float* __restrict__ out,
+                                                   int imgs, int heads) {
     const int b = blockIdx.z;
     const int y = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
         }
     }
     const float cnt = (float)((r1 - r0 + 1) * (c1 - c0 + 1));
-    float* o = out + (size_t)b * CH * g.N + (size_t)y * g.W + x;
+    const int head = b / imgs, img = b - head * imgs;
+    float* o = out + ((size_t)img * heads + head) * CH * g.N + (size_t)y * g.W + x;
 #pragma unroll
     for (int u = 0; u < CH / 4; ++u) {
         o[(size_t)(4 * u + 0) * g.N] = acc[u].x / cnt;
@@ -341,10 +343,63 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
     }
 }
 
-int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out) {
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads) {
     dim3 grid((g.W + 63) / 64, g.H, B), block(64);
-    hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out);
+    hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out, B / heads, heads);
     DAGL_LAUNCH_CHECK("fold_kernel");
+    return DAGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stage mix: out = conv1x1(cat(4 heads)) + x   (CES.forward, DN_Gray/model/dagl.py:114,116,118)
+// ------------------------------------------------------------------------------------------------------
+// fp32 MFMA 16x16x4: one wave = 64 outputs x 16 pixels; A = the 64x64 mix weights in registers, B[channel][pixel]
+// straight from the NCHW concat map (16 consecutive pixels of a channel plane = one 64-byte run); the result tile has
+// pixels along the lanes, so the NCHW stores are 64-byte runs too.
+__global__ __launch_bounds__(256) void stage_mix_kernel(int HW, const float* __restrict__ cat, const float* __restrict__ x,
+                                                        const float* __restrict__ mix_w, const float* __restrict__ mix_b,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 16;
+    if (p0 >= HW) return;
+    int px = p0 + i; if (px >= HW) px = HW - 1;
+    float w[4][16];                                            // B fragment (n, T): w[o = n*16 + i][c = 4T + g]
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int T = 0; T < 16; ++T) w[n][T] = mix_w[(n * 16 + i) * 64 + 4 * T + g];
+    const float* cb = cat + (size_t)b * 64 * HW + px;
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const float a = cb[(size_t)(4 * T + g) * HW];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][T], a, acc[n], 0, 0, 0);
+    }
+    // D[row = output n*16 + 4g + r][col = pixel p0 + i]
+    const int pp = p0 + i;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = n * 16 + 4 * g + r;
+            if (pp < HW) {
+                const size_t idx = ((size_t)b * 64 + o) * HW + pp;
+                out[idx] = (acc[n][r] + mix_b[o]) + x[idx];
+            }
+        }
+    }
+}
+
+int launch_stage_mix(hipStream_t s, int B, int HW, const float* cat, const float* x, const float* mix_w,
+                     const float* mix_b, float* out) {
+    dim3 grid((HW + 63) / 64, B), block(256);
+    hipLaunchKernelGGL(stage_mix_kernel, grid, block, 0, s, HW, cat, x, mix_w, mix_b, out);
+    DAGL_LAUNCH_CHECK("stage_mix_kernel");
     return DAGL_OK;
 }
 

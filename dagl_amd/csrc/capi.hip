@@ -154,8 +154,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     if (!exact) {
         p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_maplo = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
-        p.o_wp1h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
-        p.o_wp2h = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
+        p.o_wp1h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));          // up to 4 heads (stage entry point)
+        p.o_wp2h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));
         p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
     p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
@@ -187,16 +187,19 @@ static int check_device() {
     return DAGL_OK;
 }
 
-struct FusedIn {                 // input of the fused-prologue entry point (all device pointers)
-    const float* x;              // [B,64,H,W]
+struct FusedIn {                 // input of the fused-prologue entry points (all device pointers), one per head
+    const float* x;              // [B,64,H,W] (shared by the heads of a stage)
     const float *g_w, *g_b, *th_w, *th_b, *thr_w, *thr_b, *bias_w, *bias_b;
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
                            const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, int mode_flags, int k, float* out, void* ws, size_t ws_bytes,
                            dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg,
-                           Profile* prof = nullptr, const FusedIn* fin = nullptr) {
+                           Profile* prof = nullptr, const FusedIn* fin = nullptr, int heads = 1) {
+    // heads > 1 (stage entry point): `B` counts head x image pairs, batch entry = head * (B / heads) + image; fin[h]
+    // carries head h's weights, `out` is the [B/heads, heads*16, H, W] concat map
     Plan p;
     int rc = make_plan(B, H, W, mode_flags, k, p);
     if (rc) return rc;
@@ -244,12 +247,19 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
+    const int imgs = B / heads;
     if (fin) {
         float* thr_ws = at<float>(ws, p.o_thr);
         float* bias_ws = at<float>(ws, p.o_bias);
-        const bool heads = (mode != DAGL_MODE_TOPK);
-        if ((rc = launch_prologue(s, B, g, fin->x, fin->g_w, fin->g_b, fin->th_w, fin->th_b, fin->thr_w, fin->thr_b,
-                                  fin->bias_w, fin->bias_b, b1p, b2p, heads ? thr_ws : nullptr, bias_ws))) return rc;
+        const bool thr_heads = (mode != DAGL_MODE_TOPK);
+        const size_t map_f = (size_t)imgs * g.Hp * g.Wp * CH;
+        for (int hd = 0; hd < heads; ++hd) {
+            const FusedIn& f = fin[hd];
+            if ((rc = launch_prologue(s, imgs, g, f.x, f.g_w, f.g_b, f.th_w, f.th_b, f.thr_w, f.thr_b, f.bias_w, f.bias_b,
+                                      b1p + hd * map_f, b2p + hd * map_f,
+                                      thr_heads ? thr_ws + (size_t)hd * imgs * g.L : nullptr,
+                                      bias_ws + (size_t)hd * imgs * g.L))) return rc;
+        }
         thr = thr_ws; bias = bias_ws;
     } else {
         if ((rc = launch_pad_nhwc(s, B, H, W, b1, b1p))) return rc;
@@ -260,9 +270,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         map_hi = at<uint16_t>(ws, p.o_maphi); map_lo = at<uint16_t>(ws, p.o_maplo);
         wp1h = at<uint16_t>(ws, p.o_wp1h); wp2h = at<uint16_t>(ws, p.o_wp2h);
         if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo))) return rc;
-        if ((rc = launch_pack_fc_weight16(s, fc1_w, wp1h))) return rc;
-        if ((rc = launch_pack_fc_weight16(s, fc2_w, wp2h))) return rc;
+        for (int hd = 0; hd < heads; ++hd) {
+            if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc1_w : fc1_w, wp1h + (size_t)hd * P16_PACKED_HALFS))) return rc;
+            if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc2_w : fc2_w, wp2h + (size_t)hd * P16_PACKED_HALFS))) return rc;
+        }
     } else {
+        DAGL_REQUIRE(heads == 1, "dagl: the stage entry point needs the default (screened) scan");
         if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
         if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
     }
@@ -285,7 +298,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
     prof_mark(prof, s, 1);
     if (p.split16) {
-        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, fc2_b, X, colsum, at<float>(ws, p.o_colpart), wp1h, fc1_b, Wq, Xh, Wqh))) return rc;
+        const float* b1s[4]; const float* b2s[4];
+        for (int hd = 0; hd < 4; ++hd) {
+            b1s[hd] = (fin && hd < heads) ? fin[hd].fc1_b : fc1_b;
+            b2s[hd] = (fin && hd < heads) ? fin[hd].fc2_b : fc2_b;
+        }
+        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, colsum, at<float>(ws, p.o_colpart), wp1h, b1s,
+                                   Wq, Xh, Wqh, heads))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }
@@ -317,7 +336,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((r = launch_aggregate_direct(s, ag2))) return r;
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if ((r = launch_fold(s, B, g, agg, out))) return r;
+        if ((r = launch_fold(s, B, g, agg, out, heads))) return r;
         prof_mark(prof, s, 8);
         return DAGL_OK;
     };
@@ -535,10 +554,50 @@ int dagl_ce_forward_fused(void* stream, int B, int H, int W, const float* x, con
                           const float* bias_w, const float* bias_b, const float* fc1_w, const float* fc1_b,
                           const float* fc2_w, const float* fc2_b, int mode, int k, float* out, void* workspace,
                           size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof) {
-    FusedIn fin{x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b};
+    FusedIn fin{x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, fc1_w, fc1_b, fc2_w, fc2_b};
     return ce_forward_impl((hipStream_t)stream, B, H, W, nullptr, nullptr, nullptr, nullptr, fc1_w, fc1_b, fc2_w, fc2_b,
                            mode, k, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr,
                            reinterpret_cast<Profile*>(prof), &fin);
+}
+
+size_t dagl_ces_stage_workspace_bytes(int B, int H, int W, int mode, int k) {
+    Plan p;
+    if (B < 1 || make_plan(4 * B, H, W, mode, k, p)) return 0;
+    return p.o_end + align_up((size_t)B * 64 * H * W * sizeof(float), 256);
+}
+
+int dagl_ces_stage_forward(void* stream, int B, int H, int W, const float* x, const dagl_ce_weights* heads4,
+                           const float* mix_w, const float* mix_b, int mode, int k, float* out, void* workspace,
+                           size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof) {
+    DAGL_REQUIRE(B >= 1 && x && heads4 && mix_w && mix_b && out, "dagl_ces_stage_forward: bad argument");
+    Plan p;
+    int rc = make_plan(4 * B, H, W, mode, k, p);
+    if (rc) return rc;
+    const size_t cat_bytes = align_up((size_t)B * 64 * H * W * sizeof(float), 256);
+    if (info) info->required_bytes = (int64_t)(p.o_end + cat_bytes);
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ces_stage_forward: workspace must be 256-byte aligned");
+    if (ws_bytes < p.o_end + cat_bytes) {
+        set_error("dagl_ces_stage_forward: workspace %zu B < required %zu B", ws_bytes, p.o_end + cat_bytes);
+        return DAGL_ERR_WORKSPACE;
+    }
+    FusedIn fin[4];
+    for (int h = 0; h < 4; ++h) {
+        const dagl_ce_weights& w = heads4[h];
+        fin[h] = FusedIn{x, w.g_w, w.g_b, w.theta_w, w.theta_b, w.thr_w, w.thr_b, w.bias_w, w.bias_b,
+                         w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b};
+        DAGL_REQUIRE(w.g_w && w.g_b && w.theta_w && w.theta_b && w.fc1_w && w.fc1_b && w.fc2_w && w.fc2_b,
+                     "dagl_ces_stage_forward: head %d has a null weight pointer", h);
+    }
+    float* cat = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.o_end);       // [B,64,H,W]
+    // a dense adaptive neighbourhood asks for more workspace than planned: give the block everything up to the concat map
+    rc = ce_forward_impl((hipStream_t)stream, 4 * B, H, W, nullptr, nullptr, nullptr, nullptr, fin[0].fc1_w, fin[0].fc1_b,
+                         fin[0].fc2_w, fin[0].fc2_b, mode, k, cat, workspace, p.o_end, info, nullptr, nullptr, nullptr,
+                         reinterpret_cast<Profile*>(prof), fin, 4);
+    if (rc) {
+        if (rc == DAGL_ERR_WORKSPACE && info) info->required_bytes = -1;    // dense neighbourhoods: use the per-head entry point
+        return rc;
+    }
+    return launch_stage_mix((hipStream_t)stream, B, H * W, cat, x, mix_w, mix_b, out);
 }
 
 int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,

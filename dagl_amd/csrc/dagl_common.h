@@ -122,9 +122,9 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, 
 int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo);
 int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp);
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
-                     const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum, float* colpart,
-                     const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16);
+                     const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
+                     float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
+                     uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1);
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
 constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216 + 8192; // packed fp16 weights (halfs) + read slack of the last stage
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
@@ -132,7 +132,10 @@ int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq,
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
 int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
                         const float* values, float* out);
-int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out);
+// out is [B/heads, heads*16, H, W]: batch entry head*imgs + image lands in channels [head*16, head*16+16) of image
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads = 1);
+int launch_stage_mix(hipStream_t s, int B, int HW, const float* cat, const float* x, const float* mix_w,
+                     const float* mix_b, float* out);
 int launch_scores_dense(hipStream_t s, int B, int L, int N, const float* wq, const float* x, float* sc);
 
 // selection

@@ -83,8 +83,10 @@ int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp) {
 struct Proj16Args {
     Grid gr;
     const unsigned short* map_hi; const unsigned short* map_lo;     // [B,Hp,Wp,16] fp16
-    const unsigned short* wp[2];                                    // packed weights: [0] keys (fc2), [1] queries (fc1)
-    const float* bias[2];
+    const unsigned short* wp[2];                                    // packed weights: [0] keys (fc2), [1] queries (fc1);
+                                                                    // head h at + h * P16_PACKED_HALFS
+    const float* bias[2][4];                                        // fc bias per head
+    int imgs_per_head;                                              // batch index = head * imgs_per_head + image
     float* feat[2];                                                 // [B, rows_alloc, DS]
     uint16_t* feat_h[2];                                            // optional bf16 copies [B, rows_alloc_h, DSH]
     int rows_alloc[2], rows_alloc_h[2];
@@ -121,7 +123,8 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const int b = blockIdx.y;
     const Grid& gr = pa.gr;
     constexpr int which = KEYS ? 0 : 1;
-    const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)n0 * 32 * P16_ROWH;
+    const int head = b / pa.imgs_per_head;
+    const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)head * P16_PACKED_HALFS + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
     constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
@@ -251,7 +254,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
-    const float* __restrict__ fbias = pa.bias[which];
+    const float* __restrict__ fbias = pa.bias[which][head];
     const int grid_row_base = gy * row_len + gx0;
     float* csum = reinterpret_cast<float*>(smem);                       // [8 waves][NT*32] (ring is dead now)
 #pragma unroll
@@ -327,13 +330,18 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(int n_blocks_k, cons
 int project16_key_blocks(const Grid& g) { return (((g.W + 31) / 32) * g.H + P16_BW - 1) / P16_BW; }
 
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
-                     const uint16_t* wp_keys, const float* bias_keys, float* feat_keys, double* colsum, float* colpart,
-                     const uint16_t* wp_q, const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16) {
+                     const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
+                     const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
+                     uint16_t* feat_q_bf16, int heads) {
     Proj16Args pa;
+    pa.imgs_per_head = B / heads;
+    for (int h = 0; h < 4; ++h) {
+        pa.bias[0][h] = bias_keys ? bias_keys[h < heads ? h : 0] : nullptr;
+        pa.bias[1][h] = bias_q ? bias_q[h < heads ? h : 0] : nullptr;
+    }
     pa.gr = g; pa.map_hi = map_hi; pa.map_lo = map_lo;
-    pa.wp[0] = wp_keys; pa.bias[0] = bias_keys; pa.feat[0] = feat_keys; pa.feat_h[0] = feat_keys_bf16;
-    pa.wp[1] = wp_q; pa.bias[1] = bias_q; pa.feat[1] = feat_q; pa.feat_h[1] = feat_q_bf16;
+    pa.wp[0] = wp_keys; pa.feat[0] = feat_keys; pa.feat_h[0] = feat_keys_bf16;
+    pa.wp[1] = wp_q; pa.feat[1] = feat_q; pa.feat_h[1] = feat_q_bf16;
     pa.rows_alloc[0] = feat_rows(g.N); pa.rows_alloc[1] = feat_rows(g.L);
     pa.rows_alloc_h[0] = feat_rows_h(g.N); pa.rows_alloc_h[1] = feat_rows_h(g.L);
     pa.segs[0] = (g.W + 31) / 32; pa.segs[1] = (g.Lw + 31) / 32;

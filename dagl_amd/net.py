@@ -45,10 +45,28 @@ class CES(nn.Module):
             for head in (1, 2, 3, 4):
                 setattr(self, f"c{stage}_{head}", ce_cls(in_channels=in_channels))
             setattr(self, f"c{stage}_c", nn.Conv2d(in_channels, in_channels, 1, 1, 0))
+        self.fuse_stage = in_channels == 64       # stage-level launch set (include/dagl_ce.h: dagl_ces_stage_forward)
+        self.last_info = None
+        from . import ops
+        self._ws = ops.Workspace()
 
     def _stage(self, s, x):
-        heads = [getattr(self, f"c{s}_{h}")(x) for h in (1, 2, 3, 4)]
-        return getattr(self, f"c{s}_c")(torch.cat(heads, dim=1)) + x
+        heads = [getattr(self, f"c{s}_{h}") for h in (1, 2, 3, 4)]
+        mix = getattr(self, f"c{s}_c")
+        if self.fuse_stage and all(isinstance(hd, CE) for hd in heads) and x.is_cuda and x.dtype == torch.float32 \
+                and not torch.is_grad_enabled() and len({(hd.select_mode, hd.select_k, hd.scan) for hd in heads}) == 1 \
+                and heads[0].scan == "screened":
+            # the four heads share x: one launch set with the heads as a batch dimension + the 1x1 mix + residual
+            from . import ops
+            prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
+            out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
+                                              mix.bias.detach().contiguous(), mode=heads[0].select_mode,
+                                              k=heads[0].select_k, workspace=self._ws)
+            self.last_info = info
+            if out is not None:
+                return out
+        outs = [hd(x) for hd in heads]                      # dense adaptive neighbourhoods / foreign heads
+        return mix(torch.cat(outs, dim=1)) + x
 
     def forward(self, x):
         out = self._stage(1, x)

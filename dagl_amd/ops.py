@@ -287,3 +287,41 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     check(rc, "dagl_ce_forward_fused")
     return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
                      max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
+
+
+def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: int = 0,
+                      workspace: "Workspace | None" = None, profile: "StageProfile | None" = None):
+    """One CES stage in one launch set: ``conv1x1(cat(head_1(x)..head_4(x))) + x`` (dagl.py:114,116,118).
+    ``head_params``: four dicts (state_dict names -> contiguous fp32 GPU tensors).  Returns (out [B,64,H,W], info), or
+    (None, info) when a dense adaptive neighbourhood needs the per-head path."""
+    lib = _lib.load()
+    if mode not in MODES:
+        raise DaglError(f"unknown mode {mode!r}")
+    _need(x, "x"); _need(mix_w, "mix_w"); _need(mix_b, "mix_b")
+    B, c, H, W = x.shape
+    if c != 64 or len(head_params) != 4:
+        raise DaglError("ces_stage_forward: x must be [B,64,H,W] and there must be four heads")
+    arr = (_lib.CeWeights * 4)()
+    for h, prm in enumerate(head_params):
+        for field, name in zip([f for f, _ in _lib.CeWeights._fields_], _lib.CeWeights.NAMES):
+            t = prm[name]
+            _need(t, name)
+            setattr(arr[h], field, t.data_ptr())
+    ws = workspace if workspace is not None else Workspace()
+    need = lib.dagl_ces_stage_workspace_bytes(B, H, W, MODES[mode], int(k))
+    if need == 0:
+        check(-1, "dagl_ces_stage_workspace_bytes")
+    out = torch.empty(B, 64, H, W, device=x.device, dtype=torch.float32)
+    info = _lib.CeInfo()
+    buf = ws.get(need, x.device)
+    base = buf.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    rc = lib.dagl_ces_stage_forward(_stream(), B, H, W, x.data_ptr(), arr, mix_w.data_ptr(), mix_b.data_ptr(),
+                                    MODES[mode], int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base),
+                                    C.byref(info), profile._h if profile is not None else None)
+    meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges, max_degree=info.max_degree,
+                path=info.path, redone_queries=info.redone_queries)
+    if rc == _lib.ERR_WORKSPACE and info.required_bytes == -1:
+        return None, meta
+    check(rc, "dagl_ces_stage_forward")
+    return out, meta

@@ -119,6 +119,21 @@ int dagl_ce_forward_fused(void* stream, int B, int H, int W, const float* x,
                           int mode, int k, float* out,
                           void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
 
+/* One CES stage (DN_Gray/model/dagl.py:114,116,118): the four heads that share the input x, the 1x1 mixing
+ * convolution over their concatenation and the residual,
+ *     out = conv1x1(cat(head_1(x), .., head_4(x))) + x,          x, out: [B,64,H,W]
+ * as ONE launch set: the heads become a batch dimension (4x fewer launches, 4x more blocks per launch).
+ * Dense adaptive neighbourhoods (degree > DAGL_FAST_CAP) are not served here: the call returns
+ * DAGL_ERR_WORKSPACE with info->required_bytes = -1 and the caller falls back to four dagl_ce_forward_fused
+ * calls + its own mix.  mix_w [64,64,1,1], mix_b [64].                                               */
+typedef struct dagl_ce_weights {
+    const float *g_w, *g_b, *theta_w, *theta_b, *thr_w, *thr_b, *bias_w, *bias_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} dagl_ce_weights;
+size_t dagl_ces_stage_workspace_bytes(int B, int H, int W, int mode, int k);
+int dagl_ces_stage_forward(void* stream, int B, int H, int W, const float* x, const dagl_ce_weights* heads4,
+                           const float* mix_w, const float* mix_b, int mode, int k, float* out,
+                           void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
+
 /* Same call with optional per-query read-outs for parity tests (any of them may be NULL):
  *   deg_out [B,L] int32  neighbours per query     (reference: (mask != 0).sum(1), dagl.py:257)
  *   rowsum_out [B,L]     sum_j A_ij               (reference: softmax mass left after masking, :261)

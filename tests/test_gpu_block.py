@@ -262,3 +262,37 @@ def test_concurrent_calls_from_two_threads():
     assert not errs, errs
     assert torch.equal(outs[0], outs[1])
     assert normwise(outs[0].cpu().numpy(), g["out"]) <= TOL_OUT
+
+
+@pytest.mark.parametrize("mode,k,variant,gain", [("topk", 8, "default", 2.0), ("adaptive", 0, "sparse", 2.6)])
+def test_fused_stage_equals_four_heads_plus_mix(mode, k, variant, gain):
+    """dagl_ces_stage_forward (heads as a batch dimension + 1x1 mix + residual) vs four module calls + torch mix."""
+    from dagl_amd import ops
+    from dagl_amd.synth import make_ce_params, make_features
+    d = _dev()
+    B, H, W = 2, 72, 72
+    x = torch.from_numpy(make_features(71, B, 64, H, W)).to(d)
+    heads = []
+    for h in range(4):
+        params = {n: torch.from_numpy(a) for n, a in make_ce_params(80 + h, variant=variant, sparse_gain=gain).items()}
+        heads.append(_module(params, mode, k))
+    g = torch.Generator().manual_seed(9)
+    mix_w = (torch.rand(64, 64, 1, 1, generator=g) - 0.5).mul(0.25).to(d)
+    mix_b = (torch.rand(64, generator=g) - 0.5).mul(0.1).to(d)
+    with torch.no_grad():
+        want = torch.nn.functional.conv2d(torch.cat([hd(x) for hd in heads], dim=1), mix_w, mix_b) + x
+        prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
+        got, info = ops.ces_stage_forward(x, prm, mix_w, mix_b, mode=mode, k=heads[0].select_k)
+    assert got is not None and info["path"] == 3
+    assert normwise(got.cpu().numpy(), want.cpu().numpy()) <= 2e-5
+
+
+def test_fused_stage_hands_dense_neighbourhoods_back():
+    from dagl_amd import ops
+    from dagl_amd.synth import make_ce_params, make_features
+    d = _dev()
+    x = torch.from_numpy(make_features(72, 1, 64, 48, 48)).to(d)
+    heads = [_module({n: torch.from_numpy(a) for n, a in make_ce_params(90 + h, variant="default").items()}) for h in range(4)]
+    prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
+    out, info = ops.ces_stage_forward(x, prm, torch.zeros(64, 64, 1, 1, device=d), torch.zeros(64, device=d), mode="adaptive")
+    assert out is None and info["required_bytes"] == -1
