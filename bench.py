@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--sparse-gain", type=float, default=2.4, help="adaptive modes: threshold gain of the synthetic thr head")
     ap.add_argument("--scan", default="screened", choices=["screened", "exact"],
                     help="screened: bf16 matrix-core screen + exact refine (default); exact: all scores on the fp32 matrix cores")
+    ap.add_argument("--stage", action="store_true",
+                    help="time one CES stage (4 heads sharing the input + 1x1 mix + residual, dagl_ces_stage_forward) instead of one head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true", help="skip the Set12 sigma=50 PSNR-delta leg")
     ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
@@ -150,17 +152,41 @@ def main():
     L, N = ((H + 3) // 4) * ((W + 3) // 4), H * W
 
     prof = ops.StageProfile(max(args.steps, 1))
+    heads_per_step = 1
+    if args.stage:
+        heads_per_step = 4
+        heads = [ce]
+        for hseed in (2025, 2026, 2027):
+            hp = {n: torch.from_numpy(a) for n, a in make_ce_params(hseed, variant=variant, sparse_gain=args.sparse_gain).items()}
+            hm = CE(in_channels=64)
+            hm.load_state_dict(hp, strict=True)
+            hm.select_mode, hm.scan, hm.select_k = ce.select_mode, ce.scan, ce.select_k
+            heads.append(hm.to(dev).eval())
+        prm = [{n: q.detach().contiguous() for n, q in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
+        gmix = torch.Generator().manual_seed(3)
+        mix_w = ((torch.rand(64, 64, 1, 1, generator=gmix) - 0.5) * 0.25).to(dev)
+        mix_b = ((torch.rand(64, generator=gmix) - 0.5) * 0.1).to(dev)
+        ws_stage = ops.Workspace()
+        info_box = {}
+
+        def step(profile=None):
+            out, inf = ops.ces_stage_forward(x, prm, mix_w, mix_b, mode=mode, k=ce.select_k, workspace=ws_stage, profile=profile)
+            assert out is not None, "dense neighbourhoods: the stage entry point handed the call back"
+            info_box["info"] = inf
+    else:
+        def step(profile=None):
+            ce.profile = profile
+            ce(x)
     with torch.no_grad():
         for _ in range(args.warmup):
-            ce(x)
-        ce.profile = prof
+            step()
         prof.reset()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            ce(x)
+            step(prof)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -168,7 +194,7 @@ def main():
         ce.profile = None
     elapsed = reduce_max_seconds(elapsed, dist, dev)
     stage_ms = prof.read()
-    info = ce.last_info
+    info = info_box["info"] if args.stage else ce.last_info
 
     # stand-alone gather kernel over materialised value rows (rank 0 only; outside the timed region)
     gather = None
@@ -205,7 +231,7 @@ def main():
         mean_ms = sm.mean(axis=0) if len(sm) else np.zeros(8)
         from dagl_amd._lib import STAGE_NAMES
         sel_ms = float(mean_ms[4])
-        flops = 2.0 * B * L * N * D_FEAT                                 # algorithmic: 2*L*N*D per image
+        flops = 2.0 * heads_per_step * B * L * N * D_FEAT                # algorithmic: 2*L*N*D per image and head
         ach = flops / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
         screened = (info or {}).get("path") == 3
         peak = PEAK_BF16_MATRIX_TFLOPS if screened else PEAK_F32_MATRIX_TFLOPS
@@ -221,14 +247,15 @@ def main():
             gather["fused_in_block"] = {"kernel": "aggregate_direct_kernel", "ms_per_launch": float(mean_ms[6]),
                                         "achieved": fb / (mean_ms[6] * 1e-3) / 1e9, "unit": "GB/s",
                                         "frac": fb / (mean_ms[6] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-        total_patches = world * B * L * args.steps
+        total_patches = world * heads_per_step * B * L * args.steps
         line = {
-            "metric": "graph-attn fwd query-patches/s @256x256x64 k=8" if (H, mode, k) == (256, "topk", 8)
+            "metric": "graph-attn fwd query-patches/s @256x256x64 k=8" if (H, mode, k, args.stage) == (256, "topk", 8, False)
                       else f"graph-attn fwd query-patches/s @{H}x{W}x64 {mode} k={k}",
             "value": total_patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: one CE head forward, features [{B},64,{H},{W}] fp32 per GPU, "
+            "config": {"workload": ("one CES stage (4 heads + 1x1 mix + residual)" if args.stage else "BASELINE configs[1]: one CE head forward")
+                                   + f", features [{B},64,{H},{W}] fp32 per GPU, "
                                    f"select mode {mode} k={k}, L={L} queries x N={N} keys per image",
                        "parallelism": f"dp{world} (independent images per rank, no data-path collective)",
                        "select_mode": mode, "k": k, "batch_per_gpu": B, "scan": args.scan,
@@ -238,9 +265,9 @@ def main():
             "stage_ms": {STAGE_NAMES[i]: float(mean_ms[i]) for i in range(8)},
             "hip_block_ms": float(mean_ms.sum()),
         }
-        if world == 1 and not args.no_quality:
+        if world == 1 and not args.no_quality and not args.stage:
             line["quality"] = quality_leg(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.stage:
             line["cpu_baseline"] = cpu_baseline(args, params, mode, k)
         print(json.dumps(line))
     if dist is not None:
