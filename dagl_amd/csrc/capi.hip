@@ -116,7 +116,10 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
         p.s_splits = (p.s_steps + p.s_steps_per_split - 1) / p.s_steps_per_split;
         p.s_sample = p.s_steps_per_split >= 8 ? 4 : (p.s_steps_per_split >= 4 ? 2 : 1);
     }
+    // candidate slots per (query, chunk, half) segment: 16 when a query has many segments, up to 64 when it has few
+    // (short key streams): ~1024 slots per query in total
     p.capseg = SCREEN_CAPSEG;
+    while (p.capseg < 64 && 2 * p.capseg * p.s_splits * 2 <= 1024) p.capseg *= 2;
 
     const size_t BL = (size_t)B * g.L;
     size_t off = 0;
