@@ -80,7 +80,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
@@ -258,10 +258,14 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         const size_t map_f = (size_t)imgs * g.Hp * g.Wp * CH;
         for (int hd = 0; hd < heads; ++hd) {
             const FusedIn& f = fin[hd];
+            // default path: the key/query map is only ever consumed as split fp16 (project16), so the prologue
+            // writes the hi / lo maps itself and no fp32 copy exists
             if ((rc = launch_prologue(s, imgs, g, f.x, f.g_w, f.g_b, f.th_w, f.th_b, f.thr_w, f.thr_b, f.bias_w, f.bias_b,
-                                      b1p + hd * map_f, b2p + hd * map_f,
+                                      p.split16 ? nullptr : b1p + hd * map_f, b2p + hd * map_f,
                                       thr_heads ? thr_ws + (size_t)hd * imgs * g.L : nullptr,
-                                      bias_ws + (size_t)hd * imgs * g.L))) return rc;
+                                      bias_ws + (size_t)hd * imgs * g.L,
+                                      p.split16 ? at<uint16_t>(ws, p.o_maphi) + hd * map_f : nullptr,
+                                      p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {
@@ -272,15 +276,18 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     if (p.split16) {
         map_hi = at<uint16_t>(ws, p.o_maphi); map_lo = at<uint16_t>(ws, p.o_maplo);
         wp1h = at<uint16_t>(ws, p.o_wp1h); wp2h = at<uint16_t>(ws, p.o_wp2h);
-        if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo))) return rc;
-        for (int hd = 0; hd < heads; ++hd) {
+        if (!fin)                                                // stock-conv entry point: split the padded fp32 map
+            if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo))) return rc;
+        for (int hd = 0; hd < heads && !(mode_flags & DAGL_FLAG_WEIGHTS_PACKED); ++hd) {
             if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc1_w : fc1_w, wp1h + (size_t)hd * P16_PACKED_HALFS))) return rc;
             if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc2_w : fc2_w, wp2h + (size_t)hd * P16_PACKED_HALFS))) return rc;
         }
     } else {
         DAGL_REQUIRE(heads == 1, "dagl: the stage entry point needs the default (screened) scan");
-        if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
-        if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
+        if (!(mode_flags & DAGL_FLAG_WEIGHTS_PACKED)) {
+            if ((rc = launch_pack_fc_weight(s, fc1_w, wp1))) return rc;
+            if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
+        }
     }
     ZeroList zl;
     {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
@@ -306,7 +313,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             b1s[hd] = (fin && hd < heads) ? fin[hd].fc1_b : fc1_b;
             b2s[hd] = (fin && hd < heads) ? fin[hd].fc2_b : fc2_b;
         }
-        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, colsum, at<float>(ws, p.o_colpart), wp1h, b1s,
+        if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
+                                   at<float>(ws, p.o_colpart), wp1h, b1s,
                                    Wq, Xh, Wqh, heads))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
@@ -610,7 +618,7 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const fl
                  "dagl_ce_prologue: bad argument");
     if (thr || bias) DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b, "dagl_ce_prologue: thr/bias heads incomplete");
     return launch_prologue((hipStream_t)stream, B, make_grid(H, W), x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w,
-                           bias_b, b1_nhwc, b2_nhwc, thr, bias);
+                           bias_b, b1_nhwc, b2_nhwc, thr, bias, nullptr, nullptr);
 }
 
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {

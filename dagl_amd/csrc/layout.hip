@@ -117,4 +117,34 @@ int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2
     return DAGL_OK;
 }
 
+// same for two fp16 maps [B,Hp,Wp,16] (32 bytes per pixel = two 16-byte stores)
+__global__ void zero_borders16_kernel(int H, int W, unsigned short* __restrict__ m1, unsigned short* __restrict__ m2) {
+    const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
+    const int b = blockIdx.y;
+    const int nb = 2 * PADPIX * Wp + 2 * PADPIX * H;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * 2) return;
+    const int pix = t >> 1, q = t & 1;
+    int yp, xp;
+    if (pix < 2 * PADPIX * Wp) {
+        const int r = pix / Wp; xp = pix - r * Wp;
+        yp = (r < PADPIX) ? r : (Hp - 2 * PADPIX + r);
+    } else {
+        const int e = pix - 2 * PADPIX * Wp;
+        const int r = e / (2 * PADPIX), c = e - r * (2 * PADPIX);
+        yp = PADPIX + r; xp = (c < PADPIX) ? c : (Wp - 2 * PADPIX + c);
+    }
+    const size_t o = ((((size_t)b * Hp + yp) * Wp + xp) * CH) / 8 + q;
+    reinterpret_cast<uint4*>(m1)[o] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(m2)[o] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2) {
+    const int Wp = W + 2 * PADPIX;
+    const int nb = (2 * PADPIX * Wp + 2 * PADPIX * H) * 2;
+    hipLaunchKernelGGL(zero_borders16_kernel, dim3((nb + 255) / 256, B), dim3(256), 0, s, H, W, m1, m2);
+    DAGL_LAUNCH_CHECK("zero_borders16_kernel");
+    return DAGL_OK;
+}
+
 }  // namespace dagl

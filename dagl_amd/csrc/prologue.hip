@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ g_w, const float* __restrict__ g_b,
                                                         const float* __restrict__ th_w, const float* __restrict__ th_b,
-                                                        float* __restrict__ b1p, float* __restrict__ b2p) {
+                                                        float* __restrict__ b1p, float* __restrict__ b2p,
+                                                        unsigned short* __restrict__ b1hi,
+                                                        unsigned short* __restrict__ b1lo) {
     __shared__ __attribute__((aligned(16))) float ring[PRO_ROWS][PC][PRO_LS];                // 69.6 KiB
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,7 +117,14 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
             const int xx = x0 + px0 + 4 * g + r;
             if (xx < W) {
                 const size_t o = (((size_t)b * Hp + y + PADPIX) * Wp + xx + PADPIX) * CH + i;
-                b1p[o] = ((a0[r] + a1[r]) + a2[r]) + bias1;
+                const float v1 = ((a0[r] + a1[r]) + a2[r]) + bias1;
+                if (b1p != nullptr) b1p[o] = v1;
+                if (b1hi != nullptr) {                           // a = hi + 2^-11 lo, both fp16 (project16.hip)
+                    const _Float16 hh = (_Float16)v1;
+                    const _Float16 ll = (_Float16)((v1 - (float)hh) * 2048.0f);
+                    b1hi[o] = __builtin_bit_cast(unsigned short, hh);
+                    b1lo[o] = __builtin_bit_cast(unsigned short, ll);
+                }
                 b2p[o] = at[r] + bias2;
             }
         }
@@ -156,9 +165,11 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, const float* __r
 
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
-                    const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias) {
-    int rcz = launch_zero_borders(s, B, g.H, g.W, b1p, b2p);
+                    const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
+                    uint16_t* b1_hi, uint16_t* b1_lo) {
+    int rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p);
     if (rcz) return rcz;
+    if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
     int chunks = (256 + strips * B - 1) / (strips * B);
@@ -167,7 +178,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     const int rows_per_block = (g.H + chunks - 1) / chunks;
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
-                       g_b, th_w, th_b, b1p, b2p);
+                       g_b, th_w, th_b, b1p, b2p, b1_hi, b1_lo);
     DAGL_LAUNCH_CHECK("conv_pair_kernel");
     if (thr != nullptr) {
         hipLaunchKernelGGL(thr_bias_kernel, dim3((g.L + 3) / 4, B), dim3(256), 0, s, g, x, thr_w, thr_b, bias_w,

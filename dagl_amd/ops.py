@@ -248,7 +248,7 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
 
 
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
-                     profile: "StageProfile | None" = None, exact_scan: bool = False):
+                     profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False):
     """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
     state_dict names to contiguous fp32 GPU tensors.  Returns (out, info)."""
     lib = _lib.load()
@@ -270,6 +270,8 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
     if need == 0:
         check(-1, "dagl_ce_workspace_bytes")
+    if weights_packed and ws.buf is not None and ws.buf.numel() >= need + 256 and ws.buf.device == x.device:
+        mode_flags |= _lib.FLAG_WEIGHTS_PACKED           # same buffer as last time: the packed weights are still in it
     out = torch.empty(B, 16, H, W, device=x.device, dtype=torch.float32)
     info = _lib.CeInfo()
     rc = 0
@@ -282,6 +284,7 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
                                        profile._h if profile is not None else None)
         if rc == _lib.ERR_WORKSPACE and info.required_bytes > need:
             need = int(info.required_bytes)
+            mode_flags &= ~_lib.FLAG_WEIGHTS_PACKED      # the buffer is about to be replaced
             continue
         break
     check(rc, "dagl_ce_forward_fused")

@@ -296,3 +296,27 @@ def test_fused_stage_hands_dense_neighbourhoods_back():
     prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
     out, info = ops.ces_stage_forward(x, prm, torch.zeros(64, 64, 1, 1, device=d), torch.zeros(64, device=d), mode="adaptive")
     assert out is None and info["required_bytes"] == -1
+
+
+def test_packed_weight_cache_is_invalidated_by_inplace_updates():
+    """The module skips repacking fc1/fc2 between calls; an optimizer-style in-place update must be picked up."""
+    path = [p for p in CASES if "topk4_64x64" in p][0]
+    meta, g = load_golden(path)
+    x, params = case_inputs(meta)
+    xd = x.to(_dev())
+    ce = _module(params, "topk", 4)
+    with torch.no_grad():
+        a1 = ce(xd).clone()
+        a2 = ce(xd).clone()                       # second call: cached packed weights
+        assert torch.equal(a1, a2)
+        ce.fc2[0].weight.mul_(0.5)
+        ce.fc1[0].weight.add_(0.01)
+        b1 = ce(xd).clone()
+    params2 = {n: t.clone() for n, t in params.items()}
+    params2["fc2.0.weight"] = params2["fc2.0.weight"] * 0.5
+    params2["fc1.0.weight"] = params2["fc1.0.weight"] + 0.01
+    fresh = _module(params2, "topk", 4)
+    with torch.no_grad():
+        b2 = fresh(xd)
+    assert not torch.equal(a1, b1)
+    assert torch.equal(b1, b2)
