@@ -55,6 +55,11 @@ SIGNATURES = {
                              C.POINTER(CeInfo)]),
     "dagl_ce_forward_debug": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                    C.POINTER(CeInfo), _vp, _vp, _vp]),
+    "dagl_ce_list_width": (_i, [_i, _i]),
+    "dagl_ce_core_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  C.POINTER(CeInfo)]),
+    "dagl_ce_core_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dagl_ce_core_backward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 17 + [_sz]),
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
     "dagl_profile_destroy": (_i, [_vp]),
     "dagl_profile_reset": (_i, [_vp]),

@@ -23,6 +23,41 @@ from ._lib import MAX_TOPK, DaglError
 from .synth import same_pad_amounts
 
 
+class _GraphCore(torch.autograd.Function):
+    """dagl.py:250-272 as one differentiable op: HIP forward (``dagl_ce_core_forward``) keeps each query's neighbour
+    list, HIP backward (``dagl_ce_core_backward``) returns the gradients autograd would derive from the dense form."""
+
+    @staticmethod
+    def forward(ctx, wq_rows, x_rows, b2, thr, bias, mode, k, exact_scan, ws_f, ws_b, sink):
+        wq_rows, x_rows, b2 = wq_rows.contiguous(), x_rows.contiguous(), b2.contiguous()
+        adaptive = mode != "topk"
+        thr_c = thr.contiguous() if adaptive else None
+        bias_c = bias.contiguous() if adaptive else None
+        out, saved = ops.ce_core_forward(wq_rows, x_rows, b2, thr_c, bias_c, mode=mode, k=k, workspace=ws_f,
+                                         exact_scan=exact_scan)
+        ctx.mode, ctx.k, ctx.ws_b, ctx.adaptive = mode, k, ws_b, adaptive
+        ctx.thr_shape = thr.shape if adaptive else None
+        tensors = [wq_rows, x_rows, b2, saved["nb_idx"], saved["nb_wgt"], saved["nb_s"], saved["nb_cnt"]]
+        if adaptive:
+            tensors += [thr_c, bias_c, saved["mu"]]
+        ctx.save_for_backward(*tensors)
+        if sink is not None:
+            sink.update(saved["info"])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        t = ctx.saved_tensors
+        wq_rows, x_rows, b2, nb_idx, nb_wgt, nb_s, nb_cnt = t[:7]
+        thr, bias, mu = (t[7], t[8], t[9]) if ctx.adaptive else (None, None, None)
+        saved = dict(nb_idx=nb_idx, nb_wgt=nb_wgt, nb_s=nb_s, nb_cnt=nb_cnt, mu=mu)
+        d_wq, d_x, d_b2, d_thr, d_bias = ops.ce_core_backward(d_out.contiguous().float(), wq_rows, x_rows, b2, thr, bias,
+                                                              saved, mode=ctx.mode, k=ctx.k, workspace=ctx.ws_b)
+        if ctx.adaptive:
+            d_thr, d_bias = d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape)
+        return d_wq, d_x, d_b2, d_thr, d_bias, None, None, None, None, None, None
+
+
 class CE(nn.Module):
     def __init__(self, ksize=7, stride_1=4, stride_2=1, softmax_scale=10, shape=64, p_len=64, in_channels=64,
                  inter_channels=16, use_multiple_size=False, use_topk=False, add_SE=False, num_edge=50):
@@ -56,6 +91,7 @@ class CE(nn.Module):
         # "exact": every score on the fp32 matrix cores.  Same neighbours either way.
         self.scan = "screened"
         self._ws = ops.Workspace()
+        self._ws_bwd = ops.Workspace()
         self._pack_key = None
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
@@ -76,6 +112,28 @@ class CE(nn.Module):
         bias = self.bias_conv(b4).reshape(b.shape[0], -1)
         return b1, b2, thr, bias
 
+    def _forward_train(self, b: torch.Tensor) -> torch.Tensor:
+        """Differentiable path (DN_Gray/trainer.py:44-50): the convolutions and the two patch projections run as
+        stock torch ops under autograd -- fc(unfold(.)) is a 7x7 convolution with the Linear weight viewed as
+        [196,16,7,7] (dagl.py:240-249) -- and the graph core (dagl.py:250-272) is the HIP op with its own backward.
+        Sparse neighbourhoods only (top-k modes, adaptive masks keeping <= 64 keys per query)."""
+        b1, b2, thr, bias = self._prologue(b)
+        B, _, H, W = b1.shape
+        t, bo = same_pad_amounts(H, self.ksize, self.stride_1)
+        l, r = same_pad_amounts(W, self.ksize, self.stride_1)
+        w1 = self.fc1[0].weight.view(-1, self.inter_channels, self.ksize, self.ksize)
+        w2 = self.fc2[0].weight.view(-1, self.inter_channels, self.ksize, self.ksize)
+        wq = F.relu(F.conv2d(F.pad(b1, (l, r, t, bo)), w1, self.fc1[0].bias, stride=self.stride_1))
+        x = F.relu(F.conv2d(b1, w2, self.fc2[0].bias, stride=self.stride_2, padding=self.ksize // 2))
+        wq_rows = wq.permute(0, 2, 3, 1).reshape(B, -1, wq.shape[1])
+        x_rows = x.permute(0, 2, 3, 1).reshape(B, -1, x.shape[1])
+        info = {}
+        out = _GraphCore.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, self.select_k, self.scan == "exact",
+                               self._ws, self._ws_bwd, info)
+        self._pack_key = None          # the shared workspace was reused with another layout
+        self.last_info = info
+        return out
+
     def forward(self, b: torch.Tensor) -> torch.Tensor:
         if b.dim() != 4 or b.shape[1] != self.in_channels:
             raise DaglError(f"CE.forward: expected [B,{self.in_channels},H,W], got {tuple(b.shape)}")
@@ -89,7 +147,8 @@ class CE(nn.Module):
         elif in_dtype != torch.float32:
             raise DaglError(f"CE.forward: unsupported dtype {in_dtype}")
         if torch.is_grad_enabled() and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise DaglError("CE.forward: the HIP block has no backward yet; call under torch.no_grad()")
+            out = self._forward_train(b.contiguous())
+            return out if in_dtype == torch.float32 else out.to(in_dtype)
         params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
         # the packed copies of fc1/fc2 live in this module's private workspace: skip repacking while neither the
         # weights (torch bumps ._version on every in-place update) nor the call geometry changed

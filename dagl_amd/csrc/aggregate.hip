@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void edge_softmax_fast_kernel(EdgeArgs a) {
     if (valid) {
         a.nb_idx[ql * a.width + lane] = key;
         a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+        if (a.nb_s != nullptr) a.nb_s[ql * a.width + lane] = s;
     }
     if (lane == 0) a.nb_cnt[ql] = n;
 }
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int 
     if (valid) {
         a.nb_idx[ql * a.width + lane] = my_key;
         a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+        if (a.nb_s != nullptr) a.nb_s[ql * a.width + lane] = my_s;
     }
     if (lane == 0) a.nb_cnt[ql] = n;
 }

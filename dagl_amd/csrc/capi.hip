@@ -196,11 +196,18 @@ struct FusedIn {                 // input of the fused-prologue entry points (al
     const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 
+struct CoreIn {                  // training entry point: features given, neighbour lists handed back for the backward
+    const float* wq_rows; const float* x_rows;                   // [B,L,196], [B,N,196] dense rows (post-ReLU)
+    int32_t* nb_idx; float* nb_wgt; float* nb_s; int32_t* nb_cnt; // [B,L,width] x3, [B,L]
+    float* mu;                                                   // [B,L] row means of S (adaptive modes)
+};
+
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
                            const float* bias, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, int mode_flags, int k, float* out, void* ws, size_t ws_bytes,
                            dagl_ce_info* info, int32_t* dbg_deg, float* dbg_rowsum, float* dbg_agg,
-                           Profile* prof = nullptr, const FusedIn* fin = nullptr, int heads = 1) {
+                           Profile* prof = nullptr, const FusedIn* fin = nullptr, int heads = 1,
+                           const CoreIn* core = nullptr) {
     // heads > 1 (stage entry point): `B` counts head x image pairs, batch entry = head * (B / heads) + image; fin[h]
     // carries head h's weights, `out` is the [B/heads, heads*16, H, W] concat map
     Plan p;
@@ -209,8 +216,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     const int mode = p.mode;
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
                 info->redone_queries = -1; }
-    DAGL_REQUIRE(fc1_w && fc1_b && fc2_w && fc2_b && out, "dagl_ce_forward: null tensor pointer");
-    if (fin) {
+    DAGL_REQUIRE(out && (core || (fc1_w && fc1_b && fc2_w && fc2_b)), "dagl_ce_forward: null tensor pointer");
+    if (core) {
+        DAGL_REQUIRE(core->wq_rows && core->x_rows && b2 && core->nb_idx && core->nb_wgt && core->nb_s && core->nb_cnt,
+                     "dagl_ce_core_forward: null tensor pointer");
+        if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias && core->mu, "dagl_ce_core_forward: thr/bias/mu required in adaptive modes");
+    } else if (fin) {
         DAGL_REQUIRE(fin->x && fin->g_w && fin->g_b && fin->th_w && fin->th_b, "dagl_ce_forward_fused: null tensor pointer");
         if (mode != DAGL_MODE_TOPK)
             DAGL_REQUIRE(fin->thr_w && fin->thr_b && fin->bias_w && fin->bias_b, "dagl_ce_forward_fused: thr/bias heads required in adaptive modes");
@@ -243,15 +254,17 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int64_t* rowoff = at<int64_t>(ws, p.o_rowoff);
     int32_t* deg = at<int32_t>(ws, p.o_deg);
     int64_t* stats = at<int64_t>(ws, p.o_stats);
-    int32_t* nbidx = at<int32_t>(ws, p.o_nbidx);
-    float* nbwgt = at<float>(ws, p.o_nbwgt);
-    int32_t* nbcnt = at<int32_t>(ws, p.o_nbcnt);
+    int32_t* nbidx = core ? core->nb_idx : at<int32_t>(ws, p.o_nbidx);
+    float* nbwgt = core ? core->nb_wgt : at<float>(ws, p.o_nbwgt);
+    int32_t* nbcnt = core ? core->nb_cnt : at<int32_t>(ws, p.o_nbcnt);
     float* agg = at<float>(ws, p.o_agg);
 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
     const int imgs = B / heads;
-    if (fin) {
+    if (core) {
+        if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
+    } else if (fin) {
         float* thr_ws = at<float>(ws, p.o_thr);
         float* bias_ws = at<float>(ws, p.o_bias);
         const bool thr_heads = (mode != DAGL_MODE_TOPK);
@@ -273,7 +286,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     }
     uint16_t *map_hi = nullptr, *map_lo = nullptr, *wp1h = nullptr, *wp2h = nullptr;
-    if (p.split16) {
+    if (core) {
+        // nothing to pack: the projections were done by the caller (under autograd)
+    } else if (p.split16) {
         map_hi = at<uint16_t>(ws, p.o_maphi); map_lo = at<uint16_t>(ws, p.o_maplo);
         wp1h = at<uint16_t>(ws, p.o_wp1h); wp2h = at<uint16_t>(ws, p.o_wp2h);
         if (!fin)                                                // stock-conv entry point: split the padded fp32 map
@@ -307,7 +322,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
     prof_mark(prof, s, 1);
-    if (p.split16) {
+    if (core) {
+        if ((rc = launch_rows_to_feat(s, B, g.N, core->x_rows, X, Xh))) return rc;
+        if ((rc = launch_rows_to_feat(s, B, g.L, core->wq_rows, Wq, Wqh))) return rc;
+        if (mode != DAGL_MODE_TOPK)
+            if ((rc = launch_colsum_rows(s, B, g.N, core->x_rows, colsum))) return rc;
+    } else if (p.split16) {
         const float* b1s[4]; const float* b2s[4];
         for (int hd = 0; hd < 4; ++hd) {
             b1s[hd] = (fin && hd < heads) ? fin[hd].fc1_b : fc1_b;
@@ -330,12 +350,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     memset(&ea, 0, sizeof(ea));
     ea.B = B; ea.L = g.L; ea.N = g.N; ea.mode = mode; ea.k = k; ea.splits = p.splits;
     ea.nb_idx = nbidx; ea.nb_wgt = nbwgt; ea.nb_cnt = nbcnt; ea.width = p.width;
+    ea.nb_s = core ? core->nb_s : nullptr;
     AggArgs ag;
     memset(&ag, 0, sizeof(ag));
     ag.B = B; ag.g = g; ag.b2p = b2p; ag.nb_idx = nbidx; ag.nb_wgt = nbwgt; ag.nb_cnt = nbcnt; ag.width = p.width;
     ag.agg = agg;
     if (mode != DAGL_MODE_TOPK) {
-        if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt))) return rc;
+        if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt, core ? core->mu : nullptr))) return rc;
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
 
@@ -380,7 +401,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         ra.width = p.width; ra.wq = Wq; ra.x = X; ra.rows_q = feat_rows(g.L); ra.rows_x = feat_rows(g.N);
         ra.mt = mt; ra.bs = bias; ra.cand_idx = sc.cand_idx; ra.seg_cnt = sc.seg_cnt;
         ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
-        ra.stats = stats;
+        ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if ((rc = launch_refine(s, ra))) return rc;
         if (info) info->path = 3;
         if (mode == DAGL_MODE_ADAPTIVE) {
@@ -437,6 +458,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 const size_t o_ni = carve(off, e * sizeof(int32_t));
                 const size_t o_nw = carve(off, e * sizeof(float));
                 if (info) { info->required_bytes = (int64_t)off; info->path = 1; }
+                if (core) {
+                    if (info) info->required_bytes = -1;
+                    set_error("dagl_ce_core_forward: dense neighbourhoods (max degree %lld > %d) have no backward in this build",
+                              (long long)hstats[1], DAGL_FAST_CAP);
+                    return DAGL_ERR_UNSUPPORTED;
+                }
                 if (ws_bytes < off) {
                     set_error("dagl_ce_forward: dense neighbourhoods (max degree %lld, %lld edges) need workspace %zu B, have %zu B",
                               (long long)hstats[1], (long long)hstats[0], off, ws_bytes);
@@ -609,6 +636,83 @@ int dagl_ces_stage_forward(void* stream, int B, int H, int W, const float* x, co
         return rc;
     }
     return launch_stage_mix((hipStream_t)stream, B, H * W, cat, x, mix_w, mix_b, out);
+}
+
+int dagl_ce_list_width(int mode, int k) {
+    const int m = mode & 0xff;
+    if (m == DAGL_MODE_ADAPTIVE) return DAGL_FAST_CAP;
+    if ((m == DAGL_MODE_TOPK || m == DAGL_MODE_ADAPTIVE_TOPK) && k >= 1 && k <= DAGL_MAX_TOPK) return k;
+    set_error("dagl_ce_list_width: bad mode 0x%x / k=%d", mode, k);
+    return DAGL_ERR_INVALID;
+}
+
+int dagl_ce_core_forward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
+                         const float* thr, const float* bias, int mode, int k, float* out, int32_t* nb_idx,
+                         float* nb_wgt, float* nb_s, int32_t* nb_cnt, float* mu, void* workspace, size_t ws_bytes,
+                         dagl_ce_info* info) {
+    CoreIn core{wq_rows, x_rows, nb_idx, nb_wgt, nb_s, nb_cnt, mu};
+    return ce_forward_impl((hipStream_t)stream, B, H, W, nullptr, b2, thr, bias, nullptr, nullptr, nullptr, nullptr, mode,
+                           k, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr, nullptr, nullptr, 1, &core);
+}
+
+static size_t backward_offsets(int B, const Grid& g, int width, size_t o[6]) {
+    size_t off = 0;
+    const size_t BL = (size_t)B * g.L;
+    o[0] = carve(off, BL * P * sizeof(float));                                  // d agg
+    o[1] = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(float));            // b2 padded NHWC
+    o[2] = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(float));            // d b2 padded NHWC
+    o[3] = carve(off, BL * width * sizeof(float));                              // d S
+    o[4] = carve(off, BL * sizeof(float));                                      // d mu
+    o[5] = carve(off, (size_t)B * DS * sizeof(double) + (size_t)B * D * sizeof(float));   // column sums, d Xbar
+    return off;
+}
+
+size_t dagl_ce_core_backward_workspace_bytes(int B, int H, int W, int mode, int k) {
+    const int width = dagl_ce_list_width(mode, k);
+    if (B < 1 || H < 1 || W < 1 || width < 0) return 0;
+    size_t o[6];
+    return backward_offsets(B, make_grid(H, W), width, o);
+}
+
+int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, const float* wq_rows, const float* x_rows,
+                          const float* b2, const float* thr, const float* bias, const int32_t* nb_idx,
+                          const float* nb_wgt, const float* nb_s, const int32_t* nb_cnt, const float* mu,
+                          const float* d_out, float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr,
+                          float* d_bias, void* workspace, size_t ws_bytes) {
+    const int width = dagl_ce_list_width(mode, k);
+    if (width < 0) return width;
+    const int m = mode & 0xff;
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl_ce_core_backward: bad shape");
+    DAGL_REQUIRE(wq_rows && x_rows && b2 && nb_idx && nb_wgt && nb_s && nb_cnt && d_out && d_wq_rows && d_x_rows && d_b2,
+                 "dagl_ce_core_backward: null tensor pointer");
+    if (m != DAGL_MODE_TOPK)
+        DAGL_REQUIRE(thr && bias && mu && d_thr && d_bias, "dagl_ce_core_backward: thr/bias/mu and their gradients required in adaptive modes");
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_backward: workspace must be 256-byte aligned");
+    const Grid g = make_grid(H, W);
+    size_t o[6];
+    const size_t need = backward_offsets(B, g, width, o);
+    if (ws_bytes < need) {
+        set_error("dagl_ce_core_backward: workspace %zu B < required %zu B", ws_bytes, need);
+        return DAGL_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    BwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.g = g; a.mode = m; a.width = width;
+    a.wq_rows = wq_rows; a.x_rows = x_rows; a.thr = thr; a.bs = bias; a.mu = mu;
+    a.nb_idx = nb_idx; a.nb_wgt = nb_wgt; a.nb_s = nb_s; a.nb_cnt = nb_cnt; a.dout = d_out;
+    a.dagg = at<float>(workspace, o[0]);
+    float* b2p = at<float>(workspace, o[1]);
+    a.b2p = b2p; a.db2p = at<float>(workspace, o[2]); a.dS = at<float>(workspace, o[3]); a.dmu = at<float>(workspace, o[4]);
+    double* colsum = at<double>(workspace, o[5]);
+    float* dxbar = reinterpret_cast<float*>(colsum + (size_t)B * DS);
+    a.colsum = colsum;
+    a.dwq_rows = d_wq_rows; a.dx_rows = d_x_rows; a.dthr = d_thr; a.dbias = d_bias;
+    int rc;
+    if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
+    if (m != DAGL_MODE_TOPK)
+        if ((rc = launch_colsum_rows(s, B, g.N, x_rows, colsum))) return rc;
+    return launch_core_backward(s, a, dxbar, d_b2);
 }
 
 int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,

@@ -130,7 +130,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
 constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216 + 8192; // packed fp16 weights (halfs) + read slack of the last stage
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
-                            const float* thr, float* mt);
+                            const float* thr, float* mt, float* mu_out = nullptr);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
 int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
                         const float* values, float* out);
@@ -177,6 +177,7 @@ struct EdgeArgs {
     int32_t* nb_cnt;                // [B,L] entries used
     int width;
     const int32_t* run_flags;       // optional [B, ceil(L/128)] (top-k merge only)
+    float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
 
@@ -219,6 +220,7 @@ struct RefineArgs {
     int32_t* redo_flags;            // [B, n_qgroups_exact]: query groups (of 128) the exact kernel must redo
     int n_qgroups_exact;
     int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
+    float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats);
@@ -226,6 +228,25 @@ int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);
 int launch_row_scan(hipStream_t s, int n_rows, const int32_t* deg, int64_t* row_off);
-int topk_slots(int k);              // per-lane list length used for a requested k (4/8/16/32)
+int topk_slots(int k);
+
+// graph-core backward (backward.hip)
+struct BwdArgs {
+    int B; Grid g; int mode, width;
+    const float* wq_rows; const float* x_rows;          // dense feature rows [B,L,196], [B,N,196]
+    const float* b2p;                                   // padded NHWC value map [B,Hp,Wp,16]
+    const float* thr; const float* bs; const float* mu; // per query [B,L] (adaptive modes): threshold, bias, row mean
+    const double* colsum;                               // [B,204] column sums of the key features (adaptive modes)
+    const int32_t* nb_idx; const float* nb_wgt; const float* nb_s; const int32_t* nb_cnt;
+    const float* dout;                                  // [B,16,H,W]
+    float* dagg;                                        // ws [B,L,784]
+    float* db2p;                                        // ws [B,Hp,Wp,16]
+    float* dS;                                          // ws [B,L,width]
+    float* dmu;                                         // ws [B,L]
+    float* dwq_rows; float* dx_rows; float* dthr; float* dbias;          // outputs
+};
+int launch_core_backward(hipStream_t s, const BwdArgs& a, float* dxbar_ws, float* db2_nchw);
+int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h);
+int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum);              // per-lane list length used for a requested k (4/8/16/32)
 
 }  // namespace dagl

@@ -234,7 +234,7 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* 
 // The row mean of S is linear in the key features, so it needs no pass over S.
 __global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const float* __restrict__ wq,
                                         const double* __restrict__ colsum, const float* __restrict__ thr,
-                                        float* __restrict__ mt) {
+                                        float* __restrict__ mt, float* __restrict__ mu_out) {
     const int b = blockIdx.y;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;     // one wave per query
     const int lane = threadIdx.x & 63;
@@ -248,13 +248,14 @@ __global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const floa
     if (lane == 0) {
         const float mean = (float)(acc / (double)N);
         mt[(size_t)b * L + wave] = mean * thr[(size_t)b * L + wave];
+        if (mu_out != nullptr) mu_out[(size_t)b * L + wave] = mean;
     }
 }
 
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
-                            const float* thr, float* mt) {
+                            const float* thr, float* mt, float* mu_out) {
     dim3 grid((L + 3) / 4, B), block(256);
-    hipLaunchKernelGGL(query_thresholds_kernel, grid, block, 0, s, L, N, feat_rows(L), wq, colsum, thr, mt);
+    hipLaunchKernelGGL(query_thresholds_kernel, grid, block, 0, s, L, N, feat_rows(L), wq, colsum, thr, mt, mu_out);
     DAGL_LAUNCH_CHECK("query_thresholds_kernel");
     return DAGL_OK;
 }

@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     if (valid) {
         a.nb_idx[ql * a.width + lane] = my_key;
         a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
+        if (a.nb_s != nullptr) a.nb_s[ql * a.width + lane] = my_s;
     }
     if (lane == 0) {
         a.nb_cnt[ql] = n;

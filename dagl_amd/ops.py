@@ -328,3 +328,84 @@ def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: i
         return None, meta
     check(rc, "dagl_ces_stage_forward")
     return out, meta
+
+
+def _aligned(buf: torch.Tensor):
+    base = buf.data_ptr()
+    a = (base + 255) // 256 * 256
+    return a, buf.numel() - (a - base)
+
+
+def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: int = 0,
+                    workspace: "Workspace | None" = None, exact_scan: bool = False):
+    """Graph core with the projections given (training path, include/dagl_ce.h ``dagl_ce_core_forward``):
+    wq_rows [B,L,196], x_rows [B,N,196], b2 [B,16,H,W], thr/bias [B,L] -> (out [B,16,H,W], saved lists dict)."""
+    lib = _lib.load()
+    if mode not in MODES:
+        raise DaglError(f"unknown mode {mode!r}")
+    for n, t in (("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2)):
+        _need(t, n)
+    B, c, H, W = b2.shape
+    Lh, Lw = query_grid(H, W)
+    L, N = Lh * Lw, H * W
+    if c != 16 or tuple(wq_rows.shape) != (B, L, 196) or tuple(x_rows.shape) != (B, N, 196):
+        raise DaglError("ce_core_forward: expected wq_rows [B,L,196], x_rows [B,H*W,196], b2 [B,16,H,W]")
+    adaptive = mode != "topk"
+    if adaptive:
+        _need(thr, "thr"); _need(bias, "bias")
+        if thr.numel() != B * L or bias.numel() != B * L:
+            raise DaglError("ce_core_forward: thr/bias must hold B*L values")
+    mode_flags = MODES[mode] | (_lib.FLAG_EXACT_SCAN if exact_scan else 0)
+    width = lib.dagl_ce_list_width(mode_flags, int(k))
+    check(min(width, 0), "dagl_ce_list_width")
+    need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
+    if need == 0:
+        check(-1, "dagl_ce_workspace_bytes")
+    ws = workspace if workspace is not None else Workspace()
+    dev = b2.device
+    out = torch.empty(B, 16, H, W, device=dev, dtype=torch.float32)
+    saved = dict(nb_idx=torch.zeros(B, L, width, device=dev, dtype=torch.int32),
+                 nb_wgt=torch.zeros(B, L, width, device=dev, dtype=torch.float32),
+                 nb_s=torch.zeros(B, L, width, device=dev, dtype=torch.float32),
+                 nb_cnt=torch.zeros(B, L, device=dev, dtype=torch.int32),
+                 mu=torch.zeros(B, L, device=dev, dtype=torch.float32) if adaptive else None)
+    info = _lib.CeInfo()
+    a, nbytes = _aligned(ws.get(need, dev))
+    rc = lib.dagl_ce_core_forward(_stream(), B, H, W, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+                                  thr.data_ptr() if adaptive else None, bias.data_ptr() if adaptive else None,
+                                  mode_flags, int(k), out.data_ptr(), saved["nb_idx"].data_ptr(),
+                                  saved["nb_wgt"].data_ptr(), saved["nb_s"].data_ptr(), saved["nb_cnt"].data_ptr(),
+                                  saved["mu"].data_ptr() if adaptive else None, a, nbytes, C.byref(info))
+    check(rc, "dagl_ce_core_forward")
+    saved["info"] = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=info.path,
+                         redone_queries=info.redone_queries)
+    return out, saved
+
+
+def ce_core_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, mode: str = "adaptive", k: int = 0,
+                     workspace: "Workspace | None" = None):
+    """Gradients of the graph core (``dagl_ce_core_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias)."""
+    lib = _lib.load()
+    for n, t in (("d_out", d_out), ("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2)):
+        _need(t, n)
+    B, _, H, W = b2.shape
+    adaptive = mode != "topk"
+    need = lib.dagl_ce_core_backward_workspace_bytes(B, H, W, MODES[mode], int(k))
+    if need == 0:
+        check(-1, "dagl_ce_core_backward_workspace_bytes")
+    ws = workspace if workspace is not None else Workspace()
+    dev = b2.device
+    d_wq = torch.empty_like(wq_rows)
+    d_x = torch.empty_like(x_rows)
+    d_b2 = torch.empty_like(b2)
+    d_thr = torch.empty(B, wq_rows.shape[1], device=dev, dtype=torch.float32) if adaptive else None
+    d_bias = torch.empty_like(d_thr) if adaptive else None
+    a, nbytes = _aligned(ws.get(need, dev))
+    p = lambda t: t.data_ptr() if t is not None else None
+    rc = lib.dagl_ce_core_backward(_stream(), B, H, W, MODES[mode], int(k), wq_rows.data_ptr(), x_rows.data_ptr(),
+                                   b2.data_ptr(), p(thr) if adaptive else None, p(bias) if adaptive else None,
+                                   saved["nb_idx"].data_ptr(), saved["nb_wgt"].data_ptr(), saved["nb_s"].data_ptr(),
+                                   saved["nb_cnt"].data_ptr(), p(saved["mu"]), d_out.data_ptr(), d_wq.data_ptr(),
+                                   d_x.data_ptr(), d_b2.data_ptr(), p(d_thr), p(d_bias), a, nbytes)
+    check(rc, "dagl_ce_core_backward")
+    return d_wq, d_x, d_b2, d_thr, d_bias

@@ -68,6 +68,7 @@ extern "C" {
 #define DAGL_ERR_WORKSPACE       -2   /* workspace too small; info->required_bytes says how much     */
 #define DAGL_ERR_HIP             -3   /* a HIP call / launch failed (message has hipGetErrorString)  */
 #define DAGL_ERR_NO_DEVICE       -4   /* no gfx950 device visible                                    */
+#define DAGL_ERR_UNSUPPORTED     -5   /* training entry point: neighbourhood denser than DAGL_FAST_CAP */
 
 typedef struct dagl_profile dagl_profile;     /* opaque stage profile, see dagl_profile_* below */
 
@@ -172,6 +173,34 @@ int dagl_ce_forward_profiled(void* stream, int B, int H, int W,
                              const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                              int mode, int k, float* out,
                              void* workspace, size_t ws_bytes, dagl_ce_info* info, dagl_profile* prof);
+
+/* ---- training: graph core with the features given, and its backward ---------------------------
+ * Replaces what autograd records for dagl.py:250-272 (score matrix, adaptive mask, non-renormalised softmax,
+ * aggregation, fold) when the block is trained (DN_Gray/trainer.py:44-50 loss.backward()).  The host computes
+ * the projections itself (under its own autograd: wq_rows = relu(fc1(unfold4(b1))) [B,L,196],
+ * x_rows = relu(fc2(unfold1(b1))) [B,N,196], dagl.py:240-249) and gets back the fixed-width neighbour lists
+ * (width = dagl_ce_list_width(mode,k)) the backward needs.  Sparse neighbourhoods only: an adaptive mask that
+ * keeps more than DAGL_FAST_CAP keys for some query returns DAGL_ERR_UNSUPPORTED.
+ * Workspace of the forward: dagl_ce_workspace_bytes(B,H,W,mode,k).                                          */
+int    dagl_ce_list_width(int mode, int k);
+int    dagl_ce_core_forward(void* stream, int B, int H, int W,
+                            const float* wq_rows, const float* x_rows, const float* b2 /* [B,16,H,W] */,
+                            const float* thr, const float* bias /* [B,L], NULL in top-k mode */,
+                            int mode, int k, float* out /* [B,16,H,W] */,
+                            int32_t* nb_idx, float* nb_wgt, float* nb_s /* [B,L,width] each */,
+                            int32_t* nb_cnt /* [B,L] */, float* mu /* [B,L] row means, adaptive modes */,
+                            void* workspace, size_t ws_bytes, dagl_ce_info* info);
+size_t dagl_ce_core_backward_workspace_bytes(int B, int H, int W, int mode, int k);
+/* Gradients of a scalar loss w.r.t. wq_rows, x_rows, b2, thr, bias given d_out = dL/d out.  d_x_rows and d_b2
+ * are accumulated with fp32 atomics (run-to-run differences at fp32 rounding level); d_thr / d_bias may be NULL
+ * in top-k mode.  The selection itself (which keys are neighbours) carries no gradient, as in the reference.  */
+int    dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k,
+                             const float* wq_rows, const float* x_rows, const float* b2,
+                             const float* thr, const float* bias,
+                             const int32_t* nb_idx, const float* nb_wgt, const float* nb_s, const int32_t* nb_cnt,
+                             const float* mu, const float* d_out,
+                             float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias,
+                             void* workspace, size_t ws_bytes);
 
 /* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
 

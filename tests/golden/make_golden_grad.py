@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Gradient golden vectors from the REFERENCE block's own autograd (CPU, build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_grad.py
+
+For each case the reference ``CE`` (DN_Gray/model/dagl.py:174-277; fixed-k variant from
+.ipynb_checkpoints/GReccR2b_3mh_1-checkpoint.py) is run WITH autograd on seeded inputs, the scalar
+``loss = sum(out * G)`` (G seeded, numpy PCG64) is back-propagated the way DN_Gray/trainer.py:44-50 does, and only
+DATA is stored in ``tests/golden/grad_<case>.npz``:
+
+    out          [B,16,H,W]      forward output
+    d_x          [B,64,H,W]      dL/d input feature map
+    d_<param>    gradient of every parameter that takes part (fc weights: every ``fc_step``-th element, flattened)
+    meta         json            case description
+
+The fixed-k variant returns ``b + W(y)``; the loss is put on ``y`` (the 16-channel block output, captured at W's input).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from dagl_amd.synth import make_ce_params, make_features  # noqa: E402
+from make_golden import _load_module  # noqa: E402
+
+# (name, task, seed, variant, sparse_gain, mode, k, B, H, W)
+CASES = [
+    ("gray_sparse_b2_40x36", "DN_Gray", 31, "sparse", 1.8, "adaptive", 0, 2, 40, 36),
+    ("gray_sparse_64x64", "DN_Gray", 32, "sparse", 2.2, "adaptive", 0, 1, 64, 64),
+    ("topk8_b2_45x38", "TOPK", 33, "default", 2.0, "topk", 8, 2, 45, 38),
+    ("topk4_64x64", "TOPK", 34, "default", 2.0, "topk", 4, 1, 64, 64),
+]
+FC_STEP = 5
+
+
+def loss_weights(seed: int, shape):
+    return np.random.Generator(np.random.PCG64(seed + 1000)).standard_normal(shape).astype(np.float32)
+
+
+def run_case(case):
+    name, task, seed, variant, gain, mode, k, B, H, W = case
+    mod = _load_module(task)
+    np_params = make_ce_params(seed, variant=variant, sparse_gain=gain)
+    x = torch.from_numpy(make_features(seed, B, 64, H, W)).requires_grad_(True)
+    if task == "TOPK":
+        ce = mod.CE(in_channels=64, num_edge=k)
+        sd = {n: torch.from_numpy(a) for n, a in np_params.items() if not n.startswith(("thr_conv", "bias_conv"))}
+        ce.load_state_dict(sd, strict=False)
+    else:
+        ce = mod.CE(in_channels=64)
+        ce.load_state_dict({n: torch.from_numpy(a) for n, a in np_params.items()}, strict=True)
+    ce.train()
+    grabbed = {}
+    if task == "TOPK":
+        ce.W.register_forward_pre_hook(lambda m, inp: grabbed.__setitem__("y", inp[0]))
+    y = ce(x)
+    out = grabbed["y"] if task == "TOPK" else y
+    G = torch.from_numpy(loss_weights(seed, tuple(out.shape)))
+    (out * G).sum().backward()
+    arrays = dict(out=out.detach().numpy().astype(np.float32), d_x=x.grad.numpy().astype(np.float32))
+    for n, p in ce.named_parameters():
+        if n.startswith(("W.", "conv33")) or p.grad is None:
+            continue
+        g = p.grad.numpy().astype(np.float32)
+        arrays["d_" + n] = g.reshape(-1)[::FC_STEP].copy() if n in ("fc1.0.weight", "fc2.0.weight") else g
+    meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode, k=k, B=B, C=64, H=H, W=W,
+                fc_step=FC_STEP, torch=torch.__version__)
+    np.savez_compressed(os.path.join(HERE, "grad_" + name + ".npz"), meta=json.dumps(meta), **arrays)
+    print(name, {n: (a.shape, float(np.abs(a).max())) for n, a in arrays.items()}, flush=True)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    for c in CASES:
+        run_case(c)

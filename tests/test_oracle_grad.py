@@ -1,0 +1,65 @@
+"""The oracle's autograd against the reference's own gradients (tests/golden/grad_*.npz, made by make_golden_grad.py
+from the reference CE run with autograd): pins the checker the GPU backward tests use."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_DIR, normwise
+from oracle.ce_oracle import ce_forward_oracle
+
+GRAD_CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "grad_*.npz")))
+
+
+def load_grad_case(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, {k: z[k] for k in z.files if k != "meta"}
+
+
+def grad_case_inputs(meta):
+    from dagl_amd.synth import make_ce_params, make_features
+    p = make_ce_params(meta["seed"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
+    x = torch.from_numpy(make_features(meta["seed"], meta["B"], meta["C"], meta["H"], meta["W"]))
+    G = np.random.Generator(np.random.PCG64(meta["seed"] + 1000)).standard_normal(
+        (meta["B"], 16, meta["H"], meta["W"])).astype(np.float32)
+    return x, {n: torch.from_numpy(a) for n, a in p.items()}, torch.from_numpy(G)
+
+
+def oracle_grads(meta, dtype):
+    x, params, G = grad_case_inputs(meta)
+    x = x.to(dtype).requires_grad_(True)
+    P = {n: t.to(dtype).requires_grad_(True) for n, t in params.items()}
+    out = ce_forward_oracle(x, P, mode=meta["mode"], k=meta["k"] or None, dtype=dtype)
+    (out * G.to(dtype)).sum().backward()
+    grads = {"d_x": x.grad}
+    grads.update({"d_" + n: t.grad for n, t in P.items() if t.grad is not None})
+    return out.detach(), grads
+
+
+def compare_grads(got: dict, want: dict, fc_step: int, tol: float):
+    worst = {}
+    for name, w in want.items():
+        if not name.startswith("d_"):
+            continue
+        g = got[name].detach().cpu().double().numpy()
+        if name in ("d_fc1.0.weight", "d_fc2.0.weight"):
+            g = g.reshape(-1)[::fc_step]
+        worst[name] = normwise(g, w)
+    bad = {n: e for n, e in worst.items() if e > tol}
+    assert not bad, f"gradient mismatch (normwise > {tol}): {bad}"
+    return worst
+
+
+@pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(p)[5:-4] for p in GRAD_CASES])
+def test_oracle_autograd_matches_reference_gradients(path):
+    meta, want = load_grad_case(path)
+    out, grads = oracle_grads(meta, torch.float32)
+    assert normwise(out.numpy(), want["out"]) <= 1e-4
+    compare_grads(grads, want, meta["fc_step"], 2e-4)
+    if meta["mode"] != "topk":          # the sparse cases must stay inside the fixed-width lists of the HIP backward
+        _, st = ce_forward_oracle(grad_case_inputs(meta)[0], grad_case_inputs(meta)[1], mode="adaptive", stages=True)
+        assert int(st["deg"].max()) <= 64
