@@ -52,6 +52,11 @@ def parse():
                     help="screened: bf16 matrix-core screen + exact refine (default); exact: all scores on the fp32 matrix cores")
     ap.add_argument("--stage", action="store_true",
                     help="time one CES stage (4 heads sharing the input + 1x1 mix + residual, dagl_ces_stage_forward) instead of one head")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary workload (BASELINE configs[4]): one optimisation step of the whole RR network on "
+                         "--crop x --crop crops, --batch crops per GPU, DDP gradient all-reduce over RCCL")
+    ap.add_argument("--crop", type=int, default=128)
+    ap.add_argument("--colors", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true", help="skip the Set12 sigma=50 PSNR-delta leg")
     ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
@@ -115,6 +120,55 @@ def quality_leg(dev):
             "bar_db": 0.02, "seconds": time.perf_counter() - t0}
 
 
+def train_bench(args, dev, dist, world, rank):
+    """BASELINE configs[4] in the sparse regime the backward serves: RR (12 CE heads, fixed-k selection) trained on
+    synthetic crops, fwd + bwd + Adam per step, one process per GPU under DDP (RCCL all-reduce of 5.7 M gradients)."""
+    from dagl_amd.net import RR, seeded_state_dict
+    from dagl_amd.shard import rank_seed, reduce_max_seconds
+    from dagl_amd.train import TrainOptions, TrainStep, freeze_unused, make_optimizer, wrap_ddp
+    from dagl_amd.ce import CE
+    B = args.batch if args.batch > 1 else 8
+    net = RR(n_colors=args.colors)
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 7), strict=True)       # same weights on every rank
+    for m in net.modules():
+        if isinstance(m, CE):
+            m.select_mode, m.select_k, m.scan = args.mode, args.k, args.scan
+    net = net.to(dev)
+    freeze_unused(net)
+    model = wrap_ddp(net, dev) if dist is not None else net
+    opt = TrainOptions(task="dn_real", lr=1e-4)
+    step = TrainStep(model, make_optimizer(model, opt), opt,
+                     generator=torch.Generator(device=dev).manual_seed(rank_seed(300, rank)))
+    g = torch.Generator().manual_seed(rank_seed(200, rank))
+    hr = torch.rand(B, args.colors, args.crop, args.crop, generator=g).to(dev)     # resident in HBM
+    losses = []
+    for _ in range(args.warmup):
+        step(hr)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step(hr)[0])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = reduce_max_seconds(time.perf_counter() - t0, dist, dev)
+    if rank == 0:
+        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+        line = {"metric": f"RR train crops/s (fwd+bwd+Adam) @{args.crop}x{args.crop} {args.mode} k={args.k}",
+                "value": world * B * args.steps / elapsed, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[4] (sparse regime): RR with 12 CE heads, crops [{B},{args.colors},"
+                                       f"{args.crop},{args.crop}] per GPU, MSE(sum)/(2B) loss, Adam, gradients of "
+                                       f"{n_par} parameters all-reduced over RCCL",
+                           "parallelism": f"ddp{world}", "select_mode": args.mode, "k": args.k, "batch_per_gpu": B},
+                "roofline": None, "cpu_baseline": None,
+                "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None}
+        print(json.dumps(line))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +184,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: used for the barriers/max only
+
+    if args.train:
+        train_bench(args, dev, dist, world, rank)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from dagl_amd import ops
     from dagl_amd.ce import CE

@@ -1,0 +1,120 @@
+"""Training-step glue around the differentiable block (BASELINE config 5).
+
+Restates what the reference trainers do per batch (DN_Gray/trainer.py:44-61, CAR/trainer.py:44-58,
+Demosaic/trainer.py:58-72) without their per-step host round trips: noise synthesis on the device, forward, the task's
+hard-coded loss, the loss-spike guard, backward, optimizer step.  PSNR of the batch is returned as a device scalar
+(the reference calls skimage on the CPU every step, ``batch_PSNR`` utils.py:18-24).
+
+Data parallelism is one process per GPU: ``wrap_ddp`` puts torch's DistributedDataParallel (backend "nccl" = RCCL over
+xGMI) around the network, which all-reduces the 5.7 M gradients in buckets while the backward is still running.  The
+reference only has ``nn.DataParallel`` (DN_Gray/model/__init__.py:101-103).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+LOSSES = {
+    # task -> (reduction, scale as a function of batch size)       reference line
+    "dn_gray": ("mse_sum", lambda b: 1.0 / (2.0 * b)),             # DN_Gray/trainer.py:19,52
+    "dn_real": ("mse_sum", lambda b: 1.0 / (2.0 * b)),             # DN_Real ships no trainer; DN_Gray's is used
+    "car": ("mse_mean", lambda b: 255.0 ** 2),                     # CAR/trainer.py:19,50
+    "demosaic": ("l1_sum", lambda b: 1.0 / (2.0 * b)),             # Demosaic/trainer.py:23,65
+}
+
+
+@dataclass
+class TrainOptions:                      # defaults of DN_Gray/option.py:88-125
+    lr: float = 4e-4
+    lr_decay: int = 200
+    gamma: float = 0.5
+    beta1: float = 0.9
+    beta2: float = 0.999
+    epsilon: float = 1e-8
+    weight_decay: float = 0.0
+    skip_threshold: float = 1e6
+    noise_sigma: float = 50.0            # --noiseL
+    rgb_range: float = 1.0
+    task: str = "dn_gray"
+
+
+def freeze_unused(model: nn.Module) -> int:
+    """``CE.W`` is registered but never applied (dagl.py:192), so it never receives a gradient: take it out of the
+    trainable set so that DDP does not wait for it.  Returns the number of parameters frozen."""
+    n = 0
+    for name, p in model.named_parameters():
+        if name.split(".")[-2:-1] == ["W"] and p.requires_grad:
+            p.requires_grad_(False)
+            n += p.numel()
+    return n
+
+
+def make_optimizer(model: nn.Module, opt: TrainOptions):
+    """ADAM over the trainable parameters (utility.make_optimizer, DN_Gray/utility.py:152-171)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    return torch.optim.Adam(params, lr=opt.lr, betas=(opt.beta1, opt.beta2), eps=opt.epsilon,
+                            weight_decay=opt.weight_decay)
+
+
+def make_scheduler(optimizer, opt: TrainOptions):
+    """Step decay (utility.make_scheduler, DN_Gray/utility.py:173-190, decay_type 'step')."""
+    return torch.optim.lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay, gamma=opt.gamma)
+
+
+def task_loss(sr: torch.Tensor, hr: torch.Tensor, task: str) -> torch.Tensor:
+    kind, scale = LOSSES[task]
+    b = hr.shape[0]
+    if kind == "mse_sum":
+        return (sr - hr).pow(2).sum() * scale(b)
+    if kind == "mse_mean":
+        return (sr - hr).pow(2).mean() * scale(b)
+    return (sr - hr).abs().sum() * scale(b)
+
+
+def batch_psnr_device(img: torch.Tensor, ref: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """Mean per-image PSNR as a device scalar (utils.batch_PSNR, DN_Gray/utils.py:18-24, without the host copy)."""
+    mse = (img.detach().float() - ref.float()).pow(2).flatten(1).mean(dim=1)
+    return (10.0 * torch.log10(data_range ** 2 / mse.clamp_min(1e-20))).mean()
+
+
+def wrap_ddp(model: nn.Module, device: torch.device, bucket_mb: int = 12):
+    """One process per GPU: gradients all-reduced over RCCL in ~2 buckets of the 22.9 MB total, overlapped with the
+    rest of the backward (xGMI rings are per-link bound: few large messages)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    freeze_unused(model)
+    ids = [device.index] if device.type == "cuda" else None
+    return DDP(model, device_ids=ids, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True,
+               broadcast_buffers=False, find_unused_parameters=False)
+
+
+class TrainStep:
+    """One optimisation step on a batch of clean crops; keeps ``error_last`` of the loss-spike guard
+    (DN_Gray/trainer.py:29,55-61: skip backward/step when loss >= skip_threshold * error_last)."""
+
+    def __init__(self, model: nn.Module, optimizer, opt: TrainOptions, generator: "torch.Generator | None" = None):
+        self.model, self.optimizer, self.opt, self.generator = model, optimizer, opt, generator
+        self.error_last = 1e8
+        self.skipped = 0
+
+    def __call__(self, hr: torch.Tensor, lr: "torch.Tensor | None" = None, check_spike: bool = False):
+        """hr: clean crops [B,C,H,W] in [0, rgb_range].  lr: degraded input, or None for synthetic Gaussian noise of
+        sigma ``noise_sigma``/255 drawn on the device (trainer.py:49).  Returns (loss, psnr) as device scalars.
+        ``check_spike`` reads the loss back (one host sync) to apply the reference's guard; off by default because
+        the shipped ``error_last`` = 1e8 can never trigger it."""
+        o = self.opt
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        if lr is None:
+            noise = torch.empty_like(hr).normal_(mean=0.0, std=o.noise_sigma / 255.0 * o.rgb_range,
+                                                 generator=self.generator)
+            lr = hr + noise
+        sr = self.model(lr)
+        loss = task_loss(sr, hr, o.task)
+        if check_spike and not (float(loss.detach()) < o.skip_threshold * self.error_last):
+            self.skipped += 1
+            return loss.detach(), batch_psnr_device(sr, hr, o.rgb_range)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), batch_psnr_device(sr, hr, o.rgb_range)
