@@ -11,8 +11,13 @@
 //   per query:  d bias = sum_t d m_t,  d thr = -mu sum_t d m_t,  d mu = -thr sum_t d m_t
 //   mu_l = Wq_l . mean_j X_j                 d Wq_l += d mu_l Xbar,   d X_j += (sum_l d mu_l Wq_l) / N   for ALL keys j
 //   S_lj = Wq_l . X_j                        d Wq_l += sum_t d S_t X_{j_t},   d X_{j_t} += d S_t Wq_l
-// Scatter-adds into d X and d b2 use fp32 atomics (their order is not fixed: gradients are reproducible only up to
-// fp32 reassociation, like the reference's cuDNN/cuBLAS backward).
+// The two scatter-adds (d V into the value map, d S Wq into the key features) are turned into gathers: the edge list is
+// sorted by key with a stable radix sort (rocPRIM -- the one library primitive of this library; edge ids ascend
+// inside a key's run), so every output element is summed by one thread in a fixed order: no atomics, bit-reproducible
+// gradients.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void unfold_dout_kernel(Grid g, const float* _
     for (int q = 0; q < CH / 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-// one wave per query: d A, softmax / logit backward, per-query threshold gradients, d V scatter
+// one wave per query: d A, softmax / logit backward, per-query threshold gradients
 __global__ __launch_bounds__(256) void edge_backward_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,7 +68,6 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(BwdArgs a) {
         voff[u] = (kh * a.g.Wp) * (CH / 4) + rem;                     // float4 offset inside a key's window
     }
     const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH);
-    float* dvm = a.db2p + (size_t)b * a.g.Hp * a.g.Wp * CH;
 
     // pass 1: d A_t (lane t keeps neighbour t's value; width <= 64)
     float my_dA = 0.f;
@@ -108,20 +112,6 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(BwdArgs a) {
             a.dmu[ql] = -a.thr[ql] * sdm;
         }
     }
-    // pass 2: d V_{j_t} += A_t d agg_l   (scatter into the padded value-map gradient)
-    for (int t = 0; t < n; ++t) {
-        const int j = a.nb_idx[ql * a.width + t];
-        const float w = a.nb_wgt[ql * a.width + t];
-        const int jy = j / a.g.W, jx = j - jy * a.g.W;
-        float* dvj = dvm + ((size_t)jy * a.g.Wp + jx) * CH;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (ok[u]) {
-                float* p = dvj + (size_t)voff[u] * 4;
-                atomicAdd(p + 0, w * d4[u].x); atomicAdd(p + 1, w * d4[u].y);
-                atomicAdd(p + 2, w * d4[u].z); atomicAdd(p + 3, w * d4[u].w);
-            }
-    }
 }
 
 // d Xbar[b,:] = sum_l d mu_l Wq_l[:]   (adaptive modes): one block per (b, column quad group); fixed-order partials
@@ -143,84 +133,263 @@ __global__ __launch_bounds__(256) void dxbar_kernel(int L, const float* __restri
     for (int c = threadIdx.x; c < D; c += 256) dxbar[(size_t)b * D + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
-// d X[b,j,:] = d Xbar[b,:]/N (adaptive) or 0 (top-k): the dense part of the key-feature gradient
-__global__ void dx_init_kernel(size_t n, int N, const float* __restrict__ dxbar, float* __restrict__ dx) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (dxbar == nullptr) { dx[i] = 0.f; return; }
-    const size_t row = i / D; const int c = (int)(i % D);
-    const size_t b = row / N;
-    dx[i] = dxbar[b * D + c] / (float)N;
+// ---- edges sorted by key ------------------------------------------------------------------------------------------
+// sort key = b*N + j (invalid list slots: B*N, sorted to the end), value = edge id = (b*L + l)*width + t
+__global__ void edge_keys_kernel(BwdArgs a, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t E = (size_t)a.B * a.g.L * a.width;
+    if (e >= E) return;
+    const size_t ql = e / a.width; const int t = (int)(e - ql * a.width);
+    const size_t b = ql / a.g.L;
+    const bool valid = t < a.nb_cnt[ql];
+    keys[e] = valid ? (uint32_t)(b * a.g.N + a.nb_idx[e]) : (uint32_t)((size_t)a.B * a.g.N);
+    vals[e] = (uint32_t)e;
 }
 
-// one wave per query: d Wq_l = sum_t d S_t X_{j_t} + d mu_l Xbar;  d X_{j_t} += d S_t Wq_l
-__global__ __launch_bounds__(256) void feature_backward_kernel(BwdArgs a) {
+// run boundaries of the sorted keys: seg[2k] = first position of key k, seg[2k+1] = one past its last (0,0 = no edge)
+__global__ void segment_bounds_kernel(size_t E, uint32_t n_keys, const uint32_t* __restrict__ keys, uint32_t* __restrict__ seg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const uint32_t k = keys[i];
+    if (k >= n_keys) return;
+    if (i == 0 || keys[i - 1] != k) seg[2 * (size_t)k] = (uint32_t)i;
+    if (i + 1 == E || keys[i + 1] != k) seg[2 * (size_t)k + 1] = (uint32_t)(i + 1);
+}
+
+// ---- segmented reduction over the key-sorted edges ------------------------------------------------------------------
+// Every key j with incoming edges gets one row of 980 floats = [ sum_e A_e d agg_{l_e}  (784: d V patch of key j) |
+// sum_e d S_e Wq_{l_e} (196: d X_j without the dense term) ], stored at rowbuf[first sorted position of j's run].
+// In-degrees are heavy-tailed (a few hub keys are neighbours of hundreds of queries), so the work is cut into fixed
+// chunks of SEG_C sorted edges, one wave each; a run that crosses chunk boundaries leaves per-chunk partial rows that
+// row_fixup_kernel adds up in chunk order.  Everything is summed in a fixed order: bit-reproducible.
+constexpr int SEG_C = 16;
+constexpr int ROWF = P + D;                 // 980 floats
+constexpr int ROWQ = ROWF / 4;              // 245 float4: lane owns slots lane + 64 u, u < 4
+
+__device__ __forceinline__ float4 f4_fma(float c, const float4& v, const float4& a) {
+    return make_float4(a.x + c * v.x, a.y + c * v.y, a.z + c * v.z, a.w + c * v.w);
+}
+
+__global__ __launch_bounds__(256) void edge_segreduce_kernel(BwdArgs a, size_t E, uint32_t n_keys,
+                                                              const uint32_t* __restrict__ keys, const uint32_t* __restrict__ eids,
+                                                              const uint32_t* __restrict__ seg, float* __restrict__ rowbuf,
+                                                              float* __restrict__ part /* [chunks][2][980] */) {
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t p0 = chunk * SEG_C;
+    if (p0 >= E) return;
+    const size_t p1 = (p0 + SEG_C < E) ? p0 + SEG_C : E;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t cur = keys[p0];
+    auto flush = [&](uint32_t key, size_t pos_end) {
+        // the run of `key` ends at sorted position pos_end (exclusive) as far as this chunk sees it
+        if (key >= n_keys) return;                                    // invalid list slots
+        const uint32_t e0 = seg[2 * (size_t)key], e1 = seg[2 * (size_t)key + 1];
+        float* dst;
+        if (e0 >= p0 && e1 <= p1) dst = rowbuf + (size_t)e0 * ROWF;           // run entirely inside this chunk
+        else if (e0 < p0) dst = part + (chunk * 2 + 0) * ROWF;                 // run came in from an earlier chunk
+        else dst = part + (chunk * 2 + 1) * ROWF;                              // run continues into later chunks
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = lane + 64 * u;
+            if (r < ROWQ) reinterpret_cast<float4*>(dst)[r] = acc[u];
+            acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    for (size_t p = p0; p < p1; ++p) {
+        const uint32_t key = keys[p];
+        if (key != cur) { flush(cur, p); cur = key; }
+        if (key >= n_keys) break;                                     // sorted: only invalid slots follow
+        const uint32_t eid = eids[p];
+        const float w = a.nb_wgt[eid], ds = a.dS[eid];
+        const size_t ql = eid / (uint32_t)a.width;
+        const float4* dg = reinterpret_cast<const float4*>(a.dagg + ql * P);
+        const float4* wq = reinterpret_cast<const float4*>(a.wq_rows + ql * D);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = lane + 64 * u;
+            if (r < P / 4) acc[u] = f4_fma(w, dg[r], acc[u]);
+            else if (r < ROWQ) acc[u] = f4_fma(ds, wq[r - P / 4], acc[u]);
+        }
+    }
+    flush(cur, p1);
+}
+
+// runs that cross chunk boundaries: the chunk in which such a run STARTS adds up its tail partial and the head
+// partials of the following chunks, in chunk order, into the run's row
+__global__ __launch_bounds__(256) void row_fixup_kernel(size_t E, uint32_t n_keys, const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ seg, float* __restrict__ rowbuf,
+                                                         const float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t p0 = chunk * SEG_C;
+    if (p0 >= E) return;
+    const size_t p1 = (p0 + SEG_C < E) ? p0 + SEG_C : E;
+    const uint32_t key = keys[p1 - 1];                                // the only run that can leave through the end
+    if (key >= n_keys) return;
+    const uint32_t e0 = seg[2 * (size_t)key], e1 = seg[2 * (size_t)key + 1];
+    if (e1 <= p1 || e0 < p0) return;                                  // ends here, or started in an earlier chunk
+    const size_t c_last = ((size_t)e1 - 1) / SEG_C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = lane + 64 * u;
+        if (r >= ROWQ) continue;
+        float4 t = reinterpret_cast<const float4*>(part + (chunk * 2 + 1) * ROWF)[r];
+        for (size_t c = chunk + 1; c <= c_last; ++c) {
+            const float4 h = reinterpret_cast<const float4*>(part + (c * 2 + 0) * ROWF)[r];
+            t.x += h.x; t.y += h.y; t.z += h.z; t.w += h.w;
+        }
+        reinterpret_cast<float4*>(rowbuf + (size_t)e0 * ROWF)[r] = t;
+    }
+}
+
+// d b2[b,c,y,x] = sum over the keys j whose 7x7 window covers (y,x) of (d V patch of j)[(kh,kw,c)]; thread = pixel
+__global__ __launch_bounds__(256) void dvalue_fold_kernel(BwdArgs a, const uint32_t* __restrict__ seg,
+                                                           const float* __restrict__ rowbuf, float* __restrict__ db2) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.B * a.g.N) return;
+    const size_t b = t / a.g.N; const size_t r = t - b * a.g.N;
+    const int y = (int)(r / a.g.W), x = (int)(r - (size_t)y * a.g.W);
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < KS; ++kh) {
+        const int jy = y + 3 - kh;
+        if (jy < 0 || jy >= a.g.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int jx = x + 3 - kw;
+            if (jx < 0 || jx >= a.g.W) continue;
+            const size_t key = b * a.g.N + (size_t)jy * a.g.W + jx;
+            const uint2 e = *reinterpret_cast<const uint2*>(seg + 2 * key);
+            if (e.y > e.x) {
+                const float4* row = reinterpret_cast<const float4*>(rowbuf + (size_t)e.x * ROWF + (kh * KS + kw) * CH);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = row[q];
+                    acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+                }
+            }
+        }
+    }
+    float* o = db2 + (b * CH * a.g.H + y) * a.g.W + x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        o[(size_t)(4 * q + 0) * a.g.N] = acc[q].x; o[(size_t)(4 * q + 1) * a.g.N] = acc[q].y;
+        o[(size_t)(4 * q + 2) * a.g.N] = acc[q].z; o[(size_t)(4 * q + 3) * a.g.N] = acc[q].w;
+    }
+}
+
+// d X[b,j,:] = d Xbar[b,:]/N (adaptive modes) + (d X part of key j's row);  thread = (key, column quad)
+__global__ __launch_bounds__(256) void dx_finalize_kernel(BwdArgs a, const uint32_t* __restrict__ seg,
+                                                           const float* __restrict__ rowbuf, const float* __restrict__ dxbar) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int Q = D / 4;                                   // 49 float4 per feature row
+    if (t >= (size_t)a.B * a.g.N * Q) return;
+    const size_t key = t / Q; const int c4 = (int)(t - key * Q);
+    const size_t b = key / a.g.N;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dxbar != nullptr) {
+        const float4 xb = *reinterpret_cast<const float4*>(dxbar + b * D + c4 * 4);
+        const float inv = 1.0f / (float)a.g.N;
+        acc = make_float4(xb.x * inv, xb.y * inv, xb.z * inv, xb.w * inv);
+    }
+    const uint2 e = *reinterpret_cast<const uint2*>(seg + 2 * key);
+    if (e.y > e.x) {
+        const float4 v = *reinterpret_cast<const float4*>(rowbuf + (size_t)e.x * ROWF + P + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.dx_rows + key * D + c4 * 4) = acc;
+}
+
+// one wave per query: d Wq_l = sum_t d S_t X_{j_t} + d mu_l Xbar
+__global__ __launch_bounds__(256) void dwq_gather_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ql >= (size_t)a.B * a.g.L) return;
     const int b = (int)(ql / a.g.L);
     const int n = a.nb_cnt[ql];
-    const float* q = a.wq_rows + ql * D;
-    float qv[4], acc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; qv[u] = (c < D) ? q[c] : 0.f; acc[u] = 0.f; }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < n; ++t) {
         const int j = a.nb_idx[ql * a.width + t];
         const float ds = a.dS[ql * a.width + t];
         const float* xr = a.x_rows + ((size_t)b * a.g.N + j) * D;
-        float* dxr = a.dx_rows + ((size_t)b * a.g.N + j) * D;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = lane + 64 * u;
-            if (c < D) { acc[u] += ds * xr[c]; atomicAdd(dxr + c, ds * qv[u]); }
-        }
+        for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) acc[u] += ds * xr[c]; }
     }
     if (a.mode != DAGL_MODE_TOPK) {
         const float g = a.dmu[ql];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) acc[u] += g * (float)(a.colsum[(size_t)b * DS + c] / (double)a.g.N); }
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            if (c < D) acc[u] += g * (float)(a.colsum[(size_t)b * DS + c] / (double)a.g.N);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) a.dwq_rows[ql * D + c] = acc[u]; }
 }
 
-// padded NHWC gradient map -> NCHW [B,16,H,W]
-__global__ void unpad_nchw_kernel(int H, int W, const float* __restrict__ src, float* __restrict__ dst) {
-    const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= W) return;
-    const float* s = src + ((((size_t)b * Hp + y + PADPIX) * Wp) + x + PADPIX) * CH;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) dst[(((size_t)b * CH + c) * H + y) * W + x] = s[c];
+static int key_bits(size_t n_keys) {             // radix bits that cover 0..n_keys (n_keys itself = the invalid marker)
+    int bits = 1;
+    while (((size_t)1 << bits) <= n_keys) ++bits;
+    return bits;
 }
 
-int launch_core_backward(hipStream_t s, const BwdArgs& a, float* dxbar_ws, float* db2_nchw) {
+size_t edge_rowbuf_floats(size_t n_edges) { return n_edges * ROWF; }
+size_t edge_part_floats(size_t n_edges) { return ((n_edges + SEG_C - 1) / SEG_C) * 2 * ROWF; }
+
+size_t edge_sort_temp_bytes(size_t n_edges, size_t n_keys) {
+    size_t bytes = 0;
+    uint32_t* k = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, n_edges, 0, key_bits(n_keys), (hipStream_t)0);
+    return bytes;
+}
+
+int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, float* dxbar_ws, float* db2_nchw) {
     const Grid& g = a.g;
     const size_t nq = (size_t)a.B * g.L;
+    const size_t E = nq * a.width, n_keys = (size_t)a.B * g.N;
     {   // d agg
         const size_t items = (size_t)g.L * KS * KS;
         hipLaunchKernelGGL(unfold_dout_kernel, dim3((unsigned)((items + 255) / 256), a.B), dim3(256), 0, s, g, a.dout, a.dagg);
         DAGL_LAUNCH_CHECK("unfold_dout_kernel");
     }
-    DAGL_HIP_TRY(hipMemsetAsync(a.db2p, 0, (size_t)a.B * g.Hp * g.Wp * CH * sizeof(float), s));
     hipLaunchKernelGGL(edge_backward_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("edge_backward_kernel");
+    // edges by key
+    hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, a, w.keys_in, w.vals_in);
+    DAGL_LAUNCH_CHECK("edge_keys_kernel");
+    size_t tb = w.temp_bytes;
+    DAGL_HIP_TRY(rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, E, 0, key_bits(n_keys), s));
+    DAGL_HIP_TRY(hipMemsetAsync(w.seg, 0, 2 * n_keys * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, E, (uint32_t)n_keys, w.keys_out, w.seg);
+    DAGL_LAUNCH_CHECK("segment_bounds_kernel");
+    {
+        const size_t chunks = (E + SEG_C - 1) / SEG_C;
+        hipLaunchKernelGGL(edge_segreduce_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, a, E, (uint32_t)n_keys,
+                           w.keys_out, w.vals_out, w.seg, w.rowbuf, w.part);
+        DAGL_LAUNCH_CHECK("edge_segreduce_kernel");
+        hipLaunchKernelGGL(row_fixup_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, E, (uint32_t)n_keys,
+                           w.keys_out, w.seg, w.rowbuf, w.part);
+        DAGL_LAUNCH_CHECK("row_fixup_kernel");
+        hipLaunchKernelGGL(dvalue_fold_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s, a, w.seg, w.rowbuf, db2_nchw);
+        DAGL_LAUNCH_CHECK("dvalue_fold_kernel");
+    }
     const bool adaptive = (a.mode != DAGL_MODE_TOPK);
     if (adaptive) {
         hipLaunchKernelGGL(dxbar_kernel, dim3(a.B), dim3(256), 0, s, g.L, a.wq_rows, a.dmu, dxbar_ws);
         DAGL_LAUNCH_CHECK("dxbar_kernel");
     }
     {
-        const size_t n = (size_t)a.B * g.N * D;
-        hipLaunchKernelGGL(dx_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, g.N,
-                           adaptive ? dxbar_ws : nullptr, a.dx_rows);
-        DAGL_LAUNCH_CHECK("dx_init_kernel");
+        const size_t n = n_keys * (D / 4);
+        hipLaunchKernelGGL(dx_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, w.seg, w.rowbuf,
+                           adaptive ? dxbar_ws : nullptr);
+        DAGL_LAUNCH_CHECK("dx_finalize_kernel");
     }
-    hipLaunchKernelGGL(feature_backward_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
-    DAGL_LAUNCH_CHECK("feature_backward_kernel");
-    hipLaunchKernelGGL(unpad_nchw_kernel, dim3((g.W + 63) / 64, g.H, a.B), dim3(64), 0, s, g.H, g.W, a.db2p, db2_nchw);
-    DAGL_LAUNCH_CHECK("unpad_nchw_kernel");
+    hipLaunchKernelGGL(dwq_gather_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("dwq_gather_kernel");
     return DAGL_OK;
 }
 

@@ -655,23 +655,29 @@ int dagl_ce_core_forward(void* stream, int B, int H, int W, const float* wq_rows
                            k, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr, nullptr, nullptr, 1, &core);
 }
 
-static size_t backward_offsets(int B, const Grid& g, int width, size_t o[6]) {
+static size_t backward_offsets(int B, const Grid& g, int width, size_t o[13], size_t* sort_temp) {
     size_t off = 0;
-    const size_t BL = (size_t)B * g.L;
+    const size_t BL = (size_t)B * g.L, E = BL * width, n_keys = (size_t)B * g.N;
     o[0] = carve(off, BL * P * sizeof(float));                                  // d agg
     o[1] = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(float));            // b2 padded NHWC
-    o[2] = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(float));            // d b2 padded NHWC
-    o[3] = carve(off, BL * width * sizeof(float));                              // d S
-    o[4] = carve(off, BL * sizeof(float));                                      // d mu
-    o[5] = carve(off, (size_t)B * DS * sizeof(double) + (size_t)B * D * sizeof(float));   // column sums, d Xbar
+    o[2] = carve(off, E * sizeof(float));                                       // d S
+    o[3] = carve(off, BL * sizeof(float));                                      // d mu
+    o[4] = carve(off, (size_t)B * DS * sizeof(double) + (size_t)B * D * sizeof(float));   // column sums, d Xbar
+    for (int i = 5; i < 9; ++i) o[i] = carve(off, E * sizeof(uint32_t));        // sort keys / edge ids, in and out
+    o[9] = carve(off, 2 * n_keys * sizeof(uint32_t));                           // run of every key
+    const size_t tb = edge_sort_temp_bytes(E, n_keys);
+    o[10] = carve(off, tb);
+    o[11] = carve(off, edge_rowbuf_floats(E) * sizeof(float));
+    o[12] = carve(off, edge_part_floats(E) * sizeof(float));
+    if (sort_temp) *sort_temp = tb;
     return off;
 }
 
 size_t dagl_ce_core_backward_workspace_bytes(int B, int H, int W, int mode, int k) {
     const int width = dagl_ce_list_width(mode, k);
     if (B < 1 || H < 1 || W < 1 || width < 0) return 0;
-    size_t o[6];
-    return backward_offsets(B, make_grid(H, W), width, o);
+    size_t o[13];
+    return backward_offsets(B, make_grid(H, W), width, o, nullptr);
 }
 
 int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, const float* wq_rows, const float* x_rows,
@@ -689,8 +695,9 @@ int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, co
         DAGL_REQUIRE(thr && bias && mu && d_thr && d_bias, "dagl_ce_core_backward: thr/bias/mu and their gradients required in adaptive modes");
     DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_backward: workspace must be 256-byte aligned");
     const Grid g = make_grid(H, W);
-    size_t o[6];
-    const size_t need = backward_offsets(B, g, width, o);
+    DAGL_REQUIRE((size_t)B * g.L * width < (1ull << 31) && (size_t)B * g.N < (1ull << 31), "dagl_ce_core_backward: batch too large for 32-bit edge ids");
+    size_t o[13], sort_temp = 0;
+    const size_t need = backward_offsets(B, g, width, o, &sort_temp);
     if (ws_bytes < need) {
         set_error("dagl_ce_core_backward: workspace %zu B < required %zu B", ws_bytes, need);
         return DAGL_ERR_WORKSPACE;
@@ -703,16 +710,21 @@ int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, co
     a.nb_idx = nb_idx; a.nb_wgt = nb_wgt; a.nb_s = nb_s; a.nb_cnt = nb_cnt; a.dout = d_out;
     a.dagg = at<float>(workspace, o[0]);
     float* b2p = at<float>(workspace, o[1]);
-    a.b2p = b2p; a.db2p = at<float>(workspace, o[2]); a.dS = at<float>(workspace, o[3]); a.dmu = at<float>(workspace, o[4]);
-    double* colsum = at<double>(workspace, o[5]);
+    a.b2p = b2p; a.dS = at<float>(workspace, o[2]); a.dmu = at<float>(workspace, o[3]);
+    double* colsum = at<double>(workspace, o[4]);
     float* dxbar = reinterpret_cast<float*>(colsum + (size_t)B * DS);
     a.colsum = colsum;
     a.dwq_rows = d_wq_rows; a.dx_rows = d_x_rows; a.dthr = d_thr; a.dbias = d_bias;
+    BwdSortWs w;
+    w.keys_in = at<uint32_t>(workspace, o[5]); w.keys_out = at<uint32_t>(workspace, o[6]);
+    w.vals_in = at<uint32_t>(workspace, o[7]); w.vals_out = at<uint32_t>(workspace, o[8]);
+    w.seg = at<uint32_t>(workspace, o[9]); w.temp = at<void>(workspace, o[10]); w.temp_bytes = sort_temp;
+    w.rowbuf = at<float>(workspace, o[11]); w.part = at<float>(workspace, o[12]);
     int rc;
     if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     if (m != DAGL_MODE_TOPK)
         if ((rc = launch_colsum_rows(s, B, g.N, x_rows, colsum))) return rc;
-    return launch_core_backward(s, a, dxbar, d_b2);
+    return launch_core_backward(s, a, w, dxbar, d_b2);
 }
 
 int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,

@@ -240,12 +240,21 @@ struct BwdArgs {
     const int32_t* nb_idx; const float* nb_wgt; const float* nb_s; const int32_t* nb_cnt;
     const float* dout;                                  // [B,16,H,W]
     float* dagg;                                        // ws [B,L,784]
-    float* db2p;                                        // ws [B,Hp,Wp,16]
     float* dS;                                          // ws [B,L,width]
     float* dmu;                                         // ws [B,L]
     float* dwq_rows; float* dx_rows; float* dthr; float* dbias;          // outputs
 };
-int launch_core_backward(hipStream_t s, const BwdArgs& a, float* dxbar_ws, float* db2_nchw);
+struct BwdSortWs {                                      // edges sorted by key (stable radix sort)
+    uint32_t *keys_in, *keys_out, *vals_in, *vals_out;  // [B*L*width] each
+    uint32_t* seg;                                      // [B*N, 2] run of every key in the sorted order
+    void* temp; size_t temp_bytes;
+    float* rowbuf;                                      // [B*L*width, 980] per-key sums (row of a key = first position of its run)
+    float* part;                                        // [chunks, 2, 980] partial rows of runs that cross chunk boundaries
+};
+size_t edge_sort_temp_bytes(size_t n_edges, size_t n_keys);
+size_t edge_rowbuf_floats(size_t n_edges);
+size_t edge_part_floats(size_t n_edges);
+int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, float* dxbar_ws, float* db2_nchw);
 int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h);
 int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum);              // per-lane list length used for a requested k (4/8/16/32)
 

@@ -192,7 +192,7 @@ int    dagl_ce_core_forward(void* stream, int B, int H, int W,
                             void* workspace, size_t ws_bytes, dagl_ce_info* info);
 size_t dagl_ce_core_backward_workspace_bytes(int B, int H, int W, int mode, int k);
 /* Gradients of a scalar loss w.r.t. wq_rows, x_rows, b2, thr, bias given d_out = dL/d out.  d_x_rows and d_b2
- * are accumulated with fp32 atomics (run-to-run differences at fp32 rounding level); d_thr / d_bias may be NULL
+ * are gathered over the edge list sorted by key (stable radix sort: bit-reproducible); d_thr / d_bias may be NULL
  * in top-k mode.  The selection itself (which keys are neighbours) carries no gradient, as in the reference.  */
 int    dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k,
                              const float* wq_rows, const float* x_rows, const float* b2,
