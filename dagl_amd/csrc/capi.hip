@@ -107,7 +107,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.s_steps = (g.N + SKEYS - 1) / SKEYS;
     {
         const int nqg = (g.L + 255) / 256;
-        int sp = (768 + nqg * B - 1) / (nqg * B);
+        static const int target = [] { const char* e = getenv("DAGL_SCREEN_BLOCKS"); return e ? atoi(e) : 512; }();
+        int sp = (target + nqg * B - 1) / (nqg * B);
         const int mx = (p.s_steps + 3) / 4;
         if (sp > mx) sp = mx;
         if (sp > 64) sp = 64;
@@ -385,6 +386,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
         redo = at<int32_t>(ws, p.o_redo);
+        { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
         prof_mark(prof, s, 3);
         if (mode == DAGL_MODE_TOPK) {
             if ((rc = launch_screen(s, sc, 0))) return rc;

@@ -206,6 +206,7 @@ struct ScreenArgs {
     int32_t* cand_idx;              // pass 1 out: [B, L, splits*2, capseg]
     int32_t* seg_cnt;               // pass 1 out: [B, L, splits*2]
     const int32_t* run_flags;
+    int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
 };
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
 int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta);

@@ -22,7 +22,6 @@ namespace dagl {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int SCR_WAVES = 8;                     // query tiles (of 32) per block
 constexpr int SK = 64;                           // keys per streaming step (two 32-row MFMA tiles)
 constexpr int STEP_ELEMS = SK * DSH;             // 13824 bf16 = 27648 B = 27 DMA pieces of 1 KiB exactly
 constexpr int STEP_PIECES = 27;
@@ -41,8 +40,14 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
 // PASS 1: candidate filter over every step: key is a candidate of query q iff S~ >= theta[q]
 //         (theta carries the whole conservative test of either mode; +inf for padding queries).
 // Keys past N are zero rows (S~ = 0): they can only pass a degenerate theta <= 0 and are dropped by refine.
-template <int PASS>
-__global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups) {
+//
+// QW = query tiles (of 32) per wave.  A block always covers SCR_QUERIES = 256 queries (8/QW waves).  Every key
+// fragment read from LDS (one ds_read_b128 per lane) feeds QW MFMAs: with QW = 1 the LDS port (128 B/clk/CU) is busy
+// exactly as long as the matrix cores (26 KiB per wave-step vs 26 x 32 clk of MFMA, two waves per SIMD), which caps
+// the kernel near 50 %; QW = 2 halves the LDS bytes per flop (query fragments: 2 x 52 VGPRs, accumulators 4 x 16).
+template <int PASS, int QW, int VAR, int SCR_QUERIES = 256>
+__global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1) void screen_kernel(ScreenArgs a, int n_qgroups) {
+    constexpr int WAVES = SCR_QUERIES / 32 / QW;
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][STEP_ELEMS];        // 54 KiB
 
     const int tid = threadIdx.x;
@@ -59,36 +64,49 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
     if (step1 > a.n_steps) step1 = a.n_steps;
     const int stride = (PASS == 0) ? a.sample : 1;
 
-    const int q = (qg * SCR_WAVES + wave) * QT + i;
-    const bool qvalid = q < a.L;
-    const int qc = qvalid ? q : a.L - 1;
-    const size_t qlin = (size_t)b * a.L + qc;
-
-    // query fragments: 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
-    bf16x8 qf[KB];
-    {
+    // query fragments: QW x 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
+    bf16x8 qf[QW][KB];
+    bool qvalid[QW];
+    size_t qlin[QW];
+    float thq[QW], thlo[QW];          // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
+    int n_loc[QW];
+    int32_t* cseg[QW];
+    size_t seg[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const int q = ((qg * WAVES + wave) * QW + w) * QT + i;
+        qvalid[w] = q < a.L;
+        const int qc = qvalid[w] ? q : a.L - 1;
+        qlin[w] = (size_t)b * a.L + qc;
         const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
 #pragma unroll
         for (int t = 0; t < KB; ++t)
-            qf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
-#pragma unroll
-        for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[t]));
+            qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        thq[w] = 0.f;
+        if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 8)) ? a.theta[qlin[w]] : __builtin_inff();
+        {
+            const unsigned tb = __float_as_uint(thq[w]);
+            thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
+        }
+        n_loc[w] = 0;
+        seg[w] = (qlin[w] * a.splits + split) * 2 + h;
+        cseg[w] = a.cand_idx + seg[w] * a.capseg;
     }
-
-    float thq = 0.f;
-    if (PASS == 1) thq = qvalid ? a.theta[qlin] : __builtin_inff();
-
-    float gm[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gm[r] = -1.0f;
-    int n_loc = 0;
-    const size_t seg = (qlin * a.splits + split) * 2 + h;
-    int32_t* cseg = a.cand_idx + seg * a.capseg;
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[w][t]));
+
+    float gm[QW][16];
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[w][r] = -1.0f;
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
     if (step0 < step1) {
-        for (int p = wave; p < STEP_PIECES; p += SCR_WAVES)
+        for (int p = wave; p < STEP_PIECES; p += WAVES)
             glds16_asm(reinterpret_cast<const float*>(xb + (size_t)step0 * STEP_ELEMS + p * 512 + lane * 8),
                        __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
     }
@@ -97,50 +115,71 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
 
     int cur = 0;
     for (int step = step0; step < step1; step += stride) {
-        if (step + stride < step1) {
+        if (step + stride < step1 && !(VAR & 1)) {
             const unsigned dst = lds0 + (cur ^ 1) * (STEP_ELEMS * 2);
-            for (int p = wave; p < STEP_PIECES; p += SCR_WAVES)
+            for (int p = wave; p < STEP_PIECES; p += WAVES)
                 glds16_asm(reinterpret_cast<const float*>(xb + (size_t)(step + stride) * STEP_ELEMS + p * 512 + lane * 8),
                            __builtin_amdgcn_readfirstlane(dst + p * 1024));
         }
-        // two 32-key row tiles, MFMA chains interleaved so that no instruction waits on its predecessor
-        f32x16 acc0, acc1;
+        // two 32-key row tiles x QW query tiles, MFMA chains interleaved so that no instruction waits on its predecessor
+        f32x16 acc[QW][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        for (int w = 0; w < QW; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
         const unsigned short* kp0 = &sK[cur][i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
         for (int t = 0; t < KB; ++t) {
             const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
             const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], acc1, 0, 0, 0);
+            if (VAR & 2) {
+#pragma unroll
+                for (int w = 0; w < QW; ++w) { acc[w][0][t] += (float)k0[0] * (float)qf[w][t][0]; acc[w][1][t] += (float)k1[0] * (float)qf[w][t][1]; }
+                continue;
+            }
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                acc[w][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[w][t], acc[w][0], 0, 0, 0);
+                acc[w][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[w][t], acc[w][1], 0, 0, 0);
+            }
         }
-        if (PASS == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gm[r] = fmaxf(fmaxf(gm[r], acc0[r]), acc1[r]);
-        } else {
-            // common case (no candidate in the whole wave): 16 v_max3 + one compare + one branch
-            float mx = acc0[0];
+        for (int w = 0; w < QW; ++w) {
+            if (VAR & 4) { gm[w][0] += acc[w][0][0] + acc[w][1][0]; continue; }
+            if (PASS == 0) {
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc0[r]);
+                for (int r = 0; r < 16; ++r) gm[w][r] = fmaxf(fmaxf(gm[w][r], acc[w][0][r]), acc[w][1][r]);
+            } else {
+                // common case (no candidate in the whole wave): 16 v_max3 + one compare + one branch
+                float mxt[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc1[r]);
-            if (__any(mx >= thq)) {
-                unsigned mask = 0;
+                for (int tl = 0; tl < 2; ++tl) {
+                    float m = acc[w][tl][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    mask |= (acc0[r] >= thq ? 1u : 0u) << r;
-                    mask |= (acc1[r] >= thq ? 1u : 0u) << (16 + r);
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[w][tl][r]);
+                    mxt[tl] = m;
                 }
-                const int kbase = step * SK + 4 * h;
-                while (mask) {
-                    const int bit = __ffs((int)mask) - 1;
-                    mask &= mask - 1;
-                    const int r = bit & 15;
-                    const int key = kbase + (bit >> 4) * 32 + (r & 3) + 8 * (r >> 2);
-                    if (n_loc < a.capseg) cseg[n_loc] = key;
-                    ++n_loc;
+                if (__any(fmaxf(mxt[0], mxt[1]) >= thq[w])) {
+                    // ~3 of 4 wave-steps hold a candidate somewhere in their 2048 scores, so this path matters: one tile at a
+                    // time, two VALU per score (sign of thlo - S~, shifted into the lane's mask by v_alignbit)
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        if (!__any(mxt[tl] >= thq[w])) continue;
+                        unsigned mask = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo[w] - acc[w][tl][r]), 31);
+                        const int kbase = step * SK + 4 * h + tl * 32;
+                        while (mask) {                                   // score r sits at bit 15 - r: ascending r
+                            const int bit = 31 - __clz((int)mask);
+                            mask &= ~(1u << bit);
+                            const int r = 15 - bit;
+                            const int key = kbase + (r & 3) + 8 * (r >> 2);
+                            if (n_loc[w] < a.capseg) cseg[w][n_loc[w]] = key;
+                            ++n_loc[w];
+                        }
+                    }
                 }
             }
         }
@@ -149,27 +188,30 @@ __global__ __launch_bounds__(512) void screen_kernel(ScreenArgs a, int n_qgroups
         cur ^= 1;
     }
 
-    if (PASS == 0) {
-        // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
-        // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
-        float top[GKEEP];
 #pragma unroll
-        for (int u = 0; u < GKEEP; ++u) {
-            float m = gm[0];
+    for (int w = 0; w < QW; ++w) {
+        if (PASS == 0) {
+            // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
+            // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
+            float top[GKEEP];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[r]);
-            top[u] = m;
-            bool taken = false;
+            for (int u = 0; u < GKEEP; ++u) {
+                float m = gm[w][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool hit = !taken && (gm[r] == m);
-                gm[r] = hit ? -1.0f : gm[r];
-                taken = taken || hit;
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[w][r]);
+                top[u] = m;
+                bool taken = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool hit = !taken && (gm[w][r] == m);
+                    gm[w][r] = hit ? -1.0f : gm[w][r];
+                    taken = taken || hit;
+                }
             }
+            if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
+        } else {
+            if (qvalid[w]) a.seg_cnt[seg[w]] = n_loc[w];
         }
-        if (qvalid) *reinterpret_cast<float4*>(a.gmax + seg * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
-    } else {
-        if (qvalid) a.seg_cnt[seg] = n_loc;
     }
 }
 
@@ -193,10 +235,32 @@ int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float*
 }
 
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
-    const int n_qgroups = (a.L + SCR_WAVES * QT - 1) / (SCR_WAVES * QT);
-    dim3 grid(n_qgroups * a.splits, a.B), block(512);
-    if (pass == 0) hipLaunchKernelGGL(screen_kernel<0>, grid, block, 0, s, a, n_qgroups);
-    else hipLaunchKernelGGL(screen_kernel<1>, grid, block, 0, s, a, n_qgroups);
+    static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
+    const int SCR_QUERIES = (qw == 3) ? 512 : 256;
+    const int n_qgroups = (a.L + SCR_QUERIES - 1) / SCR_QUERIES;
+    dim3 grid(n_qgroups * a.splits, a.B);
+#define SCR_LAUNCH(P_, Q_, V_) hipLaunchKernelGGL((screen_kernel<P_, Q_, V_>), grid, dim3(256 / Q_ * 2), 0, s, a, n_qgroups)
+#define SCR_VARIANTS(P_, Q_)                                              \
+    switch (a.variant) {                                                 \
+        case 0: SCR_LAUNCH(P_, Q_, 0); break;                            \
+        case 1: SCR_LAUNCH(P_, Q_, 1); break;                            \
+        case 2: SCR_LAUNCH(P_, Q_, 2); break;                            \
+        case 4: SCR_LAUNCH(P_, Q_, 4); break;                            \
+        case 5: SCR_LAUNCH(P_, Q_, 5); break;                            \
+        case 6: SCR_LAUNCH(P_, Q_, 6); break;                            \
+        case 8: SCR_LAUNCH(P_, Q_, 8); break;                            \
+        case 9: SCR_LAUNCH(P_, Q_, 9); break;                            \
+        case 10: SCR_LAUNCH(P_, Q_, 10); break;                          \
+        default: SCR_LAUNCH(P_, Q_, 7); break;                           \
+    }
+    if (qw == 1) {
+        if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) }
+    } else if (qw == 3) {
+        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 2, 0, 512>), grid, dim3(512), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 2, 0, 512>), grid, dim3(512), 0, s, a, n_qgroups);
+    } else {
+        if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) }
+    }
     DAGL_LAUNCH_CHECK("screen_kernel");
     return DAGL_OK;
 }
