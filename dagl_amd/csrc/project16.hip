@@ -29,11 +29,12 @@ constexpr int P16_ROWH = 40;                     // halfs per output row of a sl
 constexpr int P16_SLICE_H = 9216;                // halfs per tap slice: 224*40 = 8960 -> 18 KiB = 18 DMA pieces
 constexpr int P16_PIECES = 18;
 constexpr int P16_STEPS = KS * KS;               // 49 taps
-constexpr float P16_LO_SCALE = 2048.0f;          // 2^11
+constexpr float P16_A_SCALE = 16.0f;              // 2^4: activations are split as 16 a = hi + lo
+constexpr float P16_W_SCALE = 1024.0f;            // 2^10: weights as 1024 w = hi + lo
 
 __device__ __forceinline__ void split_f16(float a, unsigned short& hi, unsigned short& lo) {
     const _Float16 h = (_Float16)a;
-    const _Float16 l = (_Float16)((a - (float)h) * P16_LO_SCALE);
+    const _Float16 l = (_Float16)(a - (float)h);
     hi = __builtin_bit_cast(unsigned short, h);
     lo = __builtin_bit_cast(unsigned short, l);
 }
@@ -45,7 +46,8 @@ __global__ void split_map_kernel(size_t n, const float* __restrict__ src, unsign
     if (i * 4 >= n) return;
     const float4 v = reinterpret_cast<const float4*>(src)[i];
     unsigned short h[4], l[4];
-    split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]); split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+    split_f16(v.x * P16_A_SCALE, h[0], l[0]); split_f16(v.y * P16_A_SCALE, h[1], l[1]);
+    split_f16(v.z * P16_A_SCALE, h[2], l[2]); split_f16(v.w * P16_A_SCALE, h[3], l[3]);
     reinterpret_cast<ushort4*>(hi)[i] = make_ushort4(h[0], h[1], h[2], h[3]);
     reinterpret_cast<ushort4*>(lo)[i] = make_ushort4(l[0], l[1], l[2], l[3]);
 }
@@ -67,7 +69,7 @@ __global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned sh
     if (o < D && e < 32) {
         const int c = e & 15;
         unsigned short hi, lo;
-        split_f16(w[(size_t)o * P + c * (KS * KS) + tap], hi, lo);
+        split_f16(w[(size_t)o * P + c * (KS * KS) + tap] * P16_W_SCALE, hi, lo);
         v = (e < 16) ? hi : lo;
     }
     wp[i] = v;
@@ -139,11 +141,11 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const int gx0 = (item % segs_per_row) * 32;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
-    f32x16 hh[NT], cx[NT];
+    f32x16 hh[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { hh[n][r] = 0.f; cx[n][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) hh[n][r] = 0.f;
 
     auto issue_w = [&](int t) {                        // weight slice of tap t -> ring stage t % RING
         if (VAR == 6) return;
@@ -227,12 +229,13 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(fa_hi), "v"(fa_lo), "v"(w_hi[n]), "v"(w_lo[n]));
             return;
         }
+        // the two cross terms (2^-11 of the main one) go into the same accumulator: small terms first
+#pragma unroll
+        for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo[n], hh[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi[n], hh[n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi[n], hh[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo[n], cx[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) cx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi[n], cx[n], 0, 0, 0);
     };
     // steady state: PD-1 younger taps stay in flight across the barrier
     for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 22 : P16_STEPS - P16_PD); ++step) {
@@ -266,7 +269,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
             const bool ok = wave_valid && (gx0 + rr < row_len);
-            float v = (hh[n][r] + cx[n][r] * (1.0f / P16_LO_SCALE)) + bv;
+            float v = hh[n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
             if (VAR == 1 && v != 12345.678f) continue;

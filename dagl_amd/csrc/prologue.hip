@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
                 const size_t o = (((size_t)b * Hp + y + PADPIX) * Wp + xx + PADPIX) * CH + i;
                 const float v1 = ((a0[r] + a1[r]) + a2[r]) + bias1;
                 if (b1p != nullptr) b1p[o] = v1;
-                if (b1hi != nullptr) {                           // a = hi + 2^-11 lo, both fp16 (project16.hip)
-                    const _Float16 hh = (_Float16)v1;
-                    const _Float16 ll = (_Float16)((v1 - (float)hh) * 2048.0f);
+                if (b1hi != nullptr) {                           // 16 a = hi + lo, both fp16 (project16.hip)
+                    const float vs = v1 * 16.0f;                 // P16_A_SCALE (project16.hip)
+                    const _Float16 hh = (_Float16)vs;
+                    const _Float16 ll = (_Float16)(vs - (float)hh);
                     b1hi[o] = __builtin_bit_cast(unsigned short, hh);
                     b1lo[o] = __builtin_bit_cast(unsigned short, ll);
                 }
