@@ -94,6 +94,7 @@ struct Proj16Args {
     int rows_alloc[2], rows_alloc_h[2];
     int n_items[2], segs[2];                                        // 32-patch work items per image / per grid row
     int n_blocks_q, n_blocks_k;
+    int n_full, n_split_groups, batch;                              // 1-D grid: full blocks, then 7 single-tile blocks per split group
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
 };
 
@@ -105,24 +106,25 @@ struct Proj16Args {
 //                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
 //              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
 constexpr int P16_BW = 4;                              // waves per block (two blocks per CU: independent barriers)
-constexpr int P16_RING = 4;
-constexpr int P16_PD = 3;                              // prefetch distance (taps)
-constexpr int P16_STAGE_B = 10 * 1024;                 // bytes per weight stage (>= NT*32*80, whole DMA pieces)
-constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 40 KiB: patch region
-constexpr int P16_AROW = 4096;                         // keys: one staged map row per wave: hi 2 KiB | lo 2 KiB
-constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 72 KiB (keys: 40 + 4 x 2 x 4 KiB = 72)
+constexpr int P16_RING = 3;
+constexpr int P16_PD = 2;                              // prefetch distance (taps)
+constexpr int P16_STAGE_B = 18 * 1024;                 // bytes per weight stage (>= 224*80, whole DMA pieces)
+constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 54 KiB: patch region
+constexpr int P16_APART = 1280;                        // keys: one part (hi or lo) of a staged map row: 38 px x 32 B, padded
+constexpr int P16_AROW = 2 * P16_APART;                // keys: one staged map row per wave: hi | lo
+constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 78 KiB (keys use 54 + 4 x 2 x 2.5 = 74)
 static_assert(P16_BW * 2 * P16_AROW <= P16_RING * P16_BW * 2048, "key row rings must fit the patch region");
+static_assert(2 * P16_LDS <= 160 * 1024, "two blocks per CU");
 
 template <int N>
 __device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NT, bool KEYS, int VAR>
-__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk) {
+__device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk, int b) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
     const Grid& gr = pa.gr;
     constexpr int which = KEYS ? 0 : 1;
     const int head = b / pa.imgs_per_head;
@@ -180,11 +182,12 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         const unsigned dst = lds0 + P16_OFF_A + wave * (2 * P16_AROW) + (r & 1) * P16_AROW;
         const size_t rowoff = krow0 + (size_t)r * gr.Wp * CH;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                  // pieces: hi px 0-31, hi px 32-63, lo px 0-31, lo px 32-63
+        for (int j = 0; j < 4; ++j) {                  // pieces: hi px 0-31, hi px 32-37 (12 lanes), lo px 0-31, lo px 32-37
             int p = (j & 1) * 32 + (lane >> 1);
             if (gx0 + p > gr.Wp - 1) p = gr.Wp - 1 - gx0;                         // stay inside the map row
             const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + rowoff + (size_t)p * CH + 8 * (lane & 1);
-            glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(dst + j * 1024));
+            const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
+            if ((j & 1) == 0 || lane < 12) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
         }
     };
     auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back
@@ -211,7 +214,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         const int kh = step / KS, kw = step - kh * KS;
         const unsigned char* sa;
         int lo_off;
-        if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = 2048; }
+        if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = P16_APART; }
         else { sa = smem + P16_OFF_A + (step % P16_RING) * (P16_BW * 2048) + wave * 2048 + lane * 16; lo_off = 1024; }
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
         const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
@@ -238,7 +241,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi[n], hh[n], 0, 0, 0);
     };
     // steady state: PD-1 younger taps stay in flight across the barrier
-    for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 22 : P16_STEPS - P16_PD); ++step) {
+    for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 23 : P16_STEPS - P16_PD); ++step) {
         if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
         issue_w(step + P16_PD);
         if (!KEYS) issue_q(step + P16_PD);
@@ -247,12 +250,11 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         __syncthreads();
     }
     // drain: the last PD taps, nothing left to issue
-    compute(P16_STEPS - 3); P16_WAIT(1); __syncthreads();
     compute(P16_STEPS - 2); P16_WAIT(0); __syncthreads();
     compute(P16_STEPS - 1);
     __syncthreads();
 #undef P16_WAIT
-    static_assert(P16_PD == 3, "the drain sequence above is written for PD = 3");
+    static_assert(P16_PD == 2, "the drain sequence above is written for PD = 2");
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
@@ -300,18 +302,20 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 
 template <int VAR>
 __global__ __launch_bounds__(64 * P16_BW, 2) void project16_kernel(Proj16Args pa) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];           // 112 KiB
-    // blocks: [query blocks x 2 halves][key blocks x 2 halves]; half 0 = output tiles 0..3, half 1 = tiles 4..6
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];
+    // 1-D grid.  Full blocks first: per image [query blocks][key blocks], every wave owns 32 patches x all 7 output
+    // tiles.  The last n_split_groups key blocks of the last image come last, cut into 7 single-tile blocks each: a grid
+    // that overhangs the resident-block capacity by a few blocks would otherwise cost a whole extra round.
     const int bid = blockIdx.x;
-    const bool queries = bid < 2 * pa.n_blocks_q;                       // block-uniform
-    const int rel = queries ? bid : bid - 2 * pa.n_blocks_q;
-    const int half = rel & 1, blk = rel >> 1;
-    if (queries) {
-        if (half == 0) project16_body<4, false, VAR>(pa, smem, 0, blk);
-        else project16_body<3, false, VAR>(pa, smem, 4, blk);
+    const int per = pa.n_blocks_q + pa.n_blocks_k;
+    if (bid < pa.n_full) {
+        const int b = bid / per, local = bid - b * per;
+        if (local < pa.n_blocks_q) project16_body<P16_NT, false, VAR>(pa, smem, 0, local, b);
+        else project16_body<P16_NT, true, VAR>(pa, smem, 0, local - pa.n_blocks_q, b);
     } else {
-        if (half == 0) project16_body<4, true, VAR>(pa, smem, 0, blk);
-        else project16_body<3, true, VAR>(pa, smem, 4, blk);
+        const int sb = bid - pa.n_full;
+        const int grp = sb / P16_NT, tile = sb - grp * P16_NT;
+        project16_body<1, true, VAR>(pa, smem, tile, pa.n_blocks_k - pa.n_split_groups + grp, pa.batch - 1);
     }
 }
 
@@ -354,7 +358,17 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
     pa.colpart = (colsum != nullptr) ? colpart : nullptr;
     static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
-    const dim3 grid(2 * (nbq + nbk), B), block(64 * P16_BW);
+    // resident capacity: two blocks per CU.  A remainder of at most half a round is cut into single-tile blocks.
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int cap = 2 * cus, total = B * (nbq + nbk), rem = total % cap;
+    int groups = (rem > 0 && rem <= cap / 2) ? rem : 0;
+    if (groups > nbk) groups = nbk;
+    pa.n_split_groups = groups; pa.n_full = total - groups; pa.batch = B;
+    const dim3 grid(pa.n_full + P16_NT * groups), block(64 * P16_BW);
     if (var == 1) hipLaunchKernelGGL(project16_kernel<1>, grid, block, 0, s, pa);
     else if (var == 3) hipLaunchKernelGGL(project16_kernel<3>, grid, block, 0, s, pa);
     else if (var == 4) hipLaunchKernelGGL(project16_kernel<4>, grid, block, 0, s, pa);
