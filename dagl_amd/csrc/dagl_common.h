@@ -128,7 +128,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
                      uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1);
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
-constexpr size_t P16_PACKED_HALFS = (size_t)49 * 9216 + 8192; // packed fp16 weights (halfs) + read slack of the last stage
+constexpr size_t P16_PACKED_HALFS = (size_t)49 * 7168 + 1024; // packed fp16 weights (halfs) + read slack
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
                             const float* thr, float* mt, float* mu_out = nullptr);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);

@@ -25,9 +25,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int P16_WAVES = 4;
 constexpr int P16_NT = 7;                        // 32-wide output tiles (224 >= 196)
 constexpr int P16_OUT = P16_NT * 32;             // 224
-constexpr int P16_ROWH = 40;                     // halfs per output row of a slice: 16 hi + 16 lo + 8 pad
-constexpr int P16_SLICE_H = 9216;                // halfs per tap slice: 224*40 = 8960 -> 18 KiB = 18 DMA pieces
-constexpr int P16_PIECES = 18;
+constexpr int P16_ROWH = 32;                     // halfs per output row of a slice: 16 hi + 16 lo (four 16-byte slots, swizzled)
+constexpr int P16_SLICE_H = 7168;                // halfs per tap slice: 224*32 -> 14 KiB = 14 DMA pieces
 constexpr int P16_STEPS = KS * KS;               // 49 taps
 constexpr float P16_A_SCALE = 16.0f;              // 2^4: activations are split as 16 a = hi + lo
 constexpr float P16_W_SCALE = 1024.0f;            // 2^10: weights as 1024 w = hi + lo
@@ -59,18 +58,21 @@ int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t*
     return DAGL_OK;
 }
 
-// fc weight [196,784] (c,kh,kw) -> packed [49 taps][P16_SLICE_H halfs]: row o = 40 halfs: w_hi[c=0..15], w_lo[c=0..15], pad
+// fc weight [196,784] (c,kh,kw) -> packed [49 taps][P16_SLICE_H halfs]: row o = 64 bytes = four 16-byte slots
+// (hi c0-7, hi c8-15, lo c0-7, lo c8-15) stored at slot ^ ((o >> 2) & 3): the ds_read_b128 of 32 consecutive rows is then
+// conflict-free without padding (rows r, r+4, r+8, r+12 of a 16-lane LDS group land in different slots)
 __global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P16_STEPS * P16_SLICE_H) return;
     const int tap = i / P16_SLICE_H, r = i % P16_SLICE_H;
     const int o = r / P16_ROWH, e = r % P16_ROWH;
     unsigned short v = 0;
-    if (o < D && e < 32) {
-        const int c = e & 15;
+    if (o < D) {
+        const int slot = (e >> 3) ^ ((o >> 2) & 3);                  // logical slot stored at this physical position
+        const int c = (slot & 1) * 8 + (e & 7);
         unsigned short hi, lo;
         split_f16(w[(size_t)o * P + c * (KS * KS) + tap] * P16_W_SCALE, hi, lo);
-        v = (e < 16) ? hi : lo;
+        v = (slot < 2) ? hi : lo;
     }
     wp[i] = v;
 }
@@ -106,14 +108,16 @@ struct Proj16Args {
 //                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
 //              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
 constexpr int P16_BW = 4;                              // waves per block (two blocks per CU: independent barriers)
-constexpr int P16_RING = 3;
-constexpr int P16_PD = 2;                              // prefetch distance (taps)
-constexpr int P16_STAGE_B = 18 * 1024;                 // bytes per weight stage (>= 224*80, whole DMA pieces)
-constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 54 KiB: patch region
+constexpr int P16_RING = 4;                            // weight stages
+constexpr int P16_PD_KEYS = 3;                         // prefetch distance (taps): key blocks
+constexpr int P16_PD_Q = 2;                            // query blocks (their per-tap patch stages leave room for 3 only)
+constexpr int P16_QRING = 3;
+constexpr int P16_STAGE_B = 14 * 1024;                 // bytes per weight stage (= 224*64, whole DMA pieces)
+constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 56 KiB: patch region
 constexpr int P16_APART = 1280;                        // keys: one part (hi or lo) of a staged map row: 38 px x 32 B, padded
 constexpr int P16_AROW = 2 * P16_APART;                // keys: one staged map row per wave: hi | lo
-constexpr int P16_LDS = P16_OFF_A + P16_RING * P16_BW * 2048;       // 78 KiB (keys use 54 + 4 x 2 x 2.5 = 74)
-static_assert(P16_BW * 2 * P16_AROW <= P16_RING * P16_BW * 2048, "key row rings must fit the patch region");
+constexpr int P16_LDS = P16_OFF_A + P16_QRING * P16_BW * 2048;      // 80 KiB (keys use 56 + 4 x 2 x 2.5 = 76)
+static_assert(P16_BW * 2 * P16_AROW <= P16_QRING * P16_BW * 2048, "key row rings must fit the patch region");
 static_assert(2 * P16_LDS <= 160 * 1024, "two blocks per CU");
 
 template <int N>
@@ -131,7 +135,8 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)head * P16_PACKED_HALFS + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
-    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 10 (NT=4) / 8 (NT=3)
+    constexpr int PD = KEYS ? P16_PD_KEYS : P16_PD_Q;
+    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 14 (NT=7) / 2 (NT=1)
     constexpr int PBASE = PIECES / P16_BW;                                      // weight pieces per wave per tap ...
     const bool extra = wave < (PIECES % P16_BW);                                // ... plus one for the first waves
 
@@ -193,7 +198,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back
         const int kh = t / KS, kw = t - kh * KS;
         const size_t o = ((size_t)kh * gr.Wp + kw) * CH;
-        const unsigned sa = lds0 + P16_OFF_A + (unsigned)(t % P16_RING) * (P16_BW * 2048) + wave * 2048;
+        const unsigned sa = lds0 + P16_OFF_A + (unsigned)(t % P16_QRING) * (P16_BW * 2048) + wave * 2048;
         glds16_asm(reinterpret_cast<const float*>(ahi + o), __builtin_amdgcn_readfirstlane(sa));
         glds16_asm(reinterpret_cast<const float*>(alo + o), __builtin_amdgcn_readfirstlane(sa + 1024));
     };
@@ -204,28 +209,30 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 
     if (KEYS) issue_row(0);
 #pragma unroll
-    for (int t = 0; t < P16_PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
-    P16_WAIT(P16_PD - 1);
+    for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
+    P16_WAIT(PD - 1);
     __syncthreads();
 
     if (VAR == 9) { if (hh[0][0] != 0.f) pa.feat[which][0] = 1.f; return; }
-    const int boff = (i * P16_ROWH + 8 * h) * 2;                       // bytes: B fragment row n*32 + i, half h
+    const int swz = (i >> 2) & 3;                                       // slot swizzle of row n*32 + i (n*32 does not change it)
+    const int boff_hi = i * (P16_ROWH * 2) + ((h ^ swz) << 4);          // bytes: B fragment row n*32 + i, hi half h
+    const int boff_lo = i * (P16_ROWH * 2) + (((2 + h) ^ swz) << 4);
     auto compute = [&](int step) {
         const int kh = step / KS, kw = step - kh * KS;
         const unsigned char* sa;
         int lo_off;
         if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = P16_APART; }
-        else { sa = smem + P16_OFF_A + (step % P16_RING) * (P16_BW * 2048) + wave * 2048 + lane * 16; lo_off = 1024; }
+        else { sa = smem + P16_OFF_A + (step % P16_QRING) * (P16_BW * 2048) + wave * 2048 + lane * 16; lo_off = 1024; }
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
         const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
-        const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE_B + boff;
+        const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE_B;
         // all fragment reads of the tap first (one exposed LDS latency per tap instead of one per tile), then the
         // MFMAs grouped so that no instruction depends on its predecessor
         f16x8 w_hi[NT], w_lo[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            w_hi[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2));
-            w_lo[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + 32));
+            w_hi[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_hi));
+            w_lo[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_lo));
         }
         if (VAR == 5) {
 #pragma unroll
@@ -241,20 +248,21 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi[n], hh[n], 0, 0, 0);
     };
     // steady state: PD-1 younger taps stay in flight across the barrier
-    for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 23 : P16_STEPS - P16_PD); ++step) {
+    for (int step = 0; step < ((VAR == 7) ? 1 : (VAR == 8) ? 23 : P16_STEPS - PD); ++step) {
         if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
-        issue_w(step + P16_PD);
-        if (!KEYS) issue_q(step + P16_PD);
+        issue_w(step + PD);
+        if (!KEYS) issue_q(step + PD);
         compute(step);
-        P16_WAIT(P16_PD - 1);
+        P16_WAIT(PD - 1);
         __syncthreads();
     }
     // drain: the last PD taps, nothing left to issue
+    if (PD == 3) { compute(P16_STEPS - 3); P16_WAIT(1); __syncthreads(); }
     compute(P16_STEPS - 2); P16_WAIT(0); __syncthreads();
     compute(P16_STEPS - 1);
     __syncthreads();
 #undef P16_WAIT
-    static_assert(P16_PD == 2, "the drain sequence above is written for PD = 2");
+    static_assert(PD == 2 || PD == 3, "the drain sequence above is written for PD = 2 or 3");
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
