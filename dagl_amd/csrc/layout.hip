@@ -17,10 +17,13 @@ __global__ void pad_nhwc_kernel(int H, int W, const float* __restrict__ src, flo
     if (xp >= Wp) return;
     const int y = yp - PADPIX, x = xp - PADPIX;
     const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
-    const float* s = src + (size_t)b * CH * H * W + (size_t)y * W + x;
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    const float* s = src + (size_t)b * CH * H * W + (size_t)yc * W + xc;
     float v[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = in ? s[(size_t)c * H * W] : 0.0f;
+    for (int c = 0; c < CH; ++c) v[c] = s[(size_t)c * H * W];         // unconditional loads (all in flight), zeroed below
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = in ? v[c] : 0.0f;
     float4* d = reinterpret_cast<float4*>(dst + (((size_t)b * Hp + yp) * Wp + xp) * CH);
 #pragma unroll
     for (int q = 0; q < CH / 4; ++q) d[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);

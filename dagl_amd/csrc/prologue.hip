@@ -11,6 +11,8 @@
 //   A[pixel][channel]   from a 4-row LDS ring of the input strip (rows y-1..y+1 live, y+2 in flight)
 //   B[channel][out]     the 3x3 + 1x1 weights, held in registers for the block's lifetime (160 VGPRs)
 // three accumulators (one per kernel row) + one for theta; exact fp32 fma chains like the stock conv.
+#include <stdlib.h>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
             const int ch = idx / PRO_LW, p = idx - ch * PRO_LW;
             const int xx = x0 - 1 + p;
             const bool ok = (idx < PC * PRO_LW) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-            st[j] = ok ? xb[((size_t)ch * H + yy) * W + xx] : 0.f;
+            const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const int cc = ch < PC ? ch : PC - 1;
+            const float raw = xb[((size_t)cc * H + yc) * W + xc];     // unconditional (clamped) load, zeroed afterwards
+            st[j] = ok ? raw : 0.f;
         }
     };
     auto stage_store = [&](int yy) {
@@ -134,6 +139,225 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(int H, int W, int rows_p
     }
 }
 
+// ---- the same two convolutions on the fp16 matrix cores with split operands (default path) ---------------------------
+// 16 x = hi + lo and 256 w = hi + lo (fp16 pairs, power-of-two pre-scaling keeps the lo parts normal; see project16.hip);
+// a product keeps hi*hi + hi*lo + lo*hi in ONE fp32 accumulator.  v_mfma_f32_16x16x32_f16 with A = weights (M = 16 output
+// channels) and B = pixels (N = 16 consecutive pixels of a row), K = 32 input channels of one tap: 3 x 3 x 2 K-blocks for
+// g, 2 for theta, three MFMAs each: 960 matrix-core cycles per 16 pixels against 5120 of the fp32 kernel above, and no
+// weights in registers, so the block starts sooner.  D[row = channel][col = pixel]: a lane ends up with 4 consecutive
+// output channels of one pixel -- 8-byte (fp16 maps) and 16-byte (fp32 value map) NHWC stores.
+// Input rows are staged transposed, [pixel][hi 64 ch | lo 64 ch] fp16 with a 272-byte pixel stride (17 slots of 16 B:
+// the B fragments of 16 consecutive pixels are conflict-free); wave w converts channels 16w..16w+15, one pixel per lane.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+constexpr int C16_PXB = 272;                             // staged bytes per pixel
+constexpr int C16_ROWB = PRO_LW * C16_PXB;               // 17952 B per ring row
+constexpr int C16_WOFF = PRO_ROWS * C16_ROWB;            // 71808: weights after the ring
+constexpr int C16_WB = (18 + 2) * 16 * 128;              // 40960 B: [K-block][out channel][hi 32 | lo 32]
+constexpr float C16_XS = 16.0f, C16_WS = 256.0f;
+
+__device__ __forceinline__ void c16_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows_per_block,
+                                                          const float* __restrict__ x,
+                                                          const float* __restrict__ g_w, const float* __restrict__ g_b,
+                                                          const float* __restrict__ th_w, const float* __restrict__ th_b,
+                                                          float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
+                                                          unsigned short* __restrict__ b1lo) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB];           // 110 KiB
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * PRO_TW;
+    const int y0 = blockIdx.y * rows_per_block;
+    int y1 = y0 + rows_per_block; if (y1 > H) y1 = H;
+    const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
+    const float* xb = x + (size_t)b * PC * H * W;
+
+    // staging: wave w owns channels 16w..16w+15 of staged pixels 0..63 (lane = pixel: coalesced row loads, one 16-byte
+    // LDS store per 8 channels); the two halo pixels 64, 65 x 64 channels are one value each for threads 0..127
+    const int hpx = 64 + (tid >> 6), hch = tid & 63;           // halo duty of threads 0..127
+    auto load_row = [&](int yy, float* st, float& sh) {
+        // unconditional loads from clamped addresses, zeroed afterwards: a predicated load makes the compiler wait for
+        // each one before issuing the next
+        const bool rok = (yy >= 0) && (yy < H);
+        const int xa = x0 - 1 + lane, xc = x0 - 1 + hpx;
+        const bool oka = rok && xa >= 0 && xa < W;
+        const bool okc = rok && xc < W;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        const int xac = xa < 0 ? 0 : (xa >= W ? W - 1 : xa);
+        const float* rp = xb + ((size_t)(16 * wave) * H + yc) * W + xac;
+        float raw[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) raw[c] = rp[(size_t)c * H * W];
+        const float rh = xb[((size_t)hch * H + yc) * W + (xc >= W ? W - 1 : xc)];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) st[c] = oka ? raw[c] : 0.f;
+        sh = okc ? rh : 0.f;
+    };
+    auto store_row = [&](int yy, const float* st, float sh) {
+        unsigned char* row = smem + ((yy + 1) & (PRO_ROWS - 1)) * C16_ROWB;
+        unsigned char* px = row + lane * C16_PXB;
+        h16x8 hi0, hi1, lo0, lo1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            _Float16 h, l;
+            c16_split(st[c] * C16_XS, h, l); hi0[c] = h; lo0[c] = l;
+            c16_split(st[c + 8] * C16_XS, h, l); hi1[c] = h; lo1[c] = l;
+        }
+        *reinterpret_cast<h16x8*>(px + 32 * wave) = hi0;
+        *reinterpret_cast<h16x8*>(px + 32 * wave + 16) = hi1;
+        *reinterpret_cast<h16x8*>(px + 128 + 32 * wave) = lo0;
+        *reinterpret_cast<h16x8*>(px + 128 + 32 * wave + 16) = lo1;
+        if (tid < 128) {
+            _Float16 h, l;
+            c16_split(sh * C16_XS, h, l);
+            *reinterpret_cast<_Float16*>(row + hpx * C16_PXB + 2 * hch) = h;
+            *reinterpret_cast<_Float16*>(row + hpx * C16_PXB + 128 + 2 * hch) = l;
+        }
+    };
+
+    // prologue: the three first rows and the weights are requested together (one memory round trip), then converted
+    float st0[16], st1[16], st2[16], sh0, sh1, sh2;
+    load_row(y0 - 1, st0, sh0);
+    load_row(y0, st1, sh1);
+    load_row(y0 + 1, st2, sh2);
+    {
+        unsigned char* wl = smem + C16_WOFF;
+        float4 wv[9], tv;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) wv[j] = reinterpret_cast<const float4*>(g_w)[tid + 256 * j];
+        tv = reinterpret_cast<const float4*>(th_w)[tid];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float* vp = &wv[j].x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = 4 * (tid + 256 * j) + q;
+                const int o = e / (PC * 9), rem = e - o * (PC * 9);
+                const int c = rem / 9, tap = rem - c * 9;
+                _Float16 h, l;
+                c16_split(vp[q] * C16_WS, h, l);
+                unsigned char* d = wl + ((tap * 2 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
+                const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;            // 16-byte slot of the row, swizzled (see reads)
+                *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
+                *reinterpret_cast<_Float16*>(d + (((4 + ks) ^ gs) << 4)) = l;
+            }
+        }
+        {
+            const float* vp = &tv.x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = 4 * tid + q;
+                const int o = e / PC, c = e - o * PC;
+                _Float16 h, l;
+                c16_split(vp[q] * C16_WS, h, l);
+                unsigned char* d = wl + ((18 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
+                const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;
+                *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
+                *reinterpret_cast<_Float16*>(d + (((4 + ks) ^ gs) << 4)) = l;
+            }
+        }
+    }
+    store_row(y0 - 1, st0, sh0);
+    store_row(y0, st1, sh1);
+    store_row(y0 + 1, st2, sh2);
+    __syncthreads();
+
+    float bg[4], bt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bg[r] = g_b[4 * kg + r]; bt[r] = th_b[4 * kg + r]; }
+    // A: row = output channel i, k = 8 kg..; the eight 16-byte slots of a 128-byte weight row are stored at
+    // slot ^ ((row >> 1) & 7), which spreads the 16 lanes of an LDS read group over all banks (unswizzled: 4-way conflicts)
+    const unsigned char* wbase = smem + C16_WOFF + i * 128;
+    const int whi = (kg ^ ((i >> 1) & 7)) << 4, wlo = ((4 + kg) ^ ((i >> 1) & 7)) << 4;
+    const int pxo = (16 * wave + i) * C16_PXB + kg * 16;                        // B: col = pixel 16 wave + i (+ dx)
+    constexpr float inv = 1.0f / (C16_XS * C16_WS);
+    // the A fragments (weights) of all 20 K-blocks stay in registers (160 VGPRs; one wave per SIMD anyway): a row then
+    // needs only its 36 pixel fragments from LDS, all requested up front
+    h16x8 wh[20], wl2[20];
+#pragma unroll
+    for (int kb = 0; kb < 20; ++kb) {
+        wh[kb] = *reinterpret_cast<const h16x8*>(wbase + kb * 2048 + whi);
+        wl2[kb] = *reinterpret_cast<const h16x8*>(wbase + kb * 2048 + wlo);
+    }
+
+    // rows y+2 and y+3 are both in flight: a row's loads are issued two iterations before its conversion (the matrix
+    // part of an iteration is ~0.5 us, a memory round trip under load 2 us), register sets A / B alternate
+    if (y0 + 2 < y1 + 1) load_row(y0 + 2, st0, sh0);
+    auto do_row = [&](int y, float* stc, float& shc, float* stn, float& shn) {
+        // stc/shc: row y+2 (requested one iteration ago) -- converted at the end; stn/shn: row y+3, requested now
+        if (y + 2 < y1) load_row(y + 3, stn, shn);
+        // independent accumulators per (kernel row, channel half, main / cross term): no MFMA waits on its predecessor
+        f32x4 am[3][2], ac[3][2], tm[2], tc[2];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { am[u][0] = zero4; am[u][1] = zero4; ac[u][0] = zero4; ac[u][1] = zero4; }
+        tm[0] = zero4; tm[1] = zero4; tc[0] = zero4; tc[1] = zero4;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const unsigned char* rowp = smem + ((y + dy) & (PRO_ROWS - 1)) * C16_ROWB + pxo;   // input row y-1+dy
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int kb = (dy * 3 + dx) * 2 + cb;
+                    const h16x8 w_hi = wh[kb], w_lo = wl2[kb];
+                    const h16x8 p_hi = *reinterpret_cast<const h16x8*>(rowp + dx * C16_PXB + cb * 64);
+                    const h16x8 p_lo = *reinterpret_cast<const h16x8*>(rowp + dx * C16_PXB + 128 + cb * 64);
+                    ac[dy][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, p_lo, ac[dy][cb], 0, 0, 0);
+                    am[dy][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, p_hi, am[dy][cb], 0, 0, 0);
+                    ac[dy][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, p_hi, ac[dy][cb], 0, 0, 0);
+                    if (dy == 1 && dx == 1) {                    // theta is the 1x1 conv on the centre pixel
+                        const h16x8 t_hi = wh[18 + cb], t_lo = wl2[18 + cb];
+                        tc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t_hi, p_lo, tc[cb], 0, 0, 0);
+                        tm[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t_hi, p_hi, tm[cb], 0, 0, 0);
+                        tc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t_lo, p_hi, tc[cb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        f32x4 ag, at;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // fixed summation order: cross terms first
+            const float cr = ((ac[0][0][r] + ac[0][1][r]) + (ac[1][0][r] + ac[1][1][r])) + (ac[2][0][r] + ac[2][1][r]);
+            const float mn = ((am[0][0][r] + am[0][1][r]) + (am[1][0][r] + am[1][1][r])) + (am[2][0][r] + am[2][1][r]);
+            ag[r] = mn + cr;
+            at[r] = (tm[0][r] + tm[1][r]) + (tc[0][r] + tc[1][r]);
+        }
+        // D[row = channel 4 kg + r][col = pixel i]
+        const int xx = x0 + 16 * wave + i;
+        if (xx < W) {
+            const size_t o = (((size_t)b * Hp + y + PADPIX) * Wp + xx + PADPIX) * CH + 4 * kg;
+            h16x4 vh, vl;
+            float4 v2;
+            float* v2p = &v2.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = ag[r] * inv + bg[r];
+                _Float16 h, l;
+                c16_split(v1 * 16.0f, h, l);                     // P16_A_SCALE (project16.hip)
+                vh[r] = h; vl[r] = l;
+                v2p[r] = at[r] * inv + bt[r];
+            }
+            *reinterpret_cast<h16x4*>(b1hi + o) = vh;
+            *reinterpret_cast<h16x4*>(b1lo + o) = vl;
+            *reinterpret_cast<float4*>(b2p + o) = v2;
+        }
+        if (y + 1 < y1) store_row(y + 2, stc, shc);              // overwrites row y-2's slot: not read any more
+        __syncthreads();
+    };
+    for (int y = y0; y < y1; y += 2) {
+        do_row(y, st0, sh0, st1, sh1);
+        if (y + 1 < y1) do_row(y + 1, st1, sh1, st0, sh0);
+    }
+}
+
 // thr / bias heads: one wave per query, lane = one of the 49 taps, loop over the 64 channels.
 __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, const float* __restrict__ x,
                                                        const float* __restrict__ thr_w, const float* __restrict__ thr_b,
@@ -150,9 +374,10 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, const float* __r
     const float* xp = x + (size_t)b * PC * gr.N + (size_t)(ok ? yy : 0) * gr.W + (ok ? xx : 0);
     const int tap = (lane < KS * KS) ? lane : 0;
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int ch = 0; ch < PC; ++ch) {
-        const float v = ok ? xp[(size_t)ch * gr.N] : 0.f;
+        const float raw = xp[(size_t)ch * gr.N];          // always a valid address (clamped above); a predicated load would
+        const float v = ok ? raw : 0.f;                    // make the compiler wait for each load before the next
         s1 = fmaf(v, thr_w[ch * (KS * KS) + tap], s1);
         s2 = fmaf(v, bias_w[ch * (KS * KS) + tap], s2);
     }
@@ -173,14 +398,21 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
-    int chunks = (256 + strips * B - 1) / (strips * B);
+    static const int target = getenv("DAGL_PRO_BLOCKS") ? atoi(getenv("DAGL_PRO_BLOCKS")) : 256;
+    int chunks = (target + strips * B - 1) / (strips * B);
     if (chunks > (g.H + 1) / 2) chunks = (g.H + 1) / 2;
     if (chunks < 1) chunks = 1;
     const int rows_per_block = (g.H + chunks - 1) / chunks;
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
-                       g_b, th_w, th_b, b1p, b2p, b1_hi, b1_lo);
-    DAGL_LAUNCH_CHECK("conv_pair_kernel");
+    if (b1p == nullptr && b1_hi != nullptr) {
+        hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
+                           g_b, th_w, th_b, b2p, b1_hi, b1_lo);
+        DAGL_LAUNCH_CHECK("conv_pair16_kernel");
+    } else {
+        hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
+                           g_b, th_w, th_b, b1p, b2p, b1_hi, b1_lo);
+        DAGL_LAUNCH_CHECK("conv_pair_kernel");
+    }
     if (thr != nullptr) {
         hipLaunchKernelGGL(thr_bias_kernel, dim3((g.L + 3) / 4, B), dim3(256), 0, s, g, x, thr_w, thr_b, bias_w,
                            bias_b, thr, bias);

@@ -194,12 +194,13 @@ def test_full_size_properties(H, W, mode, k):
     # fold(agg) == out (stage consistency at full size)
     out2 = ops.fold_normalize(info["agg"], H, W)
     assert torch.equal(out, out2)
-    # linearity in the values: theta scaled by 2 (exact in fp32) doubles the output bit for bit
+    # linearity in the values: theta scaled by 2 doubles the output (up to the last bit: the split-fp16 prologue rounds a
+    # weight's low part on an absolute grid, so doubling is exact only where that part is a normal fp16 number)
     with torch.no_grad():
         out_x1 = ce(x).clone()
         ce.theta.weight.mul_(2.0); ce.theta.bias.mul_(2.0)
         out_x2 = ce(x)
-    assert torch.equal(out_x2, out_x1 * 2.0)
+    assert normwise(out_x2.cpu().numpy(), (out_x1 * 2.0).cpu().numpy()) <= 1e-6
     # fused prologue (module path) vs stock-conv prologue + block entry point: rounding-level differences of b1,
     # except where they flip a near-tie of the selection (top-k is discontinuous): allow 0.1 % of the pixels
     d = (out_x1 - out).abs() / out.abs().max()
