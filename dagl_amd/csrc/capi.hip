@@ -64,7 +64,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_ssegcnt, o_redo, o_thr, o_bias, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
+        o_ssegcnt, o_redo, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -154,6 +154,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.o_agg = carve(off, BL * P * sizeof(float));
     p.o_thr = carve(off, BL * sizeof(float));
     p.o_bias = carve(off, BL * sizeof(float));
+    p.o_thrpart = carve(off, 8 * BL * sizeof(float));                       // prologue: partial thr/bias sums of 4 channel groups
     p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = p.o_colpart = 0;
     if (!exact) {
         p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
@@ -279,7 +280,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       thr_heads ? thr_ws + (size_t)hd * imgs * g.L : nullptr,
                                       bias_ws + (size_t)hd * imgs * g.L,
                                       p.split16 ? at<uint16_t>(ws, p.o_maphi) + hd * map_f : nullptr,
-                                      p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr))) return rc;
+                                      p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr,
+                                      at<float>(ws, p.o_thrpart) + (size_t)hd * 8 * imgs * g.L))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {
@@ -735,8 +737,14 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const fl
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && x && g_w && g_b && theta_w && theta_b && b1_nhwc && b2_nhwc,
                  "dagl_ce_prologue: bad argument");
     if (thr || bias) DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b, "dagl_ce_prologue: thr/bias heads incomplete");
-    return launch_prologue((hipStream_t)stream, B, make_grid(H, W), x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w,
-                           bias_b, b1_nhwc, b2_nhwc, thr, bias, nullptr, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    const Grid g = make_grid(H, W);
+    float* part = nullptr;                                   // stream-ordered scratch of the thr/bias heads
+    if (thr) DAGL_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)8 * B * g.L * sizeof(float), s));
+    const int rc = launch_prologue(s, B, g, x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, b1_nhwc, b2_nhwc,
+                                   thr, bias, nullptr, nullptr, part);
+    if (part) DAGL_HIP_TRY(hipFreeAsync(part, s));
+    return rc;
 }
 
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {

@@ -358,41 +358,104 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
     }
 }
 
-// thr / bias heads: one wave per query, lane = one of the 49 taps, loop over the 64 channels.
-__global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, const float* __restrict__ x,
-                                                       const float* __restrict__ thr_w, const float* __restrict__ thr_b,
-                                                       const float* __restrict__ bias_w, const float* __restrict__ bias_b,
-                                                       float* __restrict__ thr, float* __restrict__ bias) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (q >= gr.L) return;
-    const int qr = q / gr.Lw, qc = q - qr * gr.Lw;
-    const int kh = lane / KS, kw = lane - kh * KS;
-    const int yy = QS * qr - gr.pt + kh, xx = QS * qc - gr.pl + kw;
-    const bool ok = (lane < KS * KS) && yy >= 0 && yy < gr.H && xx >= 0 && xx < gr.W;   // SAME zero padding
-    const float* xp = x + (size_t)b * PC * gr.N + (size_t)(ok ? yy : 0) * gr.W + (ok ? xx : 0);
-    const int tap = (lane < KS * KS) ? lane : 0;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll 16
-    for (int ch = 0; ch < PC; ++ch) {
-        const float raw = xp[(size_t)ch * gr.N];          // always a valid address (clamped above); a predicated load would
-        const float v = ok ? raw : 0.f;                    // make the compiler wait for each load before the next
-        s1 = fmaf(v, thr_w[ch * (KS * KS) + tap], s1);
-        s2 = fmaf(v, bias_w[ch * (KS * KS) + tap], s2);
+// thr / bias heads (two 7x7 stride-4 convolutions 64 -> 1 over the SAME-padded input, dagl.py:212-215).
+// One block per (image, query row, 32 queries, 16-channel group): the 7 input rows the queries need are staged in LDS
+// with coalesced row loads (a per-query gather touches seven 28-byte pieces per channel: 22 % of every cache line,
+// 27 us at 256^2); all loads are unconditional (clamped addresses, zeroed afterwards) and in flight together.
+// lane = (query, half of the 7 rows) reads its 7 taps per row as two conflict-free ds_read_b128, the weights as broadcast
+// float4; wave w owns channels 4j + w of the group.  The four channel groups write partial sums which
+// thr_bias_reduce_kernel adds in a fixed order.
+constexpr int TB_Q = 32;                    // queries per block
+constexpr int TB_XW = 4 * TB_Q + 4;         // input columns a block needs (4 (Q-1) + 7, rounded up to float4)
+constexpr int TB_CG = 16;                   // channels per block
+constexpr int TB_GROUPS = PC / TB_CG;       // 4
+constexpr int TB_N = TB_CG * KS * TB_XW;    // staged floats: 14784
+constexpr int TB_PER = (TB_N + 255) / 256;  // 58 per thread
+__global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, int B, const float* __restrict__ x,
+                                                       const float* __restrict__ thr_w, const float* __restrict__ bias_w,
+                                                       float* __restrict__ part_out /* [4][B][L][2] */) {
+    __shared__ __attribute__((aligned(16))) float tile[TB_N + 256];                  // 58.8 KiB
+    __shared__ __attribute__((aligned(16))) float wl[2][TB_CG][KS][8];               // 7 KiB: both heads' weights, rows of 7 (+1)
+    __shared__ float part[4][TB_Q][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, hh = lane >> 5;
+    const int chunks = (gr.Lw + TB_Q - 1) / TB_Q;
+    const int qr = blockIdx.x / chunks, q0 = (blockIdx.x - qr * chunks) * TB_Q;
+    const int b = blockIdx.y, grp = blockIdx.z;
+    const int c0 = grp * TB_CG;
+    const int y0 = QS * qr - gr.pt, x0 = QS * q0 - gr.pl;
+    const float* xc0 = x + ((size_t)b * PC + c0) * gr.N;
+    float v[TB_PER];
+#pragma unroll
+    for (int j = 0; j < TB_PER; ++j) {
+        const int idx = tid + 256 * j;
+        const int c = idx / (KS * TB_XW), rem = idx - c * (KS * TB_XW);
+        const int r = rem / TB_XW, col = rem - r * TB_XW;
+        const int yy = y0 + r, xx = x0 + col;
+        const int yc = yy < 0 ? 0 : (yy >= gr.H ? gr.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= gr.W ? gr.W - 1 : xx);
+        const int cc = c < TB_CG ? c : TB_CG - 1;
+        v[j] = xc0[(size_t)cc * gr.N + yc * gr.W + xc];
+    }
+    for (int e = tid; e < TB_CG * KS * KS; e += 256) {
+        const int ch = e / (KS * KS), t = e - ch * (KS * KS);
+        const int kh = t / KS, kw = t - kh * KS;
+        wl[0][ch][kh][kw] = thr_w[c0 * (KS * KS) + e];
+        wl[1][ch][kh][kw] = bias_w[c0 * (KS * KS) + e];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane == 0) {
-        thr[(size_t)b * gr.L + q] = s1 + thr_b[0];
-        bias[(size_t)b * gr.L + q] = s2 + bias_b[0];
+    for (int j = 0; j < TB_PER; ++j) {
+        const int idx = tid + 256 * j;
+        const int c = idx / (KS * TB_XW), rem = idx - c * (KS * TB_XW);
+        const int r = rem / TB_XW, col = rem - r * TB_XW;
+        const int yy = y0 + r, xx = x0 + col;
+        const bool ok = yy >= 0 && yy < gr.H && xx >= 0 && xx < gr.W;                 // SAME zero padding
+        tile[idx] = ok ? v[j] : 0.f;
     }
+    __syncthreads();
+    const int kh0 = hh ? 4 : 0, kh1 = hh ? KS : 4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < TB_CG / 4; ++j) {
+        const int cl = 4 * j + w;
+        for (int kh = kh0; kh < kh1; ++kh) {
+            const float* rp = tile + (cl * KS + kh) * TB_XW + 4 * qi;
+            const float4 v0 = *reinterpret_cast<const float4*>(rp);
+            const float4 v1 = *reinterpret_cast<const float4*>(rp + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(&wl[0][cl][kh][0]);
+            const float4 a1 = *reinterpret_cast<const float4*>(&wl[0][cl][kh][4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&wl[1][cl][kh][0]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&wl[1][cl][kh][4]);
+            s1 = fmaf(v0.x, a0.x, s1); s1 = fmaf(v0.y, a0.y, s1); s1 = fmaf(v0.z, a0.z, s1); s1 = fmaf(v0.w, a0.w, s1);
+            s1 = fmaf(v1.x, a1.x, s1); s1 = fmaf(v1.y, a1.y, s1); s1 = fmaf(v1.z, a1.z, s1);
+            s2 = fmaf(v0.x, b0.x, s2); s2 = fmaf(v0.y, b0.y, s2); s2 = fmaf(v0.z, b0.z, s2); s2 = fmaf(v0.w, b0.w, s2);
+            s2 = fmaf(v1.x, b1.x, s2); s2 = fmaf(v1.y, b1.y, s2); s2 = fmaf(v1.z, b1.z, s2);
+        }
+    }
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (hh == 0) { part[w][qi][0] = s1; part[w][qi][1] = s2; }
+    __syncthreads();
+    if (tid < TB_Q && q0 + tid < gr.Lw) {
+        const size_t o = (((size_t)grp * B + b) * gr.L + (size_t)qr * gr.Lw + q0 + tid) * 2;
+        part_out[o] = (part[0][tid][0] + part[1][tid][0]) + (part[2][tid][0] + part[3][tid][0]);
+        part_out[o + 1] = (part[0][tid][1] + part[1][tid][1]) + (part[2][tid][1] + part[3][tid][1]);
+    }
+}
+
+__global__ void thr_bias_reduce_kernel(size_t n /* B*L */, const float* __restrict__ part, const float* __restrict__ thr_b,
+                                       const float* __restrict__ bias_b, float* __restrict__ thr, float* __restrict__ bias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p0 = reinterpret_cast<const float2*>(part)[i], p1 = reinterpret_cast<const float2*>(part)[n + i];
+    const float2 p2 = reinterpret_cast<const float2*>(part)[2 * n + i], p3 = reinterpret_cast<const float2*>(part)[3 * n + i];
+    thr[i] = ((p0.x + p1.x) + (p2.x + p3.x)) + thr_b[0];
+    bias[i] = ((p0.y + p1.y) + (p2.y + p3.y)) + bias_b[0];
 }
 
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
-                    uint16_t* b1_hi, uint16_t* b1_lo) {
+                    uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part) {
     int rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p);
     if (rcz) return rcz;
     if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
@@ -414,9 +477,14 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
         DAGL_LAUNCH_CHECK("conv_pair_kernel");
     }
     if (thr != nullptr) {
-        hipLaunchKernelGGL(thr_bias_kernel, dim3((g.L + 3) / 4, B), dim3(256), 0, s, g, x, thr_w, thr_b, bias_w,
-                           bias_b, thr, bias);
+        // thr_part: [4][B][L][2] floats of scratch for the channel groups' partial sums
+        hipLaunchKernelGGL(thr_bias_kernel, dim3(g.Lh * ((g.Lw + TB_Q - 1) / TB_Q), B, TB_GROUPS), dim3(256), 0, s, g, B, x,
+                           thr_w, bias_w, thr_part);
         DAGL_LAUNCH_CHECK("thr_bias_kernel");
+        const size_t n = (size_t)B * g.L;
+        hipLaunchKernelGGL(thr_bias_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, thr_part, thr_b,
+                           bias_b, thr, bias);
+        DAGL_LAUNCH_CHECK("thr_bias_reduce_kernel");
     }
     return DAGL_OK;
 }
