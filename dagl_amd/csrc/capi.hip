@@ -64,7 +64,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_ssegcnt, o_redo, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -163,13 +163,14 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
         p.o_wp2h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));
         p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
-    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_ssegcnt = p.o_redo = 0;
+    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
         p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int32_t));
+        p.o_scandv = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(float));
         p.o_ssegcnt = carve(off, BL * p.s_splits * 2 * sizeof(int32_t));
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
@@ -387,6 +388,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
+        sc.cand_val = at<float>(ws, p.o_scandv);
         redo = at<int32_t>(ws, p.o_redo);
         { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
         prof_mark(prof, s, 3);
@@ -404,6 +406,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         ra.B = B; ra.L = g.L; ra.N = g.N; ra.mode = mode; ra.k = k; ra.splits = p.s_splits; ra.capseg = p.capseg;
         ra.width = p.width; ra.wq = Wq; ra.x = X; ra.rows_q = feat_rows(g.L); ra.rows_x = feat_rows(g.N);
         ra.mt = mt; ra.bs = bias; ra.cand_idx = sc.cand_idx; ra.seg_cnt = sc.seg_cnt;
+        ra.cand_val = sc.cand_val; ra.theta = sc.theta;
         ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if ((rc = launch_refine(s, ra))) return rc;

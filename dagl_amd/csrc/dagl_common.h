@@ -205,6 +205,7 @@ struct ScreenArgs {
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
     int capseg;
     int32_t* cand_idx;              // pass 1 out: [B, L, splits*2, capseg]
+    float* cand_val;                // pass 1 out: screened score of each candidate (sign bit set = upper bound only)
     int32_t* seg_cnt;               // pass 1 out: [B, L, splits*2]
     const int32_t* run_flags;
     int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
@@ -218,6 +219,7 @@ struct RefineArgs {
     const float* wq; const float* x; int rows_q, rows_x;     // fp32 features
     const float* mt; const float* bs;
     const int32_t* cand_idx; const int32_t* seg_cnt;
+    const float* cand_val; const float* theta;     // screened scores of the candidates, candidate threshold per query
     int32_t* nb_idx; float* nb_wgt; int32_t* nb_cnt;
     int32_t* redo_flags;            // [B, n_qgroups_exact]: query groups (of 128) the exact kernel must redo
     int n_qgroups_exact;

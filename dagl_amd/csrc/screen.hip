@@ -71,6 +71,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
     float thq[QW], thlo[QW];          // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
     int n_loc[QW];
     int32_t* cseg[QW];
+    float* vseg[QW];
     size_t seg[QW];
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         n_loc[w] = 0;
         seg[w] = (qlin[w] * a.splits + split) * 2 + h;
         cseg[w] = a.cand_idx + seg[w] * a.capseg;
+        vseg[w] = a.cand_val + seg[w] * a.capseg;
     }
 #pragma unroll
     for (int w = 0; w < QW; ++w)
@@ -171,12 +173,15 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                         for (int r = 0; r < 16; ++r)
                             mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo[w] - acc[w][tl][r]), 31);
                         const int kbase = step * SK + 4 * h + tl * 32;
+                        // the screened score travels with the key: exact when the lane has one candidate in this tile (it is
+                        // the tile maximum), otherwise the maximum with the sign bit set = "upper bound only"
+                        const float sv = (__popc(mask) == 1) ? mxt[tl] : -mxt[tl];
                         while (mask) {                                   // score r sits at bit 15 - r: ascending r
                             const int bit = 31 - __clz((int)mask);
                             mask &= ~(1u << bit);
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
-                            if (n_loc[w] < a.capseg) cseg[w][n_loc[w]] = key;
+                            if (n_loc[w] < a.capseg) { cseg[w][n_loc[w]] = key; vseg[w][n_loc[w]] = sv; }
                             ++n_loc[w];
                         }
                     }
@@ -348,22 +353,56 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         const size_t sg = ql * S2 + (sv ? sgi : 0);
         int cnt = sv ? a.seg_cnt[sg] : 0;
         const int4 f4 = *reinterpret_cast<const int4*>(a.cand_idx + sg * a.capseg);
+        const float4 g4 = *reinterpret_cast<const float4*>(a.cand_val + sg * a.capseg);
         if (cnt > a.capseg) { overflow = true; cnt = a.capseg; }
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int off = total + incl - cnt;
         if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
-        if (cnt > 0) c_idx[w][off] = f4.x;
-        if (cnt > 1) c_idx[w][off + 1] = f4.y;
-        if (cnt > 2) c_idx[w][off + 2] = f4.z;
-        if (cnt > 3) c_idx[w][off + 3] = f4.w;
-        for (int e = 4; e < cnt; ++e) c_idx[w][off + e] = a.cand_idx[sg * a.capseg + e];
+        if (cnt > 0) { c_idx[w][off] = f4.x; c_val[w][off] = g4.x; }
+        if (cnt > 1) { c_idx[w][off + 1] = f4.y; c_val[w][off + 1] = g4.y; }
+        if (cnt > 2) { c_idx[w][off + 2] = f4.z; c_val[w][off + 2] = g4.z; }
+        if (cnt > 3) { c_idx[w][off + 3] = f4.w; c_val[w][off + 3] = g4.w; }
+        for (int e = 4; e < cnt; ++e) {
+            c_idx[w][off + e] = a.cand_idx[sg * a.capseg + e];
+            c_val[w][off + e] = a.cand_val[sg * a.capseg + e];
+        }
         total += __shfl(incl, 63);
     }
     overflow = __any(overflow);
     if (total > RF_MAX_CAND) total = RF_MAX_CAND;
     __threadfence_block();
+
+    // 1b. top-k modes: most candidates owe their place to the loose threshold of the sampling pass.  With the screened
+    //     scores at hand the wave tightens it before any feature row is fetched (that gather is what this kernel costs):
+    //     k candidates have S~ >= t (t = k-th largest lower bound), so the k-th largest true score is >= t/(1+DELTA), and a
+    //     candidate whose upper bound is below t (1-DELTA)/(1+DELTA) cannot be among the k best.
+    if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k && total <= 64) {
+        const float thq = a.theta[ql];
+        const bool have = lane < total;
+        const int key = have ? c_idx[w][lane] : -1;
+        const float u = have ? c_val[w][lane] : 0.f;
+        const float ub = fabsf(u);
+        float lb = have ? ((u >= 0.f) ? u : thq) : -1.0f;
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {                  // bitonic sort of the lower bounds, descending
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const float o = __shfl_xor(lb, j);
+                const bool desc = ((lane & k2) == 0);
+                const bool lower = ((lane & j) == 0);
+                lb = (lower == desc) ? fmaxf(lb, o) : fminf(lb, o);
+            }
+        }
+        const float tk = __shfl(lb, a.k - 1);
+        const bool keep = have && (ub >= tk * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f));
+        const unsigned long long bal = __ballot(keep);
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) c_idx[w][pos] = key;                           // pos <= lane, every lane has read its own slot already
+        total = __popcll(bal);
+        __threadfence_block();
+    }
 
     // 2. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation
     const int grp = lane >> 3, gl = lane & 7;
