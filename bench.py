@@ -41,8 +41,8 @@ D_FEAT, P_ROW = 196, 784
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="topk", choices=["topk", "adaptive", "adaptive_topk"])
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
@@ -240,7 +240,9 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        prof.reset()
+        # timed region: only the dominant kernel is bracketed by hipEvents (on the launch stream); an event record costs
+        # ~4 us of stream time, so the full nine-boundary stage profile is taken in a separate pass below
+        prof.select_stage("select")
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -251,6 +253,11 @@ def main():
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        dominant_ms = [c[4] for c in prof.read()]
+        prof.select_stage(-1)
+        for _ in range(min(args.steps, 20)):
+            step(prof)
+        torch.cuda.synchronize()
         ce.profile = None
     elapsed = reduce_max_seconds(elapsed, dist, dev)
     stage_ms = prof.read()
@@ -290,7 +297,7 @@ def main():
         sm = np.asarray(stage_ms, dtype=np.float64)                      # [steps, 8]
         mean_ms = sm.mean(axis=0) if len(sm) else np.zeros(8)
         from dagl_amd._lib import STAGE_NAMES
-        sel_ms = float(mean_ms[4])
+        sel_ms = float(np.mean(dominant_ms)) if len(dominant_ms) else float(mean_ms[4])     # from the timed steps
         flops = 2.0 * heads_per_step * B * L * N * D_FEAT                # algorithmic: 2*L*N*D per image and head
         ach = flops / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
         screened = (info or {}).get("path") == 3
@@ -323,6 +330,7 @@ def main():
             "roofline": roofline,
             "roofline_gather": gather,
             "stage_ms": {STAGE_NAMES[i]: float(mean_ms[i]) for i in range(8)},
+            "stage_ms_note": "separate instrumented pass after the timed steps (nine event records per call add ~35 us)",
             "hip_block_ms": float(mean_ms.sum()),
         }
         if world == 1 and not args.no_quality and not args.stage:

@@ -63,6 +63,7 @@ SIGNATURES = {
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
     "dagl_profile_destroy": (_i, [_vp]),
     "dagl_profile_reset": (_i, [_vp]),
+    "dagl_profile_select_stage": (_i, [_vp, _i]),
     "dagl_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_float), _i]),
     "dagl_ce_forward_profiled": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                       C.POINTER(CeInfo), _vp]),

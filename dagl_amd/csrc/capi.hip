@@ -44,10 +44,13 @@ static int read_back(hipStream_t s, const int64_t* dev, int n, int64_t* out) {
 // ---- optional stage profile: hipEvents recorded at stage boundaries on the caller's stream ------------------
 struct Profile {
     int max_calls = 0, n_calls = 0;
+    int only_stage = -1;                 // >= 0: record just the two events around that stage (an event record costs
+                                         // ~4 us of stream time; nine per call are 12 % of a 256^2 forward)
     hipEvent_t* ev = nullptr;            // [max_calls][DAGL_N_STAGES + 1]
 };
 static inline void prof_mark(Profile* p, hipStream_t s, int stage_boundary) {
-    if (p && p->n_calls < p->max_calls)
+    if (p && p->n_calls < p->max_calls &&
+        (p->only_stage < 0 || stage_boundary == p->only_stage || stage_boundary == p->only_stage + 1))
         (void)hipEventRecord(p->ev[(size_t)p->n_calls * (DAGL_N_STAGES + 1) + stage_boundary], s);
 }
 
@@ -561,6 +564,14 @@ int dagl_profile_destroy(dagl_profile* prof) {
     return DAGL_OK;
 }
 
+int dagl_profile_select_stage(dagl_profile* prof, int stage) {
+    Profile* p = reinterpret_cast<Profile*>(prof);
+    DAGL_REQUIRE(p && stage >= -1 && stage < DAGL_N_STAGES, "dagl_profile_select_stage: bad argument");
+    p->only_stage = stage;
+    p->n_calls = 0;
+    return DAGL_OK;
+}
+
 int dagl_profile_reset(dagl_profile* prof) {
     Profile* p = reinterpret_cast<Profile*>(prof);
     DAGL_REQUIRE(p, "dagl_profile_reset: null profile");
@@ -576,10 +587,10 @@ int dagl_profile_read(dagl_profile* prof, int* n_calls, float* stage_ms, int cap
     const int n = p->n_calls < capacity_calls ? p->n_calls : capacity_calls;
     for (int c = 0; c < n; ++c) {
         hipEvent_t* e = p->ev + (size_t)c * (DAGL_N_STAGES + 1);
-        DAGL_HIP_TRY(hipEventSynchronize(e[DAGL_N_STAGES]));
+        DAGL_HIP_TRY(hipEventSynchronize(e[p->only_stage < 0 ? DAGL_N_STAGES : p->only_stage + 1]));
         for (int st = 0; st < DAGL_N_STAGES; ++st) {
             float ms = 0.f;
-            DAGL_HIP_TRY(hipEventElapsedTime(&ms, e[st], e[st + 1]));
+            if (p->only_stage < 0 || st == p->only_stage) DAGL_HIP_TRY(hipEventElapsedTime(&ms, e[st], e[st + 1]));
             stage_ms[(size_t)c * DAGL_N_STAGES + st] = ms;
         }
     }

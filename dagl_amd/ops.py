@@ -130,6 +130,12 @@ class StageProfile:
     def reset(self):
         check(_lib.load().dagl_profile_reset(self._h), "dagl_profile_reset")
 
+    def select_stage(self, stage: "int | str"):
+        """Record only the two events around one stage (index or name; -1 = every boundary again)."""
+        if isinstance(stage, str):
+            stage = list(_lib.STAGE_NAMES).index(stage)
+        check(_lib.load().dagl_profile_select_stage(self._h, int(stage)), "dagl_profile_select_stage")
+
     def read(self):
         """-> list of per-call lists of N_STAGES milliseconds (waits for the recorded events)."""
         lib = _lib.load()

@@ -166,6 +166,9 @@ int dagl_ce_forward_debug(void* stream, int B, int H, int W,
 int dagl_profile_create(int max_calls, dagl_profile** out);
 int dagl_profile_destroy(dagl_profile* prof);
 int dagl_profile_reset(dagl_profile* prof);
+/* stage >= 0: record only the two events around that stage (the others read back as 0 ms); -1 = all boundaries.
+ * Also resets the recorded calls. */
+int dagl_profile_select_stage(dagl_profile* prof, int stage);
 /* stage_ms [capacity_calls][DAGL_N_STAGES] (host memory, may be NULL to query n_calls only) */
 int dagl_profile_read(dagl_profile* prof, int* n_calls, float* stage_ms, int capacity_calls);
 int dagl_ce_forward_profiled(void* stream, int B, int H, int W,
