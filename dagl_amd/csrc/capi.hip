@@ -268,6 +268,10 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
     const int imgs = B / heads;
+    // "prepared": the caller vouches that this workspace last served an identical call (same geometry, mode, weights):
+    // packed weights, the maps' zero borders and the zero guard rows of the feature matrices are still in place, and
+    // the few per-call counters are cleared by the prologue kernel itself -- three launches fewer
+    const bool prepared = fin && p.split16 && (mode_flags & DAGL_FLAG_WEIGHTS_PACKED);
     if (core) {
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     } else if (fin) {
@@ -285,7 +289,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       bias_ws + (size_t)hd * imgs * g.L,
                                       p.split16 ? at<uint16_t>(ws, p.o_maphi) + hd * map_f : nullptr,
                                       p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr,
-                                      at<float>(ws, p.o_thrpart) + (size_t)hd * 8 * imgs * g.L))) return rc;
+                                      at<float>(ws, p.o_thrpart) + (size_t)hd * 8 * imgs * g.L,
+                                      prepared, (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
+                                      (prepared && hd == 0) ? 8 : 0,
+                                      (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
+                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {
@@ -312,7 +320,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
     }
     ZeroList zl;
-    {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
+    if (!prepared) {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
         const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
         zl.add(X + (size_t)g.N * DS, (size_t)(rx - g.N) * DS * sizeof(float), B, (size_t)rx * DS * sizeof(float));

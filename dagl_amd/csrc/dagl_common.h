@@ -115,7 +115,10 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p /* may be null */, float* b2p, float* thr,
                     float* bias, uint16_t* b1_hi /* optional fp16 split of b1 */, uint16_t* b1_lo,
-                    float* thr_part /* scratch [4][B][L][2] floats when thr != null */);
+                    float* thr_part /* scratch [4][B][L][2] floats when thr != null */,
+                    bool borders_zero = false /* the maps' 3-pixel borders still hold the zeros of an earlier call */,
+                    uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
+                    /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */);
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,

@@ -166,9 +166,14 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                                                           const float* __restrict__ g_w, const float* __restrict__ g_b,
                                                           const float* __restrict__ th_w, const float* __restrict__ th_b,
                                                           float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
-                                                          unsigned short* __restrict__ b1lo) {
+                                                          unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
+                                                          int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB];           // 110 KiB
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {      // per-call counters / flags of the later stages
+        for (int t = tid; t < clear_a_words; t += 256) clear_a[t] = 0u;
+        for (int t = tid; t < clear_b_words; t += 256) clear_b[t] = 0u;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 15, kg = lane >> 4;
@@ -455,10 +460,13 @@ __global__ void thr_bias_reduce_kernel(size_t n /* B*L */, const float* __restri
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
-                    uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part) {
-    int rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p);
-    if (rcz) return rcz;
-    if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
+                    uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, uint32_t* clear_a,
+                    int clear_a_words, uint32_t* clear_b, int clear_b_words) {
+    int rcz;
+    if (!borders_zero) {
+        if ((rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p))) return rcz;
+        if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
+    }
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
     static const int target = getenv("DAGL_PRO_BLOCKS") ? atoi(getenv("DAGL_PRO_BLOCKS")) : 256;
@@ -469,7 +477,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
     if (b1p == nullptr && b1_hi != nullptr) {
         hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
-                           g_b, th_w, th_b, b2p, b1_hi, b1_lo);
+                           g_b, th_w, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
     } else {
         hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,

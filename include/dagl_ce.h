@@ -55,8 +55,10 @@ extern "C" {
 /* OR-ed into `mode`: scan all L*N scores on the fp32 matrix cores instead of screening them in bf16 and
  * refining the survivors (both give the same neighbours)                             */
 #define DAGL_FLAG_EXACT_SCAN     0x100
-/* OR-ed into `mode`: the packed fc weights of the previous call are still valid -- same workspace memory, same
- * (B,H,W,mode,k), unchanged fc1/fc2 weights -- so repacking them is skipped (inference loops)            */
+/* OR-ed into `mode`: this workspace last served an identical call -- same memory, same (B,H,W,mode,k), unchanged
+ * fc1/fc2 weights -- and nothing else wrote to it since.  The call then reuses what that call left behind (packed fc
+ * weights, the zero borders of the padded maps, the zero guard rows of the feature matrices) instead of rebuilding
+ * it: three launches fewer per forward (inference loops)                                                    */
 #define DAGL_FLAG_WEIGHTS_PACKED 0x200
 
 #define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
