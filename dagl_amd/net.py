@@ -48,7 +48,8 @@ class CES(nn.Module):
         self.fuse_stage = in_channels == 64       # stage-level launch set (include/dagl_ce.h: dagl_ces_stage_forward)
         self.last_info = None
         from . import ops
-        self._ws = ops.Workspace()
+        self._ws = {1: ops.Workspace(), 2: ops.Workspace(), 3: ops.Workspace()}     # one per stage: packed weights persist
+        self._pack_key = {1: None, 2: None, 3: None}
 
     def _stage(self, s, x):
         heads = [getattr(self, f"c{s}_{h}") for h in (1, 2, 3, 4)]
@@ -59,9 +60,15 @@ class CES(nn.Module):
             # the four heads share x: one launch set with the heads as a batch dimension + the 1x1 mix + residual
             from . import ops
             prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
+            ws = self._ws[s]
+            fcs = [prm[h][n] for h in range(4) for n in ("fc1.0.weight", "fc2.0.weight")]
+            key = (tuple(x.shape), heads[0].select_mode, heads[0].select_k,
+                   tuple((t.data_ptr(), t._version) for t in fcs), ws.buf.data_ptr() if ws.buf is not None else 0)
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
                                               mix.bias.detach().contiguous(), mode=heads[0].select_mode,
-                                              k=heads[0].select_k, workspace=self._ws)
+                                              k=heads[0].select_k, workspace=ws,
+                                              weights_packed=(key == self._pack_key[s]))
+            self._pack_key[s] = key[:-1] + (ws.buf.data_ptr(),) if out is not None else None
             self.last_info = info
             if out is not None:
                 return out

@@ -299,7 +299,8 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
 
 
 def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: int = 0,
-                      workspace: "Workspace | None" = None, profile: "StageProfile | None" = None):
+                      workspace: "Workspace | None" = None, profile: "StageProfile | None" = None,
+                      weights_packed: bool = False):
     """One CES stage in one launch set: ``conv1x1(cat(head_1(x)..head_4(x))) + x`` (dagl.py:114,116,118).
     ``head_params``: four dicts (state_dict names -> contiguous fp32 GPU tensors).  Returns (out [B,64,H,W], info), or
     (None, info) when a dense adaptive neighbourhood needs the per-head path."""
@@ -326,7 +327,8 @@ def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: i
     base = buf.data_ptr()
     aligned = (base + 255) // 256 * 256
     rc = lib.dagl_ces_stage_forward(_stream(), B, H, W, x.data_ptr(), arr, mix_w.data_ptr(), mix_b.data_ptr(),
-                                    MODES[mode], int(k), out.data_ptr(), aligned, buf.numel() - (aligned - base),
+                                    MODES[mode] | (_lib.FLAG_WEIGHTS_PACKED if weights_packed else 0), int(k),
+                                    out.data_ptr(), aligned, buf.numel() - (aligned - base),
                                     C.byref(info), profile._h if profile is not None else None)
     meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges, max_degree=info.max_degree,
                 path=info.path, redone_queries=info.redone_queries)
