@@ -156,6 +156,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 
     auto issue_w = [&](int t) {                        // weight slice of tap t -> ring stage t % RING
         if (VAR == 6) return;
+        if (VAR == 11 && (t & 1)) return;
         const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
 #pragma unroll
@@ -205,8 +206,53 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     // landing of tap t+1: its weight pieces (and everything issued before them) are complete once at most the DMAs
     // issued after them are outstanding.  Patch-row pieces issued in between only make the wait stricter.
     constexpr int PER_Q = KEYS ? 0 : 2;
-#define P16_WAIT(P) do { if (VAR == 4 || VAR == 6) break; if (extra) dma_wait_le<(P) * (PBASE + 1 + PER_Q)>(); else dma_wait_le<(P) * (PBASE + PER_Q)>(); } while (0)
+#define P16_WAIT(P) do { if (VAR == 4 || VAR == 6 || VAR == 11) break; if (extra) dma_wait_le<(P) * (PBASE + 1 + PER_Q)>(); else dma_wait_le<(P) * (PBASE + PER_Q)>(); } while (0)
 
+    const int swz = (i >> 2) & 3;                                       // slot swizzle of row n*32 + i (n*32 does not change it)
+    const int boff_hi = i * (P16_ROWH * 2) + ((h ^ swz) << 4);          // bytes: B fragment row n*32 + i, hi half h
+    const int boff_lo = i * (P16_ROWH * 2) + (((2 + h) ^ swz) << 4);
+    if (NT == 1 && KEYS) {
+        // single-tile blocks (the split remainder of the grid) have 3 MFMAs per tap: a barrier per tap would leave them
+        // latency-bound, so a ring stage holds the 7 taps of one kernel row (7 x 2 KiB) and there is one barrier per row
+        auto issue_wrow = [&](int kh) {
+            const unsigned st = lds0 + (unsigned)(kh % P16_RING) * P16_STAGE_B;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = wave + P16_BW * j;                      // 14 pieces: tap kw = p >> 1, half (p & 1) of its 2 KiB
+                if (p < 2 * KS)
+                    glds16_asm(reinterpret_cast<const float*>(wp + (size_t)(kh * KS + (p >> 1)) * P16_SLICE_H + (p & 1) * 512 + lane * 8),
+                               __builtin_amdgcn_readfirstlane(st + p * 1024));
+            }
+        };
+        const bool four = wave < 2;                                    // waves 0, 1 carry 4 weight pieces per row, waves 2, 3 carry 3
+        f32x16 c1, c2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c2[r] = 0.f; }
+        issue_row(0); issue_wrow(0); issue_wrow(1);
+        if (four) dma_wait_le<4>(); else dma_wait_le<3>();             // row 0 and weight row 0 landed
+        __syncthreads();
+        for (int kh = 0; kh < KS; ++kh) {
+            if (kh + 1 < KS) issue_row(kh + 1);
+            if (kh + 2 < KS) issue_wrow(kh + 2);
+            const unsigned char* sa0 = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + i * 32 + 16 * h;
+            const unsigned char* sb = smem + (kh % P16_RING) * P16_STAGE_B;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa0 + kw * 32));
+                const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa0 + kw * 32 + P16_APART));
+                const f16x8 w_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + kw * 2048 + boff_hi));
+                const f16x8 w_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + kw * 2048 + boff_lo));
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_lo, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo, w_hi, c2, 0, 0, 0);
+                hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi, w_hi, hh[0], 0, 0, 0);
+            }
+            // next row's patches and weights must have landed; only the weight row issued above may still be in flight
+            if (kh + 2 < KS) { if (four) dma_wait_le<4>(); else dma_wait_le<3>(); } else dma_wait_le<0>();
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[0][r] += c1[r] + c2[r];
+    } else {
     if (KEYS) issue_row(0);
 #pragma unroll
     for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
@@ -214,9 +260,6 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     __syncthreads();
 
     if (VAR == 9) { if (hh[0][0] != 0.f) pa.feat[which][0] = 1.f; return; }
-    const int swz = (i >> 2) & 3;                                       // slot swizzle of row n*32 + i (n*32 does not change it)
-    const int boff_hi = i * (P16_ROWH * 2) + ((h ^ swz) << 4);          // bytes: B fragment row n*32 + i, hi half h
-    const int boff_lo = i * (P16_ROWH * 2) + (((2 + h) ^ swz) << 4);
     auto compute = [&](int step) {
         const int kh = step / KS, kw = step - kh * KS;
         const unsigned char* sa;
@@ -261,6 +304,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     compute(P16_STEPS - 2); P16_WAIT(0); __syncthreads();
     compute(P16_STEPS - 1);
     __syncthreads();
+    }
 #undef P16_WAIT
     static_assert(PD == 2 || PD == 3, "the drain sequence above is written for PD = 2 or 3");
 
@@ -385,6 +429,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     else if (var == 7) hipLaunchKernelGGL(project16_kernel<7>, grid, block, 0, s, pa);
     else if (var == 8) hipLaunchKernelGGL(project16_kernel<8>, grid, block, 0, s, pa);
     else if (var == 9) hipLaunchKernelGGL(project16_kernel<9>, grid, block, 0, s, pa);
+    else if (var == 11) hipLaunchKernelGGL(project16_kernel<11>, grid, block, 0, s, pa);
     else hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
     if (pa.colpart != nullptr && nbk > 0) {
