@@ -1,18 +1,23 @@
 // Patch projection on the fp16 matrix cores with split operands -- same result class as the fp32 kernel of
-// project.hip at a third of its matrix-core cycles per product and 16x its rate.
+// project.hip at a fifth of its matrix-core cycles.
 //
-// Every fp32 operand is split into two fp16 numbers, a = a_hi + 2^-11 a_lo (a_hi = fp16(a), a_lo =
-// fp16((a - a_hi) 2^11)): 22 significant bits.  A product keeps its three leading terms
-//     a w  ~  a_hi w_hi  +  2^-11 (a_hi w_lo + a_lo w_hi)            (dropped: 2^-22 a_lo w_lo)
-// Each fp16 x fp16 product is exact in fp32; v_mfma_f32_32x32x16_f16 sums 16 of them into an fp32 accumulator.
-// The hh chain has 49 links (one per kernel tap) instead of the 784 of an fp32 fma chain, so its accumulation
-// error is smaller, and the split itself costs 1.2e-5 normwise on the block output (measured against fp64; the
-// fp32-input bound is 3e-6) -- well inside the reference's own fp32 noise of 2e-5..6e-5.
+// Every fp32 operand is split into two fp16 numbers after an exact power-of-two pre-scaling that keeps the low part a
+// normal fp16 number for ordinary magnitudes (16 a = a_hi + a_lo for activations, 1024 w = w_hi + w_lo for weights; the
+// matrix cores keep fp16 denormals, so smaller values only lose relative, not absolute, precision): >= 21 significant
+// bits.  A product keeps its three leading terms
+//     a w  ~  a_hi w_hi + a_hi w_lo + a_lo w_hi                       (dropped: a_lo w_lo, 2^-22 relative)
+// each an exact fp32 number inside v_mfma_f32_32x32x16_f16, all three accumulated into ONE fp32 accumulator (147 links
+// per output instead of the 784 of an fp32 fma chain); the result is scaled back by 2^-14.  Measured cost of the split on
+// the block output: 1.2e-5 normwise against fp64 -- inside the reference's own fp32 noise of 2e-5..6e-5.
+// Range: |16 a| and |1024 w| must stay below 65504 (fp16); the exact scan (project.hip) has no such limit.
 //
-// Tiling: one wave = 32 consecutive patches x 224 (= 7 x 32, 196 real) outputs: accumulators hh[7], cross[7].
-//   A: hi/lo fp16 NHWC maps, one 16-byte load per lane per tap and part (coalesced, L2 resident)
-//   B: per tap the [224 outs][hi 16 | lo 16 | pad 8] fp16 slice (18 KiB) is shared by the 4 waves of a block
-//      through LDS, double buffered by LDS-DMA; 80-byte rows (5 slots, odd) make the ds_read_b128 conflict-free.
+// Tiling: one wave = 32 consecutive patches of a row x 224 (= 7 x 32, 196 real) outputs, 7 accumulators.
+//   A (patches): keys -- per wave a 2-row ring of the hi / lo map rows its patches touch (38 pixels), by LDS-DMA: each
+//                input pixel is fetched once per kernel ROW, not once per tap; queries (stride-4 grid) -- per tap each lane
+//                DMA-copies the 16 bytes it reads back
+//   B (weights): per tap the [224 outs][hi 16 | lo 16] fp16 slice (14 KiB) is shared by the 4 waves of a block through a
+//                4-stage LDS ring filled by LDS-DMA; the four 16-byte slots of a 64-byte row are stored at
+//                slot ^ ((row >> 2) & 3), which makes the ds_read_b128 of 32 consecutive rows conflict-free unpadded
 #include <stdlib.h>
 
 #include "dagl_common.h"
@@ -22,7 +27,6 @@ namespace dagl {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int P16_WAVES = 4;
 constexpr int P16_NT = 7;                        // 32-wide output tiles (224 >= 196)
 constexpr int P16_OUT = P16_NT * 32;             // 224
 constexpr int P16_ROWH = 32;                     // halfs per output row of a slice: 16 hi + 16 lo (four 16-byte slots, swizzled)
@@ -100,13 +104,8 @@ struct Proj16Args {
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
 };
 
-// Block = 8 waves = 8 x 32 consecutive-row patches x NT x 32 outputs (the 7 output tiles are split 4 + 3 over two
-// blocks: accumulators 2 x NT x 16 registers).  All operands arrive by LDS-DMA issued from inline asm and are
-// consumed behind COUNTED s_waitcnt vmcnt(N):
-//   weights  : ring of P16_RING tap slices (NT*32 rows x 80 B), prefetched P16_PD taps ahead, shared by the 8 waves
-//   patches  : keys    -- per wave a 2-row ring of the map rows its 32 patches touch (38 pixels x hi|lo): every input
-//                         pixel is fetched 7 times (once per kernel row) instead of 49 (once per tap)
-//              queries -- stride-4 grid: per tap, each lane DMA-copies the 16 bytes it will read back (ring stage)
+// Block = 4 waves (two blocks per CU, independent barriers).  All operands arrive by LDS-DMA issued from inline asm and are
+// consumed behind COUNTED s_waitcnt vmcnt(N): the weight slice of tap t+PD is requested while tap t is multiplied.
 constexpr int P16_BW = 4;                              // waves per block (two blocks per CU: independent barriers)
 constexpr int P16_RING = 4;                            // weight stages
 constexpr int P16_PD_KEYS = 3;                         // prefetch distance (taps): key blocks
@@ -313,7 +312,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which][head];
     const int grid_row_base = gy * row_len + gx0;
-    float* csum = reinterpret_cast<float*>(smem);                       // [8 waves][NT*32] (ring is dead now)
+    float* csum = reinterpret_cast<float*>(smem);                       // [4 waves][NT*32] (the weight ring is dead now)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = (n0 + n) * 32 + i;

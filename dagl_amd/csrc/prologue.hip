@@ -5,9 +5,10 @@
 //     thr  = thr_conv (same_pad(b))  7x7 stride 4, 64->1              dagl.py:212-214
 //     bias = bias_conv(same_pad(b))  7x7 stride 4, 64->1              dagl.py:215
 // written directly in the layout the rest of the path consumes: b1/b2 as zero-bordered NHWC maps (so the
-// pad/transposes of layout.hip disappear), thr/bias as [B,L].  The input is read once.
+// pad/transposes of layout.hip disappear), thr/bias as [B,L].
 //
-// conv_pair_kernel: one wave = 16 consecutive pixels of a row; v_mfma_f32_16x16x4_f32 with
+// conv_pair16_kernel (default path, further down): split-fp16 operands on the 16x16x32 matrix instruction.
+// conv_pair_kernel (exact scan): one wave = 16 consecutive pixels of a row; v_mfma_f32_16x16x4_f32 with
 //   A[pixel][channel]   from a 4-row LDS ring of the input strip (rows y-1..y+1 live, y+2 in flight)
 //   B[channel][out]     the 3x3 + 1x1 weights, held in registers for the block's lifetime (160 VGPRs)
 // three accumulators (one per kernel row) + one for theta; exact fp32 fma chains like the stock conv.

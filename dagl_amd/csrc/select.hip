@@ -30,11 +30,6 @@ constexpr int TILE_LDS = TILE_PIECES * 256;      // floats reserved per LDS buff
 constexpr int KG = 25;                           // groups of 8 k-values (200 = 196 + 4 zeros)
 constexpr int KCH = 5;                           // accumulation chunks (5 groups = 40 terms each)
 
-__device__ __forceinline__ void glds16s(const float* gsrc, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 // XCD-aware, bijective block remap: the blocks an XCD receives (bid % 8 == xcd) form one contiguous
 // range of logical ids, so blocks that stream the same key chunk share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
