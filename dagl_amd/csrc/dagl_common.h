@@ -237,6 +237,22 @@ int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg
 int launch_row_scan(hipStream_t s, int n_rows, const int32_t* deg, int64_t* row_off);
 int topk_slots(int k);
 
+// dense adaptive neighbourhoods (dense.hip)
+struct DenseArgs {
+    int B; Grid g;
+    const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
+    const float* mt; const float* bs;                          // [B,L] mean*thr, bias
+    const float* smax;                                         // [B,L] row maximum of the bf16-screened scores
+    const float* b2p;                                          // padded NHWC value map
+    int splits, tiles_per_split, n_tiles, tiles_per_row;       // 32-key tiles (row aligned), key ranges per 64-query group
+    float* part_acc; float* part_m; double* part_z; int32_t* part_deg;   // per (split, query) partial results
+};
+size_t dense_workspace_bytes(int B, const Grid& g);
+int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);
+int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
+                        const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
+                        float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */);
+
 // graph-core backward (backward.hip)
 struct BwdArgs {
     int B; Grid g; int mode, width;

@@ -1,0 +1,321 @@
+// Dense neighbourhoods of the adaptive mask (DN_Gray/model/dagl.py:250-264 when most keys pass, e.g. with
+// default-initialised thr/bias heads ~95 % of them): per-query neighbour lists stop making sense, so this path is the
+// reference's dense formulation, streamed -- S = Wq X^T, mask, softmax over ALL keys, A V -- in one pass over the keys
+// nothing of size L x N ever stored.
+//
+//   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32), one wave per SIMD
+//   per 32-key tile (keys = 32 consecutive pixels of one image row):
+//     S      v_mfma_f32_32x32x2_f32, keys x queries, 196-term fp32 fma chains in 5 chunks (as select.hip): a lane ends up
+//            with 16 scores of ONE query;
+//     l, p   the reference's fp32 expression order for m and l = (S m) 10; masked keys keep l = 0 and count in the
+//            denominator (no renormalisation), keys outside the image row count nowhere; p = e^(l - M') with M' an UPPER
+//            bound of the row maximum known before the pass (from the bf16 screen's row maxima, dense_rowmax_kernel): the
+//            softmax is shift invariant, M' is within ~1 % of the true maximum, so nothing is ever rescaled and the
+//            accumulators live in the matrix cores' registers untouched;
+//     A V    v_mfma_f32_32x32x2_f32 again, out^T[col][q] += V[key][col] p[q][key]: the B operand (p) is the lane's own
+//            score registers, the A operand one float of the value-map region staged in LDS (7 rows x 38 pixels x 16
+//            channels: every value is reused by 49 patch positions), so queries stay along lanes and the rescale is a
+//            per-lane scalar.  fp32 throughout: the result carries the reference's own rounding class.
+//   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial (max, sums, rows).
+//
+// Cost: (100 + 400 [+100 redundant]) MFMAs of 64 cycles per 32 x 32 (key, query) tile: ~4 ms per head at 256^2 against
+// 56 ms through CSR lists (and ~10 s for the reference on the host).
+#include "dagl_common.h"
+
+namespace dagl {
+
+constexpr int DN_XT = 26 * 256;                       // floats of one staged key-feature tile (32 rows x 204, 26 KiB pieces)
+constexpr int DN_RROW = 38 * CH;                      // floats per staged value-map row: 38 pixels x 16 channels
+constexpr int DN_REG = 17 * 256;                      // floats reserved for the 7-row region (7 x 608 = 4256 <= 4352)
+constexpr int DN_STAGE = DN_XT + DN_REG;              // 11008 floats = 43 KiB
+constexpr int DN_KG = 25, DN_KCH = 5;                 // K groups of 8 (200 = 196 + 4 zeros), accumulation chunks
+constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
+constexpr int DN_CT0 = 13;                            // tiles of column half 0 (half 1: 12)
+
+__device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
+    const float m = (s - mtq) + bsq;                  // same expression order as dagl.py:256
+    pass = m > 0.f;
+    return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;
+}
+
+// column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes i >= 16 ("second") take the odd tap (tap 49 does not exist:
+// those lanes of tile 24 recompute tap 48 and their columns are never stored)
+template <int HALF>
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const float* reg, const float (&pv)[16], bool second) {
+#pragma unroll
+    for (int t = 0; t < DN_CT0; ++t) {
+        constexpr int dummy = 0; (void)dummy;
+        const int ct = HALF * DN_CT0 + t;                                    // compile-time after unrolling
+        if (ct >= DN_CT) continue;
+        const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
+        const int offa = (tapa / KS) * DN_RROW + (tapa % KS) * CH;
+        const int offb = (tapb / KS) * DN_RROW + (tapb % KS) * CH;
+        const float* vp = reg + (second ? offb : offa);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = vp[((r & 3) + 8 * (r >> 2)) * CH];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pv[r], acc[t], 0, 0, 0);
+        }
+        // keep the scheduler from hoisting the value loads of ALL tiles above the first MFMA (208 more live registers on
+        // top of 208 accumulators and 100 query registers: it spills); two tiles in flight are enough to cover the LDS latency
+        if (t & 1) asm volatile("" ::: "memory");
+    }
+}
+
+template <int HALF>
+__device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po, int h) {
+#pragma unroll
+    for (int t = 0; t < DN_CT0; ++t) {
+        const int ct = HALF * DN_CT0 + t;
+        if (ct >= DN_CT) continue;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int col = 32 * ct + 8 * gq + 4 * h;                        // acc[t][4 gq + u] = out[q][col + u]
+            if (col < P)
+                *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[2][DN_STAGE];                 // 86 KiB
+    __shared__ __attribute__((aligned(16))) float sq[64 * DS];                     // 51 KiB: the block's 64 query rows
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const Grid& g = a.g;
+    const int n_qblocks = (g.L + 63) / 64;
+    const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
+    const int qt = wave >> 1, half = wave & 1;
+    const int tile0 = split * a.tiles_per_split;
+    int tile1 = tile0 + a.tiles_per_split;
+    if (tile1 > a.n_tiles) tile1 = a.n_tiles;
+
+    const int q = qb * 64 + qt * 32 + i;
+    const bool qvalid = q < g.L;
+    const int qc = qvalid ? q : g.L - 1;
+    const size_t qlin = (size_t)b * g.L + qc;
+
+    // the 64 query rows -> LDS (feature rows are 816 B: whole float4s; rows past L are the zero guard rows)
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.wq + ((size_t)b * a.rows_q + (size_t)qb * 64) * DS);
+        for (int e = tid; e < 64 * DS / 4; e += 256) reinterpret_cast<float4*>(sq)[e] = src[e];
+    }
+    const float* qrow = sq + (qt * 32 + i) * DS + 4 * h;       // B operand of the score MFMAs: Wq[q][8t+4h .. +3]
+    const float mtq = a.mt[qlin], bsq = a.bs[qlin];
+
+    f32x16 acc[DN_CT0];
+#pragma unroll
+    for (int t = 0; t < DN_CT0; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
+    float m_run;
+    {
+        const float sub = a.smax[qlin] * (1.0f / (1.0f - 0.004f)) * (1.0f + 1e-6f);
+        bool ps;
+        const float lub = dn_logit(sub, mtq, bsq, ps);
+        m_run = fmaxf(lub, 0.f);                       // masked keys have l = 0
+    }
+    double z_run = 0.0, zp_run = 0.0;                  // sum over all keys / over passing keys of e^(l - m_run)
+    int deg = 0;
+
+    const float* xb = a.x + (size_t)b * a.rows_x * DS;
+    const float* vb = a.b2p + (size_t)b * g.Hp * g.Wp * CH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
+    auto stage = [&](int tile, int buf) {
+        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
+        const unsigned dst = lds0 + (unsigned)buf * (DN_STAGE * 4);
+        const float* xs = xb + ((size_t)jy * g.W + jx0) * DS;
+        // 26 feature pieces + 7 rows x 3 region pieces = 47 one-KiB pieces, round-robin over the 4 waves
+        for (int p = wave; p < 47; p += 4) {
+            if (p < 26) {
+                glds16_asm(xs + p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+            } else {
+                const int rr = (p - 26) / 3, pc = (p - 26) - rr * 3;
+                int px = 16 * pc + (lane >> 2);
+                const bool on = px < 38;
+                const int lim = g.Wp - 1 - jx0;                              // stay inside the map row
+                if (px > lim) px = lim;
+                const float* src = vb + (((size_t)(jy + rr) * g.Wp + jx0 + px) * CH + 4 * (lane & 3));
+                if (on) glds16_asm(src, __builtin_amdgcn_readfirstlane(dst + (DN_XT + rr * DN_RROW) * 4 + pc * 1024));
+            }
+        }
+    };
+
+    // per-lane float offsets of the value operand inside the region: column tile t = taps (2t, 2t+1), lane i < 16 takes
+    // the first; tap -> (kh, kw) -> kh * 608 + kw * 16; + channel; + 4 h pixels (the lane half's key offset)
+    const int vlane = (i & 15) + 4 * h * CH;
+    const bool second = i >= 16;
+
+    if (tile0 < tile1) stage(tile0, 0);
+    dma_wait_all();
+    __syncthreads();
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        if (tile + 1 < tile1) stage(tile + 1, cur ^ 1);
+        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
+
+        // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const float* kp = &sm[cur][i * DS + 4 * h];
+#pragma unroll
+        for (int c = 0; c < DN_KCH; ++c) {
+            f32x16 part;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+            for (int t = c * (DN_KG / DN_KCH); t < (c + 1) * (DN_KG / DN_KCH); ++t) {
+                const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * t);
+                const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * t);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qv.x, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qv.y, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qv.z, part, 0, 0, 0);
+                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv.w, part, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] += part[r];
+        }
+        // ---- logits, weights -----------------------------------------------------------------------
+        float lg[16];
+        unsigned passmask = 0, validmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mkey = (r & 3) + 8 * (r >> 2) + 4 * h;                 // sc[r] = S[key jx0 + mkey][query q]
+            const bool valid = jx0 + mkey < g.W;
+            bool pass;
+            lg[r] = dn_logit(sc[r], mtq, bsq, pass);
+            validmask |= (valid ? 1u : 0u) << r;
+            passmask |= ((valid && pass) ? 1u : 0u) << r;
+        }
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = (validmask >> r) & 1u, pass = (passmask >> r) & 1u;
+            const float p = valid ? expf(fminf(lg[r] - m_run, 0.f)) : 0.f;     // (the bound holds; the clamp is a seat belt)
+            z_run += (double)p;
+            if (pass) { zp_run += (double)p; ++deg; }
+            pv[r] = pass ? p : 0.f;
+        }
+        // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
+        const float* reg = &sm[cur][DN_XT] + vlane;
+        if (half == 0) dn_pv<0>(acc, reg, pv, second); else dn_pv<1>(acc, reg, pv, second);
+        dma_wait_all();
+        __syncthreads();
+    }
+
+    // ---- partial results of this key range ------------------------------------------------------------------------------
+    const size_t prow = ((size_t)split * a.B + b) * g.L + qc;
+    if (qvalid) {
+        const double z2 = z_run + __shfl_xor(z_run, 32), zp2 = zp_run + __shfl_xor(zp_run, 32);
+        const int d2 = deg + __shfl_xor(deg, 32);
+        if (half == 0 && h == 0) {
+            a.part_m[prow] = m_run;
+            a.part_z[2 * prow] = z2; a.part_z[2 * prow + 1] = zp2;
+            a.part_deg[prow] = d2;
+        }
+        float* po = a.part_acc + prow * P;
+        if (half == 0) dn_store<0>(acc, po, h); else dn_store<1>(acc, po, h);
+    } else {
+        (void)__shfl_xor(z_run, 32); (void)__shfl_xor(zp_run, 32); (void)__shfl_xor(deg, 32);
+    }
+}
+
+// merge the key-range partials of a query: M = max M_s, Z = sum Z_s e^(M_s - M), agg = sum acc_s e^(M_s - M) / Z
+__global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* __restrict__ agg, int32_t* __restrict__ deg_out,
+                                                            float* __restrict__ rowsum_out, int64_t* __restrict__ stats) {
+    const size_t ql = blockIdx.x;                                            // (b, q) flattened
+    const size_t nq = (size_t)a.B * a.g.L;
+    float M = -__builtin_inff();
+    for (int s = 0; s < a.splits; ++s) M = fmaxf(M, a.part_m[s * nq + ql]);
+    double Z = 0.0, Zp = 0.0;
+    int deg = 0;
+    float w[16];
+    for (int s = 0; s < a.splits; ++s) {
+        const float ms = a.part_m[s * nq + ql];
+        const float ws = (ms == -__builtin_inff()) ? 0.f : expf(ms - M);
+        w[s] = ws;
+        Z += a.part_z[2 * (s * nq + ql)] * (double)ws;
+        Zp += a.part_z[2 * (s * nq + ql) + 1] * (double)ws;
+        deg += a.part_deg[s * nq + ql];
+    }
+    const float invz = (float)(1.0 / Z);
+    for (int c = threadIdx.x; c < P; c += 256) {
+        float t = 0.f;
+        for (int s = 0; s < a.splits; ++s) t += a.part_acc[(s * nq + ql) * P + c] * w[s];
+        agg[ql * P + c] = t * invz;
+    }
+    if (threadIdx.x == 0) {
+        if (deg_out) deg_out[ql] = deg;
+        if (rowsum_out) rowsum_out[ql] = (float)(Zp / Z);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&stats[0]), (unsigned long long)deg);
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[1]), (unsigned long long)deg);
+    }
+}
+
+// row maximum of the screened scores: gmax holds, per query, the 4 largest values of each of its G/4 scan segments
+__global__ void dense_rowmax_kernel(size_t n_rows, int G, const float* __restrict__ gmax, float* __restrict__ smax) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float m = 0.f;
+    for (int t = lane; t < G; t += 64) m = fmaxf(m, gmax[row * G + t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) smax[row] = m;
+}
+
+int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax) {
+    hipLaunchKernelGGL(dense_rowmax_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, n_rows, G, gmax, smax);
+    DAGL_LAUNCH_CHECK("dense_rowmax_kernel");
+    return DAGL_OK;
+}
+
+int dense_splits(int B, const Grid& g) {                                     // blocks = 64-query groups x splits ~ one per CU
+    const int n_qblocks = (g.L + 63) / 64;
+    int s = (256 + n_qblocks * B - 1) / (n_qblocks * B);
+    const int n_tiles = g.H * ((g.W + KT - 1) / KT);
+    if (s > n_tiles) s = n_tiles;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return s;
+}
+
+size_t dense_workspace_bytes(int B, const Grid& g) {
+    const size_t rows = (size_t)dense_splits(B, g) * B * g.L;
+    return align_up(rows * P * sizeof(float), 256) + align_up(rows * sizeof(float), 256) +
+           align_up(rows * 2 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256);
+}
+
+int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
+                        const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
+                        float* rowsum_out, int64_t* stats) {
+    DenseArgs a;
+    a.smax = smax;
+    a.B = B; a.g = g; a.wq = wq; a.x = x; a.rows_q = feat_rows(g.L); a.rows_x = feat_rows(g.N);
+    a.mt = mt; a.bs = bs; a.b2p = b2p;
+    a.splits = dense_splits(B, g);
+    a.tiles_per_row = (g.W + KT - 1) / KT;
+    a.n_tiles = g.H * a.tiles_per_row;
+    a.tiles_per_split = (a.n_tiles + a.splits - 1) / a.splits;
+    a.splits = (a.n_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    const size_t rows = (size_t)dense_splits(B, g) * B * g.L;                // carve with the planned (upper) split count
+    char* p = static_cast<char*>(ws);
+    a.part_acc = reinterpret_cast<float*>(p); p += align_up(rows * P * sizeof(float), 256);
+    a.part_m = reinterpret_cast<float*>(p); p += align_up(rows * sizeof(float), 256);
+    a.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 2 * sizeof(double), 256);
+    a.part_deg = reinterpret_cast<int32_t*>(p);
+    const int n_qblocks = (g.L + 63) / 64;
+    hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("dense_attend_kernel");
+    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)((size_t)B * g.L)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, stats);
+    DAGL_LAUNCH_CHECK("dense_combine_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl
