@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool valid = (validmask >> r) & 1u, pass = (passmask >> r) & 1u;
-            const float p = valid ? expf(fminf(lg[r] - m_run, 0.f)) : 0.f;     // (the bound holds; the clamp is a seat belt)
+            const float p = valid ? __expf(fminf(lg[r] - m_run, 0.f)) : 0.f;   // (the bound holds; the clamp is a seat belt)
             z_run += (double)p;
             if (pass) { zp_run += (double)p; ++deg; }
             pv[r] = pass ? p : 0.f;
