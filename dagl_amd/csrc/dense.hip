@@ -18,7 +18,7 @@
 //            per-lane scalar.  fp32 throughout: the result carries the reference's own rounding class.
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial (max, sums, rows).
 //
-// Cost: (100 + 400 [+100 redundant]) MFMAs of 64 cycles per 32 x 32 (key, query) tile: ~4 ms per head at 256^2 against
+// Cost: 100 + 400 MFMAs of 64 cycles per 32 x 32 (key, query) tile: ~4 ms of matrix time per head at 256^2 against
 // 56 ms through CSR lists (and ~10 s for the reference on the host).
 #include "dagl_common.h"
 
@@ -80,6 +80,7 @@ __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po,
 __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[2][DN_STAGE];                 // 86 KiB
     __shared__ __attribute__((aligned(16))) float sq[64 * DS];                     // 51 KiB: the block's 64 query rows
+    __shared__ float sx[2 * 2 * 16 * 64];                                          // 16 KiB: partial scores exchanged per tile
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -160,12 +161,15 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
 
         // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
-        f32x16 sc;
+        // the two waves of a query tile (column halves) split the 196-term sum: chunks 0-2 / chunks 3-4 of 40 terms, exchanged
+        // through LDS and added in chunk order by both (identical scores in both waves, no redundant matrix work)
+        f32x16 mine;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
         const float* kp = &sm[cur][i * DS + 4 * h];
 #pragma unroll
         for (int c = 0; c < DN_KCH; ++c) {
+            if ((c < 3) != (half == 0)) continue;                            // wave-uniform
             f32x16 part;
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = 0.f;
@@ -179,8 +183,17 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
                 part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv.w, part, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] += part[r];
+            for (int r = 0; r < 16; ++r) mine[r] += part[r];
         }
+        float* ex = sx + ((qt * 2 + half) * 16) * 64 + lane;                  // [query tile][half][register][lane]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[r * 64] = mine[r];
+        __syncthreads();
+        const float* e0 = sx + ((qt * 2 + 0) * 16) * 64 + lane;
+        const float* e1 = sx + ((qt * 2 + 1) * 16) * 64 + lane;
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = e0[r * 64] + e1[r * 64];
         // ---- logits, weights -----------------------------------------------------------------------
         float lg[16];
         unsigned passmask = 0, validmask = 0;
