@@ -82,7 +82,8 @@ typedef struct dagl_ce_info {
                                  read it)                                                             */
     int32_t max_degree;       /* largest per-query degree                                           */
     int32_t path;             /* 0 = fp32 scan, single-pass lists, 1 = fp32 scan, two-pass CSR (some degree >
-                                 FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine */
+                                 FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine,
+                                 4 = dense neighbourhoods: streamed dense formulation (no lists)        */
 } dagl_ce_info;
 
 /* ---- library ------------------------------------------------------------------------------- */
