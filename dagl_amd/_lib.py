@@ -24,6 +24,7 @@ N_STAGES = 8
 STAGE_NAMES = ("layout", "project", "thresholds", "screen_sample", "select", "edge_softmax", "gather", "fold")
 FLAG_EXACT_SCAN = 0x100
 FLAG_WEIGHTS_PACKED = 0x200
+FLAG_DENSE_HINT = 0x400
 
 
 class DaglError(RuntimeError):

@@ -93,6 +93,8 @@ class CE(nn.Module):
         self._ws = ops.Workspace()
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
+        self._dense_hint = False       # the last adaptive call ended in the dense formulation: start there next time
+        self._dense_calls = 0
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
 
@@ -155,9 +157,19 @@ class CE(nn.Module):
         key = (tuple(b.shape), self.select_mode, self.select_k, self.scan,
                tuple((params[n].data_ptr(), params[n]._version) for n in ("fc1.0.weight", "fc2.0.weight")),
                self._ws.buf.data_ptr() if self._ws.buf is not None else 0)
+        # dense regime: the edge statistics (and with them a host synchronisation) are only fetched every 16th call, to
+        # notice when the neighbourhoods have become sparse again
+        hint = self._dense_hint and self.select_mode == "adaptive" and self.scan != "exact"
+        self._dense_calls = self._dense_calls + 1 if hint else 0
+        want_info = (not hint) or (self._dense_calls % 16 == 1) or self.profile is not None
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=self.select_k,
                                          workspace=self._ws, profile=self.profile,
-                                         exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key))
+                                         exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
+                                         dense_hint=hint, want_info=want_info)
         self._pack_key = key[:-1] + (self._ws.buf.data_ptr(),)
-        self.last_info = info
+        if info is not None:
+            self.last_info = info
+            if self.select_mode == "adaptive":
+                n_pairs = b.shape[0] * (-(-b.shape[2] // 4)) * (-(-b.shape[3] // 4)) * b.shape[2] * b.shape[3]
+                self._dense_hint = info["path"] == 4 and info["total_edges"] > 0.08 * n_pairs
         return out if in_dtype == torch.float32 else out.to(in_dtype)

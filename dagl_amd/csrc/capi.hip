@@ -83,7 +83,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
@@ -402,6 +402,48 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.cand_val = at<float>(ws, p.o_scandv);
         redo = at<int32_t>(ws, p.o_redo);
         { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
+        // most queries keep more keys than the screen has candidate slots for: the dense regime.  Lists are pointless
+        // there; stream the dense formulation instead (dense.hip).  Reached after the screen found out, or directly when
+        // the caller passes DAGL_FLAG_DENSE_HINT (its previous call on this module ended here): always correct, only
+        // slower than the lists when the neighbourhoods are in fact sparse.
+        auto run_dense = [&]() -> int {
+            size_t off = p.o_end;
+            const size_t o_dn = carve(off, dense_workspace_bytes(B, g));
+            if (info) { info->required_bytes = (int64_t)off; info->path = 4; }
+            if (core) {
+                if (info) info->required_bytes = -1;
+                set_error("dagl_ce_core_forward: dense neighbourhoods (most queries keep more than %d keys) have no backward in this build",
+                          DAGL_FAST_CAP);
+                return DAGL_ERR_UNSUPPORTED;
+            }
+            if (ws_bytes < off) {
+                set_error("dagl_ce_forward: dense neighbourhoods need workspace %zu B, have %zu B", off, ws_bytes);
+                return DAGL_ERR_WORKSPACE;
+            }
+            DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), s));
+            prof_mark(prof, s, 6);
+            // row maxima of the screened scores (full bf16 scan, ~0.1 ms at 256^2): the softmax's shift, known up front
+            sc.sample = 1;
+            if ((rc = launch_screen(s, sc, 0))) return rc;
+            float* smax = at<float>(ws, p.o_theta);
+            if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
+            if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats))) return rc;
+            prof_mark(prof, s, 7);
+            if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if ((rc = launch_fold(s, B, g, agg, out, heads))) return rc;
+            prof_mark(prof, s, 8);
+            if (info) {
+                int64_t hd[2] = {0, 0};
+                if ((rc = read_back(s, stats, 2, hd))) return rc;
+                info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
+            }
+            if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
+            return DAGL_OK;
+        };
+        if (mode == DAGL_MODE_ADAPTIVE && (mode_flags & DAGL_FLAG_DENSE_HINT) && !core) {
+            prof_mark(prof, s, 3); prof_mark(prof, s, 4); prof_mark(prof, s, 5);
+            return run_dense();
+        }
         prof_mark(prof, s, 3);
         if (mode == DAGL_MODE_TOPK) {
             if ((rc = launch_screen(s, sc, 0))) return rc;
@@ -435,42 +477,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
                 return DAGL_OK;
             }
-            if (hs[2] * 2 > (int64_t)BL) {
-                // most queries keep more keys than the screen has candidate slots for: the dense regime.  Lists are
-                // pointless there; stream the dense formulation instead (dense.hip)
-                size_t off = p.o_end;
-                const size_t o_dn = carve(off, dense_workspace_bytes(B, g));
-                if (info) { info->required_bytes = (int64_t)off; info->path = 4; }
-                if (core) {
-                    if (info) info->required_bytes = -1;
-                    set_error("dagl_ce_core_forward: dense neighbourhoods (%lld of %zu queries keep more than %d keys) have no backward in this build",
-                              (long long)hs[2], BL, DAGL_FAST_CAP);
-                    return DAGL_ERR_UNSUPPORTED;
-                }
-                if (ws_bytes < off) {
-                    set_error("dagl_ce_forward: dense neighbourhoods need workspace %zu B, have %zu B", off, ws_bytes);
-                    return DAGL_ERR_WORKSPACE;
-                }
-                DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), s));
-                prof_mark(prof, s, 6);
-                // row maxima of the screened scores (full bf16 scan, ~0.1 ms at 256^2): the softmax's shift, known up front
-                sc.sample = 1;
-                if ((rc = launch_screen(s, sc, 0))) return rc;
-                float* smax = at<float>(ws, p.o_theta);
-                if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
-                if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats))) return rc;
-                prof_mark(prof, s, 7);
-                if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-                if ((rc = launch_fold(s, B, g, agg, out, heads))) return rc;
-                prof_mark(prof, s, 8);
-                if (info) {
-                    int64_t hd[2] = {0, 0};
-                    if ((rc = read_back(s, stats, 2, hd))) return rc;
-                    info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
-                }
-                if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
-                return DAGL_OK;
-            }
+            if (hs[2] * 2 > (int64_t)BL) return run_dense();
             need_exact = true;                                   // redo everything with the fp32 scan (CSR capable)
         } else {
             // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it

@@ -50,13 +50,14 @@ class CES(nn.Module):
         from . import ops
         self._ws = {1: ops.Workspace(), 2: ops.Workspace(), 3: ops.Workspace()}     # one per stage: packed weights persist
         self._pack_key = {1: None, 2: None, 3: None}
+        self._skip_fused = {1: 0, 2: 0, 3: 0}     # calls for which a stage stays on the per-head path after it met dense masks
 
     def _stage(self, s, x):
         heads = [getattr(self, f"c{s}_{h}") for h in (1, 2, 3, 4)]
         mix = getattr(self, f"c{s}_c")
         if self.fuse_stage and all(isinstance(hd, CE) for hd in heads) and x.is_cuda and x.dtype == torch.float32 \
                 and not torch.is_grad_enabled() and len({(hd.select_mode, hd.select_k, hd.scan) for hd in heads}) == 1 \
-                and heads[0].scan == "screened":
+                and heads[0].scan == "screened" and self._skip_fused[s] == 0:
             # the four heads share x: one launch set with the heads as a batch dimension + the 1x1 mix + residual
             from . import ops
             prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
@@ -72,6 +73,9 @@ class CES(nn.Module):
             self.last_info = info
             if out is not None:
                 return out
+            self._skip_fused[s] = 16                        # dense masks: the heads' own dense path serves the next calls
+        elif self._skip_fused[s] > 0:
+            self._skip_fused[s] -= 1
         outs = [hd(x) for hd in heads]                      # dense adaptive neighbourhoods / foreign heads
         return mix(torch.cat(outs, dim=1)) + x
 

@@ -254,9 +254,12 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
 
 
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
-                     profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False):
+                     profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False,
+                     dense_hint: bool = False, want_info: bool = True):
     """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
-    state_dict names to contiguous fp32 GPU tensors.  Returns (out, info)."""
+    state_dict names to contiguous fp32 GPU tensors.  Returns (out, info).  ``dense_hint``: go straight to the streamed
+    dense formulation (adaptive mode; same result, see DAGL_FLAG_DENSE_HINT); with ``want_info=False`` that path does
+    not read its edge statistics back (no host synchronisation) and info is None."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -278,22 +281,32 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
         check(-1, "dagl_ce_workspace_bytes")
     if weights_packed and ws.buf is not None and ws.buf.numel() >= need + 256 and ws.buf.device == x.device:
         mode_flags |= _lib.FLAG_WEIGHTS_PACKED           # same buffer as last time: the packed weights are still in it
+    if dense_hint and mode == "adaptive" and not exact_scan:
+        mode_flags |= _lib.FLAG_DENSE_HINT
+        if ws.buf is not None:
+            need = max(need, ws.buf.numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
+    quiet = dense_hint and not want_info
     out = torch.empty(B, 16, H, W, device=x.device, dtype=torch.float32)
     info = _lib.CeInfo()
     rc = 0
-    for _attempt in range(2):
+    for _attempt in range(3):
         buf = ws.get(need, x.device)
         base = buf.data_ptr()
         aligned = (base + 255) // 256 * 256
         rc = lib.dagl_ce_forward_fused(_stream(), B, H, W, x.data_ptr(), *ptrs, mode_flags, int(k), out.data_ptr(),
-                                       aligned, buf.numel() - (aligned - base), C.byref(info),
+                                       aligned, buf.numel() - (aligned - base), None if quiet else C.byref(info),
                                        profile._h if profile is not None else None)
+        if rc == _lib.ERR_WORKSPACE and quiet:
+            quiet = False                                # ask again, this time for the size
+            continue
         if rc == _lib.ERR_WORKSPACE and info.required_bytes > need:
             need = int(info.required_bytes)
             mode_flags &= ~_lib.FLAG_WEIGHTS_PACKED      # the buffer is about to be replaced
             continue
         break
     check(rc, "dagl_ce_forward_fused")
+    if quiet:
+        return out, None
     return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
                      max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
 

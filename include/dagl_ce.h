@@ -60,6 +60,10 @@ extern "C" {
  * weights, the zero borders of the padded maps, the zero guard rows of the feature matrices) instead of rebuilding
  * it: three launches fewer per forward (inference loops)                                                    */
 #define DAGL_FLAG_WEIGHTS_PACKED 0x200
+/* OR-ed into `mode` (adaptive mode, >= 2048 keys): expect dense neighbourhoods -- go straight to the streamed dense
+ * formulation (info->path 4) instead of trying per-query lists first.  A performance hint only: the result is the
+ * same either way; info->total_edges tells the caller whether the hint still pays                              */
+#define DAGL_FLAG_DENSE_HINT     0x400
 
 #define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
 #define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path            */

@@ -155,6 +155,34 @@ def test_dense_formulation_equals_csr_lists(B, H, W):
         assert normwise(o_c.cpu().numpy(), ref64) <= TOL_OUT
 
 
+def test_dense_hint_skips_the_list_attempt_and_recovers():
+    """After a call that ended in the dense formulation the module starts there (no screen / refine / read-back first);
+    the result is the same, and sparse inputs switch the hint off again at the next statistics read-back."""
+    from dagl_amd.synth import make_ce_params, make_features
+    dense_p = {n: torch.from_numpy(a) for n, a in make_ce_params(54, variant="default").items()}
+    x = torch.from_numpy(make_features(54, 2, 64, 72, 72)).to(_dev())
+    ce = _module(dense_p, "adaptive", 0)
+    with torch.no_grad():
+        first = ce(x)
+        assert ce.last_info["path"] == 4 and ce._dense_hint
+        second = ce(x)                                     # hinted, with statistics
+        assert ce.last_info["path"] == 4
+        third = ce(x)                                      # hinted, no read-back
+        assert torch.equal(first, second) and torch.equal(first, third)
+        # same module, sparse weights: the hinted dense pass still gives the right answer, then the hint goes away
+        sparse_p = {n: torch.from_numpy(a) for n, a in make_ce_params(54, variant="sparse", sparse_gain=2.6).items()}
+        ce.load_state_dict(sparse_p, strict=True)
+        ce._dense_calls = 0                                # next call fetches statistics
+        ref = _module(sparse_p, "adaptive", 0)
+        want = ref(x)
+        got = ce(x)
+        assert ce.last_info["path"] == 4 and not ce._dense_hint
+        assert normwise(got.cpu().numpy(), want.cpu().numpy()) <= 5e-5
+        again = ce(x)
+        assert ce.last_info["path"] == 3
+        assert torch.equal(again, want)
+
+
 def test_adaptive_topk_mode_matches_oracle():
     from oracle.ce_oracle import ce_forward_oracle
     path = [p for p in CASES if "gray_sparse_64x64" in p][0]
