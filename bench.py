@@ -180,7 +180,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DAGL_BENCH_FORCE_DIST"):          # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: used for the barriers/max only

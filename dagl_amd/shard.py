@@ -31,7 +31,7 @@ def rank_seed(seed: int, rank: int) -> int:
 
 def reduce_max_seconds(seconds: float, dist=None, device: Optional[torch.device] = None) -> float:
     """MAX over ranks of a wall-clock duration (all_reduce on the job's backend; identity without a group)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
