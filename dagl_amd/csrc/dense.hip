@@ -240,32 +240,50 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
 }
 
 // merge the key-range partials of a query: M = max M_s, Z = sum Z_s e^(M_s - M), agg = sum acc_s e^(M_s - M) / Z
+// (all partials of a query share one shift today, so the weights are 1; kept general).  One wave per query, float4 columns.
 __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* __restrict__ agg, int32_t* __restrict__ deg_out,
                                                             float* __restrict__ rowsum_out, int64_t* __restrict__ stats) {
-    const size_t ql = blockIdx.x;                                            // (b, q) flattened
+    const int lane = threadIdx.x & 63;
     const size_t nq = (size_t)a.B * a.g.L;
-    float M = -__builtin_inff();
-    for (int s = 0; s < a.splits; ++s) M = fmaxf(M, a.part_m[s * nq + ql]);
-    double Z = 0.0, Zp = 0.0;
-    int deg = 0;
-    float w[16];
-    for (int s = 0; s < a.splits; ++s) {
-        const float ms = a.part_m[s * nq + ql];
-        const float ws = (ms == -__builtin_inff()) ? 0.f : expf(ms - M);
-        w[s] = ws;
-        Z += a.part_z[2 * (s * nq + ql)] * (double)ws;
-        Zp += a.part_z[2 * (s * nq + ql) + 1] * (double)ws;
-        deg += a.part_deg[s * nq + ql];
+    const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);           // (b, q) flattened
+    if (ql >= nq) return;
+    // lane s < splits holds partial s's scalars
+    const bool has = lane < a.splits;
+    const float ms = has ? a.part_m[lane * nq + ql] : -__builtin_inff();
+    float M = ms;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+    const float wl = (has && ms != -__builtin_inff()) ? __expf(ms - M) : 0.f;
+    double z = has ? a.part_z[2 * (lane * nq + ql)] * (double)wl : 0.0;
+    double zp = has ? a.part_z[2 * (lane * nq + ql) + 1] * (double)wl : 0.0;
+    int deg = has ? a.part_deg[lane * nq + ql] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); zp += __shfl_xor(zp, o); deg += __shfl_xor(deg, o); }
+    const float invz = (float)(1.0 / z);
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.splits; ++s) {                                      // fixed order
+        const float ws = __shfl(wl, s);
+        const float4* row = reinterpret_cast<const float4*>(a.part_acc + (s * nq + ql) * P);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c4 = lane + 64 * u;
+            if (c4 < P / 4) {
+                const float4 v = row[c4];
+                acc[u].x += v.x * ws; acc[u].y += v.y * ws; acc[u].z += v.z * ws; acc[u].w += v.w * ws;
+            }
+        }
     }
-    const float invz = (float)(1.0 / Z);
-    for (int c = threadIdx.x; c < P; c += 256) {
-        float t = 0.f;
-        for (int s = 0; s < a.splits; ++s) t += a.part_acc[(s * nq + ql) * P + c] * w[s];
-        agg[ql * P + c] = t * invz;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c4 = lane + 64 * u;
+        if (c4 < P / 4)
+            reinterpret_cast<float4*>(agg + ql * P)[c4] = make_float4(acc[u].x * invz, acc[u].y * invz, acc[u].z * invz, acc[u].w * invz);
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         if (deg_out) deg_out[ql] = deg;
-        if (rowsum_out) rowsum_out[ql] = (float)(Zp / Z);
+        if (rowsum_out) rowsum_out[ql] = (float)(zp / z);
         atomicAdd(reinterpret_cast<unsigned long long*>(&stats[0]), (unsigned long long)deg);
         atomicMax(reinterpret_cast<unsigned long long*>(&stats[1]), (unsigned long long)deg);
     }
@@ -326,7 +344,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     const int n_qblocks = (g.L + 63) / 64;
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
-    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)((size_t)B * g.L)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, stats);
+    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, stats);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
     return DAGL_OK;
 }
