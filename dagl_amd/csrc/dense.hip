@@ -307,9 +307,9 @@ int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, 
     return DAGL_OK;
 }
 
-int dense_splits(int B, const Grid& g) {                                     // blocks = 64-query groups x splits ~ one per CU
-    const int n_qblocks = (g.L + 63) / 64;
-    int s = (256 + n_qblocks * B - 1) / (n_qblocks * B);
+int dense_splits(int B, const Grid& g) {                 // blocks = 64-query groups x splits: at most one per CU, ONE round
+    const int n_qblocks = (g.L + 63) / 64;                // (one block per CU is resident: block 257 would wait for a whole block time)
+    int s = 256 / (n_qblocks * B);
     const int n_tiles = g.H * ((g.W + KT - 1) / KT);
     if (s > n_tiles) s = n_tiles;
     if (s > 16) s = 16;
