@@ -1,36 +1,44 @@
 // Dense neighbourhoods of the adaptive mask (DN_Gray/model/dagl.py:250-264 when most keys pass, e.g. with
 // default-initialised thr/bias heads ~95 % of them): per-query neighbour lists stop making sense, so this path is the
-// reference's dense formulation, streamed -- S = Wq X^T, mask, softmax over ALL keys, A V -- in one pass over the keys
+// reference's dense formulation, streamed -- S = Wq X^T, mask, softmax over ALL keys, A V -- in one pass over the keys,
 // nothing of size L x N ever stored.
 //
-//   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32), one wave per SIMD
+//   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32 = two patch taps x 16 channels)
 //   per 32-key tile (keys = 32 consecutive pixels of one image row):
-//     S      v_mfma_f32_32x32x2_f32, keys x queries, 196-term fp32 fma chains in 5 chunks (as select.hip): a lane ends up
-//            with 16 scores of ONE query;
+//     S      v_mfma_f32_32x32x2_f32, keys x queries, 196-term fp32 fma chains in 5 chunks (as select.hip), split between
+//            the two waves of a query tile and exchanged through LDS.  The key rows enter the MFMA in a permuted order so
+//            that a lane ends up with scores of 16 keys of ONE query that are two runs of 8 CONSECUTIVE keys -- exactly the
+//            K-layout of the next MFMA's operand;
 //     l, p   the reference's fp32 expression order for m and l = (S m) 10; masked keys keep l = 0 and count in the
 //            denominator (no renormalisation), keys outside the image row count nowhere; p = e^(l - M') with M' an UPPER
 //            bound of the row maximum known before the pass (from the bf16 screen's row maxima, dense_rowmax_kernel): the
 //            softmax is shift invariant, M' is within ~1 % of the true maximum, so nothing is ever rescaled and the
 //            accumulators live in the matrix cores' registers untouched;
-//     A V    v_mfma_f32_32x32x2_f32 again, out^T[col][q] += V[key][col] p[q][key]: the B operand (p) is the lane's own
-//            score registers, the A operand one float of the value-map region staged in LDS (7 rows x 38 pixels x 16
-//            channels: every value is reused by 49 patch positions), so queries stay along lanes and the rescale is a
-//            per-lane scalar.  fp32 throughout: the result carries the reference's own rounding class.
-//   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial (max, sums, rows).
+//     A V    v_mfma_f32_32x32x16_f16 with split operands (2^14 p = hi + lo, 16 v = hi + lo, three products, one fp32
+//            accumulator: the projection's recipe): out^T[col][q] += V[key][col] p[q][key].  B = the lane's own weights,
+//            straight from its registers.  A needs 8 consecutive KEYS of one column, i.e. 8 consecutive pixels of one
+//            channel: the value-map region (7 rows x 38 pixels x 16 channels) is staged PLANAR in LDS as fp16 hi / lo, and a
+//            patch tap's kw shift becomes a 2-byte-granular offset: five dwords are read and funnel-shifted (v_alignbyte).
+//   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
-// Cost: 100 + 400 MFMAs of 64 cycles per 32 x 32 (key, query) tile: ~4 ms of matrix time per head at 256^2 against
-// 56 ms through CSR lists (and ~10 s for the reference on the host).
+// Matrix time per 32 x 32 (key, query) tile: 100 fp32 MFMAs (64 clk) + 150 fp16 MFMAs (32 clk) instead of 500 fp32 ones.
 #include "dagl_common.h"
 
 namespace dagl {
 
+typedef _Float16 dnh8 __attribute__((ext_vector_type(8)));
+typedef unsigned dnu4 __attribute__((ext_vector_type(4)));
+
 constexpr int DN_XT = 26 * 256;                       // floats of one staged key-feature tile (32 rows x 204, 26 KiB pieces)
-constexpr int DN_RROW = 38 * CH;                      // floats per staged value-map row: 38 pixels x 16 channels
-constexpr int DN_REG = 17 * 256;                      // floats reserved for the 7-row region (7 x 608 = 4256 <= 4352)
-constexpr int DN_STAGE = DN_XT + DN_REG;              // 11008 floats = 43 KiB
+constexpr int DN_XW = 48;                             // staged pixels per plane row (38 used; dword reads run to 44)
+constexpr int DN_CSTR = KS * DN_XW + 2;                // halfs per channel plane: 7 rows x 48 + 2 (169 dwords: odd, the 16 channels
+                                                      // of a column tile hit different banks)
+constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
 constexpr int DN_KG = 25, DN_KCH = 5;                 // K groups of 8 (200 = 196 + 4 zeros), accumulation chunks
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
 constexpr int DN_CT0 = 13;                            // tiles of column half 0 (half 1: 12)
+constexpr int DN_NQ4 = (KS * 38 * CH / 4 + 255) / 256;    // float4 loads per thread of one region (1064 float4): 5
+constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
     const float m = (s - mtq) + bsq;                  // same expression order as dagl.py:256
@@ -39,31 +47,45 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
 }
 
 // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes i >= 16 ("second") take the odd tap (tap 49 does not exist:
-// those lanes of tile 24 recompute tap 48 and their columns are never stored)
+// those lanes of tile 24 recompute tap 48 and their columns are never stored).
+// A operand of kblock kb: halfs e = 0..7 = V[key 16 kb + 8 h + e][tap][c] = plane[c][kh][16 kb + 8 h + kw + e]
 template <int HALF>
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const float* reg, const float (&pv)[16], bool second) {
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char* planes, int c, int h, bool second,
+                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2]) {
 #pragma unroll
     for (int t = 0; t < DN_CT0; ++t) {
-        constexpr int dummy = 0; (void)dummy;
         const int ct = HALF * DN_CT0 + t;                                    // compile-time after unrolling
         if (ct >= DN_CT) continue;
         const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
-        const int offa = (tapa / KS) * DN_RROW + (tapa % KS) * CH;
-        const int offb = (tapb / KS) * DN_RROW + (tapb % KS) * CH;
-        const float* vp = reg + (second ? offb : offa);
+        const int kh = second ? tapb / KS : tapa / KS, kw = second ? tapb % KS : tapa % KS;
+        // byte offset of (c, kh, pixel 8 h + kw) inside a part; dword-aligned base + byte shift 0 / 2
+        const int boff = (c * DN_CSTR + kh * DN_XW + 8 * h + kw) * 2;
+        const unsigned char* base = planes + (boff & ~3);
+        const unsigned shift = (unsigned)(boff & 3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = vp[((r & 3) + 8 * (r >> 2)) * CH];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, pv[r], acc[t], 0, 0, 0);
+        for (int kb = 0; kb < 2; ++kb) {
+            dnh8 v_hi, v_lo;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const unsigned* dp = reinterpret_cast<const unsigned*>(base + part * (DN_PLANE_H * 2) + kb * 32);
+                const unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4];
+                dnu4 w;
+                w[0] = __builtin_amdgcn_alignbyte(d1, d0, shift);
+                w[1] = __builtin_amdgcn_alignbyte(d2, d1, shift);
+                w[2] = __builtin_amdgcn_alignbyte(d3, d2, shift);
+                w[3] = __builtin_amdgcn_alignbyte(d4, d3, shift);
+                if (part == 0) v_hi = __builtin_bit_cast(dnh8, w); else v_lo = __builtin_bit_cast(dnh8, w);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[kb], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[kb], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[kb], acc[t], 0, 0, 0);
         }
-        // keep the scheduler from hoisting the value loads of ALL tiles above the first MFMA (208 more live registers on
-        // top of 208 accumulators and 100 query registers: it spills); two tiles in flight are enough to cover the LDS latency
-        if (t & 1) asm volatile("" ::: "memory");
     }
 }
 
 template <int HALF>
 __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po, int h) {
+    constexpr float inv = 1.0f / (DN_PS * DN_VS);
 #pragma unroll
     for (int t = 0; t < DN_CT0; ++t) {
         const int ct = HALF * DN_CT0 + t;
@@ -72,13 +94,15 @@ __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po,
         for (int gq = 0; gq < 4; ++gq) {
             const int col = 32 * ct + 8 * gq + 4 * h;                        // acc[t][4 gq + u] = out[q][col + u]
             if (col < P)
-                *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]);
+                *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
+                                                                   acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2][DN_STAGE];                 // 86 KiB
+    __shared__ __attribute__((aligned(16))) float sm[2][DN_XT];                    // 52 KiB: key-feature tiles (LDS-DMA)
+    __shared__ __attribute__((aligned(16))) unsigned short spl[2 * DN_PLANE_H + 64]; // 21 KiB: value planes hi | lo of ONE tile
     __shared__ __attribute__((aligned(16))) float sq[64 * DS];                     // 51 KiB: the block's 64 query rows
     __shared__ float sx[2 * 2 * 16 * 64];                                          // 16 KiB: partial scores exchanged per tile
     const int tid = threadIdx.x;
@@ -126,39 +150,63 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const float* xb = a.x + (size_t)b * a.rows_x * DS;
     const float* vb = a.b2p + (size_t)b * g.Hp * g.Wp * CH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
-    auto stage = [&](int tile, int buf) {
+    auto stage_x = [&](int tile, int buf) {            // key features: 26 one-KiB pieces by LDS-DMA
         const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
-        const unsigned dst = lds0 + (unsigned)buf * (DN_STAGE * 4);
         const float* xs = xb + ((size_t)jy * g.W + jx0) * DS;
-        // 26 feature pieces + 7 rows x 3 region pieces = 47 one-KiB pieces, round-robin over the 4 waves
-        for (int p = wave; p < 47; p += 4) {
-            if (p < 26) {
-                glds16_asm(xs + p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(dst + p * 1024));
-            } else {
-                const int rr = (p - 26) / 3, pc = (p - 26) - rr * 3;
-                int px = 16 * pc + (lane >> 2);
-                const bool on = px < 38;
-                const int lim = g.Wp - 1 - jx0;                              // stay inside the map row
-                if (px > lim) px = lim;
-                const float* src = vb + (((size_t)(jy + rr) * g.Wp + jx0 + px) * CH + 4 * (lane & 3));
-                if (on) glds16_asm(src, __builtin_amdgcn_readfirstlane(dst + (DN_XT + rr * DN_RROW) * 4 + pc * 1024));
+        for (int p = wave; p < 26; p += 4)
+            glds16_asm(xs + p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (DN_XT * 4) + p * 1024));
+    };
+    // value-map region of a tile: 7 rows x 38 pixels x 16 channels fp32 NHWC -> registers (float4 = 4 channels of a pixel)
+    float4 rv[DN_NQ4];
+    auto load_region = [&](int tile) {
+        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
+        const int lim = g.Wp - 1 - jx0;                                      // stay inside the map row
+#pragma unroll
+        for (int j = 0; j < DN_NQ4; ++j) {
+            int idx = tid + 256 * j;
+            if (idx >= KS * 38 * 4) idx = KS * 38 * 4 - 1;                   // clamped duplicate, dropped at the store
+            const int kh = idx / (38 * 4), rem = idx - kh * (38 * 4);
+            int px = rem >> 2; const int c4 = rem & 3;
+            if (px > lim) px = lim;
+            rv[j] = *reinterpret_cast<const float4*>(vb + ((size_t)(jy + kh) * g.Wp + jx0 + px) * CH + 4 * c4);
+        }
+    };
+    auto store_region = [&]() {                        // -> planar fp16 hi | lo: spl[part][c][kh][px]
+#pragma unroll
+        for (int j = 0; j < DN_NQ4; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx >= KS * 38 * 4) continue;
+            const int kh = idx / (38 * 4), rem = idx - kh * (38 * 4);
+            const int px = rem >> 2, c4 = rem & 3;
+            const float v[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float vs = v[u] * DN_VS;
+                const _Float16 hi = (_Float16)vs;
+                const _Float16 lo = (_Float16)(vs - (float)hi);
+                const int o = (4 * c4 + u) * DN_CSTR + kh * DN_XW + px;
+                spl[o] = __builtin_bit_cast(unsigned short, hi);
+                spl[DN_PLANE_H + o] = __builtin_bit_cast(unsigned short, lo);
             }
         }
     };
 
-    // per-lane float offsets of the value operand inside the region: column tile t = taps (2t, 2t+1), lane i < 16 takes
-    // the first; tap -> (kh, kw) -> kh * 608 + kw * 16; + channel; + 4 h pixels (the lane half's key offset)
-    const int vlane = (i & 15) + 4 * h * CH;
     const bool second = i >= 16;
+    // key row fed to MFMA row rho: bits (a b c dd) -> (a c b dd), so that a lane's registers are two runs of 8 consecutive keys
+    const int prow = (i & 0x13) | ((i & 8) >> 1) | ((i & 4) << 1);
 
-    if (tile0 < tile1) stage(tile0, 0);
+    if (tile0 < tile1) { stage_x(tile0, 0); load_region(tile0); }
+    for (int e = tid; e < (2 * DN_PLANE_H + 64) / 2; e += 256) reinterpret_cast<unsigned*>(spl)[e] = 0u;   // pad pixels stay zero
+    __syncthreads();
+    if (tile0 < tile1) store_region();
     dma_wait_all();
     __syncthreads();
 
     for (int tile = tile0; tile < tile1; ++tile) {
         const int cur = (tile - tile0) & 1;
-        if (tile + 1 < tile1) stage(tile + 1, cur ^ 1);
+        if (tile + 1 < tile1) { stage_x(tile + 1, cur ^ 1); load_region(tile + 1); }
         const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
+        (void)jy;
 
         // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
         // the two waves of a query tile (column halves) split the 196-term sum: chunks 0-2 / chunks 3-4 of 40 terms, exchanged
@@ -166,7 +214,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         f32x16 mine;
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        const float* kp = &sm[cur][i * DS + 4 * h];
+        const float* kp = &sm[cur][prow * DS + 4 * h];
 #pragma unroll
         for (int c = 0; c < DN_KCH; ++c) {
             if ((c < 3) != (half == 0)) continue;                            // wave-uniform
@@ -194,45 +242,43 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         f32x16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = e0[r * 64] + e1[r * 64];
-        // ---- logits, weights -----------------------------------------------------------------------
-        float lg[16];
-        unsigned passmask = 0, validmask = 0;
+        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile -----------------------------
+        dnh8 p_hi[2], p_lo[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int mkey = (r & 3) + 8 * (r >> 2) + 4 * h;                 // sc[r] = S[key jx0 + mkey][query q]
+            const int mkey = 16 * (r >> 3) + 8 * h + (r & 7);
             const bool valid = jx0 + mkey < g.W;
             bool pass;
-            lg[r] = dn_logit(sc[r], mtq, bsq, pass);
-            validmask |= (valid ? 1u : 0u) << r;
-            passmask |= ((valid && pass) ? 1u : 0u) << r;
-        }
-        float pv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool valid = (validmask >> r) & 1u, pass = (passmask >> r) & 1u;
-            const float p = valid ? __expf(fminf(lg[r] - m_run, 0.f)) : 0.f;   // (the bound holds; the clamp is a seat belt)
+            const float l = dn_logit(sc[r], mtq, bsq, pass);
+            const float p = valid ? __expf(fminf(l - m_run, 0.f)) : 0.f;      // (the bound holds; the clamp is a seat belt)
             z_run += (double)p;
+            pass = pass && valid;
             if (pass) { zp_run += (double)p; ++deg; }
-            pv[r] = pass ? p : 0.f;
+            const float ps = pass ? p * DN_PS : 0.f;
+            const _Float16 hi = (_Float16)ps;
+            p_hi[r >> 3][r & 7] = hi;
+            p_lo[r >> 3][r & 7] = (_Float16)(ps - (float)hi);
         }
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
-        const float* reg = &sm[cur][DN_XT] + vlane;
-        if (half == 0) dn_pv<0>(acc, reg, pv, second); else dn_pv<1>(acc, reg, pv, second);
+        const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
+        if (half == 0) dn_pv<0>(acc, planes, i & 15, h, second, p_hi, p_lo); else dn_pv<1>(acc, planes, i & 15, h, second, p_hi, p_lo);
         dma_wait_all();
+        __syncthreads();                                   // everyone is done with this tile's planes and features
+        if (tile + 1 < tile1) store_region();
         __syncthreads();
     }
 
     // ---- partial results of this key range ------------------------------------------------------------------------------
-    const size_t prow = ((size_t)split * a.B + b) * g.L + qc;
+    const size_t orow = ((size_t)split * a.B + b) * g.L + qc;
     if (qvalid) {
         const double z2 = z_run + __shfl_xor(z_run, 32), zp2 = zp_run + __shfl_xor(zp_run, 32);
         const int d2 = deg + __shfl_xor(deg, 32);
         if (half == 0 && h == 0) {
-            a.part_m[prow] = m_run;
-            a.part_z[2 * prow] = z2; a.part_z[2 * prow + 1] = zp2;
-            a.part_deg[prow] = d2;
+            a.part_m[orow] = m_run;
+            a.part_z[2 * orow] = z2; a.part_z[2 * orow + 1] = zp2;
+            a.part_deg[orow] = d2;
         }
-        float* po = a.part_acc + prow * P;
+        float* po = a.part_acc + orow * P;
         if (half == 0) dn_store<0>(acc, po, h); else dn_store<1>(acc, po, h);
     } else {
         (void)__shfl_xor(z_run, 32); (void)__shfl_xor(zp_run, 32); (void)__shfl_xor(deg, 32);
