@@ -241,11 +241,13 @@ int topk_slots(int k);
 struct DenseArgs {
     int B; Grid g;
     const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
+    const uint16_t *x_hi, *x_lo, *wq_hi, *wq_lo; int rows_xh, rows_qh;   // the same, split fp16 [B, rows_h, DSH] (64 x = hi + lo)
     const float* mt; const float* bs;                          // [B,L] mean*thr, bias
     const float* smax;                                         // [B,L] row maximum of the bf16-screened scores
     const float* b2p;                                          // padded NHWC value map
     int splits, tiles_per_split, n_tiles, tiles_per_row;       // 32-key tiles (row aligned), key ranges per 64-query group
     float* part_acc; float* part_m; double* part_z; int32_t* part_deg;   // per (split, query) partial results
+    int variant;                                               // debug ablations (DAGL_DENSE_VARIANT): 1 no A V, 2 no S, 4 no staging
 };
 size_t dense_workspace_bytes(int B, const Grid& g);
 int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);

@@ -5,10 +5,11 @@
 //
 //   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32 = two patch taps x 16 channels)
 //   per 32-key tile (keys = 32 consecutive pixels of one image row):
-//     S      v_mfma_f32_32x32x2_f32, keys x queries, 196-term fp32 fma chains in 5 chunks (as select.hip), split between
-//            the two waves of a query tile and exchanged through LDS.  The key rows enter the MFMA in a permuted order so
-//            that a lane ends up with scores of 16 keys of ONE query that are two runs of 8 CONSECUTIVE keys -- exactly the
-//            K-layout of the next MFMA's operand;
+//     S      v_mfma_f32_32x32x16_f16 on split features (64 x = hi + lo, made once per call by feat_split_kernel; three
+//            products per 16 features as in the projection), keys x queries, the 13 K-blocks split between the two waves of
+//            a query tile and exchanged through LDS.  The key rows enter the MFMA in a permuted order so that a lane ends
+//            up with scores of 16 keys of ONE query that are two runs of 8 CONSECUTIVE keys -- exactly the K-layout of
+//            the next MFMA's operand;
 //     l, p   the reference's fp32 expression order for m and l = (S m) 10; masked keys keep l = 0 and count in the
 //            denominator (no renormalisation), keys outside the image row count nowhere; p = e^(l - M') with M' an UPPER
 //            bound of the row maximum known before the pass (from the bf16 screen's row maxima, dense_rowmax_kernel): the
@@ -21,7 +22,9 @@
 //            patch tap's kw shift becomes a 2-byte-granular offset: five dwords are read and funnel-shifted (v_alignbyte).
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
-// Matrix time per 32 x 32 (key, query) tile: 100 fp32 MFMAs (64 clk) + 150 fp16 MFMAs (32 clk) instead of 500 fp32 ones.
+// Matrix time per 32 x 32 (key, query) tile: 39 + 150 fp16 MFMAs (32 clk) instead of 500 fp32 ones (64 clk).
+#include <stdlib.h>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -29,12 +32,14 @@ namespace dagl {
 typedef _Float16 dnh8 __attribute__((ext_vector_type(8)));
 typedef unsigned dnu4 __attribute__((ext_vector_type(4)));
 
-constexpr int DN_XT = 26 * 256;                       // floats of one staged key-feature tile (32 rows x 204, 26 KiB pieces)
+constexpr int DN_XPART = 14 * 512;                    // halfs of one part (hi or lo) of a staged key-feature tile: 32 rows x 216, 14 KiB pieces
+constexpr int DN_XT = 2 * DN_XPART;                   // halfs per tile buffer: hi | lo
+constexpr int DN_KB = 13;                             // K blocks of 16 features (208 >= 196)
+constexpr float DN_FS = 64.0f;                        // pre-scaling of the split features: 64 x = hi + lo
 constexpr int DN_XW = 48;                             // staged pixels per plane row (38 used; dword reads run to 44)
 constexpr int DN_CSTR = KS * DN_XW + 2;                // halfs per channel plane: 7 rows x 48 + 2 (169 dwords: odd, the 16 channels
                                                       // of a column tile hit different banks)
 constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
-constexpr int DN_KG = 25, DN_KCH = 5;                 // K groups of 8 (200 = 196 + 4 zeros), accumulation chunks
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
 constexpr int DN_CT0 = 13;                            // tiles of column half 0 (half 1: 12)
 constexpr int DN_NQ4 = (KS * 38 * CH / 4 + 255) / 256;    // float4 loads per thread of one region (1064 float4): 5
@@ -101,9 +106,9 @@ __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po,
 }
 
 __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2][DN_XT];                    // 52 KiB: key-feature tiles (LDS-DMA)
+    __shared__ __attribute__((aligned(16))) unsigned short sm[2][DN_XT];           // 56 KiB: key-feature tiles hi | lo (LDS-DMA)
     __shared__ __attribute__((aligned(16))) unsigned short spl[2 * DN_PLANE_H + 64]; // 21 KiB: value planes hi | lo of ONE tile
-    __shared__ __attribute__((aligned(16))) float sq[64 * DS];                     // 51 KiB: the block's 64 query rows
+    __shared__ __attribute__((aligned(16))) unsigned short sq[2][64 * DSH];        // 54 KiB: the block's 64 query rows hi | lo
     __shared__ float sx[2 * 2 * 16 * 64];                                          // 16 KiB: partial scores exchanged per tile
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const int qc = qvalid ? q : g.L - 1;
     const size_t qlin = (size_t)b * g.L + qc;
 
-    // the 64 query rows -> LDS (feature rows are 816 B: whole float4s; rows past L are the zero guard rows)
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.wq + ((size_t)b * a.rows_q + (size_t)qb * 64) * DS);
-        for (int e = tid; e < 64 * DS / 4; e += 256) reinterpret_cast<float4*>(sq)[e] = src[e];
+    // the 64 query rows (split fp16, 432-byte rows: whole 16-byte pieces; rows past L are zero guard rows) -> LDS
+    for (int part = 0; part < 2; ++part) {
+        const uint4* src = reinterpret_cast<const uint4*>((part ? a.wq_lo : a.wq_hi) + ((size_t)b * a.rows_qh + (size_t)qb * 64) * DSH);
+        for (int e = tid; e < 64 * DSH / 8; e += 256) reinterpret_cast<uint4*>(&sq[part][0])[e] = src[e];
     }
-    const float* qrow = sq + (qt * 32 + i) * DS + 4 * h;       // B operand of the score MFMAs: Wq[q][8t+4h .. +3]
+    const unsigned short* qrow = &sq[0][(qt * 32 + i) * DSH + 8 * h];       // B operand of the score MFMAs: Wq[q][16 kb + 8 h ..]
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
 
     f32x16 acc[DN_CT0];
@@ -147,14 +152,17 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     double z_run = 0.0, zp_run = 0.0;                  // sum over all keys / over passing keys of e^(l - m_run)
     int deg = 0;
 
-    const float* xb = a.x + (size_t)b * a.rows_x * DS;
     const float* vb = a.b2p + (size_t)b * g.Hp * g.Wp * CH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
-    auto stage_x = [&](int tile, int buf) {            // key features: 26 one-KiB pieces by LDS-DMA
+    auto stage_x = [&](int tile, int buf) {            // key features hi | lo: 2 x 14 one-KiB pieces by LDS-DMA
         const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
-        const float* xs = xb + ((size_t)jy * g.W + jx0) * DS;
-        for (int p = wave; p < 26; p += 4)
-            glds16_asm(xs + p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (DN_XT * 4) + p * 1024));
+        const size_t roff = ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
+        for (int p = wave; p < 28; p += 4) {
+            const int part = p >= 14, pc = p - 14 * part;
+            const unsigned short* xs = (part ? a.x_lo : a.x_hi) + roff;
+            glds16_asm(reinterpret_cast<const float*>(xs + pc * 512 + lane * 8),
+                       __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + part * DN_XPART) * 2 + pc * 1024)));
+        }
     };
     // value-map region of a tile: 7 rows x 38 pixels x 16 channels fp32 NHWC -> registers (float4 = 4 channels of a pixel)
     float4 rv[DN_NQ4];
@@ -209,30 +217,27 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         (void)jy;
 
         // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
-        // the two waves of a query tile (column halves) split the 196-term sum: chunks 0-2 / chunks 3-4 of 40 terms, exchanged
-        // through LDS and added in chunk order by both (identical scores in both waves, no redundant matrix work)
-        f32x16 mine;
+        // the two waves of a query tile (column halves) split the 13 K-blocks of the 196-term sum, exchange the partial
+        // sums through LDS and add them in the same order (identical scores in both waves, no redundant matrix work)
+        f32x16 mine, cross;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        const float* kp = &sm[cur][prow * DS + 4 * h];
+        for (int r = 0; r < 16; ++r) { mine[r] = 0.f; cross[r] = 0.f; }
+        const unsigned short* kp = &sm[cur][prow * DSH + 8 * h];
+        if (!(a.variant & 2)) {
 #pragma unroll
-        for (int c = 0; c < DN_KCH; ++c) {
-            if ((c < 3) != (half == 0)) continue;                            // wave-uniform
-            f32x16 part;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[r] = 0.f;
-#pragma unroll
-            for (int t = c * (DN_KG / DN_KCH); t < (c + 1) * (DN_KG / DN_KCH); ++t) {
-                const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * t);
-                const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * t);
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qv.x, part, 0, 0, 0);
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qv.y, part, 0, 0, 0);
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qv.z, part, 0, 0, 0);
-                part = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv.w, part, 0, 0, 0);
+            for (int kb = 0; kb < DN_KB; ++kb) {
+                if ((kb < 7) != (half == 0)) continue;                       // wave-uniform: K blocks 0-6 / 7-12
+                const dnh8 k_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + 16 * kb));
+                const dnh8 k_lo = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + DN_XPART + 16 * kb));
+                const dnh8 q_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(qrow + 16 * kb));
+                const dnh8 q_lo = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(qrow + 64 * DSH + 16 * kb));
+                cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_hi, q_lo, cross, 0, 0, 0);
+                mine = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_hi, q_hi, mine, 0, 0, 0);
+                cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_lo, q_hi, cross, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r] += part[r];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r] += cross[r];
         float* ex = sx + ((qt * 2 + half) * 16) * 64 + lane;                  // [query tile][half][register][lane]
 #pragma unroll
         for (int r = 0; r < 16; ++r) ex[r * 64] = mine[r];
@@ -241,9 +246,11 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         const float* e1 = sx + ((qt * 2 + 1) * 16) * 64 + lane;
         f32x16 sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = e0[r * 64] + e1[r * 64];
+        for (int r = 0; r < 16; ++r) sc[r] = (e0[r * 64] + e1[r * 64]) * (1.0f / (DN_FS * DN_FS));
         // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile -----------------------------
         dnh8 p_hi[2], p_lo[2];
+        float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32 (16 terms), one fp64 add per tile
+        unsigned passmask = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mkey = 16 * (r >> 3) + 8 * h + (r & 7);
@@ -251,21 +258,23 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
             bool pass;
             const float l = dn_logit(sc[r], mtq, bsq, pass);
             const float p = valid ? __expf(fminf(l - m_run, 0.f)) : 0.f;      // (the bound holds; the clamp is a seat belt)
-            z_run += (double)p;
+            zt += p;
             pass = pass && valid;
-            if (pass) { zp_run += (double)p; ++deg; }
-            const float ps = pass ? p * DN_PS : 0.f;
+            const float pp = pass ? p : 0.f;
+            zpt += pp;
+            passmask |= (pass ? 1u : 0u) << r;
+            const float ps = pp * DN_PS;
             const _Float16 hi = (_Float16)ps;
             p_hi[r >> 3][r & 7] = hi;
             p_lo[r >> 3][r & 7] = (_Float16)(ps - (float)hi);
         }
+        z_run += (double)zt; zp_run += (double)zpt; deg += __popc(passmask);
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
         const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
-        if (half == 0) dn_pv<0>(acc, planes, i & 15, h, second, p_hi, p_lo); else dn_pv<1>(acc, planes, i & 15, h, second, p_hi, p_lo);
+        if (!(a.variant & 1)) { if (half == 0) dn_pv<0>(acc, planes, i & 15, h, second, p_hi, p_lo); else dn_pv<1>(acc, planes, i & 15, h, second, p_hi, p_lo); }
         dma_wait_all();
         __syncthreads();                                   // everyone is done with this tile's planes and features
-        if (tile + 1 < tile1) store_region();
-        __syncthreads();
+        if (tile + 1 < tile1 && !(a.variant & 4)) store_region();   // published by the next tile's exchange barrier
     }
 
     // ---- partial results of this key range ------------------------------------------------------------------------------
@@ -335,6 +344,27 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
     }
 }
 
+// fp32 feature rows [B, rows_in, 204] -> split fp16 rows [B, rows_out, 216] hi and lo, 64 x = hi + lo (pad columns zero)
+__global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const float* __restrict__ src,
+                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int b = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)rows_out * (DSH / 8)) return;
+    const int r = (int)(t / (DSH / 8)), c8 = (int)(t % (DSH / 8));
+    unsigned short vh[8], vl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = 8 * c8 + u;
+        const float v = (r < rows && c < D) ? src[((size_t)b * rows_in + r) * DS + c] * DN_FS : 0.f;
+        const _Float16 h = (_Float16)v;
+        vh[u] = __builtin_bit_cast(unsigned short, h);
+        vl[u] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+    }
+    const size_t o = (((size_t)b * rows_out + r) * DSH + 8 * c8) / 8;
+    reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(vh);
+    reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(vl);
+}
+
 // row maximum of the screened scores: gmax holds, per query, the 4 largest values of each of its G/4 scan segments
 __global__ void dense_rowmax_kernel(size_t n_rows, int G, const float* __restrict__ gmax, float* __restrict__ smax) {
     const int lane = threadIdx.x & 63;
@@ -363,10 +393,13 @@ int dense_splits(int B, const Grid& g) {                 // blocks = 64-query gr
     return s;
 }
 
+static size_t dn_feat16_bytes(int B, int rows) { return align_up((size_t)B * feat_rows_h(rows) * DSH * sizeof(uint16_t), 256); }
+
 size_t dense_workspace_bytes(int B, const Grid& g) {
     const size_t rows = (size_t)dense_splits(B, g) * B * g.L;
     return align_up(rows * P * sizeof(float), 256) + align_up(rows * sizeof(float), 256) +
-           align_up(rows * 2 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256);
+           align_up(rows * 2 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256) +
+           2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L);
 }
 
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
@@ -374,6 +407,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
                         float* rowsum_out, int64_t* stats) {
     DenseArgs a;
     a.smax = smax;
+    { static const int var = getenv("DAGL_DENSE_VARIANT") ? atoi(getenv("DAGL_DENSE_VARIANT")) : 0; a.variant = var; }
     a.B = B; a.g = g; a.wq = wq; a.x = x; a.rows_q = feat_rows(g.L); a.rows_x = feat_rows(g.N);
     a.mt = mt; a.bs = bs; a.b2p = b2p;
     a.splits = dense_splits(B, g);
@@ -386,7 +420,20 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.part_acc = reinterpret_cast<float*>(p); p += align_up(rows * P * sizeof(float), 256);
     a.part_m = reinterpret_cast<float*>(p); p += align_up(rows * sizeof(float), 256);
     a.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 2 * sizeof(double), 256);
-    a.part_deg = reinterpret_cast<int32_t*>(p);
+    a.part_deg = reinterpret_cast<int32_t*>(p); p += align_up(rows * sizeof(int32_t), 256);
+    uint16_t* xh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
+    uint16_t* xl = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
+    uint16_t* qh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
+    uint16_t* ql = reinterpret_cast<uint16_t*>(p);
+    a.x_hi = xh; a.x_lo = xl; a.wq_hi = qh; a.wq_lo = ql;
+    a.rows_xh = feat_rows_h(g.N); a.rows_qh = feat_rows_h(g.L);
+    {
+        const size_t nx = (size_t)a.rows_xh * (DSH / 8), nq8 = (size_t)a.rows_qh * (DSH / 8);
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl);
+        DAGL_LAUNCH_CHECK("feat_split_kernel");
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql);
+        DAGL_LAUNCH_CHECK("feat_split_kernel");
+    }
     const int n_qblocks = (g.L + 63) / 64;
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
