@@ -42,7 +42,6 @@ constexpr int DN_CSTR = KS * DN_XW + 2;                // halfs per channel plan
 constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
 constexpr int DN_CT0 = 13;                            // tiles of column half 0 (half 1: 12)
-constexpr int DN_NQ4 = (KS * 38 * CH / 4 + 255) / 256;    // float4 loads per thread of one region (1064 float4): 5
 constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
@@ -164,37 +163,51 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
                        __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + part * DN_XPART) * 2 + pc * 1024)));
         }
     };
-    // value-map region of a tile: 7 rows x 38 pixels x 16 channels fp32 NHWC -> registers (float4 = 4 channels of a pixel)
-    float4 rv[DN_NQ4];
+    // value-map region of a tile: 7 rows x 38 pixels x 16 channels fp32 NHWC -> registers -> planar fp16 hi | lo in LDS.
+    // Work item = (kernel row, pixel PAIR, channel quad): two float4 loads, then per channel the two pixels' halfs go out
+    // as one 4-byte store.  The index arithmetic does not depend on the tile and is done once.
+    constexpr int DN_ITEMS = KS * 19 * 4;                                    // 532
+    constexpr int DN_NIT = (DN_ITEMS + 255) / 256;                           // 3 per thread
+    float4 rv[DN_NIT][2];
+    int it_src[DN_NIT], it_px[DN_NIT], it_lds[DN_NIT];
+#pragma unroll
+    for (int j = 0; j < DN_NIT; ++j) {
+        int idx = tid + 256 * j;
+        const bool on = idx < DN_ITEMS;
+        if (!on) idx = DN_ITEMS - 1;
+        const int kh = idx / 76, rem = idx - kh * 76;
+        const int pp = rem >> 2, c4 = rem & 3;
+        it_px[j] = 2 * pp;
+        it_src[j] = kh * g.Wp * CH + 4 * c4;                                 // + (jy * Wp + jx0 + px) * 16 per tile
+        it_lds[j] = on ? (4 * c4) * DN_CSTR + kh * DN_XW + 2 * pp : -1;
+    }
     auto load_region = [&](int tile) {
         const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
         const int lim = g.Wp - 1 - jx0;                                      // stay inside the map row
+        const float* tb = vb + ((size_t)jy * g.Wp + jx0) * CH;
 #pragma unroll
-        for (int j = 0; j < DN_NQ4; ++j) {
-            int idx = tid + 256 * j;
-            if (idx >= KS * 38 * 4) idx = KS * 38 * 4 - 1;                   // clamped duplicate, dropped at the store
-            const int kh = idx / (38 * 4), rem = idx - kh * (38 * 4);
-            int px = rem >> 2; const int c4 = rem & 3;
-            if (px > lim) px = lim;
-            rv[j] = *reinterpret_cast<const float4*>(vb + ((size_t)(jy + kh) * g.Wp + jx0 + px) * CH + 4 * c4);
+        for (int j = 0; j < DN_NIT; ++j) {
+            const int p0 = it_px[j] > lim ? lim : it_px[j], p1 = it_px[j] + 1 > lim ? lim : it_px[j] + 1;
+            rv[j][0] = *reinterpret_cast<const float4*>(tb + it_src[j] + p0 * CH);
+            rv[j][1] = *reinterpret_cast<const float4*>(tb + it_src[j] + p1 * CH);
         }
     };
-    auto store_region = [&]() {                        // -> planar fp16 hi | lo: spl[part][c][kh][px]
+    auto store_region = [&]() {
 #pragma unroll
-        for (int j = 0; j < DN_NQ4; ++j) {
-            const int idx = tid + 256 * j;
-            if (idx >= KS * 38 * 4) continue;
-            const int kh = idx / (38 * 4), rem = idx - kh * (38 * 4);
-            const int px = rem >> 2, c4 = rem & 3;
-            const float v[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+        for (int j = 0; j < DN_NIT; ++j) {
+            if (it_lds[j] < 0) continue;
+            const float v0[4] = {rv[j][0].x, rv[j][0].y, rv[j][0].z, rv[j][0].w};
+            const float v1[4] = {rv[j][1].x, rv[j][1].y, rv[j][1].z, rv[j][1].w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float vs = v[u] * DN_VS;
-                const _Float16 hi = (_Float16)vs;
-                const _Float16 lo = (_Float16)(vs - (float)hi);
-                const int o = (4 * c4 + u) * DN_CSTR + kh * DN_XW + px;
-                spl[o] = __builtin_bit_cast(unsigned short, hi);
-                spl[DN_PLANE_H + o] = __builtin_bit_cast(unsigned short, lo);
+                const float a0 = v0[u] * DN_VS, a1 = v1[u] * DN_VS;
+                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                const unsigned hw = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                const unsigned lw = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                const int o = it_lds[j] + u * DN_CSTR;                       // even half index: 4-byte aligned
+                *reinterpret_cast<unsigned*>(&spl[o]) = hw;
+                *reinterpret_cast<unsigned*>(&spl[DN_PLANE_H + o]) = lw;
             }
         }
     };
