@@ -154,8 +154,20 @@ def train_bench(args, dev, dist, world, rank):
     if dist is not None:
         dist.barrier()
     elapsed = reduce_max_seconds(time.perf_counter() - t0, dist, dev)
+    n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    allreduce_ms = None
+    if dist is not None:
+        # the collective on its own (outside the timed steps): one all-reduce of a gradient-sized fp32 buffer over RCCL
+        flat = torch.zeros(n_par, device=dev)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        allreduce_ms = reduce_max_seconds((time.perf_counter() - t1) / 10, dist, dev) * 1e3
     if rank == 0:
-        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
         line = {"metric": f"RR train crops/s (fwd+bwd+Adam) @{args.crop}x{args.crop} {args.mode} k={args.k}",
                 "value": world * B * args.steps / elapsed, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
@@ -165,6 +177,7 @@ def train_bench(args, dev, dist, world, rank):
                                        f"{n_par} parameters all-reduced over RCCL",
                            "parallelism": f"ddp{world}", "select_mode": args.mode, "k": args.k, "batch_per_gpu": B},
                 "roofline": None, "cpu_baseline": None,
+                "allreduce_ms": allreduce_ms, "allreduce_bytes": 4 * n_par if dist is not None else None,
                 "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None}
         print(json.dumps(line))
 
