@@ -155,3 +155,31 @@ def test_fused_prologue_matches_stock_convs(B, H, W):
     assert float(b1p[:, :3].abs().max()) == 0.0 and float(b1p[:, :, -3:].abs().max()) == 0.0
     assert normwise(thr.cpu().numpy(), st["thr"].numpy()) <= 2e-6
     assert normwise(bias.cpu().numpy(), st["bias"].numpy()) <= 2e-6
+
+
+def test_stage_profile_can_bracket_a_single_stage():
+    """dagl_profile_select_stage: only the two events around one stage are recorded (the benchmark's timed steps use it:
+    nine event records per call cost ~12 % of a 256^2 forward)."""
+    from dagl_amd import ops
+    from dagl_amd._lib import STAGE_NAMES
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(81, variant="default").items()}
+    ce = CE(in_channels=64)
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode, ce.select_k = "topk", 8
+    ce = ce.cuda().eval()
+    x = torch.from_numpy(make_features(81, 1, 64, 96, 96)).cuda()
+    prof = ops.StageProfile(4)
+    ce.profile = prof
+    with torch.no_grad():
+        prof.select_stage("select")
+        ce(x); ce(x)
+        sel = prof.read()
+        assert len(sel) == 2
+        k = list(STAGE_NAMES).index("select")
+        assert all(row[k] > 0 and sum(row) == row[k] for row in sel)
+        prof.select_stage(-1)
+        ce(x)
+        full = prof.read()
+        assert len(full) == 1 and sum(v > 0 for v in full[0]) >= 6
