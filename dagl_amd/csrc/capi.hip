@@ -445,12 +445,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             return run_dense();
         }
         prof_mark(prof, s, 3);
-        if (mode == DAGL_MODE_TOPK) {
+        if (mode != DAGL_MODE_ADAPTIVE) {                       // top-k threshold from the sampling pass
             if ((rc = launch_screen(s, sc, 0))) return rc;
             if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
-        } else {
-            if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta)))) return rc;
         }
+        if (mode != DAGL_MODE_TOPK)                             // adaptive threshold; the intersection mode takes the larger
+            if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta), mode == DAGL_MODE_ADAPTIVE_TOPK))) return rc;
         prof_mark(prof, s, 4);
         if ((rc = launch_screen(s, sc, 1))) return rc;
         prof_mark(prof, s, 5);

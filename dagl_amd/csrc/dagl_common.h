@@ -215,7 +215,7 @@ struct ScreenArgs {
 };
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
 int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta);
-int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta);
+int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta, bool both = false);
 
 struct RefineArgs {
     int B, L, N, mode, k, splits, capseg, width;

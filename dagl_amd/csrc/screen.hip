@@ -222,19 +222,21 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 
 // theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32
 // rounding of either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32).
+// `both` (adaptive AND top-k mask): theta already holds the top-k threshold; a key must pass both tests, so the larger wins.
 __global__ void adaptive_theta_kernel(size_t n, const float* __restrict__ mt, const float* __restrict__ bs,
-                                      float* __restrict__ theta) {
+                                      float* __restrict__ theta, int both) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double m = (double)mt[i], bb = (double)bs[i];
     double t = (m - bb) - 1e-5 * (fabs(m) + fabs(bb) + 1.0);
     t = t / (1.0 + (double)DELTA);
     t -= 1e-6 * fabs(t);
-    theta[i] = (float)t - 1e-30f;
+    const float ta = (float)t - 1e-30f;
+    theta[i] = both ? fmaxf(ta, theta[i]) : ta;
 }
 
-int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta) {
-    hipLaunchKernelGGL(adaptive_theta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, mt, bs, theta);
+int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta, bool both) {
+    hipLaunchKernelGGL(adaptive_theta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, mt, bs, theta, both ? 1 : 0);
     DAGL_LAUNCH_CHECK("adaptive_theta_kernel");
     return DAGL_OK;
 }
