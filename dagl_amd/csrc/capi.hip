@@ -290,7 +290,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       p.split16 ? at<uint16_t>(ws, p.o_maphi) + hd * map_f : nullptr,
                                       p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr,
                                       at<float>(ws, p.o_thrpart) + (size_t)hd * 8 * imgs * g.L,
-                                      prepared, (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
+                                      prepared, /*defer_thr_reduce=*/thr_heads,
+                                      (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
                                       (prepared && hd == 0) ? 8 : 0,
                                       (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
                                       (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0))) return rc;
@@ -356,6 +357,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     }
 
     // ---- stage 2: adaptive thresholds ----------------------------------------------------------------------
+    bool fused_theta = false;
     prof_mark(prof, s, 2);
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -371,7 +373,17 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     ag.B = B; ag.g = g; ag.b2p = b2p; ag.nb_idx = nbidx; ag.nb_wgt = nbwgt; ag.nb_cnt = nbcnt; ag.width = p.width;
     ag.agg = agg;
     if (mode != DAGL_MODE_TOPK) {
-        if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt, core ? core->mu : nullptr))) return rc;
+        ThrFuse tf;
+        if (fin) {                                   // finish the thr / bias heads here (their partial sums are per head)
+            tf.part = at<float>(ws, p.o_thrpart); tf.imgs_per_head = imgs;
+            for (int hd = 0; hd < heads; ++hd) { tf.thr_b[hd] = fin[hd].thr_b; tf.bias_b[hd] = fin[hd].bias_b; }
+            tf.thr_out = at<float>(ws, p.o_thr); tf.bias_out = at<float>(ws, p.o_bias);
+        } else {
+            tf.bias_out = const_cast<float*>(bias);   // read only in this case
+        }
+        fused_theta = p.screen && mode == DAGL_MODE_ADAPTIVE;
+        if (fused_theta) tf.theta_out = at<float>(ws, p.o_theta);
+        if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt, core ? core->mu : nullptr, &tf))) return rc;
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
 
@@ -449,7 +461,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_screen(s, sc, 0))) return rc;
             if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
         }
-        if (mode != DAGL_MODE_TOPK)                             // adaptive threshold; the intersection mode takes the larger
+        if (mode != DAGL_MODE_TOPK && !fused_theta)             // adaptive threshold; the intersection mode takes the larger
             if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta), mode == DAGL_MODE_ADAPTIVE_TOPK))) return rc;
         prof_mark(prof, s, 4);
         if ((rc = launch_screen(s, sc, 1))) return rc;

@@ -117,6 +117,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     float* bias, uint16_t* b1_hi /* optional fp16 split of b1 */, uint16_t* b1_lo,
                     float* thr_part /* scratch [4][B][L][2] floats when thr != null */,
                     bool borders_zero = false /* the maps' 3-pixel borders still hold the zeros of an earlier call */,
+                    bool defer_thr_reduce = false /* leave the partial sums in thr_part: launch_query_thresholds finishes them */,
                     uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
                     /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */);
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);
@@ -133,8 +134,29 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1);
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
 constexpr size_t P16_PACKED_HALFS = (size_t)49 * 7168 + 1024; // packed fp16 weights (halfs) + read slack
+// Optional extra duties of the thresholds kernel on the fused path (one launch instead of three): finish the thr / bias
+// heads (fixed-order sum of the prologue's four channel-group partials + the conv bias) and derive the screen's
+// candidate threshold of the adaptive mode.
+struct ThrFuse {
+    const float* part = nullptr;            // [heads][4][imgs][L][2] partial sums (thr_bias_kernel), or null = thr/bias are final
+    const float* thr_b[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* bias_b[4] = {nullptr, nullptr, nullptr, nullptr};
+    int imgs_per_head = 1;
+    float* thr_out = nullptr; float* bias_out = nullptr;     // [B,L] final values (written when part != null)
+    float* theta_out = nullptr;             // [B,L] adaptive candidate threshold on the screened scores, or null
+};
+constexpr float SCREEN_DELTA = 0.004f;     // relative band of the bf16-screened scores (screen.hip)
+// theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32 rounding of
+// either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32)
+__host__ __device__ inline float adaptive_theta_of(float mt, float bs) {
+    const double m = (double)mt, bb = (double)bs;
+    double t = (m - bb) - 1e-5 * (fabs(m) + fabs(bb) + 1.0);
+    t = t / (1.0 + (double)SCREEN_DELTA);
+    t -= 1e-6 * fabs(t);
+    return (float)t - 1e-30f;
+}
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
-                            const float* thr, float* mt, float* mu_out = nullptr);
+                            const float* thr, float* mt, float* mu_out = nullptr, const ThrFuse* fuse = nullptr);
 int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, float* rows);
 int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
                         const float* values, float* out);

@@ -234,7 +234,7 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* 
 // The row mean of S is linear in the key features, so it needs no pass over S.
 __global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const float* __restrict__ wq,
                                         const double* __restrict__ colsum, const float* __restrict__ thr,
-                                        float* __restrict__ mt, float* __restrict__ mu_out) {
+                                        float* __restrict__ mt, float* __restrict__ mu_out, ThrFuse f) {
     const int b = blockIdx.y;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;     // one wave per query
     const int lane = threadIdx.x & 63;
@@ -246,16 +246,34 @@ __global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const floa
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) {
+        const size_t ql = (size_t)b * L + wave;
         const float mean = (float)(acc / (double)N);
-        mt[(size_t)b * L + wave] = mean * thr[(size_t)b * L + wave];
-        if (mu_out != nullptr) mu_out[(size_t)b * L + wave] = mean;
+        float tv, bv = 0.f;
+        if (f.part != nullptr) {
+            // batch entry b = head * imgs + img; partials of a head: [4 groups][imgs][L][2]
+            const int head = b / f.imgs_per_head, img = b - head * f.imgs_per_head;
+            const size_t n = (size_t)f.imgs_per_head * L;
+            const float2* pp = reinterpret_cast<const float2*>(f.part) + (size_t)head * 4 * n + (size_t)img * L + wave;
+            const float2 p0 = pp[0], p1 = pp[n], p2 = pp[2 * n], p3 = pp[3 * n];
+            tv = ((p0.x + p1.x) + (p2.x + p3.x)) + f.thr_b[head][0];
+            bv = ((p0.y + p1.y) + (p2.y + p3.y)) + f.bias_b[head][0];
+            f.thr_out[ql] = tv; f.bias_out[ql] = bv;
+        } else {
+            tv = thr[ql];
+            if (f.theta_out != nullptr) bv = f.bias_out[ql];
+        }
+        const float m = mean * tv;
+        mt[ql] = m;
+        if (mu_out != nullptr) mu_out[ql] = mean;
+        if (f.theta_out != nullptr) f.theta_out[ql] = adaptive_theta_of(m, bv);
     }
 }
 
 int launch_query_thresholds(hipStream_t s, int B, int L, int N, const float* wq, const double* colsum,
-                            const float* thr, float* mt, float* mu_out) {
+                            const float* thr, float* mt, float* mu_out, const ThrFuse* fuse) {
     dim3 grid((L + 3) / 4, B), block(256);
-    hipLaunchKernelGGL(query_thresholds_kernel, grid, block, 0, s, L, N, feat_rows(L), wq, colsum, thr, mt, mu_out);
+    const ThrFuse f = fuse ? *fuse : ThrFuse();
+    hipLaunchKernelGGL(query_thresholds_kernel, grid, block, 0, s, L, N, feat_rows(L), wq, colsum, thr, mt, mu_out, f);
     DAGL_LAUNCH_CHECK("query_thresholds_kernel");
     return DAGL_OK;
 }

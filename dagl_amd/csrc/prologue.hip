@@ -461,7 +461,7 @@ __global__ void thr_bias_reduce_kernel(size_t n /* B*L */, const float* __restri
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
-                    uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, uint32_t* clear_a,
+                    uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, bool defer_thr_reduce, uint32_t* clear_a,
                     int clear_a_words, uint32_t* clear_b, int clear_b_words) {
     int rcz;
     if (!borders_zero) {
@@ -491,6 +491,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                            thr_w, bias_w, thr_part);
         DAGL_LAUNCH_CHECK("thr_bias_kernel");
         const size_t n = (size_t)B * g.L;
+        if (!defer_thr_reduce)
         hipLaunchKernelGGL(thr_bias_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, thr_part, thr_b,
                            bias_b, thr, bias);
         DAGL_LAUNCH_CHECK("thr_bias_reduce_kernel");

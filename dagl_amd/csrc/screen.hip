@@ -26,7 +26,7 @@ constexpr int SK = 64;                           // keys per streaming step (two
 constexpr int STEP_ELEMS = SK * DSH;             // 13824 bf16 = 27648 B = 27 DMA pieces of 1 KiB exactly
 constexpr int STEP_PIECES = 27;
 constexpr int KB = 13;                           // MFMAs (K=16 each) per 32x32 tile: 208 = 196 + 12 zeros
-constexpr float DELTA = 0.004f;
+constexpr float DELTA = SCREEN_DELTA;
 constexpr int GKEEP = 4;                         // group maxima kept per (query, chunk, half) segment
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
@@ -227,11 +227,7 @@ __global__ void adaptive_theta_kernel(size_t n, const float* __restrict__ mt, co
                                       float* __restrict__ theta, int both) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double m = (double)mt[i], bb = (double)bs[i];
-    double t = (m - bb) - 1e-5 * (fabs(m) + fabs(bb) + 1.0);
-    t = t / (1.0 + (double)DELTA);
-    t -= 1e-6 * fabs(t);
-    const float ta = (float)t - 1e-30f;
+    const float ta = adaptive_theta_of(mt[i], bs[i]);
     theta[i] = both ? fmaxf(ta, theta[i]) : ta;
 }
 
