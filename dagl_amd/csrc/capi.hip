@@ -432,7 +432,6 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 set_error("dagl_ce_forward: dense neighbourhoods need workspace %zu B, have %zu B", off, ws_bytes);
                 return DAGL_ERR_WORKSPACE;
             }
-            DAGL_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), s));
             prof_mark(prof, s, 6);
             // row maxima of the screened scores (full bf16 scan, ~0.1 ms at 256^2): the softmax's shift, known up front
             sc.sample = 1;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
 // merge the key-range partials of a query: M = max M_s, Z = sum Z_s e^(M_s - M), agg = sum acc_s e^(M_s - M) / Z
 // (all partials of a query share one shift today, so the weights are 1; kept general).  One wave per query, float4 columns.
 __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* __restrict__ agg, int32_t* __restrict__ deg_out,
-                                                            float* __restrict__ rowsum_out, int64_t* __restrict__ stats) {
+                                                            float* __restrict__ rowsum_out) {
     const int lane = threadIdx.x & 63;
     const size_t nq = (size_t)a.B * a.g.L;
     const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);           // (b, q) flattened
@@ -352,8 +352,7 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
     if (lane == 0) {
         if (deg_out) deg_out[ql] = deg;
         if (rowsum_out) rowsum_out[ql] = (float)(zp / z);
-        atomicAdd(reinterpret_cast<unsigned long long*>(&stats[0]), (unsigned long long)deg);
-        atomicMax(reinterpret_cast<unsigned long long*>(&stats[1]), (unsigned long long)deg);
+        a.part_deg[ql] = deg;        // slot of split 0 (read above): final degree, summed up by degree_stats_kernel afterwards
     }
 }
 
@@ -450,9 +449,9 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     const int n_qblocks = (g.L + 63) / 64;
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
-    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, stats);
+    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
-    return DAGL_OK;
+    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats);     // total edges, max degree (no per-query atomics)
 }
 
 }  // namespace dagl
