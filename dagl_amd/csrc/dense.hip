@@ -395,10 +395,23 @@ int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, 
     return DAGL_OK;
 }
 
-int dense_splits(int B, const Grid& g) {                 // blocks = 64-query groups x splits: at most one per CU, ONE round
-    const int n_qblocks = (g.L + 63) / 64;                // (one block per CU is resident: block 257 would wait for a whole block time)
-    int s = 256 / (n_qblocks * B);
+int dense_splits(int B, const Grid& g) {
+    // One block per CU is resident (LDS), so the grid runs in rounds of 256 blocks.  Few query groups: as many key ranges
+    // as still fit one round.  More query groups than CUs: the split count that wastes least of the last round
+    // (384 groups: 1 split = 2 rounds of whole ranges, 2 splits = 3 rounds of half ranges).
+    const int n = ((g.L + 63) / 64) * B;
     const int n_tiles = g.H * ((g.W + KT - 1) / KT);
+    int s;
+    if (n <= 256) {
+        s = 256 / n;
+    } else {
+        s = 1;
+        double best = (double)((n + 255) / 256);
+        for (int c = 2; c <= 4; ++c) {
+            const double cost = (double)((n * c + 255) / 256) / c;
+            if (cost < best - 1e-9) { best = cost; s = c; }
+        }
+    }
     if (s > n_tiles) s = n_tiles;
     if (s > 16) s = 16;
     if (s < 1) s = 1;
