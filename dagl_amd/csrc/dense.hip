@@ -4,7 +4,7 @@
 // nothing of size L x N ever stored.
 //
 //   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32 = two patch taps x 16 channels)
-//   per 32-key tile (keys = 32 consecutive pixels of one image row):
+//   per 32-key tile (keys = an 8 x 4 pixel block of the map):
 //     S      v_mfma_f32_32x32x16_f16 on split features (64 x = hi + lo, made once per call by feat_split_kernel; three
 //            products per 16 features as in the projection), keys x queries, the 13 K-blocks split between the two waves of
 //            a query tile and exchanged through LDS.  The key rows enter the MFMA in a permuted order so that a lane ends
@@ -18,7 +18,7 @@
 //     A V    v_mfma_f32_32x32x16_f16 with split operands (2^14 p = hi + lo, 16 v = hi + lo, three products, one fp32
 //            accumulator: the projection's recipe): out^T[col][q] += V[key][col] p[q][key].  B = the lane's own weights,
 //            straight from its registers.  A needs 8 consecutive KEYS of one column, i.e. 8 consecutive pixels of one
-//            channel: the value-map region (7 rows x 38 pixels x 16 channels) is staged PLANAR in LDS as fp16 hi / lo, and a
+//            channel: the value-map region (10 rows x 14 pixels x 16 channels) is staged PLANAR in LDS as fp16 hi / lo, and a
 //            patch tap's kw shift becomes a 2-byte-granular offset: five dwords are read and funnel-shifted (v_alignbyte).
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
@@ -36,8 +36,10 @@ constexpr int DN_XPART = 14 * 512;                    // halfs of one part (hi o
 constexpr int DN_XT = 2 * DN_XPART;                   // halfs per tile buffer: hi | lo
 constexpr int DN_KB = 13;                             // K blocks of 16 features (208 >= 196)
 constexpr float DN_FS = 64.0f;                        // pre-scaling of the split features: 64 x = hi + lo
-constexpr int DN_XW = 48;                             // staged pixels per plane row (38 used; dword reads run to 44)
-constexpr int DN_CSTR = KS * DN_XW + 2;                // halfs per channel plane: 7 rows x 48 + 2 (169 dwords: odd, the 16 channels
+constexpr int DN_TW = 8, DN_TH = 4;                   // a key tile = 8 x 4 pixels (32 keys): narrow maps waste little of it
+constexpr int DN_RH = DN_TH + KS - 1, DN_RW = DN_TW + KS - 1;   // value-map region of a tile: 10 rows x 14 pixels
+constexpr int DN_XW = 16;                             // staged pixels per plane row (14 used; dword reads run to 15)
+constexpr int DN_CSTR = DN_RH * DN_XW + 2;            // halfs per channel plane: 10 rows x 16 + 2 (81 dwords: odd, the 16 channels
                                                       // of a column tile hit different banks)
 constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
@@ -52,7 +54,8 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
 
 // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes i >= 16 ("second") take the odd tap (tap 49 does not exist:
 // those lanes of tile 24 recompute tap 48 and their columns are never stored).
-// A operand of kblock kb: halfs e = 0..7 = V[key 16 kb + 8 h + e][tap][c] = plane[c][kh][16 kb + 8 h + kw + e]
+// A operand of kblock kb: halfs e = 0..7 = V[key 16 kb + 8 h + e][tap][c]; key = pixel (row 2 kb + h, column e) of the tile,
+// so the value is plane[c][2 kb + h + kh][kw + e]
 template <int HALF>
 __device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char* planes, int c, int h, bool second,
                                       const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2]) {
@@ -62,8 +65,8 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char
         if (ct >= DN_CT) continue;
         const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
         const int kh = second ? tapb / KS : tapa / KS, kw = second ? tapb % KS : tapa % KS;
-        // byte offset of (c, kh, pixel 8 h + kw) inside a part; dword-aligned base + byte shift 0 / 2
-        const int boff = (c * DN_CSTR + kh * DN_XW + 8 * h + kw) * 2;
+        // byte offset of (c, row h + kh, pixel kw) inside a part; dword-aligned base + byte shift 0 / 2
+        const int boff = (c * DN_CSTR + (h + kh) * DN_XW + kw) * 2;
         const unsigned char* base = planes + (boff & ~3);
         const unsigned shift = (unsigned)(boff & 3);
 #pragma unroll
@@ -71,7 +74,7 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char
             dnh8 v_hi, v_lo;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
-                const unsigned* dp = reinterpret_cast<const unsigned*>(base + part * (DN_PLANE_H * 2) + kb * 32);
+                const unsigned* dp = reinterpret_cast<const unsigned*>(base + part * (DN_PLANE_H * 2) + kb * (2 * DN_XW * 2));
                 const unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4];
                 dnu4 w;
                 w[0] = __builtin_amdgcn_alignbyte(d1, d0, shift);
@@ -153,43 +156,44 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
 
     const float* vb = a.b2p + (size_t)b * g.Hp * g.Wp * CH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
-    auto stage_x = [&](int tile, int buf) {            // key features hi | lo: 2 x 14 one-KiB pieces by LDS-DMA
-        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
-        const size_t roff = ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
-        for (int p = wave; p < 28; p += 4) {
-            const int part = p >= 14, pc = p - 14 * part;
-            const unsigned short* xs = (part ? a.x_lo : a.x_hi) + roff;
-            glds16_asm(reinterpret_cast<const float*>(xs + pc * 512 + lane * 8),
-                       __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + part * DN_XPART) * 2 + pc * 1024)));
+    auto stage_x = [&](int tile, int buf) {            // key features hi | lo: per part 4 pixel rows x 8 keys x 432 B by LDS-DMA
+        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
+        for (int p = wave; p < 32; p += 4) {                                 // (part, row dy, piece): 3456 B = 3 x 1 KiB + 384 B
+            const int part = p >> 4, dy = (p >> 2) & 3, pc = p & 3;
+            int jy = jy0 + dy; if (jy > g.H - 1) jy = g.H - 1;               // ragged bottom: a valid row, keys masked below
+            const unsigned short* xs = (part ? a.x_lo : a.x_hi) + ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
+            if (pc < 3 || lane < 24)
+                glds16_asm(reinterpret_cast<const float*>(xs + pc * 512 + lane * 8),
+                           __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + part * DN_XPART + dy * 8 * DSH) * 2 + pc * 1024)));
         }
     };
-    // value-map region of a tile: 7 rows x 38 pixels x 16 channels fp32 NHWC -> registers -> planar fp16 hi | lo in LDS.
-    // Work item = (kernel row, pixel PAIR, channel quad): two float4 loads, then per channel the two pixels' halfs go out
+    // value-map region of a tile: 10 rows x 14 pixels x 16 channels fp32 NHWC -> registers -> planar fp16 hi | lo in LDS.
+    // Work item = (region row, pixel PAIR, channel quad): two float4 loads, then per channel the two pixels' halfs go out
     // as one 4-byte store.  The index arithmetic does not depend on the tile and is done once.
-    constexpr int DN_ITEMS = KS * 19 * 4;                                    // 532
-    constexpr int DN_NIT = (DN_ITEMS + 255) / 256;                           // 3 per thread
+    constexpr int DN_ITEMS = DN_RH * (DN_RW / 2) * 4;                        // 280
+    constexpr int DN_NIT = (DN_ITEMS + 255) / 256;                           // 2 per thread
     float4 rv[DN_NIT][2];
-    int it_src[DN_NIT], it_px[DN_NIT], it_lds[DN_NIT];
+    int it_row[DN_NIT], it_px[DN_NIT], it_c4[DN_NIT], it_lds[DN_NIT];
 #pragma unroll
     for (int j = 0; j < DN_NIT; ++j) {
         int idx = tid + 256 * j;
         const bool on = idx < DN_ITEMS;
         if (!on) idx = DN_ITEMS - 1;
-        const int kh = idx / 76, rem = idx - kh * 76;
+        const int row = idx / (DN_RW / 2 * 4), rem = idx - row * (DN_RW / 2 * 4);
         const int pp = rem >> 2, c4 = rem & 3;
-        it_px[j] = 2 * pp;
-        it_src[j] = kh * g.Wp * CH + 4 * c4;                                 // + (jy * Wp + jx0 + px) * 16 per tile
-        it_lds[j] = on ? (4 * c4) * DN_CSTR + kh * DN_XW + 2 * pp : -1;
+        it_row[j] = row; it_px[j] = 2 * pp; it_c4[j] = 4 * c4;
+        it_lds[j] = on ? (4 * c4) * DN_CSTR + row * DN_XW + 2 * pp : -1;
     }
     auto load_region = [&](int tile) {
-        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
-        const int lim = g.Wp - 1 - jx0;                                      // stay inside the map row
-        const float* tb = vb + ((size_t)jy * g.Wp + jx0) * CH;
+        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
+        const int limx = g.Wp - 1 - jx0, limy = g.Hp - 1 - jy0;              // stay inside the padded map
 #pragma unroll
         for (int j = 0; j < DN_NIT; ++j) {
-            const int p0 = it_px[j] > lim ? lim : it_px[j], p1 = it_px[j] + 1 > lim ? lim : it_px[j] + 1;
-            rv[j][0] = *reinterpret_cast<const float4*>(tb + it_src[j] + p0 * CH);
-            rv[j][1] = *reinterpret_cast<const float4*>(tb + it_src[j] + p1 * CH);
+            const int r = it_row[j] > limy ? limy : it_row[j];
+            const int p0 = it_px[j] > limx ? limx : it_px[j], p1 = it_px[j] + 1 > limx ? limx : it_px[j] + 1;
+            const float* rb = vb + ((size_t)(jy0 + r) * g.Wp + jx0) * CH + it_c4[j];
+            rv[j][0] = *reinterpret_cast<const float4*>(rb + p0 * CH);
+            rv[j][1] = *reinterpret_cast<const float4*>(rb + p1 * CH);
         }
     };
     auto store_region = [&]() {
@@ -226,8 +230,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     for (int tile = tile0; tile < tile1; ++tile) {
         const int cur = (tile - tile0) & 1;
         if (tile + 1 < tile1) { stage_x(tile + 1, cur ^ 1); load_region(tile + 1); }
-        const int jy = tile / a.tiles_per_row, jx0 = (tile - jy * a.tiles_per_row) * KT;
-        (void)jy;
+        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
 
         // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
         // the two waves of a query tile (column halves) split the 13 K-blocks of the 196-term sum, exchange the partial
@@ -260,14 +263,13 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         f32x16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = (e0[r * 64] + e1[r * 64]) * (1.0f / (DN_FS * DN_FS));
-        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile -----------------------------
+        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile = pixel (2 (r >> 3) + h, r & 7) -----
         dnh8 p_hi[2], p_lo[2];
         float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32 (16 terms), one fp64 add per tile
         unsigned passmask = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int mkey = 16 * (r >> 3) + 8 * h + (r & 7);
-            const bool valid = jx0 + mkey < g.W;
+            const bool valid = (jx0 + (r & 7) < g.W) && (jy0 + 2 * (r >> 3) + h < g.H);   // pixel (row 2 (r>>3) + h, column r & 7) of the tile
             bool pass;
             const float l = dn_logit(sc[r], mtq, bsq, pass);
             const float p = valid ? __expf(fminf(l - m_run, 0.f)) : 0.f;      // (the bound holds; the clamp is a seat belt)
@@ -400,7 +402,7 @@ int dense_splits(int B, const Grid& g) {
     // as still fit one round.  More query groups than CUs: the split count that wastes least of the last round
     // (384 groups: 1 split = 2 rounds of whole ranges, 2 splits = 3 rounds of half ranges).
     const int n = ((g.L + 63) / 64) * B;
-    const int n_tiles = g.H * ((g.W + KT - 1) / KT);
+    const int n_tiles = ((g.H + 3) / 4) * ((g.W + 7) / 8);
     int s;
     if (n <= 256) {
         s = 256 / n;
@@ -436,8 +438,8 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.B = B; a.g = g; a.wq = wq; a.x = x; a.rows_q = feat_rows(g.L); a.rows_x = feat_rows(g.N);
     a.mt = mt; a.bs = bs; a.b2p = b2p;
     a.splits = dense_splits(B, g);
-    a.tiles_per_row = (g.W + KT - 1) / KT;
-    a.n_tiles = g.H * a.tiles_per_row;
+    a.tiles_per_row = (g.W + DN_TW - 1) / DN_TW;
+    a.n_tiles = ((g.H + DN_TH - 1) / DN_TH) * a.tiles_per_row;
     a.tiles_per_split = (a.n_tiles + a.splits - 1) / a.splits;
     a.splits = (a.n_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
     const size_t rows = (size_t)dense_splits(B, g) * B * g.L;                // carve with the planned (upper) split count
