@@ -341,6 +341,16 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     const int b = (int)(ql / a.L);
     const int S2 = a.splits * 2;
     bool overflow = false;
+    // this query's features are needed only in step 2, but nothing stops the loads from flying during step 1
+    const int grp = lane >> 3, gl = lane & 7;
+    const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.L)) * DS;
+    float4 qv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int c4 = gl + 8 * u;                         // unconditional (clamped) loads, zeroed afterwards: a predicated
+        const float4 raw = *reinterpret_cast<const float4*>(qrow + 4 * (c4 < D / 4 ? c4 : D / 4 - 1));   // load serialises
+        qv[u] = (c4 < D / 4) ? raw : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // 1. gather candidate indices: lane <-> segment; the first four slots of a segment are fetched together with
     //    its count (one memory round trip), longer segments are rare and finished in a loop
@@ -349,7 +359,8 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         const int sgi = s0 + lane;
         const bool sv = sgi < S2;
         const size_t sg = ql * S2 + (sv ? sgi : 0);
-        int cnt = sv ? a.seg_cnt[sg] : 0;
+        int cnt = a.seg_cnt[sg];                           // sg is a valid slot also for idle lanes
+        if (!sv) cnt = 0;
         const int4 f4 = *reinterpret_cast<const int4*>(a.cand_idx + sg * a.capseg);
         const float4 g4 = *reinterpret_cast<const float4*>(a.cand_val + sg * a.capseg);
         if (cnt > a.capseg) { overflow = true; cnt = a.capseg; }
@@ -403,14 +414,6 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     }
 
     // 2. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation
-    const int grp = lane >> 3, gl = lane & 7;
-    const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.L)) * DS;
-    float4 qv[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        const int c4 = gl + 8 * u;
-        qv[u] = (c4 < D / 4) ? *reinterpret_cast<const float4*>(qrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     const float* xb = a.x + (size_t)b * a.rows_x * DS;
 #pragma unroll 2
     for (int c0 = 0; c0 < total; c0 += 8) {
