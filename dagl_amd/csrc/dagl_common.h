@@ -145,7 +145,11 @@ struct ThrFuse {
     float* thr_out = nullptr; float* bias_out = nullptr;     // [B,L] final values (written when part != null)
     float* theta_out = nullptr;             // [B,L] adaptive candidate threshold on the screened scores, or null
 };
-constexpr float SCREEN_DELTA = 0.004f;     // relative band of the bf16-screened scores (screen.hip)
+// Relative band of the bf16-screened scores (screen.hip): bf16 keeps 8 significant bits, so round-to-nearest moves a value
+// by up to 2^-8 relative (attained just above a power of two) and a product of two rounded operands by up to
+// (1 + 2^-8)^2 - 1 = 0.0078278; the fp32 accumulation of 196 non-negative terms adds < 196 * 2^-23 = 2.4e-5.  Every
+// user of the band (adaptive_theta_of, screen_theta_kernel, refine_kernel, dense_attend_kernel) takes this constant.
+constexpr float SCREEN_DELTA = 0.0079f;
 // theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32 rounding of
 // either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32)
 __host__ __device__ inline float adaptive_theta_of(float mt, float bs) {

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
     float m_run;
     {
-        const float sub = a.smax[qlin] * (1.0f / (1.0f - 0.004f)) * (1.0f + 1e-6f);
+        const float sub = a.smax[qlin] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
         bool ps;
         const float lub = dn_logit(sub, mtq, bsq, ps);
         m_run = fmaxf(lub, 0.f);                       // masked keys have l = 0

@@ -6,9 +6,11 @@
 // which keys MIGHT be kept; the kept scores themselves are then recomputed from the fp32 features with
 // fp64 accumulation (more accurate than an fp32 GEMM) by the refine kernels.  The screen is conservative, not
 // approximate:
-//   all features are >= 0 (post-ReLU), so with q~ = bf16(q), x~ = bf16(x) (round to nearest even, relative
-//   error <= 2^-9 each) every product and therefore the whole sum satisfies
-//        S~ = sum q~ x~  in  [S (1-d), S (1+d)],   d = 2^-8 + 2^-18 + accumulation slack  <  DELTA = 0.004
+//   all features are >= 0 (post-ReLU), so with q~ = bf16(q), x~ = bf16(x) (round to nearest even: 8 significant bits,
+//   relative error <= 2^-8 each, attained just above a power of two) every product and therefore the whole sum satisfies
+//        S~ = sum q~ x~  in  [S (1-d), S (1+d)],   d = (1 + 2^-8)^2 - 1 + accumulation slack = 0.00786  <  DELTA = 0.0079
+//   (tests/test_screen_band.py, tests/test_gpu_adversarial.py: rows built so that a true neighbour rounds down on every
+//   feature while its competitors round up)
 //   - adaptive mask:  a key with relu(S - mean*thr + bias) != 0 has S~ (1+DELTA) - mean*thr + bias > 0;
 //   - top-k: split the keys into >= k disjoint groups; the k-th largest group maximum of S~, theta, is
 //     attained by k distinct keys whose true S >= theta/(1+DELTA), hence tau_k(S) >= theta/(1+DELTA) and

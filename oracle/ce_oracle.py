@@ -118,36 +118,72 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     for n in range(B):                                                # dagl.py:245
         Wq = F.relu(F.linear(q_rows[n], P["fc1.0.weight"], P["fc1.0.bias"]))  # [L,196] :248
         X = F.relu(F.linear(k_rows[n], P["fc2.0.weight"], P["fc2.0.bias"]))   # [N,196] :249
-        S = Wq @ X.t()                                                         # [L,N]   :250
-        T = S.mean(dim=1) * thr[n] - bias[n]          # threshold of :256, per query
-        if mode == "topk":
-            kk = min(k, S.shape[1])
-            sel = torch.zeros_like(S)
-            sel.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
-            m, mb = sel, sel
-        else:
-            m = F.relu(S - S.mean(dim=1, keepdim=True) * thr[n].unsqueeze(1)
-                       + bias[n].unsqueeze(1))                                 # :256
-            mb = (m != 0).to(dtype)                                            # :257
-            if mode == "adaptive_topk":
-                kk = min(k, S.shape[1])
-                keep = torch.zeros_like(S)
-                keep.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
-                m, mb = m * keep, mb * keep
-        A = F.softmax(S * m * SOFTMAX_SCALE, dim=1) * mb                       # :259-261
-        agg = A @ v_rows[n]                                                    # [L,784] :263-264
-        z = F.fold(agg.t().unsqueeze(0), (H, W), (KSIZE, KSIZE),
-                   padding=fold_pad, stride=STRIDE_Q)                          # :265-267
+        z, c = _graph_core(Wq, X, thr[n], bias[n], v_rows[n], mode, k, H, W, fold_pad)
         outs.append(z / cnt)                                                   # :272
         if stages:
-            st["Wq"].append(Wq); st["X"].append(X); st["S"].append(S); st["T"].append(T)
-            st["deg"].append(mb.sum(dim=1)); st["rowsum"].append(A.sum(dim=1))
-            st["agg"].append(agg); st["mask_b"].append(mb)
+            st["Wq"].append(Wq); st["X"].append(X)
+            for k_ in ("S", "T", "deg", "rowsum", "agg", "mask_b"):
+                st[k_].append(c[k_])
     out = torch.cat(outs, dim=0)                                               # :274
     if stages:
         st = {k_: torch.stack(v) for k_, v in st.items()}
         st.update(b1=b1, b2=b2, thr=thr, bias=bias, cnt=cnt)
         return out, st
+    return out
+
+
+def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad):
+    """One sample of dagl.py:250-267 from its feature rows: similarity, mask, edge softmax, aggregate, fold
+    (not yet divided by the overlap count).  Returns (folded [1,c,H,W], dict of intermediates)."""
+    dtype = Wq.dtype
+    S = Wq @ X.t()                                                             # [L,N]   :250
+    T = S.mean(dim=1) * thr_n - bias_n                # threshold of :256, per query
+    if mode == "topk":
+        kk = min(k, S.shape[1])
+        sel = torch.zeros_like(S)
+        sel.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
+        m, mb = sel, sel
+    else:
+        m = F.relu(S - S.mean(dim=1, keepdim=True) * thr_n.unsqueeze(1)
+                   + bias_n.unsqueeze(1))                                      # :256
+        mb = (m != 0).to(dtype)                                                # :257
+        if mode == "adaptive_topk":
+            kk = min(k, S.shape[1])
+            keep = torch.zeros_like(S)
+            keep.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
+            m, mb = m * keep, mb * keep
+    A = F.softmax(S * m * SOFTMAX_SCALE, dim=1) * mb                           # :259-261
+    agg = A @ v_rows_n                                                         # [L,784] :263-264
+    z = F.fold(agg.t().unsqueeze(0), (H, W), (KSIZE, KSIZE),
+               padding=fold_pad, stride=STRIDE_Q)                              # :265-267
+    return z, dict(S=S, T=T, deg=mb.sum(dim=1), rowsum=A.sum(dim=1), agg=agg, mask_b=mb)
+
+
+def ce_core_oracle(wq_rows: torch.Tensor, x_rows: torch.Tensor, b2: torch.Tensor,
+                   thr: Optional[torch.Tensor], bias: Optional[torch.Tensor], *, mode: str = "adaptive",
+                   k: Optional[int] = None, dtype: torch.dtype = torch.float64, stages: bool = False):
+    """dagl.py:250-274 with the feature rows given (the boundary of ``dagl_ce_core_forward``):
+    wq_rows [B,L,196] = relu(fc1(query patches)), x_rows [B,N,196] = relu(fc2(key patches)), b2 [B,c,H,W]
+    the value map, thr / bias [B,L] the per-query heads (ignored by "topk").  Same loop body as
+    ``ce_forward_oracle`` (``_graph_core``)."""
+    B, c, H, W = b2.shape
+    b2 = b2.to(dtype)
+    v_rows = patch_rows(b2, KSIZE, STRIDE_KV)
+    fold_pad = same_pad(b2[:1, :1], KSIZE, STRIDE_KV)[1][0]
+    cnt = overlap_count(H, W, dtype, pad=fold_pad)
+    cnt = cnt + (cnt == 0).to(dtype)
+    L = wq_rows.shape[1]
+    zero = torch.zeros(L, dtype=dtype)
+    outs, sts = [], []
+    for n in range(B):
+        z, cst = _graph_core(wq_rows[n].to(dtype), x_rows[n].to(dtype),
+                             thr[n].to(dtype) if thr is not None else zero,
+                             bias[n].to(dtype) if bias is not None else zero, v_rows[n], mode, k, H, W, fold_pad)
+        outs.append(z / cnt)
+        sts.append(cst)
+    out = torch.cat(outs, dim=0)
+    if stages:
+        return out, {k_: torch.stack([s[k_] for s in sts]) for k_ in sts[0]}
     return out
 
 
