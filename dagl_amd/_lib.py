@@ -20,6 +20,7 @@ P = 784
 D = 196
 DS = 204
 ERR_WORKSPACE = -2
+ERR_UNSUPPORTED = -5
 N_STAGES = 8
 STAGE_NAMES = ("layout", "project", "thresholds", "screen_sample", "select", "edge_softmax", "gather", "fold")
 FLAG_EXACT_SCAN = 0x100
@@ -28,7 +29,7 @@ FLAG_DENSE_HINT = 0x400
 
 
 class DaglError(RuntimeError):
-    pass
+    code = 0          # the C ABI's status code when the error came from the library (include/dagl_ce.h DAGL_ERR_*)
 
 
 class CeInfo(C.Structure):
@@ -61,6 +62,11 @@ SIGNATURES = {
                                   C.POINTER(CeInfo)]),
     "dagl_ce_core_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dagl_ce_core_backward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 17 + [_sz]),
+    "dagl_ce_core_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
+    "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i] + [_vp] * 14 + [_sz]),
+    "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
+                           _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i]),
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
     "dagl_profile_destroy": (_i, [_vp]),
     "dagl_profile_reset": (_i, [_vp]),
@@ -72,7 +78,7 @@ SIGNATURES = {
     "dagl_ces_stage_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dagl_ces_stage_forward": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(CeWeights), _vp, _vp, _i, _i, _vp, _vp, _sz,
                                     C.POINTER(CeInfo), _vp]),
-    "dagl_ce_prologue": (_i, [_vp, _i, _i, _i] + [_vp] * 13),
+    "dagl_ce_prologue": (_i, [_vp, _i, _i, _i] + [_vp] * 14),
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
     "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -104,6 +110,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError => the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if torch.cuda.is_available():
+        # once per process: the kernels are gfx950 code objects (MFMA shapes, LDS-DMA, 160 KiB LDS)
+        rc = lib.dagl_device_check()
+        if rc != 0:
+            raise DaglError("dagl_amd needs an MI355X (gfx950): " + lib.dagl_last_error().decode("utf-8", "replace"))
     _lib = lib
     return lib
 
@@ -111,4 +122,6 @@ def load():
 def check(rc: int, what: str):
     if rc != 0:
         msg = load().dagl_last_error().decode("utf-8", "replace")
-        raise DaglError(f"{what} failed (code {rc}): {msg}")
+        err = DaglError(f"{what} failed (code {rc}): {msg}")
+        err.code = rc
+        raise err

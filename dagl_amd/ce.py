@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import MAX_TOPK, DaglError
+from ._lib import ERR_UNSUPPORTED, FAST_CAP, MAX_TOPK, DaglError
 from .synth import same_pad_amounts
 
 
@@ -58,6 +58,30 @@ class _GraphCore(torch.autograd.Function):
         return d_wq, d_x, d_b2, d_thr, d_bias, None, None, None, None, None, None
 
 
+class _GraphCoreDense(torch.autograd.Function):
+    """dagl.py:250-272 for dense neighbourhoods (adaptive masks that keep more keys than a fixed-width list holds --
+    default-initialised heads keep ~95 %): the dense formulation chunked over the queries, forward and backward on the
+    fp32 matrix cores (``dagl_ce_core_dense_forward`` / ``_backward``, dense_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, wq_rows, x_rows, b2, thr, bias, ws_f, ws_b, sink, want_info):
+        wq_rows, x_rows, b2 = wq_rows.contiguous(), x_rows.contiguous(), b2.contiguous()
+        thr_c, bias_c = thr.contiguous(), bias.contiguous()
+        out, saved = ops.ce_core_dense_forward(wq_rows, x_rows, b2, thr_c, bias_c, workspace=ws_f, want_info=want_info)
+        ctx.ws_b, ctx.thr_shape = ws_b, thr.shape
+        ctx.save_for_backward(wq_rows, x_rows, b2, thr_c, bias_c, saved["lse"], saved["mu"])
+        if sink is not None and saved["info"] is not None:
+            sink.update(saved["info"])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        wq_rows, x_rows, b2, thr, bias, lse, mu = ctx.saved_tensors
+        d_wq, d_x, d_b2, d_thr, d_bias = ops.ce_core_dense_backward(d_out.contiguous().float(), wq_rows, x_rows, b2, thr, bias,
+                                                                    dict(lse=lse, mu=mu), workspace=ctx.ws_b)
+        return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None
+
+
 class CE(nn.Module):
     def __init__(self, ksize=7, stride_1=4, stride_2=1, softmax_scale=10, shape=64, p_len=64, in_channels=64,
                  inter_channels=16, use_multiple_size=False, use_topk=False, add_SE=False, num_edge=50):
@@ -93,10 +117,29 @@ class CE(nn.Module):
         self._ws = ops.Workspace()
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
+        self._pack_epoch = 0           # bumped by invalidate_packed()
+        self._train_dense = False      # the differentiable path met dense neighbourhoods last time (dense_train.hip)
+        self._train_dense_calls = 0
         self._dense_hint = False       # the last adaptive call ended in the dense formulation: start there next time
         self._dense_calls = 0
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
+
+    def invalidate_packed(self):
+        """Forget the packed copies of fc1 / fc2 kept in the workspace.  The cache is keyed on the weights' storage and
+        torch's version counter, which every in-place op and optimizer step bumps -- but edits through ``.data``
+        (``w.data.mul_()``, EMA / clipping written that way) do NOT: call this after such an edit.  ``.to()`` / ``.cuda()`` /
+        ``.half()`` (``_apply``) and ``load_state_dict`` call it themselves."""
+        self._pack_epoch += 1
+        self._pack_key = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def extra_repr(self):
         return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
@@ -117,8 +160,8 @@ class CE(nn.Module):
     def _forward_train(self, b: torch.Tensor) -> torch.Tensor:
         """Differentiable path (DN_Gray/trainer.py:44-50): the convolutions and the two patch projections run as
         stock torch ops under autograd -- fc(unfold(.)) is a 7x7 convolution with the Linear weight viewed as
-        [196,16,7,7] (dagl.py:240-249) -- and the graph core (dagl.py:250-272) is the HIP op with its own backward.
-        Sparse neighbourhoods only (top-k modes, adaptive masks keeping <= 64 keys per query)."""
+        [196,16,7,7] (dagl.py:240-249) -- and the graph core (dagl.py:250-272) is a HIP op with its own backward: neighbour
+        lists (top-k modes, adaptive masks keeping <= 64 keys per query) or, for denser masks, the dense formulation."""
         b1, b2, thr, bias = self._prologue(b)
         B, _, H, W = b1.shape
         t, bo = same_pad_amounts(H, self.ksize, self.stride_1)
@@ -130,10 +173,27 @@ class CE(nn.Module):
         wq_rows = wq.permute(0, 2, 3, 1).reshape(B, -1, wq.shape[1])
         x_rows = x.permute(0, 2, 3, 1).reshape(B, -1, x.shape[1])
         info = {}
-        out = _GraphCore.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, self.select_k, self.scan == "exact",
-                               self._ws, self._ws_bwd, info)
-        self._pack_key = None          # the shared workspace was reused with another layout
-        self.last_info = info
+        self._pack_key = None          # the shared workspace is reused with another layout
+        out = None
+        if self.select_mode == "adaptive" and self._train_dense:
+            # the last training call met dense neighbourhoods: start in the dense formulation; every 16th call reads the
+            # degrees back (one host synchronisation) to notice when the masks have become sparse enough for the lists
+            self._train_dense_calls += 1
+            probe = self._train_dense_calls % 16 == 1
+            out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, probe)
+            if probe and 0 <= info.get("max_degree", -1) <= FAST_CAP:
+                self._train_dense = False
+        else:
+            try:
+                out = _GraphCore.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, self.select_k, self.scan == "exact",
+                                       self._ws, self._ws_bwd, info)
+            except DaglError as e:
+                if self.select_mode != "adaptive" or e.code != ERR_UNSUPPORTED:
+                    raise
+                self._train_dense, self._train_dense_calls = True, 1
+                out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, True)
+        if info:
+            self.last_info = info
         return out
 
     def forward(self, b: torch.Tensor) -> torch.Tensor:
@@ -148,15 +208,20 @@ class CE(nn.Module):
             b = b.float()
         elif in_dtype != torch.float32:
             raise DaglError(f"CE.forward: unsupported dtype {in_dtype}")
-        if torch.is_grad_enabled() and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
+        # differentiable route: a gradient can reach the input, or the module is training its own parameters.  An eval()
+        # module fed a constant input stays on the inference path even when autograd is on (the reference's test loop
+        # relies on the long-dead ``volatile`` flag, DN_Gray/trainer.py:132, i.e. runs with autograd enabled)
+        if torch.is_grad_enabled() and (b.requires_grad or
+                                        (self.training and any(p.requires_grad for p in self.parameters()))):
             out = self._forward_train(b.contiguous())
             return out if in_dtype == torch.float32 else out.to(in_dtype)
         params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
         # the packed copies of fc1/fc2 live in this module's private workspace: skip repacking while neither the
         # weights (torch bumps ._version on every in-place update) nor the call geometry changed
-        key = (tuple(b.shape), self.select_mode, self.select_k, self.scan,
+        wsb = self._ws.peek(b.device)
+        key = (tuple(b.shape), self.select_mode, self.select_k, self.scan, self._pack_epoch,
                tuple((params[n].data_ptr(), params[n]._version) for n in ("fc1.0.weight", "fc2.0.weight")),
-               self._ws.buf.data_ptr() if self._ws.buf is not None else 0)
+               wsb.data_ptr() if wsb is not None else 0)
         # dense regime: the edge statistics (and with them a host synchronisation) are only fetched every 16th call, to
         # notice when the neighbourhoods have become sparse again
         hint = self._dense_hint and self.select_mode == "adaptive" and self.scan != "exact"
@@ -166,7 +231,7 @@ class CE(nn.Module):
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
                                          dense_hint=hint, want_info=want_info)
-        self._pack_key = key[:-1] + (self._ws.buf.data_ptr(),)
+        self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
         if info is not None:
             self.last_info = info
             if self.select_mode == "adaptive":

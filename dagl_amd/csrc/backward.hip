@@ -331,6 +331,19 @@ __global__ __launch_bounds__(256) void dwq_gather_kernel(BwdArgs a) {
     for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) a.dwq_rows[ql * D + c] = acc[u]; }
 }
 
+int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, float* dagg) {
+    const size_t items = (size_t)g.L * KS * KS;
+    hipLaunchKernelGGL(unfold_dout_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s, g, dout, dagg);
+    DAGL_LAUNCH_CHECK("unfold_dout_kernel");
+    return DAGL_OK;
+}
+
+int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar) {
+    hipLaunchKernelGGL(dxbar_kernel, dim3(B), dim3(256), 0, s, L, wq_rows, dmu, dxbar);
+    DAGL_LAUNCH_CHECK("dxbar_kernel");
+    return DAGL_OK;
+}
+
 static int key_bits(size_t n_keys) {             // radix bits that cover 0..n_keys (n_keys itself = the invalid marker)
     int bits = 1;
     while (((size_t)1 << bits) <= n_keys) ++bits;

@@ -110,7 +110,11 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     p.s_steps = (g.N + SKEYS - 1) / SKEYS;
     {
         const int nqg = (g.L + 255) / 256;
+#ifdef DAGL_ABLATION
         static const int target = [] { const char* e = getenv("DAGL_SCREEN_BLOCKS"); return e ? atoi(e) : 512; }();
+#else
+        constexpr int target = 512;               // two resident rounds of 256 blocks
+#endif
         int sp = (target + nqg * B - 1) / (nqg * B);
         const int mx = (p.s_steps + 3) / 4;
         if (sp > mx) sp = mx;
@@ -413,7 +417,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
         sc.cand_val = at<float>(ws, p.o_scandv);
         redo = at<int32_t>(ws, p.o_redo);
+#ifdef DAGL_ABLATION
         { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
+#endif
         // most queries keep more keys than the screen has candidate slots for: the dense regime.  Lists are pointless
         // there; stream the dense formulation instead (dense.hip).  Reached after the screen found out, or directly when
         // the caller passes DAGL_FLAG_DENSE_HINT (its previous call on this module ended here): always correct, only
@@ -424,8 +430,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if (info) { info->required_bytes = (int64_t)off; info->path = 4; }
             if (core) {
                 if (info) info->required_bytes = -1;
-                set_error("dagl_ce_core_forward: dense neighbourhoods (most queries keep more than %d keys) have no backward in this build",
-                          DAGL_FAST_CAP);
+                set_error("dagl_ce_core_forward: dense neighbourhoods (most queries keep more than %d keys) do not fit fixed-width lists: "
+                          "use dagl_ce_core_dense_forward", DAGL_FAST_CAP);
                 return DAGL_ERR_UNSUPPORTED;
             }
             if (ws_bytes < off) {
@@ -532,8 +538,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if (info) { info->required_bytes = (int64_t)off; info->path = 1; }
                 if (core) {
                     if (info) info->required_bytes = -1;
-                    set_error("dagl_ce_core_forward: dense neighbourhoods (max degree %lld > %d) have no backward in this build",
-                              (long long)hstats[1], DAGL_FAST_CAP);
+                    set_error("dagl_ce_core_forward: dense neighbourhoods (max degree %lld > %d) do not fit fixed-width lists: "
+                              "use dagl_ce_core_dense_forward", (long long)hstats[1], DAGL_FAST_CAP);
                     return DAGL_ERR_UNSUPPORTED;
                 }
                 if (ws_bytes < off) {
@@ -807,20 +813,72 @@ int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, co
     return launch_core_backward(s, a, w, dxbar, d_b2);
 }
 
+size_t dagl_ce_core_dense_workspace_bytes(int B, int H, int W, int backward) {
+    if (B < 1 || H < 1 || W < 1) return 0;
+    return dense_train_workspace_bytes(B, make_grid(H, W), backward != 0);
+}
+
+int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
+                               const float* thr, const float* bias, float* out, float* lse, float* mu, void* workspace,
+                               size_t ws_bytes, dagl_ce_info* info) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && thr && bias && out && lse && mu,
+                 "dagl_ce_core_dense_forward: bad argument");
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_dense_forward: workspace must be 256-byte aligned");
+    const Grid g = make_grid(H, W);
+    hipStream_t s = (hipStream_t)stream;
+    if (info) { info->required_bytes = (int64_t)dense_train_workspace_bytes(B, g, false); info->total_edges = -1;
+                info->max_degree = -1; info->redone_queries = -1; info->path = 5; }
+    // the two statistics words live at the very end of the caller's buffer (past the plan)
+    const size_t need = dense_train_workspace_bytes(B, g, false) + 256;
+    if (ws_bytes < need) { set_error("dagl_ce_core_dense_forward: workspace %zu B < required %zu B", ws_bytes, need);
+                           if (info) info->required_bytes = (int64_t)need; return DAGL_ERR_WORKSPACE; }
+    int64_t* stats = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + need - 256);
+    int rc = launch_dense_train_forward(s, B, g, wq_rows, x_rows, b2, thr, bias, out, lse, mu, workspace, need - 256,
+                                        info ? stats : nullptr);
+    if (rc) return rc;
+    if (info) {
+        int64_t hs[2] = {0, 0};
+        if ((rc = read_back(s, stats, 2, hs))) return rc;
+        info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1];
+    }
+    return DAGL_OK;
+}
+
+int dagl_ce_core_dense_backward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
+                                const float* thr, const float* bias, const float* lse, const float* mu, const float* d_out,
+                                float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias, void* workspace,
+                                size_t ws_bytes) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && thr && bias && lse && mu && d_out && d_wq_rows &&
+                 d_x_rows && d_b2 && d_thr && d_bias, "dagl_ce_core_dense_backward: bad argument");
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_dense_backward: workspace must be 256-byte aligned");
+    return launch_dense_train_backward((hipStream_t)stream, B, make_grid(H, W), wq_rows, x_rows, b2, thr, bias, lse, mu, d_out,
+                                       d_wq_rows, d_x_rows, d_b2, d_thr, d_bias, workspace, ws_bytes);
+}
+
+int dagl_gemm_f32(void* stream, int batch, int M, int N, int K, const float* A, long long lda, long long stride_a, int a_k_contiguous,
+                  const float* B, long long ldb, long long stride_b, int b_k_contiguous, float* C, long long ldc, long long stride_c,
+                  float alpha, float beta, const float* bias, int relu) {
+    DAGL_REQUIRE(batch >= 1 && M >= 0 && N >= 0 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "dagl_gemm_f32: bad shape");
+    Gemm32 g;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.A = A; g.lda = lda; g.sA = stride_a; g.a_kc = a_k_contiguous;
+    g.B = B; g.ldb = ldb; g.sB = stride_b; g.b_kc = b_k_contiguous; g.C = C; g.ldc = ldc; g.sC = stride_c;
+    g.alpha = alpha; g.beta = beta; g.bias = bias; g.relu = relu;
+    return launch_gemm32((hipStream_t)stream, g);
+}
+
 int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,
                      const float* theta_w, const float* theta_b, const float* thr_w, const float* thr_b,
-                     const float* bias_w, const float* bias_b, float* b1_nhwc, float* b2_nhwc, float* thr, float* bias) {
+                     const float* bias_w, const float* bias_b, float* b1_nhwc, float* b2_nhwc, float* thr, float* bias,
+                     float* scratch) {
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && x && g_w && g_b && theta_w && theta_b && b1_nhwc && b2_nhwc,
                  "dagl_ce_prologue: bad argument");
-    if (thr || bias) DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b, "dagl_ce_prologue: thr/bias heads incomplete");
+    if (thr || bias)
+        DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b && scratch,
+                     "dagl_ce_prologue: thr/bias heads incomplete (weights, outputs and 8*B*L floats of scratch)");
     hipStream_t s = (hipStream_t)stream;
     const Grid g = make_grid(H, W);
-    float* part = nullptr;                                   // stream-ordered scratch of the thr/bias heads
-    if (thr) DAGL_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)8 * B * g.L * sizeof(float), s));
-    const int rc = launch_prologue(s, B, g, x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, b1_nhwc, b2_nhwc,
-                                   thr, bias, nullptr, nullptr, part);
-    if (part) DAGL_HIP_TRY(hipFreeAsync(part, s));
-    return rc;
+    return launch_prologue(s, B, g, x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, b1_nhwc, b2_nhwc,
+                           thr, bias, nullptr, nullptr, scratch);
 }
 
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {

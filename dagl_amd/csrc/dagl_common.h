@@ -307,6 +307,28 @@ size_t edge_rowbuf_floats(size_t n_edges);
 size_t edge_part_floats(size_t n_edges);
 int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, float* dxbar_ws, float* db2_nchw);
 int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h);
+
+// batched fp32 GEMM on the matrix cores (gemm32.hip): C[b] = alpha * A[b] B[b] + beta * C[b] (+ bias[n], relu)
+struct Gemm32 {
+    int M, N, K, batch;
+    const float* A; long long lda, sA; int a_kc;      // a_kc: element (m,k) at A[m*lda + k], else at A[k*lda + m]
+    const float* B; long long ldb, sB; int b_kc;      // b_kc: element (k,n) at B[n*ldb + k], else at B[k*ldb + n]
+    float* C; long long ldc, sC;
+    float alpha, beta;
+    const float* bias; int relu;
+};
+int launch_gemm32(hipStream_t s, const Gemm32& g);
+
+int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, float* dagg);
+int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar);
+// dense neighbourhoods under autograd (dense_train.hip): the dense formulation chunked over queries
+size_t dense_train_workspace_bytes(int B, const Grid& g, bool backward);
+int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
+                               const float* thr, const float* bias, float* out, float* lse /*[B,L,2]*/, float* mu /*[B,L]*/,
+                               void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */);
+int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
+                                const float* thr, const float* bias, const float* lse, const float* mu, const float* dout,
+                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes);
 int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum);              // per-lane list length used for a requested k (4/8/16/32)
 
 }  // namespace dagl

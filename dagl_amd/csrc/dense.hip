@@ -434,7 +434,10 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
                         float* rowsum_out, int64_t* stats) {
     DenseArgs a;
     a.smax = smax;
+    a.variant = 0;
+#ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
     { static const int var = getenv("DAGL_DENSE_VARIANT") ? atoi(getenv("DAGL_DENSE_VARIANT")) : 0; a.variant = var; }
+#endif
     a.B = B; a.g = g; a.wq = wq; a.x = x; a.rows_q = feat_rows(g.L); a.rows_x = feat_rows(g.N);
     a.mt = mt; a.bs = bs; a.b2p = b2p;
     a.splits = dense_splits(B, g);

@@ -1,0 +1,363 @@
+// Dense neighbourhoods under autograd: forward + backward of the graph core (DN_Gray/model/dagl.py:250-272) when a
+// query keeps more keys than a fixed-width list holds (default-initialised thr/bias heads keep ~95 % of the keys: the
+// regime a training run starts in).  This is the reference's dense formulation -- S = Wq X^T, mask, softmax over ALL
+// keys, A V -- and exactly what autograd derives from it, chunked over the queries so that the [L,N] matrices exist only
+// one chunk at a time:
+//
+//   forward, per chunk of queries          S = Wq X^T                               gemm32  (dagl.py:250)
+//                                          A = softmax(10 S m) mask_b, m = relu(..)  dense_softmax_fwd_kernel (:256-261)
+//                                          agg = A V                                gemm32  (:263-264),  then fold (:265-272)
+//   backward, per chunk                    d A = d agg V^T                          gemm32
+//                                          S recomputed; c = sum_j A d A; d l = A (d A - c);
+//                                          d S = 10 (m + S) d l, d m = 10 S d l       dense_softmax_bwd_kernel
+//                                          d Wq = d S X,  d X += d S^T Wq,  d V += A^T d agg        gemm32 x 3
+//   plus the dense mean term of dagl.py:256: mu_l = Wq_l . Xbar  ->  d Wq_l += d mu_l Xbar, d X_j += (sum_l d mu_l Wq_l)/N.
+// V = the unfolded value patches [N,784] of one image (materialised here, as the reference does at :224-231; the
+// inference paths never do); d V is folded back onto the 16-channel map by a gather (49 taps per pixel, no atomics).
+// All sums run in a fixed order: bit-reproducible gradients.
+#include "dagl_common.h"
+
+namespace dagl {
+
+constexpr size_t DT_CHUNK_FLOATS = (size_t)128 << 20;      // floats per [chunk, N] matrix (512 MiB)
+
+struct DtPlan {
+    int Lc, n_chunks, Bc;            // queries per chunk, chunks per image, images per group
+    long long ldn;                   // leading dimension of the [L,N] chunk matrices (N rounded up to 32)
+    size_t o_sbuf, o_abuf, o_vrows, o_dvrows, o_dagg, o_agg, o_b2p, o_colsum, o_mt, o_dmu, o_dxbar, o_deg, o_rowsum, o_end;
+};
+
+static DtPlan dt_plan(int B, const Grid& g, bool backward) {
+    DtPlan p;
+    p.ldn = (g.N + 31) / 32 * 32;
+    long long lc = (long long)(DT_CHUNK_FLOATS / (size_t)p.ldn) / 128 * 128;
+    if (lc < 128) lc = 128;
+    p.Lc = (int)(lc < g.L ? lc : g.L);
+    p.n_chunks = (g.L + p.Lc - 1) / p.Lc;
+    p.Bc = 1;
+    if (p.n_chunks == 1) {
+        long long bc = (long long)(DT_CHUNK_FLOATS / ((size_t)p.Lc * p.ldn));
+        p.Bc = (int)(bc < 1 ? 1 : (bc > B ? B : bc));
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t chunk = (size_t)p.Bc * p.Lc * p.ldn * sizeof(float);
+    p.o_sbuf = carve(chunk);
+    p.o_abuf = backward ? carve(chunk) : 0;
+    p.o_vrows = carve((size_t)p.Bc * g.N * P * sizeof(float));
+    p.o_dvrows = backward ? carve((size_t)p.Bc * g.N * P * sizeof(float)) : 0;
+    p.o_dagg = backward ? carve((size_t)B * g.L * P * sizeof(float)) : 0;
+    p.o_agg = backward ? 0 : carve((size_t)B * g.L * P * sizeof(float));
+    p.o_b2p = carve((size_t)B * g.Hp * g.Wp * CH * sizeof(float));
+    p.o_colsum = carve((size_t)B * DS * sizeof(double));
+    p.o_mt = carve((size_t)B * g.L * sizeof(float));
+    p.o_dmu = carve((size_t)B * g.L * sizeof(float));
+    p.o_dxbar = carve((size_t)B * D * sizeof(float));
+    p.o_deg = carve((size_t)B * g.L * sizeof(int32_t));
+    p.o_rowsum = carve((size_t)B * g.L * sizeof(float));
+    p.o_end = off;
+    return p;
+}
+
+size_t dense_train_workspace_bytes(int B, const Grid& g, bool backward) { return dt_plan(B, g, backward).o_end; }
+
+template <class T>
+static T* dt_at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+// mu[b,l] = Wq_l . colsum / N (fp64 dot, as query_thresholds_kernel), mt = mu * thr: one wave per query, dense rows
+__global__ __launch_bounds__(256) void dt_thresholds_kernel(int L, int N, const float* __restrict__ wq_rows,
+                                                            const double* __restrict__ colsum, const float* __restrict__ thr,
+                                                            float* __restrict__ mt, float* __restrict__ mu) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const float* q = wq_rows + ((size_t)b * L + l) * D;
+    const double* cs = colsum + (size_t)b * DS;
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) acc += (double)q[d] * cs[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const float mean = (float)(acc / (double)N);
+        mu[(size_t)b * L + l] = mean;
+        mt[(size_t)b * L + l] = mean * thr[(size_t)b * L + l];
+    }
+}
+
+__device__ __forceinline__ double dt_block_sum(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ __forceinline__ float dt_block_max(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__device__ __forceinline__ float dt_logit(float s, float mtq, float bsq, bool& pass, float& m) {
+    m = (s - mtq) + bsq;                               // expression order of dagl.py:256
+    pass = m > 0.f;
+    return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;       // (S m) 10, dagl.py:259-260
+}
+
+// one block per query row: S row -> A row in place (dagl.py:256-261); saves the softmax shift and denominator
+__global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(int N, long long ldn, int L, int l0, int Lc,
+                                                                float* __restrict__ sbuf, const float* __restrict__ mt,
+                                                                const float* __restrict__ bs, float* __restrict__ lse,
+                                                                int32_t* __restrict__ deg, float* __restrict__ rowsum, int b0) {
+    __shared__ double shd[4];
+    __shared__ float shf[4];
+    const int lr = blockIdx.x, bi = blockIdx.y;
+    const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
+    float* row = sbuf + ((size_t)bi * Lc + lr) * ldn;
+    const float mtq = mt[ql], bsq = bs[ql];
+    float mx = 0.f;                                    // masked keys have logit 0 (N > deg) -- and if all pass, max >= ... handled below
+    int cnt = 0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        cnt += pass ? 1 : 0;
+        mx = pass ? fmaxf(mx, l) : mx;
+    }
+    // (logits of passing keys are positive: S > 0 and m > 0, or zero when S = 0; so max over all keys = max(0, ...) either way)
+    const float M = dt_block_max(mx, shf);
+    double z = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        z += (double)expf(l - M);
+    }
+    const double Z = dt_block_sum(z, shd);
+    const float invz = (float)(1.0 / Z);
+    double rs = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        const float a = pass ? expf(l - M) * invz : 0.f;
+        row[j] = a;
+        rs += (double)a;
+    }
+    for (int j = N + threadIdx.x; j < ldn; j += 256) row[j] = 0.f;           // pad columns: zero weights
+    const double RS = dt_block_sum(rs, shd);
+    const double C = dt_block_sum((double)cnt, shd);
+    if (threadIdx.x == 0) {
+        lse[2 * ql] = M; lse[2 * ql + 1] = (float)Z;
+        deg[ql] = (int32_t)C; rowsum[ql] = (float)RS;
+    }
+}
+
+// one block per query row: sbuf = recomputed S row, abuf = d A row  ->  sbuf = d S row, abuf = A row
+__global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long ldn, int L, int l0, int Lc,
+                                                                float* __restrict__ sbuf, float* __restrict__ abuf,
+                                                                const float* __restrict__ mt, const float* __restrict__ bs,
+                                                                const float* __restrict__ lse, const float* __restrict__ mu,
+                                                                const float* __restrict__ thr, float* __restrict__ dthr,
+                                                                float* __restrict__ dbias, float* __restrict__ dmu, int b0) {
+    __shared__ double shd[4];
+    const int lr = blockIdx.x, bi = blockIdx.y;
+    const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
+    float* srow = sbuf + ((size_t)bi * Lc + lr) * ldn;
+    float* arow = abuf + ((size_t)bi * Lc + lr) * ldn;
+    const float mtq = mt[ql], bsq = bs[ql];
+    const float M = lse[2 * ql], invz = 1.0f / lse[2 * ql + 1];
+    double c = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        const float a = pass ? expf(l - M) * invz : 0.f;
+        c += (double)a * (double)arow[j];
+    }
+    const float cf = (float)dt_block_sum(c, shd);
+    double sdm = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float s = srow[j];
+        const float l = dt_logit(s, mtq, bsq, pass, m);
+        const float a = pass ? expf(l - M) * invz : 0.f;
+        const float dl = a * (arow[j] - cf);           // non-neighbours: A = 0 and their logit is the constant 0
+        srow[j] = SOFTMAX_SCALE * (m + s) * dl;        // d S  (a = 0 -> 0)
+        arow[j] = a;
+        sdm += (double)(SOFTMAX_SCALE * s * dl);       // d m
+    }
+    for (int j = N + threadIdx.x; j < ldn; j += 256) { srow[j] = 0.f; arow[j] = 0.f; }
+    const float S = (float)dt_block_sum(sdm, shd);
+    if (threadIdx.x == 0) {
+        dbias[ql] = S;
+        dthr[ql] = -mu[ql] * S;
+        dmu[ql] = -thr[ql] * S;
+    }
+}
+
+// out[r, c] += rs[r] * v[c] * scale   (the rank-one terms of the dense row mean)
+__global__ void dt_rank1_add_kernel(size_t rows, int rows_per_batch, const float* __restrict__ rs, const float* __restrict__ vf,
+                                    const double* __restrict__ vd, int vstride, float scale, float* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * D) return;
+    const size_t r = t / D; const int c = (int)(t - r * D);
+    const size_t b = r / rows_per_batch;
+    const float v = vf ? vf[b * vstride + c] : (float)(vd[b * vstride + c] * (double)scale);
+    out[t] += (rs ? rs[r] : 1.0f) * (vf ? v * scale : v);
+}
+
+// d b2[b,c,y,x] = sum over the 49 keys whose window covers (y,x) of d V[key][(kh,kw,c)]; thread = pixel, fixed order
+__global__ __launch_bounds__(256) void dt_fold_dv_kernel(Grid g, int nb, const float* __restrict__ dv, float* __restrict__ db2) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nb * g.N) return;
+    const size_t b = t / g.N; const size_t r = t - b * g.N;
+    const int y = (int)(r / g.W), x = (int)(r - (size_t)y * g.W);
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < KS; ++kh) {
+        const int jy = y + 3 - kh;
+        if (jy < 0 || jy >= g.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int jx = x + 3 - kw;
+            if (jx < 0 || jx >= g.W) continue;
+            const float4* row = reinterpret_cast<const float4*>(dv + ((b * g.N + (size_t)jy * g.W + jx) * P + (kh * KS + kw) * CH));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float4 v = row[q]; acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w; }
+        }
+    }
+    float* o = db2 + (b * CH * g.H + y) * g.W + x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        o[(size_t)(4 * q + 0) * g.N] = acc[q].x; o[(size_t)(4 * q + 1) * g.N] = acc[q].y;
+        o[(size_t)(4 * q + 2) * g.N] = acc[q].z; o[(size_t)(4 * q + 3) * g.N] = acc[q].w;
+    }
+}
+
+static Gemm32 dt_gemm(int M, int N, int K, int batch, const float* A, long long lda, long long sA, int a_kc, const float* Bm,
+                      long long ldb, long long sB, int b_kc, float* C, long long ldc, long long sC, float beta) {
+    Gemm32 g;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.A = A; g.lda = lda; g.sA = sA; g.a_kc = a_kc;
+    g.B = Bm; g.ldb = ldb; g.sB = sB; g.b_kc = b_kc; g.C = C; g.ldc = ldc; g.sC = sC;
+    g.alpha = 1.0f; g.beta = beta; g.bias = nullptr; g.relu = 0;
+    return g;
+}
+
+static int dt_prepare(hipStream_t s, int B, const Grid& g, const DtPlan& p, void* ws, const float* wq_rows, const float* x_rows,
+                      const float* b2, const float* thr, float* mu) {
+    int rc;
+    if ((rc = launch_pad_nhwc(s, B, g.H, g.W, b2, dt_at<float>(ws, p.o_b2p)))) return rc;
+    if ((rc = launch_colsum_rows(s, B, g.N, x_rows, dt_at<double>(ws, p.o_colsum)))) return rc;
+    hipLaunchKernelGGL(dt_thresholds_kernel, dim3((g.L + 3) / 4, B), dim3(256), 0, s, g.L, g.N, wq_rows,
+                       dt_at<double>(ws, p.o_colsum), thr, dt_at<float>(ws, p.o_mt), mu);
+    DAGL_LAUNCH_CHECK("dt_thresholds_kernel");
+    return DAGL_OK;
+}
+
+int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
+                               const float* thr, const float* bias, float* out, float* lse, float* mu, void* ws, size_t ws_bytes,
+                               int64_t* stats_dev) {
+    const DtPlan p = dt_plan(B, g, false);
+    if (ws_bytes < p.o_end) { set_error("dense forward: workspace %zu B < required %zu B", ws_bytes, p.o_end); return DAGL_ERR_WORKSPACE; }
+    int rc;
+    if ((rc = dt_prepare(s, B, g, p, ws, wq_rows, x_rows, b2, thr, mu))) return rc;
+    float* sbuf = dt_at<float>(ws, p.o_sbuf);
+    float* vrows = dt_at<float>(ws, p.o_vrows);
+    float* agg = dt_at<float>(ws, p.o_agg);
+    const float* b2p = dt_at<float>(ws, p.o_b2p);
+    const float* mt = dt_at<float>(ws, p.o_mt);
+    int32_t* deg = dt_at<int32_t>(ws, p.o_deg);
+    float* rowsum = dt_at<float>(ws, p.o_rowsum);
+    for (int b0 = 0; b0 < B; b0 += p.Bc) {
+        const int nb = (B - b0 < p.Bc) ? B - b0 : p.Bc;
+        if ((rc = launch_unfold_values(s, nb, g, b2p + (size_t)b0 * g.Hp * g.Wp * CH, vrows))) return rc;
+        for (int l0 = 0; l0 < g.L; l0 += p.Lc) {
+            const int lc = (g.L - l0 < p.Lc) ? g.L - l0 : p.Lc;
+            // S = Wq X^T
+            if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 1,
+                                               x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1,
+                                               sbuf, p.ldn, (long long)p.Lc * p.ldn, 0.f)))) return rc;
+            hipLaunchKernelGGL(dense_softmax_fwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, mt, bias,
+                               lse, deg, rowsum, b0);
+            DAGL_LAUNCH_CHECK("dense_softmax_fwd_kernel");
+            // agg = A V
+            if ((rc = launch_gemm32(s, dt_gemm(lc, P, g.N, nb, sbuf, p.ldn, (long long)p.Lc * p.ldn, 1,
+                                               vrows, P, (long long)g.N * P, 0,
+                                               agg + ((size_t)b0 * g.L + l0) * P, P, (long long)g.L * P, 0.f)))) return rc;
+        }
+    }
+    if ((rc = launch_fold(s, B, g, agg, out))) return rc;
+    if (stats_dev) if ((rc = launch_degree_stats(s, (size_t)B * g.L, deg, stats_dev))) return rc;
+    return DAGL_OK;
+}
+
+int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
+                                const float* thr, const float* bias, const float* lse, const float* mu_saved, const float* dout,
+                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes) {
+    const DtPlan p = dt_plan(B, g, true);
+    if (ws_bytes < p.o_end) { set_error("dense backward: workspace %zu B < required %zu B", ws_bytes, p.o_end); return DAGL_ERR_WORKSPACE; }
+    int rc;
+    float* mu = dt_at<float>(ws, p.o_rowsum);                    // recomputed with the thresholds (same values as the forward's)
+    if ((rc = dt_prepare(s, B, g, p, ws, wq_rows, x_rows, b2, thr, mu))) return rc;
+    (void)mu_saved;
+    float* sbuf = dt_at<float>(ws, p.o_sbuf);
+    float* abuf = dt_at<float>(ws, p.o_abuf);
+    float* vrows = dt_at<float>(ws, p.o_vrows);
+    float* dvrows = dt_at<float>(ws, p.o_dvrows);
+    float* dagg = dt_at<float>(ws, p.o_dagg);
+    const float* b2p = dt_at<float>(ws, p.o_b2p);
+    const float* mt = dt_at<float>(ws, p.o_mt);
+    float* dmu = dt_at<float>(ws, p.o_dmu);
+    float* dxbar = dt_at<float>(ws, p.o_dxbar);
+    const double* colsum = dt_at<double>(ws, p.o_colsum);
+    if ((rc = launch_unfold_dout(s, B, g, dout, dagg))) return rc;
+    for (int b0 = 0; b0 < B; b0 += p.Bc) {
+        const int nb = (B - b0 < p.Bc) ? B - b0 : p.Bc;
+        if ((rc = launch_unfold_values(s, nb, g, b2p + (size_t)b0 * g.Hp * g.Wp * CH, vrows))) return rc;
+        for (int l0 = 0; l0 < g.L; l0 += p.Lc) {
+            const int lc = (g.L - l0 < p.Lc) ? g.L - l0 : p.Lc;
+            const float* wq_c = wq_rows + ((size_t)b0 * g.L + l0) * D;
+            const float* dagg_c = dagg + ((size_t)b0 * g.L + l0) * P;
+            const long long sS = (long long)p.Lc * p.ldn;
+            const float beta = (l0 == 0) ? 0.f : 1.f;
+            // d A = d agg V^T ; S = Wq X^T
+            if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, P, nb, dagg_c, P, (long long)g.L * P, 1, vrows, P, (long long)g.N * P, 1,
+                                               abuf, p.ldn, sS, 0.f)))) return rc;
+            if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_c, D, (long long)g.L * D, 1,
+                                               x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1, sbuf, p.ldn, sS, 0.f)))) return rc;
+            hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias,
+                               lse, mu, thr, dthr, dbias, dmu, b0);
+            DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+            // d Wq = d S X
+            if ((rc = launch_gemm32(s, dt_gemm(lc, D, g.N, nb, sbuf, p.ldn, sS, 1, x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 0,
+                                               dwq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 0.f)))) return rc;
+            // d X (+)= d S^T Wq
+            if ((rc = launch_gemm32(s, dt_gemm(g.N, D, lc, nb, sbuf, p.ldn, sS, 0, wq_c, D, (long long)g.L * D, 0,
+                                               dx_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, beta)))) return rc;
+            // d V (+)= A^T d agg
+            if ((rc = launch_gemm32(s, dt_gemm(g.N, P, lc, nb, abuf, p.ldn, sS, 0, dagg_c, P, (long long)g.L * P, 0,
+                                               dvrows, P, (long long)g.N * P, beta)))) return rc;
+        }
+        {
+            const size_t n = (size_t)nb * g.N;
+            hipLaunchKernelGGL(dt_fold_dv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, nb, dvrows,
+                               db2 + (size_t)b0 * CH * g.N);
+            DAGL_LAUNCH_CHECK("dt_fold_dv_kernel");
+        }
+    }
+    // dense mean term: d Wq_l += d mu_l Xbar ;  d X_j += (sum_l d mu_l Wq_l) / N
+    {
+        const size_t nq = (size_t)B * g.L * D, nk = (size_t)B * g.N * D;
+        hipLaunchKernelGGL(dt_rank1_add_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (size_t)B * g.L, g.L, dmu, nullptr,
+                           colsum, DS, 1.0f / (float)g.N, dwq_rows);
+        DAGL_LAUNCH_CHECK("dt_rank1_add_kernel");
+        if ((rc = launch_dxbar(s, B, g.L, wq_rows, dmu, dxbar))) return rc;
+        hipLaunchKernelGGL(dt_rank1_add_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (size_t)B * g.N, g.N, nullptr, dxbar,
+                           nullptr, D, 1.0f / (float)g.N, dx_rows);
+        DAGL_LAUNCH_CHECK("dt_rank1_add_kernel");
+    }
+    return DAGL_OK;
+}
+
+}  // namespace dagl

@@ -1,0 +1,156 @@
+// Batched fp32 GEMM on the matrix cores: C[b] = alpha * A[b] B[b] + beta * C[b] (+ bias, relu), v_mfma_f32_32x32x2_f32.
+//
+// The training path's dense stages (dense_train.hip: S = Wq X^T, agg = A V, d A = d agg V^T, d Wq = d S X,
+// d X = d S^T Wq, d V = A^T d agg -- the reference's torch.matmul / torch.mm of DN_Gray/model/dagl.py:250,263 and what
+// autograd derives from them) are plain matrix products over operands that already sit in HBM in row-major form, so they
+// share this one kernel.  The f32-input MFMA is bitwise an fmaf chain along K (one rounding per product, no wider
+// accumulator): the numerics class of the reference's own fp32 GEMMs, which is what the gradient parity tests need.
+//
+// Tile 128 x 128 x 16, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles; operands staged K-major in LDS
+// (As[k][m], Bs[k][n]) so that a fragment read is 32 consecutive words per half-wave (conflict-free); global tiles are
+// fetched as 16-byte vectors along whichever dimension is contiguous in memory and double-buffered through registers.
+// No split-K, no atomics: deterministic.  Either operand may be stored "K-contiguous" (row-major M x K / N x K) or
+// "K-major" (K x M / K x N), which covers NN, NT, TN without copies.
+#include "dagl_common.h"
+
+namespace dagl {
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 16, G_PAD = 4;
+
+// one operand tile: 128 (rows = M or N index) x 16 (k) floats -> two float4 per thread
+template <bool KC>
+struct TileLoader {
+    const float* base; long long ld; int rows, K, row0; bool vec;
+    float4 v[2];
+    __device__ __forceinline__ void load(int k0, int tid) {
+        if (KC) {                                   // element (r, k) at base[r * ld + k]: vectors along k
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = row0 + (tid >> 2) + 64 * u, k = k0 + 4 * (tid & 3);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < rows) {
+                    const float* p = base + (long long)r * ld + k;
+                    if (vec && k + 3 < K) t = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (k < K) t.x = p[0];
+                        if (k + 1 < K) t.y = p[1];
+                        if (k + 2 < K) t.z = p[2];
+                        if (k + 3 < K) t.w = p[3];
+                    }
+                }
+                v[u] = t;
+            }
+        } else {                                    // element (r, k) at base[k * ld + r]: vectors along r
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + (tid >> 5) + 8 * u, r = row0 + 4 * (tid & 31);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K) {
+                    const float* p = base + (long long)k * ld + r;
+                    if (vec && r + 3 < rows) t = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (r < rows) t.x = p[0];
+                        if (r + 1 < rows) t.y = p[1];
+                        if (r + 2 < rows) t.z = p[2];
+                        if (r + 3 < rows) t.w = p[3];
+                    }
+                }
+                v[u] = t;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float (*s)[G_BM + G_PAD], int tid) const {
+        if (KC) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = (tid >> 2) + 64 * u, k = 4 * (tid & 3);
+                s[k][r] = v[u].x; s[k + 1][r] = v[u].y; s[k + 2][r] = v[u].z; s[k + 3][r] = v[u].w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = (tid >> 5) + 8 * u, r = 4 * (tid & 31);
+                *reinterpret_cast<float4*>(&s[k][r]) = v[u];
+            }
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[2][G_BK][G_BM + G_PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][G_BK][G_BN + G_PAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+    const long long bz = blockIdx.z;
+
+    TileLoader<AKC> la{g.A + bz * g.sA, g.lda, g.M, g.K, m0, vecA != 0, {}};
+    TileLoader<BKC> lb{g.B + bz * g.sB, g.ldb, g.N, g.K, n0, vecB != 0, {}};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nt = (g.K + G_BK - 1) / G_BK;
+    la.load(0, tid); lb.load(0, tid);
+    la.store(As[0], tid); lb.store(Bs[0], tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) { la.load((t + 1) * G_BK, tid); lb.load((t + 1) * G_BK, tid); }
+#pragma unroll
+        for (int kk = 0; kk < G_BK; kk += 2) {
+            const float a0 = As[cur][kk + h][wm * 64 + i], a1 = As[cur][kk + h][wm * 64 + 32 + i];
+            const float b0 = Bs[cur][kk + h][wn * 64 + i], b1 = Bs[cur][kk + h][wn * 64 + 32 + i];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < nt) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
+        __syncthreads();
+    }
+
+    // D[row = (r&3) + 8 (r>>2) + 4 h][col = i] of each 32 x 32 tile
+    float* C = g.C + bz * g.sC;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 64 + b * 32 + i;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float* c = C + (long long)m * g.ldc + n;
+                float v = g.alpha * acc[a][b][r] + bv;
+                if (g.beta != 0.f) v += g.beta * *c;
+                if (g.relu) v = v > 0.f ? v : 0.f;
+                *c = v;
+            }
+        }
+}
+
+int launch_gemm32(hipStream_t s, const Gemm32& g) {
+    if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DAGL_OK;
+    if (g.K <= 0 || !g.A || !g.B || !g.C) { set_error("gemm32: bad argument"); return DAGL_ERR_INVALID; }
+    const int vecA = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0) && (g.sA % 4 == 0);
+    const int vecB = ((uintptr_t)g.B % 16 == 0) && (g.ldb % 4 == 0) && (g.sB % 4 == 0);
+    const dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.batch), block(256);
+    if (g.a_kc && g.b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, block, 0, s, g, vecA, vecB);
+    else if (g.a_kc && !g.b_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, block, 0, s, g, vecA, vecB);
+    else if (!g.a_kc && g.b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, block, 0, s, g, vecA, vecB);
+    else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
+    DAGL_LAUNCH_CHECK("gemm32_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

@@ -408,7 +408,6 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     const int nbk = (which & 1) ? project16_key_blocks(g) : 0;
     pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
     pa.colpart = (colsum != nullptr) ? colpart : nullptr;
-    static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
     // resident capacity: two blocks per CU.  A remainder of at most half a round is cut into single-tile blocks.
     static const int cus = [] {
         int dev = 0, n = 256;
@@ -420,6 +419,8 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     if (groups > nbk) groups = nbk;
     pa.n_split_groups = groups; pa.n_full = total - groups; pa.batch = B;
     const dim3 grid(pa.n_full + P16_NT * groups), block(64 * P16_BW);
+#ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
+    static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
     if (var == 1) hipLaunchKernelGGL(project16_kernel<1>, grid, block, 0, s, pa);
     else if (var == 3) hipLaunchKernelGGL(project16_kernel<3>, grid, block, 0, s, pa);
     else if (var == 4) hipLaunchKernelGGL(project16_kernel<4>, grid, block, 0, s, pa);
@@ -429,7 +430,9 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     else if (var == 8) hipLaunchKernelGGL(project16_kernel<8>, grid, block, 0, s, pa);
     else if (var == 9) hipLaunchKernelGGL(project16_kernel<9>, grid, block, 0, s, pa);
     else if (var == 11) hipLaunchKernelGGL(project16_kernel<11>, grid, block, 0, s, pa);
-    else hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
+    else
+#endif
+    hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
     if (pa.colpart != nullptr && nbk > 0) {
         hipLaunchKernelGGL(colsum_reduce_kernel, dim3((D + 3) / 4, B), dim3(256), 0, s, nbk, colpart, colsum);

@@ -470,7 +470,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     }
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
-    static const int target = getenv("DAGL_PRO_BLOCKS") ? atoi(getenv("DAGL_PRO_BLOCKS")) : 256;
+    constexpr int target = 256;
     int chunks = (target + strips * B - 1) / (strips * B);
     if (chunks > (g.H + 1) / 2) chunks = (g.H + 1) / 2;
     if (chunks < 1) chunks = 1;

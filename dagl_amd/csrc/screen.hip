@@ -240,10 +240,9 @@ int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float*
 }
 
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
-    static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
-    const int SCR_QUERIES = (qw == 3) ? 512 : 256;
-    const int n_qgroups = (a.L + SCR_QUERIES - 1) / SCR_QUERIES;
+    const int n_qgroups = (a.L + 255) / 256;
     dim3 grid(n_qgroups * a.splits, a.B);
+#ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
 #define SCR_LAUNCH(P_, Q_, V_) hipLaunchKernelGGL((screen_kernel<P_, Q_, V_>), grid, dim3(256 / Q_ * 2), 0, s, a, n_qgroups)
 #define SCR_VARIANTS(P_, Q_)                                              \
     switch (a.variant) {                                                 \
@@ -251,21 +250,16 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
         case 1: SCR_LAUNCH(P_, Q_, 1); break;                            \
         case 2: SCR_LAUNCH(P_, Q_, 2); break;                            \
         case 4: SCR_LAUNCH(P_, Q_, 4); break;                            \
-        case 5: SCR_LAUNCH(P_, Q_, 5); break;                            \
-        case 6: SCR_LAUNCH(P_, Q_, 6); break;                            \
         case 8: SCR_LAUNCH(P_, Q_, 8); break;                            \
-        case 9: SCR_LAUNCH(P_, Q_, 9); break;                            \
-        case 10: SCR_LAUNCH(P_, Q_, 10); break;                          \
         default: SCR_LAUNCH(P_, Q_, 7); break;                           \
     }
-    if (qw == 1) {
-        if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) }
-    } else if (qw == 3) {
-        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 2, 0, 512>), grid, dim3(512), 0, s, a, n_qgroups);
-        else hipLaunchKernelGGL((screen_kernel<1, 2, 0, 512>), grid, dim3(512), 0, s, a, n_qgroups);
-    } else {
-        if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) }
-    }
+    static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
+    if (qw == 2) { if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) } }
+    else { if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) } }
+#else
+    if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
+    else hipLaunchKernelGGL((screen_kernel<1, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
+#endif
     DAGL_LAUNCH_CHECK("screen_kernel");
     return DAGL_OK;
 }

@@ -63,13 +63,14 @@ class CES(nn.Module):
             prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
             ws = self._ws[s]
             fcs = [prm[h][n] for h in range(4) for n in ("fc1.0.weight", "fc2.0.weight")]
-            key = (tuple(x.shape), heads[0].select_mode, heads[0].select_k,
-                   tuple((t.data_ptr(), t._version) for t in fcs), ws.buf.data_ptr() if ws.buf is not None else 0)
+            wsb = ws.peek(x.device)
+            key = (tuple(x.shape), heads[0].select_mode, heads[0].select_k, tuple(hd._pack_epoch for hd in heads),
+                   tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
                                               mix.bias.detach().contiguous(), mode=heads[0].select_mode,
                                               k=heads[0].select_k, workspace=ws,
                                               weights_packed=(key == self._pack_key[s]))
-            self._pack_key[s] = key[:-1] + (ws.buf.data_ptr(),) if out is not None else None
+            self._pack_key[s] = key[:-1] + (ws.peek(x.device).data_ptr(),) if out is not None else None
             self.last_info = info
             if out is not None:
                 return out
@@ -137,9 +138,18 @@ def seeded_state_dict(template: "OrderedDict[str, torch.Tensor]", seed: int) -> 
     return out
 
 
-def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4):
-    """Recursive 4-way tiled inference: the reference's ``Model.forward_chop`` for scale 1 without self-ensemble
-    (DN_Gray/model/__init__.py:179-231).  A tile of h x w is split into four overlapping corner tiles of
+CHOP_PRESETS = {       # (min_size, shave_size_max) of the four forks' forward_chop
+    "dn_gray": (10000, 24),      # DN_Gray/model/__init__.py:179,187
+    "car": (10000, 24),          # CAR/model/__init__.py:190,199
+    "demosaic": (10000, 12),     # Demosaic/model/__init__.py:179,188
+    "dn_real": (70000, 12),      # DN_Real/model/__init__.py:135,144  (no self-ensemble in that fork)
+}
+
+
+def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
+                 ensemble: bool = False):
+    """Recursive 4-way tiled inference: the reference's ``Model.forward_chop`` for scale 1
+    (DN_Gray/model/__init__.py:179-231); ``ensemble`` = its ``--ensemble`` switch: ``test_x8`` on every leaf (:205-208).  A tile of h x w is split into four overlapping corner tiles of
     (h//2//4*4 + 24) x (w//2//4*4 + 24) until the corner area drops below ``min_size``; the four leaf tiles of one
     split form one batch; the outputs' inner quadrants are stitched back."""
     b, c, h, w = x.shape
@@ -150,9 +160,9 @@ def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: 
              x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
     if w_size * h_size < min_size:
         # the reference runs the four leaves one by one with n_GPUs == 1 (__init__.py:203-209)
-        outs = [model(t.contiguous()) for t in tiles]
+        outs = [forward_x8(model, t) if ensemble else model(t.contiguous()) for t in tiles]
     else:
-        outs = [chop_forward(model, t, min_size, shave_size_max, shave_scale) for t in tiles]
+        outs = [chop_forward(model, t, min_size, shave_size_max, shave_scale, ensemble) for t in tiles]
     out = x.new_empty(b, c, h, w)
     out[:, :, 0:h_half, 0:w_half] = outs[0][:, :, 0:h_half, 0:w_half]
     out[:, :, 0:h_half, w_half:w] = outs[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
@@ -162,7 +172,7 @@ def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: 
 
 
 def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
-                         max_batch: int = 64):
+                         max_batch: int = 64, ensemble: bool = False):
     """Same tiling and stitching as ``chop_forward``, but all leaf tiles (they share one shape) go through the network in
     batches of up to ``max_batch`` instead of one by one: tiles are independent, and a batch is just
     another grid dimension of the HIP block.  Device-side equivalent of the reference's per-leaf loop."""
@@ -184,11 +194,14 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
     collect(x)
     shapes = {tuple(t.shape) for t in plan}
     if len(shapes) != 1:                                  # ragged leaves (odd sizes): fall back to the sequential driver
-        return chop_forward(model, x, min_size, shave_size_max, shave_scale)
+        return chop_forward(model, x, min_size, shave_size_max, shave_scale, ensemble)
     outs = []
     for i in range(0, len(plan), max_batch):
         batch = torch.cat([t for t in plan[i:i + max_batch]], dim=0).contiguous()
-        outs.extend(model(batch).split(x.shape[0], dim=0))
+        # self-ensemble: each of the 8 variants of ALL leaves of the batch is one network call (the leaves of a variant
+        # share a shape); per leaf this is exactly test_x8's stack and mean
+        res = forward_x8(model, batch) if ensemble else model(batch)
+        outs.extend(res.split(x.shape[0], dim=0))
     it = iter(outs)
 
     def stitch(t):
@@ -211,30 +224,28 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
     return stitch(x)
 
 
+# The 8 symmetries of the square in the order the reference enumerates them (``augment_img`` modes 0..7,
+# DN_Gray/model/__init__.py:35-51): (quarter turns counter-clockwise in the (H, W) plane, then flip the rows?)
+_X8_MODES = ((0, False), (1, True), (0, True), (3, False), (2, True), (1, False), (2, False), (3, True))
+_X8_INVERSE = (0, 1, 2, 5, 4, 3, 6, 7)      # modes 3 and 5 undo each other, the rest are involutions (test_x8, :56-59)
+
+
+def _x8_apply(t: torch.Tensor, mode: int) -> torch.Tensor:
+    k, flip = _X8_MODES[mode]
+    if k:
+        t = t.rot90(k, (-2, -1))
+    if flip:
+        t = t.flip(-2)
+    return t
+
+
 def forward_x8(forward_fn, x: torch.Tensor) -> torch.Tensor:
-    """Geometric self-ensemble of the reference (``test_x8`` / ``forward_x8``, DN_Gray/model/__init__.py:53-62, :260-293):
-    the 8 flip/transpose variants go through ``forward_fn`` and the back-transformed outputs are averaged.  The reference
-    round-trips every variant through numpy on the host; here the transforms stay on the device."""
-    outs = []
-    for transpose in (False, True):
-        for vflip in (False, True):
-            for hflip in (False, True):
-                t = x
-                if hflip:
-                    t = t.flip(-1)
-                if vflip:
-                    t = t.flip(-2)
-                if transpose:
-                    t = t.transpose(-1, -2)
-                y = forward_fn(t.contiguous())
-                if transpose:
-                    y = y.transpose(-1, -2)
-                if vflip:
-                    y = y.flip(-2)
-                if hflip:
-                    y = y.flip(-1)
-                outs.append(y)
-    return torch.stack(outs, dim=0).mean(dim=0)
+    """Geometric self-ensemble of the reference (``test_x8``, DN_Gray/model/__init__.py:53-62): the 8 flip / rotate
+    variants go through ``forward_fn``, the outputs are transformed back and averaged -- same variants, same order of the
+    stack that is averaged.  The reference round-trips every variant through numpy on the host (``augment_img_tensor``,
+    :18-32); here the transforms stay on the device."""
+    outs = [_x8_apply(forward_fn(_x8_apply(x, m).contiguous()), _X8_INVERSE[m]) for m in range(8)]
+    return torch.stack(outs, dim=0).mean(dim=0, keepdim=False)
 
 
 def psnr(img: torch.Tensor, ref: torch.Tensor, data_range: float = 1.0) -> float:

@@ -15,7 +15,45 @@ from ._lib import DS, MODES, P, DaglError, check
 
 
 def _stream() -> int:
+    """torch's current stream ON THE CURRENT DEVICE -- every entry point below runs under ``_on_device`` which makes the
+    tensors' device current first (the C ABI launches on the current HIP device)."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _tensors_of(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            yield a
+        elif isinstance(a, dict):
+            yield from (v for v in a.values() if isinstance(v, torch.Tensor))
+        elif isinstance(a, (list, tuple)):
+            for e in a:
+                if isinstance(e, torch.Tensor):
+                    yield e
+                elif isinstance(e, dict):
+                    yield from (v for v in e.values() if isinstance(v, torch.Tensor))
+
+
+def _on_device(fn):
+    """Run ``fn`` with the device of its tensor arguments as the current device (a module living on cuda:1 must not
+    launch on cuda:0's stream) and refuse tensors spread over several devices."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for t in _tensors_of(args, kwargs):
+            if not t.is_cuda:
+                continue
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise DaglError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None:
+            return fn(*args, **kwargs)          # the per-argument checks below report the CPU tensor
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _need(t: torch.Tensor, name: str, dtype=torch.float32):
@@ -34,6 +72,7 @@ def query_grid(H: int, W: int):
     return -(-H // 4), -(-W // 4)
 
 
+@_on_device
 def pad_nhwc(x: torch.Tensor) -> torch.Tensor:
     """[B,16,H,W] -> zero-bordered channels-last [B,H+6,W+6,16]."""
     _need(x, "x")
@@ -45,6 +84,7 @@ def pad_nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def pack_fc_weight(w: torch.Tensor) -> torch.Tensor:
     _need(w, "w")
     if tuple(w.shape) != (196, 784):
@@ -54,6 +94,7 @@ def pack_fc_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def project_patches(map_nhwc: torch.Tensor, w_packed: torch.Tensor, fc_bias: torch.Tensor, H: int, W: int,
                     queries: bool, want_colsum: bool = False):
     """relu(Linear(patch)) for every patch -> ([B, rows_alloc, 204] features, optional [B,204] fp64 column sums)."""
@@ -71,6 +112,7 @@ def project_patches(map_nhwc: torch.Tensor, w_packed: torch.Tensor, fc_bias: tor
     return feat, colsum
 
 
+@_on_device
 def query_thresholds(wq: torch.Tensor, colsum: torch.Tensor, thr: torch.Tensor, L: int, N: int) -> torch.Tensor:
     _need(wq, "wq"); _need(colsum, "colsum", torch.float64); _need(thr, "thr")
     B = wq.shape[0]
@@ -80,6 +122,7 @@ def query_thresholds(wq: torch.Tensor, colsum: torch.Tensor, thr: torch.Tensor, 
     return mt
 
 
+@_on_device
 def scores_dense(wq: torch.Tensor, x: torch.Tensor, L: int, N: int) -> torch.Tensor:
     _need(wq, "wq"); _need(x, "x")
     B = wq.shape[0]
@@ -89,6 +132,7 @@ def scores_dense(wq: torch.Tensor, x: torch.Tensor, L: int, N: int) -> torch.Ten
     return s
 
 
+@_on_device
 def gather_aggregate(idx: torch.Tensor, wgt: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
     """out[l,:] = sum_k wgt[l,k] * values[idx[l,k],:]   (idx < 0 = empty slot)."""
     _need(idx, "idx", torch.int32); _need(wgt, "wgt"); _need(values, "values")
@@ -102,6 +146,7 @@ def gather_aggregate(idx: torch.Tensor, wgt: torch.Tensor, values: torch.Tensor)
     return out
 
 
+@_on_device
 def unfold_values(b2_nhwc: torch.Tensor, H: int, W: int) -> torch.Tensor:
     _need(b2_nhwc, "b2_nhwc")
     B = b2_nhwc.shape[0]
@@ -111,6 +156,7 @@ def unfold_values(b2_nhwc: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return rows
 
 
+@_on_device
 def fold_normalize(agg: torch.Tensor, H: int, W: int) -> torch.Tensor:
     _need(agg, "agg")
     B = agg.shape[0]
@@ -154,19 +200,41 @@ class StageProfile:
 
 
 class Workspace:
-    """Grow-only device scratch buffer reused across calls (allocated through torch's caching allocator, so it
-    is stream-ordered and visible to torch's memory accounting)."""
+    """Grow-only device scratch buffers reused across calls, one per device (allocated through torch's caching allocator,
+    so they are stream-ordered and visible to torch's memory accounting).  ``nn.DataParallel`` replicas share the
+    object across per-device threads: the buffer is built in a local and looked up by device, never handed across."""
 
     def __init__(self):
-        self.buf = None
+        self._bufs = {}
+
+    @property
+    def buf(self):
+        """The buffer of the current device (None before the first call there)."""
+        if not self._bufs:
+            return None
+        if torch.cuda.is_available():
+            b = self._bufs.get(torch.device("cuda", torch.cuda.current_device()))
+            if b is not None:
+                return b
+        return next(iter(self._bufs.values())) if len(self._bufs) == 1 else None
+
+    def peek(self, device):
+        return self._bufs.get(torch.device(device))
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != device:
-            self.buf = None
-            self.buf = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)
-        return self.buf
+        device = torch.device(device)
+        if device.index is None and device.type == "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
+        b = self._bufs.get(device)
+        if b is None or b.numel() < nbytes + 256:
+            self._bufs.pop(device, None)
+            b = None                                              # release before the larger allocation
+            b = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)
+            self._bufs[device] = b
+        return b
 
 
+@_on_device
 def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
                workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False,
                profile: "StageProfile | None" = None, exact_scan: bool = False):
@@ -230,6 +298,7 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
     return out
 
 
+@_on_device
 def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None):
     """The four prologue convolutions (dagl.py:208-215) -> (b1_nhwc, b2_nhwc, thr, bias); heads optional."""
     for n, t in (("x", x), ("g_w", g_w), ("g_b", g_b), ("theta_w", theta_w), ("theta_b", theta_b)):
@@ -246,13 +315,15 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
     if heads:
         for n, t in (("thr_w", thr_w), ("thr_b", thr_b), ("bias_w", bias_w), ("bias_b", bias_b)):
             _need(t, n)
+    scratch = torch.empty(8 * B * Lh * Lw, device=x.device, dtype=torch.float32) if heads else None
     p = lambda t: t.data_ptr() if t is not None else None
     check(_lib.load().dagl_ce_prologue(_stream(), B, H, W, x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(),
                                        theta_w.data_ptr(), theta_b.data_ptr(), p(thr_w), p(thr_b), p(bias_w), p(bias_b),
-                                       b1p.data_ptr(), b2p.data_ptr(), p(thr), p(bias)), "dagl_ce_prologue")
+                                       b1p.data_ptr(), b2p.data_ptr(), p(thr), p(bias), p(scratch)), "dagl_ce_prologue")
     return b1p, b2p, thr, bias
 
 
+@_on_device
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
                      profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False,
                      dense_hint: bool = False, want_info: bool = True):
@@ -279,12 +350,12 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
     if need == 0:
         check(-1, "dagl_ce_workspace_bytes")
-    if weights_packed and ws.buf is not None and ws.buf.numel() >= need + 256 and ws.buf.device == x.device:
+    if weights_packed and ws.peek(x.device) is not None and ws.peek(x.device).numel() >= need + 256:
         mode_flags |= _lib.FLAG_WEIGHTS_PACKED           # same buffer as last time: the packed weights are still in it
     if dense_hint and mode == "adaptive" and not exact_scan:
         mode_flags |= _lib.FLAG_DENSE_HINT
-        if ws.buf is not None:
-            need = max(need, ws.buf.numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
+        if ws.peek(x.device) is not None:
+            need = max(need, ws.peek(x.device).numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
     quiet = dense_hint and not want_info
     out = torch.empty(B, 16, H, W, device=x.device, dtype=torch.float32)
     info = _lib.CeInfo()
@@ -311,6 +382,7 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
                      max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
 
 
+@_on_device
 def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: int = 0,
                       workspace: "Workspace | None" = None, profile: "StageProfile | None" = None,
                       weights_packed: bool = False):
@@ -357,6 +429,7 @@ def _aligned(buf: torch.Tensor):
     return a, buf.numel() - (a - base)
 
 
+@_on_device
 def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: int = 0,
                     workspace: "Workspace | None" = None, exact_scan: bool = False):
     """Graph core with the projections given (training path, include/dagl_ce.h ``dagl_ce_core_forward``):
@@ -403,6 +476,7 @@ def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: i
     return out, saved
 
 
+@_on_device
 def ce_core_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, mode: str = "adaptive", k: int = 0,
                      workspace: "Workspace | None" = None):
     """Gradients of the graph core (``dagl_ce_core_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias)."""
@@ -429,4 +503,82 @@ def ce_core_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, mode: s
                                    saved["nb_cnt"].data_ptr(), p(saved["mu"]), d_out.data_ptr(), d_wq.data_ptr(),
                                    d_x.data_ptr(), d_b2.data_ptr(), p(d_thr), p(d_bias), a, nbytes)
     check(rc, "dagl_ce_core_backward")
+    return d_wq, d_x, d_b2, d_thr, d_bias
+
+
+@_on_device
+def gemm_f32(A: torch.Tensor, B: torch.Tensor, a_k_contiguous: bool = True, b_k_contiguous: bool = False, out=None,
+             alpha: float = 1.0, beta: float = 0.0, bias=None, relu: bool = False) -> torch.Tensor:
+    """Batched fp32 matrix product on the matrix cores (``dagl_gemm_f32``).  A: [b,M,K] (a_k_contiguous) or [b,K,M];
+    B: [b,N,K] (b_k_contiguous) or [b,K,N]; 2-D operands = batch of one.  Returns C [b,M,N] (= alpha A B + beta out)."""
+    _need(A, "A"); _need(B, "B")
+    squeeze = A.dim() == 2
+    if squeeze:
+        A, B = A[None], B[None]
+    nb = A.shape[0]
+    M, K = (A.shape[1], A.shape[2]) if a_k_contiguous else (A.shape[2], A.shape[1])
+    N, K2 = (B.shape[1], B.shape[2]) if b_k_contiguous else (B.shape[2], B.shape[1])
+    if K != K2 or B.shape[0] != nb:
+        raise DaglError("gemm_f32: shape mismatch")
+    if out is None:
+        if beta != 0.0:
+            raise DaglError("gemm_f32: beta needs an existing output")
+        out = torch.empty(nb, M, N, device=A.device, dtype=torch.float32)
+    else:
+        _need(out, "out")
+    if bias is not None:
+        _need(bias, "bias")
+    check(_lib.load().dagl_gemm_f32(_stream(), nb, M, N, K, A.data_ptr(), A.shape[2], A.shape[1] * A.shape[2],
+                                    int(a_k_contiguous), B.data_ptr(), B.shape[2], B.shape[1] * B.shape[2],
+                                    int(b_k_contiguous), out.data_ptr(), N, M * N, float(alpha), float(beta),
+                                    bias.data_ptr() if bias is not None else None, int(relu)), "dagl_gemm_f32")
+    return out[0] if squeeze and out.dim() == 3 else out
+
+
+@_on_device
+def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace | None" = None, want_info: bool = True):
+    """Graph core in the dense regime under autograd (``dagl_ce_core_dense_forward``): same operands as
+    ``ce_core_forward`` (adaptive mode) -> (out [B,16,H,W], saved dict(lse [B,L,2], mu [B,L], info))."""
+    lib = _lib.load()
+    for n, t in (("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2), ("thr", thr), ("bias", bias)):
+        _need(t, n)
+    B, c, H, W = b2.shape
+    Lh, Lw = query_grid(H, W)
+    L, N = Lh * Lw, H * W
+    if c != 16 or tuple(wq_rows.shape) != (B, L, 196) or tuple(x_rows.shape) != (B, N, 196) or thr.numel() != B * L \
+            or bias.numel() != B * L:
+        raise DaglError("ce_core_dense_forward: expected wq_rows [B,L,196], x_rows [B,H*W,196], b2 [B,16,H,W], thr/bias [B,L]")
+    need = lib.dagl_ce_core_dense_workspace_bytes(B, H, W, 0) + 256
+    ws = workspace if workspace is not None else Workspace()
+    dev = b2.device
+    out = torch.empty(B, 16, H, W, device=dev, dtype=torch.float32)
+    lse = torch.empty(B, L, 2, device=dev, dtype=torch.float32)
+    mu = torch.empty(B, L, device=dev, dtype=torch.float32)
+    info = _lib.CeInfo()
+    a, nbytes = _aligned(ws.get(need, dev))
+    check(lib.dagl_ce_core_dense_forward(_stream(), B, H, W, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+                                         thr.data_ptr(), bias.data_ptr(), out.data_ptr(), lse.data_ptr(), mu.data_ptr(),
+                                         a, nbytes, C.byref(info) if want_info else None), "dagl_ce_core_dense_forward")
+    meta = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=5, redone_queries=-1) if want_info else None
+    return out, dict(lse=lse, mu=mu, info=meta)
+
+
+@_on_device
+def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, workspace: "Workspace | None" = None):
+    """Gradients of the dense graph core (``dagl_ce_core_dense_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias)."""
+    lib = _lib.load()
+    for n, t in (("d_out", d_out), ("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2), ("thr", thr), ("bias", bias)):
+        _need(t, n)
+    B, _, H, W = b2.shape
+    need = lib.dagl_ce_core_dense_workspace_bytes(B, H, W, 1)
+    ws = workspace if workspace is not None else Workspace()
+    dev = b2.device
+    d_wq, d_x, d_b2 = torch.empty_like(wq_rows), torch.empty_like(x_rows), torch.empty_like(b2)
+    d_thr = torch.empty(B, wq_rows.shape[1], device=dev, dtype=torch.float32)
+    d_bias = torch.empty_like(d_thr)
+    a, nbytes = _aligned(ws.get(need, dev))
+    check(lib.dagl_ce_core_dense_backward(_stream(), B, H, W, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+                                          thr.data_ptr(), bias.data_ptr(), saved["lse"].data_ptr(), saved["mu"].data_ptr(),
+                                          d_out.data_ptr(), d_wq.data_ptr(), d_x.data_ptr(), d_b2.data_ptr(),
+                                          d_thr.data_ptr(), d_bias.data_ptr(), a, nbytes), "dagl_ce_core_dense_backward")
     return d_wq, d_x, d_b2, d_thr, d_bias

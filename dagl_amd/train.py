@@ -42,12 +42,19 @@ class TrainOptions:                      # defaults of DN_Gray/option.py:88-125
 
 def freeze_unused(model: nn.Module) -> int:
     """``CE.W`` is registered but never applied (dagl.py:192), so it never receives a gradient: take it out of the
-    trainable set so that DDP does not wait for it.  Returns the number of parameters frozen."""
+    trainable set so that DDP does not wait for it.  A head in fixed-k mode (``select_mode == "topk"``) does not use its
+    thr / bias heads either.  Returns the number of parameters frozen."""
     n = 0
     for name, p in model.named_parameters():
         if name.split(".")[-2:-1] == ["W"] and p.requires_grad:
             p.requires_grad_(False)
             n += p.numel()
+    for m in model.modules():
+        if getattr(m, "select_mode", None) == "topk" and hasattr(m, "thr_conv"):
+            for p in list(m.thr_conv.parameters()) + list(m.bias_conv.parameters()):
+                if p.requires_grad:
+                    p.requires_grad_(False)
+                    n += p.numel()
     return n
 
 

@@ -212,14 +212,45 @@ int    dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k,
                              float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias,
                              void* workspace, size_t ws_bytes);
 
+/* Dense neighbourhoods under autograd (an adaptive mask that keeps more than DAGL_FAST_CAP keys for some query -- the
+ * regime of default-initialised thr/bias heads, i.e. where a training run starts): the reference's dense formulation
+ * (dagl.py:250-264) and the gradients autograd derives from it, chunked over the queries so that the [L,N] matrices
+ * exist one chunk at a time; all matrix products on the fp32 matrix cores (bitwise fmaf chains).  Adaptive mode only
+ * (the top-k modes always have fixed-width lists).  Same operands as dagl_ce_core_forward / _backward; instead of
+ * neighbour lists the forward hands back `lse` [B,L,2] = (softmax shift, denominator) per query and `mu` [B,L].
+ * info (may be NULL; non-NULL costs one host synchronisation): path 5, total_edges, max_degree.                   */
+size_t dagl_ce_core_dense_workspace_bytes(int B, int H, int W, int backward);
+int    dagl_ce_core_dense_forward(void* stream, int B, int H, int W,
+                                  const float* wq_rows, const float* x_rows, const float* b2,
+                                  const float* thr, const float* bias, float* out, float* lse, float* mu,
+                                  void* workspace, size_t ws_bytes, dagl_ce_info* info);
+int    dagl_ce_core_dense_backward(void* stream, int B, int H, int W,
+                                   const float* wq_rows, const float* x_rows, const float* b2,
+                                   const float* thr, const float* bias, const float* lse, const float* mu,
+                                   const float* d_out,
+                                   float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias,
+                                   void* workspace, size_t ws_bytes);
+
 /* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
 
+/* Batched fp32 matrix product on the matrix cores, the building block of the dense training stages:
+ * C[b] = alpha * A[b] B[b] + beta * C[b] (+ bias[n], relu).  A is logically M x K, stored row-major
+ * (a_k_contiguous: element (m,k) at A[m*lda + k]) or K-major (A[k*lda + m]); B is logically K x N, stored
+ * as N x K rows (b_k_contiguous: B[n*ldb + k]) or K x N rows (B[k*ldb + n]).  Replaces torch.matmul / torch.mm
+ * of dagl.py:250,263 and their autograd counterparts.  Deterministic (no split-K, no atomics).                  */
+int dagl_gemm_f32(void* stream, int batch, int M, int N, int K,
+                  const float* A, long long lda, long long stride_a, int a_k_contiguous,
+                  const float* B, long long ldb, long long stride_b, int b_k_contiguous,
+                  float* C, long long ldc, long long stride_c, float alpha, float beta, const float* bias, int relu);
+
 /* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
- * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).                             */
+ * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).  `scratch` = 8*B*L floats of
+ * caller-owned device memory for the heads' partial sums (may be NULL without the heads): like every
+ * entry point, nothing is allocated in here.                                                       */
 int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x,
                      const float* g_w, const float* g_b, const float* theta_w, const float* theta_b,
                      const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
-                     float* b1_nhwc, float* b2_nhwc, float* thr, float* bias);
+                     float* b1_nhwc, float* b2_nhwc, float* thr, float* bias, float* scratch);
 
 /* NCHW [B,16,H,W] -> zero-bordered NHWC [B,H+6,W+6,16]  (patch unfold without materialising
  * patches: replaces same_padding/extract_image_patches, dagl.py:123-169, for all three uses).    */

@@ -154,8 +154,10 @@ def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad):
             m, mb = m * keep, mb * keep
     A = F.softmax(S * m * SOFTMAX_SCALE, dim=1) * mb                           # :259-261
     agg = A @ v_rows_n                                                         # [L,784] :263-264
-    z = F.fold(agg.t().unsqueeze(0), (H, W), (KSIZE, KSIZE),
-               padding=fold_pad, stride=STRIDE_Q)                              # :265-267
+    z = None
+    if fold_pad is not None:                          # (None: a sample of the queries, nothing to fold)
+        z = F.fold(agg.t().unsqueeze(0), (H, W), (KSIZE, KSIZE),
+                   padding=fold_pad, stride=STRIDE_Q)                          # :265-267
     return z, dict(S=S, T=T, deg=mb.sum(dim=1), rowsum=A.sum(dim=1), agg=agg, mask_b=mb)
 
 
@@ -185,6 +187,31 @@ def ce_core_oracle(wq_rows: torch.Tensor, x_rows: torch.Tensor, b2: torch.Tensor
     if stages:
         return out, {k_: torch.stack([s[k_] for s in sts]) for k_ in sts[0]}
     return out
+
+
+def ce_rows_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], rows: torch.Tensor, *, mode: str = "adaptive",
+                   k: Optional[int] = None, dtype: torch.dtype = torch.float32):
+    """``ce_forward_oracle`` restricted to the query patches ``rows`` (indices into the L queries) of ONE image
+    ``x [1,C,H,W]``: every row of S is independent of the others (the mean of dagl.py:256 runs over the keys), so a
+    sample of queries can be checked against all N keys at sizes where the full ``[L,N]`` matrix does not fit the host
+    (512^2: 16 GiB, 1024^2: 256 GiB).  Returns dict(deg, rowsum, agg [len(rows),784] in (c,kh,kw) order, S, T)."""
+    assert x.shape[0] == 1
+    P = {n: t.to(dtype) for n, t in params.items()}
+    x = x.to(dtype)
+    b1 = F.conv2d(x, P["g.weight"], P["g.bias"], padding=1)
+    b2 = F.conv2d(x, P["theta.weight"], P["theta.bias"])
+    xq, _ = same_pad(x, KSIZE, STRIDE_Q)
+    thr = F.conv2d(xq, P["thr_conv.weight"], P["thr_conv.bias"], stride=STRIDE_Q).reshape(-1)[rows]
+    bias = F.conv2d(xq, P["bias_conv.weight"], P["bias_conv.bias"], stride=STRIDE_Q).reshape(-1)[rows]
+    q_rows = patch_rows(b1, KSIZE, STRIDE_Q)[0][rows]
+    Wq = F.relu(F.linear(q_rows, P["fc1.0.weight"], P["fc1.0.bias"]))
+    N = x.shape[2] * x.shape[3]
+    # keys / values in slabs of rows of the image would need halos; the unfolds of one image are affordable (N x 784)
+    X = F.relu(F.linear(patch_rows(b1, KSIZE, STRIDE_KV)[0], P["fc2.0.weight"], P["fc2.0.bias"]))
+    v_rows = patch_rows(b2, KSIZE, STRIDE_KV)[0]
+    H, W = x.shape[2:]
+    _, c = _graph_core(Wq, X, thr, bias, v_rows, mode, k, H, W, None)
+    return c
 
 
 def gather_aggregate_oracle(idx: torch.Tensor, wgt: torch.Tensor, values: torch.Tensor) -> torch.Tensor:

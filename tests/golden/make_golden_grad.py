@@ -38,6 +38,9 @@ CASES = [
     ("gray_sparse_64x64", "DN_Gray", 32, "sparse", 2.2, "adaptive", 0, 1, 64, 64),
     ("topk8_b2_45x38", "TOPK", 33, "default", 2.0, "topk", 8, 2, 45, 38),
     ("topk4_64x64", "TOPK", 34, "default", 2.0, "topk", 4, 1, 64, 64),
+    # dense neighbourhoods: default-initialised heads keep ~95 % of the keys; "longtail": a few queries beyond 64 keys
+    ("gray_default_64x64", "DN_Gray", 35, "default", 2.0, "adaptive", 0, 1, 64, 64),
+    ("gray_longtail_b2_40x36", "DN_Gray", 36, "sparse", 1.45, "adaptive", 0, 2, 40, 36),
 ]
 FC_STEP = 5
 
@@ -80,5 +83,7 @@ def run_case(case):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    only = set(sys.argv[1:])
     for c in CASES:
-        run_case(c)
+        if not only or c[0] in only:
+            run_case(c)

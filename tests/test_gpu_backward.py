@@ -48,11 +48,21 @@ def test_gradients_match_reference_autograd(path, scan):
     ce, out, grads = _hip_grads(meta, scan)
     assert normwise(out.cpu().numpy(), want["out"]) <= TOL_OUT
     assert "d_W.weight" not in grads                      # registered but never applied (dagl.py:192)
+    dense = meta["mode"] != "topk" and "sparse" not in meta["name"]
+    if dense:
+        # the two scalar head biases are sums over all queries with heavy cancellation: the REFERENCE's own fp32 values
+        # sit 3e-3 .. 5e-3 from an fp64 evaluation in this regime (measured: make_golden_grad's gray_default_64x64), so
+        # they are held to 1e-2 here and to the fp64 oracle in test_gradients_are_as_close_to_fp64_as_the_reference
+        scal = {k: v for k, v in want.items() if k in ("d_thr_conv.bias", "d_bias_conv.bias")}
+        compare_grads(grads, scal, meta["fc_step"], 1e-2)
+        want = {k: v for k, v in want.items() if k not in scal}
     compare_grads(grads, want, meta["fc_step"], TOL_GRAD)
     if meta["mode"] == "topk":
         assert "d_thr_conv.weight" not in grads           # the fixed-k variant has no threshold heads
-    else:
-        assert ce.last_info["max_degree"] <= 64
+    elif "sparse" in meta["name"]:
+        assert ce.last_info["max_degree"] <= 64 and ce.last_info["path"] != 5
+    else:                                                 # "default" / "longtail": dense formulation (dense_train.hip)
+        assert ce.last_info["max_degree"] > 64 and ce.last_info["path"] == 5
 
 
 @pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(p)[5:-4] for p in GRAD_CASES])
@@ -182,16 +192,78 @@ def test_hub_keys_shared_by_every_query():
         assert p.grad is None or torch.isfinite(p.grad).all()
 
 
-def test_dense_neighbourhoods_are_refused_when_training():
-    import dagl_amd
+def test_dense_neighbourhoods_train_through_the_dense_formulation():
+    """Default-initialised heads keep ~95 % of the keys: the list form refuses (DAGL_ERR_UNSUPPORTED) and the module goes
+    to the dense formulation (dense_train.hip); forward equals the inference path, and the module remembers the regime."""
+    from dagl_amd import ops
+    from dagl_amd._lib import ERR_UNSUPPORTED, DaglError
     from dagl_amd.synth import make_ce_params, make_features
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(16, variant="default").items()}
     ce = _module(params, "adaptive", 0)
-    x = torch.from_numpy(make_features(16, 1, 64, 64, 64)).to(_dev()).requires_grad_(True)
-    with pytest.raises(dagl_amd.DaglError, match="dense neighbourhoods"):
-        ce(x)
-    with torch.no_grad():                                   # inference on the same input is served (CSR path)
-        assert ce(x.detach()).shape == (1, 16, 64, 64)
+    x = torch.from_numpy(make_features(16, 1, 64, 64, 64)).to(_dev())
+    with torch.no_grad():
+        ref = ce(x)
+        b1, b2, thr, bias = ce._prologue(x)
+        wq = torch.rand(1, 256, 196, device=_dev()); xr = torch.rand(1, 4096, 196, device=_dev())
+        with pytest.raises(DaglError) as ei:                       # the C ABI contract of the list entry point
+            ops.ce_core_forward(wq, xr, b2.contiguous(), torch.zeros(1, 256, device=_dev()),
+                                torch.zeros(1, 256, device=_dev()), mode="adaptive")
+        assert ei.value.code == ERR_UNSUPPORTED
+    out = ce(x.clone().requires_grad_(True))
+    assert out.requires_grad and ce._train_dense and ce.last_info["path"] == 5
+    assert ce.last_info["max_degree"] > 64
+    assert normwise(out.detach().cpu().numpy(), ref.cpu().numpy()) <= 1e-4
+    out2 = ce(x.clone().requires_grad_(True))                       # second call: straight to the dense formulation
+    assert torch.equal(out2.detach(), out.detach())
+    out2.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for n, p in ce.named_parameters() if not n.startswith("W."))
+
+
+def test_dense_backward_is_bit_reproducible_and_chunking_invariant():
+    from dagl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 2, 24, 28
+    L, N = 6 * 7, H * W
+    dev = _dev()
+    wq = (torch.rand(B, L, 196, generator=g) * 0.1).to(dev); xr = (torch.rand(B, N, 196, generator=g) * 0.1).to(dev)
+    b2 = torch.randn(B, 16, H, W, generator=g).to(dev); G = torch.randn(B, 16, H, W, generator=g).to(dev)
+    thr = torch.full((B, L), 0.9, device=dev); bias = torch.zeros(B, L, device=dev)
+    out, saved = ops.ce_core_dense_forward(wq, xr, b2, thr, bias)
+    g1 = ops.ce_core_dense_backward(G, wq, xr, b2, thr, bias, saved)
+    g2 = ops.ce_core_dense_backward(G, wq, xr, b2, thr, bias, saved)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    # one image at a time = other batch grouping: same numbers
+    o1, s1 = ops.ce_core_dense_forward(wq[1:], xr[1:], b2[1:], thr[1:], bias[1:])
+    assert torch.equal(o1, out[1:])
+    h1 = ops.ce_core_dense_backward(G[1:], wq[1:], xr[1:], b2[1:], thr[1:], bias[1:], s1)
+    assert all(torch.equal(a, b[1:]) for a, b in zip(h1, g1))
+
+
+def test_dense_core_matches_the_oracle_and_its_autograd():
+    """dagl_ce_core_dense_forward / _backward against the fp64 oracle on the same feature rows (odd sizes, N not a multiple
+    of 4, thresholds that keep about half of the keys)."""
+    from dagl_amd import ops
+    from oracle.ce_oracle import ce_core_oracle
+    g = torch.Generator().manual_seed(12)
+    B, H, W = 2, 45, 38
+    L, N = 12 * 10, H * W
+    wq = torch.rand(B, L, 196, generator=g) * 0.1; xr = torch.rand(B, N, 196, generator=g) * 0.1
+    b2 = torch.randn(B, 16, H, W, generator=g); G = torch.randn(B, 16, H, W, generator=g)
+    thr = 1.0 + 0.02 * torch.randn(B, L, generator=g); bias = 0.002 * torch.randn(B, L, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (wq, xr, b2, thr, bias)]
+    ref, st = ce_core_oracle(*leaves, mode="adaptive", stages=True)
+    (ref * G.double()).sum().backward()
+    assert 0.2 * N < float(st["deg"].mean()) < 0.8 * N
+    dev = _dev()
+    d = [t.to(dev) for t in (wq, xr, b2, thr, bias)]
+    out, saved = ops.ce_core_dense_forward(*d)
+    # (a key within rounding of its threshold may flip between fp32 and fp64 scores)
+    assert abs(saved["info"]["total_edges"] - int(st["deg"].sum())) <= 3
+    assert abs(saved["info"]["max_degree"] - int(st["deg"].max())) <= 2
+    assert normwise(out.cpu().numpy(), ref.detach().numpy()) <= TOL_OUT
+    grads = ops.ce_core_dense_backward(G.to(dev), *d, saved)
+    for name, got, leaf in zip(("d_wq", "d_x", "d_b2", "d_thr", "d_bias"), grads, leaves):
+        assert normwise(got.cpu().numpy(), leaf.grad.numpy()) <= 3e-4, name
 
 
 def test_one_sgd_step_reduces_the_loss():

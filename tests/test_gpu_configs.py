@@ -1,0 +1,253 @@
+"""Oracle parity at BASELINE.json's own sizes and configurations, through the module / C ABI:
+
+  config 2  [1,64,256,256] fp32, top-k k=8 and adaptive at mean degree ~8: the whole dense oracle (10 s of host time)
+  config 3  512x512 with bf16 feature maps: a sample of the queries against ALL keys (the full [L,N] matrix is 16 GiB),
+            and the bf16-input block against the oracle fed the same bf16-rounded input
+  config 4  1024x1024, adaptive AND top-16: a sample of the queries against all 1 048 576 keys
+  config 5  one optimisation step of the whole RR (n_colors=3) on [8,3,128,128]; whole-network gradients against the
+            fp64 oracle's autograd at a size the oracle can do; the RCCL process group on one GPU
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import normwise
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _params(seed, variant, gain):
+    from dagl_amd.synth import make_ce_params
+    return {n: torch.from_numpy(a) for n, a in make_ce_params(seed, variant=variant, sparse_gain=gain).items()}
+
+
+def _module(params, mode, k):
+    from dagl_amd.ce import CE
+    ce = CE(in_channels=64)
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode = mode
+    if k:
+        ce.select_k = k
+    return ce.to(_dev()).eval()
+
+
+def _debug(ce, x):
+    from dagl_amd import ops
+    with torch.no_grad():
+        b1, b2, thr, bias = ce._prologue(x)
+        return ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
+                              ce.fc1[0].weight, ce.fc1[0].bias, ce.fc2[0].weight, ce.fc2[0].bias,
+                              mode=ce.select_mode, k=ce.select_k, debug=True)
+
+
+def _agg_ckk(agg):                       # [.., 784] (kh,kw,c) -> (c,kh,kw), the reference's row order
+    s = agg.shape[:-1]
+    return agg.reshape(*s, 7, 7, 16).movedim(-1, -3).reshape(*s, 784)
+
+
+@pytest.mark.parametrize("mode,k,variant,gain", [("topk", 8, "default", 2.0), ("adaptive", 0, "sparse", 1.8),
+                                                 ("adaptive", 0, "sparse", 1.95)])
+def test_config2_256x256_matches_the_dense_oracle(mode, k, variant, gain):
+    """BASELINE configs[1] itself: [1,64,256,256], L = 4096 queries x N = 65536 keys, against the dense fp32 oracle."""
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    params = _params(41, variant, gain)
+    x = torch.from_numpy(make_features(41, 1, 64, 256, 256))
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        want, st = ce_forward_oracle(x, params, mode=mode, k=k or None, stages=True)
+    deg_ref = st["deg"][0].numpy().astype(np.int64)
+    rowsum_ref, agg_ref = st["rowsum"][0].numpy(), st["agg"][0]
+    del st
+    # the oracle in fp32 IS the reference's arithmetic, rounding noise included: logits 10 S m of a few tens turn the last
+    # bits of S into ~1e-4 of a softmax weight.  So the yardstick is an fp64 evaluation: the block must be within 1e-4 of
+    # it, and within 1e-4 + (the fp32 oracle's own distance to fp64) of the fp32 oracle
+    with torch.no_grad():
+        want64 = ce_forward_oracle(x, params, mode=mode, k=k or None, dtype=torch.float64).float()
+    e_ref = normwise(want.numpy(), want64.numpy())
+    ce = _module(params, mode, k)
+    with torch.no_grad():
+        out = ce(x.to(_dev())).cpu()
+    assert normwise(out.numpy(), want64.numpy()) <= TOL
+    assert normwise(out.numpy(), want.numpy()) <= TOL + e_ref
+    out_d, info = _debug(ce, x.to(_dev()))
+    deg = info["deg"][0].cpu().numpy().astype(np.int64)
+    ndiff = int((deg != deg_ref).sum())
+    # (a key within rounding of its threshold may flip between two fp32 evaluations)
+    assert ndiff <= max(1, int(1e-4 * deg.size)), f"{ndiff} of {deg.size} queries differ in degree"
+    assert normwise(info["rowsum"][0].cpu().numpy(), rowsum_ref) <= TOL + e_ref
+    assert normwise(_agg_ckk(info["agg"][0].cpu()).numpy(), agg_ref.numpy()) <= TOL + e_ref
+    assert normwise(out_d.cpu().numpy(), want64.numpy()) <= TOL
+    if mode == "adaptive":
+        assert 4.0 <= deg_ref.mean() <= 16.0 or gain > 1.9, deg_ref.mean()       # the "mean degree ~8" regime of section 8d
+
+
+@pytest.mark.parametrize("H,W,mode,k,in_dtype", [(512, 512, "topk", 8, torch.bfloat16),
+                                                 (1024, 1024, "adaptive_topk", 16, torch.float32)])
+def test_config3_config4_query_sample_against_all_keys(H, W, mode, k, in_dtype):
+    """512^2 (bf16 feature maps) and 1024^2 (adaptive AND top-16): 64 queries spread over the image, each against ALL keys,
+    on the oracle; the block's degrees, softmax mass and aggregated patches for those queries must match."""
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_rows_oracle
+    params = _params(61, "sparse", 1.7)
+    x = torch.from_numpy(make_features(61 + H, 1, 64, H, W))
+    if in_dtype != torch.float32:
+        x = x.to(in_dtype).float()                                   # what the block sees after its boundary conversion
+    L = (H // 4) * (W // 4)
+    rows = torch.linspace(0, L - 1, 64).long()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = ce_rows_oracle(x, params, rows, mode=mode, k=k)
+    ce = _module(params, mode, k)
+    out_d, info = _debug(ce, x.to(_dev()))
+    deg = info["deg"][0].cpu()[rows].numpy()
+    assert np.array_equal(deg, ref["deg"].numpy().astype(deg.dtype))
+    assert normwise(info["rowsum"][0].cpu()[rows].numpy(), ref["rowsum"].numpy()) <= TOL
+    agg = _agg_ckk(info["agg"][0].cpu()[rows])
+    assert normwise(agg.numpy(), ref["agg"].numpy()) <= TOL
+    with torch.no_grad():
+        out = ce(x.to(_dev()).to(in_dtype))
+    assert out.dtype == in_dtype and torch.isfinite(out.float()).all()
+    # module output (fused fp16-split prologue) vs the debug entry point (stock-conv prologue): the same fold of the same
+    # aggregated patches up to the rounding of b1, plus one bf16 rounding at the boundary in config 3
+    assert normwise(out.float().cpu().numpy(), out_d.cpu().numpy()) <= (2.0 ** -8 if in_dtype == torch.bfloat16 else TOL)
+
+
+def test_config3_bf16_feature_maps_vs_oracle_on_the_rounded_input():
+    """bf16 I/O (config 3) against the ORACLE (not against the block itself): the block computes in fp32 on the bf16-rounded
+    map, so oracle(x.bf16().float()) is the yardstick; the output carries one bf16 rounding (2^-8 relative)."""
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    params = _params(63, "default", 2.0)
+    x = torch.from_numpy(make_features(63, 2, 64, 128, 128))
+    xr = x.to(torch.bfloat16)
+    with torch.no_grad():
+        want = ce_forward_oracle(xr.float(), params, mode="topk", k=8)
+    ce = _module(params, "topk", 8)
+    with torch.no_grad():
+        y16 = ce(xr.to(_dev()))
+        y32 = ce(xr.float().to(_dev()))
+    assert y16.dtype == torch.bfloat16
+    assert normwise(y32.cpu().numpy(), want.numpy()) <= TOL
+    err = (y16.float().cpu() - want).abs()
+    assert bool((err <= 2.0 ** -8 * want.abs() + TOL * want.abs().max()).all())
+
+
+# ---- config 5: training ----------------------------------------------------------------------------------------------
+
+def _oracle_ce_cls():
+    from dagl_amd.ce import CE
+    from oracle.ce_oracle import ce_forward_oracle
+
+    class OracleCE(CE):
+        """The block's parameter surface with the dense differentiable CPU oracle as forward (autograd derives what the
+        reference's autograd derives)."""
+
+        def forward(self, b):
+            prm = {n: p for n, p in self.named_parameters() if not n.startswith("W.")}
+            return ce_forward_oracle(b, prm, mode=self.select_mode, k=self.select_k if self.select_mode != "adaptive" else None,
+                                     dtype=b.dtype)
+    return OracleCE
+
+
+@pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive", 0)])
+def test_config5_whole_network_gradients_match_oracle_autograd(mode, k):
+    from dagl_amd.ce import CE
+    from dagl_amd.net import RR, seeded_state_dict
+    from dagl_amd.train import freeze_unused, task_loss
+    # N = 2304 keys per image: the screened scan runs.  "adaptive" = the shipped semantics at default-like init: dense
+    # neighbourhoods, forward and backward in the dense formulation (dense_train.hip)
+    B, C, H, W = 2, 3, 48, 48
+    ref = RR(n_colors=C, ce_cls=_oracle_ce_cls())
+    sd = seeded_state_dict(ref.state_dict(), 19)
+    ref.load_state_dict(sd, strict=True)
+    net = RR(n_colors=C)
+    net.load_state_dict(sd, strict=True)
+    for m in list(ref.modules()) + list(net.modules()):
+        if isinstance(m, CE):
+            m.select_mode, m.select_k = mode, k or m.select_k
+    freeze_unused(ref); freeze_unused(net)
+    g = torch.Generator().manual_seed(23)
+    hr = torch.rand(B, C, H, W, generator=g)
+    lr = hr + (50.0 / 255.0) * torch.randn(B, C, H, W, generator=g)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))                # (hundreds of threads crawl on these small fp64 ops)
+    ref = ref.double().train()
+    loss_ref = task_loss(ref(lr.double()), hr.double(), "dn_real")
+    loss_ref.backward()
+    net = net.to(_dev()).train()
+    loss = task_loss(net(lr.to(_dev())), hr.to(_dev()), "dn_real")
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
+    worst, errs = ("", 0.0), []
+    gref = dict(ref.named_parameters())
+    for name, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        if gref[name].grad is None:                                    # fixed-k selection: the thr / bias heads take no part
+            assert p.grad is None and mode == "topk" and ("thr_conv" in name or "bias_conv" in name), name
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        e = normwise(p.grad.cpu().numpy(), gref[name].grad.numpy())
+        errs.append(e)
+        if e > worst[1]:
+            worst = (name, e)
+    if mode == "topk":
+        # fixed-k selection is discontinuous: one near-tie between an 8th and a 9th neighbour in one of the 12 heads, resolved
+        # differently by fp64 and fp32 scores, moves that head's gradients by ~1e-2 while everything else agrees
+        assert float(np.median(errs)) <= 1e-3 and worst[1] <= 5e-2, (worst, float(np.median(errs)))
+    else:
+        assert worst[1] <= 2e-3, worst
+
+
+@pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive", 0)])
+def test_config5_train_step_128x128_batch8(mode, k):
+    """BASELINE configs[4] per GPU: RR(n_colors=3), [8,3,128,128] crops, MSE(sum)/(2B), Adam: the loss goes down."""
+    from dagl_amd.ce import CE
+    from dagl_amd.net import RR, seeded_state_dict
+    from dagl_amd.train import TrainOptions, TrainStep, freeze_unused, make_optimizer
+    net = RR(n_colors=3)
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 7), strict=True)
+    for m in net.modules():
+        if isinstance(m, CE):
+            m.select_mode, m.select_k = mode, k or m.select_k
+    net = net.to(_dev())
+    freeze_unused(net)
+    opt = TrainOptions(task="dn_real", lr=1e-4)
+    step = TrainStep(net, make_optimizer(net, opt), opt, generator=torch.Generator(device=_dev()).manual_seed(5))
+    hr = torch.rand(8, 3, 128, 128, generator=torch.Generator().manual_seed(6)).to(_dev())
+    losses = [float(step(hr)[0]) for _ in range(6)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    for name, p in net.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        elif mode == "topk":
+            assert ".W." in name or "thr_conv" in name or "bias_conv" in name or name.startswith("add_mean"), name
+
+
+def test_config5_rccl_process_group_on_one_gpu():
+    """The 8-GPU run must not be the first execution of init_process_group("nccl") / DDP over RCCL: world size 1 here."""
+    env = dict(os.environ, DAGL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--train", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--crop", "64"], env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["parallelism"] == "ddp1" and line["allreduce_ms"] is not None and line["allreduce_ms"] > 0
+    assert np.isfinite(line["loss_first_last"]).all()
+    # forward bench through the same process-group path
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--size", "64",
+                        "--no-quality", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]

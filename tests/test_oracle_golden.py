@@ -56,3 +56,23 @@ def test_adaptive_topk_equals_adaptive_when_k_covers_degree():
     kmax = int(g["deg"].max())
     out = ce_forward_oracle(x, params, mode="adaptive_topk", k=kmax)
     assert normwise(out.numpy(), g["out"]) <= 1e-4
+
+
+def test_core_and_row_sample_entries_agree_with_the_pinned_forward():
+    """ce_core_oracle (features given) and ce_rows_oracle (a sample of the queries) are the same loop body as the pinned
+    ce_forward_oracle: fed with its own stage outputs they reproduce it."""
+    import torch
+    from oracle.ce_oracle import ce_core_oracle, ce_forward_oracle, ce_rows_oracle
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(5, variant="sparse", sparse_gain=1.5).items()}
+    x = torch.from_numpy(make_features(5, 2, 64, 23, 30))
+    for mode, k in (("adaptive", None), ("topk", 5), ("adaptive_topk", 3)):
+        out, st = ce_forward_oracle(x, params, mode=mode, k=k, stages=True)
+        out_c, st_c = ce_core_oracle(st["Wq"], st["X"], st["b2"], st["thr"], st["bias"], mode=mode, k=k,
+                                     dtype=torch.float32, stages=True)
+        assert torch.equal(out, out_c) and torch.equal(st["deg"], st_c["deg"])
+        rows = torch.tensor([0, 7, 19, 47])
+        r = ce_rows_oracle(x[1:2], params, rows, mode=mode, k=k)
+        assert torch.equal(r["deg"], st["deg"][1][rows])
+        assert torch.allclose(r["agg"], st["agg"][1][rows], rtol=0, atol=1e-6 * float(st["agg"].abs().max()))
+        assert torch.allclose(r["rowsum"], st["rowsum"][1][rows], rtol=1e-5, atol=1e-7)
