@@ -65,8 +65,14 @@ SIGNATURES = {
     "dagl_ce_core_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
     "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i] + [_vp] * 14 + [_sz]),
+    "dagl_gemm_f32_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
-                           _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i]),
+                           _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i, _i, _vp]),
+    "dagl_unfold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),
+    "dagl_fold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),
+    "dagl_copy4": (_i, [_vp, _i, _i, _i, _i, _vp] + [C.c_longlong] * 4 + [_vp] + [C.c_longlong] * 4),
+    "dagl_relu_backward": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "dagl_col_sum": (_i, [_vp, _sz, _i, _vp, _vp]),
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
     "dagl_profile_destroy": (_i, [_vp]),
     "dagl_profile_reset": (_i, [_vp]),

@@ -158,20 +158,35 @@ class CE(nn.Module):
         return b1, b2, thr, bias
 
     def _forward_train(self, b: torch.Tensor) -> torch.Tensor:
-        """Differentiable path (DN_Gray/trainer.py:44-50): the convolutions and the two patch projections run as
-        stock torch ops under autograd -- fc(unfold(.)) is a 7x7 convolution with the Linear weight viewed as
-        [196,16,7,7] (dagl.py:240-249) -- and the graph core (dagl.py:250-272) is a HIP op with its own backward: neighbour
-        lists (top-k modes, adaptive masks keeping <= 64 keys per query) or, for denser masks, the dense formulation."""
-        b1, b2, thr, bias = self._prologue(b)
-        B, _, H, W = b1.shape
-        t, bo = same_pad_amounts(H, self.ksize, self.stride_1)
-        l, r = same_pad_amounts(W, self.ksize, self.stride_1)
-        w1 = self.fc1[0].weight.view(-1, self.inter_channels, self.ksize, self.ksize)
-        w2 = self.fc2[0].weight.view(-1, self.inter_channels, self.ksize, self.ksize)
-        wq = F.relu(F.conv2d(F.pad(b1, (l, r, t, bo)), w1, self.fc1[0].bias, stride=self.stride_1))
-        x = F.relu(F.conv2d(b1, w2, self.fc2[0].bias, stride=self.stride_2, padding=self.ksize // 2))
-        wq_rows = wq.permute(0, 2, 3, 1).reshape(B, -1, wq.shape[1])
-        x_rows = x.permute(0, 2, 3, 1).reshape(B, -1, x.shape[1])
+        """Differentiable path (DN_Gray/trainer.py:44-50), every stage on the HIP library: the four prologue convolutions
+        and the two patch projections as unfold + fp32 matrix-core GEMM with explicit backward (train_ops.py; fc(unfold(.))
+        = a product of the patch rows with the Linear weight, dagl.py:240-249), the graph core (dagl.py:250-272) as a HIP
+        op with its own backward: neighbour lists (top-k modes, adaptive masks keeping <= 64 keys per query) or, for
+        denser masks, the dense formulation."""
+        from . import train_ops as T
+        B, _, H, W = b.shape
+        ks, c = self.ksize, self.inter_channels
+        t, _bo = same_pad_amounts(H, ks, self.stride_1)
+        l, _r = same_pad_amounts(W, ks, self.stride_1)
+        Lh, Lw = -(-H // self.stride_1), -(-W // self.stride_1)
+        xp = T.to_padded_nhwc(b, H, W)                                                       # [B,H+6,W+6,64]
+        # dagl.py:208-209  g (3x3, pad 1), theta (1x1)
+        b1_rows = T.patch_linear(xp, T.conv_weight_rows(self.g.weight), self.g.bias, 3, 1, T.PAD - 1, T.PAD - 1, H, W)
+        b2_rows = T.patch_linear(xp, T.conv_weight_rows(self.theta.weight), self.theta.bias, 1, 1, T.PAD, T.PAD, H, W)
+        b2 = b2_rows.view(B, H, W, c).permute(0, 3, 1, 2)                                    # NCHW view of the value map
+        # dagl.py:213-215  thr_conv / bias_conv on the SAME-padded input (7x7, stride 4): one product with two outputs
+        thr = bias = None
+        if self.select_mode != "topk":                 # (the fixed-k variant has no threshold heads)
+            w_tb = torch.cat([T.conv_weight_rows(self.thr_conv.weight), T.conv_weight_rows(self.bias_conv.weight)], dim=0)
+            b_tb = torch.cat([self.thr_conv.bias, self.bias_conv.bias], dim=0)
+            tb = T.patch_linear(xp, w_tb, b_tb, ks, self.stride_1, T.PAD - t, T.PAD - l, Lh, Lw)  # [B,L,2]
+            thr, bias = tb[..., 0], tb[..., 1]
+        # dagl.py:216-249  patches of b1 (stride 4 SAME / stride 1) through fc1 / fc2 + ReLU
+        b1p = T.to_padded_nhwc(b1_rows, H, W, from_rows=True)                                 # [B,H+6,W+6,16]
+        wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, self.stride_1,
+                                 T.PAD - t, T.PAD - l, Lh, Lw, relu=True)                     # [B,L,196]
+        x_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc2[0].weight, c, ks), self.fc2[0].bias, ks, self.stride_2,
+                                0, 0, H, W, relu=True)                                        # [B,N,196]
         info = {}
         self._pack_key = None          # the shared workspace is reused with another layout
         out = None

@@ -855,14 +855,21 @@ int dagl_ce_core_dense_backward(void* stream, int B, int H, int W, const float* 
                                        d_wq_rows, d_x_rows, d_b2, d_thr, d_bias, workspace, ws_bytes);
 }
 
+size_t dagl_gemm_f32_scratch_floats(int batch, int M, int N, int K) {
+    if (batch != 1 || M < 1 || N < 1 || K < 1) return 0;
+    const int sl = gemm32_auto_slices(M, N, K);
+    return sl > 1 ? (size_t)sl * M * N : 0;
+}
+
 int dagl_gemm_f32(void* stream, int batch, int M, int N, int K, const float* A, long long lda, long long stride_a, int a_k_contiguous,
                   const float* B, long long ldb, long long stride_b, int b_k_contiguous, float* C, long long ldc, long long stride_c,
-                  float alpha, float beta, const float* bias, int relu) {
-    DAGL_REQUIRE(batch >= 1 && M >= 0 && N >= 0 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "dagl_gemm_f32: bad shape");
+                  float alpha, float beta, const float* bias, int relu, int chunk_tiles, float* scratch) {
+    DAGL_REQUIRE(batch >= 1 && M >= 0 && N >= 0 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N && chunk_tiles >= 0, "dagl_gemm_f32: bad shape");
     Gemm32 g;
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.A = A; g.lda = lda; g.sA = stride_a; g.a_kc = a_k_contiguous;
     g.B = B; g.ldb = ldb; g.sB = stride_b; g.b_kc = b_k_contiguous; g.C = C; g.ldc = ldc; g.sC = stride_c;
-    g.alpha = alpha; g.beta = beta; g.bias = bias; g.relu = relu;
+    g.alpha = alpha; g.beta = beta; g.bias = bias; g.relu = relu; g.chunk_tiles = chunk_tiles;
+    if (scratch != nullptr && batch == 1) { g.slices = gemm32_auto_slices(M, N, K); g.scratch = scratch; }
     return launch_gemm32((hipStream_t)stream, g);
 }
 

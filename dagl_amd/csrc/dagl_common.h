@@ -316,8 +316,12 @@ struct Gemm32 {
     float* C; long long ldc, sC;
     float alpha, beta;
     const float* bias; int relu;
+    int chunk_tiles = 0;                              // > 0: partial sums of chunk_tiles * 16 products, added in fp32
+    int slices = 1; float* scratch = nullptr;         // split-K (batch == 1): slices * M * N floats of scratch, fixed-order sum
+    int k_total = 0;                                  // (set by launch_gemm32)
 };
 int launch_gemm32(hipStream_t s, const Gemm32& g);
+int gemm32_auto_slices(int M, int N, int K);
 
 int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, float* dagg);
 int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar);

@@ -241,6 +241,7 @@ static Gemm32 dt_gemm(int M, int N, int K, int batch, const float* A, long long 
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.A = A; g.lda = lda; g.sA = sA; g.a_kc = a_kc;
     g.B = Bm; g.ldb = ldb; g.sB = sB; g.b_kc = b_kc; g.C = C; g.ldc = ldc; g.sC = sC;
     g.alpha = 1.0f; g.beta = beta; g.bias = nullptr; g.relu = 0;
+    g.chunk_tiles = (K == D) ? 3 : 8;                 // S: chains of 48 products; the long contractions: 128
     return g;
 }
 

@@ -9,8 +9,10 @@
 // Tile 128 x 128 x 16, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles; operands staged K-major in LDS
 // (As[k][m], Bs[k][n]) so that a fragment read is 32 consecutive words per half-wave (conflict-free); global tiles are
 // fetched as 16-byte vectors along whichever dimension is contiguous in memory and double-buffered through registers.
-// No split-K, no atomics: deterministic.  Either operand may be stored "K-contiguous" (row-major M x K / N x K) or
-// "K-major" (K x M / K x N), which covers NN, NT, TN without copies.
+// Either operand may be stored "K-contiguous" (row-major M x K / N x K) or "K-major" (K x M / K x N), which covers NN, NT,
+// TN without copies.  Products with few output tiles and a long K (the weight gradients: 196 x 784 outputs over 131072
+// patch rows) are cut into K slices that write their own partial C, summed in slice order by gemm32_reduce_kernel:
+// no atomics anywhere, deterministic.  Optional chunked accumulation keeps the fmaf chains short.
 #include "dagl_common.h"
 
 namespace dagl {
@@ -97,7 +99,22 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nt = (g.K + G_BK - 1) / G_BK;
+    // split-K launch (launch_gemm32): slice bz covers k in [bz * K, min((bz + 1) * K, k_total)) and writes its own C slice
+    if (g.k_total > 0) {
+        const int k_eff = g.k_total - (int)bz * g.K;
+        la.K = lb.K = k_eff < g.K ? k_eff : g.K;
+    }
+    const int K = la.K;
+    f32x16 sum[2][2];
+    if (g.chunk_tiles > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[a][b][r] = 0.f;
+    }
+    const int nt = (K + G_BK - 1) / G_BK;
     la.load(0, tid); lb.load(0, tid);
     la.store(As[0], tid); lb.store(Bs[0], tid);
     __syncthreads();
@@ -113,8 +130,26 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (g.chunk_tiles > 0 && (t + 1) % g.chunk_tiles == 0) {
+            // chunked accumulation: a chain of chunk_tiles * 16 products per partial sum instead of K (the partial sums are
+            // added in fp32): the rounding error of a long fmaf chain grows with its length
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { sum[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+        }
         if (t + 1 < nt) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
         __syncthreads();
+    }
+    if (g.chunk_tiles > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += sum[a][b][r];
     }
 
     // D[row = (r&3) + 8 (r>>2) + 4 h][col = i] of each 32 x 32 tile
@@ -139,9 +174,48 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
         }
 }
 
-int launch_gemm32(hipStream_t s, const Gemm32& g) {
+// C = epilogue(sum over slices, in slice order): the second half of a split-K product
+__global__ void gemm32_reduce_kernel(int slices, int M, int N, const float* __restrict__ part, float* __restrict__ C, long long ldc,
+                                     float alpha, float beta, const float* __restrict__ bias, int relu) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)M * N) return;
+    const int m = (int)(t / N), n = (int)(t - (size_t)m * N);
+    float v = 0.f;
+    for (int sidx = 0; sidx < slices; ++sidx) v += part[(size_t)sidx * M * N + t];
+    v = alpha * v + (bias ? bias[n] : 0.f);
+    float* c = C + (long long)m * ldc + n;
+    if (beta != 0.f) v += beta * *c;
+    if (relu) v = v > 0.f ? v : 0.f;
+    *c = v;
+}
+
+// slices a K-heavy product (few output tiles, long K: the weight gradients) is cut into so that the launch fills the chip
+int gemm32_auto_slices(int M, int N, int K) {
+    const long long tiles = (long long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    if (tiles >= 256 || K < 4096) return 1;
+    long long sl = (512 + tiles - 1) / tiles;
+    const long long by_k = K / 1024;                       // at least 64 K-tiles per slice
+    if (sl > by_k) sl = by_k;
+    if (sl > 256) sl = 256;
+    return (int)(sl < 1 ? 1 : sl);
+}
+
+int launch_gemm32(hipStream_t s, const Gemm32& g_in) {
+    Gemm32 g = g_in;
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DAGL_OK;
     if (g.K <= 0 || !g.A || !g.B || !g.C) { set_error("gemm32: bad argument"); return DAGL_ERR_INVALID; }
+    const float alpha = g.alpha, beta = g.beta; const float* bias = g.bias; const int relu = g.relu;
+    float* C = g.C; const long long ldc = g.ldc;
+    const int slices = (g.slices > 1 && g.batch == 1 && g.scratch != nullptr) ? g.slices : 1;
+    g.k_total = 0;
+    if (slices > 1) {
+        const int kc = ((g.K + slices - 1) / slices + G_BK - 1) / G_BK * G_BK;      // whole K-tiles per slice
+        g.k_total = g.K; g.K = kc; g.batch = (g.k_total + kc - 1) / kc;
+        g.sA = g.a_kc ? kc : (long long)kc * g.lda;
+        g.sB = g.b_kc ? kc : (long long)kc * g.ldb;
+        g.C = g.scratch; g.ldc = g.N; g.sC = (long long)g.M * g.N;
+        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0;
+    }
     const int vecA = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0) && (g.sA % 4 == 0);
     const int vecB = ((uintptr_t)g.B % 16 == 0) && (g.ldb % 4 == 0) && (g.sB % 4 == 0);
     const dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.batch), block(256);
@@ -150,6 +224,12 @@ int launch_gemm32(hipStream_t s, const Gemm32& g) {
     else if (!g.a_kc && g.b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, block, 0, s, g, vecA, vecB);
     else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
     DAGL_LAUNCH_CHECK("gemm32_kernel");
+    if (slices > 1) {
+        const size_t n = (size_t)g.M * g.N;
+        hipLaunchKernelGGL(gemm32_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.batch, g.M, g.N, g.scratch, C,
+                           ldc, alpha, beta, bias, relu);
+        DAGL_LAUNCH_CHECK("gemm32_reduce_kernel");
+    }
     return DAGL_OK;
 }
 

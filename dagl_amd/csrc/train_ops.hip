@@ -1,0 +1,151 @@
+// Stages of the differentiable path that are not matrix products: patch unfold / fold on zero-bordered NHWC maps, layout
+// copies, ReLU backward, column sums.  Together with gemm32.hip they make up the prologue convolutions and the two patch
+// projections of CE.forward under autograd (DN_Gray/model/dagl.py:208-249):
+//     conv / Linear over patches   =  unfold (im2col, element order (kh,kw,c))  ->  rows x weight^T  (+ bias, ReLU)
+//     d weight = d Z^T rows,   d rows = d Z weight,   d map = fold(d rows)   (gather form: no atomics, fixed order)
+// The inference path never materialises patches (project16.hip, prologue.hip); under autograd the unfolded rows are
+// what the weight gradient contracts with, so they are built here (recomputed in the backward, not kept).
+#include "dagl_common.h"
+
+namespace dagl {
+
+// rows[b, (py,px), (kh,kw,c)] = map[b, oy + py*stride + kh, ox + px*stride + kw, c];  thread = one float4 of a row
+__global__ __launch_bounds__(256) void unfold_patches_kernel(int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh,
+                                                             int ow, const float* __restrict__ map, float* __restrict__ rows) {
+    const int b = blockIdx.y;
+    const int c4n = C / 4, per_row = k * k * c4n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)oh * ow * per_row) return;
+    const int patch = (int)(t / per_row), e = (int)(t - (size_t)patch * per_row);
+    const int tap = e / c4n, c4 = e - tap * c4n;
+    const int kh = tap / k, kw = tap - kh * k;
+    const int py = patch / ow, px = patch - py * ow;
+    const float4 v = *reinterpret_cast<const float4*>(
+        map + (((size_t)b * Hp + oy + py * stride + kh) * Wp + ox + px * stride + kw) * C + 4 * c4);
+    reinterpret_cast<float4*>(rows + ((size_t)b * oh * ow + patch) * (size_t)(k * k * C))[e] = v;
+}
+
+// dmap[b, y, x, c] = sum over the patches (py,px) and taps (kh,kw) with oy + py*stride + kh = y, ox + px*stride + kw = x of
+// drows[b, (py,px), (kh,kw,c)];  thread = one float4 of a map pixel, taps visited in (kh, kw) order
+__global__ __launch_bounds__(256) void fold_patches_kernel(int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh,
+                                                           int ow, const float* __restrict__ drows, float* __restrict__ dmap) {
+    const int b = blockIdx.y;
+    const int c4n = C / 4;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Hp * Wp * c4n) return;
+    const int pix = (int)(t / c4n), c4 = (int)(t - (size_t)pix * c4n);
+    const int y = pix / Wp, x = pix - y * Wp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t row_len = (size_t)k * k * C;
+    for (int kh = 0; kh < k; ++kh) {
+        const int ty = y - oy - kh;
+        if (ty < 0 || (ty % stride) != 0 || ty / stride >= oh) continue;
+        for (int kw = 0; kw < k; ++kw) {
+            const int tx = x - ox - kw;
+            if (tx < 0 || (tx % stride) != 0 || tx / stride >= ow) continue;
+            const float4 v = *reinterpret_cast<const float4*>(
+                drows + ((size_t)b * oh * ow + (size_t)(ty / stride) * ow + tx / stride) * row_len + (size_t)(kh * k + kw) * C + 4 * c4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    reinterpret_cast<float4*>(dmap + ((size_t)b * Hp * Wp + pix) * C)[c4] = acc;
+}
+
+// generic strided 4-D copy dst[i0,i1,i2,i3] = src[i0,i1,i2,i3] (element strides); the fastest index is i3
+__global__ void copy4_kernel(int n0, int n1, int n2, int n3, const float* __restrict__ src, long long s0, long long s1,
+                             long long s2, long long s3, float* __restrict__ dst, long long d0, long long d1, long long d2,
+                             long long d3) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)n0 * n1 * n2 * n3;
+    if (t >= n) return;
+    const int i3 = (int)(t % n3); size_t r = t / n3;
+    const int i2 = (int)(r % n2); r /= n2;
+    const int i1 = (int)(r % n1); const int i0 = (int)(r / n1);
+    dst[i0 * d0 + i1 * d1 + i2 * d2 + i3 * d3] = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+}
+
+__global__ void relu_backward_kernel(size_t n, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// out[c] = sum_r src[r, c]: one block per column, fp64 partials in a fixed order
+__global__ __launch_bounds__(256) void col_sum_kernel(size_t rows, int cols, const float* __restrict__ src, float* __restrict__ out) {
+    __shared__ double part[4];
+    const int c = blockIdx.x;
+    double t = 0.0;
+    for (size_t r = threadIdx.x; r < rows; r += 256) t += (double)src[r * cols + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (float)((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+int launch_unfold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                          const float* map, float* rows) {
+    const size_t n = (size_t)oh * ow * k * k * (C / 4);
+    hipLaunchKernelGGL(unfold_patches_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, Hp, Wp, C, k, stride, oy, ox,
+                       oh, ow, map, rows);
+    DAGL_LAUNCH_CHECK("unfold_patches_kernel");
+    return DAGL_OK;
+}
+
+int launch_fold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                        const float* drows, float* dmap) {
+    const size_t n = (size_t)Hp * Wp * (C / 4);
+    hipLaunchKernelGGL(fold_patches_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, Hp, Wp, C, k, stride, oy, ox,
+                       oh, ow, drows, dmap);
+    DAGL_LAUNCH_CHECK("fold_patches_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl
+
+using namespace dagl;
+
+extern "C" {
+
+static int patch_geometry_ok(int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow) {
+    return B >= 1 && Hp >= 1 && Wp >= 1 && C >= 4 && (C % 4) == 0 && k >= 1 && stride >= 1 && oy >= 0 && ox >= 0 && oh >= 1 &&
+           ow >= 1 && oy + (oh - 1) * stride + k <= Hp && ox + (ow - 1) * stride + k <= Wp;
+}
+
+int dagl_unfold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                        const float* map, float* rows) {
+    DAGL_REQUIRE(patch_geometry_ok(B, Hp, Wp, C, k, stride, oy, ox, oh, ow) && map && rows, "dagl_unfold_patches: bad argument");
+    return launch_unfold_patches((hipStream_t)stream, B, Hp, Wp, C, k, stride, oy, ox, oh, ow, map, rows);
+}
+
+int dagl_fold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                      const float* drows, float* dmap) {
+    DAGL_REQUIRE(patch_geometry_ok(B, Hp, Wp, C, k, stride, oy, ox, oh, ow) && drows && dmap, "dagl_fold_patches: bad argument");
+    return launch_fold_patches((hipStream_t)stream, B, Hp, Wp, C, k, stride, oy, ox, oh, ow, drows, dmap);
+}
+
+int dagl_copy4(void* stream, int n0, int n1, int n2, int n3, const float* src, long long s0, long long s1, long long s2,
+               long long s3, float* dst, long long d0, long long d1, long long d2, long long d3) {
+    DAGL_REQUIRE(n0 >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1 && src && dst, "dagl_copy4: bad argument");
+    const size_t n = (size_t)n0 * n1 * n2 * n3;
+    hipLaunchKernelGGL(copy4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n0, n1, n2, n3, src, s0,
+                       s1, s2, s3, dst, d0, d1, d2, d3);
+    DAGL_LAUNCH_CHECK("copy4_kernel");
+    return DAGL_OK;
+}
+
+int dagl_relu_backward(void* stream, size_t n, const float* y, const float* dy, float* dz) {
+    DAGL_REQUIRE(y && dy && dz, "dagl_relu_backward: null pointer");
+    if (n == 0) return DAGL_OK;
+    hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, y, dy, dz);
+    DAGL_LAUNCH_CHECK("relu_backward_kernel");
+    return DAGL_OK;
+}
+
+int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out) {
+    DAGL_REQUIRE(cols >= 1 && src && out, "dagl_col_sum: bad argument");
+    hipLaunchKernelGGL(col_sum_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, rows, cols, src, out);
+    DAGL_LAUNCH_CHECK("col_sum_kernel");
+    return DAGL_OK;
+}
+
+}  // extern "C"

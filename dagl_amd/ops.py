@@ -508,7 +508,8 @@ def ce_core_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, mode: s
 
 @_on_device
 def gemm_f32(A: torch.Tensor, B: torch.Tensor, a_k_contiguous: bool = True, b_k_contiguous: bool = False, out=None,
-             alpha: float = 1.0, beta: float = 0.0, bias=None, relu: bool = False) -> torch.Tensor:
+             alpha: float = 1.0, beta: float = 0.0, bias=None, relu: bool = False, chunk_tiles: int = 0,
+             split_k: bool = True) -> torch.Tensor:
     """Batched fp32 matrix product on the matrix cores (``dagl_gemm_f32``).  A: [b,M,K] (a_k_contiguous) or [b,K,M];
     B: [b,N,K] (b_k_contiguous) or [b,K,N]; 2-D operands = batch of one.  Returns C [b,M,N] (= alpha A B + beta out)."""
     _need(A, "A"); _need(B, "B")
@@ -528,10 +529,17 @@ def gemm_f32(A: torch.Tensor, B: torch.Tensor, a_k_contiguous: bool = True, b_k_
         _need(out, "out")
     if bias is not None:
         _need(bias, "bias")
-    check(_lib.load().dagl_gemm_f32(_stream(), nb, M, N, K, A.data_ptr(), A.shape[2], A.shape[1] * A.shape[2],
-                                    int(a_k_contiguous), B.data_ptr(), B.shape[2], B.shape[1] * B.shape[2],
-                                    int(b_k_contiguous), out.data_ptr(), N, M * N, float(alpha), float(beta),
-                                    bias.data_ptr() if bias is not None else None, int(relu)), "dagl_gemm_f32")
+    lib = _lib.load()
+    scratch = None
+    if split_k and nb == 1:
+        nf = lib.dagl_gemm_f32_scratch_floats(nb, M, N, K)
+        if nf:
+            scratch = torch.empty(nf, device=A.device, dtype=torch.float32)
+    check(lib.dagl_gemm_f32(_stream(), nb, M, N, K, A.data_ptr(), A.shape[2], A.shape[1] * A.shape[2],
+                            int(a_k_contiguous), B.data_ptr(), B.shape[2], B.shape[1] * B.shape[2],
+                            int(b_k_contiguous), out.data_ptr(), N, M * N, float(alpha), float(beta),
+                            bias.data_ptr() if bias is not None else None, int(relu), int(chunk_tiles),
+                            scratch.data_ptr() if scratch is not None else None), "dagl_gemm_f32")
     return out[0] if squeeze and out.dim() == 3 else out
 
 

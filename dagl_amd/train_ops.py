@@ -1,0 +1,124 @@
+"""The prologue convolutions and the two patch projections of ``CE.forward`` (DN_Gray/model/dagl.py:208-249) as
+differentiable ops on the HIP library: ``unfold -> fp32 matrix-core GEMM (+ bias, ReLU)`` forward, explicit
+``d weight / d bias / d rows -> fold`` backward (include/dagl_ce.h: dagl_unfold_patches, dagl_gemm_f32,
+dagl_fold_patches, dagl_copy4, dagl_relu_backward, dagl_col_sum).  No MIOpen / rocBLAS call is made on behalf of the
+block when it trains; torch keeps the parameters, the autograd tape and trivial views (weight permutes).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from ._lib import DaglError, check
+
+PAD = 3      # border of the NHWC maps: covers the 3x3 (pad 1), 7x7 (pad 3) and stride-4 SAME (top/left <= 3) windows
+
+
+def _copy4(src, sizes, s_strides, dst, d_strides):
+    check(_lib.load().dagl_copy4(ops._stream(), *sizes, src.data_ptr(), *s_strides, dst.data_ptr(), *d_strides), "dagl_copy4")
+
+
+class _ToPaddedNHWC(torch.autograd.Function):
+    """[B,C,H,W] (NCHW) or [B,H*W,C] rows -> zero-bordered channels-last map [B,H+6,W+6,C]; backward = crop."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, from_rows):
+        x = x.contiguous()
+        B = x.shape[0]
+        C = x.shape[2] if from_rows else x.shape[1]
+        Hp, Wp = H + 2 * PAD, W + 2 * PAD
+        with torch.cuda.device(x.device):
+            out = torch.zeros(B, Hp, Wp, C, device=x.device, dtype=torch.float32)
+            inner = (PAD * Wp + PAD) * C
+            if from_rows:       # src index (b, y, x, c)
+                _copy4(x, (B, H, W, C), (H * W * C, W * C, C, 1), out.view(-1)[inner:], (Hp * Wp * C, Wp * C, C, 1))
+            else:               # src NCHW, iterate (b, y, x, c) with c fastest in the destination
+                _copy4(x, (B, H, W, C), (C * H * W, W, 1, H * W), out.view(-1)[inner:], (Hp * Wp * C, Wp * C, C, 1))
+        ctx.geom = (B, C, H, W, from_rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, C, H, W, from_rows = ctx.geom
+        d_out = d_out.contiguous()
+        Hp, Wp = H + 2 * PAD, W + 2 * PAD
+        inner = (PAD * Wp + PAD) * C
+        with torch.cuda.device(d_out.device):
+            if from_rows:
+                dx = torch.empty(B, H * W, C, device=d_out.device, dtype=torch.float32)
+                _copy4(d_out.view(-1)[inner:], (B, H, W, C), (Hp * Wp * C, Wp * C, C, 1), dx, (H * W * C, W * C, C, 1))
+            else:
+                dx = torch.empty(B, C, H, W, device=d_out.device, dtype=torch.float32)
+                # iterate (b, c, y, x): x fastest in the destination
+                _copy4(d_out.view(-1)[inner:], (B, C, H, W), (Hp * Wp * C, 1, Wp * C, C), dx, (C * H * W, H * W, W, 1))
+        return dx, None, None, None
+
+
+def to_padded_nhwc(x, H, W, from_rows=False):
+    return _ToPaddedNHWC.apply(x, H, W, from_rows)
+
+
+class _PatchLinear(torch.autograd.Function):
+    """y[b, patch, :] = act(W . unfold(map)[b, patch, :] + bias): a convolution (any kernel size / stride) or a Linear over
+    extracted patches.  ``weight`` is [O, k*k*C] with the patch elements in (kh, kw, c) order."""
+
+    @staticmethod
+    def forward(ctx, pmap, weight, bias, k, stride, oy, ox, oh, ow, relu):
+        pmap, weight, bias = pmap.contiguous(), weight.contiguous(), bias.contiguous()
+        B, Hp, Wp, C = pmap.shape
+        O, K = weight.shape
+        if K != k * k * C:
+            raise DaglError("patch_linear: weight does not match the patch size")
+        lib = _lib.load()
+        with torch.cuda.device(pmap.device):
+            rows = torch.empty(B * oh * ow, K, device=pmap.device, dtype=torch.float32)
+            check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
+                                          rows.data_ptr()), "dagl_unfold_patches")
+            y = ops.gemm_f32(rows, weight, a_k_contiguous=True, b_k_contiguous=True, bias=bias, relu=relu, chunk_tiles=7)
+        ctx.geom = (B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K)
+        ctx.save_for_backward(pmap, weight, y if relu else pmap.new_empty(0))
+        return y.view(B, oh * ow, O)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K = ctx.geom
+        pmap, weight, y = ctx.saved_tensors
+        lib = _lib.load()
+        n = B * oh * ow
+        with torch.cuda.device(pmap.device):
+            dz = d_y.contiguous().view(n, O).float()
+            if relu:
+                dzr = torch.empty_like(dz)
+                check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
+                      "dagl_relu_backward")
+                dz = dzr
+            rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32)          # recomputed, not kept
+            check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
+                                          rows.data_ptr()), "dagl_unfold_patches")
+            d_w = d_b = d_map = None
+            if ctx.needs_input_grad[1]:
+                d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False, chunk_tiles=8)   # [O,n] x [n,K], split-K
+            if ctx.needs_input_grad[2]:
+                d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
+                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr()), "dagl_col_sum")
+            if ctx.needs_input_grad[0]:
+                d_rows = ops.gemm_f32(dz, weight, a_k_contiguous=True, b_k_contiguous=False, out=rows)   # [n,O] x [O,K]
+                d_map = torch.empty_like(pmap)
+                check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, d_rows.data_ptr(),
+                                            d_map.data_ptr()), "dagl_fold_patches")
+        return d_map, d_w, d_b, None, None, None, None, None, None, None
+
+
+def patch_linear(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu=False):
+    return _PatchLinear.apply(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu)
+
+
+def conv_weight_rows(w: torch.Tensor) -> torch.Tensor:
+    """conv weight [O,C,kh,kw] -> [O, kh*kw*C] in the unfold's (kh,kw,c) element order (a torch view + copy: autograd
+    carries the gradient back to the parameter)."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def fc_weight_rows(w: torch.Tensor, c: int, k: int) -> torch.Tensor:
+    """Linear weight over Unfold's (c,kh,kw) patch order (dagl.py:196-203, :248-249) -> (kh,kw,c) order."""
+    return w.view(w.shape[0], c, k, k).permute(0, 2, 3, 1).reshape(w.shape[0], -1)

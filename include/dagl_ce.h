@@ -237,11 +237,31 @@ int    dagl_ce_core_dense_backward(void* stream, int B, int H, int W,
  * C[b] = alpha * A[b] B[b] + beta * C[b] (+ bias[n], relu).  A is logically M x K, stored row-major
  * (a_k_contiguous: element (m,k) at A[m*lda + k]) or K-major (A[k*lda + m]); B is logically K x N, stored
  * as N x K rows (b_k_contiguous: B[n*ldb + k]) or K x N rows (B[k*ldb + n]).  Replaces torch.matmul / torch.mm
- * of dagl.py:250,263 and their autograd counterparts.  Deterministic (no split-K, no atomics).                  */
+ * of dagl.py:250,263 and their autograd counterparts.  chunk_tiles > 0: partial sums over chunk_tiles * 16 products
+ * added in fp32 (shorter rounding chains).  scratch (batch == 1 only, may be NULL): dagl_gemm_f32_scratch_floats()
+ * floats; when given, a product with few output tiles and a long K (a weight gradient) is cut into K slices that fill
+ * the chip, summed in slice order.  Deterministic either way (no atomics).                                        */
+size_t dagl_gemm_f32_scratch_floats(int batch, int M, int N, int K);
 int dagl_gemm_f32(void* stream, int batch, int M, int N, int K,
                   const float* A, long long lda, long long stride_a, int a_k_contiguous,
                   const float* B, long long ldb, long long stride_b, int b_k_contiguous,
-                  float* C, long long ldc, long long stride_c, float alpha, float beta, const float* bias, int relu);
+                  float* C, long long ldc, long long stride_c, float alpha, float beta, const float* bias, int relu,
+                  int chunk_tiles, float* scratch);
+
+/* Stages of the differentiable path besides the matrix products (train_ops.hip): a convolution / Linear over patches
+ * under autograd is  unfold -> dagl_gemm_f32 (+ bias, ReLU);  d weight = d Z^T rows,  d rows = d Z weight,
+ * d map = fold(d rows).  Replaces nn.Conv2d / nn.Linear / nn.Unfold of dagl.py:208-249 in the training path.
+ *   unfold: rows[b, (py,px), (kh,kw,c)] = map[b, oy + py*stride + kh, ox + px*stride + kw, c]   (map [B,Hp,Wp,C], C % 4 == 0)
+ *   fold:   the adjoint, written for every pixel of the [B,Hp,Wp,C] map (gather form, no atomics)
+ *   copy4:  generic strided 4-D copy (layout changes NCHW <-> zero-bordered NHWC and their adjoints)             */
+int dagl_unfold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                        const float* map, float* rows);
+int dagl_fold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                      const float* d_rows, float* d_map);
+int dagl_copy4(void* stream, int n0, int n1, int n2, int n3, const float* src, long long s0, long long s1, long long s2,
+               long long s3, float* dst, long long d0, long long d1, long long d2, long long d3);
+int dagl_relu_backward(void* stream, size_t n, const float* y, const float* dy, float* dz);   /* dz = dy * (y > 0)   */
+int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out);         /* out[c] = sum_r src   */
 
 /* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
  * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).  `scratch` = 8*B*L floats of

@@ -90,7 +90,8 @@ def test_training_forward_equals_inference_forward():
             ref = ce(xd)
         out = ce(xd.clone().requires_grad_(True))
         assert out.requires_grad
-        assert normwise(out.detach().cpu().numpy(), ref.cpu().numpy()) <= 2e-5
+        # (two evaluations of the same maths: fused split-fp16 kernels vs unfold + fp32 GEMM chains)
+        assert normwise(out.detach().cpu().numpy(), ref.cpu().numpy()) <= 5e-5
         with torch.no_grad():                               # and the inference path still works afterwards
             again = ce(xd)
         assert torch.equal(again, ref)
@@ -249,7 +250,16 @@ def test_dense_core_matches_the_oracle_and_its_autograd():
     L, N = 12 * 10, H * W
     wq = torch.rand(B, L, 196, generator=g) * 0.1; xr = torch.rand(B, N, 196, generator=g) * 0.1
     b2 = torch.randn(B, 16, H, W, generator=g); G = torch.randn(B, 16, H, W, generator=g)
-    thr = 1.0 + 0.02 * torch.randn(B, L, generator=g); bias = 0.002 * torch.randn(B, L, generator=g)
+    # every query's threshold sits in the middle of its widest score gap around the median (the mask is discontinuous: a
+    # key within rounding of the threshold would flip between fp32 and fp64 scores and move the output by 1/deg)
+    S = torch.einsum("bld,bnd->bln", wq.double(), xr.double())
+    v = S.sort(dim=2).values
+    lo = int(0.3 * N)
+    gap = v[:, :, lo + 1:int(0.7 * N)] - v[:, :, lo:int(0.7 * N) - 1]
+    at = gap.argmax(dim=2, keepdim=True) + lo
+    T = 0.5 * (v.gather(2, at) + v.gather(2, at + 1)).squeeze(2)
+    thr = 1.0 + 0.02 * torch.randn(B, L, generator=g)
+    bias = (S.mean(dim=2) * thr.double() - T).float()                  # T = mu * thr - bias
     leaves = [t.double().requires_grad_(True) for t in (wq, xr, b2, thr, bias)]
     ref, st = ce_core_oracle(*leaves, mode="adaptive", stages=True)
     (ref * G.double()).sum().backward()
@@ -257,9 +267,7 @@ def test_dense_core_matches_the_oracle_and_its_autograd():
     dev = _dev()
     d = [t.to(dev) for t in (wq, xr, b2, thr, bias)]
     out, saved = ops.ce_core_dense_forward(*d)
-    # (a key within rounding of its threshold may flip between fp32 and fp64 scores)
-    assert abs(saved["info"]["total_edges"] - int(st["deg"].sum())) <= 3
-    assert abs(saved["info"]["max_degree"] - int(st["deg"].max())) <= 2
+    assert saved["info"]["total_edges"] == int(st["deg"].sum()) and saved["info"]["max_degree"] == int(st["deg"].max())
     assert normwise(out.cpu().numpy(), ref.detach().numpy()) <= TOL_OUT
     grads = ops.ce_core_dense_backward(G.to(dev), *d, saved)
     for name, got, leaf in zip(("d_wq", "d_x", "d_b2", "d_thr", "d_bias"), grads, leaves):

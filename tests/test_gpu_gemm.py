@@ -45,3 +45,38 @@ def test_gemm_f32_is_an_fmaf_chain_and_deterministic():
     assert torch.equal(got.cpu(), A @ Bm)
     x = torch.randn(500, 196, generator=g).to(dev); y = torch.randn(1234, 196, generator=g).to(dev)
     assert torch.equal(ops.gemm_f32(x, y, True, True), ops.gemm_f32(x, y, True, True))
+
+
+@pytest.mark.parametrize("k,stride,C,H,W", [(7, 1, 16, 23, 30), (7, 4, 16, 23, 30), (3, 1, 64, 17, 21), (1, 1, 64, 9, 12),
+                                            (7, 4, 64, 33, 47)])
+def test_patch_linear_is_the_convolution_and_its_autograd(k, stride, C, H, W):
+    """unfold + GEMM (+ bias, ReLU) and its explicit backward (train_ops.py) against torch's conv2d autograd in fp64:
+    3x3 / 1x1 / 7x7 windows, stride 1 and the stride-4 SAME grid (asymmetric padding, dagl.py:123-139)."""
+    import torch.nn.functional as F
+    from dagl_amd import train_ops as T
+    from dagl_amd.synth import same_pad_amounts
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(k * 100 + stride)
+    B, O = 2, 20
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(O, C, k, k, generator=g) * 0.1
+    b = torch.randn(O, generator=g)
+    G = torch.randn(B, O, -(-H // stride), -(-W // stride), generator=g)
+    # reference: SAME padding for stride 4, symmetric k//2 for stride 1
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    if stride == 1:
+        pt = pl = k // 2
+        ref = F.relu(F.conv2d(xr, wr, br, padding=k // 2))
+    else:
+        (pt, pb), (pl, pr) = same_pad_amounts(H, k, stride), same_pad_amounts(W, k, stride)
+        ref = F.relu(F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, br, stride=stride))
+    (ref * G.double()).sum().backward()
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    oh, ow = ref.shape[-2:]
+    xp = T.to_padded_nhwc(xd, H, W)
+    y = T.patch_linear(xp, T.conv_weight_rows(wd), bd, k, stride, T.PAD - pt, T.PAD - pl, oh, ow, relu=True)   # [B, oh*ow, O]
+    out = y.view(B, oh, ow, O).permute(0, 3, 1, 2)
+    assert normwise(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-6
+    (out * G.to(dev)).sum().backward()
+    for got, want in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert normwise(got.cpu().numpy(), want.numpy()) <= 5e-6
