@@ -64,12 +64,14 @@ struct Plan {
     int s_splits, s_steps_per_split, s_steps, s_sample;   // bf16 screen (screen.hip)
     int capseg;
     int width;                      // neighbour-list width of the fixed-width paths
+    int ovf_cap;                    // adaptive lists behind the screen: queries that may be redone one by one (overflow.hip)
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_scandv, o_ssegcnt, o_redo, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
 };
 
+static bool g_N_small(int H, int W);
 static size_t carve(size_t& off, size_t bytes) {
     const size_t o = off;
     off = align_up(off + bytes, 256);
@@ -78,8 +80,9 @@ static size_t carve(size_t& off, size_t bytes) {
 
 constexpr int SCREEN_MIN_KEYS = 2048;     // below this the fp32 scan is launch-bound anyway
 constexpr int SCREEN_CAPSEG = 16;
+static bool g_N_small(int H, int W) { return (int64_t)H * W < SCREEN_MIN_KEYS; }
 
-static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
+static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool core = false) {
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
@@ -105,7 +108,9 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
     if (splits < 1) splits = 1;
     p.tiles_per_split = (p.n_tiles + splits - 1) / splits;
     p.splits = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
-    p.width = (mode == DAGL_MODE_ADAPTIVE) ? DAGL_FAST_CAP : k;
+    // adaptive lists: 256 slots behind the screen (mean degrees of ~8 come with maxima of ~100), 64 for the exact scan and for
+    // the training entry point (its backward keeps one neighbour per lane)
+    p.width = (mode == DAGL_MODE_ADAPTIVE) ? ((core || exact || g_N_small(H, W)) ? DAGL_FAST_CAP : DAGL_LIST_CAP) : k;
     // bf16 screen: 256 queries per block, chunks of >= 4 steps of 64 keys, <= 64 chunks
     p.s_steps = (g.N + SKEYS - 1) / SKEYS;
     {
@@ -124,10 +129,10 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
         p.s_splits = (p.s_steps + p.s_steps_per_split - 1) / p.s_steps_per_split;
         p.s_sample = p.s_steps_per_split >= 8 ? 4 : (p.s_steps_per_split >= 4 ? 2 : 1);
     }
-    // candidate slots per (query, chunk, half) segment: 16 when a query has many segments, up to 64 when it has few
+    // candidate slots per (query, chunk, half) segment: 16 when a query has many segments, up to 256 when it has few
     // (short key streams): ~1024 slots per query in total
     p.capseg = SCREEN_CAPSEG;
-    while (p.capseg < 64 && 2 * p.capseg * p.s_splits * 2 <= 1024) p.capseg *= 2;
+    while (p.capseg < 256 && 2 * p.capseg * p.s_splits * 2 <= 1024) p.capseg *= 2;
 
     const size_t BL = (size_t)B * g.L;
     size_t off = 0;
@@ -181,6 +186,13 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p) {
         p.o_ssegcnt = carve(off, BL * p.s_splits * 2 * sizeof(int32_t));
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
+    p.ovf_cap = 0; p.o_ovflist = p.o_ovfq = p.o_ovfscores = 0;
+    if (p.screen && mode == DAGL_MODE_ADAPTIVE && !core) {
+        p.ovf_cap = overflow_cap(g.N);
+        p.o_ovflist = carve(off, (size_t)p.ovf_cap * sizeof(int32_t));
+        p.o_ovfq = carve(off, (size_t)p.ovf_cap * DS * sizeof(float));
+        p.o_ovfscores = carve(off, (size_t)B * p.ovf_cap * ((g.N + 31) / 32 * 32) * sizeof(float));
+    }
     p.o_end = off;
     return DAGL_OK;
 }
@@ -221,7 +233,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // heads > 1 (stage entry point): `B` counts head x image pairs, batch entry = head * (B / heads) + image; fin[h]
     // carries head h's weights, `out` is the [B/heads, heads*16, H, W] concat map
     Plan p;
-    int rc = make_plan(B, H, W, mode_flags, k, p);
+    int rc = make_plan(B, H, W, mode_flags, k, p, core != nullptr);
     if (rc) return rc;
     const int mode = p.mode;
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
@@ -391,12 +403,25 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
 
+    bool ovf_active = false;         // set once the refine kernel has listed its overflowed queries (adaptive, screened)
     auto run_tail = [&](const AggArgs& ag2) -> int {
         int r;
         if (dbg_deg || dbg_rowsum)
             if ((r = launch_row_stats(s, BL, ag2.nb_wgt, ag2.nb_cnt, ag2.row_off, ag2.width, dbg_deg, dbg_rowsum))) return r;
         prof_mark(prof, s, 6);
         if ((r = launch_aggregate_direct(s, ag2))) return r;
+        if (ovf_active) {
+            // the few queries whose neighbourhood overflowed the lists are redone one by one (dense rows); their aggregated
+            // rows, degrees and softmax mass replace what the clipped lists gave.  Exits at once when nothing is flagged.
+            OvfArgs oa;
+            memset(&oa, 0, sizeof(oa));
+            oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
+            oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
+            oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap;
+            oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32;
+            oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
+            if ((r = launch_overflow_rows(s, oa))) return r;
+        }
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((r = launch_fold(s, B, g, agg, out, heads))) return r;
@@ -479,6 +504,10 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         ra.cand_val = sc.cand_val; ra.theta = sc.theta;
         ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
+        if (p.ovf_cap > 0) {
+            ra.ovf_list = at<int32_t>(ws, p.o_ovflist); ra.ovf_count = reinterpret_cast<int32_t*>(stats + 3); ra.ovf_cap = p.ovf_cap;
+            ovf_active = true;
+        }
         if ((rc = launch_refine(s, ra))) return rc;
         if (info) info->path = 3;
         if (mode == DAGL_MODE_ADAPTIVE) {
@@ -489,12 +518,14 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             int64_t hs[4] = {0, 0, 0, 0};
             if ((rc = read_back(s, stats, 4, hs))) return rc;
             if (info) info->redone_queries = hs[2];
-            if (hs[2] == 0) {
+            const bool mostly = hs[2] * 2 > (int64_t)BL;                  // most queries overflow: dense regime
+            if (hs[2] == 0 || (!mostly && ovf_active && hs[2] <= p.ovf_cap)) {   // (few overflowed queries: redone in-stream)
                 if (info) { info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1]; }
                 if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
                 return DAGL_OK;
             }
-            if (hs[2] * 2 > (int64_t)BL) return run_dense();
+            ovf_active = false;
+            if (mostly) return run_dense();
             need_exact = true;                                   // redo everything with the fp32 scan (CSR capable)
         } else {
             // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it

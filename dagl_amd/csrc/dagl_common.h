@@ -253,10 +253,24 @@ struct RefineArgs {
     int32_t* redo_flags;            // [B, n_qgroups_exact]: query groups (of 128) the exact kernel must redo
     int n_qgroups_exact;
     int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
+    int32_t* ovf_list; int32_t* ovf_count; int ovf_cap;    // adaptive mode: overflowed queries are listed for the per-query redo
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats);
+
+// per-query dense redo of the queries that overflowed the screened adaptive lists (overflow.hip)
+struct OvfArgs {
+    int B; Grid g;
+    const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
+    const float* mt; const float* bs; const float* b2p;
+    const int32_t* list; const int32_t* count; int cap;        // flagged queries (b*L + l), how many (device), list capacity
+    float* qrows;                                              // [cap, DS] feature rows of the flagged queries
+    float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys
+    float* agg; int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;
+};
+int launch_overflow_rows(hipStream_t s, const OvfArgs& a);
+int overflow_cap(int N);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);
@@ -319,6 +333,7 @@ struct Gemm32 {
     int chunk_tiles = 0;                              // > 0: partial sums of chunk_tiles * 16 products, added in fp32
     int slices = 1; float* scratch = nullptr;         // split-K (batch == 1): slices * M * N floats of scratch, fixed-order sum
     int k_total = 0;                                  // (set by launch_gemm32)
+    const int32_t* m_limit = nullptr;                 // optional device word: only rows < *m_limit are computed
 };
 int launch_gemm32(hipStream_t s, const Gemm32& g);
 int gemm32_auto_slices(int M, int N, int K);

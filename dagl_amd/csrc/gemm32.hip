@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
     const int i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
     const long long bz = blockIdx.z;
+    if (g.m_limit != nullptr) {                     // row count known on the device only: blocks past it have nothing to do
+        const int ml = *g.m_limit;
+        if (m0 >= ml) return;
+        if (ml < g.M) g.M = ml;
+    }
 
     TileLoader<AKC> la{g.A + bz * g.sA, g.lda, g.M, g.K, m0, vecA != 0, {}};
     TileLoader<BKC> lb{g.B + bz * g.sB, g.ldb, g.N, g.K, n0, vecB != 0, {}};

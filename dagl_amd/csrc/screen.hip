@@ -442,10 +442,13 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     const bool adaptive = (a.mode != DAGL_MODE_TOPK);
     const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
     int n = 0;
-    float my_s = 0.f; int my_key = -1;
+    constexpr int RU = DAGL_LIST_CAP / 64;                 // list entries per lane: entry e lives in lane e % 64, slot e / 64
+    float my_s[RU]; int my_key[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) { my_s[u] = 0.f; my_key[u] = -1; }
 
     if (a.mode == DAGL_MODE_ADAPTIVE) {
-        // keep order, drop candidates failing the exact test; lane j keeps the j-th survivor (<= width)
+        // keep order, drop candidates failing the exact test; survivor j goes to list entry j (<= width <= DAGL_LIST_CAP)
         for (int c0 = 0; c0 < total; c0 += 64) {
             const int c = c0 + lane;
             float s = 0.f; int key = -1; bool pass = false;
@@ -464,7 +467,11 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         }
         overflow = __any(overflow);
         if (n > a.width) n = a.width;
-        if (lane < n) { my_s = c_val[w][lane]; my_key = c_idx[w][lane]; }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int e = lane + 64 * u;
+            if (e < n) { my_s[u] = c_val[w][e]; my_key[u] = c_idx[w][e]; }
+        }
     } else if (total <= 64) {
         // top-k of <= 64 candidates: bitonic sort in registers, (value desc, key asc)
         float v = -3.0f; int key = 0x7fffffff;
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         }
         const unsigned long long valid_mask = __ballot(v > -2.0f);
         n = min(a.k, (int)__popcll(valid_mask));
-        if (lane < n) { my_s = v; my_key = key; }
+        if (lane < n) { my_s[0] = v; my_key[0] = key; }
     } else {
         if (a.mode == DAGL_MODE_ADAPTIVE_TOPK) {
             for (int c = lane; c < total; c += 64)
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
             }
             if (bpos < 0) break;
-            if (lane == r) { my_s = bv; my_key = bi; }
+            if (lane == r) { my_s[0] = bv; my_key[0] = bi; }
             if (lane == 0) c_idx[w][bpos] = -1;
             __threadfence_block();
             ++n;
@@ -513,21 +520,34 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     }
 
     // 3. edge softmax over the kept neighbours (non-neighbours contribute exp(0) each to the denominator)
-    const bool valid = lane < n;
-    const float lg = valid ? rf_logit(my_s, mtq, bsq, adaptive) : 0.f;
-    double M = valid ? (double)lg : -1e300;
+    float lg[RU];
+    double M = -1e300;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const bool valid = lane + 64 * u < n;
+        lg[u] = valid ? rf_logit(my_s[u], mtq, bsq, adaptive) : 0.f;
+        if (valid) M = fmax(M, (double)lg[u]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
     if (n < a.N) M = fmax(M, 0.0);
-    const double e = valid ? exp((double)lg - M) : 0.0;
-    double sum = e;
+    double ev[RU], sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        ev[u] = (lane + 64 * u < n) ? exp((double)lg[u] - M) : 0.0;      // (slots past the first are empty outside the long-tail case)
+        sum += ev[u];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     sum += (double)(a.N - n) * exp(-M);
-    if (valid) {
-        a.nb_idx[ql * a.width + lane] = my_key;
-        a.nb_wgt[ql * a.width + lane] = (float)(e / sum);
-        if (a.nb_s != nullptr) a.nb_s[ql * a.width + lane] = my_s;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int e = lane + 64 * u;
+        if (e < n) {
+            a.nb_idx[ql * a.width + e] = my_key[u];
+            a.nb_wgt[ql * a.width + e] = (float)(ev[u] / sum);
+            if (a.nb_s != nullptr) a.nb_s[ql * a.width + e] = my_s[u];
+        }
     }
     if (lane == 0) {
         a.nb_cnt[ql] = n;
@@ -535,6 +555,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             const size_t qg = (size_t)b * a.n_qgroups_exact + (size_t)(ql - (size_t)b * a.L) / 128;
             a.redo_flags[qg] = 1;
             atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[2]), 1ull);
+            if (a.ovf_list != nullptr) {                  // adaptive: this query is redone on its own (overflow.hip)
+                const int pos = atomicAdd(a.ovf_count, 1);
+                if (pos < a.ovf_cap) a.ovf_list[pos] = (int32_t)ql;
+            }
         }
     }
 }

@@ -66,7 +66,8 @@ extern "C" {
 #define DAGL_FLAG_DENSE_HINT     0x400
 
 #define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
-#define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path            */
+#define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path (fp32 scan, training lists) */
+#define DAGL_LIST_CAP           256   /* per-query slots of the screened adaptive path (inference): long-tailed degrees */
 
 /* error codes */
 #define DAGL_OK                   0

@@ -91,7 +91,11 @@ def test_config2_256x256_matches_the_dense_oracle(mode, k, variant, gain):
     assert normwise(_agg_ckk(info["agg"][0].cpu()).numpy(), agg_ref.numpy()) <= TOL + e_ref
     assert normwise(out_d.cpu().numpy(), want64.numpy()) <= TOL
     if mode == "adaptive":
-        assert 4.0 <= deg_ref.mean() <= 16.0 or gain > 1.9, deg_ref.mean()       # the "mean degree ~8" regime of section 8d
+        # gain 1.95 is the "mean degree ~8" regime of section 8d (7.7, maximum 890: long-tailed); gain 1.8: mean 55, maximum
+        # 4578.  Either way the lists serve all but a few queries and those are redone one by one (overflow.hip): no fp32 rescan
+        assert (4.0 <= deg_ref.mean() <= 16.0) if gain > 1.9 else deg_ref.mean() > 16.0, deg_ref.mean()
+        assert deg_ref.max() > 256
+        assert info["path"] == 3 and 0 < info["redone_queries"] <= 256, info
 
 
 @pytest.mark.parametrize("H,W,mode,k,in_dtype", [(512, 512, "topk", 8, torch.bfloat16),
