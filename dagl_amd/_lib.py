@@ -34,7 +34,7 @@ class DaglError(RuntimeError):
 
 class CeInfo(C.Structure):
     _fields_ = [("required_bytes", C.c_int64), ("total_edges", C.c_int64), ("redone_queries", C.c_int64),
-                ("max_degree", C.c_int32), ("path", C.c_int32)]
+                ("max_degree", C.c_int32), ("path", C.c_int32), ("range_fallback", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CeWeights(C.Structure):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "dagl_ce_forward_debug": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz,
                                    C.POINTER(CeInfo), _vp, _vp, _vp]),
     "dagl_ce_list_width": (_i, [_i, _i]),
+    "dagl_ce_range_check": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, C.POINTER(_i)]),
     "dagl_ce_core_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                   C.POINTER(CeInfo)]),
     "dagl_ce_core_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -118,12 +118,33 @@ class CE(nn.Module):
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
         self._pack_epoch = 0           # bumped by invalidate_packed()
+        self._last_call = None
+        self._calls_since_range_check = 0
         self._train_dense = False      # the differentiable path met dense neighbourhoods last time (dense_train.hip)
         self._train_dense_calls = 0
         self._dense_hint = False       # the last adaptive call ended in the dense formulation: start there next time
         self._dense_calls = 0
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
+
+    def range_ok(self) -> bool:
+        """False when the last inference call on this module met operands outside the split-fp16 range (|activation| >=
+        3750; include/dagl_ce.h): that call's output is NaN-filled.  Switches the module to ``scan = "exact"`` (the fp32
+        path, no range limit) in that case.  One host synchronisation."""
+        self._calls_since_range_check = 0
+        if self.scan == "exact" or self._last_call is None:
+            return True
+        shape, dev = self._last_call
+        bad = ops.ce_range_check(shape, self.select_mode, self.select_k, self._ws, dev)
+        if bad:
+            self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
+        return not bad
+
+    def _note_range_violation(self, what):
+        import warnings
+        warnings.warn(f"dagl_amd.CE: {what}; this module now uses scan='exact' (fp32 matrix cores, no range limit)")
+        self.scan = "exact"
+        self._pack_key = None
 
     def invalidate_packed(self):
         """Forget the packed copies of fc1 / fc2 kept in the workspace.  The cache is keyed on the weights' storage and
@@ -247,6 +268,15 @@ class CE(nn.Module):
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
                                          dense_hint=hint, want_info=want_info)
         self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
+        self._last_call = (tuple(b.shape), b.device)
+        if info is not None and info.get("range_fallback"):
+            self._note_range_violation("an adaptive call left the split-fp16 range and was re-run on the fp32 path")
+        elif self.select_mode != "adaptive" and self.scan != "exact":
+            # no host round trip in the top-k modes: look at the range word every 64th call (one synchronisation); a call
+            # that left the range has returned NaN (never wrong numbers), the module moves to the fp32 path from here on
+            self._calls_since_range_check += 1
+            if self._calls_since_range_check >= 64:
+                self.range_ok()
         if info is not None:
             self.last_info = info
             if self.select_mode == "adaptive":

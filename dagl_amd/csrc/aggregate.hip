@@ -307,10 +307,13 @@ int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx,
 // padding 3, stride 4 -- dagl.py:266), i.e. NOT where it was read (SAME grid, top-left 4r-pt).  A pixel is
 // covered by <= 2 x 2 windows; the divisor fold(unfold(1)) (dagl.py:268-270) is that window count.
 __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restrict__ agg, float* __restrict__ out,
-                                                   int imgs, int heads) {
+                                                   int imgs, int heads, RangeTag range) {
     const int b = blockIdx.z;
     const int y = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // range guard: a kernel of THIS call met a value outside the split-fp16 range -> the numbers are worthless: NaN
+    const bool poisoned = range.word != nullptr && *range.word == range.tag;
+    if (range.done != nullptr && b == 0 && y == 0 && blockIdx.x == 0 && threadIdx.x == 0) *range.done = range.tag;
     if (x >= g.W) return;
     // rows r with 4r-3 <= y <= 4r+3
     int r0 = (y - 3 + QS - 1) / QS; if (y - 3 < 0) r0 = 0;
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
             }
         }
     }
-    const float cnt = (float)((r1 - r0 + 1) * (c1 - c0 + 1));
+    float cnt = (float)((r1 - r0 + 1) * (c1 - c0 + 1));
+    if (poisoned) cnt = __builtin_nanf("");
     const int head = b / imgs, img = b - head * imgs;
     float* o = out + ((size_t)img * heads + head) * CH * g.N + (size_t)y * g.W + x;
 #pragma unroll
@@ -345,9 +349,9 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
     }
 }
 
-int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads) {
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads, RangeTag range) {
     dim3 grid((g.W + 63) / 64, g.H, B), block(64);
-    hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out, B / heads, heads);
+    hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out, B / heads, heads, range);
     DAGL_LAUNCH_CHECK("fold_kernel");
     return DAGL_OK;
 }

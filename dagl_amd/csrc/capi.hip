@@ -2,11 +2,19 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "dagl_common.h"
 
 namespace dagl {
 
 static thread_local char g_err[512] = "";
+// tags the calls of this process for the range guard (RangeTag): the only process-wide state of the library
+static std::atomic<uint32_t> g_call_tag{1};
+static int32_t next_call_tag() {
+    uint32_t t = g_call_tag.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu;
+    return (int32_t)(t ? t : 1u);
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -150,7 +158,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int32_t));
     p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
     p.o_deg = carve(off, BL * sizeof(int32_t));
-    p.o_stats = carve(off, 4 * sizeof(int64_t));
+    p.o_stats = carve(off, 8 * sizeof(int64_t));          // [0..3] per-call counters, [4] range word, [5] tag of the last completed call
     if (mode == DAGL_MODE_ADAPTIVE) {
         p.o_lidx = carve(off, BL * DAGL_FAST_CAP * sizeof(int32_t));
         p.o_lval = carve(off, BL * DAGL_FAST_CAP * sizeof(float));
@@ -237,7 +245,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     if (rc) return rc;
     const int mode = p.mode;
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
-                info->redone_queries = -1; }
+                info->redone_queries = -1; info->range_fallback = 0; info->reserved = 0; }
     DAGL_REQUIRE(out && (core || (fc1_w && fc1_b && fc2_w && fc2_b)), "dagl_ce_forward: null tensor pointer");
     if (core) {
         DAGL_REQUIRE(core->wq_rows && core->x_rows && b2 && core->nb_idx && core->nb_wgt && core->nb_s && core->nb_cnt,
@@ -281,6 +289,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int32_t* nbcnt = core ? core->nb_cnt : at<int32_t>(ws, p.o_nbcnt);
     float* agg = at<float>(ws, p.o_agg);
 
+    // range guard of the split-fp16 kernels (dagl_common.h RangeTag); the fp32 path and the training entry point have no
+    // such range
+    RangeTag rt;
+    if (p.split16 && !core) {
+        rt.word = reinterpret_cast<int32_t*>(stats + 4); rt.done = reinterpret_cast<int32_t*>(stats + 5); rt.tag = next_call_tag();
+    }
+
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
     const int imgs = B / heads;
@@ -288,6 +303,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // packed weights, the maps' zero borders and the zero guard rows of the feature matrices are still in place, and
     // the few per-call counters are cleared by the prologue kernel itself -- three launches fewer
     const bool prepared = fin && p.split16 && (mode_flags & DAGL_FLAG_WEIGHTS_PACKED);
+    if (rt.word != nullptr && !prepared) DAGL_HIP_TRY(hipMemsetAsync(stats + 4, 0, 2 * sizeof(int64_t), s));   // fresh workspace
     if (core) {
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     } else if (fin) {
@@ -310,7 +326,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
                                       (prepared && hd == 0) ? 8 : 0,
                                       (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
-                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0))) return rc;
+                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {
@@ -324,7 +340,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         map_hi = at<uint16_t>(ws, p.o_maphi); map_lo = at<uint16_t>(ws, p.o_maplo);
         wp1h = at<uint16_t>(ws, p.o_wp1h); wp2h = at<uint16_t>(ws, p.o_wp2h);
         if (!fin)                                                // stock-conv entry point: split the padded fp32 map
-            if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo))) return rc;
+            if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b1p, map_hi, map_lo, rt))) return rc;
         for (int hd = 0; hd < heads && !(mode_flags & DAGL_FLAG_WEIGHTS_PACKED); ++hd) {
             if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc1_w : fc1_w, wp1h + (size_t)hd * P16_PACKED_HALFS))) return rc;
             if ((rc = launch_pack_fc_weight16(s, fin ? fin[hd].fc2_w : fc2_w, wp2h + (size_t)hd * P16_PACKED_HALFS))) return rc;
@@ -367,7 +383,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
                                    at<float>(ws, p.o_colpart), wp1h, b1s,
-                                   Wq, Xh, Wqh, heads))) return rc;
+                                   Wq, Xh, Wqh, heads, rt))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }
@@ -404,6 +420,22 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     }
 
     bool ovf_active = false;         // set once the refine kernel has listed its overflowed queries (adaptive, screened)
+    // the statistics read-back of the adaptive modes also carries the range word: a call that left the split-fp16 range is
+    // re-run on the fp32 path right here (same arguments, DAGL_FLAG_EXACT_SCAN); without a read-back (top-k modes) the
+    // poisoned output and dagl_ce_range_check report it
+    auto rerun_exact = [&]() -> int {
+        if (heads > 1) {            // stage entry point: no fp32 form of the four-head launch set; hand the call back (per-head path)
+            if (info) { info->required_bytes = -1; info->range_fallback = 1; }
+            set_error("dagl_ces_stage_forward: an operand left the split-fp16 range: use the per-head entry point");
+            return DAGL_ERR_WORKSPACE;
+        }
+        if (info) info->range_fallback = 1;
+        const int rc2 = ce_forward_impl(s, B, H, W, b1, b2, fin ? nullptr : thr, fin ? nullptr : bias, fc1_w, fc1_b, fc2_w, fc2_b,
+                                        (mode_flags | DAGL_FLAG_EXACT_SCAN) & ~(DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT), k, out,
+                                        ws, ws_bytes, info, dbg_deg, dbg_rowsum, dbg_agg, nullptr, fin, heads, nullptr);
+        if (info) info->range_fallback = 1;
+        return rc2;
+    };
     auto run_tail = [&](const AggArgs& ag2) -> int {
         int r;
         if (dbg_deg || dbg_rowsum)
@@ -424,7 +456,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if ((r = launch_fold(s, B, g, agg, out, heads))) return r;
+        if ((r = launch_fold(s, B, g, agg, out, heads, rt))) return r;
         prof_mark(prof, s, 8);
         return DAGL_OK;
     };
@@ -469,14 +501,15 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_screen(s, sc, 0))) return rc;
             float* smax = at<float>(ws, p.o_theta);
             if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
-            if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats))) return rc;
+            if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt))) return rc;
             prof_mark(prof, s, 7);
             if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if ((rc = launch_fold(s, B, g, agg, out, heads))) return rc;
+            if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
             prof_mark(prof, s, 8);
             if (info) {
-                int64_t hd[2] = {0, 0};
-                if ((rc = read_back(s, stats, 2, hd))) return rc;
+                int64_t hd[5] = {0, 0, 0, 0, 0};
+                if ((rc = read_back(s, stats, 5, hd))) return rc;
+                if (rt.word != nullptr && (int32_t)hd[4] == rt.tag) return rerun_exact();
                 info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
             }
             if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
@@ -515,8 +548,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             // the optimistic gather + fold are already queued, so the device does not idle during the round trip.
             if ((rc = run_tail(ag))) return rc;
             if ((rc = launch_degree_stats(s, BL, nbcnt, stats))) return rc;
-            int64_t hs[4] = {0, 0, 0, 0};
-            if ((rc = read_back(s, stats, 4, hs))) return rc;
+            int64_t hs[5] = {0, 0, 0, 0, 0};
+            if ((rc = read_back(s, stats, 5, hs))) return rc;
+            if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) return rerun_exact();
             if (info) info->redone_queries = hs[2];
             const bool mostly = hs[2] * 2 > (int64_t)BL;                  // most queries overflow: dense regime
             if (hs[2] == 0 || (!mostly && ovf_active && hs[2] <= p.ovf_cap)) {   // (few overflowed queries: redone in-stream)
@@ -753,6 +787,22 @@ int dagl_ces_stage_forward(void* stream, int B, int H, int W, const float* x, co
         return rc;
     }
     return launch_stage_mix((hipStream_t)stream, B, H * W, cat, x, mix_w, mix_b, out);
+}
+
+int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, const void* workspace, size_t ws_bytes,
+                        int* violated) {
+    DAGL_REQUIRE(workspace && violated, "dagl_ce_range_check: null pointer");
+    Plan p;
+    int rc = make_plan(B, H, W, mode, k, p);
+    if (rc) return rc;
+    DAGL_REQUIRE(ws_bytes >= p.o_end && ((uintptr_t)workspace % 256) == 0, "dagl_ce_range_check: not the workspace of such a call");
+    *violated = 0;
+    if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range
+    int64_t h[2] = {0, 0};
+    const int64_t* st = reinterpret_cast<const int64_t*>(static_cast<const char*>(workspace) + p.o_stats);
+    if ((rc = read_back((hipStream_t)stream, st + 4, 2, h))) return rc;
+    *violated = ((int32_t)h[0] != 0 && (int32_t)h[0] == (int32_t)h[1]) ? 1 : 0;   // the last completed call left the range
+    return DAGL_OK;
 }
 
 int dagl_ce_list_width(int mode, int k) {

@@ -69,6 +69,18 @@ int hip_fail(hipError_t e, const char* what);
         }                                                          \
     } while (0)
 
+// Range guard of the split-fp16 kernels (prologue.hip, project16.hip, dense.hip): operands are pre-scaled by powers of two
+// and split into two fp16 numbers, which holds for |16 x|, |16 b1|, |256 w_conv|, |1024 w_fc|, |64 feature| < 65504.  A kernel
+// that meets a larger value stores the call's tag into the workspace's range word; the last kernel of the call (fold) then
+// writes NaN instead of numbers computed from inf / NaN halves, and the host side re-runs the call on the fp32 path where
+// it reads statistics back anyway (adaptive modes) or on request (dagl_ce_range_check).
+struct RangeTag {
+    int32_t* word = nullptr;     // workspace word: tag of the last call that left the fp16 range
+    int32_t* done = nullptr;     // workspace word: tag of the last completed call (written by the fold)
+    int32_t tag = 0;             // this call's tag (process-wide counter, never 0)
+};
+constexpr float RANGE_LIMIT = 60000.0f;
+
 struct Grid {            // geometry of one image
     int H, W;            // feature map
     int Hp, Wp;          // padded map (H+6, W+6)
@@ -119,21 +131,22 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     bool borders_zero = false /* the maps' 3-pixel borders still hold the zeros of an earlier call */,
                     bool defer_thr_reduce = false /* leave the partial sums in thr_part: launch_query_thresholds finishes them */,
                     uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
-                    /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */);
+                    /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */,
+                    RangeTag range = RangeTag());
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                    const float* wp_q, const float* bias_q, float* feat_q,
                    uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr);
 // fp16 split-operand projection (project16.hip)
-int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo);
+int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range = RangeTag());
 int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp);
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
-                     uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1);
+                     uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag());
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
-constexpr size_t P16_PACKED_HALFS = (size_t)49 * 7168 + 1024; // packed fp16 weights (halfs) + read slack
+constexpr size_t P16_PACKED_HALFS = (size_t)49 * 7168 + 1024; // packed fp16 weights (halfs) + read slack; the last 4 bytes = range flag of the weights
 // Optional extra duties of the thresholds kernel on the fused path (one launch instead of three): finish the thr / bias
 // heads (fixed-order sum of the prologue's four channel-group partials + the conv bias) and derive the screen's
 // candidate threshold of the adaptive mode.
@@ -165,7 +178,7 @@ int launch_unfold_values(hipStream_t s, int B, const Grid& g, const float* b2p, 
 int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt,
                         const float* values, float* out);
 // out is [B/heads, heads*16, H, W]: batch entry head*imgs + image lands in channels [head*16, head*16+16) of image
-int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads = 1);
+int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads = 1, RangeTag range = RangeTag());
 int launch_stage_mix(hipStream_t s, int B, int HW, const float* cat, const float* x, const float* mix_w,
                      const float* mix_b, float* out);
 int launch_scores_dense(hipStream_t s, int B, int L, int N, const float* wq, const float* x, float* sc);
@@ -293,7 +306,7 @@ size_t dense_workspace_bytes(int B, const Grid& g);
 int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */);
+                        float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag());
 
 // graph-core backward (backward.hip)
 struct BwdArgs {

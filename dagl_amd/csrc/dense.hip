@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
 
 // fp32 feature rows [B, rows_in, 204] -> split fp16 rows [B, rows_out, 216] hi and lo, 64 x = hi + lo (pad columns zero)
 __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const float* __restrict__ src,
-                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, RangeTag range) {
     const int b = blockIdx.y;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)rows_out * (DSH / 8)) return;
@@ -370,6 +370,7 @@ __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const flo
     for (int u = 0; u < 8; ++u) {
         const int c = 8 * c8 + u;
         const float v = (r < rows && c < D) ? src[((size_t)b * rows_in + r) * DS + c] * DN_FS : 0.f;
+        if (range.word != nullptr && !(fabsf(v) < RANGE_LIMIT)) *range.word = range.tag;
         const _Float16 h = (_Float16)v;
         vh[u] = __builtin_bit_cast(unsigned short, h);
         vl[u] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
@@ -431,7 +432,7 @@ size_t dense_workspace_bytes(int B, const Grid& g) {
 
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats) {
+                        float* rowsum_out, int64_t* stats, RangeTag range) {
     DenseArgs a;
     a.smax = smax;
     a.variant = 0;
@@ -459,9 +460,9 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.rows_xh = feat_rows_h(g.N); a.rows_qh = feat_rows_h(g.L);
     {
         const size_t nx = (size_t)a.rows_xh * (DSH / 8), nq8 = (size_t)a.rows_qh * (DSH / 8);
-        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl);
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl, range);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
-        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql);
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql, range);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
     }
     const int n_qblocks = (g.L + 63) / 64;

@@ -44,10 +44,12 @@ __device__ __forceinline__ void split_f16(float a, unsigned short& hi, unsigned 
 
 // fp32 NHWC map -> hi / lo fp16 NHWC maps (same [B,Hp,Wp,16] geometry, 32 B per pixel each)
 __global__ void split_map_kernel(size_t n, const float* __restrict__ src, unsigned short* __restrict__ hi,
-                                 unsigned short* __restrict__ lo) {
+                                 unsigned short* __restrict__ lo, RangeTag range) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // float4 index
     if (i * 4 >= n) return;
     const float4 v = reinterpret_cast<const float4*>(src)[i];
+    const float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) * P16_A_SCALE;
+    if (range.word != nullptr && !(am < RANGE_LIMIT)) *range.word = range.tag;
     unsigned short h[4], l[4];
     split_f16(v.x * P16_A_SCALE, h[0], l[0]); split_f16(v.y * P16_A_SCALE, h[1], l[1]);
     split_f16(v.z * P16_A_SCALE, h[2], l[2]); split_f16(v.w * P16_A_SCALE, h[3], l[3]);
@@ -55,9 +57,9 @@ __global__ void split_map_kernel(size_t n, const float* __restrict__ src, unsign
     reinterpret_cast<ushort4*>(lo)[i] = make_ushort4(l[0], l[1], l[2], l[3]);
 }
 
-int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo) {
+int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range) {
     const size_t n4 = (n_floats + 3) / 4;
-    hipLaunchKernelGGL(split_map_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n_floats, src, hi, lo);
+    hipLaunchKernelGGL(split_map_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n_floats, src, hi, lo, range);
     DAGL_LAUNCH_CHECK("split_map_kernel");
     return DAGL_OK;
 }
@@ -75,14 +77,18 @@ __global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned sh
         const int slot = (e >> 3) ^ ((o >> 2) & 3);                  // logical slot stored at this physical position
         const int c = (slot & 1) * 8 + (e & 7);
         unsigned short hi, lo;
-        split_f16(w[(size_t)o * P + c * (KS * KS) + tap] * P16_W_SCALE, hi, lo);
+        const float wv = w[(size_t)o * P + c * (KS * KS) + tap] * P16_W_SCALE;
+        split_f16(wv, hi, lo);
         v = (slot < 2) ? hi : lo;
+        // range flag of these packed weights: the last 4 bytes of the buffer (cleared by launch_pack_fc_weight16)
+        if (!(fabsf(wv) < RANGE_LIMIT)) *reinterpret_cast<int32_t*>(wp + P16_PACKED_HALFS - 2) = 1;
     }
     wp[i] = v;
 }
 
 int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp) {
     const int n = P16_STEPS * P16_SLICE_H;
+    DAGL_HIP_TRY(hipMemsetAsync(wp + P16_PACKED_HALFS - 2, 0, 4, s));
     hipLaunchKernelGGL(pack_fc_weight16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wp);
     DAGL_LAUNCH_CHECK("pack_fc_weight16_kernel");
     return DAGL_OK;
@@ -102,6 +108,7 @@ struct Proj16Args {
     int n_blocks_q, n_blocks_k;
     int n_full, n_split_groups, batch;                              // 1-D grid: full blocks, then 7 single-tile blocks per split group
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
+    RangeTag range; int heads;                                      // range guard: the packed weights' flags feed the call's word
 };
 
 // Block = 4 waves (two blocks per CU, independent barriers).  All operands arrive by LDS-DMA issued from inline asm and are
@@ -358,6 +365,12 @@ __global__ __launch_bounds__(64 * P16_BW, 2) void project16_kernel(Proj16Args pa
     // tiles.  The last n_split_groups key blocks of the last image come last, cut into 7 single-tile blocks each: a grid
     // that overhangs the resident-block capacity by a few blocks would otherwise cost a whole extra round.
     const int bid = blockIdx.x;
+    if (bid == 0 && threadIdx.x < 2 * pa.heads && pa.range.word != nullptr) {        // weights packed from out-of-range values?
+        const unsigned short* wpk = pa.wp[threadIdx.x & 1];
+        if (wpk != nullptr &&
+            *reinterpret_cast<const int32_t*>(wpk + (size_t)(threadIdx.x >> 1) * P16_PACKED_HALFS + P16_PACKED_HALFS - 2) != 0)
+            *pa.range.word = pa.range.tag;
+    }
     const int per = pa.n_blocks_q + pa.n_blocks_k;
     if (bid < pa.n_full) {
         const int b = bid / per, local = bid - b * per;
@@ -390,8 +403,9 @@ int project16_key_blocks(const Grid& g) { return (((g.W + 31) / 32) * g.H + P16_
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16, int heads) {
+                     uint16_t* feat_q_bf16, int heads, RangeTag range) {
     Proj16Args pa;
+    pa.range = range; pa.heads = heads;
     pa.imgs_per_head = B / heads;
     for (int h = 0; h < 4; ++h) {
         pa.bias[0][h] = bias_keys ? bias_keys[h < heads ? h : 0] : nullptr;

@@ -168,9 +168,11 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                                                           const float* __restrict__ th_w, const float* __restrict__ th_b,
                                                           float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
-                                                          int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words) {
+                                                          int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
+                                                          RangeTag range) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB];           // 110 KiB
     const int tid = threadIdx.x;
+    float amax = 0.f;                                      // largest |pre-scaled operand| this thread splits (range guard)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {      // per-call counters / flags of the later stages
         for (int t = tid; t < clear_a_words; t += 256) clear_a[t] = 0u;
         for (int t = tid; t < clear_b_words; t += 256) clear_b[t] = 0u;
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
             _Float16 h, l;
             c16_split(st[c] * C16_XS, h, l); hi0[c] = h; lo0[c] = l;
             c16_split(st[c + 8] * C16_XS, h, l); hi1[c] = h; lo1[c] = l;
+            amax = fmaxf(amax, fmaxf(fabsf(st[c]), fabsf(st[c + 8])) * C16_XS);
         }
         *reinterpret_cast<h16x8*>(px + 32 * wave) = hi0;
         *reinterpret_cast<h16x8*>(px + 32 * wave + 16) = hi1;
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                 const int c = rem / 9, tap = rem - c * 9;
                 _Float16 h, l;
                 c16_split(vp[q] * C16_WS, h, l);
+                amax = fmaxf(amax, fabsf(vp[q]) * C16_WS);
                 unsigned char* d = wl + ((tap * 2 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
                 const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;            // 16-byte slot of the row, swizzled (see reads)
                 *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                 const int o = e / PC, c = e - o * PC;
                 _Float16 h, l;
                 c16_split(vp[q] * C16_WS, h, l);
+                amax = fmaxf(amax, fabsf(vp[q]) * C16_WS);
                 unsigned char* d = wl + ((18 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
                 const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;
                 *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                 const float v1 = ag[r] * inv + bg[r];
                 _Float16 h, l;
                 c16_split(v1 * 16.0f, h, l);                     // P16_A_SCALE (project16.hip)
+                amax = fmaxf(amax, fabsf(v1) * 16.0f);
                 vh[r] = h; vl[r] = l;
                 v2p[r] = at[r] * inv + bt[r];
             }
@@ -362,6 +368,8 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         do_row(y, st0, sh0, st1, sh1);
         if (y + 1 < y1) do_row(y + 1, st1, sh1, st0, sh0);
     }
+    // (a NaN / inf input compares false / true here and is flagged as well: !(amax < limit))
+    if (range.word != nullptr && !(amax < RANGE_LIMIT)) *range.word = range.tag;
 }
 
 // thr / bias heads (two 7x7 stride-4 convolutions 64 -> 1 over the SAME-padded input, dagl.py:212-215).
@@ -462,7 +470,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
                     uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, bool defer_thr_reduce, uint32_t* clear_a,
-                    int clear_a_words, uint32_t* clear_b, int clear_b_words) {
+                    int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range) {
     int rcz;
     if (!borders_zero) {
         if ((rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p))) return rcz;
@@ -478,7 +486,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
     if (b1p == nullptr && b1_hi != nullptr) {
         hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
-                           g_b, th_w, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words);
+                           g_b, th_w, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
     } else {
         hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,

@@ -290,7 +290,8 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
         break
     check(rc, "dagl_ce_forward")
     meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
-                max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
+                max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries,
+                range_fallback=info.range_fallback)
     if dbg is not None:
         meta.update(dbg)
     if return_info or debug:
@@ -379,7 +380,23 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     if quiet:
         return out, None
     return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
-                     max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries)
+                     max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries,
+                     range_fallback=info.range_fallback)
+
+
+def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> bool:
+    """True when the last forward on ``workspace`` (input shape ``shape``) left the range of the split-fp16 kernels and
+    returned a NaN-filled output (``dagl_ce_range_check``; one host synchronisation)."""
+    lib = _lib.load()
+    buf = workspace.peek(device)
+    if buf is None:
+        return False
+    B, _, H, W = shape
+    a, nbytes = _aligned(buf)
+    out = C.c_int(0)
+    with torch.cuda.device(device):
+        check(lib.dagl_ce_range_check(_stream(), B, H, W, MODES[mode], int(k), a, nbytes, C.byref(out)), "dagl_ce_range_check")
+    return bool(out.value)
 
 
 @_on_device

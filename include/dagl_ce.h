@@ -88,8 +88,22 @@ typedef struct dagl_ce_info {
     int32_t max_degree;       /* largest per-query degree                                           */
     int32_t path;             /* 0 = fp32 scan, single-pass lists, 1 = fp32 scan, two-pass CSR (some degree >
                                  FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine,
-                                 4 = dense neighbourhoods: streamed dense formulation (no lists)        */
+                                 4 = dense neighbourhoods: streamed dense formulation (no lists),
+                                 5 = dense formulation under autograd (dagl_ce_core_dense_forward)        */
+    int32_t range_fallback;   /* 1 = an operand left the range of the split-fp16 kernels (|activation| >= 3750, see
+                                 below) and the call was re-run on the fp32 path (DAGL_FLAG_EXACT_SCAN)  */
+    int32_t reserved;
 } dagl_ce_info;
+
+/* Range of the default (split-fp16) path: |x|, |b1| < 3750, |w_conv| < 234, |w_fc| < 58, |features| < 937 in the dense
+ * regime.  A call that meets a larger (or non-finite) operand never returns numbers computed from it: its output is
+ * NaN-filled by the last kernel, and
+ *   - the adaptive modes, which read statistics back anyway, notice and re-run the call on the fp32 path at once
+ *     (info->range_fallback = 1; the result is the exact scan's);
+ *   - the top-k modes have no host round trip: dagl_ce_range_check(workspace) tells (one synchronisation) whether the
+ *     last call on that workspace left the range; re-run with DAGL_FLAG_EXACT_SCAN (no range limit).                  */
+int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, const void* workspace, size_t ws_bytes,
+                        int* violated);
 
 /* ---- library ------------------------------------------------------------------------------- */
 int         dagl_version(void);                 /* 10000*major + 100*minor + patch                  */

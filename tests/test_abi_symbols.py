@@ -72,4 +72,4 @@ def test_info_struct_layout_matches_header():
     fields = re.findall(r"(int64_t|int32_t)\s+(\w+)\s*;", body)
     assert [n for _, n in fields] == [n for n, _ in _lib.CeInfo._fields_]
     assert [t for t, _ in fields] == ["int64_t" if f is C.c_int64 else "int32_t" for _, f in _lib.CeInfo._fields_]
-    assert C.sizeof(_lib.CeInfo) == 32
+    assert C.sizeof(_lib.CeInfo) == 40
