@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--sparse-gain", type=float, default=2.4, help="adaptive modes: threshold gain of the synthetic thr head")
+    ap.add_argument("--variant", default="auto", choices=["auto", "default", "sparse"],
+                    help="synthetic thr/bias heads: default = torch-like init (adaptive: ~95 %% of the keys pass, dense regime); "
+                         "sparse = threshold gain --sparse-gain; auto = default for topk, sparse otherwise")
     ap.add_argument("--scan", default="screened", choices=["screened", "exact"],
                     help="screened: bf16 matrix-core screen + exact refine (default); exact: all scores on the fp32 matrix cores")
     ap.add_argument("--stage", action="store_true",
@@ -304,7 +307,7 @@ def main():
     from dagl_amd.synth import make_ce_params, make_features
 
     mode, k = args.mode, (args.k if args.mode != "adaptive" else 0)
-    variant = "default" if mode == "topk" else "sparse"
+    variant = ("default" if mode == "topk" else "sparse") if args.variant == "auto" else args.variant
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(2024, variant=variant, sparse_gain=args.sparse_gain).items()}
     ce = CE(in_channels=64)
     ce.load_state_dict(params, strict=True)

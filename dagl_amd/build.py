@@ -11,6 +11,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdagl_ce.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("DAGL_EXTRA_FLAGS", "").split()       # e.g. -DDAGL_ABLATION for the debug variants (tools/ablate.sh)
 
 
 def _stale(target: str, deps) -> bool:

@@ -96,11 +96,10 @@ __global__ __launch_bounds__(256) void edge_softmax_csr_kernel(EdgeArgs a) {
 // MODE 2/3: merge the per-(chunk, half) k-best candidate lists of a query into its exact k best
 // (value descending, ties -> smaller key index), then weights.  One wave per query; candidates in LDS.
 constexpr int TOPK_MAX_CAND = 1024;
-__global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int kslots) {
-    __shared__ float cv[4][TOPK_MAX_CAND];
-    __shared__ int ci[4][TOPK_MAX_CAND];
+__device__ __forceinline__ void edge_softmax_topk_unit(const EdgeArgs& a, int kslots, float (*cv)[TOPK_MAX_CAND],
+                                                       int (*ci)[TOPK_MAX_CAND], size_t blk) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t ql = (size_t)blockIdx.x * 4 + w;
+    const size_t ql = blk * 4 + w;
     bool active = ql < (size_t)a.B * a.L;
     if (active && a.run_flags != nullptr) {
         const size_t b = ql / a.L, qg = (ql - b * a.L) / 128;
@@ -150,6 +149,22 @@ __global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int 
     if (lane == 0) a.nb_cnt[ql] = n;
 }
 
+// one block = 4 queries; as the redo pass behind the screen (run_flags given) a small grid walks over all of them and
+// skips the unflagged ones (see score_select_kernel)
+__global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int kslots, unsigned n_blocks) {
+    __shared__ float cv[4][TOPK_MAX_CAND];
+    __shared__ int ci[4][TOPK_MAX_CAND];
+    if (a.run_flags == nullptr) { edge_softmax_topk_unit(a, kslots, cv, ci, blockIdx.x); return; }
+    const int nqg = (a.L + 127) / 128;
+    for (size_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        // block-uniform skip: none of the block's 4 queries sits in a flagged group
+        const size_t q0 = blk * 4, q1 = (q0 + 3 < (size_t)a.B * a.L - 1) ? q0 + 3 : (size_t)a.B * a.L - 1;
+        const size_t b0 = q0 / a.L, b1 = q1 / a.L;
+        if (a.run_flags[b0 * nqg + (q0 - b0 * a.L) / 128] == 0 && a.run_flags[b1 * nqg + (q1 - b1 * a.L) / 128] == 0) continue;
+        edge_softmax_topk_unit(a, kslots, cv, ci, blk);
+    }
+}
+
 // per-query degree and softmax mass (parity tests: the reference's mask_b.sum(1) and A.sum(1))
 __global__ void row_stats_kernel(size_t n_rows, const float* __restrict__ nb_wgt, const int32_t* __restrict__ nb_cnt,
                                  const int64_t* __restrict__ row_off, int width, int32_t* __restrict__ deg,
@@ -184,7 +199,9 @@ int launch_edge_softmax(hipStream_t s, const EdgeArgs& a) {
             set_error("edge softmax: %d candidates per query exceed %d", a.splits * 2 * ks, TOPK_MAX_CAND);
             return DAGL_ERR_INVALID;
         }
-        hipLaunchKernelGGL(edge_softmax_topk_kernel, grid, block, 0, s, a, ks);
+        dim3 g2 = grid;
+        if (a.run_flags != nullptr && g2.x > 128) g2.x = 128;            // redo pass: blocks walk over the queries
+        hipLaunchKernelGGL(edge_softmax_topk_kernel, g2, block, 0, s, a, ks, grid.x);
     }
     DAGL_LAUNCH_CHECK("edge_softmax_kernel");
     return DAGL_OK;

@@ -63,20 +63,16 @@ struct TopK {
 };
 
 template <int PASS, int K>
-__global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int n_qgroups, int n_tiles,
-                                                              int rows_q, int rows_x) {
-    __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB
-
+__device__ __forceinline__ void score_select_unit(const SelectArgs& a, float (*sK)[TILE_LDS], int n_qgroups, int n_tiles,
+                                                  int rows_q, int rows_x, int logical) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / n_qgroups;
     const int qg = logical % n_qgroups;
-    if (a.run_flags != nullptr && a.run_flags[b * n_qgroups + qg] == 0) return;     // block-uniform
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > n_tiles) tile1 = n_tiles;
@@ -206,30 +202,50 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
     }
 }
 
+// Kernel: one (query group, key chunk) unit per block -- or, as the REDO pass behind the screen (run_flags given, almost
+// always nothing flagged), a small grid whose blocks walk over the units and skip the unflagged ones: an empty redo costs
+// one wave of flag reads instead of the dispatch of a thousand blocks that exit.
+template <int PASS, int K>
+__global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int n_qgroups, int n_tiles,
+                                                              int rows_q, int rows_x, int n_units) {
+    __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB
+    if (a.run_flags == nullptr) {
+        score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, xcd_remap(blockIdx.x, gridDim.x));
+        return;
+    }
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform
+        score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, unit);
+        __syncthreads();
+    }
+}
+
 template <int PASS>
 static int launch_pass(hipStream_t s, const SelectArgs& a, dim3 grid, int n_qgroups, int n_tiles, int rows_q,
                        int rows_x) {
     dim3 block(256);
+    const int n_units = (int)grid.x;
+    if (a.run_flags != nullptr && grid.x > 128) grid.x = 128;            // redo pass: blocks walk over the units
     if (PASS < 2) {
         hipLaunchKernelGGL((score_select_kernel<PASS, 1>), grid, block, 0, s, a, n_qgroups, n_tiles, rows_q,
-                           rows_x);
+                           rows_x, n_units);
     } else {
         switch (a.k <= 4 ? 4 : a.k <= 8 ? 8 : a.k <= 16 ? 16 : 32) {
             case 4:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 4>), grid, block, 0, s, a, n_qgroups, n_tiles,
-                                   rows_q, rows_x);
+                                   rows_q, rows_x, n_units);
                 break;
             case 8:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 8>), grid, block, 0, s, a, n_qgroups, n_tiles,
-                                   rows_q, rows_x);
+                                   rows_q, rows_x, n_units);
                 break;
             case 16:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 16>), grid, block, 0, s, a, n_qgroups, n_tiles,
-                                   rows_q, rows_x);
+                                   rows_q, rows_x, n_units);
                 break;
             default:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 32>), grid, block, 0, s, a, n_qgroups, n_tiles,
-                                   rows_q, rows_x);
+                                   rows_q, rows_x, n_units);
                 break;
         }
     }

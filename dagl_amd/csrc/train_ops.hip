@@ -69,17 +69,34 @@ __global__ void relu_backward_kernel(size_t n, const float* __restrict__ y, cons
     if (i < n) dz[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// out[c] = sum_r src[r, c]: one block per column, fp64 partials in a fixed order
-__global__ __launch_bounds__(256) void col_sum_kernel(size_t rows, int cols, const float* __restrict__ src, float* __restrict__ out) {
-    __shared__ double part[4];
-    const int c = blockIdx.x;
+// out[c] = sum_r src[r, c] (bias gradients).  Two fixed-order stages: a block sums CS_ROWS consecutive rows -- thread t owns
+// column t % cols and every (256 / cols)-th row of the chunk, so a wave reads consecutive addresses -- into part[block, c];
+// the second launch adds the blocks' partials in block order (fp64).  cols <= 256.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(size_t rows, int cols, const float* __restrict__ src,
+                                                               double* __restrict__ part) {
+    __shared__ double sh[256];
+    const int groups = 256 / cols;                                     // row phases handled in parallel
+    const int c = threadIdx.x % cols, gph = threadIdx.x / cols;
+    const size_t r0 = (size_t)blockIdx.x * CS_ROWS;
+    const size_t r1 = (r0 + CS_ROWS < rows) ? r0 + CS_ROWS : rows;
     double t = 0.0;
-    for (size_t r = threadIdx.x; r < rows; r += 256) t += (double)src[r * cols + c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    if (gph < groups)
+        for (size_t r = r0 + gph; r < r1; r += groups) t += (double)src[r * cols + c];
+    sh[threadIdx.x] = t;
     __syncthreads();
-    if (threadIdx.x == 0) out[c] = (float)((part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x < cols) {
+        double a = 0.0;
+        for (int g2 = 0; g2 < groups; ++g2) a += sh[g2 * cols + threadIdx.x];
+        part[(size_t)blockIdx.x * cols + threadIdx.x] = a;
+    }
+}
+__global__ void col_sum_final_kernel(int n_part, int cols, const double* __restrict__ part, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0.0;
+    for (int p = 0; p < n_part; ++p) a += part[(size_t)p * cols + c];
+    out[c] = (float)a;
 }
 
 int launch_unfold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
@@ -141,10 +158,19 @@ int dagl_relu_backward(void* stream, size_t n, const float* y, const float* dy, 
     return DAGL_OK;
 }
 
-int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out) {
-    DAGL_REQUIRE(cols >= 1 && src && out, "dagl_col_sum: bad argument");
-    hipLaunchKernelGGL(col_sum_kernel, dim3(cols), dim3(256), 0, (hipStream_t)stream, rows, cols, src, out);
-    DAGL_LAUNCH_CHECK("col_sum_kernel");
+size_t dagl_col_sum_scratch_bytes(size_t rows, int cols) {
+    return ((rows + CS_ROWS - 1) / CS_ROWS) * (size_t)cols * sizeof(double);
+}
+
+int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out, void* scratch) {
+    DAGL_REQUIRE(cols >= 1 && cols <= 256 && src && out && scratch, "dagl_col_sum: bad argument (1 <= cols <= 256, scratch required)");
+    const int n_part = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(n_part > 0 ? n_part : 1), dim3(256), 0, (hipStream_t)stream, rows, cols, src,
+                       static_cast<double*>(scratch));
+    DAGL_LAUNCH_CHECK("col_sum_partial_kernel");
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_part > 0 ? n_part : 1, cols,
+                       static_cast<const double*>(scratch), out);
+    DAGL_LAUNCH_CHECK("col_sum_final_kernel");
     return DAGL_OK;
 }
 

@@ -100,7 +100,8 @@ class _PatchLinear(torch.autograd.Function):
                 d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False, chunk_tiles=8)   # [O,n] x [n,K], split-K
             if ctx.needs_input_grad[2]:
                 d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
-                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr()), "dagl_col_sum")
+                scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
+                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr(), scr.data_ptr()), "dagl_col_sum")
             if ctx.needs_input_grad[0]:
                 d_rows = ops.gemm_f32(dz, weight, a_k_contiguous=True, b_k_contiguous=False, out=rows)   # [n,O] x [O,K]
                 d_map = torch.empty_like(pmap)

@@ -276,7 +276,8 @@ int dagl_fold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int str
 int dagl_copy4(void* stream, int n0, int n1, int n2, int n3, const float* src, long long s0, long long s1, long long s2,
                long long s3, float* dst, long long d0, long long d1, long long d2, long long d3);
 int dagl_relu_backward(void* stream, size_t n, const float* y, const float* dy, float* dz);   /* dz = dy * (y > 0)   */
-int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out);         /* out[c] = sum_r src   */
+size_t dagl_col_sum_scratch_bytes(size_t rows, int cols);
+int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out, void* scratch);   /* out[c] = sum_r src[r,c], cols <= 256 */
 
 /* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
  * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).  `scratch` = 8*B*L floats of

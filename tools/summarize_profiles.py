@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/collect_profiles.sh into the small files kept under profiles/.
+
+    python tools/summarize_profiles.py <prof dir> <out dir> <tag>
+
+  <tag>_kernel_stats_topk8_256.csv   rocprofv3 --kernel-trace --stats of the default bench command (copied as is)
+  <tag>_kernel_stats_dense_256.csv   the same for the dense adaptive regime, <tag>_kernel_stats_train.csv for bench --train
+  <tag>_traffic.json                 HBM bytes per launch per kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE counts
+                                     128-B requests at 64 B on gfx950: MI355X_MICROARCH.md, HBM section), mean over launches
+  <tag>_pmc_sq.json                  SQ counters per kernel (mean per launch) + MFMA utilisation =
+                                     SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES summed over the 4 SIMDs of a CU ...) -- see note
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return f[0] if f else None
+
+
+def counters(d):
+    """-> {kernel name: {counter: mean value per launch}}"""
+    f = find(d, "*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(list))
+    if not f:
+        return {}
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def short(name):
+    for key in ("screen_kernel<1", "screen_kernel<0", "project16_kernel", "refine_kernel", "conv_pair16_kernel", "gather_rows_kernel",
+                "aggregate_direct_kernel", "fold_kernel", "screen_theta_kernel", "dense_attend_kernel", "gemm32_kernel",
+                "score_select_kernel", "edge_softmax_topk_kernel", "thr_bias_kernel"):
+        if key in name:
+            return key + (">" if key.endswith(("<1", "<0")) else "")
+    return None
+
+
+def main():
+    src, dst, tag = sys.argv[1:4]
+    os.makedirs(dst, exist_ok=True)
+    for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("train", "train")):
+        f = find(os.path.join(src, sub), "*kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
+    fetch, write = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write"))
+    traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py default workload 256x256 top-k k=8, "
+                       "--steps 20 --warmup 5); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts 128-B "
+                       "requests at 64 B (MI355X_MICROARCH.md, HBM section); gather_rows_kernel's launches rotate over 4 row sets "
+                       "(833 MiB, past the 256 MiB Infinity Cache)"}
+    for k in fetch:
+        sk = short(k)
+        if sk and "FETCH_SIZE" in fetch[k]:
+            w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+            traffic[sk] = (2.0 * fetch[k]["FETCH_SIZE"] + w) * 1024.0
+    json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+    durations = {}
+    f = find(os.path.join(src, "stats"), "*kernel_stats.csv")
+    if f:
+        for row in csv.DictReader(open(f)):
+            sk = short(row["Name"])
+            if sk:
+                durations[sk] = float(row["AverageNs"]) / 1e3
+    sq = counters(os.path.join(src, "sq"))
+    sq2 = counters(os.path.join(src, "sq2"))
+    out = {"note": "mean per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts "
+                   "cycles (= 32 x the number of v_mfma_f32_32x32x16 issued, summed over all SIMDs); GRBM_GUI_ACTIVE is summed over the 8 "
+                   "XCDs (clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                   "GRBM_GUI_ACTIVE / 8) = fraction of the cycles the matrix pipes are busy AT THE CLOCK THE KERNEL RAN AT; "
+                   "lds_util = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8)"}
+    for k in sq:
+        sk = short(k)
+        if not sk:
+            continue
+        e = dict(sq[k])
+        e.update(sq2.get(k, {}))
+        if e.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+            cyc = e["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+            if "SQ_LDS_IDX_ACTIVE" in e:
+                e["lds_util"] = e["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+            if sk in durations:
+                e["avg_duration_us"] = durations[sk]
+                e["clock_ghz"] = cyc / (durations[sk] * 1e3)
+        out[sk] = e
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
