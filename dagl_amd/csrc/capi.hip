@@ -449,7 +449,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             memset(&oa, 0, sizeof(oa));
             oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
             oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
-            oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap;
+            oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
             oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32;
             oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
             if ((r = launch_overflow_rows(s, oa))) return r;

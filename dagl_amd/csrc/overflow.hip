@@ -25,7 +25,10 @@ constexpr int OVF_GRID_B = 256;   // fixed small grid (an empty call costs one w
 
 // feature rows of the flagged queries -> compact [cap, DS] matrix (rows past the count: untouched, never used)
 __global__ __launch_bounds__(256) void ovf_gather_kernel(OvfArgs a) {
-    int nf = *a.count; if (nf > a.cap) nf = a.cap;
+    // more flagged queries than the list holds: the host is about to send the whole call to the dense formulation (or the
+    // fp32 scan) -- nothing to do here (redoing 256 rows of a DENSE mask one by one costs 17 ms at 256^2)
+    int nf = *a.count; if (nf > a.cap) nf = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.eff = nf;                       // what the product and the attend kernel use
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slot >= nf) return;
     const size_t ql = (size_t)a.list[slot];
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     __shared__ int lk[OVF_KEYS];
     __shared__ float lw[OVF_KEYS];
     __shared__ int wcnt[4];
-    int nf = *a.count; if (nf > a.cap) nf = a.cap;
+    const int nf = *a.eff;
     for (int slot = blockIdx.x; slot < nf; slot += gridDim.x) {
     const size_t ql = (size_t)a.list[slot];
     const int b = (int)(ql / a.g.L);
@@ -140,7 +143,7 @@ int launch_overflow_rows(hipStream_t s, const OvfArgs& a) {
         g.A = a.qrows; g.lda = DS; g.sA = 0; g.a_kc = 1;                          // the same flagged rows for every image
         g.B = a.x; g.ldb = DS; g.sB = (long long)a.rows_x * DS; g.b_kc = 1;
         g.C = a.scores; g.ldc = a.ldn; g.sC = (long long)a.cap * a.ldn;
-        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3; g.m_limit = a.count;
+        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3; g.m_limit = a.eff;
         const int rc = launch_gemm32(s, g);
         if (rc) return rc;
     }

@@ -89,7 +89,10 @@ def main():
                 e["lds_util"] = e["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
             if sk in durations:
                 e["avg_duration_us"] = durations[sk]
-                e["clock_ghz"] = cyc / (durations[sk] * 1e3)
+                if durations[sk] >= 40.0:                  # (GRBM_GUI_ACTIVE of a short kernel is dominated by its ramp)
+                    e["clock_ghz"] = cyc / (durations[sk] * 1e3)
+                else:
+                    e.pop("mfma_util", None); e.pop("lds_util", None)
         out[sk] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)
 
