@@ -40,15 +40,14 @@ __global__ __launch_bounds__(256) void ovf_gather_kernel(OvfArgs a) {
 __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     __shared__ double shd[4];
     __shared__ float shf[4];
-    __shared__ int lk[OVF_KEYS];
-    __shared__ float lw[OVF_KEYS];
     __shared__ int wcnt[4];
+    __shared__ float4 part[4][P / 4];                                       // the four waves' partial rows (12.25 KiB)
     const int nf = *a.eff;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int N = a.g.N, C4 = P / 4;
     for (int slot = blockIdx.x; slot < nf; slot += gridDim.x) {
     const size_t ql = (size_t)a.list[slot];
     const int b = (int)(ql / a.g.L);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int N = a.g.N;
     const float* row = a.scores + ((size_t)b * a.cap + slot) * a.ldn;
     const float mtq = a.mt[ql], bsq = a.bs[ql];
 
@@ -65,7 +64,6 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     const int deg = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     double M = (double)fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
     if (deg < N) M = fmax(M, 0.0);
-    __syncthreads();
     // 2. denominator over ALL keys (masked keys: e^(0 - M) each)
     double z = 0.0;
     for (int j = tid; j < N; j += 256) {
@@ -77,46 +75,75 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     if (lane == 0) shd[w] = z;
     __syncthreads();
     const double Z = ((shd[0] + shd[1]) + (shd[2] + shd[3])) + (double)(N - deg) * exp(-M);
-    __syncthreads();
+    const double invZ = 1.0 / Z;
+    __syncthreads();                                                        // (shd is reused for the softmax mass below)
 
-    // 3. weighted sum of the value patches, neighbours in ascending key order, 256 keys per round
-    const int C4 = P / 4;                                                 // thread r < 196 owns float4 column r = kh*28 + (kw*4 + c4)
-    const int r = tid < C4 ? tid : 0;
-    const int kh = r / 28, rem = r % 28;
-    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH) + rem;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // 3. weighted sum of the value patches.  No block barrier inside: every wave walks its own quarter of the keys in
+    //    chunks of 64 (ballot of the passing keys, ascending), lane l owns the float4 columns l + 64 u of the 784-float row;
+    //    neighbours are taken two at a time so that their loads are in flight together.  The four partial rows are added
+    //    in wave order at the end: a fixed summation order.
+    int kh[4], rem[4]; bool cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = lane + 64 * u;
+        cv[u] = r < C4;
+        const int rc = cv[u] ? r : 0;
+        kh[u] = rc / 28; rem[u] = rc % 28;
+    }
+    const float4* vmb = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH);
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     double rs = 0.0;
-    for (int c0 = 0; c0 < N; c0 += OVF_KEYS) {
-        const int j = c0 + tid;
-        bool pass = false; float wgt = 0.f;
-        if (j < N) {
-            const float l = ovf_logit(row[j], mtq, bsq, pass);
-            if (pass) wgt = (float)((double)expf((float)((double)l - M)) / Z);
+    const int per_wave = ((N + 3) / 4 + 63) / 64 * 64;
+    const int j0 = w * per_wave;
+    const int j1 = (j0 + per_wave < N) ? j0 + per_wave : N;
+    auto take = [&](int key, float wv) {
+        const int jy = key / a.g.W, jx = key - jy * a.g.W;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!cv[u]) continue;
+            const float4 v = vmb[((size_t)(jy + kh[u]) * a.g.Wp + jx) * (CH / 4) + rem[u]];
+            acc[u].x = fmaf(wv, v.x, acc[u].x); acc[u].y = fmaf(wv, v.y, acc[u].y);
+            acc[u].z = fmaf(wv, v.z, acc[u].z); acc[u].w = fmaf(wv, v.w, acc[u].w);
         }
-        const unsigned long long bal = __ballot(pass);
-        if (lane == 0) wcnt[w] = (int)__popcll(bal);
-        __syncthreads();
-        int base = 0;
-        for (int u = 0; u < w; ++u) base += wcnt[u];
-        const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        if (pass) { const int pos = base + (int)__popcll(bal & ((1ull << lane) - 1ull)); lk[pos] = j; lw[pos] = wgt; }
-        __syncthreads();
-        if (tid < C4) {
-            for (int e = 0; e < total; ++e) {
-                const int key = lk[e]; const float wv = lw[e];
-                const int jy = key / a.g.W, jx = key - jy * a.g.W;
-                const float4 v = vm[((size_t)(jy + kh) * a.g.Wp + jx) * (CH / 4)];
-                acc.x = fmaf(wv, v.x, acc.x); acc.y = fmaf(wv, v.y, acc.y); acc.z = fmaf(wv, v.z, acc.z); acc.w = fmaf(wv, v.w, acc.w);
+    };
+    for (int c0 = j0; c0 < j1; c0 += 64) {
+        const int j = c0 + lane;
+        bool pass = false; float wgt = 0.f;
+        if (j < j1) {
+            const float l = ovf_logit(row[j], mtq, bsq, pass);
+            if (pass) wgt = (float)((double)expf((float)((double)l - M)) * invZ);
+        }
+        unsigned long long bal = __ballot(pass);
+        while (bal) {
+            const int b0 = __ffsll((long long)bal) - 1; bal &= bal - 1;
+            const float w0 = __shfl(wgt, b0);
+            if (bal) {
+                const int b1 = __ffsll((long long)bal) - 1; bal &= bal - 1;
+                const float w1 = __shfl(wgt, b1);
+                take(c0 + b0, w0); take(c0 + b1, w1);
+                rs += (double)w0; rs += (double)w1;
+            } else {
+                take(c0 + b0, w0);
+                rs += (double)w0;
             }
         }
-        if (tid == 0) for (int e = 0; e < total; ++e) rs += (double)lw[e];
-        __syncthreads();
     }
-    if (tid < C4) reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (cv[u]) part[w][lane + 64 * u] = acc[u];
+    if (lane == 0) shd[w] = rs;
+    __syncthreads();
+    if (tid < C4) {
+        float4 t = part[0][tid];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) { const float4 v = part[ww][tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = t;
+    }
     if (tid == 0) {
         a.nb_cnt[ql] = deg;                                               // true degree (the list itself stays clipped)
         if (a.dbg_deg) a.dbg_deg[ql] = deg;
-        if (a.dbg_rowsum) a.dbg_rowsum[ql] = (float)rs;
+        if (a.dbg_rowsum) a.dbg_rowsum[ql] = (float)((shd[0] + shd[1]) + (shd[2] + shd[3]));
     }
     __syncthreads();
     }

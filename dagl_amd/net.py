@@ -146,6 +146,23 @@ CHOP_PRESETS = {       # (min_size, shave_size_max) of the four forks' forward_c
 }
 
 
+def sparse_heads_state_dict(sd: "OrderedDict[str, torch.Tensor]", seed: int, gain: float = 1.65,
+                            prefix: str = "body.8.") -> "OrderedDict[str, torch.Tensor]":
+    """Replace the parameters of the 12 ``CE`` heads in ``sd`` (keys ``<prefix>c<stage>_<head>.*``) by
+    ``synth.make_ce_params(seed + index, "sparse", gain)``: thr / bias heads that keep a handful of neighbours per query
+    (mean degrees of ~5-10, long-tailed) -- the regime a trained DAGL works in, as opposed to default-initialised heads
+    that keep ~95 % of the keys.  Regenerable anywhere (numpy PCG64)."""
+    from .synth import make_ce_params
+    out = OrderedDict(sd)
+    idx = 0
+    for s in (1, 2, 3):
+        for h in (1, 2, 3, 4):
+            for n, a in make_ce_params(seed + idx, variant="sparse", sparse_gain=gain).items():
+                out[f"{prefix}c{s}_{h}.{n}"] = torch.from_numpy(a)
+            idx += 1
+    return out
+
+
 def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
                  ensemble: bool = False):
     """Recursive 4-way tiled inference: the reference's ``Model.forward_chop`` for scale 1

@@ -44,12 +44,17 @@ def reference_modules():
 
 
 def main():
-    from dagl_amd.net import chop_forward, psnr, seeded_state_dict, set12_protocol_noise
+    from dagl_amd.net import chop_forward, psnr, seeded_state_dict, set12_protocol_noise, sparse_heads_state_dict
+    sparse = "--sparse" in sys.argv       # second regime: sparse adaptive masks (sparse_heads_state_dict, gain 1.65)
+    suffix = "_sparse" if sparse else ""
     torch.set_num_threads(os.cpu_count() or 1)
     ref_pkg, ref_dagl = reference_modules()
     args = SimpleNamespace(n_resblocks=16, n_feats=64, n_colors=1, res_scale=1, rgb_range=1.0)
     net = ref_dagl.RR(args).eval()
-    net.load_state_dict(seeded_state_dict(net.state_dict(), SEED), strict=True)
+    sd = seeded_state_dict(net.state_dict(), SEED)
+    if sparse:
+        sd = sparse_heads_state_dict(sd, SEED + 100, 1.65)
+    net.load_state_dict(sd, strict=True)
 
     # 1. tiling check: my chop_forward == the reference's Model.forward_chop (cheap stand-in network)
     m = ref_pkg.Model.__new__(ref_pkg.Model)
@@ -66,7 +71,10 @@ def main():
     files = sorted(glob.glob(os.path.join(REF, "testsets", "Set12", "*.png")))
     assert len(files) == 12
     images = {os.path.basename(f)[:-4]: np.asarray(Image.open(f).convert("L"), dtype=np.uint8) for f in files}
-    np.savez_compressed(os.path.join(HERE, "set12.npz"), **{f"img_{k}": v for k, v in images.items()})
+    if not sparse:
+        np.savez_compressed(os.path.join(HERE, "set12.npz"), **{f"img_{k}": v for k, v in images.items()})
+    else:
+        images = {k: images[k] for k in ("01", "05", "09")}             # three images (two 256^2, one 512^2) suffice here
 
     result, subs = {}, {}
     for name, img in images.items():
@@ -81,9 +89,10 @@ def main():
         subs[f"out_{name}"] = out[0, 0, ::8, ::8].numpy().astype(np.float32)
         print(name, result[name], flush=True)
         json.dump(dict(seed=SEED, sigma=50, protocol="DN_Gray/test.py:49-66, forward_chop without ensemble",
+                       heads=("sparse_heads_state_dict(seed + 100, gain 1.65)" if sparse else "seeded_state_dict"),
                        torch=torch.__version__, images=result),
-                  open(os.path.join(HERE, "set12_psnr_ref.json"), "w"), indent=1)
-        np.savez_compressed(os.path.join(HERE, "set12_out_sub.npz"), **subs)
+                  open(os.path.join(HERE, f"set12_psnr_ref{suffix}.json"), "w"), indent=1)
+        np.savez_compressed(os.path.join(HERE, f"set12_out_sub{suffix}.npz"), **subs)
     print("mean output PSNR", np.mean([r["psnr_out"] for r in result.values()]))
 
 
