@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void edge_softmax_topk_kernel(EdgeArgs a, int 
     __shared__ float cv[4][TOPK_MAX_CAND];
     __shared__ int ci[4][TOPK_MAX_CAND];
     if (a.run_flags == nullptr) { edge_softmax_topk_unit(a, kslots, cv, ci, blockIdx.x); return; }
+    if (a.run_count != nullptr && *a.run_count == 0) return;           // nothing flagged anywhere (the usual case)
     const int nqg = (a.L + 127) / 128;
     for (size_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         // block-uniform skip: none of the block's 4 queries sits in a flagged group

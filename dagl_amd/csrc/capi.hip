@@ -136,6 +136,9 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.s_steps_per_split = (p.s_steps + sp - 1) / sp;
         p.s_splits = (p.s_steps + p.s_steps_per_split - 1) / p.s_steps_per_split;
         p.s_sample = p.s_steps_per_split >= 8 ? 4 : (p.s_steps_per_split >= 4 ? 2 : 1);
+#ifdef DAGL_ABLATION
+        { static const int smp = [] { const char* e = getenv("DAGL_SCREEN_SAMPLE"); return e ? atoi(e) : 0; }(); if (smp > 0) p.s_sample = smp; }
+#endif
     }
     // candidate slots per (query, chunk, half) segment: 16 when a query has many segments, up to 256 when it has few
     // (short key streams): ~1024 slots per query in total
@@ -189,9 +192,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
         p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
-        p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int32_t));
-        p.o_scandv = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(float));
-        p.o_ssegcnt = carve(off, BL * p.s_splits * 2 * sizeof(int32_t));
+        p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int2));     // candidate records (count in slot 0)
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_ovfq = p.o_ovfscores = 0;
@@ -471,8 +472,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.rows_qh = feat_rows_h(g.L); sc.rows_xh = feat_rows_h(g.N);
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
-        sc.capseg = p.capseg; sc.cand_idx = at<int32_t>(ws, p.o_scand); sc.seg_cnt = at<int32_t>(ws, p.o_ssegcnt);
-        sc.cand_val = at<float>(ws, p.o_scandv);
+        sc.capseg = p.capseg; sc.cand = at<int2>(ws, p.o_scand);
         redo = at<int32_t>(ws, p.o_redo);
 #ifdef DAGL_ABLATION
         { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
@@ -533,8 +533,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         memset(&ra, 0, sizeof(ra));
         ra.B = B; ra.L = g.L; ra.N = g.N; ra.mode = mode; ra.k = k; ra.splits = p.s_splits; ra.capseg = p.capseg;
         ra.width = p.width; ra.wq = Wq; ra.x = X; ra.rows_q = feat_rows(g.L); ra.rows_x = feat_rows(g.N);
-        ra.mt = mt; ra.bs = bias; ra.cand_idx = sc.cand_idx; ra.seg_cnt = sc.seg_cnt;
-        ra.cand_val = sc.cand_val; ra.theta = sc.theta;
+        ra.mt = mt; ra.bs = bias; ra.cand = sc.cand; ra.theta = sc.theta;
         ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if (p.ovf_cap > 0) {
@@ -564,7 +563,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         } else {
             // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it
             // exits at once for every other group, so no host round trip is needed
-            sa.run_flags = redo; ea.run_flags = redo;
+            sa.run_flags = redo; ea.run_flags = redo; sa.run_count = stats + 2; ea.run_count = stats + 2;
             need_exact = true;
             if (info && (dbg_deg || dbg_rowsum || dbg_agg)) {        // debug entry point: report the overflow count
                 int64_t hs[4] = {0, 0, 0, 0};

@@ -204,6 +204,7 @@ struct SelectArgs {
     int32_t* cand_idx;              // [B, L, splits*2, k]
     float*   cand_val;
     const int32_t* run_flags;       // optional [B, ceil(L/128)]: only flagged query groups are processed
+    const int64_t* run_count;       // with run_flags: number of flagged queries of this call; 0 = the launch exits after one load
 };
 int launch_score_select(hipStream_t s, const SelectArgs& a, int pass /*0 fast, 1 fill, 2 topk*/);
 
@@ -220,6 +221,7 @@ struct EdgeArgs {
     int32_t* nb_cnt;                // [B,L] entries used
     int width;
     const int32_t* run_flags;       // optional [B, ceil(L/128)] (top-k merge only)
+    const int64_t* run_count;       // with run_flags: number of flagged queries of this call (0 = exit at once)
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
@@ -246,9 +248,10 @@ struct ScreenArgs {
     const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
     int capseg;
-    int32_t* cand_idx;              // pass 1 out: [B, L, splits*2, capseg]
-    float* cand_val;                // pass 1 out: screened score of each candidate (sign bit set = upper bound only)
-    int32_t* seg_cnt;               // pass 1 out: [B, L, splits*2]
+    // pass 1 out: one record of capseg 8-byte slots per (query, chunk, half) segment: slot 0 = {candidates found, 0}, slot
+    // 1 + e = {key, screened score (sign bit set = upper bound only)} of candidate e -- the count and the first three
+    // candidates share one 32-byte read.  A segment holds capseg - 1 candidates; a larger count means overflow.
+    int2* cand;                     // [B, L, splits*2, capseg]
     const int32_t* run_flags;
     int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
 };
@@ -260,8 +263,8 @@ struct RefineArgs {
     int B, L, N, mode, k, splits, capseg, width;
     const float* wq; const float* x; int rows_q, rows_x;     // fp32 features
     const float* mt; const float* bs;
-    const int32_t* cand_idx; const int32_t* seg_cnt;
-    const float* cand_val; const float* theta;     // screened scores of the candidates, candidate threshold per query
+    const int2* cand;                              // candidate records of the screen (ScreenArgs::cand)
+    const float* theta;                            // candidate threshold per query
     int32_t* nb_idx; float* nb_wgt; int32_t* nb_cnt;
     int32_t* redo_flags;            // [B, n_qgroups_exact]: query groups (of 128) the exact kernel must redo
     int n_qgroups_exact;

@@ -113,7 +113,11 @@ struct Proj16Args {
 
 // Block = 4 waves (two blocks per CU, independent barriers).  All operands arrive by LDS-DMA issued from inline asm and are
 // consumed behind COUNTED s_waitcnt vmcnt(N): the weight slice of tap t+PD is requested while tap t is multiplied.
-constexpr int P16_BW = 4;                              // waves per block (two blocks per CU: independent barriers)
+#ifndef DAGL_P16_BW
+#define DAGL_P16_BW 4
+#endif
+constexpr int P16_BW = DAGL_P16_BW;                    // waves per block (two blocks per CU: independent barriers)
+constexpr int P16_BLOCKS_PER_CU = (P16_BW > 4) ? 1 : 2;
 constexpr int P16_RING = 4;                            // weight stages
 constexpr int P16_PD_KEYS = 3;                         // prefetch distance (taps): key blocks
 constexpr int P16_PD_Q = 2;                            // query blocks (their per-tap patch stages leave room for 3 only)
@@ -124,7 +128,7 @@ constexpr int P16_APART = 1280;                        // keys: one part (hi or 
 constexpr int P16_AROW = 2 * P16_APART;                // keys: one staged map row per wave: hi | lo
 constexpr int P16_LDS = P16_OFF_A + P16_QRING * P16_BW * 2048;      // 80 KiB (keys use 56 + 4 x 2 x 2.5 = 76)
 static_assert(P16_BW * 2 * P16_AROW <= P16_QRING * P16_BW * 2048, "key row rings must fit the patch region");
-static_assert(2 * P16_LDS <= 160 * 1024, "two blocks per CU");
+static_assert(P16_BLOCKS_PER_CU * P16_LDS <= 160 * 1024, "resident blocks per CU");
 
 template <int N>
 __device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -359,7 +363,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 }
 
 template <int VAR>
-__global__ __launch_bounds__(64 * P16_BW, 2) void project16_kernel(Proj16Args pa) {
+__global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kernel(Proj16Args pa) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];
     // 1-D grid.  Full blocks first: per image [query blocks][key blocks], every wave owns 32 patches x all 7 output
     // tiles.  The last n_split_groups key blocks of the last image come last, cut into 7 single-tile blocks each: a grid
@@ -428,7 +432,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    const int cap = 2 * cus, total = B * (nbq + nbk), rem = total % cap;
+    const int cap = P16_BLOCKS_PER_CU * cus, total = B * (nbq + nbk), rem = total % cap;
     int groups = (rem > 0 && rem <= cap / 2) ? rem : 0;
     if (groups > nbk) groups = nbk;
     pa.n_split_groups = groups; pa.n_full = total - groups; pa.batch = B;

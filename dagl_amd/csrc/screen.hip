@@ -72,8 +72,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
     size_t qlin[QW];
     float thq[QW], thlo[QW];          // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
     int n_loc[QW];
-    int32_t* cseg[QW];
-    float* vseg[QW];
+    int2* cseg[QW];
     size_t seg[QW];
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
@@ -93,8 +92,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         }
         n_loc[w] = 0;
         seg[w] = (qlin[w] * a.splits + split) * 2 + h;
-        cseg[w] = a.cand_idx + seg[w] * a.capseg;
-        vseg[w] = a.cand_val + seg[w] * a.capseg;
+        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
     }
 #pragma unroll
     for (int w = 0; w < QW; ++w)
@@ -127,16 +125,27 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         }
         // two 32-key row tiles x QW query tiles, MFMA chains interleaved so that no instruction waits on its predecessor
         f32x16 acc[QW][2];
+        if (VAR & 64) {                                  // ablation: accumulators carried across the steps, no epilogue
+#pragma unroll
+            for (int w = 0; w < QW; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[w][0][r] = gm[w][r]; acc[w][1][r] = gm[w][(r + 1) & 15]; }
+        } else {
 #pragma unroll
         for (int w = 0; w < QW; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
+        }
         const unsigned short* kp0 = &sK[cur][i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
         for (int t = 0; t < KB; ++t) {
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
+            bf16x8 k0, k1;
+            if (VAR & 16) { k0 = qf[0][t]; k1 = qf[0][(t + 1) % KB]; }
+            else {
+                k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
+                k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
+            }
             if (VAR & 2) {
 #pragma unroll
                 for (int w = 0; w < QW; ++w) { acc[w][0][t] += (float)k0[0] * (float)qf[w][t][0]; acc[w][1][t] += (float)k1[0] * (float)qf[w][t][1]; }
@@ -150,6 +159,11 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         }
 #pragma unroll
         for (int w = 0; w < QW; ++w) {
+            if (VAR & 64) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[w][r] = acc[w][0][r] + acc[w][1][r];
+                continue;
+            }
             if (VAR & 4) { gm[w][0] += acc[w][0][0] + acc[w][1][0]; continue; }
             if (PASS == 0) {
 #pragma unroll
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                             mask &= ~(1u << bit);
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
-                            if (n_loc[w] < a.capseg) { cseg[w][n_loc[w]] = key; vseg[w][n_loc[w]] = sv; }
+                            if (n_loc[w] < a.capseg - 1) cseg[w][n_loc[w]] = make_int2(key, __float_as_int(sv));
                             ++n_loc[w];
                         }
                     }
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
             }
         }
         dma_wait_all();
-        __syncthreads();
+        if (!(VAR & 32)) __syncthreads();
         cur ^= 1;
     }
 
@@ -217,7 +231,11 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
             }
             if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
         } else {
-            if (qvalid[w]) a.seg_cnt[seg[w]] = n_loc[w];
+            if (VAR & 64) { float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += gm[w][r];
+                if (t == 12345.f) n_loc[w] = 1; }
+            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
         }
     }
 }
@@ -251,6 +269,24 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
         case 2: SCR_LAUNCH(P_, Q_, 2); break;                            \
         case 4: SCR_LAUNCH(P_, Q_, 4); break;                            \
         case 8: SCR_LAUNCH(P_, Q_, 8); break;                            \
+        case 16: SCR_LAUNCH(P_, Q_, 16); break;                          \
+        case 40: SCR_LAUNCH(P_, Q_, 40); break;                          \
+        case 9: SCR_LAUNCH(P_, Q_, 9); break;                            \
+        case 41: SCR_LAUNCH(P_, Q_, 41); break;                          \
+        case 32: SCR_LAUNCH(P_, Q_, 32); break;                          \
+        case 48: SCR_LAUNCH(P_, Q_, 48); break;                          \
+        case 24: SCR_LAUNCH(P_, Q_, 24); break;                          \
+        case 25: SCR_LAUNCH(P_, Q_, 25); break;                          \
+        case 57: SCR_LAUNCH(P_, Q_, 57); break;                          \
+        case 23: SCR_LAUNCH(P_, Q_, 23); break;                          \
+        case 39: SCR_LAUNCH(P_, Q_, 39); break;                          \
+        case 55: SCR_LAUNCH(P_, Q_, 55); break;                          \
+        case 15: SCR_LAUNCH(P_, Q_, 15); break;                          \
+        case 63: SCR_LAUNCH(P_, Q_, 63); break;                          \
+        case 121: SCR_LAUNCH(P_, Q_, 121); break;                        \
+        case 89: SCR_LAUNCH(P_, Q_, 89); break;                          \
+        case 73: SCR_LAUNCH(P_, Q_, 73); break;                          \
+        case 72: SCR_LAUNCH(P_, Q_, 72); break;                          \
         default: SCR_LAUNCH(P_, Q_, 7); break;                           \
     }
     static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
@@ -348,30 +384,35 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         qv[u] = (c4 < D / 4) ? raw : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // 1. gather candidate indices: lane <-> segment; the first four slots of a segment are fetched together with
+    // per-query scalars of the later steps, requested up front as well
+    const bool adaptive = (a.mode != DAGL_MODE_TOPK);
+    const float thq = (a.mode != DAGL_MODE_ADAPTIVE) ? a.theta[ql] : 0.f;
+    const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
+
+    // 1. gather candidate indices: lane <-> segment; the first three candidates of a segment are fetched together with
     //    its count (one memory round trip), longer segments are rare and finished in a loop
     int total = 0;
     for (int s0 = 0; s0 < S2; s0 += 64) {
         const int sgi = s0 + lane;
         const bool sv = sgi < S2;
         const size_t sg = ql * S2 + (sv ? sgi : 0);
-        int cnt = a.seg_cnt[sg];                           // sg is a valid slot also for idle lanes
-        if (!sv) cnt = 0;
-        const int4 f4 = *reinterpret_cast<const int4*>(a.cand_idx + sg * a.capseg);
-        const float4 g4 = *reinterpret_cast<const float4*>(a.cand_val + sg * a.capseg);
-        if (cnt > a.capseg) { overflow = true; cnt = a.capseg; }
+        // one record per segment: {count, -} {key0, s0} {key1, s1} {key2, s2} arrive with two 16-byte loads of one line
+        const int2* rec = a.cand + sg * a.capseg;                // sg is a valid slot also for idle lanes
+        const int4 r0 = *reinterpret_cast<const int4*>(rec);
+        const int4 r1 = *reinterpret_cast<const int4*>(rec + 2);
+        int cnt = sv ? r0.x : 0;
+        if (cnt > a.capseg - 1) { overflow = true; cnt = a.capseg - 1; }
         int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int off = total + incl - cnt;
         if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
-        if (cnt > 0) { c_idx[w][off] = f4.x; c_val[w][off] = g4.x; }
-        if (cnt > 1) { c_idx[w][off + 1] = f4.y; c_val[w][off + 1] = g4.y; }
-        if (cnt > 2) { c_idx[w][off + 2] = f4.z; c_val[w][off + 2] = g4.z; }
-        if (cnt > 3) { c_idx[w][off + 3] = f4.w; c_val[w][off + 3] = g4.w; }
-        for (int e = 4; e < cnt; ++e) {
-            c_idx[w][off + e] = a.cand_idx[sg * a.capseg + e];
-            c_val[w][off + e] = a.cand_val[sg * a.capseg + e];
+        if (cnt > 0) { c_idx[w][off] = r0.z; c_val[w][off] = __int_as_float(r0.w); }
+        if (cnt > 1) { c_idx[w][off + 1] = r1.x; c_val[w][off + 1] = __int_as_float(r1.y); }
+        if (cnt > 2) { c_idx[w][off + 2] = r1.z; c_val[w][off + 2] = __int_as_float(r1.w); }
+        for (int e = 3; e < cnt; ++e) {
+            const int2 c = rec[1 + e];
+            c_idx[w][off + e] = c.x; c_val[w][off + e] = __int_as_float(c.y);
         }
         total += __shfl(incl, 63);
     }
@@ -384,7 +425,6 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     //     k candidates have S~ >= t (t = k-th largest lower bound), so the k-th largest true score is >= t/(1+DELTA), and a
     //     candidate whose upper bound is below t (1-DELTA)/(1+DELTA) cannot be among the k best.
     if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k && total <= 64) {
-        const float thq = a.theta[ql];
         const bool have = lane < total;
         const int key = have ? c_idx[w][lane] : -1;
         const float u = have ? c_val[w][lane] : 0.f;
@@ -439,11 +479,11 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     }
     __threadfence_block();
 
-    const bool adaptive = (a.mode != DAGL_MODE_TOPK);
-    const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
     int n = 0;
     constexpr int RU = DAGL_LIST_CAP / 64;                 // list entries per lane: entry e lives in lane e % 64, slot e / 64
     float my_s[RU]; int my_key[RU];
+    int pos0 = lane;                                       // list position of slot 0 (-1: none); differs from the lane only
+                                                           // after the rank-counting selection below
 #pragma unroll
     for (int u = 0; u < RU; ++u) { my_s[u] = 0.f; my_key[u] = -1; }
 
@@ -473,27 +513,22 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             if (e < n) { my_s[u] = c_val[w][e]; my_key[u] = c_idx[w][e]; }
         }
     } else if (total <= 64) {
-        // top-k of <= 64 candidates: bitonic sort in registers, (value desc, key asc)
+        // top-k of <= 64 candidates by rank counting: (value desc, key asc) is a strict order on the valid candidates, so the
+        // number of candidates ahead of a lane's own is its list position.  `total` uniform lane reads, no shuffle chain.
         float v = -3.0f; int key = 0x7fffffff;
         if (lane < total) {
             v = c_val[w][lane]; key = c_idx[w][lane];
             if (key < 0 || (a.mode == DAGL_MODE_ADAPTIVE_TOPK && !(((v - mtq) + bsq) > 0.f))) { v = -3.0f; key = 0x7fffffff; }
         }
-#pragma unroll
-        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-                const float ov = __shfl_xor(v, j); const int ok = __shfl_xor(key, j);
-                const bool first = ((lane & k2) == 0);            // this k2-block sorts "best first"
-                const bool lower = ((lane & j) == 0);
-                const bool other_better = rf_before(ov, ok, v, key);
-                const bool take = (lower == first) ? other_better : (!other_better && (ov != v || ok != key));
-                if (take) { v = ov; key = ok; }
-            }
+        int rank = 0;
+        for (int j = 0; j < total; ++j) {
+            const float vj = __shfl(v, j); const int kj = __shfl(key, j);
+            rank += rf_before(vj, kj, v, key) ? 1 : 0;
         }
         const unsigned long long valid_mask = __ballot(v > -2.0f);
         n = min(a.k, (int)__popcll(valid_mask));
-        if (lane < n) { my_s[0] = v; my_key[0] = key; }
+        if (v > -2.0f && rank < n) { my_s[0] = v; my_key[0] = key; pos0 = rank; }
+        else pos0 = -1;
     } else {
         if (a.mode == DAGL_MODE_ADAPTIVE_TOPK) {
             for (int c = lane; c < total; c += 64)
@@ -524,7 +559,8 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     double M = -1e300;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-        const bool valid = lane + 64 * u < n;
+        const int e = (u == 0) ? pos0 : lane + 64 * u;
+        const bool valid = e >= 0 && e < n;
         lg[u] = valid ? rf_logit(my_s[u], mtq, bsq, adaptive) : 0.f;
         if (valid) M = fmax(M, (double)lg[u]);
     }
@@ -534,7 +570,8 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     double ev[RU], sum = 0.0;
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-        ev[u] = (lane + 64 * u < n) ? exp((double)lg[u] - M) : 0.0;      // (slots past the first are empty outside the long-tail case)
+        const int e = (u == 0) ? pos0 : lane + 64 * u;
+        ev[u] = (e >= 0 && e < n) ? exp((double)lg[u] - M) : 0.0;        // (slots past the first are empty outside the long-tail case)
         sum += ev[u];
     }
 #pragma unroll
@@ -542,8 +579,8 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     sum += (double)(a.N - n) * exp(-M);
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
-        const int e = lane + 64 * u;
-        if (e < n) {
+        const int e = (u == 0) ? pos0 : lane + 64 * u;
+        if (e >= 0 && e < n) {
             a.nb_idx[ql * a.width + e] = my_key[u];
             a.nb_wgt[ql * a.width + e] = (float)(ev[u] / sum);
             if (a.nb_s != nullptr) a.nb_s[ql * a.width + e] = my_s[u];

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int 
         score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, xcd_remap(blockIdx.x, gridDim.x));
         return;
     }
+    if (a.run_count != nullptr && *a.run_count == 0) return;           // nothing flagged anywhere (the usual case)
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform
         score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, unit);
