@@ -69,7 +69,7 @@ struct Plan {
     bool screen;                    // bf16 screen + exact refine (default) vs. the all-fp32 scan
     bool split16;                   // fp16 split-operand projection (default) vs. the fp32 MFMA projection
     int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
-    int s_splits, s_steps_per_split, s_steps, s_sample;   // bf16 screen (screen.hip)
+    int s_splits, s_steps_per_split, s_steps, s_sample, s_qblock;   // bf16 screen (screen.hip)
     int capseg;
     int width;                      // neighbour-list width of the fixed-width paths
     int ovf_cap;                    // adaptive lists behind the screen: queries that may be redone one by one (overflow.hip)
@@ -119,20 +119,28 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     // adaptive lists: 256 slots behind the screen (mean degrees of ~8 come with maxima of ~100), 64 for the exact scan and for
     // the training entry point (its backward keeps one neighbour per lane)
     p.width = (mode == DAGL_MODE_ADAPTIVE) ? ((core || exact || g_N_small(H, W)) ? DAGL_FAST_CAP : DAGL_LIST_CAP) : k;
-    // bf16 screen: 256 queries per block, chunks of >= 4 steps of 64 keys, <= 64 chunks
+    // bf16 screen: the key stream from L2 into LDS is what bounds it (LDS-DMA lands ~25 GB/s per CU, 6.4 TB/s over the chip;
+    // at 256^2 sixteen groups of 256 queries stream the 28 MB of bf16 keys 16 times = 453 MB = 71 us against 46 us of matrix
+    // work), so a block covers 512 queries (16 waves, one block per CU: every key tile is fetched half as often) whenever
+    // that still gives one block per CU; otherwise 256 queries (8 waves, two blocks per CU).  Key chunks of >= 4 steps of 64
+    // keys, <= 64 chunks.
     p.s_steps = (g.N + SKEYS - 1) / SKEYS;
     {
-        const int nqg = (g.L + 255) / 256;
+        const int mx = (p.s_steps + 3) / 4 > 64 ? 64 : (p.s_steps + 3) / 4;
+        const int nq512 = (g.L + 511) / 512;
+        int qb = ((long long)nq512 * B * mx >= 256) ? 512 : 256;
 #ifdef DAGL_ABLATION
-        static const int target = [] { const char* e = getenv("DAGL_SCREEN_BLOCKS"); return e ? atoi(e) : 512; }();
+        { static const int e = [] { const char* v = getenv("DAGL_SCREEN_QBLOCK"); return v ? atoi(v) : 0; }(); if (e == 256 || e == 512) qb = e; }
+        static const int target_env = [] { const char* e = getenv("DAGL_SCREEN_BLOCKS"); return e ? atoi(e) : 0; }();
+        const int target = target_env > 0 ? target_env : (qb == 512 ? 256 : 512);
 #else
-        constexpr int target = 512;               // two resident rounds of 256 blocks
+        const int target = (qb == 512) ? 256 : 512;   // one resident round
 #endif
+        const int nqg = (g.L + qb - 1) / qb;
         int sp = (target + nqg * B - 1) / (nqg * B);
-        const int mx = (p.s_steps + 3) / 4;
         if (sp > mx) sp = mx;
-        if (sp > 64) sp = 64;
         if (sp < 1) sp = 1;
+        p.s_qblock = qb;
         p.s_steps_per_split = (p.s_steps + sp - 1) / sp;
         p.s_splits = (p.s_steps + p.s_steps_per_split - 1) / p.s_steps_per_split;
         p.s_sample = p.s_steps_per_split >= 8 ? 4 : (p.s_steps_per_split >= 4 ? 2 : 1);
@@ -470,7 +478,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         memset(&sc, 0, sizeof(sc));
         sc.B = B; sc.L = g.L; sc.N = g.N; sc.mode = mode; sc.wqh = Wqh; sc.xh = Xh;
         sc.rows_qh = feat_rows_h(g.L); sc.rows_xh = feat_rows_h(g.N);
-        sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample;
+        sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample; sc.qblock = p.s_qblock;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand = at<int2>(ws, p.o_scand);
         redo = at<int32_t>(ws, p.o_redo);

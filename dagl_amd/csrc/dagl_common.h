@@ -40,6 +40,21 @@ __device__ __forceinline__ void glds16_asm(const float* gsrc, unsigned lds_byte_
                  : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// counted form: returns once at most N of this wave's vector-memory operations are outstanding (loads land in issue order, so
+// everything but the N youngest has arrived)
+template <int N>
+__device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// phase stamps of a block (ablation builds only; 100 MHz constant clock): tools/block_times.py turns them into a timeline
+__device__ __forceinline__ void dbg_stamp(unsigned long long* buf, int block, int slot) {
+#ifdef DAGL_ABLATION
+    if (buf != nullptr && threadIdx.x == 0) buf[(size_t)block * 4 + slot] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+#ifdef DAGL_ABLATION
+unsigned long long* dbg_times_buffer(size_t blocks);                 // lazily allocated device buffer (project16.hip)
+void dbg_times_dump(hipStream_t s, const char* kernel, const unsigned long long* buf, size_t blocks);   // env DAGL_TIMES_FILE
+#endif
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -244,6 +259,7 @@ struct ScreenArgs {
     const uint16_t* wqh; const uint16_t* xh;        // bf16 features [B, rows_*h, DSH]
     int rows_qh, rows_xh;
     int splits, steps_per_split, n_steps, sample;
+    int qblock;                     // queries per block: 256 (8 waves, two blocks per CU) or 512 (16 waves, one block per CU)
     float* gmax;                    // pass 0 out: [B, L, splits*2, 4] largest group maxima of S~ per segment
     const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
@@ -254,6 +270,7 @@ struct ScreenArgs {
     int2* cand;                     // [B, L, splits*2, capseg]
     const int32_t* run_flags;
     int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
+    unsigned long long* times;      // ablation builds: [blocks][4] 100 MHz stamps (entry, loop start, loop end, exit) or null
 };
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
 int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta);

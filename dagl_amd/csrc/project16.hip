@@ -109,6 +109,7 @@ struct Proj16Args {
     int n_full, n_split_groups, batch;                              // 1-D grid: full blocks, then 7 single-tile blocks per split group
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
     RangeTag range; int heads;                                      // range guard: the packed weights' flags feed the call's word
+    unsigned long long* times;                                      // ablation builds: block phase stamps (debug.hip) or null
 };
 
 // Block = 4 waves (two blocks per CU, independent barriers).  All operands arrive by LDS-DMA issued from inline asm and are
@@ -130,8 +131,6 @@ constexpr int P16_LDS = P16_OFF_A + P16_QRING * P16_BW * 2048;      // 80 KiB (k
 static_assert(P16_BW * 2 * P16_AROW <= P16_QRING * P16_BW * 2048, "key row rings must fit the patch region");
 static_assert(P16_BLOCKS_PER_CU * P16_LDS <= 160 * 1024, "resident blocks per CU");
 
-template <int N>
-__device__ __forceinline__ void dma_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NT, bool KEYS, int VAR>
 __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk, int b) {
@@ -268,6 +267,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
     P16_WAIT(PD - 1);
     __syncthreads();
+    dbg_stamp(pa.times, blockIdx.x, 1);
 
     if (VAR == 9) { if (hh[0][0] != 0.f) pa.feat[which][0] = 1.f; return; }
     auto compute = [&](int step) {
@@ -318,6 +318,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 #undef P16_WAIT
     static_assert(PD == 2 || PD == 3, "the drain sequence above is written for PD = 2 or 3");
 
+    dbg_stamp(pa.times, blockIdx.x, 2);
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i] ----------------------------
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
     // tiles.  The last n_split_groups key blocks of the last image come last, cut into 7 single-tile blocks each: a grid
     // that overhangs the resident-block capacity by a few blocks would otherwise cost a whole extra round.
     const int bid = blockIdx.x;
+    dbg_stamp(pa.times, bid, 0);
     if (bid == 0 && threadIdx.x < 2 * pa.heads && pa.range.word != nullptr) {        // weights packed from out-of-range values?
         const unsigned short* wpk = pa.wp[threadIdx.x & 1];
         if (wpk != nullptr &&
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
         const int grp = sb / P16_NT, tile = sb - grp * P16_NT;
         project16_body<1, true, VAR>(pa, smem, tile, pa.n_blocks_k - pa.n_split_groups + grp, pa.batch - 1);
     }
+    dbg_stamp(pa.times, bid, 3);
 }
 
 // colsum[b][col] = sum over key blocks of colpart[b][blk][col]: one wave per column, lane-strided partial sums
@@ -409,7 +412,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
                      uint16_t* feat_q_bf16, int heads, RangeTag range) {
     Proj16Args pa;
-    pa.range = range; pa.heads = heads;
+    pa.range = range; pa.heads = heads; pa.times = nullptr;
     pa.imgs_per_head = B / heads;
     for (int h = 0; h < 4; ++h) {
         pa.bias[0][h] = bias_keys ? bias_keys[h < heads ? h : 0] : nullptr;
@@ -438,6 +441,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.n_split_groups = groups; pa.n_full = total - groups; pa.batch = B;
     const dim3 grid(pa.n_full + P16_NT * groups), block(64 * P16_BW);
 #ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
+    if (getenv("DAGL_TIMES_FILE")) pa.times = dbg_times_buffer(grid.x);
     static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
     if (var == 1) hipLaunchKernelGGL(project16_kernel<1>, grid, block, 0, s, pa);
     else if (var == 3) hipLaunchKernelGGL(project16_kernel<3>, grid, block, 0, s, pa);
@@ -452,6 +456,9 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
 #endif
     hipLaunchKernelGGL(project16_kernel<0>, grid, block, 0, s, pa);
     DAGL_LAUNCH_CHECK("project16_kernel");
+#ifdef DAGL_ABLATION
+    if (pa.times) dbg_times_dump(s, "project16_kernel", pa.times, grid.x);
+#endif
     if (pa.colpart != nullptr && nbk > 0) {
         hipLaunchKernelGGL(colsum_reduce_kernel, dim3((D + 3) / 4, B), dim3(256), 0, s, nbk, colpart, colsum);
         DAGL_LAUNCH_CHECK("colsum_reduce_kernel");

@@ -50,9 +50,15 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
 template <int PASS, int QW, int VAR, int SCR_QUERIES = 256>
 __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1) void screen_kernel(ScreenArgs a, int n_qgroups) {
     constexpr int WAVES = SCR_QUERIES / 32 / QW;
-    __shared__ __attribute__((aligned(16))) unsigned short sK[2][STEP_ELEMS];        // 54 KiB
+    // key tiles in flight: a tile is requested NBUF-1 steps before it is multiplied.  LDS-DMA lands a tile ~2 us after its
+    // request under load, a step's matrix work is 1.45 us: with two buffers (request one step ahead) every step ends waiting
+    // for the next tile.  512-query blocks are alone on their CU and can afford four buffers (108 KiB).
+    constexpr int NBUF = (SCR_QUERIES == 512) ? 4 : 2;
+    constexpr int PPW = STEP_PIECES / WAVES;                                  // DMA pieces per wave and step (+1 for the first waves)
+    __shared__ __attribute__((aligned(16))) unsigned short sK[NBUF][STEP_ELEMS];     // 54 / 108 KiB
 
     const int tid = threadIdx.x;
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -107,22 +113,26 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
-    if (step0 < step1) {
+    const int n_it = (step1 > step0) ? (step1 - step0 + stride - 1) / stride : 0;
+    const bool more = wave < (STEP_PIECES % WAVES);                          // this wave carries PPW + 1 pieces per step
+    auto request = [&](int it) {                                             // key tile of iteration it -> buffer it % NBUF
+        const unsigned dst = lds0 + (unsigned)(it % NBUF) * (STEP_ELEMS * 2);
+        const unsigned short* src = xb + (size_t)(step0 + it * stride) * STEP_ELEMS;
         for (int p = wave; p < STEP_PIECES; p += WAVES)
-            glds16_asm(reinterpret_cast<const float*>(xb + (size_t)step0 * STEP_ELEMS + p * 512 + lane * 8),
-                       __builtin_amdgcn_readfirstlane(lds0 + p * 1024));
-    }
+            glds16_asm(reinterpret_cast<const float*>(src + p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (j < n_it) request(j);
     dma_wait_all();
     __syncthreads();
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 1);
 
     int cur = 0;
-    for (int step = step0; step < step1; step += stride) {
-        if (step + stride < step1 && !(VAR & 1)) {
-            const unsigned dst = lds0 + (cur ^ 1) * (STEP_ELEMS * 2);
-            for (int p = wave; p < STEP_PIECES; p += WAVES)
-                glds16_asm(reinterpret_cast<const float*>(xb + (size_t)(step + stride) * STEP_ELEMS + p * 512 + lane * 8),
-                           __builtin_amdgcn_readfirstlane(dst + p * 1024));
-        }
+    for (int it = 0; it < n_it; ++it) {
+        const int step = step0 + it * stride;
+        const bool ahead = it + NBUF - 1 < n_it;
+        if (ahead && !(VAR & 1)) request(it + NBUF - 1);                    // into the buffer the previous step has left
         // two 32-key row tiles x QW query tiles, MFMA chains interleaved so that no instruction waits on its predecessor
         f32x16 acc[QW][2];
         if (VAR & 64) {                                  // ablation: accumulators carried across the steps, no epilogue
@@ -204,10 +214,13 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                 }
             }
         }
-        dma_wait_all();
+        // the next tile must have landed; the NBUF-2 tiles requested after it may still be in flight
+        if (ahead && NBUF > 2) { if (more) dma_wait_le<(NBUF - 2) * (PPW + 1)>(); else dma_wait_le<(NBUF - 2) * PPW>(); }
+        else dma_wait_all();
         if (!(VAR & 32)) __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1 == NBUF) ? 0 : cur + 1;
     }
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 2);
 
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
             if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
         }
     }
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
 }
 
 // theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32
@@ -258,7 +272,8 @@ int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float*
 }
 
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
-    const int n_qgroups = (a.L + 255) / 256;
+    const int qblock = (a.qblock == 512) ? 512 : 256;
+    const int n_qgroups = (a.L + qblock - 1) / qblock;
     dim3 grid(n_qgroups * a.splits, a.B);
 #ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
 #define SCR_LAUNCH(P_, Q_, V_) hipLaunchKernelGGL((screen_kernel<P_, Q_, V_>), grid, dim3(256 / Q_ * 2), 0, s, a, n_qgroups)
@@ -290,11 +305,27 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
         default: SCR_LAUNCH(P_, Q_, 7); break;                           \
     }
     static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
+    const size_t n_blk = (size_t)grid.x * grid.y;
+    ScreenArgs at = a; at.times = (getenv("DAGL_TIMES_FILE") && pass == 1) ? dbg_times_buffer(n_blk) : nullptr;
+#define a at
+    if (qblock == 512) {                                                  // 512-query blocks: a few variants only
+#define SCR_L5(P_, V_) hipLaunchKernelGGL((screen_kernel<P_, 1, V_, 512>), grid, dim3(1024), 0, s, a, n_qgroups)
+#define SCR_V5(P_) switch (a.variant) { case 0: SCR_L5(P_, 0); break; case 8: SCR_L5(P_, 8); break; case 24: SCR_L5(P_, 24); break; \
+                                         case 25: SCR_L5(P_, 25); break; case 9: SCR_L5(P_, 9); break; default: SCR_L5(P_, 57); break; }
+        if (pass == 0) { SCR_V5(0) } else { SCR_V5(1) }
+    } else
     if (qw == 2) { if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) } }
     else { if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) } }
+#undef a
+    if (at.times) dbg_times_dump(s, "screen_kernel<1>", at.times, n_blk);
 #else
-    if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
-    else hipLaunchKernelGGL((screen_kernel<1, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
+    if (qblock == 512) {
+        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
+    } else {
+        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
+    }
 #endif
     DAGL_LAUNCH_CHECK("screen_kernel");
     return DAGL_OK;

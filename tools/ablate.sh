@@ -7,6 +7,6 @@ WHICH=$1; shift
 cd $GRAFT_REPO_ROOT
 DAGL_EXTRA_FLAGS=-DDAGL_ABLATION python -m dagl_amd.build --force > /dev/null 2>&1
 for v in "$@"; do
-  env DAGL_${WHICH}_VARIANT=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-quality --no-extra 2>/dev/null | python -c "
+  env DAGL_${WHICH}_VARIANT=$v python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-quality --no-extra 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$WHICH variant $v', round(d['ms_per_step'],4), {k: round(x*1e3,1) for k,x in d['stage_ms'].items()})"
 done
