@@ -60,6 +60,8 @@ def parse():
                          "--crop x --crop crops, --batch crops per GPU, DDP gradient all-reduce over RCCL")
     ap.add_argument("--crop", type=int, default=128)
     ap.add_argument("--colors", type=int, default=3)
+    ap.add_argument("--wseed", type=int, default=2024, help="seed of the synthetic head weights")
+    ap.add_argument("--fseed", type=int, default=None, help="seed of the synthetic feature maps (+ rank); default: the per-rank stream of seed 100")
     ap.add_argument("--prewarm", type=float, default=0.5,
                     help="seconds of untimed passes before the W warm-up steps (clock ramp of an idle GPU); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -325,7 +327,7 @@ def main():
 
     mode, k = args.mode, (args.k if args.mode != "adaptive" else 0)
     variant = ("default" if mode == "topk" else "sparse") if args.variant == "auto" else args.variant
-    params = {n: torch.from_numpy(a) for n, a in make_ce_params(2024, variant=variant, sparse_gain=args.sparse_gain).items()}
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(args.wseed, variant=variant, sparse_gain=args.sparse_gain).items()}
     ce = CE(in_channels=64)
     ce.load_state_dict(params, strict=True)
     ce.select_mode = mode
@@ -335,7 +337,7 @@ def main():
     ce = ce.to(dev).eval()
 
     B, H, W = args.batch, args.size, args.size
-    x = torch.from_numpy(make_features(rank_seed(100, rank), B, 64, H, W)).to(dev)     # resident in HBM
+    x = torch.from_numpy(make_features(rank_seed(100, rank) if args.fseed is None else args.fseed + rank, B, 64, H, W)).to(dev)     # resident in HBM
     L, N = ((H + 3) // 4) * ((W + 3) // 4), H * W
 
     prof = ops.StageProfile(max(args.steps, 1))

@@ -76,7 +76,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
 };
 
 static bool g_N_small(int H, int W);
@@ -203,12 +203,13 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int2));     // candidate records (count in slot 0)
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
-    p.ovf_cap = 0; p.o_ovflist = p.o_ovfq = p.o_ovfscores = 0;
+    p.ovf_cap = 0; p.o_ovflist = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
     if (p.screen && mode == DAGL_MODE_ADAPTIVE && !core) {
         p.ovf_cap = overflow_cap(g.N);
         p.o_ovflist = carve(off, (size_t)p.ovf_cap * sizeof(int32_t));
         p.o_ovfq = carve(off, (size_t)p.ovf_cap * DS * sizeof(float));
         p.o_ovfscores = carve(off, (size_t)B * p.ovf_cap * ((g.N + 31) / 32 * 32) * sizeof(float));
+        p.o_ovfpart = carve(off, (size_t)p.ovf_cap * OVF_CHUNKS * OVF_PART_FLOATS * sizeof(float));
     }
     p.o_end = off;
     return DAGL_OK;
@@ -459,7 +460,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
             oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
             oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
-            oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32;
+            oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32; oa.part = at<float>(ws, p.o_ovfpart);
             oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
             if ((r = launch_overflow_rows(s, oa))) return r;
         }

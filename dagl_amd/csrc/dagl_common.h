@@ -302,7 +302,10 @@ struct OvfArgs {
     float* qrows;                                              // [cap, DS] feature rows of the flagged queries
     float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys
     float* agg; int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;
+    float* part;                                               // [cap, OVF_CHUNKS, OVF_PART_FLOATS] per-chunk partial results
 };
+constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (one block each)
+constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}
 int launch_overflow_rows(hipStream_t s, const OvfArgs& a);
 int overflow_cap(int N);
 

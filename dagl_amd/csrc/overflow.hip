@@ -6,8 +6,8 @@
 //   A  gather + gemm32     scores of every flagged query against ALL keys as ONE matrix product [flagged, 196] x [196, N] on
 //                          the fp32 matrix cores (every key row is read once for all flagged queries, not once per query; the
 //                          row count lives in device memory: blocks past it exit)
-//   B  ovf_attend_kernel   one block per flagged query: mask, softmax over all N keys (masked keys count e^0), weighted sum
-//                          of the value patches straight from the value map; overwrites the query's aggregated row
+//   B  stats / attend / combine (below): mask, softmax over all N keys (masked keys count e^0), weighted sum of the value
+//                          patches straight from the value map; overwrites the query's aggregated row
 // All kernels read the number of flagged queries from device memory and exit at once when it is zero.
 #include "dagl_common.h"
 
@@ -37,51 +37,77 @@ __global__ __launch_bounds__(256) void ovf_gather_kernel(OvfArgs a) {
     for (int c = lane; c < DS; c += 64) a.qrows[(size_t)slot * DS + c] = qrow[c];
 }
 
-__global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
-    __shared__ double shd[4];
+// A flagged query's score row is cut into OVF_CHUNKS key chunks, one block each: a row with hundreds of passing keys is a
+// latency chain of value-patch gathers, and one block per query (10 blocks at 256^2) left it at 290 us.
+//   B1 ovf_stats_kernel    per (query, chunk): largest logit and number of passing keys
+//   B2 ovf_attend_kernel   per (query, chunk): with the row's M and degree from B1, z = sum of e^(l - M) over the chunk's
+//                          passing keys and the UNNORMALISED weighted sum of their value patches
+//   B3 ovf_combine_kernel  per query: Z = sum of z + (N - degree) e^(-M)  (masked keys count e^0 each, dagl.py:259-261),
+//                          row = sum of the chunks' partial rows / Z in chunk order; overwrites the aggregated row
+__device__ __forceinline__ void ovf_chunk_range(int N, int chunk, int& j0, int& j1) {
+    const int per = ((N + OVF_CHUNKS - 1) / OVF_CHUNKS + 255) / 256 * 256;
+    j0 = chunk * per; j1 = j0 + per;
+    if (j0 > N) j0 = N;
+    if (j1 > N) j1 = N;
+}
+
+__global__ __launch_bounds__(256) void ovf_stats_kernel(OvfArgs a) {
     __shared__ float shf[4];
     __shared__ int wcnt[4];
+    const int nf = *a.eff;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int j0, j1; ovf_chunk_range(a.g.N, blockIdx.x, j0, j1);
+    for (int slot = blockIdx.y; slot < nf; slot += gridDim.y) {
+        const size_t ql = (size_t)a.list[slot];
+        const int b = (int)(ql / a.g.L);
+        const float* row = a.scores + ((size_t)b * a.cap + slot) * a.ldn;
+        const float mtq = a.mt[ql], bsq = a.bs[ql];
+        float mx = -1.f; int cnt = 0;
+        for (int j = j0 + tid; j < j1; j += 256) {
+            bool pass; const float l = ovf_logit(row[j], mtq, bsq, pass);
+            if (pass) { mx = fmaxf(mx, l); ++cnt; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); cnt += __shfl_xor(cnt, o); }
+        if (lane == 0) { shf[w] = mx; wcnt[w] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float* pr = a.part + ((size_t)slot * OVF_CHUNKS + blockIdx.x) * OVF_PART_FLOATS + P;
+            pr[0] = fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
+            reinterpret_cast<int*>(pr)[1] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        }
+        __syncthreads();
+    }
+}
+
+// the row's largest logit (0 joins in when a key is masked) and degree, from the chunks' partials (fixed order)
+__device__ __forceinline__ void ovf_row_stats(const OvfArgs& a, int slot, double& M, int& deg) {
+    float mx = -1.f; deg = 0;
+    for (int c = 0; c < OVF_CHUNKS; ++c) {
+        const float* pr = a.part + ((size_t)slot * OVF_CHUNKS + c) * OVF_PART_FLOATS + P;
+        mx = fmaxf(mx, pr[0]); deg += reinterpret_cast<const int*>(pr)[1];
+    }
+    M = (double)mx;
+    if (deg < a.g.N) M = fmax(M, 0.0);
+}
+
+__global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
+    __shared__ double shd[4];
     __shared__ float4 part[4][P / 4];                                       // the four waves' partial rows (12.25 KiB)
     const int nf = *a.eff;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int N = a.g.N, C4 = P / 4;
-    for (int slot = blockIdx.x; slot < nf; slot += gridDim.x) {
+    const int C4 = P / 4;
+    int j0c, j1c; ovf_chunk_range(a.g.N, blockIdx.x, j0c, j1c);
+    for (int slot = blockIdx.y; slot < nf; slot += gridDim.y) {
     const size_t ql = (size_t)a.list[slot];
     const int b = (int)(ql / a.g.L);
     const float* row = a.scores + ((size_t)b * a.cap + slot) * a.ldn;
     const float mtq = a.mt[ql], bsq = a.bs[ql];
+    double M; int deg; ovf_row_stats(a, slot, M, deg);
 
-    // 1. degree, largest logit
-    float mx = -1.f; int cnt = 0;
-    for (int j = tid; j < N; j += 256) {
-        bool pass; const float l = ovf_logit(row[j], mtq, bsq, pass);
-        if (pass) { mx = fmaxf(mx, l); ++cnt; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); cnt += __shfl_xor(cnt, o); }
-    if (lane == 0) { shf[w] = mx; wcnt[w] = cnt; }
-    __syncthreads();
-    const int deg = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    double M = (double)fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
-    if (deg < N) M = fmax(M, 0.0);
-    // 2. denominator over ALL keys (masked keys: e^(0 - M) each)
-    double z = 0.0;
-    for (int j = tid; j < N; j += 256) {
-        bool pass; const float l = ovf_logit(row[j], mtq, bsq, pass);
-        if (pass) z += (double)expf((float)((double)l - M));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
-    if (lane == 0) shd[w] = z;
-    __syncthreads();
-    const double Z = ((shd[0] + shd[1]) + (shd[2] + shd[3])) + (double)(N - deg) * exp(-M);
-    const double invZ = 1.0 / Z;
-    __syncthreads();                                                        // (shd is reused for the softmax mass below)
-
-    // 3. weighted sum of the value patches.  No block barrier inside: every wave walks its own quarter of the keys in
-    //    chunks of 64 (ballot of the passing keys, ascending), lane l owns the float4 columns l + 64 u of the 784-float row;
-    //    neighbours are taken two at a time so that their loads are in flight together.  The four partial rows are added
-    //    in wave order at the end: a fixed summation order.
+    // No block barrier inside the sum: every wave walks its own quarter of the chunk in pieces of 64 keys (ballot of the
+    // passing keys, ascending), lane l owns the float4 columns l + 64 u of the 784-float row; neighbours are taken two at a
+    // time so that their loads are in flight together.  The four partial rows are added in wave order at the end.
     int kh[4], rem[4]; bool cv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -94,10 +120,10 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    double rs = 0.0;
-    const int per_wave = ((N + 3) / 4 + 63) / 64 * 64;
-    const int j0 = w * per_wave;
-    const int j1 = (j0 + per_wave < N) ? j0 + per_wave : N;
+    double z = 0.0;
+    const int per_wave = ((j1c - j0c + 3) / 4 + 63) / 64 * 64;
+    const int j0 = j0c + w * per_wave;
+    const int j1 = (j0 + per_wave < j1c) ? j0 + per_wave : j1c;
     auto take = [&](int key, float wv) {
         const int jy = key / a.g.W, jx = key - jy * a.g.W;
 #pragma unroll
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
         bool pass = false; float wgt = 0.f;
         if (j < j1) {
             const float l = ovf_logit(row[j], mtq, bsq, pass);
-            if (pass) wgt = (float)((double)expf((float)((double)l - M)) * invZ);
+            if (pass) wgt = expf((float)((double)l - M));
         }
         unsigned long long bal = __ballot(pass);
         while (bal) {
@@ -123,29 +149,55 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
                 const int b1 = __ffsll((long long)bal) - 1; bal &= bal - 1;
                 const float w1 = __shfl(wgt, b1);
                 take(c0 + b0, w0); take(c0 + b1, w1);
-                rs += (double)w0; rs += (double)w1;
+                z += (double)w0; z += (double)w1;
             } else {
                 take(c0 + b0, w0);
-                rs += (double)w0;
+                z += (double)w0;
             }
         }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (cv[u]) part[w][lane + 64 * u] = acc[u];
-    if (lane == 0) shd[w] = rs;
+    if (lane == 0) shd[w] = z;
     __syncthreads();
+    float* pr = a.part + ((size_t)slot * OVF_CHUNKS + blockIdx.x) * OVF_PART_FLOATS;
     if (tid < C4) {
         float4 t = part[0][tid];
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) { const float4 v = part[ww][tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = t;
+        reinterpret_cast<float4*>(pr)[tid] = t;
     }
-    if (tid == 0) {
-        a.nb_cnt[ql] = deg;                                               // true degree (the list itself stays clipped)
-        if (a.dbg_deg) a.dbg_deg[ql] = deg;
-        if (a.dbg_rowsum) a.dbg_rowsum[ql] = (float)((shd[0] + shd[1]) + (shd[2] + shd[3]));
-    }
+    if (tid == 0) *reinterpret_cast<double*>(pr + P + 2) = (shd[0] + shd[1]) + (shd[2] + shd[3]);
     __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a) {
+    const int nf = *a.eff;
+    const int tid = threadIdx.x;
+    const int C4 = P / 4;
+    for (int slot = blockIdx.x; slot < nf; slot += gridDim.x) {
+        const size_t ql = (size_t)a.list[slot];
+        double M; int deg; ovf_row_stats(a, slot, M, deg);
+        double zs = 0.0;
+        for (int c = 0; c < OVF_CHUNKS; ++c)
+            zs += *reinterpret_cast<const double*>(a.part + ((size_t)slot * OVF_CHUNKS + c) * OVF_PART_FLOATS + P + 2);
+        const double Z = zs + (double)(a.g.N - deg) * exp(-M);
+        const float inv = (float)(1.0 / Z);
+        if (tid < C4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < OVF_CHUNKS; ++c) {
+                const float4 v = reinterpret_cast<const float4*>(a.part + ((size_t)slot * OVF_CHUNKS + c) * OVF_PART_FLOATS)[tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+            reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = t;
+        }
+        if (tid == 0) {
+            a.nb_cnt[ql] = deg;                                               // true degree (the list itself stays clipped)
+            if (a.dbg_deg) a.dbg_deg[ql] = deg;
+            if (a.dbg_rowsum) a.dbg_rowsum[ql] = (float)(zs / Z);
+        }
     }
 }
 
@@ -174,8 +226,13 @@ int launch_overflow_rows(hipStream_t s, const OvfArgs& a) {
         const int rc = launch_gemm32(s, g);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(ovf_attend_kernel, dim3(a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B), dim3(256), 0, s, a);
+    const int gy = a.cap < 32 ? a.cap : 32;                               // flagged queries are strided over grid.y
+    hipLaunchKernelGGL(ovf_stats_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("ovf_stats_kernel");
+    hipLaunchKernelGGL(ovf_attend_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_attend_kernel");
+    hipLaunchKernelGGL(ovf_combine_kernel, dim3(a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("ovf_combine_kernel");
     return DAGL_OK;
 }
 

@@ -19,10 +19,23 @@ def main():
     for line in open(path):
         f = line.split()
         name, n = f[0], int(f[1])
+        if name.endswith("_phases"):                  # per-wave sums of shader-clock deltas, 5 phases per wave
+            w = np.array(f[2:2 + 4 * n], dtype=np.float64)
+            w = w[:len(w) - len(w) % 5].reshape(-1, 5)
+            by.setdefault(name, []).append(w)
+            continue
         t = np.array(f[2:2 + 4 * n], dtype=np.float64).reshape(n, 4) / 100.0      # us
         by.setdefault(name, []).append(t)
     for name, runs in by.items():
         runs = runs[skip:] if len(runs) > skip else runs
+        if name.endswith("_phases"):
+            m = np.mean([r.mean(axis=0) for r in runs], axis=0)
+            mx = np.mean([r.max(axis=0) for r in runs], axis=0)
+            tot = m.sum()
+            print(f"{name}: per-wave clocks inside the loop, mean over waves (max): total {tot:.0f}")
+            for k, lab in enumerate(["tile request", "reads + multiplies", "test + extraction", "wait for tile", "barrier"]):
+                print(f"  {lab:20s} {m[k]:9.0f} ({mx[k]:9.0f})  {100 * m[k] / tot:5.1f} %")
+            continue
         spans, ent, pro, loop, epi, ends = [], [], [], [], [], []
         for t in runs:
             ok = t[:, 3] > 0
