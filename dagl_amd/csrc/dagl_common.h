@@ -298,7 +298,7 @@ struct OvfArgs {
     const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
     const float* mt; const float* bs; const float* b2p;
     const int32_t* list; const int32_t* count; int cap;        // flagged queries (b*L + l), how many (device), list capacity
-    int32_t* eff;                                              // device word: rows actually redone (0 when count > cap)
+    int32_t* eff;                                              // two device words: rows actually redone (0 when count > cap); rows of the matrix-core product
     float* qrows;                                              // [cap, DS] feature rows of the flagged queries
     float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys
     float* agg; int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;

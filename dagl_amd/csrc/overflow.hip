@@ -21,6 +21,7 @@ __device__ __forceinline__ float ovf_logit(float s, float mtq, float bsq, bool& 
     return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;
 }
 
+constexpr int OVF_SMALL = 16;     // up to this many flagged queries the scores come from a VALU kernel instead of the product
 constexpr int OVF_GRID_B = 256;   // fixed small grid (an empty call costs one wave of exits): flagged queries are strided
 
 // feature rows of the flagged queries -> compact [cap, DS] matrix (rows past the count: untouched, never used)
@@ -28,13 +29,52 @@ __global__ __launch_bounds__(256) void ovf_gather_kernel(OvfArgs a) {
     // more flagged queries than the list holds: the host is about to send the whole call to the dense formulation (or the
     // fp32 scan) -- nothing to do here (redoing 256 rows of a DENSE mask one by one costs 17 ms at 256^2)
     int nf = *a.count; if (nf > a.cap) nf = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.eff = nf;                       // what the product and the attend kernel use
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.eff[0] = nf;                                                          // what the attend kernels use
+        a.eff[1] = (nf > OVF_SMALL) ? nf : 0;                                   // rows of the matrix-core product (few rows: VALU kernel)
+    }
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slot >= nf) return;
     const size_t ql = (size_t)a.list[slot];
     const int b = (int)(ql / a.g.L);
     const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.g.L)) * DS;
     for (int c = lane; c < DS; c += 64) a.qrows[(size_t)slot * DS + c] = qrow[c];
+}
+
+// A' few flagged queries (<= OVF_SMALL; 10 at 256^2 mean degree 8): a 128-row matrix-core tile would be 90 % padding (45 us);
+// instead four lanes share a key, each sums a quarter of the 49 float4 products per flagged row (query rows broadcast from
+// LDS), two shuffle steps finish the dot product.  Every key row is still read once for all flagged queries.
+__global__ __launch_bounds__(256) void ovf_scores_small_kernel(OvfArgs a) {
+    __shared__ float4 sq[OVF_SMALL][DS / 4];                                    // 12.5 KiB
+    const int nf = a.eff[0];
+    if (nf == 0 || nf > OVF_SMALL) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < nf * (DS / 4); e += 256) sq[e / (DS / 4)][e % (DS / 4)] = reinterpret_cast<const float4*>(a.qrows)[e];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int k = lane >> 2, qd = lane & 3;
+    const long long key = ((long long)blockIdx.x * 4 + w) * 16 + k;
+    const bool ok = key < a.g.N;
+    const float4* xr = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.rows_x + (ok ? key : 0)) * DS);
+    float acc[OVF_SMALL];
+#pragma unroll
+    for (int r = 0; r < OVF_SMALL; ++r) acc[r] = 0.f;
+    for (int c = qd; c < D / 4; c += 4) {
+        const float4 x = xr[c];
+#pragma unroll
+        for (int r = 0; r < OVF_SMALL; ++r)
+            if (r < nf) {                                                        // wave-uniform
+                const float4 q = sq[r][c];
+                acc[r] = fmaf(q.x, x.x, fmaf(q.y, x.y, fmaf(q.z, x.z, fmaf(q.w, x.w, acc[r]))));
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < OVF_SMALL; ++r)
+        if (r < nf) {
+            float sum = acc[r];
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+            if (ok && qd == 0) a.scores[((size_t)b * a.cap + r) * a.ldn + key] = sum;
+        }
 }
 
 // A flagged query's score row is cut into OVF_CHUNKS key chunks, one block each: a row with hundreds of passing keys is a
@@ -222,10 +262,12 @@ int launch_overflow_rows(hipStream_t s, const OvfArgs& a) {
         g.A = a.qrows; g.lda = DS; g.sA = 0; g.a_kc = 1;                          // the same flagged rows for every image
         g.B = a.x; g.ldb = DS; g.sB = (long long)a.rows_x * DS; g.b_kc = 1;
         g.C = a.scores; g.ldc = a.ldn; g.sC = (long long)a.cap * a.ldn;
-        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3; g.m_limit = a.eff;
+        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3; g.m_limit = a.eff + 1;
         const int rc = launch_gemm32(s, g);
         if (rc) return rc;
     }
+    hipLaunchKernelGGL(ovf_scores_small_kernel, dim3((a.g.N + 63) / 64, a.B), dim3(256), 0, s, a);
+    DAGL_LAUNCH_CHECK("ovf_scores_small_kernel");
     const int gy = a.cap < 32 ? a.cap : 32;                               // flagged queries are strided over grid.y
     hipLaunchKernelGGL(ovf_stats_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_stats_kernel");

@@ -449,6 +449,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     }
     overflow = __any(overflow);
     if (total > RF_MAX_CAND) total = RF_MAX_CAND;
+    // adaptive lists with the per-query redo behind them: twice as many candidates as the list is wide will not fit it
+    // (nearly every candidate of this mode passes the exact test) -- the row is redone on its own anyway (overflow.hip),
+    // so its candidates are not rescored here (a thousand candidates = 128 rounds of row gathers by one wave)
+    if (a.mode == DAGL_MODE_ADAPTIVE && a.ovf_list != nullptr && total > 2 * a.width) { overflow = true; total = 0; }
     __threadfence_block();
 
     // 1b. top-k modes: most candidates owe their place to the loose threshold of the sampling pass.  With the screened
