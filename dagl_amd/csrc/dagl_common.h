@@ -280,6 +280,7 @@ struct RefineArgs {
     int B, L, N, mode, k, splits, capseg, width;
     const float* wq; const float* x; int rows_q, rows_x;     // fp32 features
     const float* mt; const float* bs;
+    unsigned long long* times;                     // ablation builds: block phase stamps (debug.hip) or null
     const int2* cand;                              // candidate records of the screen (ScreenArgs::cand)
     const float* theta;                            // candidate threshold per query
     int32_t* nb_idx; float* nb_wgt; int32_t* nb_cnt;

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     __shared__ int c_idx[4][RF_MAX_CAND];
     __shared__ float c_val[4][RF_MAX_CAND];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    dbg_stamp(a.times, blockIdx.x, 0);
     const size_t ql = (size_t)blockIdx.x * 4 + w;
     if (ql >= (size_t)a.B * a.L) return;                   // no block-level sync below
     const int b = (int)(ql / a.L);
@@ -459,31 +460,55 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     //     scores at hand the wave tightens it before any feature row is fetched (that gather is what this kernel costs):
     //     k candidates have S~ >= t (t = k-th largest lower bound), so the k-th largest true score is >= t/(1+DELTA), and a
     //     candidate whose upper bound is below t (1-DELTA)/(1+DELTA) cannot be among the k best.
-    if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k && total <= 64) {
-        const bool have = lane < total;
-        const int key = have ? c_idx[w][lane] : -1;
-        const float u = have ? c_val[w][lane] : 0.f;
-        const float ub = fabsf(u);
-        float lb = have ? ((u >= 0.f) ? u : thq) : -1.0f;
+    //     Up to 256 candidates, four per lane; t by k rounds of "take the largest lower bound away" (a wave maximum each).
+    constexpr int TU = 4;
+    if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k && total <= 64 * TU) {
+        int key[TU]; float ub[TU], lb[TU], work[TU];
 #pragma unroll
-        for (int k2 = 2; k2 <= 64; k2 <<= 1) {                  // bitonic sort of the lower bounds, descending
+        for (int u = 0; u < TU; ++u) {
+            const int c = lane + 64 * u;
+            const bool have = c < total;
+            key[u] = have ? c_idx[w][c] : -1;
+            const float sv = have ? c_val[w][c] : 0.f;
+            ub[u] = fabsf(sv);
+            lb[u] = have ? ((sv >= 0.f) ? sv : thq) : -1.0f;
+            work[u] = lb[u];
+        }
+        float tk = -1.0f;
+        for (int r = 0; r < a.k; ++r) {
+            float lm = work[0];
 #pragma unroll
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-                const float o = __shfl_xor(lb, j);
-                const bool desc = ((lane & k2) == 0);
-                const bool lower = ((lane & j) == 0);
-                lb = (lower == desc) ? fmaxf(lb, o) : fminf(lb, o);
+            for (int u = 1; u < TU; ++u) lm = fmaxf(lm, work[u]);
+            float wm = lm;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            tk = wm;
+            const unsigned long long bal = __ballot(lm == wm);              // the first lane holding it drops one copy
+            const int owner = __ffsll((long long)bal) - 1;
+            bool taken = false;
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const bool hit = (lane == owner) && !taken && (work[u] == wm);
+                work[u] = hit ? -2.0f : work[u];
+                taken = taken || hit;
             }
         }
-        const float tk = __shfl(lb, a.k - 1);
-        const bool keep = have && (ub >= tk * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f));
-        const unsigned long long bal = __ballot(keep);
-        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep) c_idx[w][pos] = key;                           // pos <= lane, every lane has read its own slot already
-        total = __popcll(bal);
+        const float cut = tk * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f);
+        __threadfence_block();                                               // every lane has read its slots
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const bool keep = key[u] >= 0 && (ub[u] >= cut) && (lane + 64 * u < total);
+            const unsigned long long bal = __ballot(keep);
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep) c_idx[w][pos] = key[u];                                // pos <= lane + 64 u: behind every unread slot
+            base += __popcll(bal);
+        }
+        total = base;
         __threadfence_block();
     }
 
+    dbg_stamp(a.times, blockIdx.x, 1);
     // 2. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation
     const float* xb = a.x + (size_t)b * a.rows_x * DS;
 #pragma unroll 2
@@ -513,6 +538,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         }
     }
     __threadfence_block();
+    dbg_stamp(a.times, blockIdx.x, 2);
 
     int n = 0;
     constexpr int RU = DAGL_LIST_CAP / 64;                 // list entries per lane: entry e lives in lane e % 64, slot e / 64
@@ -633,6 +659,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             }
         }
     }
+    dbg_stamp(a.times, blockIdx.x, 3);
 }
 
 // total / max degree over all queries: one block (a same-address atomic per query would serialise ~12 ns each)
@@ -664,7 +691,13 @@ int launch_refine(hipStream_t s, const RefineArgs& a) {
         set_error("refine: too many segments"); return DAGL_ERR_INVALID;
     }
     const size_t nq = (size_t)a.B * a.L;
+#ifdef DAGL_ABLATION
+    RefineArgs at = a; at.times = getenv("DAGL_TIMES_FILE") ? dbg_times_buffer((nq + 3) / 4) : nullptr;
+    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, at);
+    if (at.times) dbg_times_dump(s, "refine_kernel", at.times, (nq + 3) / 4);
+#else
     hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
+#endif
     DAGL_LAUNCH_CHECK("refine_kernel");
     return DAGL_OK;
 }
