@@ -460,10 +460,11 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     //     scores at hand the wave tightens it before any feature row is fetched (that gather is what this kernel costs):
     //     k candidates have S~ >= t (t = k-th largest lower bound), so the k-th largest true score is >= t/(1+DELTA), and a
     //     candidate whose upper bound is below t (1-DELTA)/(1+DELTA) cannot be among the k best.
-    //     Up to 256 candidates, four per lane; t by k rounds of "take the largest lower bound away" (a wave maximum each).
+    //     t by k rounds of "take the largest lower bound away" (a wave maximum each); a lane owns candidates lane + 64 u.
+    //     Up to 256 candidates (the usual case) the lane's four slots stay in registers, beyond that they are re-read from LDS.
     constexpr int TU = 4;
     if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k && total <= 64 * TU) {
-        int key[TU]; float ub[TU], lb[TU], work[TU];
+        int key[TU]; float ub[TU], work[TU];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const int c = lane + 64 * u;
@@ -471,8 +472,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             key[u] = have ? c_idx[w][c] : -1;
             const float sv = have ? c_val[w][c] : 0.f;
             ub[u] = fabsf(sv);
-            lb[u] = have ? ((sv >= 0.f) ? sv : thq) : -1.0f;
-            work[u] = lb[u];
+            work[u] = have ? ((sv >= 0.f) ? sv : thq) : -1.0f;               // exact screened score, or only "passed theta"
         }
         float tk = -1.0f;
         for (int r = 0; r < a.k; ++r) {
@@ -494,14 +494,49 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             }
         }
         const float cut = tk * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f);
-        __threadfence_block();                                               // every lane has read its slots
         int base = 0;
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
-            const bool keep = key[u] >= 0 && (ub[u] >= cut) && (lane + 64 * u < total);
+        for (int u = 0; u < TU; ++u) {                                       // (every slot was read above)
+            const bool keep = key[u] >= 0 && ub[u] >= cut;
             const unsigned long long bal = __ballot(keep);
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep) c_idx[w][pos] = key[u];                                // pos <= lane + 64 u: behind every unread slot
+            if (keep) c_idx[w][pos] = key[u];
+            base += __popcll(bal);
+        }
+        total = base;
+        __threadfence_block();
+    } else if (a.mode != DAGL_MODE_ADAPTIVE && total > a.k) {
+        const int nu = (total + 63) >> 6;                                    // <= RF_MAX_CAND / 64 = 16
+        unsigned taken = 0u;                                                 // this lane's slots already taken away
+        float tk = -1.0f;
+        for (int r = 0; r < a.k; ++r) {
+            float lm = -1.0f; int lu = -1;
+            for (int u = 0; u < nu; ++u) {
+                const int c = lane + 64 * u;
+                if (c < total && !((taken >> u) & 1u)) {
+                    const float sv = c_val[w][c];
+                    const float lbv = (sv >= 0.f) ? sv : thq;
+                    if (lbv > lm) { lm = lbv; lu = u; }
+                }
+            }
+            float wm = lm;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            tk = wm;
+            const unsigned long long bal = __ballot(lu >= 0 && lm == wm);
+            if (bal != 0ull && lane == __ffsll((long long)bal) - 1) taken |= 1u << lu;
+        }
+        const float cut = tk * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f);
+        int base = 0;
+        for (int u = 0; u < nu; ++u) {
+            const int c = lane + 64 * u;
+            const bool have = c < total;
+            const int key = have ? c_idx[w][c] : -1;
+            const float ub = have ? fabsf(c_val[w][c]) : 0.f;
+            const bool keep = key >= 0 && ub >= cut;
+            const unsigned long long bal = __ballot(keep);
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep) c_idx[w][pos] = key;                                   // pos <= c: only slots that have been read
             base += __popcll(bal);
         }
         total = base;
