@@ -147,7 +147,7 @@ class CE(nn.Module):
         self._pack_key = None
 
     def invalidate_packed(self):
-        """Forget the packed copies of fc1 / fc2 kept in the workspace.  The cache is keyed on the weights' storage and
+        """Forget the packed copies of fc1 / fc2 / g / theta kept in the workspace.  The cache is keyed on the weights' storage and
         torch's version counter, which every in-place op and optimizer step bumps -- but edits through ``.data``
         (``w.data.mul_()``, EMA / clipping written that way) do NOT: call this after such an edit.  ``.to()`` / ``.cuda()`` /
         ``.half()`` (``_apply``) and ``load_state_dict`` call it themselves."""
@@ -252,11 +252,11 @@ class CE(nn.Module):
             out = self._forward_train(b.contiguous())
             return out if in_dtype == torch.float32 else out.to(in_dtype)
         params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
-        # the packed copies of fc1/fc2 live in this module's private workspace: skip repacking while neither the
-        # weights (torch bumps ._version on every in-place update) nor the call geometry changed
+        # the packed copies of fc1/fc2 and of the g / theta convolutions live in this module's private workspace: skip
+        # repacking while neither the weights (torch bumps ._version on every in-place update) nor the call geometry changed
         wsb = self._ws.peek(b.device)
         key = (tuple(b.shape), self.select_mode, self.select_k, self.scan, self._pack_epoch,
-               tuple((params[n].data_ptr(), params[n]._version) for n in ("fc1.0.weight", "fc2.0.weight")),
+               tuple((params[n].data_ptr(), params[n]._version) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")),
                wsb.data_ptr() if wsb is not None else 0)
         # dense regime: the edge statistics (and with them a host synchronisation) are only fetched every 16th call, to
         # notice when the neighbourhoods have become sparse again

@@ -76,7 +76,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
 static bool g_N_small(int H, int W);
@@ -191,12 +191,13 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.o_thr = carve(off, BL * sizeof(float));
     p.o_bias = carve(off, BL * sizeof(float));
     p.o_thrpart = carve(off, 8 * BL * sizeof(float));                       // prologue: partial thr/bias sums of 4 channel groups
-    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = p.o_colpart = 0;
+    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = p.o_convw = p.o_colpart = 0;
     if (!exact) {
         p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_maplo = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_wp1h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));          // up to 4 heads (stage entry point)
         p.o_wp2h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));
+        p.o_convw = carve(off, 4 * CONV_W16_BYTES);                                       // packed g / theta weights per head
         p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
     p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
@@ -328,6 +329,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         const size_t map_f = (size_t)imgs * g.Hp * g.Wp * CH;
         for (int hd = 0; hd < heads; ++hd) {
             const FusedIn& f = fin[hd];
+            unsigned char* convw = p.split16 ? at<unsigned char>(ws, p.o_convw) + (size_t)hd * CONV_W16_BYTES : nullptr;
+            if (convw && !(mode_flags & DAGL_FLAG_WEIGHTS_PACKED) && (rc = launch_pack_conv_weight16(s, f.g_w, f.th_w, convw))) return rc;
             // default path: the key/query map is only ever consumed as split fp16 (project16), so the prologue
             // writes the hi / lo maps itself and no fp32 copy exists
             if ((rc = launch_prologue(s, imgs, g, f.x, f.g_w, f.g_b, f.th_w, f.th_b, f.thr_w, f.thr_b, f.bias_w, f.bias_b,
@@ -341,7 +344,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
                                       (prepared && hd == 0) ? 8 : 0,
                                       (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
-                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt))) return rc;
+                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt, convw))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {

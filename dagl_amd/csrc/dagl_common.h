@@ -147,7 +147,9 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     bool defer_thr_reduce = false /* leave the partial sums in thr_part: launch_query_thresholds finishes them */,
                     uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
                     /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */,
-                    RangeTag range = RangeTag());
+                    RangeTag range = RangeTag(), const unsigned char* conv_w16 = nullptr /* packed g / theta weights (split-fp16 path) */);
+constexpr size_t CONV_W16_BYTES = (18 + 2) * 16 * 128 + 256;   // packed conv weights of one head + range flag
+int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w, unsigned char* img);
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,

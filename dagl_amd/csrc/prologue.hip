@@ -162,10 +162,44 @@ __device__ __forceinline__ void c16_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// weights of g (3x3) and theta (1x1) as the conv kernel wants them in LDS: [K-block: 18 of g (tap, channel half) + 2 of theta]
+// [out channel][hi 32 | lo 32] fp16 with the eight 16-byte slots of a 128-byte row stored at slot ^ ((row >> 1) & 7);
+// built once per weight set (launch_pack_conv_weight16) -- every block used to convert all 10240 weights itself.  The last
+// word flags weights outside the split-fp16 range.
+__global__ __launch_bounds__(256) void pack_conv_weight16_kernel(const float* __restrict__ g_w, const float* __restrict__ th_w,
+                                                                 unsigned char* __restrict__ img) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 16 * PC * 9 + 16 * PC) return;
+    float v; int o, c, kb;
+    if (e < 16 * PC * 9) {                                   // g_w[o][c][tap]
+        o = e / (PC * 9); const int rem = e - o * (PC * 9);
+        c = rem / 9; const int tap = rem - c * 9;
+        v = g_w[e]; kb = tap * 2 + (c >> 5);
+    } else {                                                 // theta_w[o][c]
+        const int t = e - 16 * PC * 9;
+        o = t / PC; c = t - o * PC;
+        v = th_w[t]; kb = 18 + (c >> 5);
+    }
+    _Float16 h, l;
+    c16_split(v * C16_WS, h, l);
+    unsigned char* d = img + (kb * 16 + o) * 128 + (c & 7) * 2;
+    const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;        // 16-byte slot of the row, swizzled (see the reads)
+    *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
+    *reinterpret_cast<_Float16*>(d + (((4 + ks) ^ gs) << 4)) = l;
+    if (!(fabsf(v) * C16_WS < RANGE_LIMIT)) *reinterpret_cast<int32_t*>(img + C16_WB) = 1;
+}
+
+int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w, unsigned char* img) {
+    DAGL_HIP_TRY(hipMemsetAsync(img + C16_WB, 0, 16, s));
+    hipLaunchKernelGGL(pack_conv_weight16_kernel, dim3((16 * PC * 9 + 16 * PC + 255) / 256), dim3(256), 0, s, g_w, th_w, img);
+    DAGL_LAUNCH_CHECK("pack_conv_weight16_kernel");
+    return DAGL_OK;
+}
+
 __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows_per_block,
                                                           const float* __restrict__ x,
-                                                          const float* __restrict__ g_w, const float* __restrict__ g_b,
-                                                          const float* __restrict__ th_w, const float* __restrict__ th_b,
+                                                          const unsigned char* __restrict__ wimg, const float* __restrict__ g_b,
+                                                          const float* __restrict__ th_b,
                                                           float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
                                                           int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
@@ -237,43 +271,13 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
     load_row(y0, st1, sh1);
     load_row(y0 + 1, st2, sh2);
     {
-        unsigned char* wl = smem + C16_WOFF;
-        float4 wv[9], tv;
+        // the packed weight image: 40 KiB = 10 x 16 B per thread, straight into LDS
+        uint4 wv[10];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) wv[j] = reinterpret_cast<const float4*>(g_w)[tid + 256 * j];
-        tv = reinterpret_cast<const float4*>(th_w)[tid];
+        for (int j = 0; j < 10; ++j) wv[j] = reinterpret_cast<const uint4*>(wimg)[tid + 256 * j];
+        if (tid == 0 && *reinterpret_cast<const int32_t*>(wimg + C16_WB) != 0) amax = __builtin_inff();   // weights out of range
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const float* vp = &wv[j].x;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 4 * (tid + 256 * j) + q;
-                const int o = e / (PC * 9), rem = e - o * (PC * 9);
-                const int c = rem / 9, tap = rem - c * 9;
-                _Float16 h, l;
-                c16_split(vp[q] * C16_WS, h, l);
-                amax = fmaxf(amax, fabsf(vp[q]) * C16_WS);
-                unsigned char* d = wl + ((tap * 2 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
-                const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;            // 16-byte slot of the row, swizzled (see reads)
-                *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
-                *reinterpret_cast<_Float16*>(d + (((4 + ks) ^ gs) << 4)) = l;
-            }
-        }
-        {
-            const float* vp = &tv.x;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 4 * tid + q;
-                const int o = e / PC, c = e - o * PC;
-                _Float16 h, l;
-                c16_split(vp[q] * C16_WS, h, l);
-                amax = fmaxf(amax, fabsf(vp[q]) * C16_WS);
-                unsigned char* d = wl + ((18 + (c >> 5)) * 16 + o) * 128 + (c & 7) * 2;
-                const int ks = (c & 31) >> 3, gs = (o >> 1) & 7;
-                *reinterpret_cast<_Float16*>(d + ((ks ^ gs) << 4)) = h;
-                *reinterpret_cast<_Float16*>(d + (((4 + ks) ^ gs) << 4)) = l;
-            }
-        }
+        for (int j = 0; j < 10; ++j) reinterpret_cast<uint4*>(smem + C16_WOFF)[tid + 256 * j] = wv[j];
     }
     store_row(y0 - 1, st0, sh0);
     store_row(y0, st1, sh1);
@@ -470,7 +474,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
                     uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, bool defer_thr_reduce, uint32_t* clear_a,
-                    int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range) {
+                    int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range, const unsigned char* conv_w16) {
     int rcz;
     if (!borders_zero) {
         if ((rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p))) return rcz;
@@ -485,8 +489,9 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     const int rows_per_block = (g.H + chunks - 1) / chunks;
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
     if (b1p == nullptr && b1_hi != nullptr) {
-        hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
-                           g_b, th_w, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
+        if (conv_w16 == nullptr) { set_error("launch_prologue: the split-fp16 convolutions need their packed weights"); return DAGL_ERR_INVALID; }
+        hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, conv_w16,
+                           g_b, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
     } else {
         hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,

@@ -62,7 +62,7 @@ class CES(nn.Module):
             from . import ops
             prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
             ws = self._ws[s]
-            fcs = [prm[h][n] for h in range(4) for n in ("fc1.0.weight", "fc2.0.weight")]
+            fcs = [prm[h][n] for h in range(4) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")]
             wsb = ws.peek(x.device)
             key = (tuple(x.shape), heads[0].select_mode, heads[0].select_k, tuple(hd._pack_epoch for hd in heads),
                    tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)

@@ -56,9 +56,9 @@ extern "C" {
  * refining the survivors (both give the same neighbours)                             */
 #define DAGL_FLAG_EXACT_SCAN     0x100
 /* OR-ed into `mode`: this workspace last served an identical call -- same memory, same (B,H,W,mode,k), unchanged
- * fc1/fc2 weights -- and nothing else wrote to it since.  The call then reuses what that call left behind (packed fc
- * weights, the zero borders of the padded maps, the zero guard rows of the feature matrices) instead of rebuilding
- * it: three launches fewer per forward (inference loops)                                                    */
+ * fc1 / fc2 / g / theta weights -- and nothing else wrote to it since.  The call then reuses what that call left behind
+ * (packed fc and convolution weights, the zero borders of the padded maps, the zero guard rows of the feature matrices)
+ * instead of rebuilding it: four launches fewer per forward (inference loops)                                */
 #define DAGL_FLAG_WEIGHTS_PACKED 0x200
 /* OR-ed into `mode` (adaptive mode, >= 2048 keys): expect dense neighbourhoods -- go straight to the streamed dense
  * formulation (info->path 4) instead of trying per-query lists first.  A performance hint only: the result is the
