@@ -367,6 +367,82 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// gather + weighted sum + fold in one pass (short fixed-width lists: the top-k modes)
+// ------------------------------------------------------------------------------------------------------
+// thread = (pixel, 4 channels).  For each of the <= 2 x 2 queries whose 7x7 window covers the pixel it forms that query's
+// aggregated value at the pixel's place in the window -- the same fma chain over the neighbours, in list order, that
+// aggregate_direct_kernel runs -- and adds the windows in fold_kernel's order: the result is bit-identical to the two
+// kernels, without the [L,784] rows ever going to memory (12.8 MB written and read back at 256^2) and one launch less.
+__global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* __restrict__ out, int imgs, int heads,
+                                                             RangeTag range) {
+    const Grid& g = a.g;
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = t >> 2, u = t & 3;
+    const bool poisoned = range.word != nullptr && *range.word == range.tag;
+    if (range.done != nullptr && b == 0 && y == 0 && blockIdx.x == 0 && threadIdx.x == 0) *range.done = range.tag;
+    if (x >= g.W) return;
+    int r0 = (y - 3 + QS - 1) / QS; if (y - 3 < 0) r0 = 0;
+    int r1 = (y + 3) / QS; if (r1 > g.Lh - 1) r1 = g.Lh - 1;
+    int c0 = (x - 3 + QS - 1) / QS; if (x - 3 < 0) c0 = 0;
+    int c1 = (x + 3) / QS; if (c1 > g.Lw - 1) c1 = g.Lw - 1;
+    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * g.Hp * g.Wp * CH) + u;
+    const int W = g.W, Wp = g.Wp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r <= r1; ++r) {
+        const int kh = y - (QS * r - 3);
+        for (int c = c0; c <= c1; ++c) {
+            const int kw = x - (QS * c - 3);
+            const size_t ql = (size_t)b * g.L + (size_t)r * g.Lw + c;
+            const int n = a.nb_cnt[ql];
+            const int32_t* ip = a.nb_idx + ql * a.width;
+            const float* wp = a.nb_wgt + ql * a.width;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                int id[4]; float w[4]; float4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { id[e] = ip[j + e]; w[e] = wp[j + e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jy = id[e] / W, jx = id[e] - jy * W;
+                    v[e] = vm[((size_t)(jy + kh) * Wp + jx + kw) * (CH / 4)];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q.x = fmaf(w[e], v[e].x, q.x); q.y = fmaf(w[e], v[e].y, q.y);
+                    q.z = fmaf(w[e], v[e].z, q.z); q.w = fmaf(w[e], v[e].w, q.w);
+                }
+            }
+            for (; j < n; ++j) {
+                const int id = ip[j]; const float w = wp[j];
+                const int jy = id / W, jx = id - jy * W;
+                const float4 v = vm[((size_t)(jy + kh) * Wp + jx + kw) * (CH / 4)];
+                q.x = fmaf(w, v.x, q.x); q.y = fmaf(w, v.y, q.y);
+                q.z = fmaf(w, v.z, q.z); q.w = fmaf(w, v.w, q.w);
+            }
+            acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+        }
+    }
+    float cnt = (float)((r1 - r0 + 1) * (c1 - c0 + 1));
+    if (poisoned) cnt = __builtin_nanf("");
+    const int head = b / imgs, img = b - head * imgs;
+    float* o = out + ((size_t)img * heads + head) * CH * g.N + (size_t)y * g.W + x;
+    o[(size_t)(4 * u + 0) * g.N] = acc.x / cnt;
+    o[(size_t)(4 * u + 1) * g.N] = acc.y / cnt;
+    o[(size_t)(4 * u + 2) * g.N] = acc.z / cnt;
+    o[(size_t)(4 * u + 3) * g.N] = acc.w / cnt;
+}
+
+int launch_aggregate_fold(hipStream_t s, const AggArgs& a, float* out, int heads, RangeTag range) {
+    dim3 grid((a.g.W * 4 + 255) / 256, a.g.H, a.B), block(256);
+    hipLaunchKernelGGL(aggregate_fold_kernel, grid, block, 0, s, a, out, a.B / heads, heads, range);
+    DAGL_LAUNCH_CHECK("aggregate_fold_kernel");
+    return DAGL_OK;
+}
+
 int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* out, int heads, RangeTag range) {
     dim3 grid((g.W + 63) / 64, g.H, B), block(64);
     hipLaunchKernelGGL(fold_kernel, grid, block, 0, s, g, agg, out, B / heads, heads, range);

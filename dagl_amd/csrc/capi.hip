@@ -459,6 +459,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if (dbg_deg || dbg_rowsum)
             if ((r = launch_row_stats(s, BL, ag2.nb_wgt, ag2.nb_cnt, ag2.row_off, ag2.width, dbg_deg, dbg_rowsum))) return r;
         prof_mark(prof, s, 6);
+        // short fixed-width lists and nobody asking for the aggregated rows: gather, weighted sum and fold in one kernel
+        if (mode != DAGL_MODE_ADAPTIVE && ag2.row_off == nullptr && !ovf_active && !dbg_agg && !core) {
+            prof_mark(prof, s, 7);
+            if ((r = launch_aggregate_fold(s, ag2, out, heads, rt))) return r;
+            prof_mark(prof, s, 8);
+            return DAGL_OK;
+        }
         if ((r = launch_aggregate_direct(s, ag2))) return r;
         if (ovf_active) {
             // the few queries whose neighbourhood overflowed the lists are redone one by one (dense rows); their aggregated

@@ -252,6 +252,7 @@ struct AggArgs {
     float* agg;                     // [B,L,784] (kh,kw,c)
 };
 int launch_aggregate_direct(hipStream_t s, const AggArgs& a);
+int launch_aggregate_fold(hipStream_t s, const AggArgs& a, float* out, int heads, RangeTag range);   // both at once (fixed-width lists)
 int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const int32_t* nb_cnt, const int64_t* row_off,
                      int width, int32_t* deg, float* rowsum);
 

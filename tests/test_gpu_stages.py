@@ -183,3 +183,20 @@ def test_stage_profile_can_bracket_a_single_stage():
         ce(x)
         full = prof.read()
         assert len(full) == 1 and sum(v > 0 for v in full[0]) >= 6
+
+
+@pytest.mark.parametrize("B,H,W,k", [(1, 64, 64, 8), (2, 45, 38, 4), (1, 130, 97, 16), (1, 7, 9, 3)])
+def test_fused_gather_fold_is_bit_identical_to_the_two_kernels(B, H, W, k):
+    """Top-k calls gather, weight and fold in one kernel (aggregate_fold_kernel); the debug entry point (which hands out the
+    aggregated rows) runs aggregate_direct_kernel + fold_kernel.  Same fma chains, same summation order: same bits."""
+    from dagl_amd import ops
+    DEV = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + H + W + k)
+    b1 = torch.randn(B, 16, H, W, generator=g).to(DEV)
+    b2 = torch.randn(B, 16, H, W, generator=g).to(DEV)
+    fc1_w = (torch.randn(196, 784, generator=g) * 0.05).to(DEV); fc1_b = (torch.randn(196, generator=g) * 0.1).to(DEV)
+    fc2_w = (torch.randn(196, 784, generator=g) * 0.05).to(DEV); fc2_b = (torch.randn(196, generator=g) * 0.1).to(DEV)
+    out_fused = ops.ce_forward(b1, b2, None, None, fc1_w, fc1_b, fc2_w, fc2_b, mode="topk", k=k)
+    out_two, meta = ops.ce_forward(b1, b2, None, None, fc1_w, fc1_b, fc2_w, fc2_b, mode="topk", k=k, debug=True)
+    assert torch.equal(out_fused, out_two)
+    assert torch.isfinite(out_fused).all()
