@@ -459,7 +459,9 @@ def main():
         if gather is not None and mean_ms[6] > 0:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
             fb = B * L * ((kk + 1) * 4 * P_ROW + 8 * kk)
-            gather["fused_in_block"] = {"kernel": "aggregate_direct_kernel", "ms_per_launch": float(mean_ms[6]),
+            gather["fused_in_block"] = {"kernel": "aggregate_fold_kernel (top-k: gather + weighted sum + fold in one kernel; value patches "
+                                                  "read from the 4 MB map, so this is a cache number)" if mode != "adaptive"
+                                                  else "aggregate_direct_kernel", "ms_per_launch": float(mean_ms[6]),
                                         "achieved": fb / (mean_ms[6] * 1e-3) / 1e9, "unit": "GB/s",
                                         "frac": fb / (mean_ms[6] * 1e-3) / 1e9 / PEAK_HBM_GBS}
         total_patches = world * heads_per_step * B * L * args.steps

@@ -461,8 +461,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         prof_mark(prof, s, 6);
         // short fixed-width lists and nobody asking for the aggregated rows: gather, weighted sum and fold in one kernel
         if (mode != DAGL_MODE_ADAPTIVE && ag2.row_off == nullptr && !ovf_active && !dbg_agg && !core) {
-            prof_mark(prof, s, 7);
             if ((r = launch_aggregate_fold(s, ag2, out, heads, rt))) return r;
+            prof_mark(prof, s, 7);                              // (the whole tail is booked on the gather stage)
             prof_mark(prof, s, 8);
             return DAGL_OK;
         }

@@ -387,3 +387,26 @@ def test_packed_weight_cache_is_invalidated_by_inplace_updates():
         b2 = fresh(xd)
     assert not torch.equal(a1, b1)
     assert torch.equal(b1, b2)
+
+
+def test_packed_conv_weights_follow_inplace_updates():
+    """g / theta weights are packed once per weight set as well (the prologue's LDS image): an in-place update must be seen."""
+    path = [p for p in CASES if "topk4_64x64" in p][0]
+    meta, g = load_golden(path)
+    x, params = case_inputs(meta)
+    xd = x.to(_dev())
+    ce = _module(params, "topk", 4)
+    with torch.no_grad():
+        a1 = ce(xd).clone()
+        assert torch.equal(a1, ce(xd))
+        ce.g.weight.mul_(0.75)
+        ce.theta.weight.add_(0.02)
+        b1 = ce(xd).clone()
+    params2 = {n: t.clone() for n, t in params.items()}
+    params2["g.weight"] = params2["g.weight"] * 0.75
+    params2["theta.weight"] = params2["theta.weight"] + 0.02
+    fresh = _module(params2, "topk", 4)
+    with torch.no_grad():
+        b2 = fresh(xd)
+    assert not torch.equal(a1, b1)
+    assert torch.equal(b1, b2)

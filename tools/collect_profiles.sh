@@ -17,6 +17,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCL
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $OUT/sq2 -o k -- $CMD > $OUT/sq2.log 2>&1
 # the dense regime (shipped semantics at default init) and the mean-degree-8 regime: kernel stats only
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense -o k -- python $GRAFT_REPO_ROOT/bench.py --mode adaptive --variant default --steps 10 --warmup 3 --no-cpu-baseline --no-quality --no-extra > $OUT/dense.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/md8 -o k -- python $GRAFT_REPO_ROOT/bench.py --mode adaptive --variant sparse --sparse-gain 1.95 --wseed 41 --fseed 41 --steps 20 --warmup 5 --no-cpu-baseline --no-quality --no-extra > $OUT/md8.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 4 --warmup 2 > $OUT/train.log 2>&1
 python $GRAFT_REPO_ROOT/tools/summarize_profiles.py $OUT $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary $TAG
 ls $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary

@@ -37,7 +37,7 @@ def counters(d):
 
 def short(name):
     for key in ("screen_kernel<1", "screen_kernel<0", "project16_kernel", "refine_kernel", "conv_pair16_kernel", "gather_rows_kernel",
-                "aggregate_direct_kernel", "fold_kernel", "screen_theta_kernel", "dense_attend_kernel", "gemm32_kernel",
+                "aggregate_direct_kernel", "aggregate_fold_kernel", "fold_kernel", "ovf_attend_kernel", "ovf_scores_small_kernel", "screen_theta_kernel", "dense_attend_kernel", "gemm32_kernel",
                 "score_select_kernel", "edge_softmax_topk_kernel", "thr_bias_kernel"):
         if key in name:
             return key + (">" if key.endswith(("<1", "<0")) else "")
@@ -47,7 +47,7 @@ def short(name):
 def main():
     src, dst, tag = sys.argv[1:4]
     os.makedirs(dst, exist_ok=True)
-    for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("train", "train")):
+    for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("md8", "adaptive_mean_degree_8_256"), ("train", "train")):
         f = find(os.path.join(src, sub), "*kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
