@@ -228,17 +228,20 @@ __global__ __launch_bounds__(256) void aggregate_direct_kernel(AggArgs a) {
     const int W = a.g.W, Wp = a.g.Wp;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int j = 0;
-    for (; j + 4 <= n; j += 4) {
-        int id[4]; float w[4]; float4 v[4];
+    // (variable-length lists only -- the top-k modes take aggregate_fold_kernel: a long list is a chain of gathers, so eight
+    // neighbours are in flight at a time; the fma order stays the list order)
+    constexpr int AU = 8;
+    for (; j + AU <= n; j += AU) {
+        int id[AU]; float w[AU]; float4 v[AU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { id[u] = ip[j + u]; w[u] = wp[j + u]; }
+        for (int u = 0; u < AU; ++u) { id[u] = ip[j + u]; w[u] = wp[j + u]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AU; ++u) {
             const int jy = id[u] / W, jx = id[u] - jy * W;
             v[u] = vm[((size_t)(jy + kh) * Wp + jx) * (CH / 4)];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AU; ++u) {
             acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
             acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
         }
