@@ -17,18 +17,35 @@
 
 namespace dagl {
 
-constexpr int G_BM = 128, G_BN = 128, G_BK = 16, G_PAD = 4;
+constexpr int G_BM = 128, G_BN = 128, G_BK = 16, G_PAD = 4;     // (k-tiles of 32 measured slower: 824 vs 657 us on the fc2 forward --
+                                                                   // the LDS then holds two blocks per CU instead of four)
+constexpr int G_KT = G_BK / 4;                                     // threads along k of a K-contiguous operand tile
+constexpr int G_VEC = G_BK / 8;                                    // float4 per thread and operand tile
 
-// one operand tile: 128 (rows = M or N index) x 16 (k) floats -> two float4 per thread
+// one operand tile: 128 (rows = M or N index) x G_BK (k) floats -> G_VEC float4 per thread
 template <bool KC>
 struct TileLoader {
     const float* base; long long ld; int rows, K, row0; bool vec;
-    float4 v[2];
+    float4 v[G_VEC];
     __device__ __forceinline__ void load(int k0, int tid) {
+        // Interior k range (block-uniform) and whole vectors: unconditional loads from clamped addresses, zeroed afterwards --
+        // a predicated load makes the compiler wait for each one before it issues the next, and four exposed memory round
+        // trips per tile are what this kernel used to cost (27 TFLOP/s on the fc2 weight gradient).
+        const bool interior = vec && (k0 + G_BK <= K);
         if (KC) {                                   // element (r, k) at base[r * ld + k]: vectors along k
+            if (interior) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = row0 + (tid >> 2) + 64 * u, k = k0 + 4 * (tid & 3);
+                for (int u = 0; u < G_VEC; ++u) {
+                    const int r = row0 + tid / G_KT + (256 / G_KT) * u, k = k0 + 4 * (tid % G_KT);
+                    const int rc = r < rows ? r : rows - 1;
+                    const float4 t = *reinterpret_cast<const float4*>(base + (long long)rc * ld + k);
+                    v[u] = (r < rows) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < G_VEC; ++u) {
+                const int r = row0 + tid / G_KT + (256 / G_KT) * u, k = k0 + 4 * (tid % G_KT);
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < rows) {
                     const float* p = base + (long long)r * ld + k;
@@ -43,8 +60,18 @@ struct TileLoader {
                 v[u] = t;
             }
         } else {                                    // element (r, k) at base[k * ld + r]: vectors along r
+            if (interior && (rows & 3) == 0 && rows >= 4) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < G_VEC; ++u) {
+                    const int k = k0 + (tid >> 5) + 8 * u, r = row0 + 4 * (tid & 31);
+                    const int rc = r < rows ? r : rows - 4;
+                    const float4 t = *reinterpret_cast<const float4*>(base + (long long)k * ld + rc);
+                    v[u] = (r < rows) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < G_VEC; ++u) {
                 const int k = k0 + (tid >> 5) + 8 * u, r = row0 + 4 * (tid & 31);
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < K) {
@@ -64,13 +91,13 @@ struct TileLoader {
     __device__ __forceinline__ void store(float (*s)[G_BM + G_PAD], int tid) const {
         if (KC) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = (tid >> 2) + 64 * u, k = 4 * (tid & 3);
+            for (int u = 0; u < G_VEC; ++u) {
+                const int r = tid / G_KT + (256 / G_KT) * u, k = 4 * (tid % G_KT);
                 s[k][r] = v[u].x; s[k + 1][r] = v[u].y; s[k + 2][r] = v[u].z; s[k + 3][r] = v[u].w;
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < G_VEC; ++u) {
                 const int k = (tid >> 5) + 8 * u, r = 4 * (tid & 31);
                 *reinterpret_cast<float4*>(&s[k][r]) = v[u];
             }
@@ -127,23 +154,26 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
         const int cur = t & 1;
         if (t + 1 < nt) { la.load((t + 1) * G_BK, tid); lb.load((t + 1) * G_BK, tid); }
 #pragma unroll
-        for (int kk = 0; kk < G_BK; kk += 2) {
-            const float a0 = As[cur][kk + h][wm * 64 + i], a1 = As[cur][kk + h][wm * 64 + 32 + i];
-            const float b0 = Bs[cur][kk + h][wn * 64 + i], b1 = Bs[cur][kk + h][wn * 64 + 32 + i];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (g.chunk_tiles > 0 && (t + 1) % g.chunk_tiles == 0) {
-            // chunked accumulation: a chain of chunk_tiles * 16 products per partial sum instead of K (the partial sums are
-            // added in fp32): the rounding error of a long fmaf chain grows with its length
+        for (int half = 0; half < G_BK / 16; ++half) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int kk = 16 * half; kk < 16 * half + 16; kk += 2) {
+                const float a0 = As[cur][kk + h][wm * 64 + i], a1 = As[cur][kk + h][wm * 64 + 32 + i];
+                const float b0 = Bs[cur][kk + h][wn * 64 + i], b1 = Bs[cur][kk + h][wn * 64 + 32 + i];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (g.chunk_tiles > 0 && (t * (G_BK / 16) + half + 1) % g.chunk_tiles == 0) {
+                // chunked accumulation: a chain of chunk_tiles * 16 products per partial sum instead of K (the partial sums
+                // are added in fp32): the rounding error of a long fmaf chain grows with its length
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { sum[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { sum[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+            }
         }
         if (t + 1 < nt) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
         __syncthreads();
