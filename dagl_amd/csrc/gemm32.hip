@@ -105,7 +105,8 @@ struct TileLoader {
     }
 };
 
-template <bool AKC, bool BKC>
+// CHUNK: chunked accumulation compiled in (a second set of 64 accumulator registers; without it a third block fits a CU)
+template <bool AKC, bool BKC, bool CHUNK>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][G_BK][G_BM + G_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][G_BK][G_BN + G_PAD];
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
         la.K = lb.K = k_eff < g.K ? k_eff : g.K;
     }
     const int K = la.K;
-    f32x16 sum[2][2];
-    if (g.chunk_tiles > 0) {
+    f32x16 sum[CHUNK ? 2 : 1][CHUNK ? 2 : 1];
+    if (CHUNK) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
-            if (g.chunk_tiles > 0 && (t * (G_BK / 16) + half + 1) % g.chunk_tiles == 0) {
+            if (CHUNK && (t * (G_BK / 16) + half + 1) % g.chunk_tiles == 0) {
                 // chunked accumulation: a chain of chunk_tiles * 16 products per partial sum instead of K (the partial sums
                 // are added in fp32): the rounding error of a long fmaf chain grows with its length
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vec
         if (t + 1 < nt) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
         __syncthreads();
     }
-    if (g.chunk_tiles > 0) {
+    if (CHUNK) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -254,10 +255,13 @@ int launch_gemm32(hipStream_t s, const Gemm32& g_in) {
     const int vecA = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0) && (g.sA % 4 == 0);
     const int vecB = ((uintptr_t)g.B % 16 == 0) && (g.ldb % 4 == 0) && (g.sB % 4 == 0);
     const dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.batch), block(256);
-    if (g.a_kc && g.b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, block, 0, s, g, vecA, vecB);
-    else if (g.a_kc && !g.b_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, block, 0, s, g, vecA, vecB);
-    else if (!g.a_kc && g.b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, block, 0, s, g, vecA, vecB);
-    else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, block, 0, s, g, vecA, vecB);
+#define G32_LAUNCH(A_, B_) do { if (g.chunk_tiles > 0) hipLaunchKernelGGL((gemm32_kernel<A_, B_, true>), grid, block, 0, s, g, vecA, vecB); \
+                                else hipLaunchKernelGGL((gemm32_kernel<A_, B_, false>), grid, block, 0, s, g, vecA, vecB); } while (0)
+    if (g.a_kc && g.b_kc) G32_LAUNCH(true, true);
+    else if (g.a_kc && !g.b_kc) G32_LAUNCH(true, false);
+    else if (!g.a_kc && g.b_kc) G32_LAUNCH(false, true);
+    else G32_LAUNCH(false, false);
+#undef G32_LAUNCH
     DAGL_LAUNCH_CHECK("gemm32_kernel");
     if (slices > 1) {
         const size_t n = (size_t)g.M * g.N;

@@ -97,7 +97,9 @@ class _PatchLinear(torch.autograd.Function):
                                           rows.data_ptr()), "dagl_unfold_patches")
             d_w = d_b = d_map = None
             if ctx.needs_input_grad[1]:
-                d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False, chunk_tiles=8)   # [O,n] x [n,K], split-K
+                # [O,n] x [n,K]: split-K keeps the fma chains at a few thousand products, no chunked accumulation needed
+                # (its second accumulator set costs a third of the kernel's occupancy)
+                d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
             if ctx.needs_input_grad[2]:
                 d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
                 scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
