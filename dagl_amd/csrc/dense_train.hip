@@ -236,12 +236,15 @@ __global__ __launch_bounds__(256) void dt_fold_dv_kernel(Grid g, int nb, const f
 }
 
 static Gemm32 dt_gemm(int M, int N, int K, int batch, const float* A, long long lda, long long sA, int a_kc, const float* Bm,
-                      long long ldb, long long sB, int b_kc, float* C, long long ldc, long long sC, float beta) {
+                      long long ldb, long long sB, int b_kc, float* C, long long ldc, long long sC, float beta, bool grad = false) {
     Gemm32 g;
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.A = A; g.lda = lda; g.sA = sA; g.a_kc = a_kc;
     g.B = Bm; g.ldb = ldb; g.sB = sB; g.b_kc = b_kc; g.C = C; g.ldc = ldc; g.sC = sC;
     g.alpha = 1.0f; g.beta = beta; g.bias = nullptr; g.relu = 0;
-    g.chunk_tiles = (K == D) ? 3 : 8;                 // S: chains of 48 products; the long contractions: 128
+    // S: chains of 48 products; the long forward contraction A V: 128.  Gradient products (1e-3 bar, contractions of at
+    // most a few thousand terms per chunk of queries / 16 384 keys) run unchunked: 140 instead of 236 registers, a third
+    // block per CU.
+    g.chunk_tiles = grad ? 0 : ((K == D) ? 3 : 8);
     return g;
 }
 
@@ -324,7 +327,7 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
             const float beta = (l0 == 0) ? 0.f : 1.f;
             // d A = d agg V^T ; S = Wq X^T
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, P, nb, dagg_c, P, (long long)g.L * P, 1, vrows, P, (long long)g.N * P, 1,
-                                               abuf, p.ldn, sS, 0.f)))) return rc;
+                                               abuf, p.ldn, sS, 0.f, true)))) return rc;
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_c, D, (long long)g.L * D, 1,
                                                x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1, sbuf, p.ldn, sS, 0.f)))) return rc;
             hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias,
@@ -332,13 +335,13 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
             DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
             // d Wq = d S X
             if ((rc = launch_gemm32(s, dt_gemm(lc, D, g.N, nb, sbuf, p.ldn, sS, 1, x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 0,
-                                               dwq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 0.f)))) return rc;
+                                               dwq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 0.f, true)))) return rc;
             // d X (+)= d S^T Wq
             if ((rc = launch_gemm32(s, dt_gemm(g.N, D, lc, nb, sbuf, p.ldn, sS, 0, wq_c, D, (long long)g.L * D, 0,
-                                               dx_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, beta)))) return rc;
+                                               dx_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, beta, true)))) return rc;
             // d V (+)= A^T d agg
             if ((rc = launch_gemm32(s, dt_gemm(g.N, P, lc, nb, abuf, p.ldn, sS, 0, dagg_c, P, (long long)g.L * P, 0,
-                                               dvrows, P, (long long)g.N * P, beta)))) return rc;
+                                               dvrows, P, (long long)g.N * P, beta, true)))) return rc;
         }
         {
             const size_t n = (size_t)nb * g.N;
