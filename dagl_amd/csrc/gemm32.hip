@@ -107,7 +107,7 @@ struct TileLoader {
 
 // CHUNK: chunked accumulation compiled in (a second set of 64 accumulator registers; without it a third block fits a CU)
 template <bool AKC, bool BKC, bool CHUNK>
-__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
+__global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][G_BK][G_BM + G_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][G_BK][G_BN + G_PAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
