@@ -375,6 +375,7 @@ struct Gemm32 {
     int slices = 1; float* scratch = nullptr;         // split-K (batch == 1): slices * M * N floats of scratch, fixed-order sum
     int k_total = 0;                                  // (set by launch_gemm32)
     const int32_t* m_limit = nullptr;                 // optional device word: only rows < *m_limit are computed
+    int variant = 0;                                  // ablation builds (DAGL_GEMM_VARIANT): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
 };
 int launch_gemm32(hipStream_t s, const Gemm32& g);
 int gemm32_auto_slices(int M, int N, int K);

@@ -13,6 +13,8 @@
 // TN without copies.  Products with few output tiles and a long K (the weight gradients: 196 x 784 outputs over 131072
 // patch rows) are cut into K slices that write their own partial C, summed in slice order by gemm32_reduce_kernel:
 // no atomics anywhere, deterministic.  Optional chunked accumulation keeps the fmaf chains short.
+#include <stdlib.h>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -153,7 +155,11 @@ __global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, in
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
+#ifdef DAGL_ABLATION
+        if (t + 1 < nt && !(g.variant & 1)) { la.load((t + 1) * G_BK, tid); lb.load((t + 1) * G_BK, tid); }
+#else
         if (t + 1 < nt) { la.load((t + 1) * G_BK, tid); lb.load((t + 1) * G_BK, tid); }
+#endif
 #pragma unroll
         for (int half = 0; half < G_BK / 16; ++half) {
 #pragma unroll
@@ -176,8 +182,13 @@ __global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, in
                         for (int r = 0; r < 16; ++r) { sum[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
             }
         }
+#ifdef DAGL_ABLATION
+        if (t + 1 < nt && !(g.variant & 2)) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
+        if (!(g.variant & 4)) __syncthreads();
+#else
         if (t + 1 < nt) { la.store(As[cur ^ 1], tid); lb.store(Bs[cur ^ 1], tid); }
         __syncthreads();
+#endif
     }
     if (CHUNK) {
 #pragma unroll
@@ -238,6 +249,9 @@ int gemm32_auto_slices(int M, int N, int K) {
 
 int launch_gemm32(hipStream_t s, const Gemm32& g_in) {
     Gemm32 g = g_in;
+#ifdef DAGL_ABLATION
+    { static const int var = getenv("DAGL_GEMM_VARIANT") ? atoi(getenv("DAGL_GEMM_VARIANT")) : 0; g.variant = var; }
+#endif
     if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return DAGL_OK;
     if (g.K <= 0 || !g.A || !g.B || !g.C) { set_error("gemm32: bad argument"); return DAGL_ERR_INVALID; }
     const float alpha = g.alpha, beta = g.beta; const float* bias = g.bias; const int relu = g.relu;
