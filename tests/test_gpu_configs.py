@@ -255,3 +255,25 @@ def test_config5_rccl_process_group_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--size", "64",
                         "--no-quality", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode,k,variant,gain", [("topk", 8, "default", 2.0), ("adaptive_topk", 16, "sparse", 1.7),
+                                                 ("adaptive", 0, "sparse", 1.95)])
+def test_config2_batches_equal_their_images_at_256x256(mode, k, variant, gain):
+    """Samples are independent (dagl.py:245): a batch of three 256x256 images through one call -- the batch is a grid dimension
+    of every kernel, the screen then runs 512-query blocks with fewer key chunks per image -- must give, image by image, what
+    three calls give.  Not bit for bit: the projection cuts the overhang of its grid into single-tile blocks whose three
+    split products meet in a different order, and WHICH patches those are depends on the batch size (and the CU count), so the
+    features' last bits do; the softmax turns that into a few 1e-6 of the output.  The same call repeated is bit-identical."""
+    from dagl_amd.synth import make_features
+    ce = _module(_params(41, variant, gain), mode, k)
+    x = torch.from_numpy(np.concatenate([make_features(41 + i, 1, 64, 256, 256) for i in range(3)], axis=0)).to(_dev())
+    with torch.no_grad():
+        whole = ce(x).clone()
+        again = ce(x).clone()
+        singles = [ce(x[i:i + 1]).clone() for i in range(3)]
+    assert torch.isfinite(whole).all()
+    assert torch.equal(whole, again)
+    for i in range(3):
+        e = normwise(whole[i:i + 1].cpu().numpy(), singles[i].cpu().numpy())
+        assert e <= 2e-5, f"image {i} differs inside the batch: {e:.2e}"
