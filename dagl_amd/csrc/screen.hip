@@ -43,10 +43,13 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
 //         (theta carries the whole conservative test of either mode; +inf for padding queries).
 // Keys past N are zero rows (S~ = 0): they can only pass a degenerate theta <= 0 and are dropped by refine.
 //
-// QW = query tiles (of 32) per wave.  A block always covers SCR_QUERIES = 256 queries (8/QW waves).  Every key
-// fragment read from LDS (one ds_read_b128 per lane) feeds QW MFMAs: with QW = 1 the LDS port (128 B/clk/CU) is busy
-// exactly as long as the matrix cores (26 KiB per wave-step vs 26 x 32 clk of MFMA, two waves per SIMD), which caps
-// the kernel near 50 %; QW = 2 halves the LDS bytes per flop (query fragments: 2 x 52 VGPRs, accumulators 4 x 16).
+// A block covers SCR_QUERIES queries (512: 16 waves, one block per CU, four key tiles in flight; 256: 8 waves, two blocks
+// per CU, two tiles), a wave QW query tiles of 32 (QW = 1 in the release build; QW = 2 -- half the LDS reads per MFMA at
+// half the occupancy -- measures the same and is kept for the ablation build).  Every key fragment is one ds_read_b128 per
+// lane; LDS (256 B/clk for b128 reads, conflict-free by the odd row stride) is ~25 % busy, the matrix pipes 50-54 %:
+// DESIGN.md section 7 lists what was tried to close that gap.
+// VAR (ablation builds only, results wrong by construction): 1 no tile DMA, 2 no MFMA, 4 no test, 8 theta = inf, 16 key
+// fragments from registers, 32 no barrier, 64 accumulators carried across steps.
 template <int PASS, int QW, int VAR, int SCR_QUERIES = 256>
 __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1) void screen_kernel(ScreenArgs a, int n_qgroups) {
     constexpr int WAVES = SCR_QUERIES / 32 / QW;
