@@ -3,17 +3,16 @@
 // in the dense formulation of the reference (DN_Gray/model/dagl.py:250-264) instead of sending the whole call to the
 // fp32 scan: an adaptive mask with a mean degree of ~8 has maxima of several hundred (measured at 256^2: mean 7.7,
 // maximum 890, 10 of 4096 queries beyond 256), and those 10 rows are 10 x N scores, not L x N.
-//   A  gather + gemm32     scores of every flagged query against ALL keys as ONE matrix product [flagged, 196] x [196, N] on
-//                          the fp32 matrix cores (every key row is read once for all flagged queries, not once per query; the
-//                          row count lives in device memory: blocks past it exit)
+//   A  gather + scores     scores of every flagged query against ALL keys: a VALU kernel for up to OVF_SMALL flagged queries,
+//                          beyond that ONE matrix product [flagged, 196] x [196, N] on the fp32 matrix cores; either way every
+//                          key row is read once for all flagged queries (the row count lives in device memory: blocks past
+//                          it exit)
 //   B  stats / attend / combine (below): mask, softmax over all N keys (masked keys count e^0), weighted sum of the value
 //                          patches straight from the value map; overwrites the query's aggregated row
 // All kernels read the number of flagged queries from device memory and exit at once when it is zero.
 #include "dagl_common.h"
 
 namespace dagl {
-
-constexpr int OVF_KEYS = 256;                    // keys per block of kernel A
 
 __device__ __forceinline__ float ovf_logit(float s, float mtq, float bsq, bool& pass) {
     const float m = (s - mtq) + bsq;                                      // dagl.py:256, same expression order
