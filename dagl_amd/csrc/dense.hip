@@ -3,11 +3,14 @@
 // reference's dense formulation, streamed -- S = Wq X^T, mask, softmax over ALL keys, A V -- in one pass over the keys,
 // nothing of size L x N ever stored.
 //
-//   one wave = 32 queries x half of the 784 output columns (13 / 12 column tiles of 32 = two patch taps x 16 channels)
+//   block = 64 queries = 2 query tiles x 4 waves; a wave = 32 queries x a share of the 784 output columns (6 / 6 / 7 / 6 column
+//   tiles of 32 = two patch taps x 16 channels; the first two waves of a query tile also form the scores).  Eight waves: two
+//   per SIMD, so that one wave's operand assembly and softmax arithmetic run under the other's matrix instructions (with four
+//   waves -- 13 / 12 tiles each, 208 accumulator registers -- every SIMD had ONE wave and nothing overlapped: 3.96 ms at 256^2)
 //   per 32-key tile (keys = an 8 x 4 pixel block of the map):
 //     S      v_mfma_f32_32x32x16_f16 on split features (64 x = hi + lo, made once per call by feat_split_kernel; three
-//            products per 16 features as in the projection), keys x queries, the 13 K-blocks split between the two waves of
-//            a query tile and exchanged through LDS.  The key rows enter the MFMA in a permuted order so that a lane ends
+//            products per 16 features as in the projection), keys x queries, the 13 K-blocks split between the first two waves
+//            of a query tile and handed to all four through LDS.  The key rows enter the MFMA in a permuted order so that a lane ends
 //            up with scores of 16 keys of ONE query that are two runs of 8 CONSECUTIVE keys -- exactly the K-layout of
 //            the next MFMA's operand;
 //     l, p   the reference's fp32 expression order for m and l = (S m) 10; masked keys keep l = 0 and count in the
@@ -43,7 +46,9 @@ constexpr int DN_CSTR = DN_RH * DN_XW + 2;            // halfs per channel plane
                                                       // of a column tile hit different banks)
 constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
-constexpr int DN_CT0 = 13;                            // tiles of column half 0 (half 1: 12)
+constexpr int DN_CTMAX = 7;                           // column tiles per wave: shares 6 / 6 / 7 / 6 (the first two waves also form S)
+__host__ __device__ constexpr int dn_ct_start(int part) { return part == 0 ? 0 : part == 1 ? 6 : part == 2 ? 12 : 19; }
+__host__ __device__ constexpr int dn_ct_count(int part) { return part == 0 ? 6 : part == 1 ? 6 : part == 2 ? 7 : 6; }
 constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
@@ -56,13 +61,14 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
 // those lanes of tile 24 recompute tap 48 and their columns are never stored).
 // A operand of kblock kb: halfs e = 0..7 = V[key 16 kb + 8 h + e][tap][c]; key = pixel (row 2 kb + h, column e) of the tile,
 // so the value is plane[c][2 kb + h + kh][kw + e]
-template <int HALF>
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char* planes, int c, int h, bool second,
-                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2]) {
+// One code path for all four column shares (ct0, cnt are wave-uniform): a four-way dispatch on the share made the register
+// allocator keep all four instantiations' fragments alive (128 spills at 256 registers).
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CTMAX], const unsigned char* planes, int c, int h, bool second,
+                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], int ct0, int cnt) {
 #pragma unroll
-    for (int t = 0; t < DN_CT0; ++t) {
-        const int ct = HALF * DN_CT0 + t;                                    // compile-time after unrolling
-        if (ct >= DN_CT) continue;
+    for (int t = 0; t < DN_CTMAX; ++t) {
+        if (t >= cnt) continue;                                              // wave-uniform
+        const int ct = ct0 + t;
         const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
         const int kh = second ? tapb / KS : tapa / KS, kw = second ? tapb % KS : tapa % KS;
         // byte offset of (c, row h + kh, pixel kw) inside a part; dword-aligned base + byte shift 0 / 2
@@ -90,16 +96,14 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CT0], const unsigned char
     }
 }
 
-template <int HALF>
-__device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po, int h) {
+__device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CTMAX], float* po, int h, int ct0, int cnt) {
     constexpr float inv = 1.0f / (DN_PS * DN_VS);
 #pragma unroll
-    for (int t = 0; t < DN_CT0; ++t) {
-        const int ct = HALF * DN_CT0 + t;
-        if (ct >= DN_CT) continue;
+    for (int t = 0; t < DN_CTMAX; ++t) {
+        if (t >= cnt) continue;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const int col = 32 * ct + 8 * gq + 4 * h;                        // acc[t][4 gq + u] = out[q][col + u]
+            const int col = 32 * (ct0 + t) + 8 * gq + 4 * h;                 // acc[t][4 gq + u] = out[q][col + u]
             if (col < P)
                 *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
                                                                    acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv);
@@ -107,7 +111,8 @@ __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CT0], float* po,
     }
 }
 
-__global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
+constexpr int DN_THREADS = 512;
+__global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sm[2][DN_XT];           // 56 KiB: key-feature tiles hi | lo (LDS-DMA)
     __shared__ __attribute__((aligned(16))) unsigned short spl[2 * DN_PLANE_H + 64]; // 21 KiB: value planes hi | lo of ONE tile
     __shared__ __attribute__((aligned(16))) unsigned short sq[2][64 * DSH];        // 54 KiB: the block's 64 query rows hi | lo
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const Grid& g = a.g;
     const int n_qblocks = (g.L + 63) / 64;
     const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
-    const int qt = wave >> 1, half = wave & 1;
+    const int qt = wave >> 2, part = wave & 3;
+    const int ct0 = dn_ct_start(part), ctn = dn_ct_count(part);                  // this wave's column tiles (wave-uniform)
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
@@ -131,16 +137,16 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const size_t qlin = (size_t)b * g.L + qc;
 
     // the 64 query rows (split fp16, 432-byte rows: whole 16-byte pieces; rows past L are zero guard rows) -> LDS
-    for (int part = 0; part < 2; ++part) {
-        const uint4* src = reinterpret_cast<const uint4*>((part ? a.wq_lo : a.wq_hi) + ((size_t)b * a.rows_qh + (size_t)qb * 64) * DSH);
-        for (int e = tid; e < 64 * DSH / 8; e += 256) reinterpret_cast<uint4*>(&sq[part][0])[e] = src[e];
+    for (int pt = 0; pt < 2; ++pt) {
+        const uint4* src = reinterpret_cast<const uint4*>((pt ? a.wq_lo : a.wq_hi) + ((size_t)b * a.rows_qh + (size_t)qb * 64) * DSH);
+        for (int e = tid; e < 64 * DSH / 8; e += DN_THREADS) reinterpret_cast<uint4*>(&sq[pt][0])[e] = src[e];
     }
     const unsigned short* qrow = &sq[0][(qt * 32 + i) * DSH + 8 * h];       // B operand of the score MFMAs: Wq[q][16 kb + 8 h ..]
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
 
-    f32x16 acc[DN_CT0];
+    f32x16 acc[DN_CTMAX];
 #pragma unroll
-    for (int t = 0; t < DN_CT0; ++t)
+    for (int t = 0; t < DN_CTMAX; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
@@ -158,25 +164,25 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
     auto stage_x = [&](int tile, int buf) {            // key features hi | lo: per part 4 pixel rows x 8 keys x 432 B by LDS-DMA
         const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
-        for (int p = wave; p < 32; p += 4) {                                 // (part, row dy, piece): 3456 B = 3 x 1 KiB + 384 B
-            const int part = p >> 4, dy = (p >> 2) & 3, pc = p & 3;
+        for (int p = wave; p < 32; p += DN_THREADS / 64) {                   // (part, row dy, piece): 3456 B = 3 x 1 KiB + 384 B
+            const int xpart = p >> 4, dy = (p >> 2) & 3, pc = p & 3;
             int jy = jy0 + dy; if (jy > g.H - 1) jy = g.H - 1;               // ragged bottom: a valid row, keys masked below
-            const unsigned short* xs = (part ? a.x_lo : a.x_hi) + ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
+            const unsigned short* xs = (xpart ? a.x_lo : a.x_hi) + ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
             if (pc < 3 || lane < 24)
                 glds16_asm(reinterpret_cast<const float*>(xs + pc * 512 + lane * 8),
-                           __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + part * DN_XPART + dy * 8 * DSH) * 2 + pc * 1024)));
+                           __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + xpart * DN_XPART + dy * 8 * DSH) * 2 + pc * 1024)));
         }
     };
     // value-map region of a tile: 10 rows x 14 pixels x 16 channels fp32 NHWC -> registers -> planar fp16 hi | lo in LDS.
     // Work item = (region row, pixel PAIR, channel quad): two float4 loads, then per channel the two pixels' halfs go out
     // as one 4-byte store.  The index arithmetic does not depend on the tile and is done once.
     constexpr int DN_ITEMS = DN_RH * (DN_RW / 2) * 4;                        // 280
-    constexpr int DN_NIT = (DN_ITEMS + 255) / 256;                           // 2 per thread
+    constexpr int DN_NIT = (DN_ITEMS + DN_THREADS - 1) / DN_THREADS;         // 1 per thread
     float4 rv[DN_NIT][2];
     int it_row[DN_NIT], it_px[DN_NIT], it_c4[DN_NIT], it_lds[DN_NIT];
 #pragma unroll
     for (int j = 0; j < DN_NIT; ++j) {
-        int idx = tid + 256 * j;
+        int idx = tid + DN_THREADS * j;
         const bool on = idx < DN_ITEMS;
         if (!on) idx = DN_ITEMS - 1;
         const int row = idx / (DN_RW / 2 * 4), rem = idx - row * (DN_RW / 2 * 4);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     const int prow = (i & 0x13) | ((i & 8) >> 1) | ((i & 4) << 1);
 
     if (tile0 < tile1) { stage_x(tile0, 0); load_region(tile0); }
-    for (int e = tid; e < (2 * DN_PLANE_H + 64) / 2; e += 256) reinterpret_cast<unsigned*>(spl)[e] = 0u;   // pad pixels stay zero
+    for (int e = tid; e < (2 * DN_PLANE_H + 64) / 2; e += DN_THREADS) reinterpret_cast<unsigned*>(spl)[e] = 0u;   // pad pixels stay zero
     __syncthreads();
     if (tile0 < tile1) store_region();
     dma_wait_all();
@@ -233,16 +239,16 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
 
         // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
-        // the two waves of a query tile (column halves) split the 13 K-blocks of the 196-term sum, exchange the partial
-        // sums through LDS and add them in the same order (identical scores in both waves, no redundant matrix work)
+        // the first two waves of a query tile split the 13 K-blocks of the 196-term sum and publish their partial sums; all four
+        // waves add them in the same order (identical scores in every wave, no redundant matrix work)
         f32x16 mine, cross;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { mine[r] = 0.f; cross[r] = 0.f; }
         const unsigned short* kp = &sm[cur][prow * DSH + 8 * h];
-        if (!(a.variant & 2)) {
+        if (!(a.variant & 2) && part < 2) {
 #pragma unroll
             for (int kb = 0; kb < DN_KB; ++kb) {
-                if ((kb < 7) != (half == 0)) continue;                       // wave-uniform: K blocks 0-6 / 7-12
+                if ((kb < 7) != (part == 0)) continue;                       // wave-uniform: K blocks 0-6 / 7-12
                 const dnh8 k_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + 16 * kb));
                 const dnh8 k_lo = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + DN_XPART + 16 * kb));
                 const dnh8 q_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(qrow + 16 * kb));
@@ -254,9 +260,11 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] += cross[r];
-        float* ex = sx + ((qt * 2 + half) * 16) * 64 + lane;                  // [query tile][half][register][lane]
+        if (part < 2) {
+            float* ex = sx + ((qt * 2 + part) * 16) * 64 + lane;              // [query tile][K half][register][lane]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ex[r * 64] = mine[r];
+            for (int r = 0; r < 16; ++r) ex[r * 64] = mine[r];
+        }
         __syncthreads();
         const float* e0 = sx + ((qt * 2 + 0) * 16) * 64 + lane;
         const float* e1 = sx + ((qt * 2 + 1) * 16) * 64 + lane;
@@ -286,7 +294,9 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
         z_run += (double)zt; zp_run += (double)zpt; deg += __popc(passmask);
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
         const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
-        if (!(a.variant & 1)) { if (half == 0) dn_pv<0>(acc, planes, i & 15, h, second, p_hi, p_lo); else dn_pv<1>(acc, planes, i & 15, h, second, p_hi, p_lo); }
+        if (!(a.variant & 1)) {
+            dn_pv(acc, planes, i & 15, h, second, p_hi, p_lo, ct0, ctn);
+        }
         dma_wait_all();
         __syncthreads();                                   // everyone is done with this tile's planes and features
         if (tile + 1 < tile1 && !(a.variant & 4)) store_region();   // published by the next tile's exchange barrier
@@ -297,13 +307,13 @@ __global__ __launch_bounds__(256) void dense_attend_kernel(DenseArgs a) {
     if (qvalid) {
         const double z2 = z_run + __shfl_xor(z_run, 32), zp2 = zp_run + __shfl_xor(zp_run, 32);
         const int d2 = deg + __shfl_xor(deg, 32);
-        if (half == 0 && h == 0) {
+        if (part == 0 && h == 0) {
             a.part_m[orow] = m_run;
             a.part_z[2 * orow] = z2; a.part_z[2 * orow + 1] = zp2;
             a.part_deg[orow] = d2;
         }
         float* po = a.part_acc + orow * P;
-        if (half == 0) dn_store<0>(acc, po, h); else dn_store<1>(acc, po, h);
+        dn_store(acc, po, h, ct0, ctn);
     } else {
         (void)__shfl_xor(z_run, 32); (void)__shfl_xor(zp_run, 32); (void)__shfl_xor(deg, 32);
     }
@@ -466,7 +476,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
         DAGL_LAUNCH_CHECK("feat_split_kernel");
     }
     const int n_qblocks = (g.L + 63) / 64;
-    hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
