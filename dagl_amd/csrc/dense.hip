@@ -117,6 +117,9 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short spl[2 * DN_PLANE_H + 64]; // 21 KiB: value planes hi | lo of ONE tile
     __shared__ __attribute__((aligned(16))) unsigned short sq[2][64 * DSH];        // 54 KiB: the block's 64 query rows hi | lo
     __shared__ float sx[2 * 2 * 16 * 64];                                          // 16 KiB: partial scores exchanged per tile
+    __shared__ __attribute__((aligned(16))) uint4 spq[2][64][5];                   // 10 KiB: a tile's weights as halfs (80 B per lane: odd slot count)
+    __shared__ double szz[2][4][32][2];                                            // 4 KiB: the waves' shares of a query's sums (end of the block)
+    __shared__ int sdg[2][4][32];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -268,30 +271,41 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         __syncthreads();
         const float* e0 = sx + ((qt * 2 + 0) * 16) * 64 + lane;
         const float* e1 = sx + ((qt * 2 + 1) * 16) * 64 + lane;
-        f32x16 sc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = (e0[r * 64] + e1[r * 64]) * (1.0f / (DN_FS * DN_FS));
-        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile = pixel (2 (r >> 3) + h, r & 7) -----
-        dnh8 p_hi[2], p_lo[2];
-        float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32 (16 terms), one fp64 add per tile
+        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile = pixel (2 (r >> 3) + h, r & 7).
+        // All four waves of a query tile need all 16 weights of a lane; each forms four of them (logit, exponential, fp16
+        // split: ~25 VALU operations per weight) and they are exchanged through LDS as packed halfs -----------------------
+        float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32, one fp64 add per tile
         unsigned passmask = 0;
+        _Float16 hq[4], lq[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int u = 0; u < 4; ++u) {
+            const int r = 4 * part + u;                                       // wave-uniform
+            const float sc = (e0[r * 64] + e1[r * 64]) * (1.0f / (DN_FS * DN_FS));
             const bool valid = (jx0 + (r & 7) < g.W) && (jy0 + 2 * (r >> 3) + h < g.H);   // pixel (row 2 (r>>3) + h, column r & 7) of the tile
             bool pass;
-            const float l = dn_logit(sc[r], mtq, bsq, pass);
+            const float l = dn_logit(sc, mtq, bsq, pass);
             const float p = valid ? __expf(fminf(l - m_run, 0.f)) : 0.f;      // (the bound holds; the clamp is a seat belt)
             zt += p;
             pass = pass && valid;
             const float pp = pass ? p : 0.f;
             zpt += pp;
-            passmask |= (pass ? 1u : 0u) << r;
+            passmask |= (pass ? 1u : 0u) << u;
             const float ps = pp * DN_PS;
-            const _Float16 hi = (_Float16)ps;
-            p_hi[r >> 3][r & 7] = hi;
-            p_lo[r >> 3][r & 7] = (_Float16)(ps - (float)hi);
+            hq[u] = (_Float16)ps;
+            lq[u] = (_Float16)(ps - (float)hq[u]);
         }
         z_run += (double)zt; zp_run += (double)zpt; deg += __popc(passmask);
+        unsigned char* pq = reinterpret_cast<unsigned char*>(&spq[qt][lane][0]);   // 80 B per lane: hi[16] | lo[16] | pad
+        {
+            typedef _Float16 dnh4 __attribute__((ext_vector_type(4)));
+            const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
+            *reinterpret_cast<dnh4*>(pq + 8 * part) = hv;
+            *reinterpret_cast<dnh4*>(pq + 32 + 8 * part) = lv;
+        }
+        __syncthreads();
+        dnh8 p_hi[2], p_lo[2];
+        p_hi[0] = *reinterpret_cast<const dnh8*>(pq);      p_hi[1] = *reinterpret_cast<const dnh8*>(pq + 16);
+        p_lo[0] = *reinterpret_cast<const dnh8*>(pq + 32); p_lo[1] = *reinterpret_cast<const dnh8*>(pq + 48);
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
         const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
         if (!(a.variant & 1)) {
@@ -304,18 +318,22 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 
     // ---- partial results of this key range ------------------------------------------------------------------------------
     const size_t orow = ((size_t)split * a.B + b) * g.L + qc;
-    if (qvalid) {
+    {
+        // every wave summed its quarter of the weights: halves h first, then the four waves of the query tile in wave order
         const double z2 = z_run + __shfl_xor(z_run, 32), zp2 = zp_run + __shfl_xor(zp_run, 32);
         const int d2 = deg + __shfl_xor(deg, 32);
+        if (h == 0) { szz[qt][part][i][0] = z2; szz[qt][part][i][1] = zp2; sdg[qt][part][i] = d2; }
+    }
+    __syncthreads();
+    if (qvalid) {
         if (part == 0 && h == 0) {
             a.part_m[orow] = m_run;
-            a.part_z[2 * orow] = z2; a.part_z[2 * orow + 1] = zp2;
-            a.part_deg[orow] = d2;
+            a.part_z[2 * orow] = (szz[qt][0][i][0] + szz[qt][1][i][0]) + (szz[qt][2][i][0] + szz[qt][3][i][0]);
+            a.part_z[2 * orow + 1] = (szz[qt][0][i][1] + szz[qt][1][i][1]) + (szz[qt][2][i][1] + szz[qt][3][i][1]);
+            a.part_deg[orow] = (sdg[qt][0][i] + sdg[qt][1][i]) + (sdg[qt][2][i] + sdg[qt][3][i]);
         }
         float* po = a.part_acc + orow * P;
         dn_store(acc, po, h, ct0, ctn);
-    } else {
-        (void)__shfl_xor(z_run, 32); (void)__shfl_xor(zp_run, 32); (void)__shfl_xor(deg, 32);
     }
 }
 
