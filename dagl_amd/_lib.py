@@ -90,6 +90,8 @@ SIGNATURES = {
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
     "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dagl_project_patches16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "dagl_project_patches16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz]),
     "dagl_feat_rows": (_i, [_i]),
     "dagl_query_thresholds": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dagl_gather_aggregate": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -992,6 +992,51 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const fl
                            thr, bias, nullptr, nullptr, scratch);
 }
 
+// ---- the 7x7x16 -> 196 patch Linear (+ReLU) of the differentiable path's FORWARD on the inference kernels: split the map,
+// pack the weight, project (split-fp16 matrix cores, no unfolded rows), copy the feature rows out densely ---------------
+static void pp16_carve(int B, const Grid& g, int n, size_t& o_hi, size_t& o_lo, size_t& o_wp, size_t& o_feat, size_t& total) {
+    size_t off = 0;
+    const size_t map_h = (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t);
+    o_hi = carve(off, map_h); o_lo = carve(off, map_h);
+    o_wp = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
+    o_feat = carve(off, (size_t)B * feat_rows(n) * DS * sizeof(float));
+    total = off;
+}
+
+size_t dagl_project_patches16_scratch_bytes(int B, int H, int W, int queries) {
+    if (B < 1 || H < 1 || W < 1) return 0;
+    const Grid g = make_grid(H, W);
+    size_t a, b2, c, d, total;
+    pp16_carve(B, g, queries ? g.L : g.N, a, b2, c, d, total);
+    return total;
+}
+
+int dagl_project_patches16(void* stream, int B, int H, int W, int queries, const float* map_nhwc, const float* w_rows,
+                           const float* fc_bias, float* rows_out, void* scratch, size_t scratch_bytes) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && map_nhwc && w_rows && fc_bias && rows_out && scratch,
+                 "dagl_project_patches16: bad argument");
+    DAGL_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "dagl_project_patches16: scratch must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const Grid g = make_grid(H, W);
+    const int n = queries ? g.L : g.N;
+    size_t o_hi, o_lo, o_wp, o_feat, total;
+    pp16_carve(B, g, n, o_hi, o_lo, o_wp, o_feat, total);
+    DAGL_REQUIRE(scratch_bytes >= total, "dagl_project_patches16: scratch %zu B, need %zu B", scratch_bytes, total);
+    uint16_t* hi = at<uint16_t>(scratch, o_hi);
+    uint16_t* lo = at<uint16_t>(scratch, o_lo);
+    uint16_t* wp = at<uint16_t>(scratch, o_wp);
+    float* feat = at<float>(scratch, o_feat);
+    int rc;
+    if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, map_nhwc, hi, lo))) return rc;
+    if ((rc = launch_pack_fc_weight16(s, w_rows, wp, /*rows_order=*/true))) return rc;
+    const float* bias1[1] = {fc_bias};
+    if (queries) rc = launch_project16(s, B, g, 2, hi, lo, nullptr, nullptr, nullptr, nullptr, nullptr, wp, bias1, feat, nullptr, nullptr);
+    else rc = launch_project16(s, B, g, 1, hi, lo, wp, bias1, feat, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    // [B, feat_rows(n), DS] -> [B, n, 196]
+    return dagl_copy4(stream, 1, B, n, D, feat, 0, (long long)feat_rows(n) * DS, DS, 1, rows_out, 0, (long long)n * D, D, 1);
+}
+
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && src_nchw && dst_nhwc, "dagl_pad_nhwc: bad argument");
     return launch_pad_nhwc((hipStream_t)stream, B, H, W, src_nchw, dst_nhwc);

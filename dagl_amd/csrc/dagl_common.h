@@ -157,7 +157,7 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, 
                    uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr);
 // fp16 split-operand projection (project16.hip)
 int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range = RangeTag());
-int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp);
+int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool rows_order = false /* [196][tap][c] instead of [196][c][tap] */);
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,

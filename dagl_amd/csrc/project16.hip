@@ -67,7 +67,8 @@ int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t*
 // fc weight [196,784] (c,kh,kw) -> packed [49 taps][P16_SLICE_H halfs]: row o = 64 bytes = four 16-byte slots
 // (hi c0-7, hi c8-15, lo c0-7, lo c8-15) stored at slot ^ ((o >> 2) & 3): the ds_read_b128 of 32 consecutive rows is then
 // conflict-free without padding (rows r, r+4, r+8, r+12 of a 16-lane LDS group land in different slots)
-__global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp) {
+// (rows_order: the weight comes as [196][49 taps][16 c] -- the differentiable path's layout -- instead of Linear's [196][c][tap])
+__global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int rows_order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P16_STEPS * P16_SLICE_H) return;
     const int tap = i / P16_SLICE_H, r = i % P16_SLICE_H;
@@ -77,7 +78,7 @@ __global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned sh
         const int slot = (e >> 3) ^ ((o >> 2) & 3);                  // logical slot stored at this physical position
         const int c = (slot & 1) * 8 + (e & 7);
         unsigned short hi, lo;
-        const float wv = w[(size_t)o * P + c * (KS * KS) + tap] * P16_W_SCALE;
+        const float wv = w[(size_t)o * P + (rows_order ? tap * CH + c : c * (KS * KS) + tap)] * P16_W_SCALE;
         split_f16(wv, hi, lo);
         v = (slot < 2) ? hi : lo;
         // range flag of these packed weights: the last 4 bytes of the buffer (cleared by launch_pack_fc_weight16)
@@ -86,10 +87,10 @@ __global__ void pack_fc_weight16_kernel(const float* __restrict__ w, unsigned sh
     wp[i] = v;
 }
 
-int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp) {
+int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool rows_order) {
     const int n = P16_STEPS * P16_SLICE_H;
     DAGL_HIP_TRY(hipMemsetAsync(wp + P16_PACKED_HALFS - 2, 0, 4, s));
-    hipLaunchKernelGGL(pack_fc_weight16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wp);
+    hipLaunchKernelGGL(pack_fc_weight16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wp, rows_order ? 1 : 0);
     DAGL_LAUNCH_CHECK("pack_fc_weight16_kernel");
     return DAGL_OK;
 }

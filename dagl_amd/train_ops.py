@@ -58,6 +58,22 @@ def to_padded_nhwc(x, H, W, from_rows=False):
     return _ToPaddedNHWC.apply(x, H, W, from_rows)
 
 
+FAST_FC_FORWARD = True          # forward of the two patch projections on the split-fp16 inference kernels (tests flip it)
+
+
+def _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W):
+    """1 (queries) / 0 (keys) when the call is one of CE's two patch projections on its own grids, else None."""
+    if not (k == 7 and C == 16 and O == 196 and relu):
+        return None
+    if (stride, oy, ox, oh, ow) == (1, 0, 0, H, W):
+        return 0
+    from .synth import same_pad_amounts
+    t, l = same_pad_amounts(H, 7, 4)[0], same_pad_amounts(W, 7, 4)[0]
+    if (stride, oy, ox, oh, ow) == (4, PAD - t, PAD - l, -(-H // 4), -(-W // 4)):
+        return 1
+    return None
+
+
 class _PatchLinear(torch.autograd.Function):
     """y[b, patch, :] = act(W . unfold(map)[b, patch, :] + bias): a convolution (any kernel size / stride) or a Linear over
     extracted patches.  ``weight`` is [O, k*k*C] with the patch elements in (kh, kw, c) order."""
@@ -70,11 +86,23 @@ class _PatchLinear(torch.autograd.Function):
         if K != k * k * C:
             raise DaglError("patch_linear: weight does not match the patch size")
         lib = _lib.load()
+        H, W = Hp - 2 * PAD, Wp - 2 * PAD
+        fast = _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W) if FAST_FC_FORWARD else None
         with torch.cuda.device(pmap.device):
-            rows = torch.empty(B * oh * ow, K, device=pmap.device, dtype=torch.float32)
-            check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
-                                          rows.data_ptr()), "dagl_unfold_patches")
-            y = ops.gemm_f32(rows, weight, a_k_contiguous=True, b_k_contiguous=True, bias=bias, relu=relu, chunk_tiles=7)
+            if fast is not None:
+                # the two 7x7x16 -> 196 projections (dagl.py:248-249): the inference kernels (split-fp16 matrix cores on the
+                # map itself, five times the fp32 rate, no [n, 784] patch rows); the backward below is unchanged
+                need = lib.dagl_project_patches16_scratch_bytes(B, H, W, fast)
+                scratch = torch.empty(need + 256, device=pmap.device, dtype=torch.uint8)
+                base = (scratch.data_ptr() + 255) // 256 * 256
+                y = torch.empty(B * oh * ow, O, device=pmap.device, dtype=torch.float32)
+                check(lib.dagl_project_patches16(ops._stream(), B, H, W, fast, pmap.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                 y.data_ptr(), base, need), "dagl_project_patches16")
+            else:
+                rows = torch.empty(B * oh * ow, K, device=pmap.device, dtype=torch.float32)
+                check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
+                                              rows.data_ptr()), "dagl_unfold_patches")
+                y = ops.gemm_f32(rows, weight, a_k_contiguous=True, b_k_contiguous=True, bias=bias, relu=relu, chunk_tiles=7)
         ctx.geom = (B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K)
         ctx.save_for_backward(pmap, weight, y if relu else pmap.new_empty(0))
         return y.view(B, oh * ow, O)

@@ -309,6 +309,15 @@ int dagl_project_patches(void* stream, int B, int H, int W, int queries,
                          float* feat, double* colsum);
 int dagl_feat_rows(int rows);          /* rows rounded up to the streaming tile + 1 guard tile     */
 
+/* The same Linear(784->196)+ReLU over patches on the split-fp16 matrix cores (the inference kernels: the map is split into
+ * fp16 hi / lo, the weight packed, no unfolded patch rows exist), for the FORWARD of the differentiable path:
+ *   map_nhwc  zero-bordered [B,H+6,W+6,16] fp32;  w_rows [196, 49 taps, 16 c] (the patch order of dagl_unfold_patches);
+ *   rows_out  [B, n, 196] dense (n = L for queries != 0, N = H*W otherwise);  scratch: 256-byte aligned device memory of
+ *   dagl_project_patches16_scratch_bytes(B,H,W,queries) bytes.  Holds for |16 map| < 65504, |1024 w| < 65504.  */
+size_t dagl_project_patches16_scratch_bytes(int B, int H, int W, int queries);
+int dagl_project_patches16(void* stream, int B, int H, int W, int queries, const float* map_nhwc, const float* w_rows,
+                           const float* fc_bias, float* rows_out, void* scratch, size_t scratch_bytes);
+
 /* Per-query threshold pieces of the adaptive mask (dagl.py:256):
  *   mt[b,l] = mean_j S[l,j] * thr[b,l]   with mean_j S[l,j] = Wq[l,:] . (colsum/N)
  *   (bias is used as is).                                                                        */

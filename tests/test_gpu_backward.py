@@ -289,3 +289,31 @@ def test_one_sgd_step_reduces_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[2] < losses[0]
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 40, 36), (2, 63, 50), (8, 128, 128)])
+def test_fast_projection_forward_equals_the_gemm_forward(B, H, W):
+    """The training forward of fc1 / fc2 runs on the inference kernels (split-fp16 matrix cores, no unfolded rows); the
+    fp32 unfold + GEMM path it replaces is kept (other layers, and the backward): both must give the same features."""
+    from dagl_amd import train_ops as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    b1_rows = torch.randn(B, H * W, 16, generator=g).to(dev)
+    w = (torch.randn(196, 784, generator=g) * 0.05).to(dev)
+    bias = (torch.randn(196, generator=g) * 0.1).to(dev)
+    b1p = T.to_padded_nhwc(b1_rows, H, W, from_rows=True)
+    from dagl_amd.synth import same_pad_amounts
+    t, l = same_pad_amounts(H, 7, 4)[0], same_pad_amounts(W, 7, 4)[0]
+    Lh, Lw = -(-H // 4), -(-W // 4)
+    outs = {}
+    for fast in (True, False):
+        T.FAST_FC_FORWARD = fast
+        try:
+            q = T.patch_linear(b1p, T.fc_weight_rows(w, 16, 7), bias, 7, 4, T.PAD - t, T.PAD - l, Lh, Lw, relu=True)
+            k = T.patch_linear(b1p, T.fc_weight_rows(w, 16, 7), bias, 7, 1, 0, 0, H, W, relu=True)
+        finally:
+            T.FAST_FC_FORWARD = True
+        outs[fast] = (q.clone(), k.clone())
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape
+        assert normwise(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
