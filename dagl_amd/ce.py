@@ -190,20 +190,15 @@ class CE(nn.Module):
         t, _bo = same_pad_amounts(H, ks, self.stride_1)
         l, _r = same_pad_amounts(W, ks, self.stride_1)
         Lh, Lw = -(-H // self.stride_1), -(-W // self.stride_1)
-        xp = T.to_padded_nhwc(b, H, W)                                                       # [B,H+6,W+6,64]
-        # dagl.py:208-209  g (3x3, pad 1), theta (1x1)
-        b1_rows = T.patch_linear(xp, T.conv_weight_rows(self.g.weight), self.g.bias, 3, 1, T.PAD - 1, T.PAD - 1, H, W)
-        b2_rows = T.patch_linear(xp, T.conv_weight_rows(self.theta.weight), self.theta.bias, 1, 1, T.PAD, T.PAD, H, W)
-        b2 = b2_rows.view(B, H, W, c).permute(0, 3, 1, 2)                                    # NCHW view of the value map
-        # dagl.py:213-215  thr_conv / bias_conv on the SAME-padded input (7x7, stride 4): one product with two outputs
+        # dagl.py:208-215  g (3x3, pad 1), theta (1x1), thr_conv / bias_conv (7x7 stride 4 on the SAME-padded input): one forward
+        # call of the library's fp32 prologue kernels, layer-by-layer unfold / GEMM backward (train_ops._PrologueConvs)
         thr = bias = None
         if self.select_mode != "topk":                 # (the fixed-k variant has no threshold heads)
-            w_tb = torch.cat([T.conv_weight_rows(self.thr_conv.weight), T.conv_weight_rows(self.bias_conv.weight)], dim=0)
-            b_tb = torch.cat([self.thr_conv.bias, self.bias_conv.bias], dim=0)
-            tb = T.patch_linear(xp, w_tb, b_tb, ks, self.stride_1, T.PAD - t, T.PAD - l, Lh, Lw)  # [B,L,2]
-            thr, bias = tb[..., 0], tb[..., 1]
+            b1p, b2p, thr, bias = T.prologue_convs(b, self.g, self.theta, self.thr_conv, self.bias_conv)
+        else:
+            b1p, b2p = T.prologue_convs(b, self.g, self.theta)
+        b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2)                  # NCHW view of the value map
         # dagl.py:216-249  patches of b1 (stride 4 SAME / stride 1) through fc1 / fc2 + ReLU
-        b1p = T.to_padded_nhwc(b1_rows, H, W, from_rows=True)                                 # [B,H+6,W+6,16]
         wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, self.stride_1,
                                  T.PAD - t, T.PAD - l, Lh, Lw, relu=True)                     # [B,L,196]
         x_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc2[0].weight, c, ks), self.fc2[0].bias, ks, self.stride_2,

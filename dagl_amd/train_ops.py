@@ -109,35 +109,127 @@ class _PatchLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_y):
-        B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K = ctx.geom
         pmap, weight, y = ctx.saved_tensors
-        lib = _lib.load()
-        n = B * oh * ow
-        with torch.cuda.device(pmap.device):
-            dz = d_y.contiguous().view(n, O).float()
-            if relu:
-                dzr = torch.empty_like(dz)
-                check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
-                      "dagl_relu_backward")
-                dz = dzr
-            rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32)          # recomputed, not kept
-            check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
-                                          rows.data_ptr()), "dagl_unfold_patches")
-            d_w = d_b = d_map = None
-            if ctx.needs_input_grad[1]:
-                # [O,n] x [n,K]: split-K keeps the fma chains at a few thousand products, no chunked accumulation needed
-                # (its second accumulator set costs a third of the kernel's occupancy)
-                d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
-            if ctx.needs_input_grad[2]:
-                d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
-                scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
-                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr(), scr.data_ptr()), "dagl_col_sum")
-            if ctx.needs_input_grad[0]:
-                d_rows = ops.gemm_f32(dz, weight, a_k_contiguous=True, b_k_contiguous=False, out=rows)   # [n,O] x [O,K]
-                d_map = torch.empty_like(pmap)
-                check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, d_rows.data_ptr(),
-                                            d_map.data_ptr()), "dagl_fold_patches")
+        d_map, d_w, d_b = _patch_linear_backward(pmap, weight, y, ctx.geom, d_y, *ctx.needs_input_grad[:3])
         return d_map, d_w, d_b, None, None, None, None, None, None, None
+
+
+def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b):
+    """d map / d weight / d bias of ``y = act(W . unfold(map) + bias)`` (the patch rows are recomputed, not kept)."""
+    B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K = geom
+    lib = _lib.load()
+    n = B * oh * ow
+    with torch.cuda.device(pmap.device):
+        dz = d_y.contiguous().view(n, O).float()
+        if relu:
+            dzr = torch.empty_like(dz)
+            check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
+                  "dagl_relu_backward")
+            dz = dzr
+        rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32)          # recomputed, not kept
+        check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
+                                      rows.data_ptr()), "dagl_unfold_patches")
+        d_w = d_b = d_map = None
+        if need_w:
+            # [O,n] x [n,K]: split-K keeps the fma chains at a few thousand products, no chunked accumulation needed
+            # (its second accumulator set costs a third of the kernel's occupancy)
+            d_w = ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
+        if need_b:
+            d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
+            scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
+            check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr(), scr.data_ptr()), "dagl_col_sum")
+        if need_map:
+            d_rows = ops.gemm_f32(dz, weight, a_k_contiguous=True, b_k_contiguous=False, out=rows)   # [n,O] x [O,K]
+            d_map = torch.empty_like(pmap)
+            check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, d_rows.data_ptr(),
+                                        d_map.data_ptr()), "dagl_fold_patches")
+    return d_map, d_w, d_b
+
+
+class _PrologueConvs(torch.autograd.Function):
+    """The four prologue convolutions of dagl.py:208-215 in one forward call of the library's fp32 prologue kernels
+    (``dagl_ce_prologue``: zero-bordered NHWC maps of g(b) and theta(b), thr / bias per query) -- as unfold + GEMM a 64 -> 16
+    convolution fills an eighth of the GEMM's 128-wide tile and writes 300 MB of patch rows first.  The backward is the
+    unfold / GEMM / fold one, layer by layer."""
+
+    @staticmethod
+    def forward(ctx, x, g_w, g_b, th_w, th_b, thr_w, thr_b, bias_w, bias_b):
+        x = x.contiguous()
+        heads = thr_w is not None
+        c = lambda t: t.contiguous() if t is not None else None
+        with torch.cuda.device(x.device):
+            b1p, b2p, thr, bias = ops.ce_prologue(x, c(g_w), c(g_b), c(th_w), c(th_b), c(thr_w), c(thr_b), c(bias_w), c(bias_b))
+        ctx.heads = heads
+        ctx.save_for_backward(x, g_w, th_w, *( (thr_w, bias_w) if heads else () ))
+        if heads:
+            return b1p, b2p, thr, bias
+        return b1p, b2p
+
+    @staticmethod
+    def backward(ctx, d_b1p, d_b2p, d_thr=None, d_bias=None):
+        saved = ctx.saved_tensors
+        x, g_w, th_w = saved[:3]
+        B, C, H, W = x.shape
+        Hp, Wp = H + 2 * PAD, W + 2 * PAD
+        from .synth import same_pad_amounts
+        t, l = same_pad_amounts(H, 7, 4)[0], same_pad_amounts(W, 7, 4)[0]
+        Lh, Lw = -(-H // 4), -(-W // 4)
+        need_x = ctx.needs_input_grad[0]
+        with torch.cuda.device(x.device):
+            xp = _ToPaddedNHWC.apply(x.detach(), H, W, False)                              # [B,H+6,W+6,64], recomputed
+            inner = (PAD * Wp + PAD) * 16
+
+            def crop_rows(d_map):                      # padded NHWC gradient -> rows [B, H*W, 16]
+                d_map = d_map.contiguous()
+                rows = torch.empty(B, H * W, 16, device=x.device, dtype=torch.float32)
+                _copy4(d_map.view(-1)[inner:], (B, H, W, 16), (Hp * Wp * 16, Wp * 16, 16, 1), rows, (H * W * 16, W * 16, 16, 1))
+                return rows
+
+            d_xp = None
+            grads = {}
+            layers = [("g", conv_weight_rows(g_w.detach()), (B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, False, 16, 9 * C), crop_rows(d_b1p), 1, 2, g_w.shape),
+                      ("theta", conv_weight_rows(th_w.detach()), (B, Hp, Wp, C, 1, 1, PAD, PAD, H, W, False, 16, C), crop_rows(d_b2p), 3, 4, th_w.shape)]
+            for name, w_rows, geom, d_rows, iw, ib, wshape in layers:
+                d_map, d_w, d_b = _patch_linear_backward(xp, w_rows.contiguous(), None, geom, d_rows, need_x,
+                                                         ctx.needs_input_grad[iw], ctx.needs_input_grad[ib])
+                if d_map is not None:
+                    d_xp = d_map if d_xp is None else d_xp.add_(d_map)
+                if d_w is not None:
+                    k = geom[4]
+                    d_w = d_w.view(wshape[0], k, k, wshape[1]).permute(0, 3, 1, 2).contiguous()
+                grads[name] = (d_w, d_b)
+            d_thr_w = d_thr_b = d_bias_w = d_bias_b = None
+            if ctx.heads:
+                thr_w, bias_w = saved[3], saved[4]
+                w_tb = torch.cat([conv_weight_rows(thr_w.detach()), conv_weight_rows(bias_w.detach())], dim=0).contiguous()
+                zero = torch.zeros(B, Lh * Lw, device=x.device, dtype=torch.float32)
+                d_tb = torch.stack([(d_thr if d_thr is not None else zero).reshape(B, Lh * Lw),
+                                    (d_bias if d_bias is not None else zero).reshape(B, Lh * Lw)], dim=-1).contiguous()   # [B,L,2]
+                geom = (B, Hp, Wp, C, 7, 4, PAD - t, PAD - l, Lh, Lw, False, 2, 49 * C)
+                need_w = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
+                need_b = ctx.needs_input_grad[6] or ctx.needs_input_grad[8]
+                d_map, d_w, d_b = _patch_linear_backward(xp, w_tb, None, geom, d_tb, need_x, need_w, need_b)
+                if d_map is not None:
+                    d_xp = d_map if d_xp is None else d_xp.add_(d_map)
+                if d_w is not None:
+                    d_w = d_w.view(2, 7, 7, C).permute(0, 3, 1, 2).contiguous()
+                    d_thr_w, d_bias_w = d_w[0:1], d_w[1:2]
+                if d_b is not None:
+                    d_thr_b, d_bias_b = d_b[0:1], d_b[1:2]
+            d_x = None
+            if need_x and d_xp is not None:
+                d_x = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+                inner64 = (PAD * Wp + PAD) * C
+                _copy4(d_xp.view(-1)[inner64:], (B, C, H, W), (Hp * Wp * C, 1, Wp * C, C), d_x, (C * H * W, H * W, W, 1))
+        return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b)
+
+
+def prologue_convs(x, g, theta, thr_conv=None, bias_conv=None):
+    """(b1p, b2p[, thr, bias]) of the block input: zero-bordered NHWC maps [B,H+6,W+6,16] and per-query thr / bias [B,L]."""
+    if thr_conv is None:
+        return _PrologueConvs.apply(x, g.weight, g.bias, theta.weight, theta.bias, None, None, None, None)
+    return _PrologueConvs.apply(x, g.weight, g.bias, theta.weight, theta.bias, thr_conv.weight, thr_conv.bias,
+                                bias_conv.weight, bias_conv.bias)
 
 
 def patch_linear(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu=False):
