@@ -186,18 +186,23 @@ class _PrologueConvs(torch.autograd.Function):
                 return rows
 
             d_xp = None
-            grads = {}
-            layers = [("g", conv_weight_rows(g_w.detach()), (B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, False, 16, 9 * C), crop_rows(d_b1p), 1, 2, g_w.shape),
-                      ("theta", conv_weight_rows(th_w.detach()), (B, Hp, Wp, C, 1, 1, PAD, PAD, H, W, False, 16, C), crop_rows(d_b2p), 3, 4, th_w.shape)]
-            for name, w_rows, geom, d_rows, iw, ib, wshape in layers:
-                d_map, d_w, d_b = _patch_linear_backward(xp, w_rows.contiguous(), None, geom, d_rows, need_x,
-                                                         ctx.needs_input_grad[iw], ctx.needs_input_grad[ib])
-                if d_map is not None:
-                    d_xp = d_map if d_xp is None else d_xp.add_(d_map)
-                if d_w is not None:
-                    k = geom[4]
-                    d_w = d_w.view(wshape[0], k, k, wshape[1]).permute(0, 3, 1, 2).contiguous()
-                grads[name] = (d_w, d_b)
+            # g (3x3) and theta (1x1 = the centre tap of the 3x3 window) share their patch rows: ONE 32-output layer over the
+            # 3x3 patches, theta's weights sitting in the centre tap (a 16-output product fills an eighth of the GEMM's tile)
+            w32 = torch.zeros(32, 9 * C, device=x.device, dtype=torch.float32)
+            w32[:16] = conv_weight_rows(g_w.detach())
+            w32[16:, 4 * C:5 * C] = th_w.detach().reshape(16, C)
+            d32 = torch.cat([crop_rows(d_b1p), crop_rows(d_b2p)], dim=-1)                   # [B, H*W, 32]
+            geom = (B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, False, 32, 9 * C)
+            need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+            need_b = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
+            d_xp, d_w32, d_b32 = _patch_linear_backward(xp, w32, None, geom, d32, need_x, need_w, need_b)
+            grads = {"g": (None, None), "theta": (None, None)}
+            if d_w32 is not None:
+                grads["g"] = (d_w32[:16].view(16, 3, 3, C).permute(0, 3, 1, 2).contiguous(), None)
+                grads["theta"] = (d_w32[16:, 4 * C:5 * C].reshape(th_w.shape).contiguous(), None)
+            if d_b32 is not None:
+                grads["g"] = (grads["g"][0], d_b32[:16].contiguous())
+                grads["theta"] = (grads["theta"][0], d_b32[16:].contiguous())
             d_thr_w = d_thr_b = d_bias_w = d_bias_b = None
             if ctx.heads:
                 thr_w, bias_w = saved[3], saved[4]
