@@ -246,6 +246,8 @@ struct CoreIn {                  // training entry point: features given, neighb
     const float* wq_rows; const float* x_rows;                   // [B,L,196], [B,N,196] dense rows (post-ReLU)
     int32_t* nb_idx; float* nb_wgt; float* nb_s; int32_t* nb_cnt; // [B,L,width] x3, [B,L]
     float* mu;                                                   // [B,L] row means of S (adaptive modes)
+    float* lse;                                                  // dense core (streamed dense formulation): [B,L,2] = {softmax shift M, sum Z};
+                                                                 // the list outputs are then unused (null)
 };
 
 static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, const float* b2, const float* thr,
@@ -264,7 +266,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 info->redone_queries = -1; info->range_fallback = 0; info->reserved = 0; }
     DAGL_REQUIRE(out && (core || (fc1_w && fc1_b && fc2_w && fc2_b)), "dagl_ce_forward: null tensor pointer");
     if (core) {
-        DAGL_REQUIRE(core->wq_rows && core->x_rows && b2 && core->nb_idx && core->nb_wgt && core->nb_s && core->nb_cnt,
+        DAGL_REQUIRE(core->wq_rows && core->x_rows && b2 && (core->lse || (core->nb_idx && core->nb_wgt && core->nb_s && core->nb_cnt)),
                      "dagl_ce_core_forward: null tensor pointer");
         if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias && core->mu, "dagl_ce_core_forward: thr/bias/mu required in adaptive modes");
     } else if (fin) {
@@ -509,7 +511,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             size_t off = p.o_end;
             const size_t o_dn = carve(off, dense_workspace_bytes(B, g));
             if (info) { info->required_bytes = (int64_t)off; info->path = 4; }
-            if (core) {
+            if (core && !core->lse) {
                 if (info) info->required_bytes = -1;
                 set_error("dagl_ce_core_forward: dense neighbourhoods (most queries keep more than %d keys) do not fit fixed-width lists: "
                           "use dagl_ce_core_dense_forward", DAGL_FAST_CAP);
@@ -525,7 +527,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_screen(s, sc, 0))) return rc;
             float* smax = at<float>(ws, p.o_theta);
             if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
-            if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt))) return rc;
+            if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt,
+                                          core ? core->lse : nullptr))) return rc;
             prof_mark(prof, s, 7);
             if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
@@ -539,7 +542,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
             return DAGL_OK;
         };
-        if (mode == DAGL_MODE_ADAPTIVE && (mode_flags & DAGL_FLAG_DENSE_HINT) && !core) {
+        if (mode == DAGL_MODE_ADAPTIVE && (mode_flags & DAGL_FLAG_DENSE_HINT) && (!core || core->lse)) {
             prof_mark(prof, s, 3); prof_mark(prof, s, 4); prof_mark(prof, s, 5);
             return run_dense();
         }
@@ -840,7 +843,7 @@ int dagl_ce_core_forward(void* stream, int B, int H, int W, const float* wq_rows
                          const float* thr, const float* bias, int mode, int k, float* out, int32_t* nb_idx,
                          float* nb_wgt, float* nb_s, int32_t* nb_cnt, float* mu, void* workspace, size_t ws_bytes,
                          dagl_ce_info* info) {
-    CoreIn core{wq_rows, x_rows, nb_idx, nb_wgt, nb_s, nb_cnt, mu};
+    CoreIn core{wq_rows, x_rows, nb_idx, nb_wgt, nb_s, nb_cnt, mu, nullptr};
     return ce_forward_impl((hipStream_t)stream, B, H, W, nullptr, b2, thr, bias, nullptr, nullptr, nullptr, nullptr, mode,
                            k, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr, nullptr, nullptr, 1, &core);
 }
@@ -917,9 +920,23 @@ int dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k, co
     return launch_core_backward(s, a, w, dxbar, d_b2);
 }
 
+// forward on the inference path's streamed kernel (split-fp16 S and A V in one pass over the keys) when the image has enough
+// keys for the screen's machinery it borrows (row-maximum scan); the chunked fp32 GEMM formulation otherwise
+static bool dense_core_streamed(int H, int W) { return (int64_t)H * W >= SCREEN_MIN_KEYS; }
+static size_t dense_core_streamed_bytes(int B, int H, int W) {
+    Plan p;
+    if (make_plan(B, H, W, DAGL_MODE_ADAPTIVE | DAGL_FLAG_DENSE_HINT, 0, p, true)) return 0;
+    size_t off = p.o_end;
+    (void)carve(off, dense_workspace_bytes(B, p.g));
+    return off;
+}
+
 size_t dagl_ce_core_dense_workspace_bytes(int B, int H, int W, int backward) {
     if (B < 1 || H < 1 || W < 1) return 0;
-    return dense_train_workspace_bytes(B, make_grid(H, W), backward != 0);
+    const size_t gemm_form = dense_train_workspace_bytes(B, make_grid(H, W), backward != 0);
+    if (backward || !dense_core_streamed(H, W)) return gemm_form;
+    const size_t streamed = dense_core_streamed_bytes(B, H, W);
+    return streamed > gemm_form ? streamed : gemm_form;
 }
 
 int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
@@ -930,6 +947,12 @@ int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, const float* w
     DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_dense_forward: workspace must be 256-byte aligned");
     const Grid g = make_grid(H, W);
     hipStream_t s = (hipStream_t)stream;
+    if (dense_core_streamed(H, W)) {
+        CoreIn core{wq_rows, x_rows, nullptr, nullptr, nullptr, nullptr, mu, lse};
+        return ce_forward_impl(s, B, H, W, nullptr, b2, thr, bias, nullptr, nullptr, nullptr, nullptr,
+                               DAGL_MODE_ADAPTIVE | DAGL_FLAG_DENSE_HINT, 0, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 1, &core);
+    }
     if (info) { info->required_bytes = (int64_t)dense_train_workspace_bytes(B, g, false); info->total_edges = -1;
                 info->max_degree = -1; info->redone_queries = -1; info->path = 5; }
     // the two statistics words live at the very end of the caller's buffer (past the plan)

@@ -334,7 +334,8 @@ size_t dense_workspace_bytes(int B, const Grid& g);
 int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag());
+                        float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag(),
+                        float* lse_out = nullptr /* [B,L,2] {shift M, sum Z} for the backward */);
 
 // graph-core backward (backward.hip)
 struct BwdArgs {

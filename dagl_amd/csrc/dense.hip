@@ -340,7 +340,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 // merge the key-range partials of a query: M = max M_s, Z = sum Z_s e^(M_s - M), agg = sum acc_s e^(M_s - M) / Z
 // (all partials of a query share one shift today, so the weights are 1; kept general).  One wave per query, float4 columns.
 __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* __restrict__ agg, int32_t* __restrict__ deg_out,
-                                                            float* __restrict__ rowsum_out) {
+                                                            float* __restrict__ rowsum_out, float* __restrict__ lse_out) {
     const int lane = threadIdx.x & 63;
     const size_t nq = (size_t)a.B * a.g.L;
     const size_t ql = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);           // (b, q) flattened
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
     if (lane == 0) {
         if (deg_out) deg_out[ql] = deg;
         if (rowsum_out) rowsum_out[ql] = (float)(zp / z);
+        if (lse_out) { lse_out[2 * ql] = M; lse_out[2 * ql + 1] = (float)z; }        // A = e^(l - M) / Z for the backward
         a.part_deg[ql] = deg;        // slot of split 0 (read above): final degree, summed up by degree_stats_kernel afterwards
     }
 }
@@ -460,7 +461,7 @@ size_t dense_workspace_bytes(int B, const Grid& g) {
 
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats, RangeTag range) {
+                        float* rowsum_out, int64_t* stats, RangeTag range, float* lse_out) {
     DenseArgs a;
     a.smax = smax;
     a.variant = 0;
@@ -496,7 +497,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     const int n_qblocks = (g.L + 63) / 64;
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
-    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out);
+    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
     return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats);     // total edges, max degree (no per-query atomics)
 }

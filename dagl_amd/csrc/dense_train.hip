@@ -166,7 +166,26 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     float* srow = sbuf + ((size_t)bi * Lc + lr) * ldn;
     float* arow = abuf + ((size_t)bi * Lc + lr) * ldn;
     const float mtq = mt[ql], bsq = bs[ql];
-    const float M = lse[2 * ql], invz = 1.0f / lse[2 * ql + 1];
+    // The softmax's shift and denominator are formed HERE, from the recomputed scores -- not taken from the forward: the
+    // forward may have run on the streamed split-fp16 kernel, whose scores differ from these in the last bits; logits of
+    // several hundred turn that into ~1e-3 of every weight of the row, and the head biases' gradients (sums over all
+    // queries that cancel to 1e-4 of their terms) are only right when the weights are normalised by their own sum.
+    (void)lse;
+    __shared__ float shf[4];
+    float mx = 0.f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        mx = pass ? fmaxf(mx, l) : mx;
+    }
+    const float M = dt_block_max(mx, shf);
+    double zz = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        bool pass; float m;
+        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        zz += (double)expf(l - M);
+    }
+    const float invz = (float)(1.0 / dt_block_sum(zz, shd));
     double c = 0.0;
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
