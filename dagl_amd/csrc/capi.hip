@@ -127,14 +127,21 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.s_steps = (g.N + SKEYS - 1) / SKEYS;
     {
         const int mx = (p.s_steps + 3) / 4 > 64 ? 64 : (p.s_steps + 3) / 4;
-        const int nq512 = (g.L + 511) / 512;
-        int qb = ((long long)nq512 * B * mx >= 256) ? 512 : 256;
+        // 512-, 384- or 256-query blocks: whichever leaves the fewest idle query slots (a 72 x 72 tile has L = 324: 12 waves
+        // instead of 16), the larger block on a tie; the 16- and 12-wave blocks only when they still give one block per CU
+        int qb = 256;
+        long long slots = (long long)((g.L + 255) / 256) * 256;
+        for (int cand = 384; cand <= 512; cand += 128) {
+            const long long nq = (g.L + cand - 1) / cand;
+            if (nq * B * mx < 256) continue;
+            if (nq * cand <= slots) { qb = cand; slots = nq * cand; }
+        }
 #ifdef DAGL_ABLATION
-        { static const int e = [] { const char* v = getenv("DAGL_SCREEN_QBLOCK"); return v ? atoi(v) : 0; }(); if (e == 256 || e == 512) qb = e; }
+        { static const int e = [] { const char* v = getenv("DAGL_SCREEN_QBLOCK"); return v ? atoi(v) : 0; }(); if (e == 256 || e == 384 || e == 512) qb = e; }
         static const int target_env = [] { const char* e = getenv("DAGL_SCREEN_BLOCKS"); return e ? atoi(e) : 0; }();
-        const int target = target_env > 0 ? target_env : (qb == 512 ? 256 : 512);
+        const int target = target_env > 0 ? target_env : (qb >= 384 ? 256 : 512);
 #else
-        const int target = (qb == 512) ? 256 : 512;   // one resident round
+        const int target = (qb >= 384) ? 256 : 512;   // one resident round
 #endif
         const int nqg = (g.L + qb - 1) / qb;
         int sp = (target + nqg * B - 1) / (nqg * B);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
     // key tiles in flight: a tile is requested NBUF-1 steps before it is multiplied.  LDS-DMA lands a tile ~2 us after its
     // request under load, a step's matrix work is 1.45 us: with two buffers (request one step ahead) every step ends waiting
     // for the next tile.  512-query blocks are alone on their CU and can afford four buffers (108 KiB).
-    constexpr int NBUF = (SCR_QUERIES == 512) ? 4 : 2;
+    constexpr int NBUF = (SCR_QUERIES >= 384) ? 4 : 2;
     constexpr int PPW = STEP_PIECES / WAVES;                                  // DMA pieces per wave and step (+1 for the first waves)
     __shared__ __attribute__((aligned(16))) unsigned short sK[NBUF][STEP_ELEMS];     // 54 / 108 KiB
 
@@ -275,7 +275,7 @@ int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float*
 }
 
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
-    const int qblock = (a.qblock == 512) ? 512 : 256;
+    const int qblock = (a.qblock == 512 || a.qblock == 384) ? a.qblock : 256;
     const int n_qgroups = (a.L + qblock - 1) / qblock;
     dim3 grid(n_qgroups * a.splits, a.B);
 #ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
@@ -316,6 +316,9 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 #define SCR_V5(P_) switch (a.variant) { case 0: SCR_L5(P_, 0); break; case 8: SCR_L5(P_, 8); break; case 24: SCR_L5(P_, 24); break; \
                                          case 25: SCR_L5(P_, 25); break; case 9: SCR_L5(P_, 9); break; default: SCR_L5(P_, 57); break; }
         if (pass == 0) { SCR_V5(0) } else { SCR_V5(1) }
+    } else if (qblock == 384) {                                           // (no variants)
+        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
     } else
     if (qw == 2) { if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) } }
     else { if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) } }
@@ -325,6 +328,9 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     if (qblock == 512) {
         if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
+    } else if (qblock == 384) {
+        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
     } else {
         if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_kernel<1, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
