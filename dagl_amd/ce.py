@@ -200,9 +200,9 @@ class CE(nn.Module):
         b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2)                  # NCHW view of the value map
         # dagl.py:216-249  patches of b1 (stride 4 SAME / stride 1) through fc1 / fc2 + ReLU
         wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, self.stride_1,
-                                 T.PAD - t, T.PAD - l, Lh, Lw, relu=True)                     # [B,L,196]
+                                 T.PAD - t, T.PAD - l, Lh, Lw, relu=True, allow_fast=self.scan != "exact")   # [B,L,196]
         x_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc2[0].weight, c, ks), self.fc2[0].bias, ks, self.stride_2,
-                                0, 0, H, W, relu=True)                                        # [B,N,196]
+                                0, 0, H, W, relu=True, allow_fast=self.scan != "exact")             # [B,N,196]
         info = {}
         self._pack_key = None          # the shared workspace is reused with another layout
         out = None

@@ -79,7 +79,7 @@ class _PatchLinear(torch.autograd.Function):
     extracted patches.  ``weight`` is [O, k*k*C] with the patch elements in (kh, kw, c) order."""
 
     @staticmethod
-    def forward(ctx, pmap, weight, bias, k, stride, oy, ox, oh, ow, relu):
+    def forward(ctx, pmap, weight, bias, k, stride, oy, ox, oh, ow, relu, allow_fast=True):
         pmap, weight, bias = pmap.contiguous(), weight.contiguous(), bias.contiguous()
         B, Hp, Wp, C = pmap.shape
         O, K = weight.shape
@@ -87,7 +87,7 @@ class _PatchLinear(torch.autograd.Function):
             raise DaglError("patch_linear: weight does not match the patch size")
         lib = _lib.load()
         H, W = Hp - 2 * PAD, Wp - 2 * PAD
-        fast = _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W) if FAST_FC_FORWARD else None
+        fast = _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W) if (FAST_FC_FORWARD and allow_fast) else None
         with torch.cuda.device(pmap.device):
             if fast is not None:
                 # the two 7x7x16 -> 196 projections (dagl.py:248-249): the inference kernels (split-fp16 matrix cores on the
@@ -111,7 +111,7 @@ class _PatchLinear(torch.autograd.Function):
     def backward(ctx, d_y):
         pmap, weight, y = ctx.saved_tensors
         d_map, d_w, d_b = _patch_linear_backward(pmap, weight, y, ctx.geom, d_y, *ctx.needs_input_grad[:3])
-        return d_map, d_w, d_b, None, None, None, None, None, None, None
+        return d_map, d_w, d_b, None, None, None, None, None, None, None, None
 
 
 def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b):
@@ -237,8 +237,9 @@ def prologue_convs(x, g, theta, thr_conv=None, bias_conv=None):
                                 bias_conv.weight, bias_conv.bias)
 
 
-def patch_linear(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu=False):
-    return _PatchLinear.apply(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu)
+def patch_linear(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu=False, allow_fast=True):
+    """``allow_fast=False`` keeps CE's two patch projections on the fp32 GEMM forward (modules moved to ``scan="exact"``)."""
+    return _PatchLinear.apply(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu, allow_fast)
 
 
 def conv_weight_rows(w: torch.Tensor) -> torch.Tensor:
