@@ -49,6 +49,36 @@ static int read_back(hipStream_t s, const int64_t* dev, int n, int64_t* out) {
     return DAGL_OK;
 }
 
+// Early verdict: the copy is queued behind the kernels that produce the words and followed by an event; the caller queues
+// the rest of its launches and then waits for the EVENT only, so the device keeps working through the host round trip
+// (a stream synchronise would drain it, and the next call's first kernels would start on an idle device).
+static hipEvent_t verdict_event() {
+    static thread_local hipEvent_t ev[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    if (ev[dev] == nullptr && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); ev[dev] = nullptr;
+    }
+    return ev[dev];
+}
+static int read_back_begin(hipStream_t s, const int64_t* dev, int n, bool* pending) {
+    int64_t* pin = pinned_scratch();
+    hipEvent_t ev = pin ? verdict_event() : nullptr;
+    *pending = false;
+    if (ev == nullptr) return DAGL_OK;                      // no pinned memory / event: read_back_end synchronises the stream
+    DAGL_HIP_TRY(hipMemcpyAsync(pin, dev, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    DAGL_HIP_TRY(hipEventRecord(ev, s));
+    *pending = true;
+    return DAGL_OK;
+}
+static int read_back_end(hipStream_t s, const int64_t* dev, int n, bool pending, int64_t* out) {
+    if (!pending) return read_back(s, dev, n, out);
+    DAGL_HIP_TRY(hipEventSynchronize(verdict_event()));
+    const int64_t* pin = pinned_scratch();
+    for (int i = 0; i < n; ++i) out[i] = pin[i];
+    return DAGL_OK;
+}
+
 // ---- optional stage profile: hipEvents recorded at stage boundaries on the caller's stream ------------------
 struct Profile {
     int max_calls = 0, n_calls = 0;
@@ -463,6 +493,16 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if (info) info->range_fallback = 1;
         return rc2;
     };
+    auto overflow_args = [&]() {
+        OvfArgs oa;
+        memset(&oa, 0, sizeof(oa));
+        oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
+        oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
+        oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
+        oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32; oa.part = at<float>(ws, p.o_ovfpart);
+        oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
+        return oa;
+    };
     auto run_tail = [&](const AggArgs& ag2) -> int {
         int r;
         if (dbg_deg || dbg_rowsum)
@@ -479,14 +519,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if (ovf_active) {
             // the few queries whose neighbourhood overflowed the lists are redone one by one (dense rows); their aggregated
             // rows, degrees and softmax mass replace what the clipped lists gave.  Exits at once when nothing is flagged.
-            OvfArgs oa;
-            memset(&oa, 0, sizeof(oa));
-            oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
-            oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
-            oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
-            oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32; oa.part = at<float>(ws, p.o_ovfpart);
-            oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
-            if ((r = launch_overflow_rows(s, oa))) return r;
+            // (their scores and per-chunk statistics were queued ahead of the verdict read-back)
+            const OvfArgs oa = overflow_args();
+            if ((r = launch_overflow_apply(s, oa))) return r;
         }
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -577,12 +612,20 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_refine(s, ra))) return rc;
         if (info) info->path = 3;
         if (mode == DAGL_MODE_ADAPTIVE) {
-            // Dense neighbourhoods need host-side CSR sizing, so the verdict must be read back -- but only after
-            // the optimistic gather + fold are already queued, so the device does not idle during the round trip.
+            // Dense neighbourhoods need host-side CSR sizing, so the verdict must be read back.  Everything it consists of
+            // is known once the flagged queries' chunk statistics exist (their true degrees): the copy is queued there,
+            // the optimistic gather, the flagged rows' weighted sums and the fold behind it, and the host waits for the
+            // copy alone -- the device works through the round trip and through the caller's next launches.
+            if (ovf_active) { const OvfArgs oa = overflow_args(); if ((rc = launch_overflow_scores(s, oa))) return rc; }
+            {
+                const OvfArgs oa = ovf_active ? overflow_args() : OvfArgs();
+                if ((rc = launch_degree_stats(s, BL, nbcnt, stats, ovf_active ? &oa : nullptr))) return rc;
+            }
+            bool pending = false;
+            if ((rc = read_back_begin(s, stats, 5, &pending))) return rc;
             if ((rc = run_tail(ag))) return rc;
-            if ((rc = launch_degree_stats(s, BL, nbcnt, stats))) return rc;
             int64_t hs[5] = {0, 0, 0, 0, 0};
-            if ((rc = read_back(s, stats, 5, hs))) return rc;
+            if ((rc = read_back_end(s, stats, 5, pending, hs))) return rc;
             if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) return rerun_exact();
             if (info) info->redone_queries = hs[2];
             const bool mostly = hs[2] * 2 > (int64_t)BL;                  // most queries overflow: dense regime

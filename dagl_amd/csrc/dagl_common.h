@@ -294,7 +294,9 @@ struct RefineArgs {
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
-int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats);
+struct OvfArgs;
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
+                        const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */);
 
 // per-query dense redo of the queries that overflowed the screened adaptive lists (overflow.hip)
 struct OvfArgs {
@@ -310,7 +312,9 @@ struct OvfArgs {
 };
 constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (one block each)
 constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}
-int launch_overflow_rows(hipStream_t s, const OvfArgs& a);
+int launch_overflow_scores(hipStream_t s, const OvfArgs& a);    // flagged rows: scores against all keys + per-chunk statistics
+int launch_overflow_apply(hipStream_t s, const OvfArgs& a);     // ... weighted sums, combined rows and degrees written back
+int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a);
 int overflow_cap(int N);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,

@@ -248,7 +248,38 @@ int overflow_cap(int N) {
     return (int)(c < 4 ? 4 : c);
 }
 
-int launch_overflow_rows(hipStream_t s, const OvfArgs& a) {
+// total edges and largest degree of a call whose flagged rows have their chunk statistics but not yet their rows:
+// the lists' counts, with every flagged row's clipped count replaced by its true degree (what ovf_combine_kernel will
+// store in nb_cnt afterwards)
+__global__ __launch_bounds__(1024) void degree_stats_flagged_kernel(size_t n_rows, const int32_t* __restrict__ nb_cnt,
+                                                                    int64_t* __restrict__ stats, OvfArgs a) {
+    __shared__ long long ssum[16];
+    __shared__ int smax[16];
+    long long sum = 0; int mx = 0;
+    for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) { const int d = nb_cnt[r]; sum += d; mx = max(mx, d); }
+    const int nf = *a.eff;
+    for (int slot = threadIdx.x; slot < nf; slot += blockDim.x) {
+        double M; int deg; ovf_row_stats(a, slot, M, deg);
+        sum += deg - nb_cnt[a.list[slot]]; mx = max(mx, deg);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0; int m = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); }
+        stats[0] = t; stats[1] = m;
+    }
+}
+
+int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a) {
+    hipLaunchKernelGGL(degree_stats_flagged_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, a);
+    DAGL_LAUNCH_CHECK("degree_stats_flagged_kernel");
+    return DAGL_OK;
+}
+
+int launch_overflow_scores(hipStream_t s, const OvfArgs& a) {
     if (a.cap <= 0) return DAGL_OK;
     hipLaunchKernelGGL(ovf_gather_kernel, dim3((a.cap + 3) / 4), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_gather_kernel");
@@ -270,6 +301,12 @@ int launch_overflow_rows(hipStream_t s, const OvfArgs& a) {
     const int gy = a.cap < 32 ? a.cap : 32;                               // flagged queries are strided over grid.y
     hipLaunchKernelGGL(ovf_stats_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_stats_kernel");
+    return DAGL_OK;
+}
+
+int launch_overflow_apply(hipStream_t s, const OvfArgs& a) {
+    if (a.cap <= 0) return DAGL_OK;
+    const int gy = a.cap < 32 ? a.cap : 32;
     hipLaunchKernelGGL(ovf_attend_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_attend_kernel");
     hipLaunchKernelGGL(ovf_combine_kernel, dim3(a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B), dim3(256), 0, s, a);
