@@ -211,54 +211,69 @@ int launch_edge_softmax(hipStream_t s, const EdgeArgs& a) {
 // ------------------------------------------------------------------------------------------------------
 // gather + weighted sum, value rows read on the fly from the padded NHWC value map
 // ------------------------------------------------------------------------------------------------------
-// thread = (query, float4 column r of the 784-float patch row): r = kh*28 + (kw*4 + c4)
+// block = one query, thread = float4 column r of its 784-float patch row: r = kh*28 + (kw*4 + c4).  The block first turns
+// the list into map offsets in LDS (one key -> (row, column) division per ENTRY instead of one per entry and thread, and
+// no global index load in front of every gather); the gather loop then reads offset and weight from LDS, so the
+// compiler can keep a whole batch of gathers in flight.  Variable-length lists only -- the top-k modes take
+// aggregate_fold_kernel.  A few queries of a long-tailed degree distribution come close to their 256 slots and set the
+// kernel's duration: batches of 16 first, then batches of 8 with the slots past the list's end predicated off (clamped
+// reads, no fma).  The fma order is the list order.
+constexpr int AGG_STAGE = 256;                                 // list entries staged at a time
 __global__ __launch_bounds__(256) void aggregate_direct_kernel(AggArgs a) {
-    const int b = blockIdx.y;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int sh_of[AGG_STAGE];
+    __shared__ float sh_w[AGG_STAGE];
+    const int b = blockIdx.y, q = blockIdx.x, r = threadIdx.x;
     const int C4 = P / 4;                                      // 196
-    if (t >= (size_t)a.g.L * C4) return;
-    const int q = (int)(t / C4), r = (int)(t % C4);
-    const int kh = r / 28, rem = r % 28;
     const size_t ql = (size_t)b * a.g.L + q;
     const int n = a.nb_cnt[ql];
     const size_t lo = a.row_off ? (size_t)a.row_off[ql] : ql * a.width;
     const int32_t* ip = a.nb_idx + lo;
     const float* wp = a.nb_wgt + lo;
-    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH) + rem;
     const int W = a.g.W, Wp = a.g.Wp;
+    const int rc = r < C4 ? r : C4 - 1;                        // (threads 196..255 stage entries, then idle along)
+    const int kh = rc / 28, rem = rc % 28;
+    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH) + (size_t)kh * Wp * (CH / 4) + rem;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j = 0;
-    // (variable-length lists only -- the top-k modes take aggregate_fold_kernel: a long list is a chain of gathers, so eight
-    // neighbours are in flight at a time; the fma order stays the list order)
-    constexpr int AU = 8;
-    for (; j + AU <= n; j += AU) {
-        int id[AU]; float w[AU]; float4 v[AU];
-#pragma unroll
-        for (int u = 0; u < AU; ++u) { id[u] = ip[j + u]; w[u] = wp[j + u]; }
-#pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            const int jy = id[u] / W, jx = id[u] - jy * W;
-            v[u] = vm[((size_t)(jy + kh) * Wp + jx) * (CH / 4)];
+    for (int base = 0; base < n; base += AGG_STAGE) {
+        const int m = min(n - base, AGG_STAGE);
+        if (base > 0) __syncthreads();
+        for (int e = r; e < m; e += 256) {
+            const int id = ip[base + e];
+            const int jy = id / W, jx = id - jy * W;
+            sh_of[e] = (jy * Wp + jx) * (CH / 4);
+            sh_w[e] = wp[base + e];
         }
+        __syncthreads();
+        int j = 0;
+        constexpr int AL = 16;
+        for (; j + AL <= m; j += AL) {
+            float w[AL]; float4 v[AL];
 #pragma unroll
-        for (int u = 0; u < AU; ++u) {
-            acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
-            acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+            for (int u = 0; u < AL; ++u) { v[u] = vm[sh_of[j + u]]; w[u] = sh_w[j + u]; }
+#pragma unroll
+            for (int u = 0; u < AL; ++u) {
+                acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+                acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+            }
+        }
+        constexpr int AU = 8;
+        for (; j < m; j += AU) {
+            float w[AU]; float4 v[AU];
+#pragma unroll
+            for (int u = 0; u < AU; ++u) { const int e = min(j + u, m - 1); v[u] = vm[sh_of[e]]; w[u] = sh_w[e]; }
+#pragma unroll
+            for (int u = 0; u < AU; ++u) {
+                const bool ok = j + u < m;
+                acc.x = ok ? fmaf(w[u], v[u].x, acc.x) : acc.x; acc.y = ok ? fmaf(w[u], v[u].y, acc.y) : acc.y;
+                acc.z = ok ? fmaf(w[u], v[u].z, acc.z) : acc.z; acc.w = ok ? fmaf(w[u], v[u].w, acc.w) : acc.w;
+            }
         }
     }
-    for (; j < n; ++j) {
-        const int id = ip[j]; const float w = wp[j];
-        const int jy = id / W, jx = id - jy * W;
-        const float4 v = vm[((size_t)(jy + kh) * Wp + jx) * (CH / 4)];
-        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
-        acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
-    }
-    reinterpret_cast<float4*>(a.agg)[ql * C4 + r] = acc;
+    if (r < C4) reinterpret_cast<float4*>(a.agg)[ql * C4 + r] = acc;
 }
 
 int launch_aggregate_direct(hipStream_t s, const AggArgs& a) {
-    const size_t items = (size_t)a.g.L * (P / 4);
-    dim3 grid((unsigned)((items + 255) / 256), a.B), block(256);
+    dim3 grid((unsigned)a.g.L, a.B), block(256);
     hipLaunchKernelGGL(aggregate_direct_kernel, grid, block, 0, s, a);
     DAGL_LAUNCH_CHECK("aggregate_direct_kernel");
     return DAGL_OK;

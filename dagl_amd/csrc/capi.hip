@@ -106,7 +106,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
-        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
 static bool g_N_small(int H, int W);
@@ -246,10 +246,11 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int2));     // candidate records (count in slot 0)
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
-    p.ovf_cap = 0; p.o_ovflist = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
+    p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
     if (p.screen && mode == DAGL_MODE_ADAPTIVE && !core) {
         p.ovf_cap = overflow_cap(g.N);
         p.o_ovflist = carve(off, (size_t)p.ovf_cap * sizeof(int32_t));
+        p.o_heavy = carve(off, (size_t)refine_heavy_cap() * sizeof(int32_t));
         p.o_ovfq = carve(off, (size_t)p.ovf_cap * DS * sizeof(float));
         p.o_ovfscores = carve(off, (size_t)B * p.ovf_cap * ((g.N + 31) / 32 * 32) * sizeof(float));
         p.o_ovfpart = carve(off, (size_t)p.ovf_cap * OVF_CHUNKS * OVF_PART_FLOATS * sizeof(float));
@@ -607,6 +608,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if (p.ovf_cap > 0) {
             ra.ovf_list = at<int32_t>(ws, p.o_ovflist); ra.ovf_count = reinterpret_cast<int32_t*>(stats + 3); ra.ovf_cap = p.ovf_cap;
+            ra.heavy_list = at<int32_t>(ws, p.o_heavy); ra.heavy_count = reinterpret_cast<int32_t*>(stats + 3) + 1;   // (cleared with the counters)
             ovf_active = true;
         }
         if ((rc = launch_refine(s, ra))) return rc;

@@ -292,8 +292,10 @@ struct RefineArgs {
     int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
     int32_t* ovf_list; int32_t* ovf_count; int ovf_cap;    // adaptive mode: overflowed queries are listed for the per-query redo
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
+    int32_t* heavy_list; int32_t* heavy_count;      // adaptive mode: queries with many candidates, refined by a whole block each
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
+int refine_heavy_cap();
 struct OvfArgs;
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
                         const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */);

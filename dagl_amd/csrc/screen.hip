@@ -404,13 +404,18 @@ __device__ __forceinline__ bool rf_before(float va, int ka, float vb, int kb) {
     return (va > vb) || (va == vb && ka < kb);
 }
 
-__global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
-    __shared__ int c_idx[4][RF_MAX_CAND];
-    __shared__ float c_val[4][RF_MAX_CAND];
+// One query.  HEAVY = false: a wave on its own (no block-level sync).  HEAVY = true: the RF_HEAVY_WAVES waves of a block on
+// ONE query of the adaptive mode with many candidates -- wave 0 collects the candidates and does everything after the exact
+// scores, the gathers of the feature rows (what a long candidate list costs: 512 candidates are 32 dependent rounds for a
+// single wave) are shared out.  A candidate's exact score does not depend on the wave that forms it: same results.
+constexpr int RF_HEAVY_WAVES = 8;
+constexpr int RF_HEAVY_MIN = 64;                           // candidates from which a query of the adaptive mode is handed over
+constexpr int RF_HEAVY_CAP = 1024;                         // listed queries (a full list: the wave keeps its query)
+template <bool HEAVY>
+__device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t ql, int* __restrict__ ci, float* __restrict__ cv,
+                                             int* sh_total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    dbg_stamp(a.times, blockIdx.x, 0);
-    const size_t ql = (size_t)blockIdx.x * 4 + w;
-    if (ql >= (size_t)a.B * a.L) return;                   // no block-level sync below
+    const bool lead = !HEAVY || w == 0;
     const int b = (int)(ql / a.L);
     const int S2 = a.splits * 2;
     bool overflow = false;
@@ -433,6 +438,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     // 1. gather candidate indices: lane <-> segment; the first three candidates of a segment are fetched together with
     //    its count (one memory round trip), longer segments are rare and finished in a loop
     int total = 0;
+    if (lead)
     for (int s0 = 0; s0 < S2; s0 += 64) {
         const int sgi = s0 + lane;
         const bool sv = sgi < S2;
@@ -448,12 +454,12 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int off = total + incl - cnt;
         if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
-        if (cnt > 0) { c_idx[w][off] = r0.z; c_val[w][off] = __int_as_float(r0.w); }
-        if (cnt > 1) { c_idx[w][off + 1] = r1.x; c_val[w][off + 1] = __int_as_float(r1.y); }
-        if (cnt > 2) { c_idx[w][off + 2] = r1.z; c_val[w][off + 2] = __int_as_float(r1.w); }
+        if (cnt > 0) { ci[off] = r0.z; cv[off] = __int_as_float(r0.w); }
+        if (cnt > 1) { ci[off + 1] = r1.x; cv[off + 1] = __int_as_float(r1.y); }
+        if (cnt > 2) { ci[off + 2] = r1.z; cv[off + 2] = __int_as_float(r1.w); }
         for (int e = 3; e < cnt; ++e) {
             const int2 c = rec[1 + e];
-            c_idx[w][off + e] = c.x; c_val[w][off + e] = __int_as_float(c.y);
+            ci[off + e] = c.x; cv[off + e] = __int_as_float(c.y);
         }
         total += __shfl(incl, 63);
     }
@@ -464,6 +470,15 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     // so its candidates are not rescored here (a thousand candidates = 128 rounds of row gathers by one wave)
     if (a.mode == DAGL_MODE_ADAPTIVE && a.ovf_list != nullptr && total > 2 * a.width) { overflow = true; total = 0; }
     __threadfence_block();
+    if (HEAVY) {
+        if (w == 0 && lane == 0) *sh_total = total;
+        __syncthreads();
+        total = *sh_total;
+    } else if (a.mode == DAGL_MODE_ADAPTIVE && a.heavy_list != nullptr && total >= RF_HEAVY_MIN) {
+        int pos = RF_HEAVY_CAP;
+        if (lane == 0) { pos = atomicAdd(a.heavy_count, 1); if (pos < RF_HEAVY_CAP) a.heavy_list[pos] = (int32_t)ql; }
+        if (__shfl(pos, 0) < RF_HEAVY_CAP) return;          // refine_heavy_kernel takes it from here
+    }
 
     // 1b. top-k modes: most candidates owe their place to the loose threshold of the sampling pass.  With the screened
     //     scores at hand the wave tightens it before any feature row is fetched (that gather is what this kernel costs):
@@ -478,8 +493,8 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         for (int u = 0; u < TU; ++u) {
             const int c = lane + 64 * u;
             const bool have = c < total;
-            key[u] = have ? c_idx[w][c] : -1;
-            const float sv = have ? c_val[w][c] : 0.f;
+            key[u] = have ? ci[c] : -1;
+            const float sv = have ? cv[c] : 0.f;
             ub[u] = fabsf(sv);
             work[u] = have ? ((sv >= 0.f) ? sv : thq) : -1.0f;               // exact screened score, or only "passed theta"
         }
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             const bool keep = key[u] >= 0 && ub[u] >= cut;
             const unsigned long long bal = __ballot(keep);
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep) c_idx[w][pos] = key[u];
+            if (keep) ci[pos] = key[u];
             base += __popcll(bal);
         }
         total = base;
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             for (int u = 0; u < nu; ++u) {
                 const int c = lane + 64 * u;
                 if (c < total && !((taken >> u) & 1u)) {
-                    const float sv = c_val[w][c];
+                    const float sv = cv[c];
                     const float lbv = (sv >= 0.f) ? sv : thq;
                     if (lbv > lm) { lm = lbv; lu = u; }
                 }
@@ -540,26 +555,26 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         for (int u = 0; u < nu; ++u) {
             const int c = lane + 64 * u;
             const bool have = c < total;
-            const int key = have ? c_idx[w][c] : -1;
-            const float ub = have ? fabsf(c_val[w][c]) : 0.f;
+            const int key = have ? ci[c] : -1;
+            const float ub = have ? fabsf(cv[c]) : 0.f;
             const bool keep = key >= 0 && ub >= cut;
             const unsigned long long bal = __ballot(keep);
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep) c_idx[w][pos] = key;                                   // pos <= c: only slots that have been read
+            if (keep) ci[pos] = key;                                   // pos <= c: only slots that have been read
             base += __popcll(bal);
         }
         total = base;
         __threadfence_block();
     }
 
-    dbg_stamp(a.times, blockIdx.x, 1);
+    if (!HEAVY) dbg_stamp(a.times, blockIdx.x, 1);
     // 2. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation
     const float* xb = a.x + (size_t)b * a.rows_x * DS;
 #pragma unroll 2
-    for (int c0 = 0; c0 < total; c0 += 8) {
+    for (int c0 = HEAVY ? 8 * w : 0; c0 < total; c0 += HEAVY ? 8 * RF_HEAVY_WAVES : 8) {
         const int c = c0 + grp;
         const bool okc = c < total;
-        int key = okc ? c_idx[w][c] : 0;
+        int key = okc ? ci[c] : 0;
         const bool inb = key < a.N;                              // zero rows past N may pass a degenerate theta
         if (!inb) key = 0;
         const float* xrow = xb + (size_t)key * DS;
@@ -577,12 +592,16 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         }
         acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
         if (okc && gl == 0) {
-            c_val[w][c] = inb ? (float)acc : -4.0f;
-            if (!inb) c_idx[w][c] = -1;                          // never selected
+            cv[c] = inb ? (float)acc : -4.0f;
+            if (!inb) ci[c] = -1;                          // never selected
         }
     }
     __threadfence_block();
-    dbg_stamp(a.times, blockIdx.x, 2);
+    if (HEAVY) {
+        __syncthreads();
+        if (!lead) return;
+    }
+    if (!HEAVY) dbg_stamp(a.times, blockIdx.x, 2);
 
     int n = 0;
     constexpr int RU = DAGL_LIST_CAP / 64;                 // list entries per lane: entry e lives in lane e % 64, slot e / 64
@@ -598,13 +617,13 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             const int c = c0 + lane;
             float s = 0.f; int key = -1; bool pass = false;
             if (c < total) {
-                s = c_val[w][c]; key = c_idx[w][c];
+                s = cv[c]; key = ci[c];
                 pass = (key >= 0) && (((s - mtq) + bsq) > 0.f);
             }
             const unsigned long long bal = __ballot(pass);
             const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
             if (pass) {
-                if (pos < a.width) { c_val[w][pos] = s; c_idx[w][pos] = key; }   // pos <= c: in-place compaction is safe
+                if (pos < a.width) { cv[pos] = s; ci[pos] = key; }   // pos <= c: in-place compaction is safe
                 else overflow = true;
             }
             n += __popcll(bal);
@@ -612,17 +631,20 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
         }
         overflow = __any(overflow);
         if (n > a.width) n = a.width;
+        // a query that goes to the per-query redo (overflow.hip) gets its row, degree and softmax mass from there: an empty
+        // list here, or the gather walks 256 neighbours whose sum is thrown away
+        if (overflow && a.ovf_list != nullptr) n = 0;
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int e = lane + 64 * u;
-            if (e < n) { my_s[u] = c_val[w][e]; my_key[u] = c_idx[w][e]; }
+            if (e < n) { my_s[u] = cv[e]; my_key[u] = ci[e]; }
         }
     } else if (total <= 64) {
         // top-k of <= 64 candidates by rank counting: (value desc, key asc) is a strict order on the valid candidates, so the
         // number of candidates ahead of a lane's own is its list position.  `total` uniform lane reads, no shuffle chain.
         float v = -3.0f; int key = 0x7fffffff;
         if (lane < total) {
-            v = c_val[w][lane]; key = c_idx[w][lane];
+            v = cv[lane]; key = ci[lane];
             if (key < 0 || (a.mode == DAGL_MODE_ADAPTIVE_TOPK && !(((v - mtq) + bsq) > 0.f))) { v = -3.0f; key = 0x7fffffff; }
         }
         int rank = 0;
@@ -637,13 +659,13 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     } else {
         if (a.mode == DAGL_MODE_ADAPTIVE_TOPK) {
             for (int c = lane; c < total; c += 64)
-                if (!(((c_val[w][c] - mtq) + bsq) > 0.f)) c_idx[w][c] = -1;
+                if (!(((cv[c] - mtq) + bsq) > 0.f)) ci[c] = -1;
             __threadfence_block();
         }
         for (int r = 0; r < a.k; ++r) {
             float bv = -2.f; int bi = 0x7fffffff, bpos = -1;
             for (int t = lane; t < total; t += 64) {
-                const float v = c_val[w][t]; const int id = c_idx[w][t];
+                const float v = cv[t]; const int id = ci[t];
                 if (id >= 0 && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; bpos = t; }
             }
 #pragma unroll
@@ -653,7 +675,7 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             }
             if (bpos < 0) break;
             if (lane == r) { my_s[0] = bv; my_key[0] = bi; }
-            if (lane == 0) c_idx[w][bpos] = -1;
+            if (lane == 0) ci[bpos] = -1;
             __threadfence_block();
             ++n;
         }
@@ -703,7 +725,28 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
+    __shared__ int c_idx[4][RF_MAX_CAND];
+    __shared__ float c_val[4][RF_MAX_CAND];
+    const int w = threadIdx.x >> 6;
+    dbg_stamp(a.times, blockIdx.x, 0);
+    const size_t ql = (size_t)blockIdx.x * 4 + w;
+    if (ql >= (size_t)a.B * a.L) return;                   // no block-level sync below
+    refine_query<false>(a, ql, c_idx[w], c_val[w], nullptr);
     dbg_stamp(a.times, blockIdx.x, 3);
+}
+
+__global__ __launch_bounds__(64 * RF_HEAVY_WAVES) void refine_heavy_kernel(RefineArgs a) {
+    __shared__ int c_idx[RF_MAX_CAND];
+    __shared__ float c_val[RF_MAX_CAND];
+    __shared__ int sh_total;
+    const int n = min(*a.heavy_count, RF_HEAVY_CAP);
+    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        refine_query<true>(a, (size_t)a.heavy_list[slot], c_idx, c_val, &sh_total);
+        __syncthreads();                                     // wave 0 is done with the candidate arrays
+    }
 }
 
 // total / max degree over all queries: one block (a same-address atomic per query would serialise ~12 ns each)
@@ -744,7 +787,12 @@ int launch_refine(hipStream_t s, const RefineArgs& a) {
     hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a);
 #endif
     DAGL_LAUNCH_CHECK("refine_kernel");
+    if (a.heavy_list != nullptr && a.mode == DAGL_MODE_ADAPTIVE) {
+        hipLaunchKernelGGL(refine_heavy_kernel, dim3(256), dim3(64 * RF_HEAVY_WAVES), 0, s, a);
+        DAGL_LAUNCH_CHECK("refine_heavy_kernel");
+    }
     return DAGL_OK;
 }
+int refine_heavy_cap() { return RF_HEAVY_CAP; }
 
 }  // namespace dagl
