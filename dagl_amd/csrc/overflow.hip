@@ -58,8 +58,19 @@ __global__ __launch_bounds__(256) void ovf_scores_small_kernel(OvfArgs a) {
     float acc[OVF_SMALL];
 #pragma unroll
     for (int r = 0; r < OVF_SMALL; ++r) acc[r] = 0.f;
-    for (int c = qd; c < D / 4; c += 4) {
-        const float4 x = xr[c];
+    // the lane's 13 pieces of the key row are requested together (the row is read once, from HBM: one round trip, not 13)
+    constexpr int NC = (D / 4 + 3) / 4;                                          // 13
+    float4 xs[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int c = qd + 4 * u;
+        const float4 raw = xr[c < D / 4 ? c : D / 4 - 1];                        // clamped, zeroed below (no predicated load)
+        xs[u] = (c < D / 4) ? raw : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int c = min(qd + 4 * u, D / 4 - 1);
+        const float4 x = xs[u];
 #pragma unroll
         for (int r = 0; r < OVF_SMALL; ++r)
             if (r < nf) {                                                        // wave-uniform
