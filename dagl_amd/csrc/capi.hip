@@ -248,7 +248,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
     if (p.screen && mode == DAGL_MODE_ADAPTIVE && !core) {
-        p.ovf_cap = overflow_cap(g.N);
+        p.ovf_cap = overflow_cap(g.N, B);
         p.o_ovflist = carve(off, (size_t)p.ovf_cap * sizeof(int32_t));
         p.o_heavy = carve(off, (size_t)refine_heavy_cap() * sizeof(int32_t));
         p.o_ovfq = carve(off, (size_t)p.ovf_cap * DS * sizeof(float));

@@ -317,7 +317,7 @@ constexpr int OVF_PART_FLOATS = P + 8;                         // partial weight
 int launch_overflow_scores(hipStream_t s, const OvfArgs& a);    // flagged rows: scores against all keys + per-chunk statistics
 int launch_overflow_apply(hipStream_t s, const OvfArgs& a);     // ... weighted sums, combined rows and degrees written back
 int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a);
-int overflow_cap(int N);
+int overflow_cap(int N, int B);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);

@@ -251,11 +251,14 @@ __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a) {
     }
 }
 
-// flagged queries a call can redo one by one: 64 MiB of score rows, at most 256 (beyond that the whole call goes dense)
-int overflow_cap(int N) {
+// flagged queries a call can redo one by one: 512 MiB of score rows (every image's keys against all listed rows), at most
+// 2048 -- at 256^2 that is half the queries, i.e. everything short of "most queries overflow" (where the whole call goes
+// dense).  The per-row cost (a row of the product, ~a thousand value patches gathered) stays below the dense formulation's
+// fixed cost up to there; the fp32 scan + CSR lists, which used to take over beyond 256 rows, was slower than either.
+int overflow_cap(int N, int B) {
     const long long ldn = (N + 31) / 32 * 32;
-    long long c = ((long long)64 << 20) / (ldn * 4);
-    if (c > 256) c = 256;
+    long long c = ((long long)512 << 20) / (ldn * 4 * (B > 0 ? B : 1));
+    if (c > 2048) c = 2048;
     return (int)(c < 4 ? 4 : c);
 }
 

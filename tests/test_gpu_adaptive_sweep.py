@@ -1,6 +1,6 @@
 """Adaptive mask over its whole range of densities at small sizes, block against the fp64 oracle: lists only, lists + heavy
-queries (64+ candidates: refine_heavy_kernel), lists + per-query redo (overflow.hip), the CSR redo (more flagged queries
-than the redo holds) and the dense formulation -- the selection path follows the mask, the result must not.
+queries (64+ candidates: refine_heavy_kernel), lists + per-query redo (overflow.hip: up to half the queries at these sizes;
+the CSR redo beyond its capacity is tests/test_gpu_configs.py's 512^2 case) and the dense formulation -- the selection path follows the mask, the result must not.
 (tools/sweep_adaptive.py is the same check over 40 cases.)  Reference: dagl.py:256-265."""
 import numpy as np
 import pytest
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
     (2, 72, 56, 1.7, 3, 3),        # a few heavy queries, 3 redone one by one
     (1, 64, 64, 1.5, 3, 3),        # mean degree 90: 74 heavy queries, 20 redone
     (1, 96, 96, 1.5, 17, 3),       # 187 heavy, 140 redone
-    (1, 128, 128, 1.5, 3, 1),      # more flagged queries than the per-query redo holds: fp32 scan + CSR lists
+    (1, 128, 128, 1.5, 3, 3),      # mean degree 384: a third of the queries redone one by one
     (1, 64, 64, 1.2, 3, 4),        # most queries overflow: dense formulation
 ])
 def test_adaptive_mask_density_sweep(B, H, W, gain, seed, path):

@@ -129,6 +129,42 @@ def test_config3_config4_query_sample_against_all_keys(H, W, mode, k, in_dtype):
     assert normwise(out.float().cpu().numpy(), out_d.cpu().numpy()) <= (2.0 ** -8 if in_dtype == torch.bfloat16 else TOL)
 
 
+def test_adaptive_with_more_flagged_queries_than_the_redo_holds_takes_the_csr_lists():
+    """512^2, adaptive at a density where ~10 % of the queries overflow their lists: more than the per-query redo holds at
+    this size (512 score rows of 1 MiB), fewer than half -- the call is redone by the fp32 scan with two-pass CSR lists
+    (path 1).  64 sampled queries against all 262 144 keys on the oracle."""
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_rows_oracle
+    H = W = 512
+    params = _params(61, "sparse", 1.8)
+    x = torch.from_numpy(make_features(61 + H, 1, 64, H, W))
+    L = (H // 4) * (W // 4)
+    rows = torch.linspace(0, L - 1, 64).long()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = ce_rows_oracle(x, params, rows, mode="adaptive", k=None)
+        ref64 = ce_rows_oracle(x, params, rows, mode="adaptive", k=None, dtype=torch.float64)
+    ce = _module(params, "adaptive", 0)
+    out_d, info = _debug(ce, x.to(_dev()))
+    assert info["path"] == 1 and 512 < info["redone_queries"] <= L // 2, info
+    deg = info["deg"][0].cpu()[rows].numpy().astype(np.int64)
+    ref_deg = ref["deg"].numpy().astype(np.int64)
+    # (a key within rounding of its threshold may flip between two fp32 evaluations)
+    assert np.abs(deg - ref_deg).max() <= 1 and int((deg != ref_deg).sum()) <= 2, (deg, ref_deg)
+    # logits of several hundred turn the last bits of an fp32 score into ~1e-4 of a softmax weight: the yardstick is the
+    # fp64 evaluation, the fp32 oracle gets its own distance to it as slack (as in the 256^2 test above)
+    rowsum, agg = info["rowsum"][0].cpu()[rows].numpy(), _agg_ckk(info["agg"][0].cpu()[rows]).numpy()
+    rs64, agg64 = ref64["rowsum"].float().numpy(), ref64["agg"].float().numpy()
+    e_rs, e_agg = normwise(ref["rowsum"].numpy(), rs64), normwise(ref["agg"].numpy(), agg64)
+    print("rowsum: block vs fp64", normwise(rowsum, rs64), "fp32 oracle vs fp64", e_rs,
+          "| agg: block vs fp64", normwise(agg, agg64), "fp32 oracle vs fp64", e_agg)
+    assert normwise(rowsum, rs64) <= TOL and normwise(agg, agg64) <= TOL
+    assert normwise(rowsum, ref["rowsum"].numpy()) <= TOL + e_rs and normwise(agg, ref["agg"].numpy()) <= TOL + e_agg
+    with torch.no_grad():
+        out = ce(x.to(_dev()))
+    assert normwise(out.cpu().numpy(), out_d.cpu().numpy()) <= TOL
+
+
 def test_config3_bf16_feature_maps_vs_oracle_on_the_rounded_input():
     """bf16 I/O (config 3) against the ORACLE (not against the block itself): the block computes in fp32 on the bf16-rounded
     map, so oracle(x.bf16().float()) is the yardstick; the output carries one bf16 rounding (2^-8 relative)."""
