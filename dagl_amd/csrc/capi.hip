@@ -581,6 +581,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if ((rc = read_back(s, stats, 5, hd))) return rc;
                 if (rt.word != nullptr && (int32_t)hd[4] == rt.tag) return rerun_exact();
                 info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
+                info->redone_queries = hd[2];                       // queries whose degree exceeds the lists' width
             }
             if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
             return DAGL_OK;

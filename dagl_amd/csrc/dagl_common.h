@@ -298,7 +298,8 @@ int launch_refine(hipStream_t s, const RefineArgs& a);
 int refine_heavy_cap();
 struct OvfArgs;
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
-                        const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */);
+                        const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */,
+                        int count_over = 0 /* > 0: stats[2] = rows with a larger degree */);
 
 // per-query dense redo of the queries that overflowed the screened adaptive lists (overflow.hip)
 struct OvfArgs {

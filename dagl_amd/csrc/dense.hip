@@ -499,7 +499,8 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
-    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats);     // total edges, max degree (no per-query atomics)
+    // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics)
+    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats, nullptr, DAGL_LIST_CAP);
 }
 
 }  // namespace dagl

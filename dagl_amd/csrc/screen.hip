@@ -750,26 +750,31 @@ __global__ __launch_bounds__(64 * RF_HEAVY_WAVES) void refine_heavy_kernel(Refin
 }
 
 // total / max degree over all queries: one block (a same-address atomic per query would serialise ~12 ns each)
+// stats[0] = total edges, stats[1] = largest degree; count_over > 0: stats[2] = rows whose degree exceeds it (the dense
+// formulation's count of the queries that would not fit the neighbour lists)
 __global__ __launch_bounds__(1024) void degree_stats_kernel(size_t n_rows, const int32_t* __restrict__ nb_cnt,
-                                                            int64_t* __restrict__ stats) {
+                                                            int64_t* __restrict__ stats, int count_over) {
     __shared__ long long ssum[16];
-    __shared__ int smax[16];
-    long long sum = 0; int mx = 0;
-    for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) { const int d = nb_cnt[r]; sum += d; mx = max(mx, d); }
+    __shared__ int smax[16], sover[16];
+    long long sum = 0; int mx = 0, over = 0;
+    for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) {
+        const int d = nb_cnt[r]; sum += d; mx = max(mx, d); over += (count_over > 0 && d > count_over) ? 1 : 0;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); }
-    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); over += __shfl_xor(over, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; sover[threadIdx.x >> 6] = over; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long t = 0; int m = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); }
+        long long t = 0; int m = 0, ov = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); ov += sover[w]; }
         stats[0] = t; stats[1] = m;
+        if (count_over > 0) stats[2] = ov;
     }
 }
 
-int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs* flagged) {
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs* flagged, int count_over) {
     if (flagged != nullptr && flagged->cap > 0) return launch_degree_stats_flagged(s, n_rows, nb_cnt, stats, *flagged);
-    hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats);
+    hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, count_over);
     DAGL_LAUNCH_CHECK("degree_stats_kernel");
     return DAGL_OK;
 }

@@ -82,9 +82,9 @@ typedef struct dagl_profile dagl_profile;     /* opaque stage profile, see dagl_
 typedef struct dagl_ce_info {
     int64_t required_bytes;   /* workspace this call needed (valid on OK and on ERR_WORKSPACE)      */
     int64_t total_edges;      /* sum of degrees over all queries of the batch                       */
-    int64_t redone_queries;   /* bf16 screen: queries whose candidate slots overflowed and were redone by the
-                                 fp32 scan (-1 = not read back; the debug entry point and the adaptive mode
-                                 read it)                                                             */
+    int64_t redone_queries;   /* bf16 screen: queries whose candidate slots / list overflowed and were redone
+                                 (-1 = not read back; the debug entry point and the adaptive mode read it);
+                                 path 4: queries whose degree exceeds the neighbour lists' width (256)     */
     int32_t max_degree;       /* largest per-query degree                                           */
     int32_t path;             /* 0 = fp32 scan, single-pass lists, 1 = fp32 scan, two-pass CSR (some degree >
                                  FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine,
