@@ -19,7 +19,7 @@
  *   - buffers are caller-owned; nothing is allocated or freed in here;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     all work is enqueued on it; entry points that must read a device value
- *     back (noted below) synchronise that stream, nothing else ever does;
+ *     back (noted below) wait for that copy (an event or a synchronise of that stream), nothing else ever does;
  *   - return value 0 = OK, negative = DAGL_ERR_*; dagl_last_error() gives a
  *     thread-local message; no entry point aborts the process;
  *   - the library holds no global mutable state and is re-entrant.
@@ -125,7 +125,9 @@ size_t dagl_ce_workspace_bytes(int B, int H, int W, int mode, int k);
  * fc1_w [196,784] fc1_b [196]  query projection  (dagl.py:196-199), element order (c,kh,kw)
  * fc2_w [196,784] fc2_b [196]  key   projection  (dagl.py:200-203)
  * out  [B,16,H,W]  the block's return value          (dagl.py:274)
- * Synchronises `stream` once in the adaptive modes (degree read-back).
+ * The adaptive mode waits on the host for its verdict (overflowed queries, degrees): a small copy + event queued
+ * behind the neighbour refinement, in front of the gather / fold -- those are still running when the call returns;
+ * calls that fall back to the dense formulation / CSR lists synchronise `stream` once more for their counters.
  */
 int dagl_ce_forward(void* stream, int B, int H, int W,
                     const float* b1, const float* b2, const float* thr, const float* bias,
