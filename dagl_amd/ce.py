@@ -277,8 +277,9 @@ class CE(nn.Module):
             if self.select_mode == "adaptive":
                 n_pairs = b.shape[0] * (-(-b.shape[2] // 4)) * (-(-b.shape[3] // 4)) * b.shape[2] * b.shape[3]
                 # stay on the dense formulation while the optimistic lists would end there again: most queries beyond the
-                # lists' width (the dense call counts them), or a mask that keeps a sizeable share of all pairs
+                # lists' width (the dense call counts them), or a mask that keeps more than 1/96 of all pairs (the library's
+                # own limit for redoing the overflowed queries one by one)
                 n_q = b.shape[0] * (-(-b.shape[2] // 4)) * (-(-b.shape[3] // 4))
-                self._dense_hint = info["path"] == 4 and (info["total_edges"] > 0.08 * n_pairs or
+                self._dense_hint = info["path"] == 4 and (96 * info["total_edges"] > n_pairs or
                                                           2 * info.get("redone_queries", 0) > n_q)
         return out if in_dtype == torch.float32 else out.to(in_dtype)

@@ -494,6 +494,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if (info) info->range_fallback = 1;
         return rc2;
     };
+    // the per-query redo gathers one value patch per edge of a flagged row (~1 ns each), the dense formulation costs ~9 ps per
+    // (query, key) PAIR whatever the mask: a call whose flagged rows hold more than 1/96 of all pairs goes dense
+    const long long ovf_edge_limit = (long long)((double)BL * (double)g.N / 96.0);
     auto overflow_args = [&]() {
         OvfArgs oa;
         memset(&oa, 0, sizeof(oa));
@@ -502,6 +505,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
         oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32; oa.part = at<float>(ws, p.o_ovfpart);
         oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
+        oa.flagged_edges = stats + 7; oa.edge_limit = ovf_edge_limit;
         return oa;
     };
     auto run_tail = [&](const AggArgs& ag2) -> int {
@@ -625,13 +629,16 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if ((rc = launch_degree_stats(s, BL, nbcnt, stats, ovf_active ? &oa : nullptr))) return rc;
             }
             bool pending = false;
-            if ((rc = read_back_begin(s, stats, 5, &pending))) return rc;
+            if ((rc = read_back_begin(s, stats, 8, &pending))) return rc;
             if ((rc = run_tail(ag))) return rc;
-            int64_t hs[5] = {0, 0, 0, 0, 0};
-            if ((rc = read_back_end(s, stats, 5, pending, hs))) return rc;
+            int64_t hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((rc = read_back_end(s, stats, 8, pending, hs))) return rc;
             if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) return rerun_exact();
             if (info) info->redone_queries = hs[2];
-            const bool mostly = hs[2] * 2 > (int64_t)BL;                  // most queries overflow: dense regime
+            // most queries overflow, or the flagged rows are too heavy to redo one by one (the attend kernels saw the same
+            // word and left them alone): dense regime
+            const bool heavy_rows = ovf_active && hs[2] > 0 && hs[2] <= p.ovf_cap && hs[7] > ovf_edge_limit;
+            const bool mostly = hs[2] * 2 > (int64_t)BL || heavy_rows;
             if (hs[2] == 0 || (!mostly && ovf_active && hs[2] <= p.ovf_cap)) {   // (few overflowed queries: redone in-stream)
                 if (info) { info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1]; }
                 if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;

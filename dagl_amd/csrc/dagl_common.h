@@ -312,6 +312,9 @@ struct OvfArgs {
     float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys
     float* agg; int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;
     float* part;                                               // [cap, OVF_CHUNKS, OVF_PART_FLOATS] per-chunk partial results
+    int64_t* flagged_edges; long long edge_limit;              // device word: sum of the flagged rows' degrees (degree_stats_flagged);
+                                                               // beyond the limit the weighted sums are NOT formed (the host sees the
+                                                               // same word and sends the call to the dense formulation)
 };
 constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (one block each)
 constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}

@@ -142,6 +142,9 @@ __device__ __forceinline__ void ovf_row_stats(const OvfArgs& a, int slot, double
 }
 
 __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
+    // (a value patch per edge: rows that are dense cost ~1 ns per edge here, the dense formulation 9 ps per PAIR -- past the
+    // limit the host, looking at the same word, runs that instead)
+    if (a.flagged_edges != nullptr && *a.flagged_edges > a.edge_limit) return;
     __shared__ double shd[4];
     __shared__ float4 part[4][P / 4];                                       // the four waves' partial rows (12.25 KiB)
     const int nf = *a.eff;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
 }
 
 __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a) {
+    if (a.flagged_edges != nullptr && *a.flagged_edges > a.edge_limit) return;
     const int nf = *a.eff;
     const int tid = threadIdx.x;
     const int C4 = P / 4;
@@ -269,21 +273,23 @@ __global__ __launch_bounds__(1024) void degree_stats_flagged_kernel(size_t n_row
                                                                     int64_t* __restrict__ stats, OvfArgs a) {
     __shared__ long long ssum[16];
     __shared__ int smax[16];
-    long long sum = 0; int mx = 0;
+    __shared__ long long sfl[16];
+    long long sum = 0, fl = 0; int mx = 0;
     for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) { const int d = nb_cnt[r]; sum += d; mx = max(mx, d); }
     const int nf = *a.eff;
     for (int slot = threadIdx.x; slot < nf; slot += blockDim.x) {
         double M; int deg; ovf_row_stats(a, slot, M, deg);
-        sum += deg - nb_cnt[a.list[slot]]; mx = max(mx, deg);
+        sum += deg - nb_cnt[a.list[slot]]; mx = max(mx, deg); fl += deg;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); }
-    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); fl += __shfl_xor(fl, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; sfl[threadIdx.x >> 6] = fl; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long t = 0; int m = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); }
+        long long t = 0, f = 0; int m = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); f += sfl[w]; }
         stats[0] = t; stats[1] = m;
+        if (a.flagged_edges != nullptr) *a.flagged_edges = f;       // what redoing the flagged rows one by one would gather
     }
 }
 
