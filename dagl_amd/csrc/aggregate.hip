@@ -471,43 +471,57 @@ int launch_fold(hipStream_t s, int B, const Grid& g, const float* agg, float* ou
 // ------------------------------------------------------------------------------------------------------
 // stage mix: out = conv1x1(cat(4 heads)) + x   (CES.forward, DN_Gray/model/dagl.py:114,116,118)
 // ------------------------------------------------------------------------------------------------------
-// fp32 MFMA 16x16x4: one wave = 64 outputs x 16 pixels; A = the 64x64 mix weights in registers, B[channel][pixel]
-// straight from the NCHW concat map (16 consecutive pixels of a channel plane = one 64-byte run); the result tile has
-// pixels along the lanes, so the NCHW stores are 64-byte runs too.
+// fp32 MFMA 16x16x4: one wave = 64 outputs x MIX_TILES tiles of 16 pixels; A = the 64x64 mix weights in registers (loaded
+// once per wave: with one tile per wave the 64 weight loads per lane outweighed the 16 pixel loads), B[channel][pixel]
+// straight from the NCHW concat map (16 consecutive pixels of a channel plane = one 64-byte run, the wave's tiles are
+// consecutive: whole lines get used); the result tile has pixels along the lanes, so the NCHW stores are 64-byte runs too.
+constexpr int MIX_TILES = 4;
 __global__ __launch_bounds__(256) void stage_mix_kernel(int HW, const float* __restrict__ cat, const float* __restrict__ x,
                                                         const float* __restrict__ mix_w, const float* __restrict__ mix_b,
                                                         float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const int p0 = (blockIdx.x * 4 + wave) * 16;
-    if (p0 >= HW) return;
-    int px = p0 + i; if (px >= HW) px = HW - 1;
+    const int pw = (blockIdx.x * 4 + wave) * (16 * MIX_TILES);
+    if (pw >= HW) return;
     float w[4][16];                                            // B fragment (n, T): w[o = n*16 + i][c = 4T + g]
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int T = 0; T < 16; ++T) w[n][T] = mix_w[(n * 16 + i) * 64 + 4 * T + g];
-    const float* cb = cat + (size_t)b * 64 * HW + px;
-    f32x4 acc[4];
+    float bo[4][4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        const float a = cb[(size_t)(4 * T + g) * HW];
+        for (int r = 0; r < 4; ++r) bo[n][r] = mix_b[n * 16 + 4 * g + r];
+    float av[MIX_TILES][16];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][T], a, acc[n], 0, 0, 0);
+    for (int t = 0; t < MIX_TILES; ++t) {
+        int px = pw + 16 * t + i; if (px >= HW) px = HW - 1;
+        const float* cb = cat + (size_t)b * 64 * HW + px;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) av[t][T] = cb[(size_t)(4 * T + g) * HW];
     }
-    // D[row = output n*16 + 4g + r][col = pixel p0 + i]
-    const int pp = p0 + i;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int t = 0; t < MIX_TILES; ++t) {
+        f32x4 acc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = n * 16 + 4 * g + r;
-            if (pp < HW) {
-                const size_t idx = ((size_t)b * 64 + o) * HW + pp;
-                out[idx] = (acc[n][r] + mix_b[o]) + x[idx];
+        for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int T = 0; T < 16; ++T)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][T], av[t][T], acc[n], 0, 0, 0);
+        // D[row = output n*16 + 4g + r][col = pixel]
+        const int pp = pw + 16 * t + i;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = n * 16 + 4 * g + r;
+                if (pp < HW) {
+                    const size_t idx = ((size_t)b * 64 + o) * HW + pp;
+                    out[idx] = (acc[n][r] + bo[n][r]) + x[idx];
+                }
             }
         }
     }
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(256) void stage_mix_kernel(int HW, const float* __r
 
 int launch_stage_mix(hipStream_t s, int B, int HW, const float* cat, const float* x, const float* mix_w,
                      const float* mix_b, float* out) {
-    dim3 grid((HW + 63) / 64, B), block(256);
+    dim3 grid((HW + 64 * MIX_TILES - 1) / (64 * MIX_TILES), B), block(256);
     hipLaunchKernelGGL(stage_mix_kernel, grid, block, 0, s, HW, cat, x, mix_w, mix_b, out);
     DAGL_LAUNCH_CHECK("stage_mix_kernel");
     return DAGL_OK;
