@@ -367,10 +367,23 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         float* bias_ws = at<float>(ws, p.o_bias);
         const bool thr_heads = (mode != DAGL_MODE_TOPK);
         const size_t map_f = (size_t)imgs * g.Hp * g.Wp * CH;
+        const bool conv_merged = heads > 1 && p.split16;       // a stage's heads: their g / theta convolutions are ONE launch
         for (int hd = 0; hd < heads; ++hd) {
             const FusedIn& f = fin[hd];
             unsigned char* convw = p.split16 ? at<unsigned char>(ws, p.o_convw) + (size_t)hd * CONV_W16_BYTES : nullptr;
             if (convw && !(mode_flags & DAGL_FLAG_WEIGHTS_PACKED) && (rc = launch_pack_conv_weight16(s, f.g_w, f.th_w, convw))) return rc;
+            if (conv_merged && hd == heads - 1) {
+                ConvHeadSet hs = {};
+                for (int h2 = 0; h2 < heads; ++h2) {
+                    hs.x[h2] = fin[h2].x; hs.w[h2] = at<unsigned char>(ws, p.o_convw) + (size_t)h2 * CONV_W16_BYTES;
+                    hs.gb[h2] = fin[h2].g_b; hs.tb[h2] = fin[h2].th_b;
+                }
+                hs.imgs = imgs;
+                if ((rc = launch_conv_pair16_heads(s, heads, imgs, g, hs, b2p, at<uint16_t>(ws, p.o_maphi), at<uint16_t>(ws, p.o_maplo),
+                                                   prepared ? reinterpret_cast<uint32_t*>(stats) : nullptr, prepared ? 8 : 0,
+                                                   (prepared && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
+                                                   (prepared && p.screen) ? B * n_qgroups : 0, rt))) return rc;
+            }
             // default path: the key/query map is only ever consumed as split fp16 (project16), so the prologue
             // writes the hi / lo maps itself and no fp32 copy exists
             if ((rc = launch_prologue(s, imgs, g, f.x, f.g_w, f.g_b, f.th_w, f.th_b, f.thr_w, f.thr_b, f.bias_w, f.bias_b,
@@ -384,7 +397,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
                                       (prepared && hd == 0) ? 8 : 0,
                                       (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
-                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt, convw))) return rc;
+                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt, convw, conv_merged))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {

@@ -138,6 +138,11 @@ int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2
 // ---- stage launchers (defined in the .hip files) ------------------------------------------------
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
+// g / theta convolutions of up to four heads (a CES stage) in one launch: per-head input, packed weights, biases
+struct ConvHeadSet { const float* x[4]; const unsigned char* w[4]; const float* gb[4]; const float* tb[4]; int imgs; };
+int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ConvHeadSet& hs, float* b2p,
+                             uint16_t* b1_hi, uint16_t* b1_lo, uint32_t* clear_a, int clear_a_words, uint32_t* clear_b,
+                             int clear_b_words, RangeTag range);
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p /* may be null */, float* b2p, float* thr,
@@ -147,7 +152,8 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     bool defer_thr_reduce = false /* leave the partial sums in thr_part: launch_query_thresholds finishes them */,
                     uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
                     /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */,
-                    RangeTag range = RangeTag(), const unsigned char* conv_w16 = nullptr /* packed g / theta weights (split-fp16 path) */);
+                    RangeTag range = RangeTag(), const unsigned char* conv_w16 = nullptr /* packed g / theta weights (split-fp16 path) */,
+                    bool skip_conv = false /* the g / theta convolutions of all heads were one launch_conv_pair16_heads */);
 constexpr size_t CONV_W16_BYTES = (18 + 2) * 16 * 128 + 256;   // packed conv weights of one head + range flag
 int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w, unsigned char* img);
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);

@@ -196,10 +196,9 @@ int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w
     return DAGL_OK;
 }
 
-__global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows_per_block,
-                                                          const float* __restrict__ x,
-                                                          const unsigned char* __restrict__ wimg, const float* __restrict__ g_b,
-                                                          const float* __restrict__ th_b,
+// (hs: per-head input, packed weights and biases; batch index b = head * hs.imgs + image -- a CES stage's four heads are
+// one launch: 256 blocks of 16 rows instead of four launches of 256 blocks of 4 rows, each of which loads the 40 KiB of weights)
+__global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows_per_block, ConvHeadSet hs,
                                                           float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
                                                           int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
@@ -215,11 +214,16 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
     const int lane = tid & 63;
     const int i = lane & 15, kg = lane >> 4;
     const int b = blockIdx.z;
+    const int head = b / hs.imgs;
+    const float* __restrict__ x = hs.x[head];
+    const unsigned char* __restrict__ wimg = hs.w[head];
+    const float* __restrict__ g_b = hs.gb[head];
+    const float* __restrict__ th_b = hs.tb[head];
     const int x0 = blockIdx.x * PRO_TW;
     const int y0 = blockIdx.y * rows_per_block;
     int y1 = y0 + rows_per_block; if (y1 > H) y1 = H;
     const int Hp = H + 2 * PADPIX, Wp = W + 2 * PADPIX;
-    const float* xb = x + (size_t)b * PC * H * W;
+    const float* xb = x + (size_t)(b - head * hs.imgs) * PC * H * W;
 
     // staging: wave w owns channels 16w..16w+15 of staged pixels 0..63 (lane = pixel: coalesced row loads, one 16-byte
     // LDS store per 8 channels); the two halo pixels 64, 65 x 64 channels are one value each for threads 0..127
@@ -549,11 +553,29 @@ __global__ void thr_bias_reduce_kernel(size_t n /* B*L */, const float* __restri
     bias[i] = ((p0.y + p1.y) + (p2.y + p3.y)) + bias_b[0];
 }
 
+int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ConvHeadSet& hs, float* b2p,
+                             uint16_t* b1_hi, uint16_t* b1_lo, uint32_t* clear_a, int clear_a_words, uint32_t* clear_b,
+                             int clear_b_words, RangeTag range) {
+    const int B = heads * imgs;
+    const int strips = (g.W + PRO_TW - 1) / PRO_TW;
+    constexpr int target = 256;                       // one block per CU over the whole launch, at least 2 rows per block
+    int chunks = (target + strips * B - 1) / (strips * B);
+    if (chunks > (g.H + 1) / 2) chunks = (g.H + 1) / 2;
+    if (chunks < 1) chunks = 1;
+    const int rows_per_block = (g.H + chunks - 1) / chunks;
+    chunks = (g.H + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
+                       b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
+    DAGL_LAUNCH_CHECK("conv_pair16_kernel");
+    return DAGL_OK;
+}
+
 int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const float* g_w, const float* g_b,
                     const float* th_w, const float* th_b, const float* thr_w, const float* thr_b,
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
                     uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, bool defer_thr_reduce, uint32_t* clear_a,
-                    int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range, const unsigned char* conv_w16) {
+                    int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range, const unsigned char* conv_w16,
+                    bool skip_conv) {
     int rcz;
     if (!borders_zero) {
         if ((rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p))) return rcz;
@@ -567,10 +589,14 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     if (chunks < 1) chunks = 1;
     const int rows_per_block = (g.H + chunks - 1) / chunks;
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
-    if (b1p == nullptr && b1_hi != nullptr) {
+    if (skip_conv) {
+        // (the caller ran launch_conv_pair16_heads for all its heads)
+    } else if (b1p == nullptr && b1_hi != nullptr) {
         if (conv_w16 == nullptr) { set_error("launch_prologue: the split-fp16 convolutions need their packed weights"); return DAGL_ERR_INVALID; }
-        hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, conv_w16,
-                           g_b, th_b, b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
+        ConvHeadSet hs = {};
+        hs.x[0] = x; hs.w[0] = conv_w16; hs.gb[0] = g_b; hs.tb[0] = th_b; hs.imgs = B;
+        hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
+                           b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
     } else {
         hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
