@@ -135,7 +135,9 @@ def _prewarm(step, seconds):
     return n
 
 
-def _time_steps(step, steps, warmup):
+def _time_steps(step, steps, warmup, prewarm_s=0.0):
+    if prewarm_s > 0:                      # building a case leaves the GPU idle for a second: same clock pre-warm as the main run
+        _prewarm(step, prewarm_s)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -146,9 +148,13 @@ def _time_steps(step, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+EXTRA_PREWARM_S = 0.15
+
+
 def extra_configs(dev):
-    """The other BASELINE configurations and regimes, each a short run (3 warm-ups + 10 timed steps, < 0.5 s of GPU time)
-    inside the one driver-timed command, so that their numbers are measured by the driver's run as well."""
+    """The other BASELINE configurations and regimes, each a short run (0.15 s of untimed passes for the clock -- see
+    --prewarm --, 3 warm-ups + 10 timed steps) inside the one driver-timed command, so that their numbers are measured by
+    the driver's run as well."""
     from dagl_amd import ops
     from dagl_amd.ce import CE
     from dagl_amd.synth import make_ce_params, make_features
@@ -176,7 +182,7 @@ def extra_configs(dev):
             ws, fs = seeds.get(name, (2024, 100))
             ce = head(ws, variant, gain, mode, k)
             x = torch.from_numpy(make_features(fs, 1, 64, size, size)).to(dev).to(dt)
-            ms = _time_steps(lambda: ce(x), 10, 3)
+            ms = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
             L = (size // 4) ** 2
             info = ce.last_info or {}
             out[name] = {"what": what, "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": size * size,
@@ -194,7 +200,7 @@ def extra_configs(dev):
         ws = ops.Workspace()
         ops.ces_stage_forward(x, prm, mix_w, mix_b, mode="topk", k=8, workspace=ws)      # packs the weights into the workspace
         ms = _time_steps(lambda: ops.ces_stage_forward(x, prm, mix_w, mix_b, mode="topk", k=8, workspace=ws,
-                                                       weights_packed=True), 10, 3)       # (CES._stage's protocol)
+                                                       weights_packed=True), 10, 3, EXTRA_PREWARM_S)     # (CES._stage's protocol)
         out["256x256_ces_stage_topk8"] = {"what": "one CES stage (4 heads + 1x1 mix + residual, dagl_ces_stage_forward)",
                                           "ms_per_step": ms, "patches_per_s": 4 * 4096 / (ms * 1e-3), "L": 4096, "N": 65536}
     return out
