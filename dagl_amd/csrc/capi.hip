@@ -383,6 +383,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                                    prepared ? reinterpret_cast<uint32_t*>(stats) : nullptr, prepared ? 8 : 0,
                                                    (prepared && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
                                                    (prepared && p.screen) ? B * n_qgroups : 0, rt))) return rc;
+                if (thr_heads) {
+                    ThrHeadSet th = {};
+                    for (int h2 = 0; h2 < heads; ++h2) { th.x[h2] = fin[h2].x; th.thr_w[h2] = fin[h2].thr_w; th.bias_w[h2] = fin[h2].bias_w; }
+                    th.imgs = imgs;
+                    if ((rc = launch_thr_bias_heads(s, heads, imgs, g, th, at<float>(ws, p.o_thrpart)))) return rc;
+                }
             }
             // default path: the key/query map is only ever consumed as split fp16 (project16), so the prologue
             // writes the hi / lo maps itself and no fp32 copy exists

@@ -140,6 +140,9 @@ int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float*
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
 // g / theta convolutions of up to four heads (a CES stage) in one launch: per-head input, packed weights, biases
 struct ConvHeadSet { const float* x[4]; const unsigned char* w[4]; const float* gb[4]; const float* tb[4]; int imgs; };
+struct ThrHeadSet { const float* x[4]; const float* thr_w[4]; const float* bias_w[4]; int imgs; };     // thr / bias heads likewise
+int launch_thr_bias_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ThrHeadSet& hs,
+                          float* thr_part /* per head [4][imgs][L][2] partial sums */);
 int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ConvHeadSet& hs, float* b2p,
                              uint16_t* b1_hi, uint16_t* b1_lo, uint32_t* clear_a, int clear_a_words, uint32_t* clear_b,
                              int clear_b_words, RangeTag range);

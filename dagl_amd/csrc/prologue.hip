@@ -393,9 +393,8 @@ constexpr int TB_CG = 16;                   // channels per block
 constexpr int TB_GROUPS = PC / TB_CG;       // 4
 constexpr int TB_N = TB_CG * KS * TB_XW;    // staged floats: 14784
 constexpr int TB_PER = (TB_N + 255) / 256;  // 58 per thread
-__global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, int B, const float* __restrict__ x,
-                                                       const float* __restrict__ thr_w, const float* __restrict__ bias_w,
-                                                       float* __restrict__ part_out /* [4][B][L][2] */) {
+__global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, ThrHeadSet hs,
+                                                       float* __restrict__ part_out /* per head [4][imgs][L][2] */) {
     __shared__ __attribute__((aligned(16))) float tile[TB_N + 256];                  // 58.8 KiB
     __shared__ __attribute__((aligned(16))) float wl[2][TB_CG][KS][8];               // 7 KiB: both heads' weights, rows of 7 (+1)
     __shared__ float part[4][TB_Q][2];
@@ -405,9 +404,12 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, int B, const flo
     const int chunks = (gr.Lw + TB_Q - 1) / TB_Q;
     const int qr = blockIdx.x / chunks, q0 = (blockIdx.x - qr * chunks) * TB_Q;
     const int b = blockIdx.y, grp = blockIdx.z;
+    const int head = b / hs.imgs, img = b - head * hs.imgs;
+    const float* __restrict__ thr_w = hs.thr_w[head];
+    const float* __restrict__ bias_w = hs.bias_w[head];
     const int c0 = grp * TB_CG;
     const int y0 = QS * qr - gr.pt, x0 = QS * q0 - gr.pl;
-    const float* xc0 = x + ((size_t)b * PC + c0) * gr.N;
+    const float* xc0 = hs.x[head] + ((size_t)img * PC + c0) * gr.N;
     float v[TB_PER];
 #pragma unroll
     for (int j = 0; j < TB_PER; ++j) {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, int B, const flo
     if (hh == 0) { part[w][qi][0] = s1; part[w][qi][1] = s2; }
     __syncthreads();
     if (tid < TB_Q && q0 + tid < gr.Lw) {
-        const size_t o = (((size_t)grp * B + b) * gr.L + (size_t)qr * gr.Lw + q0 + tid) * 2;
+        const size_t o = (size_t)head * 8 * hs.imgs * gr.L + (((size_t)grp * hs.imgs + img) * gr.L + (size_t)qr * gr.Lw + q0 + tid) * 2;
         part_out[o] = (part[0][tid][0] + part[1][tid][0]) + (part[2][tid][0] + part[3][tid][0]);
         part_out[o + 1] = (part[0][tid][1] + part[1][tid][1]) + (part[2][tid][1] + part[3][tid][1]);
     }
@@ -471,9 +473,8 @@ __global__ __launch_bounds__(256) void thr_bias_kernel(Grid gr, int B, const flo
 constexpr int TB4_XW = 4 * TB_Q + 8;                       // 136 staged columns = 34 float4
 constexpr int TB4_F4 = TB_CG * KS * (TB4_XW / 4);          // 3808 float4 per block
 constexpr int TB4_PER = (TB4_F4 + 255) / 256;              // 15 per thread
-__global__ __launch_bounds__(256) void thr_bias4_kernel(Grid gr, int B, const float* __restrict__ x,
-                                                        const float* __restrict__ thr_w, const float* __restrict__ bias_w,
-                                                        float* __restrict__ part_out /* [4][B][L][2] */) {
+__global__ __launch_bounds__(256) void thr_bias4_kernel(Grid gr, ThrHeadSet hs,
+                                                        float* __restrict__ part_out /* per head [4][imgs][L][2] */) {
     __shared__ __attribute__((aligned(16))) float4 tile4[TB4_F4 + 32];               // 60 KiB
     __shared__ __attribute__((aligned(16))) float wl[2][TB_CG][KS][8];
     __shared__ float part[4][TB_Q][2];
@@ -483,9 +484,12 @@ __global__ __launch_bounds__(256) void thr_bias4_kernel(Grid gr, int B, const fl
     const int chunks = (gr.Lw + TB_Q - 1) / TB_Q;
     const int qr = blockIdx.x / chunks, q0 = (blockIdx.x - qr * chunks) * TB_Q;
     const int b = blockIdx.y, grp = blockIdx.z;
+    const int head = b / hs.imgs, img = b - head * hs.imgs;
+    const float* __restrict__ thr_w = hs.thr_w[head];
+    const float* __restrict__ bias_w = hs.bias_w[head];
     const int c0 = grp * TB_CG;
     const int y0 = QS * qr - gr.pt, xa = QS * q0 - 4;                                 // (pl = 1: window of query q0 starts at xa + 3)
-    const float* xc0 = x + ((size_t)b * PC + c0) * gr.N;
+    const float* xc0 = hs.x[head] + ((size_t)img * PC + c0) * gr.N;
     constexpr int RW4 = TB4_XW / 4;                                                   // 34
     float4 v[TB4_PER];
 #pragma unroll
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void thr_bias4_kernel(Grid gr, int B, const fl
     if (hh == 0) { part[w][qi][0] = s1; part[w][qi][1] = s2; }
     __syncthreads();
     if (tid < TB_Q && q0 + tid < gr.Lw) {
-        const size_t o = (((size_t)grp * B + b) * gr.L + (size_t)qr * gr.Lw + q0 + tid) * 2;
+        const size_t o = (size_t)head * 8 * hs.imgs * gr.L + (((size_t)grp * hs.imgs + img) * gr.L + (size_t)qr * gr.Lw + q0 + tid) * 2;
         part_out[o] = (part[0][tid][0] + part[1][tid][0]) + (part[2][tid][0] + part[3][tid][0]);
         part_out[o + 1] = (part[0][tid][1] + part[1][tid][1]) + (part[2][tid][1] + part[3][tid][1]);
     }
@@ -567,6 +571,18 @@ int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, 
     hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
                        b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
     DAGL_LAUNCH_CHECK("conv_pair16_kernel");
+    return DAGL_OK;
+}
+
+int launch_thr_bias_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ThrHeadSet& hs, float* thr_part) {
+    const dim3 tb_grid(g.Lh * ((g.Lw + TB_Q - 1) / TB_Q), heads * imgs, TB_GROUPS);
+    bool aligned = true;
+    for (int h = 0; h < heads; ++h) aligned = aligned && (reinterpret_cast<uintptr_t>(hs.x[h]) & 15u) == 0;
+    if (g.W % 4 == 0 && g.W >= 4 && g.pl == 1 && aligned)
+        hipLaunchKernelGGL(thr_bias4_kernel, tb_grid, dim3(256), 0, s, g, hs, thr_part);
+    else
+        hipLaunchKernelGGL(thr_bias_kernel, tb_grid, dim3(256), 0, s, g, hs, thr_part);
+    DAGL_LAUNCH_CHECK("thr_bias_kernel");
     return DAGL_OK;
 }
 
@@ -605,12 +621,12 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     }
     if (thr != nullptr) {
         // thr_part: [4][B][L][2] floats of scratch for the channel groups' partial sums
-        const dim3 tb_grid(g.Lh * ((g.Lw + TB_Q - 1) / TB_Q), B, TB_GROUPS);
-        if (g.W % 4 == 0 && g.W >= 4 && g.pl == 1 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0)
-            hipLaunchKernelGGL(thr_bias4_kernel, tb_grid, dim3(256), 0, s, g, B, x, thr_w, bias_w, thr_part);
-        else
-            hipLaunchKernelGGL(thr_bias_kernel, tb_grid, dim3(256), 0, s, g, B, x, thr_w, bias_w, thr_part);
-        DAGL_LAUNCH_CHECK("thr_bias_kernel");
+        if (!skip_conv) {                                          // (else: one launch_thr_bias_heads for all the caller's heads)
+            ThrHeadSet hs = {};
+            hs.x[0] = x; hs.thr_w[0] = thr_w; hs.bias_w[0] = bias_w; hs.imgs = B;
+            const int rct = launch_thr_bias_heads(s, 1, B, g, hs, thr_part);
+            if (rct) return rct;
+        }
         const size_t n = (size_t)B * g.L;
         if (!defer_thr_reduce)
         hipLaunchKernelGGL(thr_bias_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, thr_part, thr_b,
