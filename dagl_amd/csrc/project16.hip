@@ -106,6 +106,9 @@ struct Proj16Args {
     uint16_t* feat_h[2];                                            // optional bf16 copies [B, rows_alloc_h, DSH]
     int rows_alloc[2], rows_alloc_h[2];
     int n_items[2], segs[2];                                        // 32-patch work items per image / per grid row
+    int lin[2];                                                     // items = 32 consecutive patches in ROW-MAJOR order (across row ends)
+                                                                    // instead of 32 patches of one row: no idle slots at the row ends
+                                                                    // (a 72-pixel row used to cost 3 items = 96 slots)
     int n_blocks_q, n_blocks_k;
     int n_full, n_split_groups, batch;                              // 1-D grid: full blocks, then 7 single-tile blocks per split group
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
@@ -126,7 +129,8 @@ constexpr int P16_PD_Q = 2;                            // query blocks (their pe
 constexpr int P16_QRING = 3;
 constexpr int P16_STAGE_B = 14 * 1024;                 // bytes per weight stage (= 224*64, whole DMA pieces)
 constexpr int P16_OFF_A = P16_RING * P16_STAGE_B;      // 56 KiB: patch region
-constexpr int P16_APART = 1280;                        // keys: one part (hi or lo) of a staged map row: 38 px x 32 B, padded
+constexpr int P16_APX = 44;                            // keys: staged pixels per map row: 32 + 6 of a row segment, + 6 for the wrap (below)
+constexpr int P16_APART = P16_APX * 32;                // keys: one part (hi or lo) of a staged map row: 44 px x 32 B
 constexpr int P16_AROW = 2 * P16_APART;                // keys: one staged map row per wave: hi | lo
 constexpr int P16_LDS = P16_OFF_A + P16_QRING * P16_BW * 2048;      // 80 KiB (keys use 56 + 4 x 2 x 2.5 = 76)
 static_assert(P16_BW * 2 * P16_AROW <= P16_QRING * P16_BW * 2048, "key row rings must fit the patch region");
@@ -154,8 +158,20 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const bool wave_valid = item < n_items;
     if (!wave_valid) item = n_items - 1;
     const int row_len = KEYS ? gr.W : gr.Lw;
-    const int gy = item / segs_per_row;
-    const int gx0 = (item % segs_per_row) * 32;
+    // the item's patches: lin -> n = 32 item + i in row-major order: nA of them in row gy from pixel gx0 on, the rest at the
+    // start of row gy + 1 (rows are at least 32 wide in this mode); else 32 patches of row gy from gx0 on
+    const bool lin = pa.lin[which] != 0;
+    int gy, gx0, nA, base_row, lim;
+    if (lin) {
+        base_row = item * 32;
+        gy = base_row / row_len; gx0 = base_row - gy * row_len;
+        nA = row_len - gx0 < 32 ? row_len - gx0 : 32;
+        lim = (KEYS ? gr.N : gr.L) - base_row;
+    } else {
+        gy = item / segs_per_row; gx0 = (item % segs_per_row) * 32;
+        nA = 32; base_row = gy * row_len + gx0; lim = row_len - gx0;
+    }
+    const int off_i = (i < nA) ? i : i + 6;            // keys: the patch's pixel position in the staged row (segment B behind A's halo)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
     f32x16 hh[NT];
@@ -186,24 +202,28 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const unsigned short* ahi = nullptr; const unsigned short* alo = nullptr;   // queries: this lane's patch corner
     size_t krow0 = 0;                                                            // keys: halfs offset of (row py, pixel gx0)
     if (KEYS) {
-        krow0 = (((size_t)b * gr.Hp + gy) * gr.Wp + gx0) * CH;
+        krow0 = (size_t)b * gr.Hp * gr.Wp * CH;
     } else {
-        int gx = gx0 + i; if (gx >= row_len) gx = row_len - 1;
-        const int py = QS * gy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
+        int qy = gy, gx = gx0 + i;
+        if (lin) { int q = base_row + i; if (q > gr.L - 1) q = gr.L - 1; qy = q / row_len; gx = q - qy * row_len; }
+        else if (gx >= row_len) gx = row_len - 1;
+        const int py = QS * qy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
         const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
         ahi = pa.map_hi + aoff; alo = pa.map_lo + aoff;
     }
-    auto issue_row = [&](int r) {                      // keys: map row gy + r (38 pixels, hi | lo) -> row buffer r & 1
-        if (VAR == 6) return;
+    auto issue_row = [&](int r) {                      // keys: kernel row r of the item (44 pixels, hi | lo) -> row buffer r & 1
+        if (VAR == 6) return;                          // positions 0 .. nA+5: map row gy + r from pixel gx0; from nA+6 on: row gy+1+r from pixel 0
         const unsigned dst = lds0 + P16_OFF_A + wave * (2 * P16_AROW) + (r & 1) * P16_AROW;
-        const size_t rowoff = krow0 + (size_t)r * gr.Wp * CH;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                  // pieces: hi px 0-31, hi px 32-37 (12 lanes), lo px 0-31, lo px 32-37
-            int p = (j & 1) * 32 + (lane >> 1);
-            if (gx0 + p > gr.Wp - 1) p = gr.Wp - 1 - gx0;                         // stay inside the map row
-            const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + rowoff + (size_t)p * CH + 8 * (lane & 1);
+        for (int j = 0; j < 4; ++j) {                  // pieces: hi px 0-31, hi px 32-43 (24 lanes), lo px 0-31, lo px 32-43
+            const int p = (j & 1) * 32 + (lane >> 1);
+            int row = gy + r, px = gx0 + p;
+            if (p >= nA + 6) { row += 1; px = p - (nA + 6); }
+            if (px > gr.Wp - 1) px = gr.Wp - 1;                                   // stay inside the map
+            if (row > gr.Hp - 1) row = gr.Hp - 1;
+            const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
             const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
-            if ((j & 1) == 0 || lane < 12) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
+            if ((j & 1) == 0 || lane < 2 * (P16_APX - 32)) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
         }
     };
     auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back
@@ -244,7 +264,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int kh = 0; kh < KS; ++kh) {
             if (kh + 1 < KS) issue_row(kh + 1);
             if (kh + 2 < KS) issue_wrow(kh + 2);
-            const unsigned char* sa0 = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + i * 32 + 16 * h;
+            const unsigned char* sa0 = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + off_i * 32 + 16 * h;
             const unsigned char* sb = smem + (kh % P16_RING) * P16_STAGE_B;
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
@@ -275,7 +295,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         const int kh = step / KS, kw = step - kh * KS;
         const unsigned char* sa;
         int lo_off;
-        if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (i + kw) * 32 + 16 * h; lo_off = P16_APART; }
+        if (KEYS) { sa = smem + P16_OFF_A + wave * (2 * P16_AROW) + (kh & 1) * P16_AROW + (off_i + kw) * 32 + 16 * h; lo_off = P16_APART; }
         else { sa = smem + P16_OFF_A + (step % P16_QRING) * (P16_BW * 2048) + wave * 2048 + lane * 16; lo_off = 1024; }
         const f16x8 fa_hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
         const f16x8 fa_lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
@@ -324,7 +344,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which][head];
-    const int grid_row_base = gy * row_len + gx0;
+    const int grid_row_base = base_row;
     float* csum = reinterpret_cast<float*>(smem);                       // [4 waves][NT*32] (the weight ring is dead now)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -334,7 +354,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool ok = wave_valid && (gx0 + rr < row_len);
+            const bool ok = wave_valid && (rr < lim);
             float v = hh[n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
@@ -406,7 +426,9 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(int n_blocks_k, cons
     if (lane == 0) colsum[(size_t)b * DS + col] = t;
 }
 
-int project16_key_blocks(const Grid& g) { return (((g.W + 31) / 32) * g.H + P16_BW - 1) / P16_BW; }
+static inline bool p16_keys_linear(const Grid& g) { return g.W >= 32; }       // a wrapped item ends inside the NEXT row
+static inline int p16_key_items(const Grid& g) { return p16_keys_linear(g) ? (g.N + 31) / 32 : ((g.W + 31) / 32) * g.H; }
+int project16_key_blocks(const Grid& g) { return (p16_key_items(g) + P16_BW - 1) / P16_BW; }
 
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
@@ -425,7 +447,8 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.rows_alloc[0] = feat_rows(g.N); pa.rows_alloc[1] = feat_rows(g.L);
     pa.rows_alloc_h[0] = feat_rows_h(g.N); pa.rows_alloc_h[1] = feat_rows_h(g.L);
     pa.segs[0] = (g.W + 31) / 32; pa.segs[1] = (g.Lw + 31) / 32;
-    pa.n_items[0] = pa.segs[0] * g.H; pa.n_items[1] = pa.segs[1] * g.Lh;
+    pa.lin[0] = p16_keys_linear(g) ? 1 : 0; pa.lin[1] = 1;           // (queries gather per lane: any row length)
+    pa.n_items[0] = p16_key_items(g); pa.n_items[1] = (g.L + 31) / 32;
     const int nbq = (which & 2) ? (pa.n_items[1] + P16_BW - 1) / P16_BW : 0;
     const int nbk = (which & 1) ? project16_key_blocks(g) : 0;
     pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
