@@ -5,15 +5,18 @@
 
 A "step" is one forward of one ``CE`` head (prologue convolutions + the whole HIP block) over one batch
 of synthetic feature maps ``[batch,64,size,size]`` that is already resident in HBM.  Default workload =
-BASELINE.json configs[1]: 256x256x64 features, k=8, fp32, one GPU.  Multi-GPU (launched by
-``python -m torch.distributed.run``) is plain image-batch data parallel: every rank runs the same step
-on its own images (weak scaling), no collective on the data path; timing = barrier + sync on both
-sides, MAX over ranks.
+BASELINE.json configs[1]: 256x256x64 features, k=8, fp32, one GPU.  Multi-GPU is plain image-batch data
+parallel, one process per GPU: every rank runs the same step on its own images (weak scaling), no collective
+on the data path; timing = barrier + sync on both sides, MAX over ranks.  ``python bench.py --gpus N`` starts
+its own N ranks (dagl_amd/launch.py: re-executes itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+rank 0 prints); launched under ``python -m torch.distributed.run --nproc-per-node N`` it uses the ranks it is
+given.  The line carries ``n_ranks_seen`` (the process group's own world size) and every rank's device name.
 
 Rank 0 prints ONE JSON line: whole-job query-patches/s, plus
-  roofline      the dominant kernel (streamed similarity + select, fp32 matrix cores): algorithmic FLOP
-                per launch / its mean duration, measured live with hipEvents at the stage boundaries of
-                the very steps that are timed (dagl_profile_*, recorded on the launch stream)
+  roofline      the dominant kernel (screen_kernel<1>: the full L x N similarity scan + candidate filter on the
+                bf16 matrix cores, v_mfma_f32_32x32x16_bf16; the fp32-MFMA score_select_kernel with --scan exact):
+                algorithmic FLOP per launch / its mean duration, measured live with hipEvents at the stage
+                boundaries of the very steps that are timed (dagl_profile_*, recorded on the launch stream)
   roofline_gather  the stand-alone gather/weighted-sum kernel over materialised value rows (HBM bound,
                 algorithmic bytes (k+1)*4P+8k per query) and the fused in-block gather
   cpu_baseline  the dense CPU oracle (a port of the reference's algorithm) timed on this box's host cores
@@ -69,7 +72,45 @@ def parse():
     ap.add_argument("--cpu-size", type=int, default=0, help="feature-map size of the CPU-baseline sample (default: --size)")
     ap.add_argument("--cpu-runs", type=int, default=5, help="timed forwards of the CPU baseline (median reported)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (other BASELINE configs, short runs)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test: the same spawn / rendezvous / barrier / MAX-over-ranks / one-JSON-line protocol with "
+                         "a trivial CPU step on the gloo backend (tests/test_bench_spawn.py); not a measurement")
     return ap.parse_args()
+
+
+def rank_devices(dist, name):
+    """Every rank's device name, gathered on the job's own process group (shows that RCCL / gloo saw N ranks)."""
+    if dist is None or not dist.is_initialized():
+        return [name]
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, name)
+    return names
+
+
+def stub_bench(args, world, rank):
+    """``--stub``: the launch protocol end to end without a GPU -- gloo process group, per-rank step on the CPU, barrier +
+    MAX-over-ranks timing, rank 0 prints the one JSON line."""
+    import torch.distributed as dist
+    from dagl_amd.shard import reduce_max_seconds
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = torch.randn(64, 64, generator=torch.Generator().manual_seed(rank))
+    for _ in range(args.warmup):
+        (a @ a).sum()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        (a @ a).sum()
+    dist.barrier()
+    elapsed = reduce_max_seconds(time.perf_counter() - t0, dist)
+    devices = rank_devices(dist, f"cpu:{rank}")
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/s (launcher self-test, not a measurement)", "value": world * args.steps / elapsed,
+                          "unit": "steps/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "devices": devices,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "stub": True}), flush=True)
+    dist.destroy_process_group()
 
 
 def cpu_baseline(args, params, mode, k, x_cpu=None, hip_out=None):
@@ -278,6 +319,7 @@ def train_bench(args, dev, dist, world, rank):
     if dist is not None:
         dist.barrier()
     elapsed = reduce_max_seconds(time.perf_counter() - t0, dist, dev)
+    devices = rank_devices(dist, torch.cuda.get_device_name(dev))
     n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
     allreduce_ms = None
     if dist is not None:
@@ -293,7 +335,8 @@ def train_bench(args, dev, dist, world, rank):
         allreduce_ms = reduce_max_seconds((time.perf_counter() - t1) / 10, dist, dev) * 1e3
     if rank == 0:
         line = {"metric": f"RR train crops/s (fwd+bwd+Adam) @{args.crop}x{args.crop} {args.mode} k={args.k}",
-                "value": world * B * args.steps / elapsed, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+                "value": world * B * args.steps / elapsed, "unit": "crops/s", "n_gpus": world,
+                "n_ranks_seen": dist.get_world_size() if dist is not None else 1, "devices": devices, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"BASELINE configs[4] (sparse regime): RR with 12 CE heads, crops [{B},{args.colors},"
@@ -308,16 +351,29 @@ def train_bench(args, dev, dist, world, rank):
 
 def main():
     args = parse()
+    from dagl_amd.launch import launched_by_torchrun, spawn_ranks
+    if not launched_by_torchrun() and (args.gpus > 1 or os.environ.get("DAGL_BENCH_FORCE_SPAWN")):
+        # plain ``python bench.py --gpus N``: start the N ranks ourselves (one process per GPU), rank 0 prints the line
+        if not args.stub:
+            visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if visible < args.gpus:
+                raise SystemExit(f"bench.py: {args.gpus} GPUs requested, {visible} visible on this node")
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                         f"(use --nproc-per-node {args.gpus}, or drop the launcher: bench.py spawns its own ranks)")
+    if args.stub:
+        return stub_bench(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("DAGL_BENCH_FORCE_DIST"):          # (the env switch exercises the RCCL path on one GPU)
+    if world > 1 or os.environ.get("DAGL_BENCH_FORCE_DIST") or os.environ.get("DAGL_SPAWNED"):   # (the switches exercise the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: used for the barriers/max only
@@ -404,6 +460,7 @@ def main():
         torch.cuda.synchronize()
         ce.profile = None
     elapsed = reduce_max_seconds(elapsed, dist, dev)
+    devices = rank_devices(dist, torch.cuda.get_device_name(dev))
     stage_ms = prof.read()
     info = info_box["info"] if args.stage else ce.last_info
 
@@ -482,7 +539,8 @@ def main():
         line = {
             "metric": "graph-attn fwd query-patches/s @256x256x64 k=8" if (H, mode, k, args.stage) == (256, "topk", 8, False)
                       else f"graph-attn fwd query-patches/s @{H}x{W}x64 {mode} k={k}",
-            "value": total_patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "value": total_patches / elapsed, "unit": "patches/s", "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1, "devices": devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "prewarm": {"seconds": args.prewarm, "untimed_steps": prewarm_steps,

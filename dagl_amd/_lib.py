@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
-MAX_TOPK = 32
+MAX_TOPK = 64
+ABI_VERSION = 300          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -64,7 +65,7 @@ SIGNATURES = {
     "dagl_ce_core_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dagl_ce_core_backward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 17 + [_sz]),
     "dagl_ce_core_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
+    "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
     "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i] + [_vp] * 14 + [_sz]),
     "dagl_gemm_f32_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
@@ -120,6 +121,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError => the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if lib.dagl_version() != ABI_VERSION:
+        raise DaglError(f"{LIB_PATH} reports ABI version {lib.dagl_version()}, this binding expects {ABI_VERSION}: "
+                        "rebuild it (`python -m dagl_amd.build --force`)")
     if torch.cuda.is_available():
         # once per process: the kernels are gfx950 code objects (MFMA shapes, LDS-DMA, 160 KiB LDS)
         rc = lib.dagl_device_check()

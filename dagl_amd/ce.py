@@ -64,10 +64,11 @@ class _GraphCoreDense(torch.autograd.Function):
     fp32 matrix cores (``dagl_ce_core_dense_forward`` / ``_backward``, dense_train.hip)."""
 
     @staticmethod
-    def forward(ctx, wq_rows, x_rows, b2, thr, bias, ws_f, ws_b, sink, want_info):
+    def forward(ctx, wq_rows, x_rows, b2, thr, bias, ws_f, ws_b, sink, want_info, exact=False):
         wq_rows, x_rows, b2 = wq_rows.contiguous(), x_rows.contiguous(), b2.contiguous()
         thr_c, bias_c = thr.contiguous(), bias.contiguous()
-        out, saved = ops.ce_core_dense_forward(wq_rows, x_rows, b2, thr_c, bias_c, workspace=ws_f, want_info=want_info)
+        out, saved = ops.ce_core_dense_forward(wq_rows, x_rows, b2, thr_c, bias_c, workspace=ws_f, want_info=want_info,
+                                               exact=exact)
         ctx.ws_b, ctx.thr_shape = ws_b, thr.shape
         ctx.save_for_backward(wq_rows, x_rows, b2, thr_c, bias_c, saved["lse"], saved["mu"])
         if sink is not None and saved["info"] is not None:
@@ -79,7 +80,30 @@ class _GraphCoreDense(torch.autograd.Function):
         wq_rows, x_rows, b2, thr, bias, lse, mu = ctx.saved_tensors
         d_wq, d_x, d_b2, d_thr, d_bias = ops.ce_core_dense_backward(d_out.contiguous().float(), wq_rows, x_rows, b2, thr, bias,
                                                                     dict(lse=lse, mu=mu), workspace=ctx.ws_b)
-        return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None
+        return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None, None
+
+
+class _EvalLazyGrad(torch.autograd.Function):
+    """An eval() block inside an autograd-enabled forward (the reference's test loop, DN_Gray/trainer.py:128-140, builds a
+    graph it never uses): forward on the inference kernels, nothing saved but the input; a backward -- rare -- recomputes
+    the block on the differentiable path (``CE._forward_train``) and hands its gradients on."""
+
+    @staticmethod
+    def forward(ctx, module, k_eff, n_params, b, *params):
+        ctx.module, ctx.n_params = module, n_params
+        ctx.save_for_backward(b, *params)
+        with torch.no_grad():
+            return module._forward_infer(b, k_eff)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        b, *params = ctx.saved_tensors
+        with torch.enable_grad():
+            bb = b.detach().requires_grad_(True)
+            out = ctx.module._forward_train(bb)
+            used = [p for p in params]
+            grads = torch.autograd.grad(out, [bb] + used, d_out.contiguous().float(), allow_unused=True)
+        return (None, None, None) + tuple(grads)
 
 
 class CE(nn.Module):
@@ -110,7 +134,7 @@ class CE(nn.Module):
         # variant (GReccR2b_3mh_1-checkpoint.py:242-250) and the intersection available:
         #   "adaptive" | "topk" | "adaptive_topk", with k = ``select_k``.
         self.select_mode = "adaptive"
-        self.select_k = min(num_edge, MAX_TOPK)
+        self.select_k = num_edge       # the fixed-k variant's own default is 50; k > MAX_TOPK raises in the top-k modes
         # "screened": bf16 matrix-core screen of all L*N scores + exact refinement of the survivors (default);
         # "exact": every score on the fp32 matrix cores.  Same neighbours either way.
         self.scan = "screened"
@@ -118,6 +142,8 @@ class CE(nn.Module):
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
         self._pack_epoch = 0           # bumped by invalidate_packed()
+        self._f32_cache = {}           # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
+        self._train_calls = 0
         self._last_call = None
         self._calls_since_range_check = 0
         self._train_dense = False      # the differentiable path met dense neighbourhoods last time (dense_train.hip)
@@ -135,7 +161,8 @@ class CE(nn.Module):
         if self.scan == "exact" or self._last_call is None:
             return True
         shape, dev = self._last_call
-        bad = ops.ce_range_check(shape, self.select_mode, self.select_k, self._ws, dev)
+        bad = ops.ce_range_check(shape, self.select_mode, min(int(self.select_k), shape[2] * shape[3]) if self.select_mode != "adaptive" else 0,
+                                 self._ws, dev)
         if bad:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
         return not bad
@@ -153,6 +180,7 @@ class CE(nn.Module):
         ``.half()`` (``_apply``) and ``load_state_dict`` call it themselves."""
         self._pack_epoch += 1
         self._pack_key = None
+        self._f32_cache = {}
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
@@ -164,6 +192,29 @@ class CE(nn.Module):
 
     def extra_repr(self):
         return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
+
+    def _params_f32(self):
+        """The block's parameters as contiguous fp32 tensors.  fp32 modules: the parameters themselves.  ``model.half()`` /
+        ``.bfloat16()`` modules (the reference's ``--precision half`` test path, DN_Gray/model/__init__.py:98-99,
+        option.py:76-78): converted once and kept until the parameter changes (storage or version counter) -- the block
+        computes in fp32 on the values the half-precision weights hold."""
+        out = {}
+        for n, p in self.named_parameters():
+            if n.startswith("W."):
+                continue
+            t = p.detach()
+            if t.dtype == torch.float32:
+                out[n] = t.contiguous()
+                continue
+            if t.dtype not in (torch.float16, torch.bfloat16):
+                raise DaglError(f"CE: parameter {n} has dtype {t.dtype}; fp32, fp16 or bf16 expected")
+            tag = (t.data_ptr(), t._version, t.dtype, t.device)
+            hit = self._f32_cache.get(n)
+            if hit is None or hit[0] != tag:
+                hit = (tag, t.float().contiguous())
+                self._f32_cache[n] = hit
+            out[n] = hit[1]
+        return out
 
     def _prologue(self, b):
         """The four prologue convolutions of dagl.py:208-215 as stock torch ops (MIOpen) -- kept for the
@@ -185,6 +236,10 @@ class CE(nn.Module):
         op with its own backward: neighbour lists (top-k modes, adaptive masks keeping <= 64 keys per query) or, for
         denser masks, the dense formulation."""
         from . import train_ops as T
+        if any(p.dtype != torch.float32 for p in self.parameters()):
+            raise DaglError("CE: the differentiable path needs fp32 parameters (the reference's --precision half is a test-time "
+                            "switch, DN_Gray/model/__init__.py:98-99); run half-precision modules under torch.no_grad()")
+        self._last_call = None         # the shared workspace is about to be reused with the training layout: no range word to poll
         B, _, H, W = b.shape
         ks, c = self.ksize, self.inter_channels
         t, _bo = same_pad_amounts(H, ks, self.stride_1)
@@ -211,20 +266,33 @@ class CE(nn.Module):
             # degrees back (one host synchronisation) to notice when the masks have become sparse enough for the lists
             self._train_dense_calls += 1
             probe = self._train_dense_calls % 16 == 1
-            out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, probe)
+            out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, probe, self.scan == "exact")
             if probe and 0 <= info.get("max_degree", -1) <= FAST_CAP:
                 self._train_dense = False
         else:
             try:
-                out = _GraphCore.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, self.select_k, self.scan == "exact",
+                out = _GraphCore.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, min(int(self.select_k), H * W), self.scan == "exact",
                                        self._ws, self._ws_bwd, info)
             except DaglError as e:
                 if self.select_mode != "adaptive" or e.code != ERR_UNSUPPORTED:
                     raise
                 self._train_dense, self._train_dense_calls = True, 1
-                out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, True)
+                out = _GraphCoreDense.apply(wq_rows, x_rows, b2, thr, bias, self._ws, self._ws_bwd, info, True, self.scan == "exact")
         if info:
             self.last_info = info
+        # range guard of the training path: its split-fp16 forward kernels (the two patch projections: |b1| < 4094, |w_fc| < 64; the
+        # streamed dense core: |feature| < 937) NaN-fill what they hand out once an operand leaves that range -- never wrong
+        # numbers -- and the dense core re-runs itself in fp32 whenever it reads statistics back.  The module finds out from
+        # that flag, or by looking at its output every 64th call (one synchronisation), and moves to scan = "exact" (fp32
+        # GEMM forward, no range limit); the call at hand is then repeated on that path.
+        if self.scan != "exact":
+            self._train_calls += 1
+            left = bool(info.get("range_fallback"))
+            if not left and self._train_calls % 64 == 1:
+                left = bool(torch.isnan(out).any())
+            if left:
+                self._note_range_violation("a training call left the split-fp16 range")
+                return self._forward_train(b)
         return out
 
     def forward(self, b: torch.Tensor) -> torch.Tensor:
@@ -232,6 +300,15 @@ class CE(nn.Module):
             raise DaglError(f"CE.forward: expected [B,{self.in_channels},H,W], got {tuple(b.shape)}")
         if not b.is_cuda:
             raise DaglError("CE.forward: input must be on the GPU; dagl_amd has no CPU path")
+        if self.select_mode not in ("adaptive", "topk", "adaptive_topk"):
+            raise DaglError(f"CE.select_mode {self.select_mode!r}: expected 'adaptive', 'topk' or 'adaptive_topk'")
+        k_eff = 0
+        if self.select_mode != "adaptive":
+            # no silent clamp: the fixed-k variant takes exactly min(num_edge, N) neighbours (GReccR2b_3mh_1-checkpoint.py:243)
+            if not 1 <= int(self.select_k) <= MAX_TOPK:
+                raise DaglError(f"CE: select_k={self.select_k} outside [1, {MAX_TOPK}] (include/dagl_ce.h DAGL_MAX_TOPK); "
+                                "the top-k modes keep per-query lists of that width")
+            k_eff = min(int(self.select_k), b.shape[2] * b.shape[3])
         in_dtype = b.dtype
         if in_dtype in (torch.bfloat16, torch.float16):
             # reduced-precision feature maps (BASELINE config 3): the block itself computes in fp32 with the bf16
@@ -239,26 +316,39 @@ class CE(nn.Module):
             b = b.float()
         elif in_dtype != torch.float32:
             raise DaglError(f"CE.forward: unsupported dtype {in_dtype}")
-        # differentiable route: a gradient can reach the input, or the module is training its own parameters.  An eval()
-        # module fed a constant input stays on the inference path even when autograd is on (the reference's test loop
-        # relies on the long-dead ``volatile`` flag, DN_Gray/trainer.py:132, i.e. runs with autograd enabled)
-        if torch.is_grad_enabled() and (b.requires_grad or
-                                        (self.training and any(p.requires_grad for p in self.parameters()))):
-            out = self._forward_train(b.contiguous())
-            return out if in_dtype == torch.float32 else out.to(in_dtype)
-        params = {n: p.detach().contiguous() for n, p in self.named_parameters() if not n.startswith("W.")}
+        # differentiable route: the module is training (its own parameters or a gradient for its input).  An eval() module
+        # stays on the inference kernels even when autograd is on -- the reference's test loop relies on the long-dead
+        # ``volatile`` flag (DN_Gray/trainer.py:132), i.e. evaluates the whole network with autograd enabled, and inside
+        # RR / CES the block's input then "requires grad" although nobody will ask for one.  Such a call keeps its place in
+        # the autograd graph (_EvalLazyGrad): should a backward arrive after all, it recomputes the block on the
+        # differentiable path then -- same gradients, paid only when used.
+        if torch.is_grad_enabled():
+            if self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
+                out = self._forward_train(b.contiguous())
+                return out if in_dtype == torch.float32 else out.to(in_dtype)
+            if b.requires_grad:
+                ps = [p for p in self.parameters() if p.requires_grad]
+                out = _EvalLazyGrad.apply(self, k_eff, len(ps), b.contiguous(), *ps)
+                return out if in_dtype == torch.float32 else out.to(in_dtype)
+        out = self._forward_infer(b, k_eff)
+        return out if in_dtype == torch.float32 else out.to(in_dtype)
+
+    def _forward_infer(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
+        """The inference kernels (``dagl_ce_forward_fused``): fp32 [B,64,H,W] in, fp32 [B,16,H,W] out, no autograd."""
+        params = self._params_f32()
         # the packed copies of fc1/fc2 and of the g / theta convolutions live in this module's private workspace: skip
         # repacking while neither the weights (torch bumps ._version on every in-place update) nor the call geometry changed
         wsb = self._ws.peek(b.device)
-        key = (tuple(b.shape), self.select_mode, self.select_k, self.scan, self._pack_epoch,
-               tuple((params[n].data_ptr(), params[n]._version) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")),
+        src = dict(self.named_parameters())       # (keyed on the module's own tensors: the fp32 copies of half weights follow them)
+        key = (tuple(b.shape), self.select_mode, k_eff, self.scan, self._pack_epoch,
+               tuple((src[n].data_ptr(), src[n]._version) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")),
                wsb.data_ptr() if wsb is not None else 0)
         # dense regime: the edge statistics (and with them a host synchronisation) are only fetched every 16th call, to
         # notice when the neighbourhoods have become sparse again
         hint = self._dense_hint and self.select_mode == "adaptive" and self.scan != "exact"
         self._dense_calls = self._dense_calls + 1 if hint else 0
         want_info = (not hint) or (self._dense_calls % 16 == 1) or self.profile is not None
-        out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=self.select_k,
+        out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
                                          dense_hint=hint, want_info=want_info)
@@ -282,4 +372,4 @@ class CE(nn.Module):
                 n_q = b.shape[0] * (-(-b.shape[2] // 4)) * (-(-b.shape[3] // 4))
                 self._dense_hint = info["path"] == 4 and (96 * info["total_edges"] > n_pairs or
                                                           2 * info.get("redone_queries", 0) > n_q)
-        return out if in_dtype == torch.float32 else out.to(in_dtype)
+        return out

@@ -29,13 +29,13 @@ int hip_fail(hipError_t e, const char* what) {
     return DAGL_ERR_HIP;
 }
 
-// 64 bytes of pinned host memory per calling thread for the small device->host read-backs (a pageable
+// 128 bytes of pinned host memory per calling thread for the small device->host read-backs (a pageable
 // destination would make every hipMemcpyAsync a blocking staged copy).  Allocated once, never freed.
 static int64_t* pinned_scratch() {
     static thread_local int64_t* p = nullptr;
     if (p == nullptr) {
         void* q = nullptr;
-        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&q, 128, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         p = static_cast<int64_t*>(q);
     }
     return p;
@@ -130,6 +130,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     if (mode != DAGL_MODE_ADAPTIVE)
         DAGL_REQUIRE(k >= 1 && k <= DAGL_MAX_TOPK, "dagl: k=%d outside [1,%d]", k, DAGL_MAX_TOPK);
     DAGL_REQUIRE((int64_t)H * W < (1ll << 30), "dagl: image too large");
+    if (mode != DAGL_MODE_ADAPTIVE && (int64_t)k > (int64_t)H * W) k = H * W;     // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
     p.g = make_grid(H, W);
     p.B = B; p.mode = mode; p.k = k;
     p.kslots = (mode == DAGL_MODE_ADAPTIVE) ? 0 : topk_slots(k);
@@ -300,6 +301,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int rc = make_plan(B, H, W, mode_flags, k, p, core != nullptr);
     if (rc) return rc;
     const int mode = p.mode;
+    k = p.k;                                                     // (clamped to the number of keys)
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
                 info->redone_queries = -1; info->range_fallback = 0; info->reserved = 0; }
     DAGL_REQUIRE(out && (core || (fc1_w && fc1_b && fc2_w && fc2_b)), "dagl_ce_forward: null tensor pointer");
@@ -348,7 +350,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // range guard of the split-fp16 kernels (dagl_common.h RangeTag); the fp32 path and the training entry point have no
     // such range
     RangeTag rt;
-    if (p.split16 && !core) {
+    if (p.split16 && (!core || core->lse)) {        // (the streamed dense core splits the features into fp16 halves too)
         rt.word = reinterpret_cast<int32_t*>(stats + 4); rt.done = reinterpret_cast<int32_t*>(stats + 5); rt.tag = next_call_tag();
     }
 
@@ -602,7 +604,10 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if (info) {
                 int64_t hd[5] = {0, 0, 0, 0, 0};
                 if ((rc = read_back(s, stats, 5, hd))) return rc;
-                if (rt.word != nullptr && (int32_t)hd[4] == rt.tag) return rerun_exact();
+                if (rt.word != nullptr && (int32_t)hd[4] == rt.tag) {
+                    if (core) { info->range_fallback = 1; return DAGL_OK; }      // (output NaN-filled; dagl_ce_core_dense_forward re-runs the GEMM form)
+                    return rerun_exact();
+                }
                 info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
                 info->redone_queries = hd[2];                       // queries whose degree exceeds the lists' width
             }
@@ -747,7 +752,7 @@ using namespace dagl;
 
 extern "C" {
 
-int dagl_version(void) { return 100; }
+int dagl_version(void) { return DAGL_ABI_VERSION; }
 
 const char* dagl_last_error(void) { return g_err; }
 
@@ -894,7 +899,7 @@ int dagl_ces_stage_forward(void* stream, int B, int H, int W, const float* x, co
     return launch_stage_mix((hipStream_t)stream, B, H * W, cat, x, mix_w, mix_b, out);
 }
 
-int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, const void* workspace, size_t ws_bytes,
+int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
                         int* violated) {
     DAGL_REQUIRE(workspace && violated, "dagl_ce_range_check: null pointer");
     Plan p;
@@ -904,9 +909,12 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, cons
     *violated = 0;
     if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range
     int64_t h[2] = {0, 0};
-    const int64_t* st = reinterpret_cast<const int64_t*>(static_cast<const char*>(workspace) + p.o_stats);
+    int64_t* st = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + p.o_stats);
     if ((rc = read_back((hipStream_t)stream, st + 4, 2, h))) return rc;
-    *violated = ((int32_t)h[0] != 0 && (int32_t)h[0] == (int32_t)h[1]) ? 1 : 0;   // the last completed call left the range
+    // sticky: the word keeps the tag of the last call that left the range until it is read here (calls that reuse a
+    // prepared workspace do not clear it), so a poll every n-th call sees a violation of ANY call since the last poll
+    *violated = ((int32_t)h[0] != 0) ? 1 : 0;
+    if (*violated) DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream));
     return DAGL_OK;
 }
 
@@ -1018,22 +1026,27 @@ size_t dagl_ce_core_dense_workspace_bytes(int B, int H, int W, int backward) {
     return streamed > gemm_form ? streamed : gemm_form;
 }
 
-int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
-                               const float* thr, const float* bias, float* out, float* lse, float* mu, void* workspace,
-                               size_t ws_bytes, dagl_ce_info* info) {
-    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && thr && bias && out && lse && mu,
-                 "dagl_ce_core_dense_forward: bad argument");
+int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, int flags, const float* wq_rows, const float* x_rows,
+                               const float* b2, const float* thr, const float* bias, float* out, float* lse, float* mu,
+                               void* workspace, size_t ws_bytes, dagl_ce_info* info) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && thr && bias && out && lse && mu &&
+                 (flags & ~DAGL_FLAG_EXACT_SCAN) == 0, "dagl_ce_core_dense_forward: bad argument");
     DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_dense_forward: workspace must be 256-byte aligned");
     const Grid g = make_grid(H, W);
     hipStream_t s = (hipStream_t)stream;
-    if (dense_core_streamed(H, W)) {
+    bool left_range = false;
+    if (dense_core_streamed(H, W) && !(flags & DAGL_FLAG_EXACT_SCAN)) {
         CoreIn core{wq_rows, x_rows, nullptr, nullptr, nullptr, nullptr, mu, lse};
-        return ce_forward_impl(s, B, H, W, nullptr, b2, thr, bias, nullptr, nullptr, nullptr, nullptr,
-                               DAGL_MODE_ADAPTIVE | DAGL_FLAG_DENSE_HINT, 0, out, workspace, ws_bytes, info, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, 1, &core);
+        const int rc0 = ce_forward_impl(s, B, H, W, nullptr, b2, thr, bias, nullptr, nullptr, nullptr, nullptr,
+                                        DAGL_MODE_ADAPTIVE | DAGL_FLAG_DENSE_HINT, 0, out, workspace, ws_bytes, info, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, 1, &core);
+        // a feature outside the split-fp16 range (|feature| >= 937): the streamed kernels NaN-filled `out`; a call that reads
+        // its statistics back (info != NULL) notices and is re-run right here in the fp32 GEMM form, which has no such range
+        if (rc0 != DAGL_OK || info == nullptr || !info->range_fallback) return rc0;
+        left_range = true;
     }
     if (info) { info->required_bytes = (int64_t)dense_train_workspace_bytes(B, g, false); info->total_edges = -1;
-                info->max_degree = -1; info->redone_queries = -1; info->path = 5; }
+                info->max_degree = -1; info->redone_queries = -1; info->path = 5; info->range_fallback = 0; info->reserved = 0; }
     // the two statistics words live at the very end of the caller's buffer (past the plan)
     const size_t need = dense_train_workspace_bytes(B, g, false) + 256;
     if (ws_bytes < need) { set_error("dagl_ce_core_dense_forward: workspace %zu B < required %zu B", ws_bytes, need);
@@ -1046,6 +1059,7 @@ int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, const float* w
         int64_t hs[2] = {0, 0};
         if ((rc = read_back(s, stats, 2, hs))) return rc;
         info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1];
+        info->range_fallback = left_range ? 1 : 0;
     }
     return DAGL_OK;
 }
@@ -1096,20 +1110,22 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const fl
 
 // ---- the 7x7x16 -> 196 patch Linear (+ReLU) of the differentiable path's FORWARD on the inference kernels: split the map,
 // pack the weight, project (split-fp16 matrix cores, no unfolded rows), copy the feature rows out densely ---------------
-static void pp16_carve(int B, const Grid& g, int n, size_t& o_hi, size_t& o_lo, size_t& o_wp, size_t& o_feat, size_t& total) {
+static void pp16_carve(int B, const Grid& g, int n, size_t& o_hi, size_t& o_lo, size_t& o_wp, size_t& o_feat, size_t& o_range,
+                       size_t& total) {
     size_t off = 0;
     const size_t map_h = (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t);
     o_hi = carve(off, map_h); o_lo = carve(off, map_h);
     o_wp = carve(off, P16_PACKED_HALFS * sizeof(uint16_t));
     o_feat = carve(off, (size_t)B * feat_rows(n) * DS * sizeof(float));
+    o_range = carve(off, 2 * sizeof(int64_t));                        // range word, completion word (RangeTag)
     total = off;
 }
 
 size_t dagl_project_patches16_scratch_bytes(int B, int H, int W, int queries) {
     if (B < 1 || H < 1 || W < 1) return 0;
     const Grid g = make_grid(H, W);
-    size_t a, b2, c, d, total;
-    pp16_carve(B, g, queries ? g.L : g.N, a, b2, c, d, total);
+    size_t a, b2, c, d, e, total;
+    pp16_carve(B, g, queries ? g.L : g.N, a, b2, c, d, e, total);
     return total;
 }
 
@@ -1121,22 +1137,28 @@ int dagl_project_patches16(void* stream, int B, int H, int W, int queries, const
     hipStream_t s = (hipStream_t)stream;
     const Grid g = make_grid(H, W);
     const int n = queries ? g.L : g.N;
-    size_t o_hi, o_lo, o_wp, o_feat, total;
-    pp16_carve(B, g, n, o_hi, o_lo, o_wp, o_feat, total);
+    size_t o_hi, o_lo, o_wp, o_feat, o_range, total;
+    pp16_carve(B, g, n, o_hi, o_lo, o_wp, o_feat, o_range, total);
     DAGL_REQUIRE(scratch_bytes >= total, "dagl_project_patches16: scratch %zu B, need %zu B", scratch_bytes, total);
     uint16_t* hi = at<uint16_t>(scratch, o_hi);
     uint16_t* lo = at<uint16_t>(scratch, o_lo);
     uint16_t* wp = at<uint16_t>(scratch, o_wp);
     float* feat = at<float>(scratch, o_feat);
     int rc;
-    if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, map_nhwc, hi, lo))) return rc;
+    // range guard (|16 map| , |1024 w| < 65504): the split / pack / projection kernels store this call's tag into the range
+    // word when they meet a larger value, and the copy-out below then writes NaN instead of numbers formed from inf halves
+    RangeTag rt;
+    int64_t* words = at<int64_t>(scratch, o_range);
+    DAGL_HIP_TRY(hipMemsetAsync(words, 0, 2 * sizeof(int64_t), s));
+    rt.word = reinterpret_cast<int32_t*>(words); rt.done = reinterpret_cast<int32_t*>(words + 1); rt.tag = next_call_tag();
+    if ((rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, map_nhwc, hi, lo, rt))) return rc;
     if ((rc = launch_pack_fc_weight16(s, w_rows, wp, /*rows_order=*/true))) return rc;
     const float* bias1[1] = {fc_bias};
-    if (queries) rc = launch_project16(s, B, g, 2, hi, lo, nullptr, nullptr, nullptr, nullptr, nullptr, wp, bias1, feat, nullptr, nullptr);
-    else rc = launch_project16(s, B, g, 1, hi, lo, wp, bias1, feat, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (queries) rc = launch_project16(s, B, g, 2, hi, lo, nullptr, nullptr, nullptr, nullptr, nullptr, wp, bias1, feat, nullptr, nullptr, 1, rt);
+    else rc = launch_project16(s, B, g, 1, hi, lo, wp, bias1, feat, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, rt);
     if (rc) return rc;
     // [B, feat_rows(n), DS] -> [B, n, 196]
-    return dagl_copy4(stream, 1, B, n, D, feat, 0, (long long)feat_rows(n) * DS, DS, 1, rows_out, 0, (long long)n * D, D, 1);
+    return launch_feat_rows_out(s, B, n, feat, rows_out, rt);
 }
 
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc) {

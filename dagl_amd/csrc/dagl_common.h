@@ -171,6 +171,8 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
                      uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag());
+int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat /* [B, feat_rows(n), DS] */, float* rows_out /* [B, n, 196] */,
+                         RangeTag range);            // dense copy of the feature rows; NaN when the call left the fp16 range
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
 constexpr size_t P16_PACKED_HALFS = (size_t)49 * 7168 + 1024; // packed fp16 weights (halfs) + read slack; the last 4 bytes = range flag of the weights
 // Optional extra duties of the thresholds kernel on the fused path (one launch instead of three): finish the thr / bias

@@ -57,6 +57,29 @@ __global__ void split_map_kernel(size_t n, const float* __restrict__ src, unsign
     reinterpret_cast<ushort4*>(lo)[i] = make_ushort4(l[0], l[1], l[2], l[3]);
 }
 
+// [B, feat_rows(n), DS] feature rows -> dense [B, n, 196] (training path: dagl_project_patches16); a call that left the
+// split-fp16 range hands out NaN, never numbers computed from inf halves
+__global__ __launch_bounds__(256) void feat_rows_out_kernel(int n, int rows_alloc, const float* __restrict__ feat,
+                                                            float* __restrict__ out, RangeTag range) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;              // one float4 = 4 of a row's 196 columns
+    const int b = blockIdx.y;
+    const bool poisoned = range.word != nullptr && *range.word == range.tag;
+    if (range.done != nullptr && b == 0 && t == 0) *range.done = range.tag;
+    if (t >= (size_t)n * (D / 4)) return;
+    const size_t row = t / (D / 4); const int c4 = (int)(t - row * (D / 4));
+    float4 v = *reinterpret_cast<const float4*>(feat + ((size_t)b * rows_alloc + row) * DS + 4 * c4);
+    if (poisoned) { const float q = __builtin_nanf(""); v = make_float4(q, q, q, q); }
+    *reinterpret_cast<float4*>(out + ((size_t)b * n + row) * D + 4 * c4) = v;
+}
+
+int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat, float* rows_out, RangeTag range) {
+    const size_t items = (size_t)n * (D / 4);
+    hipLaunchKernelGGL(feat_rows_out_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s, n, feat_rows(n), feat,
+                       rows_out, range);
+    DAGL_LAUNCH_CHECK("feat_rows_out_kernel");
+    return DAGL_OK;
+}
+
 int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range) {
     const size_t n4 = (n_floats + 3) / 4;
     hipLaunchKernelGGL(split_map_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n_floats, src, hi, lo, range);

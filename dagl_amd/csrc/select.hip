@@ -206,7 +206,7 @@ __device__ __forceinline__ void score_select_unit(const SelectArgs& a, float (*s
 // always nothing flagged), a small grid whose blocks walk over the units and skip the unflagged ones: an empty redo costs
 // one wave of flag reads instead of the dispatch of a thousand blocks that exit.
 template <int PASS, int K>
-__global__ __launch_bounds__(256, 2) void score_select_kernel(SelectArgs a, int n_qgroups, int n_tiles,
+__global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void score_select_kernel(SelectArgs a, int n_qgroups, int n_tiles,
                                                               int rows_q, int rows_x, int n_units) {
     __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB
     if (a.run_flags == nullptr) {
@@ -231,7 +231,7 @@ static int launch_pass(hipStream_t s, const SelectArgs& a, dim3 grid, int n_qgro
         hipLaunchKernelGGL((score_select_kernel<PASS, 1>), grid, block, 0, s, a, n_qgroups, n_tiles, rows_q,
                            rows_x, n_units);
     } else {
-        switch (a.k <= 4 ? 4 : a.k <= 8 ? 8 : a.k <= 16 ? 16 : 32) {
+        switch (topk_slots(a.k)) {
             case 4:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 4>), grid, block, 0, s, a, n_qgroups, n_tiles,
                                    rows_q, rows_x, n_units);
@@ -244,8 +244,13 @@ static int launch_pass(hipStream_t s, const SelectArgs& a, dim3 grid, int n_qgro
                 hipLaunchKernelGGL((score_select_kernel<PASS, 16>), grid, block, 0, s, a, n_qgroups, n_tiles,
                                    rows_q, rows_x, n_units);
                 break;
-            default:
+            case 32:
                 hipLaunchKernelGGL((score_select_kernel<PASS, 32>), grid, block, 0, s, a, n_qgroups, n_tiles,
+                                   rows_q, rows_x, n_units);
+                break;
+            default:       // 33..64: per-lane lists of 64 (128 registers) next to the query fragments: one wave per SIMD (512
+                           // registers); this scan only serves images under 2048 keys, scan = "exact" and the screen's rare redo
+                hipLaunchKernelGGL((score_select_kernel<PASS, 64>), grid, block, 0, s, a, n_qgroups, n_tiles,
                                    rows_q, rows_x, n_units);
                 break;
         }
@@ -254,7 +259,7 @@ static int launch_pass(hipStream_t s, const SelectArgs& a, dim3 grid, int n_qgro
     return DAGL_OK;
 }
 
-int topk_slots(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : 32; }
+int topk_slots(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
 
 int launch_score_select(hipStream_t s, const SelectArgs& a, int pass) {
     const int n_qgroups = (a.L + SEL_WAVES * QT - 1) / (SEL_WAVES * QT);

@@ -51,29 +51,51 @@ class CES(nn.Module):
         self._ws = {1: ops.Workspace(), 2: ops.Workspace(), 3: ops.Workspace()}     # one per stage: packed weights persist
         self._pack_key = {1: None, 2: None, 3: None}
         self._skip_fused = {1: 0, 2: 0, 3: 0}     # calls for which a stage stays on the per-head path after it met dense masks
+        self._fused_calls = {1: 0, 2: 0, 3: 0}    # fused calls since the stage's range word was last looked at
 
     def _stage(self, s, x):
         heads = [getattr(self, f"c{s}_{h}") for h in (1, 2, 3, 4)]
         mix = getattr(self, f"c{s}_c")
+        from ._lib import MAX_TOPK
+        mode = heads[0].select_mode if isinstance(heads[0], CE) else None
+        k_eff = 0 if mode in (None, "adaptive") else min(int(heads[0].select_k), x.shape[-2] * x.shape[-1])
+        # (an eval() stage fed a constant input under an autograd-enabled test loop counts as "no gradient wanted", like CE)
+        no_grad = not torch.is_grad_enabled() or (not self.training and not x.requires_grad)
         if self.fuse_stage and all(isinstance(hd, CE) for hd in heads) and x.is_cuda and x.dtype == torch.float32 \
-                and not torch.is_grad_enabled() and len({(hd.select_mode, hd.select_k, hd.scan) for hd in heads}) == 1 \
-                and heads[0].scan == "screened" and self._skip_fused[s] == 0:
+                and no_grad and len({(hd.select_mode, hd.select_k, hd.scan) for hd in heads}) == 1 \
+                and heads[0].scan == "screened" and self._skip_fused[s] == 0 and 0 <= k_eff <= MAX_TOPK \
+                and all(p.dtype == torch.float32 for hd in heads for p in hd.parameters()):
             # the four heads share x: one launch set with the heads as a batch dimension + the 1x1 mix + residual
             from . import ops
             prm = [{n: p.detach().contiguous() for n, p in hd.named_parameters() if not n.startswith("W.")} for hd in heads]
             ws = self._ws[s]
             fcs = [prm[h][n] for h in range(4) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")]
             wsb = ws.peek(x.device)
-            key = (tuple(x.shape), heads[0].select_mode, heads[0].select_k, tuple(hd._pack_epoch for hd in heads),
+            key = (tuple(x.shape), heads[0].select_mode, k_eff, tuple(hd._pack_epoch for hd in heads),
                    tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
                                               mix.bias.detach().contiguous(), mode=heads[0].select_mode,
-                                              k=heads[0].select_k, workspace=ws,
+                                              k=k_eff, workspace=ws,
                                               weights_packed=(key == self._pack_key[s]))
             self._pack_key[s] = key[:-1] + (ws.peek(x.device).data_ptr(),) if out is not None else None
             self.last_info = info
+            violated = False
+            if out is not None and mode != "adaptive":
+                # the top-k modes never read anything back: look at the stage workspace's (sticky) range word every 64th
+                # fused call -- one synchronisation.  A call that left the split-fp16 range has NaN-filled outputs (never
+                # wrong numbers); the heads move to scan = "exact" (which takes them off the fused path) and this call is redone
+                self._fused_calls[s] += 1
+                if self._fused_calls[s] >= 64:
+                    self._fused_calls[s] = 0
+                    if ops.ce_range_check((4 * x.shape[0],) + tuple(x.shape[1:]), mode, k_eff, ws, x.device):
+                        for hd in heads:
+                            hd._note_range_violation("a fused CES stage call left the split-fp16 range (outputs NaN-filled)")
+                        self._pack_key[s] = None
+                        out, violated = None, True
             if out is not None:
                 return out
+            if violated:
+                return self._stage(s, x)                    # (heads now on scan = "exact": per-head path)
             self._skip_fused[s] = 16                        # dense masks: the heads' own dense path serves the next calls
         elif self._skip_fused[s] > 0:
             self._skip_fused[s] -= 1

@@ -385,8 +385,9 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
 
 
 def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> bool:
-    """True when the last forward on ``workspace`` (input shape ``shape``) left the range of the split-fp16 kernels and
-    returned a NaN-filled output (``dagl_ce_range_check``; one host synchronisation)."""
+    """True when a forward on ``workspace`` (input shape ``shape``) since the last check left the range of the split-fp16
+    kernels and returned a NaN-filled output (``dagl_ce_range_check``; one host synchronisation; the word is sticky and
+    cleared by the check that reports it).  ``shape[0]`` counts head x image pairs for a stage workspace."""
     lib = _lib.load()
     buf = workspace.peek(device)
     if buf is None:
@@ -466,6 +467,8 @@ def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: i
         _need(thr, "thr"); _need(bias, "bias")
         if thr.numel() != B * L or bias.numel() != B * L:
             raise DaglError("ce_core_forward: thr/bias must hold B*L values")
+    if mode != "adaptive":
+        k = min(int(k), N)                 # top_k = min(num_edge, N): the lists are that wide
     mode_flags = MODES[mode] | (_lib.FLAG_EXACT_SCAN if exact_scan else 0)
     width = lib.dagl_ce_list_width(mode_flags, int(k))
     check(min(width, 0), "dagl_ce_list_width")
@@ -502,6 +505,8 @@ def ce_core_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, mode: s
         _need(t, n)
     B, _, H, W = b2.shape
     adaptive = mode != "topk"
+    if mode != "adaptive":
+        k = min(int(k), H * W)
     need = lib.dagl_ce_core_backward_workspace_bytes(B, H, W, MODES[mode], int(k))
     if need == 0:
         check(-1, "dagl_ce_core_backward_workspace_bytes")
@@ -561,9 +566,11 @@ def gemm_f32(A: torch.Tensor, B: torch.Tensor, a_k_contiguous: bool = True, b_k_
 
 
 @_on_device
-def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace | None" = None, want_info: bool = True):
+def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace | None" = None, want_info: bool = True,
+                          exact: bool = False):
     """Graph core in the dense regime under autograd (``dagl_ce_core_dense_forward``): same operands as
-    ``ce_core_forward`` (adaptive mode) -> (out [B,16,H,W], saved dict(lse [B,L,2], mu [B,L], info))."""
+    ``ce_core_forward`` (adaptive mode) -> (out [B,16,H,W], saved dict(lse [B,L,2], mu [B,L], info)).  ``exact``: the
+    chunked fp32 GEMM form whatever the size (modules with ``scan="exact"``: no split-fp16 range limit)."""
     lib = _lib.load()
     for n, t in (("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2), ("thr", thr), ("bias", bias)):
         _need(t, n)
@@ -581,10 +588,12 @@ def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace 
     mu = torch.empty(B, L, device=dev, dtype=torch.float32)
     info = _lib.CeInfo()
     a, nbytes = _aligned(ws.get(need, dev))
-    check(lib.dagl_ce_core_dense_forward(_stream(), B, H, W, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
-                                         thr.data_ptr(), bias.data_ptr(), out.data_ptr(), lse.data_ptr(), mu.data_ptr(),
-                                         a, nbytes, C.byref(info) if want_info else None), "dagl_ce_core_dense_forward")
-    meta = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=5, redone_queries=-1) if want_info else None
+    check(lib.dagl_ce_core_dense_forward(_stream(), B, H, W, _lib.FLAG_EXACT_SCAN if exact else 0, wq_rows.data_ptr(),
+                                         x_rows.data_ptr(), b2.data_ptr(), thr.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                         lse.data_ptr(), mu.data_ptr(), a, nbytes, C.byref(info) if want_info else None),
+          "dagl_ce_core_dense_forward")
+    meta = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=5, redone_queries=-1,
+                range_fallback=info.range_fallback) if want_info else None
     return out, dict(lse=lse, mu=mu, info=meta)
 
 

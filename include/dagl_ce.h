@@ -65,7 +65,9 @@ extern "C" {
  * same either way; info->total_edges tells the caller whether the hint still pays                              */
 #define DAGL_FLAG_DENSE_HINT     0x400
 
-#define DAGL_MAX_TOPK            32   /* largest k of the top-k modes                                */
+#define DAGL_MAX_TOPK            64   /* largest k of the top-k modes (the fixed-k variant defaults to num_edge = 50,
+                                         GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
+                                         top_k = min(k, N) (:243), the lists are then min(k, N) wide               */
 #define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path (fp32 scan, training lists) */
 #define DAGL_LIST_CAP           256   /* per-query slots of the screened adaptive path (inference): long-tailed degrees */
 
@@ -100,13 +102,20 @@ typedef struct dagl_ce_info {
  * NaN-filled by the last kernel, and
  *   - the adaptive modes, which read statistics back anyway, notice and re-run the call on the fp32 path at once
  *     (info->range_fallback = 1; the result is the exact scan's);
- *   - the top-k modes have no host round trip: dagl_ce_range_check(workspace) tells (one synchronisation) whether the
- *     last call on that workspace left the range; re-run with DAGL_FLAG_EXACT_SCAN (no range limit).                  */
-int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, const void* workspace, size_t ws_bytes,
+ *   - the top-k modes have no host round trip: dagl_ce_range_check(workspace) tells (one synchronisation) whether ANY
+ *     call on that workspace left the range since the last check (the word is sticky and cleared by the check that
+ *     reports it); re-run with DAGL_FLAG_EXACT_SCAN (no range limit).
+ *   - the training entry points (dagl_project_patches16, dagl_ce_core_dense_forward) NaN-fill their outputs likewise; the
+ *     dense forward re-runs itself in its fp32 form when it reads statistics back (info != NULL, range_fallback = 1).   */
+int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
                         int* violated);
 
 /* ---- library ------------------------------------------------------------------------------- */
-int         dagl_version(void);                 /* 10000*major + 100*minor + patch                  */
+/* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
+ * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64).  A caller compares
+ * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
+#define DAGL_ABI_VERSION 300
+int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
 
@@ -235,9 +244,12 @@ int    dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k,
  * exist one chunk at a time; all matrix products on the fp32 matrix cores (bitwise fmaf chains).  Adaptive mode only
  * (the top-k modes always have fixed-width lists).  Same operands as dagl_ce_core_forward / _backward; instead of
  * neighbour lists the forward hands back `lse` [B,L,2] = (softmax shift, denominator) per query and `mu` [B,L].
- * info (may be NULL; non-NULL costs one host synchronisation): path 5, total_edges, max_degree.                   */
+ * info (may be NULL; non-NULL costs one host synchronisation): path 5, total_edges, max_degree.
+ * flags: DAGL_FLAG_EXACT_SCAN = the chunked fp32 GEMM form whatever the size (no split-fp16 range limit); 0 = the
+ * streamed split-fp16 kernel for images of >= 2048 keys (|feature| < 937; beyond it `out` is NaN-filled, and a call
+ * with info != NULL re-runs itself in the GEMM form and sets info->range_fallback).                              */
 size_t dagl_ce_core_dense_workspace_bytes(int B, int H, int W, int backward);
-int    dagl_ce_core_dense_forward(void* stream, int B, int H, int W,
+int    dagl_ce_core_dense_forward(void* stream, int B, int H, int W, int flags /* 0 or DAGL_FLAG_EXACT_SCAN */,
                                   const float* wq_rows, const float* x_rows, const float* b2,
                                   const float* thr, const float* bias, float* out, float* lse, float* mu,
                                   void* workspace, size_t ws_bytes, dagl_ce_info* info);

@@ -53,6 +53,11 @@ CASES = [
     ("topk4_64x64",          "TOPK",     22, "default", 2.0, "topk",     4, 1, 64, 64),
     ("topk8_b2_45x38",       "TOPK",     23, "default", 2.0, "topk",     8, 2, 45, 38),
     ("topk16_72x72",         "TOPK",     24, "default", 2.0, "topk",    16, 1, 72, 72),
+    # the fixed-k variant's own default, num_edge=50 (GReccR2b_3mh_1-checkpoint.py:155,243), and k > N
+    # (top_k = min(num_edge, N), :243: every key is a neighbour)
+    ("topk50_64x64",         "TOPK",     25, "default", 2.0, "topk",    50, 1, 64, 64),
+    ("topk64_b2_40x36",      "TOPK",     26, "default", 2.0, "topk",    64, 2, 40, 36),
+    ("topk50_k_gt_n_6x7",    "TOPK",     27, "default", 2.0, "topk",    50, 1, 6, 7),
 ]
 
 

@@ -1,0 +1,200 @@
+"""Round-3 boundary items on the GPU: the shipped forward() against every reference golden directly, k up to 64 without a
+silent clamp (the fixed-k variant's default num_edge = 50, GReccR2b_3mh_1-checkpoint.py:155,243; k > N), half-precision
+modules (``model.half()``, DN_Gray/model/__init__.py:98-99), eval-mode routing under an autograd-enabled test loop
+(DN_Gray/trainer.py:128-140), the sticky range word, the training path's range guard."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden_cases
+from tests.helpers import case_inputs, load_golden, normwise
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+DEV = "cuda:0"
+
+
+def _module(params, mode="adaptive", k=0, scan="screened"):
+    from dagl_amd.ce import CE
+    ce = CE(in_channels=64)
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode, ce.scan = mode, scan
+    if k:
+        ce.select_k = k
+    return ce.to(DEV).eval()
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_shipped_forward_matches_reference_golden_directly(path):
+    """``ce(x)`` -- fused split-fp16 prologue and all -- against the reference's own output, no oracle in between."""
+    meta, g = load_golden(path)
+    x, params = case_inputs(meta)
+    ce = _module(params, meta["mode"], meta["k"])
+    with torch.no_grad():
+        out = ce(x.to(DEV)).cpu().numpy()
+    err = normwise(out, g["out"])
+    print(f"[parity] {meta['name']}: ce(x) vs reference golden, normwise {err:.2e} (bar 1e-4), path {ce.last_info['path']}")
+    assert out.shape == g["out"].shape and err <= 1e-4, err
+
+
+def test_num_edge_beyond_the_list_width_raises_instead_of_clamping():
+    from dagl_amd._lib import MAX_TOPK, DaglError
+    from dagl_amd.ce import CE
+    assert MAX_TOPK == 64
+    ce = CE(in_channels=64, num_edge=500).to(DEV).eval()          # CA_model-checkpoint.py:134-143 builds heads like this
+    assert ce.select_k == 500                                      # nothing clamped at construction
+    x = torch.randn(1, 64, 32, 32, device=DEV)
+    with torch.no_grad():
+        ce(x)                                                      # the shipped (adaptive) semantics ignore num_edge: fine
+        ce.select_mode = "topk"
+        with pytest.raises(DaglError, match="select_k=500"):
+            ce(x)
+        ce.select_k = 64
+        assert ce(x).shape == (1, 16, 32, 32)
+
+
+@pytest.mark.parametrize("k,H,W", [(50, 64, 64), (64, 40, 36), (50, 6, 7), (33, 23, 30)])
+@pytest.mark.parametrize("mode", ["topk", "adaptive_topk"])
+def test_k_up_to_64_against_the_fp64_oracle(k, H, W, mode):
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    variant = "default" if mode == "topk" else "allpass"          # (all-pass adaptive mask: the intersection is the top-k set)
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(61, variant=variant).items()}
+    x = torch.from_numpy(make_features(61, 2, 64, H, W))
+    want, st = ce_forward_oracle(x, params, mode=mode, k=k, dtype=torch.float64, stages=True)
+    assert int(st["deg"].max()) == min(k, H * W)
+    for scan in ("screened", "exact"):
+        ce = _module(params, mode, k, scan)
+        with torch.no_grad():
+            out = ce(x.to(DEV)).cpu()
+        err = normwise(out.numpy(), want.float().numpy())
+        print(f"[parity] {mode} k={k} {H}x{W} scan={scan}: normwise {err:.2e} vs fp64 oracle")
+        assert err <= 1e-4, (scan, err)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["half", "bfloat16"])
+@pytest.mark.parametrize("mode,k,variant", [("topk", 8, "default"), ("adaptive", 0, "sparse")])
+def test_half_precision_module_against_the_oracle_on_the_rounded_weights(dt, mode, k, variant):
+    """``model.half()`` (the reference's --precision half test path): the block computes in fp32 on exactly the values the
+    half-precision parameters and input hold -- <= 1e-4 against the oracle fed those values, before the output rounding."""
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(62, variant=variant, sparse_gain=1.8).items()}
+    x = torch.from_numpy(make_features(62, 1, 64, 48, 56))
+    ce = _module(params, mode, k)
+    ce = ce.half() if dt == torch.float16 else ce.bfloat16()
+    assert ce.fc1[0].weight.dtype == dt
+    xr = x.to(dt)
+    rounded = {n: p.to(dt).float() for n, p in params.items()}
+    want = ce_forward_oracle(xr.float(), rounded, mode=mode, k=k or None, dtype=torch.float64).float()
+    with torch.no_grad():
+        out_h = ce(xr.to(DEV))                                                      # the public call: half in, half out
+        out_f = ce._forward_infer(xr.to(DEV).float(), k)                            # the same numbers before the output rounding
+    assert out_h.dtype == dt and torch.equal(out_h, out_f.to(dt))
+    err = normwise(out_f.cpu().numpy(), want.numpy())
+    print(f"[parity] {dt} module, {mode}: normwise {err:.2e} vs oracle on the rounded weights")
+    assert err <= 1e-4, err
+    # a weight edit is seen (the fp32 copies follow the parameters' version counters)
+    with torch.no_grad():
+        ce.fc1[0].bias.add_(0.25)
+        out2 = ce._forward_infer(xr.to(DEV).float(), k)
+    assert not torch.equal(out2, out_f)
+
+
+def test_whole_network_in_half_precision_runs():
+    from dagl_amd.net import RR, seeded_state_dict
+    net = RR().eval()
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 3), strict=True)
+    net = net.to(DEV).half()                                        # Model.__init__: if args.precision == 'half': self.model.half()
+    x = torch.rand(1, 1, 48, 48, device=DEV).half()
+    with torch.no_grad():
+        y = net(x)
+    assert y.dtype == torch.float16 and y.shape == x.shape and torch.isfinite(y).all()
+
+
+def test_eval_network_under_enabled_autograd_stays_on_the_inference_kernels():
+    """The reference's test loop runs with autograd on (``volatile`` is long dead, DN_Gray/trainer.py:132): inside RR every
+    head's input then requires grad.  eval() heads must still take the inference kernels -- and a backward, should one
+    arrive, must give the differentiable path's gradients."""
+    from dagl_amd.ce import CE
+    from dagl_amd.net import RR, seeded_state_dict
+    net = RR().eval()
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 4), strict=True)
+    heads = [m for m in net.modules() if isinstance(m, CE)]
+    for m in heads:
+        m.select_mode, m.select_k = "topk", 8
+    net = net.to(DEV)
+    x = torch.rand(1, 1, 40, 44, device=DEV)
+    with torch.no_grad():
+        ref = net(x)
+    for m in heads:
+        m.last_info = None
+    y = net(x)                                                       # autograd enabled, eval mode
+    assert y.requires_grad and torch.equal(y.detach(), ref)
+    infos = [m.last_info for m in heads]
+    assert all(i is not None and i["path"] in (2, 3) for i in infos), infos     # inference paths (screen or fp32 top-k), not the core
+    # gradients through the lazily recomputed block == gradients of the train()-mode forward
+    loss = (y ** 2).sum()
+    g_eval = torch.autograd.grad(loss, [p for p in net.parameters() if p.requires_grad], allow_unused=True)
+    net.train()
+    y2 = net(x)
+    g_train = torch.autograd.grad((y2 ** 2).sum(), [p for p in net.parameters() if p.requires_grad], allow_unused=True)
+    worst = 0.0
+    for a, b in zip(g_eval, g_train):
+        assert (a is None) == (b is None)
+        if a is not None and float(b.abs().max()) > 0:
+            worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+    print(f"[parity] eval-mode lazy backward vs train-mode backward: worst tensor {worst:.2e}")
+    assert worst <= 1e-3
+
+
+def test_range_word_is_sticky_until_read():
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(77, variant="default").items()}
+    ce = _module(params, "topk", 8)
+    x = torch.from_numpy(make_features(77, 1, 64, 64, 64)).to(DEV)
+    with torch.no_grad():
+        assert torch.isfinite(ce(x)).all()
+        assert torch.isnan(ce(x * 3.0e3)).all()                      # leaves the split-fp16 range: NaN, never wrong numbers
+        for _ in range(3):
+            assert torch.isfinite(ce(x)).all()                       # later calls are fine again ...
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            assert not ce.range_ok()                                 # ... and the violation is still reported
+        assert ce.scan == "exact"
+
+
+def test_fused_stage_polls_its_range_word():
+    from dagl_amd.ce import CE
+    from dagl_amd.net import CES
+    ces = CES(64).to(DEV).eval()
+    heads = [m for m in ces.modules() if isinstance(m, CE)]
+    for m in heads:
+        m.select_mode, m.select_k = "topk", 8
+    x = torch.randn(1, 64, 48, 48, device=DEV)
+    with torch.no_grad(), warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        ces._stage(1, x)
+        ces._fused_calls[1] = 63                                     # the next fused call is the polling one
+        bad = ces._stage(1, x * 1.0e4)                               # |x| ~ 4e4: outside the range
+        assert all(hd.scan == "exact" for hd in heads[:4])           # stage 1's heads left the fused path ...
+        assert torch.isfinite(bad).all()                             # ... and the call was redone per head on the fp32 path
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_training_path_range_guard_moves_the_module_to_the_fp32_forward(dense):
+    from dagl_amd.synth import make_ce_params, make_features
+    variant = "default" if dense else "sparse"
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(78, variant=variant, sparse_gain=2.2).items()}
+    ce = _module(params, "adaptive").train()
+    x = (torch.from_numpy(make_features(78, 1, 64, 48, 48)) * 2.0e3).to(DEV).requires_grad_(True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = ce(x)                                                  # first training call: its output is looked at
+    assert ce.scan == "exact" and any("split-fp16 range" in str(m.message) for m in w)
+    assert torch.isfinite(out).all()
+    out.sum().backward()
+    assert torch.isfinite(x.grad).all()
