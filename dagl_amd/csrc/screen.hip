@@ -257,6 +257,208 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
     dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
 }
 
+// ---- ring form of the same kernel: no block barrier in the step loop ---------------------------------------------------
+// screen_kernel's step is "26 multiplies per wave, then the wave's tail (threshold test, candidate extraction, its share of the
+// next tile request), then a barrier of all 16 waves".  The four waves of a SIMD share one matrix pipe (oldest first), so
+// they leave the multiplies one after the other -- and the LAST one's tail runs with the pipe idle before the barrier lets
+// anybody start the next step: step = 4 x 832 cycles of multiplies + ~1400 of tail, the matrix pipes 63 % busy in the loop
+// (DESIGN.md section 7).  Here the waves are not re-aligned every step: key tiles live in a five-deep LDS ring guarded by two
+// words per slot instead of the barrier,
+//   ready[slot] = 1 + the tile that has landed there   (written by the wave that requested it, after its vmcnt wait)
+//   done[slot]  = number of wave-steps that have finished reading the slot (one LDS add per wave and step)
+// a wave starts step t as soon as ready[t % 5] says tile t is there -- while slower waves are still in their tails --, and tile
+// t + 3 is requested (all 27 LDS-DMA pieces) by ONE wave, (t + 3) % 16, at the start of ITS step t, once done[] says everybody
+// has left the slot's previous tile, t - 2.  Waves drift by up to a step against each other; a tail runs under the other waves'
+// multiplies.  LDS operations of a wave execute in issue order and LDS-DMA data is in the LDS when the requesting wave's vmcnt
+// has counted it (MI355X_MICROARCH.md, two-waves-per-SIMD item 7), so flag-after-wait / read-after-flag needs no barrier.
+constexpr int RING_NBUF = 5;                       // 5 x 27 KiB = 135 KiB of the CU's 160
+constexpr int RING_AHEAD = 3;                      // tile t + 3 is requested during step t, published during step t + 1
+constexpr int RING_FLAG_BYTES = 64;
+
+// flag words are touched through explicit DS instructions: a volatile C++ access through the generic pointer became
+// flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e. every poll drained the wave's LDS-DMA requests and candidate stores
+__device__ __forceinline__ unsigned lds_flag_load(unsigned byte_addr) {          // wave-uniform address -> wave-uniform value
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(byte_addr) : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_flag_store(unsigned byte_addr, unsigned val) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void lds_flag_add(unsigned byte_addr, unsigned val) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+}
+
+template <int PASS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a, int n_qgroups) {
+    // ONE shared object (a second one makes hipcc drain vmcnt(0) in front of every ds_read of the loop)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[RING_NBUF * STEP_ELEMS + RING_FLAG_BYTES / 2];
+    unsigned* const flags = reinterpret_cast<unsigned*>(smem + RING_NBUF * STEP_ELEMS);     // ready[0..4] at +0, done[0..4] at +32 bytes
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+
+    const int logical = xcd_remap2(blockIdx.x, gridDim.x);
+    const int split = logical / n_qgroups;
+    const int qg = logical % n_qgroups;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.n_steps) step1 = a.n_steps;
+    const int stride = (PASS == 0) ? a.sample : 1;
+
+    // query fragments: 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
+    bf16x8 qf[KB];
+    const int q = (qg * WAVES + wave) * QT + i;
+    const bool qvalid = q < a.L;
+    const int qc = qvalid ? q : a.L - 1;
+    const size_t qlin = (size_t)b * a.L + qc;
+    {
+        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
+#pragma unroll
+        for (int t = 0; t < KB; ++t) qf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+    }
+    float thq = 0.f;
+    if (PASS == 1) thq = qvalid ? a.theta[qlin] : __builtin_inff();
+    // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
+    float thlo;
+    {
+        const unsigned tb = __float_as_uint(thq);
+        thlo = __uint_as_float(thq > 0.f ? tb - 1u : (thq == 0.f ? 0x80000001u : tb + 1u));
+    }
+    int n_loc = 0;
+    const size_t seg = (qlin * a.splits + split) * 2 + h;
+    int2* const cseg = a.cand + seg * a.capseg + 1;               // slot 0 is the record's header
+#pragma unroll
+    for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[t]));
+
+    float gm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gm[r] = -1.0f;
+
+    const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&smem[0]));
+    const int n_it = (step1 > step0) ? (step1 - step0 + stride - 1) / stride : 0;
+
+    // prologue: the first RING_AHEAD tiles are requested by all waves together (one barrier, outside the loop)
+    const unsigned ready0 = lds0 + RING_NBUF * STEP_ELEMS * 2, done0 = ready0 + 32;        // LDS byte addresses of the flag words
+    if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)(tid + 1) : 0u; flags[8 + tid] = 0u; }
+#pragma unroll
+    for (int j = 0; j < RING_AHEAD; ++j)
+        if (j < n_it) {
+            const unsigned dst = lds0 + (unsigned)j * (STEP_ELEMS * 2);
+            const unsigned short* src = xb + (size_t)(step0 + j * stride) * STEP_ELEMS;
+            for (int p = wave; p < STEP_PIECES; p += WAVES)
+                glds16_asm(reinterpret_cast<const float*>(src + p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+        }
+    dma_wait_all();
+    __syncthreads();
+
+    int pend_tile = -1;                              // tile this wave has requested and not yet published (wave-uniform)
+    int buf = 0;                                     // it % RING_NBUF
+    for (int it = 0; it < n_it; ++it) {
+        const int step = step0 + it * stride;
+        // --- requester duty: tile it + AHEAD belongs to wave (it + AHEAD) % WAVES ---------------------------------------
+        {
+            const int T = it + RING_AHEAD;
+            if (T < n_it && (T % WAVES) == wave) {
+                const int tb = T % RING_NBUF;
+                const unsigned need = (unsigned)(WAVES * (T / RING_NBUF));        // wave-steps that have used the slot before
+                if (need) {
+                    while (lds_flag_load(done0 + 4 * tb) < need) __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
+                const unsigned short* src = xb + (size_t)(step0 + T * stride) * STEP_ELEMS + lane * 8;
+#pragma unroll
+                for (int p = 0; p < STEP_PIECES; ++p)
+                    glds16_asm(reinterpret_cast<const float*>(src + p * 512), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+                pend_tile = T;
+            }
+        }
+        // --- tile `it` must have been published -----------------------------------------------------------------------------
+        while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
+        const unsigned short* kp1 = kp0 + 32 * DSH;
+#pragma unroll
+        for (int t = 0; t < KB; ++t) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], acc[1], 0, 0, 0);
+        }
+        // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
+        if (lane == 0) lds_flag_add(done0 + 4 * buf, 1u);
+        // --- publisher duty: the tile this wave requested a step ago has had ~1.7 steps to land ---------------------------
+        if (pend_tile >= 0 && it > pend_tile - RING_AHEAD) {
+            dma_wait_all();
+            if (lane == 0) lds_flag_store(ready0 + 4 * (pend_tile % RING_NBUF), (unsigned)(pend_tile + 1));
+            pend_tile = -1;
+        }
+        // --- tail: threshold test, candidate extraction ---------------------------------------------------------------------
+        if (PASS == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gm[r] = fmaxf(fmaxf(gm[r], acc[0][r]), acc[1][r]);
+        } else {
+            float mxt[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                float m = acc[tl][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[tl][r]);
+                mxt[tl] = m;
+            }
+            if (__any(fmaxf(mxt[0], mxt[1]) >= thq)) {
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    if (!__any(mxt[tl] >= thq)) continue;
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo - acc[tl][r]), 31);
+                    const int kbase = step * SK + 4 * h + tl * 32;
+                    const float sv = (__popc(mask) == 1) ? mxt[tl] : -mxt[tl];
+                    while (mask) {                                   // score r sits at bit 15 - r: ascending r
+                        const int bit = 31 - __clz((int)mask);
+                        mask &= ~(1u << bit);
+                        const int r = 15 - bit;
+                        const int key = kbase + (r & 3) + 8 * (r >> 2);
+                        if (n_loc < a.capseg - 1) cseg[n_loc] = make_int2(key, __float_as_int(sv));
+                        ++n_loc;
+                    }
+                }
+            }
+        }
+        buf = (buf + 1 == RING_NBUF) ? 0 : buf + 1;
+    }
+
+    if (PASS == 0) {
+        float top[GKEEP];
+#pragma unroll
+        for (int u = 0; u < GKEEP; ++u) {
+            float m = gm[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[r]);
+            top[u] = m;
+            bool taken = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool hit = !taken && (gm[r] == m);
+                gm[r] = hit ? -1.0f : gm[r];
+                taken = taken || hit;
+            }
+        }
+        if (qvalid) *reinterpret_cast<float4*>(a.gmax + seg * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
+    } else {
+        if (qvalid) cseg[-1] = make_int2(n_loc, 0);
+    }
+}
+
 // theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32
 // rounding of either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32).
 // `both` (adaptive AND top-k mask): theta already holds the top-k threshold; a key must pass both tests, so the larger wins.
@@ -325,7 +527,14 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 #undef a
     if (at.times) dbg_times_dump(s, "screen_kernel<1>", at.times, n_blk);
 #else
-    if (qblock == 512) {
+    static const bool ring = [] { const char* e = getenv("DAGL_SCREEN_RING"); return e == nullptr || atoi(e) != 0; }();
+    if (qblock == 512 && ring) {
+        if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_ring_kernel<1, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
+    } else if (qblock == 384 && ring) {
+        if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 12>), grid, dim3(768), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_ring_kernel<1, 12>), grid, dim3(768), 0, s, a, n_qgroups);
+    } else if (qblock == 512) {
         if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
     } else if (qblock == 384) {

@@ -133,7 +133,8 @@ def test_eval_network_under_enabled_autograd_stays_on_the_inference_kernels():
     for m in heads:
         m.last_info = None
     y = net(x)                                                       # autograd enabled, eval mode
-    assert y.requires_grad and torch.equal(y.detach(), ref)
+    # (no_grad runs the fused four-head stage, this call the heads one by one: same numbers up to the last bits of the features)
+    assert y.requires_grad and float((y.detach() - ref).abs().max() / ref.abs().max()) <= 2e-5
     infos = [m.last_info for m in heads]
     assert all(i is not None and i["path"] in (2, 3) for i in infos), infos     # inference paths (screen or fp32 top-k), not the core
     # gradients through the lazily recomputed block == gradients of the train()-mode forward
@@ -190,7 +191,7 @@ def test_training_path_range_guard_moves_the_module_to_the_fp32_forward(dense):
     variant = "default" if dense else "sparse"
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(78, variant=variant, sparse_gain=2.2).items()}
     ce = _module(params, "adaptive").train()
-    x = (torch.from_numpy(make_features(78, 1, 64, 48, 48)) * 2.0e3).to(DEV).requires_grad_(True)
+    x = (torch.from_numpy(make_features(78, 1, 64, 48, 48)) * 1.0e4).to(DEV).requires_grad_(True)       # |b1| ~ 1e4 > 4094
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         out = ce(x)                                                  # first training call: its output is looked at
