@@ -58,6 +58,21 @@ void dbg_times_dump(hipStream_t s, const char* kernel, const unsigned long long*
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
+// LDS flag words of the barrier-free rings (screen.hip, project16.hip): 
+// flag words are touched through explicit DS instructions: a volatile C++ access through the generic pointer became
+// flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e. every poll drained the wave's LDS-DMA requests and candidate stores
+__device__ __forceinline__ unsigned lds_flag_load(unsigned byte_addr) {          // wave-uniform address -> wave-uniform value
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(byte_addr) : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_flag_store(unsigned byte_addr, unsigned val) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void lds_flag_add(unsigned byte_addr, unsigned val) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+}
+
 #endif
 
 // thread-local error text

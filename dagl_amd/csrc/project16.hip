@@ -173,7 +173,9 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
     constexpr int PD = KEYS ? P16_PD_KEYS : P16_PD_Q;
-    constexpr int PIECES = (NT * 32 * P16_ROWH * 2 + 1023) / 1024;              // 14 (NT=7) / 2 (NT=1)
+    // the 14th KiB of a tap's slice holds output rows 208..223: padding whose products are never stored (feature rows end at
+    // column 203, the bf16 copies at 207; an output column depends on its own weight row only) -- not fetched
+    constexpr int PIECES = (NT == P16_NT) ? 13 : (NT * 32 * P16_ROWH * 2 + 1023) / 1024;   // 13 (NT=7) / 2 (NT=1)
     constexpr int PBASE = PIECES / P16_BW;                                      // weight pieces per wave per tap ...
     const bool extra = wave < (PIECES % P16_BW);                                // ... plus one for the first waves
 
@@ -368,7 +370,73 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
     const float* __restrict__ fbias = pa.bias[which][head];
     const int grid_row_base = base_row;
-    float* csum = reinterpret_cast<float*>(smem);                       // [4 waves][NT*32] (the weight ring is dead now)
+    float colsum_r[NT];                                                 // keys: this lane's share of the column sums
+    if (NT == P16_NT && VAR == 0) {
+        // Full blocks: a lane holds 16 rows x 7 columns of its wave's 32 x 224 tile, one dword of a row per store -- 224 store
+        // instructions per wave (fp32 + bf16), each covering two 128-byte (64-byte) row segments; with every CU storing at once
+        // that was 14.6 us of the kernel (store-issue bound: MI355X_MICROARCH.md, epilogue store tail).  The wave's 32 feature
+        // rows are CONTIGUOUS in memory (row stride = row length = 816 bytes; 432 for the bf16 copy), so the tile goes through
+        // the LDS (the weight ring is dead now: 20 KiB per wave, two passes of 16 rows) and leaves as lane-linear 16-byte
+        // stores: 26 + 14 store instructions per wave instead of 224, whole cache lines.
+        float* stg = reinterpret_cast<float*>(smem) + wave * (16 * DS);     // [16 rows][204] floats = 13056 B per wave
+#pragma unroll
+        for (int n = 0; n < NT; ++n) colsum_r[n] = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = n * 32 + i;
+                const float bv = (col < D) ? fbias[col] : 0.0f;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = 8 * pass + r8;
+                    const int rl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;              // row inside the pass: 0..15
+                    const int rr = rl + 16 * pass;
+                    float v = hh[n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
+                    v = v > 0.f ? v : 0.f;
+                    if (col >= D) v = 0.f;
+                    if (col < DS) stg[rl * DS + col] = v;
+                    colsum_r[n] += (wave_valid && rr < lim) ? v : 0.f;
+                }
+            }
+            // (the wave only reads back what it wrote itself: LDS operations of a wave execute in order, no barrier)
+            const int rows_here = wave_valid ? (lim - 16 * pass < 16 ? (lim - 16 * pass < 0 ? 0 : lim - 16 * pass) : 16) : 0;
+            const int n4 = rows_here * (DS / 4);                                  // float4 chunks of the contiguous rows
+            float4* dst = reinterpret_cast<float4*>(fb + (size_t)(grid_row_base + 16 * pass) * DS);
+            const float4* src = reinterpret_cast<const float4*>(stg);
+#pragma unroll
+            for (int j = 0; j < (16 * (DS / 4) + 63) / 64; ++j) {                 // 13
+                const int e = lane + 64 * j;
+                if (e < n4) dst[e] = src[e];
+            }
+            if (hb != nullptr) {
+                // bf16 copy: rows of 216 halfs = 27 chunks of 8 columns; columns 196.. are zero
+                const int n8 = rows_here * (DSH / 8);
+                uint4* dh = reinterpret_cast<uint4*>(hb + (size_t)(grid_row_base + 16 * pass) * DSH);
+#pragma unroll
+                for (int j = 0; j < (16 * (DSH / 8) + 63) / 64; ++j) {            // 7
+                    const int e = lane + 64 * j;
+                    if (e < n8) {
+                        const int row = e / (DSH / 8), c8 = e - row * (DSH / 8);
+                        // columns 8 c8 .. + 7 of the staged row: two 16-byte reads (row stride 816 B = 51 x 16); past column 203: zeros
+                        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 lo4 = (8 * c8 < DS) ? *reinterpret_cast<const float4*>(stg + row * DS + 8 * c8) : z4;
+                        const float4 hi4 = (8 * c8 + 4 < DS) ? *reinterpret_cast<const float4*>(stg + row * DS + 8 * c8 + 4) : z4;
+                        const float f8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                        unsigned short q[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            unsigned bits = __float_as_uint(f8[u]);
+                            bits = (bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16;   // fp32 -> bf16, round to nearest even
+                            q[u] = (unsigned short)bits;
+                        }
+                        dh[e] = make_uint4(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16),
+                                           q[4] | ((unsigned)q[5] << 16), q[6] | ((unsigned)q[7] << 16));
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = (n0 + n) * 32 + i;
@@ -390,7 +458,15 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             }
             s += ok ? v : 0.f;
         }
-        if (KEYS) {
+        colsum_r[n] = s;
+    }
+    }
+    float* csum = reinterpret_cast<float*>(smem);                       // [waves][NT*32] (everything else in the LDS is dead now)
+    if (KEYS) {
+        if (NT == P16_NT && VAR == 0) __syncthreads();                  // the staging regions are about to be overwritten
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float s = colsum_r[n];
             s += __shfl_xor(s, 32);                                   // the two row halves of the tile
             if (h == 0) csum[wave * (NT * 32) + n * 32 + i] = s;
         }

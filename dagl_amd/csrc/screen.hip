@@ -275,21 +275,12 @@ constexpr int RING_NBUF = 5;                       // 5 x 27 KiB = 135 KiB of th
 constexpr int RING_AHEAD = 3;                      // tile t + 3 is requested during step t, published during step t + 1
 constexpr int RING_FLAG_BYTES = 64;
 
-// flag words are touched through explicit DS instructions: a volatile C++ access through the generic pointer became
-// flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e. every poll drained the wave's LDS-DMA requests and candidate stores
-__device__ __forceinline__ unsigned lds_flag_load(unsigned byte_addr) {          // wave-uniform address -> wave-uniform value
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(byte_addr) : "memory");
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-__device__ __forceinline__ void lds_flag_store(unsigned byte_addr, unsigned val) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
-}
-__device__ __forceinline__ void lds_flag_add(unsigned byte_addr, unsigned val) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
-}
-
-template <int PASS, int WAVES>
+// VAR (ablation builds only, results wrong by construction): 1 no tile requests, 2 theta = inf (no extraction), 4 key fragments
+// from registers, 8 no ready / done words, 16 no threshold test at all
+// QW = query tiles of 32 per wave: 1 = 16 waves x 32 queries (four waves per SIMD, 128 registers), 2 = 8 waves x 64 queries (two per
+// SIMD, 256 registers: every key fragment read from the LDS feeds two multiplies -- half the LDS traffic, requests and flag
+// words per multiply)
+template <int PASS, int WAVES, int VAR = 0, int QW = 1>
 __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a, int n_qgroups) {
     // ONE shared object (a second one makes hipcc drain vmcnt(0) in front of every ds_read of the loop)
     __shared__ __attribute__((aligned(16))) unsigned short smem[RING_NBUF * STEP_ELEMS + RING_FLAG_BYTES / 2];
@@ -309,34 +300,40 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
     if (step1 > a.n_steps) step1 = a.n_steps;
     const int stride = (PASS == 0) ? a.sample : 1;
 
-    // query fragments: 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
-    bf16x8 qf[KB];
-    const int q = (qg * WAVES + wave) * QT + i;
-    const bool qvalid = q < a.L;
-    const int qc = qvalid ? q : a.L - 1;
-    const size_t qlin = (size_t)b * a.L + qc;
-    {
+    // query fragments: QW x 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
+    bf16x8 qf[QW][KB];
+    bool qvalid[QW];
+    float thq[QW], thlo[QW];          // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
+    int n_loc[QW];
+    int2* cseg[QW];
+    size_t seg[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const int q = ((qg * WAVES + wave) * QW + w) * QT + i;
+        qvalid[w] = q < a.L;
+        const int qc = qvalid[w] ? q : a.L - 1;
+        const size_t qlin = (size_t)b * a.L + qc;
         const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
 #pragma unroll
-        for (int t = 0; t < KB; ++t) qf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        thq[w] = 0.f;
+        if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
+        const unsigned tb = __float_as_uint(thq[w]);
+        thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
+        n_loc[w] = 0;
+        seg[w] = (qlin * a.splits + split) * 2 + h;
+        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
     }
-    float thq = 0.f;
-    if (PASS == 1) thq = qvalid ? a.theta[qlin] : __builtin_inff();
-    // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
-    float thlo;
-    {
-        const unsigned tb = __float_as_uint(thq);
-        thlo = __uint_as_float(thq > 0.f ? tb - 1u : (thq == 0.f ? 0x80000001u : tb + 1u));
-    }
-    int n_loc = 0;
-    const size_t seg = (qlin * a.splits + split) * 2 + h;
-    int2* const cseg = a.cand + seg * a.capseg + 1;               // slot 0 is the record's header
 #pragma unroll
-    for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[t]));
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[w][t]));
 
-    float gm[16];
+    float gm[QW][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gm[r] = -1.0f;
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[w][r] = -1.0f;
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&smem[0]));
@@ -363,10 +360,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         // --- requester duty: tile it + AHEAD belongs to wave (it + AHEAD) % WAVES ---------------------------------------
         {
             const int T = it + RING_AHEAD;
-            if (T < n_it && (T % WAVES) == wave) {
+            if (T < n_it && (T % WAVES) == wave && !(VAR & 1)) {
                 const int tb = T % RING_NBUF;
                 const unsigned need = (unsigned)(WAVES * (T / RING_NBUF));        // wave-steps that have used the slot before
-                if (need) {
+                if (need && !(VAR & 8)) {
                     while (lds_flag_load(done0 + 4 * tb) < need) __builtin_amdgcn_s_sleep(1);
                 }
                 const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
@@ -378,22 +375,43 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             }
         }
         // --- tile `it` must have been published -----------------------------------------------------------------------------
-        while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
+        if (!(VAR & 1) && !(VAR & 8))
+            while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
 
-        f32x16 acc[2];
+        f32x16 acc[QW][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int w = 0; w < QW; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
         const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
         for (int t = 0; t < KB; ++t) {
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], acc[1], 0, 0, 0);
+            bf16x8 k0, k1;
+            if (VAR & 4) { k0 = qf[0][t]; k1 = qf[0][(t + 1) % KB]; }
+            else {
+                k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp0 + 16 * t));
+                k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp1 + 16 * t));
+            }
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                acc[w][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[w][t], acc[w][0], 0, 0, 0);
+                acc[w][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[w][t], acc[w][1], 0, 0, 0);
+            }
+        }
+        // issue order of the block above: key fragments are read RING_PF taps ahead of their multiplies (left alone, hipcc waits
+        // for a fragment two instructions after asking for it: one exposed LDS latency per tap and wave)
+        if (!(VAR & 4)) {
+            constexpr int PF = (QW == 2) ? 3 : 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * QW, 0);
+                if (t + PF < KB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
         }
         // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
-        if (lane == 0) lds_flag_add(done0 + 4 * buf, 1u);
+        if (lane == 0 && !(VAR & 8)) lds_flag_add(done0 + 4 * buf, 1u);
         // --- publisher duty: the tile this wave requested a step ago has had ~1.7 steps to land ---------------------------
         if (pend_tile >= 0 && it > pend_tile - RING_AHEAD) {
             dma_wait_all();
@@ -401,35 +419,43 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             pend_tile = -1;
         }
         // --- tail: threshold test, candidate extraction ---------------------------------------------------------------------
-        if (PASS == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gm[r] = fmaxf(fmaxf(gm[r], acc[0][r]), acc[1][r]);
-        } else {
-            float mxt[2];
+        for (int w = 0; w < QW; ++w) {
+            if (VAR & 16) {
+                gm[w][0] += acc[w][0][0] + acc[w][1][0];
+            } else if (PASS == 0) {
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                float m = acc[tl][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[tl][r]);
-                mxt[tl] = m;
-            }
-            if (__any(fmaxf(mxt[0], mxt[1]) >= thq)) {
+                for (int r = 0; r < 16; ++r) gm[w][r] = fmaxf(fmaxf(gm[w][r], acc[w][0][r]), acc[w][1][r]);
+            } else {
+                // common case (no candidate in the whole wave): 16 v_max3 + one compare + one branch
+                float mxt[2];
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
-                    if (!__any(mxt[tl] >= thq)) continue;
-                    unsigned mask = 0;
+                    float m = acc[w][tl][0];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo - acc[tl][r]), 31);
-                    const int kbase = step * SK + 4 * h + tl * 32;
-                    const float sv = (__popc(mask) == 1) ? mxt[tl] : -mxt[tl];
-                    while (mask) {                                   // score r sits at bit 15 - r: ascending r
-                        const int bit = 31 - __clz((int)mask);
-                        mask &= ~(1u << bit);
-                        const int r = 15 - bit;
-                        const int key = kbase + (r & 3) + 8 * (r >> 2);
-                        if (n_loc < a.capseg - 1) cseg[n_loc] = make_int2(key, __float_as_int(sv));
-                        ++n_loc;
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[w][tl][r]);
+                    mxt[tl] = m;
+                }
+                if (__any(fmaxf(mxt[0], mxt[1]) >= thq[w])) {
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        if (!__any(mxt[tl] >= thq[w])) continue;
+                        unsigned mask = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo[w] - acc[w][tl][r]), 31);
+                        const int kbase = step * SK + 4 * h + tl * 32;
+                        // the screened score travels with the key: exact when the lane has one candidate in this tile (it is
+                        // the tile maximum), otherwise the maximum with the sign bit set = "upper bound only"
+                        const float sv = (__popc(mask) == 1) ? mxt[tl] : -mxt[tl];
+                        while (mask) {                                   // score r sits at bit 15 - r: ascending r
+                            const int bit = 31 - __clz((int)mask);
+                            mask &= ~(1u << bit);
+                            const int r = 15 - bit;
+                            const int key = kbase + (r & 3) + 8 * (r >> 2);
+                            if (n_loc[w] < a.capseg - 1) cseg[w][n_loc[w]] = make_int2(key, __float_as_int(sv));
+                            ++n_loc[w];
+                        }
                     }
                 }
             }
@@ -437,25 +463,31 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         buf = (buf + 1 == RING_NBUF) ? 0 : buf + 1;
     }
 
-    if (PASS == 0) {
-        float top[GKEEP];
 #pragma unroll
-        for (int u = 0; u < GKEEP; ++u) {
-            float m = gm[0];
+    for (int w = 0; w < QW; ++w) {
+        if (PASS == 0) {
+            // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
+            // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
+            float top[GKEEP];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[r]);
-            top[u] = m;
-            bool taken = false;
+            for (int u = 0; u < GKEEP; ++u) {
+                float m = gm[w][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool hit = !taken && (gm[r] == m);
-                gm[r] = hit ? -1.0f : gm[r];
-                taken = taken || hit;
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[w][r]);
+                top[u] = m;
+                bool taken = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool hit = !taken && (gm[w][r] == m);
+                    gm[w][r] = hit ? -1.0f : gm[w][r];
+                    taken = taken || hit;
+                }
             }
+            if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
+        } else {
+            if ((VAR & 16) && gm[w][0] == 12345.f) n_loc[w] = 1;      // (keeps the ablated loop's accumulators alive)
+            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
         }
-        if (qvalid) *reinterpret_cast<float4*>(a.gmax + seg * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
-    } else {
-        if (qvalid) cseg[-1] = make_int2(n_loc, 0);
     }
 }
 
@@ -513,6 +545,15 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     const size_t n_blk = (size_t)grid.x * grid.y;
     ScreenArgs at = a; at.times = (getenv("DAGL_TIMES_FILE") && pass == 1) ? dbg_times_buffer(n_blk) : nullptr;
 #define a at
+    static const int ring_env = [] { const char* e = getenv("DAGL_SCREEN_RING"); return e ? atoi(e) : 1; }();
+    if (qblock == 512 && ring_env) {
+#define SCR_R5(P_, V_) do { if (ring_env == 2) hipLaunchKernelGGL((screen_ring_kernel<P_, 8, V_, 2>), grid, dim3(512), 0, s, a, n_qgroups); \
+                            else hipLaunchKernelGGL((screen_ring_kernel<P_, 16, V_>), grid, dim3(1024), 0, s, a, n_qgroups); } while (0)
+#define SCR_RV(P_) switch (a.variant) { case 0: SCR_R5(P_, 0); break; case 1: SCR_R5(P_, 1); break; case 2: SCR_R5(P_, 2); break; case 3: SCR_R5(P_, 3); break; \
+                                         case 7: SCR_R5(P_, 7); break; case 15: SCR_R5(P_, 15); break; case 31: SCR_R5(P_, 31); break; case 6: SCR_R5(P_, 6); break; \
+                                         case 18: SCR_R5(P_, 18); break; case 8: SCR_R5(P_, 8); break; default: SCR_R5(P_, 0); break; }
+        if (pass == 0) { SCR_R5(0, 0); } else { SCR_RV(1) }
+    } else
     if (qblock == 512) {                                                  // 512-query blocks: a few variants only
 #define SCR_L5(P_, V_) hipLaunchKernelGGL((screen_kernel<P_, 1, V_, 512>), grid, dim3(1024), 0, s, a, n_qgroups)
 #define SCR_V5(P_) switch (a.variant) { case 0: SCR_L5(P_, 0); break; case 8: SCR_L5(P_, 8); break; case 24: SCR_L5(P_, 24); break; \
@@ -527,19 +568,14 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 #undef a
     if (at.times) dbg_times_dump(s, "screen_kernel<1>", at.times, n_blk);
 #else
-    static const bool ring = [] { const char* e = getenv("DAGL_SCREEN_RING"); return e == nullptr || atoi(e) != 0; }();
-    if (qblock == 512 && ring) {
+    // blocks that are alone on their CU (512 / 384 queries): the ring form; 256-query blocks (two per CU, small images) keep
+    // the barrier form -- two five-deep rings do not fit one CU's LDS
+    if (qblock == 512) {
         if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_ring_kernel<1, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
-    } else if (qblock == 384 && ring) {
+    } else if (qblock == 384) {
         if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 12>), grid, dim3(768), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_ring_kernel<1, 12>), grid, dim3(768), 0, s, a, n_qgroups);
-    } else if (qblock == 512) {
-        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
-        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 512>), grid, dim3(1024), 0, s, a, n_qgroups);
-    } else if (qblock == 384) {
-        if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
-        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 384>), grid, dim3(768), 0, s, a, n_qgroups);
     } else {
         if (pass == 0) hipLaunchKernelGGL((screen_kernel<0, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_kernel<1, 1, 0>), grid, dim3(512), 0, s, a, n_qgroups);

@@ -46,7 +46,10 @@ def reference_modules():
 def main():
     from dagl_amd.net import chop_forward, psnr, seeded_state_dict, set12_protocol_noise, sparse_heads_state_dict
     sparse = "--sparse" in sys.argv       # second regime: sparse adaptive masks (sparse_heads_state_dict, gain 1.65)
-    suffix = "_sparse" if sparse else ""
+    # third: a briefly TRAINED checkpoint (tools/train_quality_ckpt.py on the GPU box: 400 DN_Gray steps from the seeded
+    # init on Set12 crops, stored as float16) -- weights that mean something: output PSNR ~10 dB above the noisy input
+    trained = "--ckpt" in sys.argv
+    suffix = "_sparse" if sparse else ("_trained" if trained else "")
     torch.set_num_threads(os.cpu_count() or 1)
     ref_pkg, ref_dagl = reference_modules()
     args = SimpleNamespace(n_resblocks=16, n_feats=64, n_colors=1, res_scale=1, rgb_range=1.0)
@@ -54,6 +57,9 @@ def main():
     sd = seeded_state_dict(net.state_dict(), SEED)
     if sparse:
         sd = sparse_heads_state_dict(sd, SEED + 100, 1.65)
+    if trained:
+        z = np.load(os.path.join(HERE, "quality_ckpt_fp16.npz"))
+        sd = {k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}
     net.load_state_dict(sd, strict=True)
 
     # 1. tiling check: my chop_forward == the reference's Model.forward_chop (cheap stand-in network)
@@ -71,7 +77,9 @@ def main():
     files = sorted(glob.glob(os.path.join(REF, "testsets", "Set12", "*.png")))
     assert len(files) == 12
     images = {os.path.basename(f)[:-4]: np.asarray(Image.open(f).convert("L"), dtype=np.uint8) for f in files}
-    if not sparse:
+    if trained:
+        pass                                                              # all twelve images
+    elif not sparse:
         np.savez_compressed(os.path.join(HERE, "set12.npz"), **{f"img_{k}": v for k, v in images.items()})
     else:
         images = {k: images[k] for k in ("01", "05", "09")}             # three images (two 256^2, one 512^2) suffice here
@@ -89,7 +97,9 @@ def main():
         subs[f"out_{name}"] = out[0, 0, ::8, ::8].numpy().astype(np.float32)
         print(name, result[name], flush=True)
         json.dump(dict(seed=SEED, sigma=50, protocol="DN_Gray/test.py:49-66, forward_chop without ensemble",
-                       heads=("sparse_heads_state_dict(seed + 100, gain 1.65)" if sparse else "seeded_state_dict"),
+                       heads=("sparse_heads_state_dict(seed + 100, gain 1.65)" if sparse else
+                              ("tests/golden/quality_ckpt_fp16.npz (tools/train_quality_ckpt.py, float16 values)" if trained
+                               else "seeded_state_dict")),
                        torch=torch.__version__, images=result),
                   open(os.path.join(HERE, f"set12_psnr_ref{suffix}.json"), "w"), indent=1)
         np.savez_compressed(os.path.join(HERE, f"set12_out_sub{suffix}.npz"), **subs)
