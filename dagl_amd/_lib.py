@@ -27,6 +27,7 @@ STAGE_NAMES = ("layout", "project", "thresholds", "screen_sample", "select", "ed
 FLAG_EXACT_SCAN = 0x100
 FLAG_WEIGHTS_PACKED = 0x200
 FLAG_DENSE_HINT = 0x400
+FLAG_NO_WAIT = 0x800
 
 
 class DaglError(RuntimeError):

@@ -150,6 +150,15 @@ class CE(nn.Module):
         self._train_dense_calls = 0
         self._dense_hint = False       # the last adaptive call ended in the dense formulation: start there next time
         self._dense_calls = 0
+        # adaptive mode: "always" (default) = read the call's verdict on the host every call: any neighbourhood structure is
+        # served (lists + per-query redo, dense formulation, CSR lists).  "auto" (opt-in, for steady sparse workloads and HIP-graph
+        # capture) = once four calls in a row were served in-stream, stop waiting (DAGL_FLAG_NO_WAIT: no synchronisation at
+        # all); the device-side verdict NaN-fills a call the in-stream kernels could not serve -- never wrong numbers -- and
+        # the sticky word is polled every 16th call, which sends the module back to waiting.
+        self.adaptive_sync = "always"
+        self._served_streak = 0
+        self._served_shape = None
+        self._nowait_calls = 0
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
 
@@ -163,7 +172,12 @@ class CE(nn.Module):
         shape, dev = self._last_call
         bad = ops.ce_range_check(shape, self.select_mode, min(int(self.select_k), shape[2] * shape[3]) if self.select_mode != "adaptive" else 0,
                                  self._ws, dev)
-        if bad:
+        if bad & 2:
+            import warnings
+            warnings.warn("dagl_amd.CE: an adaptive call that did not wait for its verdict met neighbourhoods the in-stream kernels "
+                          "could not serve (its output is NaN-filled); the module reads the verdict on the host again")
+            self._served_streak = 0
+        if bad & 1:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
         return not bad
 
@@ -348,12 +362,24 @@ class CE(nn.Module):
         hint = self._dense_hint and self.select_mode == "adaptive" and self.scan != "exact"
         self._dense_calls = self._dense_calls + 1 if hint else 0
         want_info = (not hint) or (self._dense_calls % 16 == 1) or self.profile is not None
+        if self._served_shape != tuple(b.shape):
+            self._served_shape, self._served_streak = tuple(b.shape), 0
+        no_wait = (self.select_mode == "adaptive" and self.scan != "exact" and not hint and self.adaptive_sync == "auto"
+                   and self._served_streak >= 4 and key == self._pack_key and self.profile is None)
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
-                                         dense_hint=hint, want_info=want_info)
+                                         dense_hint=hint, want_info=want_info, no_wait=no_wait)
         self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
         self._last_call = (tuple(b.shape), b.device)
+        if no_wait:
+            self._nowait_calls += 1
+            if self._nowait_calls >= 16 and not torch.cuda.is_current_stream_capturing():
+                self._nowait_calls = 0
+                self.range_ok()                    # (one synchronisation: sticky verdict + range word since the last poll)
+        elif self.select_mode == "adaptive" and info is not None:
+            served = info.get("path") == 3 and not info.get("range_fallback")
+            self._served_streak = self._served_streak + 1 if served else 0
         if info is not None and info.get("range_fallback"):
             self._note_range_violation("an adaptive call left the split-fp16 range and was re-run on the fp32 path")
         elif self.select_mode != "adaptive" and self.scan != "exact":

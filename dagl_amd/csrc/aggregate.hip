@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
     const int y = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     // range guard: a kernel of THIS call met a value outside the split-fp16 range -> the numbers are worthless: NaN
-    const bool poisoned = range.word != nullptr && *range.word == range.tag;
+    const bool poisoned = (range.word != nullptr && *range.word == range.tag) || (range.veto != nullptr && *range.veto == range.tag);
     if (range.done != nullptr && b == 0 && y == 0 && blockIdx.x == 0 && threadIdx.x == 0) *range.done = range.tag;
     if (x >= g.W) return;
     // rows r with 4r-3 <= y <= 4r+3

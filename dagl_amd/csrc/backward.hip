@@ -12,11 +12,10 @@
 //   mu_l = Wq_l . mean_j X_j                 d Wq_l += d mu_l Xbar,   d X_j += (sum_l d mu_l Wq_l) / N   for ALL keys j
 //   S_lj = Wq_l . X_j                        d Wq_l += sum_t d S_t X_{j_t},   d X_{j_t} += d S_t Wq_l
 // The two scatter-adds (d V into the value map, d S Wq into the key features) are turned into gathers: the edge list is
-// sorted by key with a stable radix sort (rocPRIM -- the one library primitive of this library; edge ids ascend
-// inside a key's run), so every output element is summed by one thread in a fixed order: no atomics, bit-reproducible
-// gradients.
+// sorted by key with a stable LSD radix sort (edge_radix_* below: 8 bits per pass, per-block digit histograms, one scan,
+// a scatter that ranks equal digits by position -- edge ids ascend inside a key's run), so every output element is summed
+// by one thread in a fixed order: no atomics whose order could matter, bit-reproducible gradients.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "dagl_common.h"
 
@@ -350,14 +349,111 @@ static int key_bits(size_t n_keys) {             // radix bits that cover 0..n_k
     return bits;
 }
 
+// ---- stable LSD radix sort of (key, edge id) pairs, 8 bits per pass ------------------------------------------------------
+// A block owns RS_TILE consecutive positions, visited in RS_ITEMS rounds of 256 (position = base + 256 round + thread): that
+// order IS the stable order.  Pass = (1) per-block digit counts (LDS integer atomics: the counts do not depend on their
+// order), stored digit-major; (2) one exclusive scan over [256 digits][blocks]; (3) scatter: an element's slot = its block's
+// start for the digit + the digit's elements in earlier rounds + in earlier waves of this round + in lower lanes of its wave
+// (eight ballots match the lanes that hold the same digit).
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = 256 * RS_ITEMS;
+
+__global__ __launch_bounds__(256) void edge_radix_hist_kernel(size_t n, int shift, const uint32_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ blockhist, unsigned nblk) {
+    __shared__ unsigned hist[256];
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t p = base + 256 * r + threadIdx.x;
+        if (p < n) atomicAdd(&hist[(keys[p] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockhist[(size_t)threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of m values in place (one block; m = 256 x blocks is a few ten thousand)
+__global__ __launch_bounds__(1024) void edge_radix_scan_kernel(size_t m, uint32_t* __restrict__ v) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const size_t per = (m + 1023) / 1024;
+    const size_t i0 = (size_t)t * per < m ? (size_t)t * per : m, i1 = i0 + per < m ? i0 + per : m;
+    uint32_t s = 0;
+    for (size_t i = i0; i < i1; ++i) s += v[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { uint32_t run = 0; for (int j = 0; j < 1024; ++j) { const uint32_t x = part[j]; part[j] = run; run += x; } }
+    __syncthreads();
+    uint32_t run = part[t];
+    for (size_t i = i0; i < i1; ++i) { const uint32_t x = v[i]; v[i] = run; run += x; }
+}
+
+__global__ __launch_bounds__(256) void edge_radix_scatter_kernel(size_t n, int shift, const uint32_t* __restrict__ keys_in,
+                                                                  const uint32_t* __restrict__ vals_in,
+                                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                  const uint32_t* __restrict__ blockoff, unsigned nblk) {
+    __shared__ unsigned start[256];            // next free slot of each digit for this block
+    __shared__ unsigned wcount[4][256];        // this round's digit counts per wave
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    start[t] = blockoff[(size_t)t * nblk + blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        wcount[0][t] = 0u; wcount[1][t] = 0u; wcount[2][t] = 0u; wcount[3][t] = 0u;
+        __syncthreads();
+        const size_t p = base + 256 * r + t;
+        const bool have = p < n;
+        const uint32_t key = have ? keys_in[p] : 0u, val = have ? vals_in[p] : 0u;
+        const unsigned d = (key >> shift) & 255u;
+        unsigned long long same = __ballot(have);                          // lanes of this wave holding the same digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((d >> bit) & 1u);
+            same &= ((d >> bit) & 1u) ? m : ~m;
+        }
+        const unsigned below = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        if (have && below == 0u) wcount[w][d] = (unsigned)__popcll(same);   // the digit's lowest lane speaks for the wave
+        __syncthreads();
+        if (have) {
+            unsigned pos = start[d] + below;
+            for (int w2 = 0; w2 < w; ++w2) pos += wcount[w2][d];
+            keys_out[pos] = key; vals_out[pos] = val;
+        }
+        __syncthreads();
+        start[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
+        __syncthreads();
+    }
+}
+
+static unsigned radix_blocks(size_t n) { return (unsigned)((n + RS_TILE - 1) / RS_TILE); }
+
+// sorts (keys_a, vals_a) by the low `bits` bits of the key, ping-ponging with (keys_b, vals_b); *sorted_in_b tells where the
+// result ended up
+static int edge_radix_sort(hipStream_t s, size_t n, int bits, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
+                           uint32_t* vals_b, uint32_t* blockhist, bool* sorted_in_b) {
+    const unsigned nblk = radix_blocks(n);
+    bool in_a = true;
+    for (int shift = 0; shift < bits; shift += 8) {
+        const uint32_t* ki = in_a ? keys_a : keys_b; const uint32_t* vi = in_a ? vals_a : vals_b;
+        uint32_t* ko = in_a ? keys_b : keys_a; uint32_t* vo = in_a ? vals_b : vals_a;
+        hipLaunchKernelGGL(edge_radix_hist_kernel, dim3(nblk), dim3(256), 0, s, n, shift, ki, blockhist, nblk);
+        DAGL_LAUNCH_CHECK("edge_radix_hist_kernel");
+        hipLaunchKernelGGL(edge_radix_scan_kernel, dim3(1), dim3(1024), 0, s, (size_t)256 * nblk, blockhist);
+        DAGL_LAUNCH_CHECK("edge_radix_scan_kernel");
+        hipLaunchKernelGGL(edge_radix_scatter_kernel, dim3(nblk), dim3(256), 0, s, n, shift, ki, vi, ko, vo, blockhist, nblk);
+        DAGL_LAUNCH_CHECK("edge_radix_scatter_kernel");
+        in_a = !in_a;
+    }
+    *sorted_in_b = !in_a;
+    return DAGL_OK;
+}
+
 size_t edge_rowbuf_floats(size_t n_edges) { return n_edges * ROWF; }
 size_t edge_part_floats(size_t n_edges) { return ((n_edges + SEG_C - 1) / SEG_C) * 2 * ROWF; }
 
-size_t edge_sort_temp_bytes(size_t n_edges, size_t n_keys) {
-    size_t bytes = 0;
-    uint32_t* k = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, n_edges, 0, key_bits(n_keys), (hipStream_t)0);
-    return bytes;
+size_t edge_sort_temp_bytes(size_t n_edges, size_t n_keys) {       // [256 digits][blocks] counts of one radix pass
+    (void)n_keys;
+    return (size_t)256 * radix_blocks(n_edges) * sizeof(uint32_t);
 }
 
 int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, float* dxbar_ws, float* db2_nchw) {
@@ -374,18 +470,24 @@ int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, fl
     // edges by key
     hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, a, w.keys_in, w.vals_in);
     DAGL_LAUNCH_CHECK("edge_keys_kernel");
-    size_t tb = w.temp_bytes;
-    DAGL_HIP_TRY(rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, E, 0, key_bits(n_keys), s));
+    bool in_b = false;
+    {
+        const int rc = edge_radix_sort(s, E, key_bits(n_keys), w.keys_in, w.vals_in, w.keys_out, w.vals_out,
+                                       static_cast<uint32_t*>(w.temp), &in_b);
+        if (rc) return rc;
+    }
+    const uint32_t* skeys = in_b ? w.keys_out : w.keys_in;
+    const uint32_t* svals = in_b ? w.vals_out : w.vals_in;
     DAGL_HIP_TRY(hipMemsetAsync(w.seg, 0, 2 * n_keys * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, E, (uint32_t)n_keys, w.keys_out, w.seg);
+    hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, E, (uint32_t)n_keys, skeys, w.seg);
     DAGL_LAUNCH_CHECK("segment_bounds_kernel");
     {
         const size_t chunks = (E + SEG_C - 1) / SEG_C;
         hipLaunchKernelGGL(edge_segreduce_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, a, E, (uint32_t)n_keys,
-                           w.keys_out, w.vals_out, w.seg, w.rowbuf, w.part);
+                           skeys, svals, w.seg, w.rowbuf, w.part);
         DAGL_LAUNCH_CHECK("edge_segreduce_kernel");
         hipLaunchKernelGGL(row_fixup_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, E, (uint32_t)n_keys,
-                           w.keys_out, w.seg, w.rowbuf, w.part);
+                           skeys, w.seg, w.rowbuf, w.part);
         DAGL_LAUNCH_CHECK("row_fixup_kernel");
         hipLaunchKernelGGL(dvalue_fold_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s, a, w.seg, w.rowbuf, db2_nchw);
         DAGL_LAUNCH_CHECK("dvalue_fold_kernel");
@@ -409,12 +511,13 @@ int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, fl
 // ---- forward-side helpers of the training entry point -------------------------------------------------------------
 // dense feature rows [B,rows,196] -> the scans' layouts: fp32 [B,rows_alloc,204] (+ zero pad columns) and bf16 [.,216]
 __global__ void rows_to_feat_kernel(int rows, int rows_alloc, int rows_alloc_h, const float* __restrict__ src,
-                                    float* __restrict__ feat, unsigned short* __restrict__ feat_h) {
+                                    float* __restrict__ feat, unsigned short* __restrict__ feat_h, RangeTag range) {
     const int b = blockIdx.y;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)rows * DPAD) return;
     const int r = (int)(t / DPAD), c = (int)(t % DPAD);
     const float v = (c < D) ? src[((size_t)b * rows + r) * D + c] : 0.f;
+    if (range.word != nullptr && !(fabsf(v) < 3.0e38f)) *range.word = range.tag;
     if (c < DS) feat[((size_t)b * rows_alloc + r) * DS + c] = v;
     if (feat_h != nullptr) {
         unsigned u = __float_as_uint(v);
@@ -423,10 +526,10 @@ __global__ void rows_to_feat_kernel(int rows, int rows_alloc, int rows_alloc_h, 
     }
 }
 
-int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h) {
+int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h, RangeTag range) {
     const size_t n = (size_t)rows * DPAD;
     hipLaunchKernelGGL(rows_to_feat_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, rows, feat_rows(rows),
-                       feat_rows_h(rows), src, feat, feat_h);
+                       feat_rows_h(rows), src, feat, feat_h, range);
     DAGL_LAUNCH_CHECK("rows_to_feat_kernel");
     return DAGL_OK;
 }

@@ -124,7 +124,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
@@ -212,7 +212,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.o_segoff = carve(off, BL * p.splits * 2 * sizeof(int32_t));
     p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
     p.o_deg = carve(off, BL * sizeof(int32_t));
-    p.o_stats = carve(off, 8 * sizeof(int64_t));          // [0..3] per-call counters, [4] range word, [5] tag of the last completed call
+    p.o_stats = carve(off, 16 * sizeof(int64_t));         // [0..3] per-call counters, [4] range word, [5] tag of the last completed call,
+                                                          // [6] redone rows, [7] their edges, [8] veto word (DAGL_FLAG_NO_WAIT)
     if (mode == DAGL_MODE_ADAPTIVE) {
         p.o_lidx = carve(off, BL * DAGL_FAST_CAP * sizeof(int32_t));
         p.o_lval = carve(off, BL * DAGL_FAST_CAP * sizeof(float));
@@ -350,7 +351,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // range guard of the split-fp16 kernels (dagl_common.h RangeTag); the fp32 path and the training entry point have no
     // such range
     RangeTag rt;
-    if (p.split16 && (!core || core->lse)) {        // (the streamed dense core splits the features into fp16 halves too)
+    if (p.split16 || core) {        // (training entry points: the streamed dense core splits the features into fp16 halves too, and
+                                    //  non-finite feature rows -- a poisoned projection upstream -- must not vanish in the selection)
         rt.word = reinterpret_cast<int32_t*>(stats + 4); rt.done = reinterpret_cast<int32_t*>(stats + 5); rt.tag = next_call_tag();
     }
 
@@ -362,6 +364,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // the few per-call counters are cleared by the prologue kernel itself -- three launches fewer
     const bool prepared = fin && p.split16 && (mode_flags & DAGL_FLAG_WEIGHTS_PACKED);
     if (rt.word != nullptr && !prepared) DAGL_HIP_TRY(hipMemsetAsync(stats + 4, 0, 2 * sizeof(int64_t), s));   // fresh workspace
+    if (!prepared && mode == DAGL_MODE_ADAPTIVE) DAGL_HIP_TRY(hipMemsetAsync(stats + 8, 0, sizeof(int64_t), s));
     if (core) {
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     } else if (fin) {
@@ -450,8 +453,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // ---- stage 1: both projections, one launch -------------------------------------------------------------
     prof_mark(prof, s, 1);
     if (core) {
-        if ((rc = launch_rows_to_feat(s, B, g.N, core->x_rows, X, Xh))) return rc;
-        if ((rc = launch_rows_to_feat(s, B, g.L, core->wq_rows, Wq, Wqh))) return rc;
+        if ((rc = launch_rows_to_feat(s, B, g.N, core->x_rows, X, Xh, rt))) return rc;
+        if ((rc = launch_rows_to_feat(s, B, g.L, core->wq_rows, Wq, Wqh, rt))) return rc;
         if (mode != DAGL_MODE_TOPK)
             if ((rc = launch_colsum_rows(s, B, g.N, core->x_rows, colsum))) return rc;
     } else if (p.split16) {
@@ -648,16 +651,32 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             // the optimistic gather, the flagged rows' weighted sums and the fold behind it, and the host waits for the
             // copy alone -- the device works through the round trip and through the caller's next launches.
             if (ovf_active) { const OvfArgs oa = overflow_args(); if ((rc = launch_overflow_scores(s, oa))) return rc; }
+            // DAGL_FLAG_NO_WAIT: the verdict is formed on the device, the call returns without reading it (no host round trip:
+            // the adaptive forward can be captured into a HIP graph); an unserved call is NaN-filled, never wrong
+            const bool no_wait = (mode_flags & DAGL_FLAG_NO_WAIT) && ovf_active && !dbg_deg && !dbg_rowsum && !dbg_agg && !core && heads == 1;
+            if (no_wait) {
+                if (rt.tag == 0) rt.tag = next_call_tag();
+                rt.veto = reinterpret_cast<const int32_t*>(stats + 8);
+            }
             {
                 const OvfArgs oa = ovf_active ? overflow_args() : OvfArgs();
-                if ((rc = launch_degree_stats(s, BL, nbcnt, stats, ovf_active ? &oa : nullptr))) return rc;
+                if ((rc = launch_degree_stats(s, BL, nbcnt, stats, ovf_active ? &oa : nullptr, 0,
+                                              no_wait ? reinterpret_cast<int32_t*>(stats + 8) : nullptr, rt.tag))) return rc;
+            }
+            if (no_wait) {
+                if ((rc = run_tail(ag))) return rc;
+                if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
+                return DAGL_OK;                                  // info: path 3, statistics not read (-1)
             }
             bool pending = false;
             if ((rc = read_back_begin(s, stats, 8, &pending))) return rc;
             if ((rc = run_tail(ag))) return rc;
             int64_t hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if ((rc = read_back_end(s, stats, 8, pending, hs))) return rc;
-            if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) return rerun_exact();
+            if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) {
+                if (core) { if (info) info->range_fallback = 1; return DAGL_OK; }   // (training entry point: non-finite features; out is NaN-filled)
+                return rerun_exact();
+            }
             if (info) info->redone_queries = hs[2];
             // most queries overflow, or the flagged rows are too heavy to redo one by one (the attend kernels saw the same
             // word and left them alone): dense regime
@@ -907,7 +926,7 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
     if (rc) return rc;
     DAGL_REQUIRE(ws_bytes >= p.o_end && ((uintptr_t)workspace % 256) == 0, "dagl_ce_range_check: not the workspace of such a call");
     *violated = 0;
-    if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range
+    if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range (and always waits)
     int64_t h[2] = {0, 0};
     int64_t* st = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + p.o_stats);
     if ((rc = read_back((hipStream_t)stream, st + 4, 2, h))) return rc;
@@ -915,6 +934,11 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
     // prepared workspace do not clear it), so a poll every n-th call sees a violation of ANY call since the last poll
     *violated = ((int32_t)h[0] != 0) ? 1 : 0;
     if (*violated) DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream));
+    if ((mode & 0xff) == DAGL_MODE_ADAPTIVE) {           // bit 1: a DAGL_FLAG_NO_WAIT call was not served in-stream (likewise sticky)
+        int64_t v[1] = {0};
+        if ((rc = read_back((hipStream_t)stream, st + 8, 1, v))) return rc;
+        if ((int32_t)v[0] != 0) { *violated |= 2; DAGL_HIP_TRY(hipMemsetAsync(st + 8, 0, sizeof(int64_t), (hipStream_t)stream)); }
+    }
     return DAGL_OK;
 }
 

@@ -108,6 +108,8 @@ struct RangeTag {
     int32_t* word = nullptr;     // workspace word: tag of the last call that left the fp16 range
     int32_t* done = nullptr;     // workspace word: tag of the last completed call (written by the fold)
     int32_t tag = 0;             // this call's tag (process-wide counter, never 0)
+    const int32_t* veto = nullptr;   // workspace word (DAGL_FLAG_NO_WAIT): tag of the last adaptive call whose neighbourhoods the
+                                     // in-stream kernels did NOT serve (too many / too heavy overflowed queries): same poison
 };
 constexpr float RANGE_LIMIT = 60000.0f;
 
@@ -325,7 +327,9 @@ int refine_heavy_cap();
 struct OvfArgs;
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
                         const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */,
-                        int count_over = 0 /* > 0: stats[2] = rows with a larger degree */);
+                        int count_over = 0 /* > 0: stats[2] = rows with a larger degree */,
+                        int32_t* veto = nullptr, int32_t tag = 0 /* flagged form: *veto = tag when the host would have had to
+                                                                    send the call elsewhere (dense formulation / CSR redo) */);
 
 // per-query dense redo of the queries that overflowed the screened adaptive lists (overflow.hip)
 struct OvfArgs {
@@ -346,7 +350,8 @@ constexpr int OVF_CHUNKS = 32;                                 // key chunks a f
 constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}
 int launch_overflow_scores(hipStream_t s, const OvfArgs& a);    // flagged rows: scores against all keys + per-chunk statistics
 int launch_overflow_apply(hipStream_t s, const OvfArgs& a);     // ... weighted sums, combined rows and degrees written back
-int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a);
+int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a,
+                                int32_t* veto = nullptr, int32_t tag = 0);
 int overflow_cap(int N, int B);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
@@ -398,7 +403,9 @@ size_t edge_sort_temp_bytes(size_t n_edges, size_t n_keys);
 size_t edge_rowbuf_floats(size_t n_edges);
 size_t edge_part_floats(size_t n_edges);
 int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, float* dxbar_ws, float* db2_nchw);
-int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h);
+int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float* feat, uint16_t* feat_h,
+                        RangeTag range = RangeTag() /* a non-finite feature (NaN-filled by a projection that left its range)
+                                                       poisons the call: a NaN score would silently drop out of the selection */);
 
 // batched fp32 GEMM on the matrix cores (gemm32.hip): C[b] = alpha * A[b] B[b] + beta * C[b] (+ bias[n], relu)
 struct Gemm32 {

@@ -46,9 +46,12 @@ constexpr int DN_CSTR = DN_RH * DN_XW + 2;            // halfs per channel plane
                                                       // of a column tile hit different banks)
 constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
-constexpr int DN_CTMAX = 7;                           // column tiles per wave: shares 6 / 6 / 7 / 6 (the first two waves also form S)
-__host__ __device__ constexpr int dn_ct_start(int part) { return part == 0 ? 0 : part == 1 ? 6 : part == 2 ? 12 : 19; }
-__host__ __device__ constexpr int dn_ct_count(int part) { return part == 0 ? 6 : part == 1 ? 6 : part == 2 ? 7 : 6; }
+// A V: every wave takes a share of the 25 column tiles for BOTH query tiles of the block (3 tiles, the last wave 4): a value
+// fragment assembled from the LDS planes (five dword reads + four funnel shifts per 16 bytes -- what this kernel's LDS time
+// consists of) then feeds six multiplies instead of three (round 2: a wave = one query tile x 6-7 column tiles, 2.08 ms)
+constexpr int DN_CTMAX = 4;
+__host__ __device__ constexpr int dn_ct_start(int w8) { return 3 * w8; }
+__host__ __device__ constexpr int dn_ct_count(int w8) { return w8 == 7 ? 4 : 3; }
 constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
@@ -63,8 +66,8 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
 // so the value is plane[c][2 kb + h + kh][kw + e]
 // One code path for all four column shares (ct0, cnt are wave-uniform): a four-way dispatch on the share made the register
 // allocator keep all four instantiations' fragments alive (128 spills at 256 registers).
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CTMAX], const unsigned char* planes, int c, int h, bool second,
-                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], int ct0, int cnt) {
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], const unsigned char* planes, int c, int h, bool second,
+                                      const dnh8 (&p_hi)[2][2], const dnh8 (&p_lo)[2][2], int ct0, int cnt) {
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
         if (t >= cnt) continue;                                              // wave-uniform
@@ -89,9 +92,12 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[DN_CTMAX], const unsigned ch
                 w[3] = __builtin_amdgcn_alignbyte(d4, d3, shift);
                 if (part == 0) v_hi = __builtin_bit_cast(dnh8, w); else v_lo = __builtin_bit_cast(dnh8, w);
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[kb], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[kb], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[kb], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[qq][kb], acc[qq][t], 0, 0, 0);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[qq][kb], acc[qq][t], 0, 0, 0);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[qq][kb], acc[qq][t], 0, 0, 0);
         }
     }
 }
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const int n_qblocks = (g.L + 63) / 64;
     const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
     const int qt = wave >> 2, part = wave & 3;
-    const int ct0 = dn_ct_start(part), ctn = dn_ct_count(part);                  // this wave's column tiles (wave-uniform)
+    const int ct0 = dn_ct_start(wave), ctn = dn_ct_count(wave);                  // this wave's column tiles (wave-uniform), both query tiles
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
@@ -147,11 +153,13 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const unsigned short* qrow = &sq[0][(qt * 32 + i) * DSH + 8 * h];       // B operand of the score MFMAs: Wq[q][16 kb + 8 h ..]
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
 
-    f32x16 acc[DN_CTMAX];
+    f32x16 acc[2][DN_CTMAX];
 #pragma unroll
-    for (int t = 0; t < DN_CTMAX; ++t)
+    for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < DN_CTMAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
     // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
     float m_run;
     {
@@ -303,9 +311,13 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             *reinterpret_cast<dnh4*>(pq + 32 + 8 * part) = lv;
         }
         __syncthreads();
-        dnh8 p_hi[2], p_lo[2];
-        p_hi[0] = *reinterpret_cast<const dnh8*>(pq);      p_hi[1] = *reinterpret_cast<const dnh8*>(pq + 16);
-        p_lo[0] = *reinterpret_cast<const dnh8*>(pq + 32); p_lo[1] = *reinterpret_cast<const dnh8*>(pq + 48);
+        dnh8 p_hi[2][2], p_lo[2][2];                       // the weights of BOTH query tiles (lane = query i, key half h)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const unsigned char* pv = reinterpret_cast<const unsigned char*>(&spq[qq][lane][0]);
+            p_hi[qq][0] = *reinterpret_cast<const dnh8*>(pv);      p_hi[qq][1] = *reinterpret_cast<const dnh8*>(pv + 16);
+            p_lo[qq][0] = *reinterpret_cast<const dnh8*>(pv + 32); p_lo[qq][1] = *reinterpret_cast<const dnh8*>(pv + 48);
+        }
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
         const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
         if (!(a.variant & 1)) {
@@ -332,8 +344,11 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             a.part_z[2 * orow + 1] = (szz[qt][0][i][1] + szz[qt][1][i][1]) + (szz[qt][2][i][1] + szz[qt][3][i][1]);
             a.part_deg[orow] = (sdg[qt][0][i] + sdg[qt][1][i]) + (sdg[qt][2][i] + sdg[qt][3][i]);
         }
-        float* po = a.part_acc + orow * P;
-        dn_store(acc, po, h, ct0, ctn);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {                       // this wave's column tiles of both query tiles
+        const int q2 = qb * 64 + qq * 32 + i;
+        if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0, ctn);
     }
 }
 

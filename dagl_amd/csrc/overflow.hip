@@ -270,7 +270,7 @@ int overflow_cap(int N, int B) {
 // the lists' counts, with every flagged row's clipped count replaced by its true degree (what ovf_combine_kernel will
 // store in nb_cnt afterwards)
 __global__ __launch_bounds__(1024) void degree_stats_flagged_kernel(size_t n_rows, const int32_t* __restrict__ nb_cnt,
-                                                                    int64_t* __restrict__ stats, OvfArgs a) {
+                                                                    int64_t* __restrict__ stats, OvfArgs a, int32_t* veto, int32_t tag) {
     __shared__ long long ssum[16];
     __shared__ int smax[16];
     __shared__ long long sfl[16];
@@ -290,11 +290,21 @@ __global__ __launch_bounds__(1024) void degree_stats_flagged_kernel(size_t n_row
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m = max(m, smax[w]); f += sfl[w]; }
         stats[0] = t; stats[1] = m;
         if (a.flagged_edges != nullptr) *a.flagged_edges = f;       // what redoing the flagged rows one by one would gather
+        if (veto != nullptr) {
+            // the host's verdict (capi.hip, adaptive mode) formed here for the calls that do not wait for it: were the overflowed
+            // queries all redone in-stream?  If not, the fold NaN-fills this call's output and dagl_ce_range_check reports it.
+            const long long ov = stats[2];
+            const bool heavy = ov > 0 && ov <= a.cap && f > a.edge_limit;
+            const bool mostly = ov * 2 > (long long)n_rows || heavy;
+            const bool served = ov == 0 || (!mostly && ov <= a.cap);
+            if (!served) *veto = tag;
+        }
     }
 }
 
-int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a) {
-    hipLaunchKernelGGL(degree_stats_flagged_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, a);
+int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a, int32_t* veto,
+                                int32_t tag) {
+    hipLaunchKernelGGL(degree_stats_flagged_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, a, veto, tag);
     DAGL_LAUNCH_CHECK("degree_stats_flagged_kernel");
     return DAGL_OK;
 }

@@ -1017,8 +1017,9 @@ __global__ __launch_bounds__(1024) void degree_stats_kernel(size_t n_rows, const
     }
 }
 
-int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs* flagged, int count_over) {
-    if (flagged != nullptr && flagged->cap > 0) return launch_degree_stats_flagged(s, n_rows, nb_cnt, stats, *flagged);
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs* flagged, int count_over,
+                        int32_t* veto, int32_t tag) {
+    if (flagged != nullptr && flagged->cap > 0) return launch_degree_stats_flagged(s, n_rows, nb_cnt, stats, *flagged, veto, tag);
     hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, count_over);
     DAGL_LAUNCH_CHECK("degree_stats_kernel");
     return DAGL_OK;

@@ -327,11 +327,13 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
 @_on_device
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
                      profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False,
-                     dense_hint: bool = False, want_info: bool = True):
+                     dense_hint: bool = False, want_info: bool = True, no_wait: bool = False):
     """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
     state_dict names to contiguous fp32 GPU tensors.  Returns (out, info).  ``dense_hint``: go straight to the streamed
     dense formulation (adaptive mode; same result, see DAGL_FLAG_DENSE_HINT); with ``want_info=False`` that path does
-    not read its edge statistics back (no host synchronisation) and info is None."""
+    not read its edge statistics back (no host synchronisation) and info is None.  ``no_wait`` (adaptive mode behind the
+    screen, DAGL_FLAG_NO_WAIT): the verdict stays on the device, an unserved call is NaN-filled and ``ce_range_check``
+    reports it; info is None."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -358,6 +360,9 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
         if ws.peek(x.device) is not None:
             need = max(need, ws.peek(x.device).numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
     quiet = dense_hint and not want_info
+    if no_wait and mode == "adaptive" and not exact_scan and not dense_hint and H * W >= 2048:
+        mode_flags |= _lib.FLAG_NO_WAIT
+        quiet = True
     out = torch.empty(B, 16, H, W, device=x.device, dtype=torch.float32)
     info = _lib.CeInfo()
     rc = 0
@@ -384,7 +389,7 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
                      range_fallback=info.range_fallback)
 
 
-def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> bool:
+def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> int:
     """True when a forward on ``workspace`` (input shape ``shape``) since the last check left the range of the split-fp16
     kernels and returned a NaN-filled output (``dagl_ce_range_check``; one host synchronisation; the word is sticky and
     cleared by the check that reports it).  ``shape[0]`` counts head x image pairs for a stage workspace."""
@@ -397,7 +402,7 @@ def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> 
     out = C.c_int(0)
     with torch.cuda.device(device):
         check(lib.dagl_ce_range_check(_stream(), B, H, W, MODES[mode], int(k), a, nbytes, C.byref(out)), "dagl_ce_range_check")
-    return bool(out.value)
+    return int(out.value)            # bit 0: range, bit 1: an unserved no-wait adaptive call
 
 
 @_on_device
@@ -492,7 +497,7 @@ def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: i
                                   saved["mu"].data_ptr() if adaptive else None, a, nbytes, C.byref(info))
     check(rc, "dagl_ce_core_forward")
     saved["info"] = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=info.path,
-                         redone_queries=info.redone_queries)
+                         redone_queries=info.redone_queries, range_fallback=info.range_fallback)
     return out, saved
 
 

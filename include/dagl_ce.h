@@ -65,6 +65,14 @@ extern "C" {
  * same either way; info->total_edges tells the caller whether the hint still pays                              */
 #define DAGL_FLAG_DENSE_HINT     0x400
 
+/* OR-ed into `mode` (adaptive mode behind the bf16 screen): do not wait for the call's verdict on the host.  The few queries
+ * whose neighbourhood overflows the lists are redone in-stream as always; whether that covered the call (it does not when
+ * most queries overflow or the flagged rows are too heavy: the host would have sent the call to the dense formulation) is
+ * decided on the device: an unserved call's output is NaN-filled -- never wrong numbers -- and dagl_ce_range_check reports
+ * it (bit 1, sticky).  No host synchronisation at all: such a call can be captured into a HIP graph.  info is not filled
+ * beyond required_bytes / path.  Callers use it once a workspace's calls have been served in-stream before (dagl_amd.CE).   */
+#define DAGL_FLAG_NO_WAIT        0x800
+
 #define DAGL_MAX_TOPK            64   /* largest k of the top-k modes (the fixed-k variant defaults to num_edge = 50,
                                          GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
                                          top_k = min(k, N) (:243), the lists are then min(k, N) wide               */
@@ -108,7 +116,7 @@ typedef struct dagl_ce_info {
  *   - the training entry points (dagl_project_patches16, dagl_ce_core_dense_forward) NaN-fill their outputs likewise; the
  *     dense forward re-runs itself in its fp32 form when it reads statistics back (info != NULL, range_fallback = 1).   */
 int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
-                        int* violated);
+                        int* violated /* bit 0: range, bit 1: an unserved DAGL_FLAG_NO_WAIT call */);
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40

@@ -15,7 +15,7 @@ def pytest_configure(config):
 def golden_cases():
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*.npz")))
-    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol"))]      # CE block cases only
+    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol", "quality_"))]      # CE block cases only
 
 
 @pytest.fixture(scope="session")
