@@ -246,7 +246,64 @@ def extra_configs(dev):
                                                        weights_packed=True), 10, 3, EXTRA_PREWARM_S)     # (CES._stage's protocol)
         out["256x256_ces_stage_topk8"] = {"what": "one CES stage (4 heads + 1x1 mix + residual, dagl_ces_stage_forward)",
                                           "ms_per_step": ms, "patches_per_s": 4 * 4096 / (ms * 1e-3), "L": 4096, "N": 65536}
+        del heads, prm, x, ws
+        torch.cuda.empty_cache()
+    out["train_rr_topk8_128x128_b8"] = train_extra(dev)
     return out
+
+
+def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
+    """BASELINE configs[4] on one GPU inside the driver-timed command: RR (12 heads, fixed-k 8) fwd + bwd + Adam on synthetic crops
+    [8,3,128,128], plus the roofline of the step's dominant matrix product -- the fc2 weight gradient dW = dZ^T rows,
+    [196 x 131072] x [131072 x 784] on the fp32 matrix cores (gemm32_kernel, split-K, summed in slice order)."""
+    from dagl_amd import ops
+    from dagl_amd.ce import CE
+    from dagl_amd.net import RR, seeded_state_dict
+    from dagl_amd.train import TrainOptions, TrainStep, freeze_unused, make_optimizer
+    net = RR(n_colors=colors)
+    net.load_state_dict(seeded_state_dict(net.state_dict(), 7), strict=True)
+    for m in net.modules():
+        if isinstance(m, CE):
+            m.select_mode, m.select_k = "topk", 8
+    net = net.to(dev)
+    freeze_unused(net)
+    opt = TrainOptions(task="dn_real", lr=1e-4)
+    step = TrainStep(net, make_optimizer(net, opt), opt, generator=torch.Generator(device=dev).manual_seed(300))
+    hr = torch.rand(B, colors, crop, crop, generator=torch.Generator().manual_seed(200)).to(dev)
+    ms = _time_steps(lambda: step(hr), steps, warmup)
+    del net, step
+    torch.cuda.empty_cache()
+    return {"what": "BASELINE configs[4] (sparse regime) on one GPU: RR with 12 CE heads, crops [8,3,128,128], fwd + bwd + Adam, "
+                    "fixed-k 8; no RCCL leg here (world size 1) -- `bench.py --train --gpus N` runs it under DDP",
+            "ms_per_step": ms, "crops_per_s": B / (ms * 1e-3), "steps": steps, "warmup": warmup,
+            "roofline": gemm_roofline(dev, B * crop * crop)}
+
+
+def gemm_roofline(dev, n):
+    """The training step's dominant matrix product on its own, hipEvent-bracketed on the launch stream: the fc2 weight gradient
+    dW = dZ^T rows, [196 x n] x [n x 784] (n = key patches of the batch) on the fp32 matrix cores."""
+    from dagl_amd import ops
+    O, K = 196, 784
+    g = torch.Generator(device=dev).manual_seed(1)
+    dz = torch.randn(n, O, device=dev, generator=g)
+    rows = torch.randn(n, K, device=dev, generator=g)
+    for _ in range(2):
+        ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 8
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
+    e1.record()
+    e1.synchronize()
+    g_ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * O * K * n
+    ach = flop / (g_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm32_kernel (fc2 weight gradient dW = dZ^T rows, [196 x %d] x [%d x 784], "
+                                                    "v_mfma_f32_32x32x2_f32, split-K)" % (n, n),
+            "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+            "flop_per_launch": flop, "ms_per_launch": g_ms, "traffic": None,
+            "calls_per_step": "12 heads x (fc2 on the key rows; fc1 on the query rows is 1/16 of it)"}
 
 
 def committed_traffic(kernel_key):
@@ -267,10 +324,15 @@ def quality_leg(dev):
     import numpy as np
     from dagl_amd.net import RR, chop_forward_batched, psnr, seeded_state_dict, set12_protocol_noise
     gdir = os.path.join(REPO, "tests", "golden")
-    ref = json.load(open(os.path.join(gdir, "set12_psnr_ref.json")))
+    trained = os.path.exists(os.path.join(gdir, "quality_ckpt_fp16.npz")) and os.path.exists(os.path.join(gdir, "set12_psnr_ref_trained.json"))
+    ref = json.load(open(os.path.join(gdir, "set12_psnr_ref_trained.json" if trained else "set12_psnr_ref.json")))
     imgs = np.load(os.path.join(gdir, "set12.npz"))
     net = RR().eval()
-    net.load_state_dict(seeded_state_dict(net.state_dict(), ref["seed"]), strict=True)
+    if trained:      # 400 DN_Gray steps from the seeded init (tools/train_quality_ckpt.py), float16 values on both sides
+        z = np.load(os.path.join(gdir, "quality_ckpt_fp16.npz"))
+        net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
+    else:
+        net.load_state_dict(seeded_state_dict(net.state_dict(), ref["seed"]), strict=True)
     net = net.to(dev)
     deltas, t0 = {}, time.perf_counter()
     for name in sorted(ref["images"]):
@@ -280,7 +342,10 @@ def quality_leg(dev):
             out = torch.clamp(chop_forward_batched(net, noisy.to(dev)), 0.0, 1.0).cpu()
         deltas[name] = psnr(out, clean) - ref["images"][name]["psnr_out"]
     return {"dataset": "Set12 (12 images), sigma=50, reference test protocol (tiled inference, no self-ensemble)",
-            "weights": f"regenerable stand-in checkpoint (numpy PCG64 seed {ref['seed']}); no trained weights ship with the reference",
+            "weights": ("tests/golden/quality_ckpt_fp16.npz: RR after 400 DN_Gray training steps on the HIP path from the seeded init "
+                        "(Set12 crops, sigma 50; float16 values loaded by both sides) -- no trained weights ship with the reference"
+                        if trained else f"regenerable stand-in checkpoint (numpy PCG64 seed {ref['seed']})"),
+            "psnr_noisy_mean_db": sum(r["psnr_noisy"] for r in ref["images"].values()) / len(ref["images"]),
             "psnr_delta_db_max_abs": max(abs(v) for v in deltas.values()),
             "psnr_delta_db_mean": sum(deltas.values()) / len(deltas),
             "psnr_ref_mean_db": sum(r["psnr_out"] for r in ref["images"].values()) / len(ref["images"]),
@@ -345,7 +410,7 @@ def train_bench(args, dev, dist, world, rank):
                                        f"{args.crop},{args.crop}] per GPU, MSE(sum)/(2B) loss, Adam, gradients of "
                                        f"{n_par} parameters all-reduced over RCCL",
                            "parallelism": f"ddp{world}", "select_mode": args.mode, "k": args.k, "batch_per_gpu": B},
-                "roofline": None, "cpu_baseline": None,
+                "roofline": gemm_roofline(dev, B * args.crop * args.crop), "cpu_baseline": None,
                 "allreduce_ms": allreduce_ms, "allreduce_bytes": 4 * n_par if dist is not None else None,
                 "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None}
         print(json.dumps(line))
@@ -524,10 +589,11 @@ def main():
         screened = (info or {}).get("path") == 3
         peak = PEAK_BF16_MATRIX_TFLOPS if screened else PEAK_F32_MATRIX_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": "screen_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter)" if screened
+                    "kernel": "screen_ring_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter; screen_kernel<1> for "
+                              "256-query blocks)" if screened
                               else "score_select_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": committed_traffic("screen_kernel<1>") if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
+                    "traffic": (committed_traffic("screen_ring_kernel<1>") or committed_traffic("screen_kernel<1>")) if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
         if gather is not None and mean_ms[6] > 0:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))

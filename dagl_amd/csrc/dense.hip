@@ -67,7 +67,7 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
 // One code path for all four column shares (ct0, cnt are wave-uniform): a four-way dispatch on the share made the register
 // allocator keep all four instantiations' fragments alive (128 spills at 256 registers).
 __device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], const unsigned char* planes, int c, int h, bool second,
-                                      const dnh8 (&p_hi)[2][2], const dnh8 (&p_lo)[2][2], int ct0, int cnt) {
+                                      const dnh8 (&p_hi)[2][2], const dnh8 (&p_lo)[2][2], int ct0, int cnt, int variant = 0) {
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
         if (t >= cnt) continue;                                              // wave-uniform
@@ -81,6 +81,8 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], const unsigned
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             dnh8 v_hi, v_lo;
+            if (variant & 8) { v_hi = p_hi[0][kb]; v_lo = p_lo[0][kb]; }       // (ablation: no value-fragment assembly)
+            else
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const unsigned* dp = reinterpret_cast<const unsigned*>(base + part * (DN_PLANE_H * 2) + kb * (2 * DN_XW * 2));
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             const bool valid = (jx0 + (r & 7) < g.W) && (jy0 + 2 * (r >> 3) + h < g.H);   // pixel (row 2 (r>>3) + h, column r & 7) of the tile
             bool pass;
             const float l = dn_logit(sc, mtq, bsq, pass);
-            const float p = valid ? __expf(fminf(l - m_run, 0.f)) : 0.f;      // (the bound holds; the clamp is a seat belt)
+            const float p = (a.variant & 16) ? 0.5f : (valid ? __expf(fminf(l - m_run, 0.f)) : 0.f);      // (the bound holds; the clamp is a seat belt)
             zt += p;
             pass = pass && valid;
             const float pp = pass ? p : 0.f;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
         const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
         if (!(a.variant & 1)) {
-            dn_pv(acc, planes, i & 15, h, second, p_hi, p_lo, ct0, ctn);
+            dn_pv(acc, planes, i & 15, h, second, p_hi, p_lo, ct0, ctn, a.variant);
         }
         dma_wait_all();
         __syncthreads();                                   // everyone is done with this tile's planes and features

@@ -383,6 +383,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         for (int w = 0; w < QW; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
+#ifdef DAGL_RING_PRIO
+        __builtin_amdgcn_s_setprio(DAGL_RING_PRIO);
+#endif
         const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
@@ -402,7 +405,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         // issue order of the block above: key fragments are read RING_PF taps ahead of their multiplies (left alone, hipcc waits
         // for a fragment two instructions after asking for it: one exposed LDS latency per tap and wave)
         if (!(VAR & 4)) {
+#ifdef DAGL_RING_PF
+            constexpr int PF = DAGL_RING_PF;
+#else
             constexpr int PF = (QW == 2) ? 3 : 2;
+#endif
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
 #pragma unroll
             for (int t = 0; t < KB; ++t) {
@@ -410,6 +417,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                 if (t + PF < KB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
+#ifdef DAGL_RING_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
         if (lane == 0 && !(VAR & 8)) lds_flag_add(done0 + 4 * buf, 1u);
         // --- publisher duty: the tile this wave requested a step ago has had ~1.7 steps to land ---------------------------

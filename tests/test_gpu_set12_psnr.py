@@ -81,3 +81,40 @@ def test_set12_psnr_delta_sparse_masks(net_sparse, name):
     with torch.no_grad():
         outb = torch.clamp(chop_forward_batched(model, noisy.to("cuda:0")), 0.0, 1.0).cpu()
     assert abs(psnr(outb, clean) - r["psnr_out"]) <= 0.02
+
+
+@pytest.fixture(scope="module")
+def net_trained():
+    """Third regime: weights that mean something.  tests/golden/quality_ckpt_fp16.npz = RR after 400 DN_Gray training steps on
+    the HIP path (tools/train_quality_ckpt.py, float16 values); the reference forward with exactly those values ran on the CPU
+    in the build container (tests/golden/make_set12_psnr.py --ckpt): 25.3 dB mean against 14.1 dB of the noisy input."""
+    from dagl_amd.net import RR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "set12_psnr_ref_trained.json")))
+    z = np.load(os.path.join(GOLDEN_DIR, "quality_ckpt_fp16.npz"))
+    m = RR().eval()
+    m.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
+    return m.to("cuda:0"), ref
+
+
+@pytest.mark.parametrize("name", ["%02d" % i for i in range(1, 13)])
+def test_set12_psnr_delta_trained_checkpoint(net_trained, name):
+    from dagl_amd.ce import CE
+    from dagl_amd.net import chop_forward_batched, psnr, set12_protocol_noise
+    model, ref = net_trained
+    imgs = np.load(os.path.join(GOLDEN_DIR, "set12.npz"))
+    subs = np.load(os.path.join(GOLDEN_DIR, "set12_out_sub_trained.npz"))
+    clean = torch.from_numpy(imgs[f"img_{name}"].astype(np.float32) / 255.0)[None, None]
+    noisy = set12_protocol_noise(clean, 50.0, 1.0)
+    r = ref["images"][name]
+    with torch.no_grad():
+        out = torch.clamp(chop_forward_batched(model, noisy.to("cuda:0")), 0.0, 1.0).cpu()
+    p = psnr(out, clean)
+    dens = []
+    for m in model.modules():
+        if isinstance(m, CE) and m.last_info and m.last_info.get("total_edges", -1) >= 0:
+            dens.append(m.last_info["total_edges"])
+    print(f"Set12/{name} (trained checkpoint): noisy {r['psnr_noisy']:.2f} dB, reference {r['psnr_out']:.4f} dB, HIP {p:.4f} dB, "
+          f"delta {p - r['psnr_out']:+.6f} dB; paths {sorted({m.last_info['path'] for m in model.modules() if isinstance(m, CE) and m.last_info})}")
+    assert p > r["psnr_noisy"] + 8.0                                     # the network denoises
+    assert abs(p - r["psnr_out"]) <= 0.02
+    assert normwise(out[0, 0, ::8, ::8].numpy(), subs[f"out_{name}"]) <= 2e-3

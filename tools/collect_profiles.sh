@@ -5,7 +5,7 @@
 #   3. --pmc SQ_* counters                           MFMA utilisation / wait breakdown of the matrix-core kernels
 # tools/summarize_profiles.py turns the CSVs into the small JSON / CSV files kept under profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
