@@ -39,6 +39,27 @@ __device__ __forceinline__ void glds16_asm(const float* gsrc, unsigned lds_byte_
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// A whole 27-KiB key tile of the screen (27 pieces of 1 KiB) requested by ONE wave in one statement: wave-uniform source
+// base in SGPRs + a 32-bit lane offset, four pieces per M0 value through the instruction's immediate offset (it advances the
+// global AND the LDS address), M0 saved / restored once.  The per-piece form above costs the issuing wave ~280 cycles a piece
+// in this kernel (phase clocks, profiles/r03_screen_ring_phases.log): every piece waits for the previous one to leave the
+// issue stage before M0 may change.
+__device__ __forceinline__ void glds_tile27_asm(const void* src_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
+    unsigned keep;
+#define DAGL_G4 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t" \
+                "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+#define DAGL_ADV "v_add_u32 %1, 0x1000, %1\n\ts_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"            // (M0 -> LDS-DMA, fresh SGPR base -> VMEM)
+                 DAGL_G4 DAGL_ADV DAGL_G4 DAGL_ADV DAGL_G4 DAGL_ADV DAGL_G4 DAGL_ADV DAGL_G4 DAGL_ADV DAGL_G4 DAGL_ADV
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(lane_byte_off)
+                 : "s"(src_uniform), "s"(lds_byte_addr)
+                 : "memory");
+#undef DAGL_G4
+#undef DAGL_ADV
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // counted form: returns once at most N of this wave's vector-memory operations are outstanding (loads land in issue order, so
 // everything but the N youngest has arrived)

@@ -341,7 +341,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 
     // prologue: the first RING_AHEAD tiles are requested by all waves together (one barrier, outside the loop)
     const unsigned ready0 = lds0 + RING_NBUF * STEP_ELEMS * 2, done0 = ready0 + 32;        // LDS byte addresses of the flag words
+#ifdef DAGL_RING_SPREAD
+    // spread form: EVERY wave requests its share of every tile (pieces wave, wave + WAVES, ..) and ready[] counts the waves whose
+    // share has landed: WAVES x (tiles the slot has held)
+    if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)WAVES : 0u; flags[8 + tid] = 0u; }
+#else
     if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)(tid + 1) : 0u; flags[8 + tid] = 0u; }
+#endif
 #pragma unroll
     for (int j = 0; j < RING_AHEAD; ++j)
         if (j < n_it) {
@@ -355,8 +361,46 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 
     int pend_tile = -1;                              // tile this wave has requested and not yet published (wave-uniform)
     int buf = 0;                                     // it % RING_NBUF
+    // VAR & 64 (ablation): per-wave sums of shader-clock deltas: 0 tile request (+ wait for the slot), 1 reads + multiplies,
+    // 2 test + extraction, 3 wait for the tile's ready word, 4 publishing (vmcnt wait)
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long ph_t = (VAR & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+#define RING_PH(k) do { if (VAR & 64) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); ph[k] += t1_ - ph_t; ph_t = t1_; } } while (0)
     for (int it = 0; it < n_it; ++it) {
         const int step = step0 + it * stride;
+#ifdef DAGL_RING_SPREAD
+        {
+            // (1) my share of tile it + AHEAD - 1 was requested a whole step ago: it has landed -> one more wave's share is in
+            if (it >= 1 && it + RING_AHEAD - 1 < n_it && !(VAR & 1)) {
+                dma_wait_all();
+                if (lane == 0) lds_flag_add(ready0 + 4 * ((it + RING_AHEAD - 1) % RING_NBUF), 1u);
+            }
+            // (2) one look at the flag words (lane l reads word l): tile `it` complete, and the slot of tile it + AHEAD left by everybody
+            const int T = it + RING_AHEAD;
+            const int tb = T % RING_NBUF;
+            const unsigned need_ready = (unsigned)(WAVES * (it / RING_NBUF + 1));
+            const unsigned need_done = (T < n_it) ? (unsigned)(WAVES * (T / RING_NBUF)) : 0u;
+            if (!(VAR & 1) && !(VAR & 8)) {
+                for (;;) {
+                    unsigned v;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ready0 + 4u * (unsigned)(lane & 15)) : "memory");
+                    const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, buf);
+                    const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 8 + tb);
+                    if (r >= need_ready && d >= need_done) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            RING_PH(3);
+            // (3) my share of tile it + AHEAD
+            if (T < n_it && !(VAR & 1)) {
+                const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
+                const unsigned short* src = xb + (size_t)(step0 + T * stride) * STEP_ELEMS + lane * 8;
+                for (int p = wave; p < STEP_PIECES; p += WAVES)
+                    glds16_asm(reinterpret_cast<const float*>(src + p * 512), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+            }
+            RING_PH(0);
+        }
+#else
         // --- requester duty: tile it + AHEAD belongs to wave (it + AHEAD) % WAVES ---------------------------------------
         {
             const int T = it + RING_AHEAD;
@@ -367,16 +411,29 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                     while (lds_flag_load(done0 + 4 * tb) < need) __builtin_amdgcn_s_sleep(1);
                 }
                 const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
+#ifdef DAGL_RING_PIECEWISE
                 const unsigned short* src = xb + (size_t)(step0 + T * stride) * STEP_ELEMS + lane * 8;
 #pragma unroll
                 for (int p = 0; p < STEP_PIECES; ++p)
                     glds16_asm(reinterpret_cast<const float*>(src + p * 512), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+#else
+                {
+                    const unsigned long long sa = (unsigned long long)(uintptr_t)(xb + (size_t)(step0 + T * stride) * STEP_ELEMS);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32));
+                    glds_tile27_asm(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)lane * 16u,
+                                    __builtin_amdgcn_readfirstlane(dst));
+                }
+#endif
                 pend_tile = T;
             }
         }
+        RING_PH(0);
         // --- tile `it` must have been published -----------------------------------------------------------------------------
         if (!(VAR & 1) && !(VAR & 8))
             while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
+        RING_PH(3);
+#endif
 
         f32x16 acc[QW][2];
 #pragma unroll
@@ -385,6 +442,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
 #ifdef DAGL_RING_PRIO
         __builtin_amdgcn_s_setprio(DAGL_RING_PRIO);
+#endif
+#ifdef DAGL_RING_TAILPRIO
+        __builtin_amdgcn_s_setprio(0);
 #endif
         const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
@@ -420,14 +480,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 #ifdef DAGL_RING_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+#ifdef DAGL_RING_TAILPRIO
+        __builtin_amdgcn_s_setprio(DAGL_RING_TAILPRIO);        // tail (and the next step's request / poll) ahead of the other waves' multiplies
+#endif
         // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
         if (lane == 0 && !(VAR & 8)) lds_flag_add(done0 + 4 * buf, 1u);
+        if (VAR & 64) { asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[0][1][15])); }       // (the multiplies have completed)
+        RING_PH(1);
         // --- publisher duty: the tile this wave requested a step ago has had ~1.7 steps to land ---------------------------
         if (pend_tile >= 0 && it > pend_tile - RING_AHEAD) {
             dma_wait_all();
             if (lane == 0) lds_flag_store(ready0 + 4 * (pend_tile % RING_NBUF), (unsigned)(pend_tile + 1));
             pend_tile = -1;
         }
+        RING_PH(4);
         // --- tail: threshold test, candidate extraction ---------------------------------------------------------------------
 #pragma unroll
         for (int w = 0; w < QW; ++w) {
@@ -471,6 +537,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             }
         }
         buf = (buf + 1 == RING_NBUF) ? 0 : buf + 1;
+        RING_PH(2);
+    }
+#undef RING_PH
+    if ((VAR & 64) && a.times != nullptr && lane == 0) {
+        unsigned long long* o = a.times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 5;
+        for (int k = 0; k < 5; ++k) o[k] = ph[k];
     }
 
 #pragma unroll
@@ -553,7 +625,8 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     }
     static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
     const size_t n_blk = (size_t)grid.x * grid.y;
-    ScreenArgs at = a; at.times = (getenv("DAGL_TIMES_FILE") && pass == 1) ? dbg_times_buffer(n_blk) : nullptr;
+    const bool ring_phases = a.variant == 64 && qblock == 512;             // per-wave phase clocks: 16 waves x 5 sums per block
+    ScreenArgs at = a; at.times = (getenv("DAGL_TIMES_FILE") && pass == 1) ? dbg_times_buffer(ring_phases ? n_blk * 20 : n_blk) : nullptr;
 #define a at
     static const int ring_env = [] { const char* e = getenv("DAGL_SCREEN_RING"); return e ? atoi(e) : 1; }();
     if (qblock == 512 && ring_env) {
@@ -561,7 +634,7 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
                             else hipLaunchKernelGGL((screen_ring_kernel<P_, 16, V_>), grid, dim3(1024), 0, s, a, n_qgroups); } while (0)
 #define SCR_RV(P_) switch (a.variant) { case 0: SCR_R5(P_, 0); break; case 1: SCR_R5(P_, 1); break; case 2: SCR_R5(P_, 2); break; case 3: SCR_R5(P_, 3); break; \
                                          case 7: SCR_R5(P_, 7); break; case 15: SCR_R5(P_, 15); break; case 31: SCR_R5(P_, 31); break; case 6: SCR_R5(P_, 6); break; \
-                                         case 18: SCR_R5(P_, 18); break; case 8: SCR_R5(P_, 8); break; default: SCR_R5(P_, 0); break; }
+                                         case 18: SCR_R5(P_, 18); break; case 8: SCR_R5(P_, 8); break; case 64: SCR_R5(P_, 64); break; default: SCR_R5(P_, 0); break; }
         if (pass == 0) { SCR_R5(0, 0); } else { SCR_RV(1) }
     } else
     if (qblock == 512) {                                                  // 512-query blocks: a few variants only
@@ -576,7 +649,7 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     if (qw == 2) { if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) } }
     else { if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) } }
 #undef a
-    if (at.times) dbg_times_dump(s, "screen_kernel<1>", at.times, n_blk);
+    if (at.times) dbg_times_dump(s, ring_phases ? "screen_ring_kernel<1>_phases" : "screen_kernel<1>", at.times, ring_phases ? n_blk * 20 : n_blk);
 #else
     // blocks that are alone on their CU (512 / 384 queries): the ring form; 256-query blocks (two per CU, small images) keep
     // the barrier form -- two five-deep rings do not fit one CU's LDS

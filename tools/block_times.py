@@ -33,7 +33,7 @@ def main():
             mx = np.mean([r.max(axis=0) for r in runs], axis=0)
             tot = m.sum()
             print(f"{name}: per-wave clocks inside the loop, mean over waves (max): total {tot:.0f}")
-            for k, lab in enumerate(["tile request", "reads + multiplies", "test + extraction", "wait for tile", "barrier"]):
+            for k, lab in enumerate(["tile request", "reads + multiplies", "test + extraction", "wait for tile", "barrier / publish"]):
                 print(f"  {lab:20s} {m[k]:9.0f} ({mx[k]:9.0f})  {100 * m[k] / tot:5.1f} %")
             continue
         spans, ent, pro, loop, epi, ends = [], [], [], [], [], []
