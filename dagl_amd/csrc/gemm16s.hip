@@ -1,0 +1,384 @@
+// Gradient products of the two patch projections (fc1 / fc2, DN_Gray/model/dagl.py:196-203,248-249) on the fp16 matrix cores
+// with split operands.  Under autograd the projections are  Z = rows W^T  (rows = unfolded 7x7x16 patches, [n,784];
+// W [196,784]); their backward needs
+//     d W    = d Z^T rows        [196 x n] x [n x 784]      (n = 131 072 key patches for a batch of eight 128 x 128 crops)
+//     d rows = d Z  W            [n x 196] x [196 x 784]
+// 40 GFLOP each and per head -- on the fp32 matrix cores (gemm32.hip, 157 TF peak) 0.75 + 0.5 ms, a fifth of the whole
+// training step.  The forward already runs the same contraction with split-fp16 operands at 16x that rate (project16.hip);
+// this file does it for the gradients:
+//   * every operand is pre-scaled by a power of two and split into two fp16 numbers, s x = hi + lo (>= 21 significant bits; the
+//     matrix cores keep fp16 denormals), a product keeps hi*hi + hi*lo + lo*hi in ONE fp32 accumulator (small terms first);
+//     activations 16 x and weights 1024 w as in the forward, the gradient d Z by a per-call power of two taken from its
+//     largest magnitude (fcg_absmax_kernel -> device word; gradients span many orders of magnitude between steps);
+//   * both operands of a product are laid out K-CONTIGUOUS ([rows][K] halfs, K a multiple of 32), so a fragment is one
+//     16-byte LDS read and no transposing loader is needed: the producers write what the GEMM wants --
+//       d Z  -> [n][224] (K = outputs, for d rows) and, through an LDS transpose, [256][n] (K = patches, for d W),
+//       rows -> [896][n] straight from the zero-bordered map (an unfold that transposes: the [n,784] fp32 rows, 411 MB
+//               at this size, are never built for the weight gradient),
+//       W    -> [896][224] (K = outputs);
+//   * gemm16s_kernel: 128 x 128 x 32 tiles, 4 waves of 64 x 64, operands by LDS-DMA into a two-stage ring (64-byte rows, the
+//     four 16-byte slots of a row stored at slot ^ ((row >> 2) & 3): conflict-free ds_read_b128 of 32 consecutive rows, the
+//     projection's weight layout), v_mfma_f32_32x32x16_f16, the operands swapped so that a lane ends up with four
+//     consecutive columns of one output row (16-byte stores); split-K with a fixed-order reduce for the weight gradient.
+// Everything is summed in a fixed order: bit-reproducible.  Range: |16 x| (the forward's own limit) and |1024 w| < 65504.
+#include "dagl_common.h"
+
+namespace dagl {
+
+typedef _Float16 g16h8 __attribute__((ext_vector_type(8)));
+
+constexpr int G16_BM = 128, G16_BN = 128, G16_BK = 32;
+constexpr int G16_PART = G16_BM * G16_BK * 2;          // bytes of one operand part (hi or lo) per stage: 128 rows x 64 B = 8 KiB
+constexpr int G16_STAGE = 4 * G16_PART;                // A hi | A lo | B hi | B lo = 32 KiB
+constexpr int FCG_O = 196, FCG_OP = 224, FCG_OM = 256; // outputs, padded to the K step / to the M tile
+constexpr int FCG_P = 784, FCG_PP = 896;               // patch length, padded to the N tile (7 x 128)
+constexpr float FCG_XS = 16.0f, FCG_WS = 1024.0f;      // activation / weight pre-scaling (project16.hip)
+
+__device__ __forceinline__ void g16_split(float a, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h = (_Float16)a;
+    const _Float16 l = (_Float16)(a - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// largest |x| of a tensor -> *word (bits of a non-negative float: integer max = float max, order-independent)
+__global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4* __restrict__ x, unsigned* __restrict__ word) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __float_as_uint(m));
+}
+
+// power of two that brings a tensor's largest magnitude into [2^13, 2^14): s = 2^(13 - floor(log2 max)); 1 for an all-zero tensor
+__device__ __forceinline__ float fcg_scale_of(unsigned max_bits) {
+    if (max_bits == 0u || max_bits >= 0x7f800000u) return 1.0f;          // zero, inf / NaN: nothing to rescue
+    const int e = (int)(max_bits >> 23) - 127;                          // floor(log2 max) for normal numbers
+    int se = 13 - e;
+    if (se > 120) se = 120;
+    if (se < -120) se = -120;
+    return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
+// d Z [n, 196] fp32 -> hi / lo [n_pad][224] halfs (pad columns and pad rows zero), scaled by the call's power of two
+__global__ __launch_bounds__(256) void fcg_split_rows_kernel(size_t n, size_t n_pad, const float* __restrict__ dz,
+                                                             const unsigned* __restrict__ max_word, unsigned short* __restrict__ hi,
+                                                             unsigned short* __restrict__ lo) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // (row, octet of columns)
+    if (t >= n_pad * (FCG_OP / 8)) return;
+    const size_t row = t / (FCG_OP / 8); const int c8 = (int)(t - row * (FCG_OP / 8));
+    const float s = fcg_scale_of(*max_word);
+    unsigned short vh[8], vl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = 8 * c8 + u;
+        const float v = (row < n && c < FCG_O) ? dz[row * FCG_O + c] * s : 0.f;
+        g16_split(v, vh[u], vl[u]);
+    }
+    reinterpret_cast<uint4*>(hi)[t] = *reinterpret_cast<const uint4*>(vh);
+    reinterpret_cast<uint4*>(lo)[t] = *reinterpret_cast<const uint4*>(vl);
+}
+
+// d Z [n, 196] fp32 -> transposed hi / lo [256][n_pad] halfs (rows 196.. and columns n.. zero).  Block = 128 rows x 32
+// columns of d Z: coalesced 128-byte row reads, transposed in LDS, 256-byte runs written.
+__global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size_t n_pad, const float* __restrict__ dz,
+                                                                  const unsigned* __restrict__ max_word,
+                                                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    __shared__ __attribute__((aligned(16))) unsigned short th[32][128 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[32][128 + 8];
+    const size_t r0 = (size_t)blockIdx.x * 128;
+    const int c0 = blockIdx.y * 32;
+    const float s = fcg_scale_of(*max_word);
+    for (int e = threadIdx.x; e < 128 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const float v = (r0 + r < n && c0 + c < FCG_O) ? dz[(r0 + r) * FCG_O + c0 + c] * s : 0.f;
+        g16_split(v, th[c][r], tl[c][r]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 16; e += 256) {                        // (column, octet of rows)
+        const int c = e >> 4, r8 = e & 15;
+        const size_t o = ((size_t)(c0 + c) * n_pad + r0) / 8 + r8;
+        reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(&th[c][8 * r8]);
+        reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(&tl[c][8 * r8]);
+    }
+}
+
+// patches of the zero-bordered map [B,Hp,Wp,16], transposed and split: out[(tap, c)][patch] = 16 map[b, oy + py s + kh, ox + px s + kw, c]
+// (patch = (b, py, px) row-major; rows 784..895 are zeroed by the caller, columns past the last patch written as zero).
+// Block = 128 consecutive patches x one tap: 64-byte pixel reads, transposed in LDS, 256-byte runs written.
+__global__ __launch_bounds__(256) void fcg_unfold_transpose_kernel(int Hp, int Wp, int stride, int oy, int ox, int oh, int ow,
+                                                                   size_t n, size_t n_pad, const float* __restrict__ map,
+                                                                   unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    __shared__ __attribute__((aligned(16))) unsigned short th[16][128 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[16][128 + 8];
+    const size_t p0 = (size_t)blockIdx.x * 128;
+    const int tap = blockIdx.y, kh = tap / KS, kw = tap - kh * KS;
+    for (int e = threadIdx.x; e < 128 * 4; e += 256) {
+        const int r = e >> 2, c4 = e & 3;
+        const size_t p = p0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < n) {
+            const size_t b = p / ((size_t)oh * ow); const int q = (int)(p - b * (size_t)oh * ow);
+            const int py = q / ow, px = q - py * ow;
+            v = *reinterpret_cast<const float4*>(map + ((b * Hp + oy + py * stride + kh) * (size_t)Wp + ox + px * stride + kw) * CH + 4 * c4);
+        }
+        g16_split(v.x * FCG_XS, th[4 * c4 + 0][r], tl[4 * c4 + 0][r]);
+        g16_split(v.y * FCG_XS, th[4 * c4 + 1][r], tl[4 * c4 + 1][r]);
+        g16_split(v.z * FCG_XS, th[4 * c4 + 2][r], tl[4 * c4 + 2][r]);
+        g16_split(v.w * FCG_XS, th[4 * c4 + 3][r], tl[4 * c4 + 3][r]);
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x >> 4, r8 = threadIdx.x & 15;               // 16 channels x 16 octets of patches
+        const size_t o = ((size_t)(tap * CH + c) * n_pad + p0) / 8 + r8;
+        reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(&th[c][8 * r8]);
+        reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(&tl[c][8 * r8]);
+    }
+}
+
+// W [196][784] -> transposed hi / lo [896][224] halfs, 1024 w = hi + lo, pads zero
+__global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FCG_PP * FCG_OP) return;
+    const int kk = t / FCG_OP, o = t - kk * FCG_OP;
+    const float v = (kk < FCG_P && o < FCG_O) ? w[(size_t)o * FCG_P + kk] * FCG_WS : 0.f;
+    g16_split(v, hi[t], lo[t]);
+}
+
+struct Gemm16s {
+    int M, N;                                   // real output extent (stores are clipped to it)
+    int K;                                      // contraction length of ONE slice (multiple of 32)
+    const unsigned short *a_hi, *a_lo;          // [>= M rounded up to 128][lda] halfs, K-contiguous
+    const unsigned short *b_hi, *b_lo;          // [>= N rounded up to 128][ldb]
+    long long lda, ldb;                         // leading dimensions in halfs (multiples of 8)
+    int a_rows, b_rows;                         // rows that exist: a tile's loads are clamped to them (clipped outputs only)
+    float* C; long long ldc;                    // slices == 1: C[m][n] = alpha acc
+    float* part;                                // slices > 1: part[slice][M][N] raw accumulators
+    int slices;
+    const unsigned* scale_word; float alpha0;   // alpha = alpha0 / fcg_scale_of(*scale_word)
+};
+
+// C[m][n] = sum_k A[m][k] B[n][k]; block = 128 x 128 outputs, grid.z = K slices
+__global__ __launch_bounds__(256, 2) void gemm16s_kernel(Gemm16s g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G16_STAGE];            // 64 KiB
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * G16_BM, n0 = blockIdx.x * G16_BN;
+    const long long k0 = (long long)blockIdx.z * g.K;
+    const int wm = wave >> 1, wn = wave & 1;                                      // 2 x 2 waves of 64 x 64
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    // LDS-DMA: a piece = 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 holds logical slot (l & 3) ^ ((row >> 2) & 3)
+    const int prow = lane >> 2, pslot = (lane & 3) ^ ((prow >> 2) & 3);
+    auto stage = [&](int buf, long long k) {
+        const unsigned dst = lds0 + (unsigned)buf * G16_STAGE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave * 8 + j;                                           // 32 pieces: part (4) x 16-row group (8)
+            const int part = p >> 3, grp = p & 7;
+            const unsigned short* base = part == 0 ? g.a_hi : part == 1 ? g.a_lo : part == 2 ? g.b_hi : g.b_lo;
+            const long long ld = part < 2 ? g.lda : g.ldb;
+            int row = (part < 2 ? m0 : n0) + grp * 16 + prow;
+            const int lim = (part < 2 ? g.a_rows : g.b_rows) - 1;
+            if (row > lim) row = lim;
+            glds16_asm(reinterpret_cast<const float*>(base + (long long)row * ld + k + 8 * pslot),
+                       __builtin_amdgcn_readfirstlane(dst + (unsigned)part * G16_PART + (unsigned)grp * 1024));
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = g.K / G16_BK;
+    stage(0, k0);
+    dma_wait_all();
+    __syncthreads();
+    const int swz = (i >> 2) & 3;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) stage(cur ^ 1, k0 + (long long)(t + 1) * G16_BK);
+        const unsigned char* sb = smem + cur * G16_STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            g16h8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+            const int off = (((2 * kb + h) ^ swz) << 4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ra = (wm * 64 + u * 32 + i) * 64 + off, rb = (wn * 64 + u * 32 + i) * 64 + off;
+                a_hi[u] = *reinterpret_cast<const g16h8*>(sb + ra);
+                a_lo[u] = *reinterpret_cast<const g16h8*>(sb + G16_PART + ra);
+                b_hi[u] = *reinterpret_cast<const g16h8*>(sb + 2 * G16_PART + rb);
+                b_lo[u] = *reinterpret_cast<const g16h8*>(sb + 3 * G16_PART + rb);
+            }
+            // D[row = n (first operand's row)][col = m]: a lane holds four consecutive n of one m per register quad
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_lo[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo[b], a_hi[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_hi[a], acc[a][b], 0, 0, 0);
+        }
+        dma_wait_all();
+        __syncthreads();
+    }
+    const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / fcg_scale_of(g.scale_word ? *g.scale_word : 0u);
+    float* out = (g.slices > 1) ? g.part + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const long long ldo = (g.slices > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int m = m0 + wm * 64 + a * 32 + i;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + b * 32 + 8 * q + 4 * h;
+                if (m < g.M && n < g.N) {                                          // (N is a multiple of 4: whole quads)
+                    *reinterpret_cast<float4*>(out + (long long)m * ldo + n) =
+                        make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
+                                    acc[a][b][4 * q + 3] * alpha);
+                }
+            }
+    }
+}
+
+// C[i] = alpha * (part[0][i] + part[1][i] + ...) in slice order
+__global__ void gemm16s_reduce_kernel(size_t n4, int slices, const float4* __restrict__ part, float4* __restrict__ C,
+                                      const unsigned* __restrict__ scale_word, float alpha0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float alpha = alpha0 / fcg_scale_of(scale_word ? *scale_word : 0u);
+    float4 s = part[i];
+    for (int k = 1; k < slices; ++k) {
+        const float4 v = part[(size_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    C[i] = make_float4(s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha);
+}
+
+static int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
+    dim3 grid((g.N + G16_BN - 1) / G16_BN, (g.M + G16_BM - 1) / G16_BM, g.slices);
+    hipLaunchKernelGGL(gemm16s_kernel, grid, dim3(256), 0, s, g);
+    DAGL_LAUNCH_CHECK("gemm16s_kernel");
+    if (g.slices > 1) {
+        const size_t n4 = (size_t)g.M * g.N / 4;
+        hipLaunchKernelGGL(gemm16s_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n4, g.slices,
+                           reinterpret_cast<const float4*>(g.part), reinterpret_cast<float4*>(g.C), g.scale_word, g.alpha0);
+        DAGL_LAUNCH_CHECK("gemm16s_reduce_kernel");
+    }
+    return DAGL_OK;
+}
+
+// ---- the two gradient products of a patch projection -------------------------------------------------------------------
+struct FcgPlan {
+    size_t n, n_pad;                  // patches of the batch, rounded up to the K granule of the weight gradient
+    int slices; size_t k_slice;       // split-K of d W
+    size_t o_word, o_zk_hi, o_zk_lo, o_zt_hi, o_zt_lo, o_rt_hi, o_rt_lo, o_wt_hi, o_wt_lo, o_part, o_end;
+};
+
+static size_t fcg_carve(size_t& off, size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; }
+
+static FcgPlan fcg_plan(size_t n) {
+    FcgPlan p;
+    p.n = n;
+    // d W has 2 x 7 output tiles: K slices fill the chip (~512 blocks), each a multiple of the 32-deep K step
+    int slices = 36;
+    size_t ks = (n + (size_t)slices - 1) / slices;
+    ks = (ks + G16_BK - 1) / G16_BK * G16_BK;
+    if (ks < 256) { ks = 256; }
+    slices = (int)((n + ks - 1) / ks);
+    if (slices < 1) slices = 1;
+    p.slices = slices; p.k_slice = ks; p.n_pad = (size_t)slices * ks;
+    if (p.n_pad % 128) p.n_pad = (p.n_pad + 127) / 128 * 128;          // (the transposing producers work in tiles of 128 patches)
+    size_t off = 0;
+    p.o_word = fcg_carve(off, 256);
+    p.o_zk_hi = fcg_carve(off, p.n_pad * FCG_OP * 2); p.o_zk_lo = fcg_carve(off, p.n_pad * FCG_OP * 2);
+    p.o_zt_hi = fcg_carve(off, (size_t)FCG_OM * p.n_pad * 2); p.o_zt_lo = fcg_carve(off, (size_t)FCG_OM * p.n_pad * 2);
+    p.o_rt_hi = fcg_carve(off, (size_t)FCG_P * p.n_pad * 2); p.o_rt_lo = fcg_carve(off, (size_t)FCG_P * p.n_pad * 2);
+    p.o_wt_hi = fcg_carve(off, (size_t)FCG_PP * FCG_OP * 2); p.o_wt_lo = fcg_carve(off, (size_t)FCG_PP * FCG_OP * 2);
+    p.o_part = fcg_carve(off, (size_t)slices * FCG_O * FCG_P * sizeof(float));
+    p.o_end = off;
+    return p;
+}
+
+}  // namespace dagl
+
+using namespace dagl;
+
+extern "C" {
+
+size_t dagl_fc_grad16_scratch_bytes(int B, int oh, int ow) {
+    if (B < 1 || oh < 1 || ow < 1) return 0;
+    return fcg_plan((size_t)B * oh * ow).o_end;
+}
+
+int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
+                   const float* w_rows, const float* dz, float* d_w, float* d_rows, void* scratch, size_t scratch_bytes) {
+    DAGL_REQUIRE(B >= 1 && Hp >= 1 && Wp >= 1 && stride >= 1 && oy >= 0 && ox >= 0 && oh >= 1 && ow >= 1 &&
+                 oy + (oh - 1) * stride + KS <= Hp && ox + (ow - 1) * stride + KS <= Wp && dz && scratch && (d_w || d_rows),
+                 "dagl_fc_grad16: bad argument");
+    DAGL_REQUIRE((!d_w || map_nhwc) && (!d_rows || w_rows), "dagl_fc_grad16: d_w needs the map, d_rows the weight");
+    DAGL_REQUIRE(((uintptr_t)scratch % 256) == 0, "dagl_fc_grad16: scratch must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * oh * ow;
+    const FcgPlan p = fcg_plan(n);
+    DAGL_REQUIRE(scratch_bytes >= p.o_end, "dagl_fc_grad16: scratch %zu B, need %zu B", scratch_bytes, p.o_end);
+    char* ws = static_cast<char*>(scratch);
+    unsigned* word = reinterpret_cast<unsigned*>(ws + p.o_word);
+    auto H = [&](size_t o) { return reinterpret_cast<unsigned short*>(ws + o); };
+    DAGL_HIP_TRY(hipMemsetAsync(word, 0, 256, s));
+    {
+        const size_t n4 = n * FCG_O / 4;
+        hipLaunchKernelGGL(fcg_absmax_kernel, dim3(1024), dim3(256), 0, s, n4, reinterpret_cast<const float4*>(dz), word);
+        DAGL_LAUNCH_CHECK("fcg_absmax_kernel");
+    }
+    if (d_rows) {
+        const size_t items = p.n_pad * (FCG_OP / 8);
+        hipLaunchKernelGGL(fcg_split_rows_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, n, p.n_pad, dz, word,
+                           H(p.o_zk_hi), H(p.o_zk_lo));
+        DAGL_LAUNCH_CHECK("fcg_split_rows_kernel");
+        hipLaunchKernelGGL(fcg_weight_transpose_kernel, dim3((FCG_PP * FCG_OP + 255) / 256), dim3(256), 0, s, w_rows, H(p.o_wt_hi),
+                           H(p.o_wt_lo));
+        DAGL_LAUNCH_CHECK("fcg_weight_transpose_kernel");
+        Gemm16s g;
+        g.M = (int)n; g.N = FCG_P; g.K = FCG_OP;
+        g.a_hi = H(p.o_zk_hi); g.a_lo = H(p.o_zk_lo); g.lda = FCG_OP; g.a_rows = (int)p.n_pad;
+        g.b_hi = H(p.o_wt_hi); g.b_lo = H(p.o_wt_lo); g.ldb = FCG_OP; g.b_rows = FCG_PP;
+        g.C = d_rows; g.ldc = FCG_P; g.part = nullptr; g.slices = 1; g.scale_word = word; g.alpha0 = 1.0f / FCG_WS;
+        const int rc = launch_gemm16s(s, g);
+        if (rc) return rc;
+    }
+    if (d_w) {
+        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, dz,
+                           word, H(p.o_zt_hi), H(p.o_zt_lo));
+        DAGL_LAUNCH_CHECK("fcg_split_transpose_kernel");
+        hipLaunchKernelGGL(fcg_unfold_transpose_kernel, dim3((unsigned)(p.n_pad / 128), KS * KS), dim3(256), 0, s, Hp, Wp, stride, oy,
+                           ox, oh, ow, n, p.n_pad, map_nhwc, H(p.o_rt_hi), H(p.o_rt_lo));
+        DAGL_LAUNCH_CHECK("fcg_unfold_transpose_kernel");
+        // (rows 784..895 of the last N tile do not exist: its loads are clamped to row 783, their products are never stored)
+        Gemm16s g;
+        g.M = FCG_O; g.N = FCG_P; g.K = (int)p.k_slice;
+        g.a_hi = H(p.o_zt_hi); g.a_lo = H(p.o_zt_lo); g.lda = (long long)p.n_pad; g.a_rows = FCG_OM;
+        g.b_hi = H(p.o_rt_hi); g.b_lo = H(p.o_rt_lo); g.ldb = (long long)p.n_pad; g.b_rows = FCG_P;
+        g.C = d_w; g.ldc = FCG_P; g.part = reinterpret_cast<float*>(ws + p.o_part); g.slices = p.slices; g.scale_word = word;
+        g.alpha0 = 1.0f / FCG_XS;
+        const int rc = launch_gemm16s(s, g);
+        if (rc) return rc;
+    }
+    return DAGL_OK;
+}
+
+}  // extern "C"

@@ -59,6 +59,7 @@ def to_padded_nhwc(x, H, W, from_rows=False):
 
 
 FAST_FC_FORWARD = True          # forward of the two patch projections on the split-fp16 inference kernels (tests flip it)
+FAST_FC_BACKWARD = True         # their two gradient products on the split-fp16 GEMM (gemm16s.hip; tests flip it)
 
 
 def _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W):
@@ -104,18 +105,20 @@ class _PatchLinear(torch.autograd.Function):
                                               rows.data_ptr()), "dagl_unfold_patches")
                 y = ops.gemm_f32(rows, weight, a_k_contiguous=True, b_k_contiguous=True, bias=bias, relu=relu, chunk_tiles=7)
         ctx.geom = (B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K)
+        ctx.fast_grad = bool(FAST_FC_BACKWARD and allow_fast and (k, C, O) == (7, 16, 196))
         ctx.save_for_backward(pmap, weight, y if relu else pmap.new_empty(0))
         return y.view(B, oh * ow, O)
 
     @staticmethod
     def backward(ctx, d_y):
         pmap, weight, y = ctx.saved_tensors
-        d_map, d_w, d_b = _patch_linear_backward(pmap, weight, y, ctx.geom, d_y, *ctx.needs_input_grad[:3])
+        d_map, d_w, d_b = _patch_linear_backward(pmap, weight, y, ctx.geom, d_y, *ctx.needs_input_grad[:3], fast=ctx.fast_grad)
         return d_map, d_w, d_b, None, None, None, None, None, None, None, None
 
 
-def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b):
-    """d map / d weight / d bias of ``y = act(W . unfold(map) + bias)`` (the patch rows are recomputed, not kept)."""
+def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b, fast=False):
+    """d map / d weight / d bias of ``y = act(W . unfold(map) + bias)`` (the patch rows are recomputed, not kept).  ``fast``: the
+    two 7x7x16 -> 196 projections take the split-fp16 gradient GEMM (``dagl_fc_grad16``: no fp32 patch rows for d W)."""
     B, Hp, Wp, C, k, stride, oy, ox, oh, ow, relu, O, K = geom
     lib = _lib.load()
     n = B * oh * ow
@@ -126,10 +129,28 @@ def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b)
             check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
                   "dagl_relu_backward")
             dz = dzr
+        d_w = d_b = d_map = None
+        if fast and (need_w or need_map):
+            need = lib.dagl_fc_grad16_scratch_bytes(B, oh, ow)
+            scratch = torch.empty(need + 256, device=pmap.device, dtype=torch.uint8)
+            base = (scratch.data_ptr() + 255) // 256 * 256
+            d_w = torch.empty(O, K, device=pmap.device, dtype=torch.float32) if need_w else None
+            d_rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32) if need_map else None
+            check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pmap.data_ptr(), weight.data_ptr(),
+                                     dz.data_ptr(), d_w.data_ptr() if need_w else None,
+                                     d_rows.data_ptr() if need_map else None, base, need), "dagl_fc_grad16")
+            if need_b:
+                d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
+                scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
+                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr(), scr.data_ptr()), "dagl_col_sum")
+            if need_map:
+                d_map = torch.empty_like(pmap)
+                check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, d_rows.data_ptr(),
+                                            d_map.data_ptr()), "dagl_fold_patches")
+            return d_map, d_w, d_b
         rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32)          # recomputed, not kept
         check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
                                       rows.data_ptr()), "dagl_unfold_patches")
-        d_w = d_b = d_map = None
         if need_w:
             # [O,n] x [n,K]: split-K keeps the fma chains at a few thousand products, no chunked accumulation needed
             # (its second accumulator set costs a third of the kernel's occupancy)

@@ -80,3 +80,76 @@ def test_patch_linear_is_the_convolution_and_its_autograd(k, stride, C, H, W):
     (out * G.to(dev)).sum().backward()
     for got, want in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
         assert normwise(got.cpu().numpy(), want.numpy()) <= 5e-6
+
+
+@pytest.mark.parametrize("B,H,W,stride,scale", [(2, 40, 36, 1, 1.0), (1, 64, 64, 1, 1e-6), (3, 23, 30, 4, 1e3), (8, 128, 128, 1, 1e-4)])
+def test_fc_grad16_matches_fp64(B, H, W, stride, scale):
+    """The split-fp16 gradient products of a patch projection (gemm16s.hip, ``dagl_fc_grad16``): d W = d Z^T rows and
+    d rows = d Z W against fp64 -- stride-1 key grid and the stride-4 SAME query grid, gradients of very different
+    magnitudes (the per-call power-of-two scale), the BASELINE config-5 size; two calls agree bit for bit."""
+    import ctypes as C
+    from dagl_amd import _lib, ops
+    from dagl_amd.synth import same_pad_amounts
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    Hp, Wp = H + 6, W + 6
+    pmap = torch.zeros(B, Hp, Wp, 16)
+    pmap[:, 3:3 + H, 3:3 + W] = torch.randn(B, H, W, 16, generator=g)
+    if stride == 1:
+        oy = ox = 0; oh, ow = H, W
+    else:
+        t, l = same_pad_amounts(H, 7, 4)[0], same_pad_amounts(W, 7, 4)[0]
+        oy, ox, oh, ow = 3 - t, 3 - l, -(-H // 4), -(-W // 4)
+    n = B * oh * ow
+    w = (torch.rand(196, 784, generator=g) - 0.5) * 0.07
+    dz = torch.randn(n, 196, generator=g) * scale * torch.rand(n, 1, generator=g) ** 4          # heavy-tailed magnitudes
+    pm, wd, dzd = pmap.to(dev), w.to(dev), dz.to(dev)
+    need = lib.dagl_fc_grad16_scratch_bytes(B, oh, ow)
+    scratch = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    outs = []
+    for _ in range(2):
+        d_w = torch.empty(196, 784, device=dev); d_rows = torch.empty(n, 784, device=dev)
+        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pm.data_ptr(), wd.data_ptr(), dzd.data_ptr(),
+                                      d_w.data_ptr(), d_rows.data_ptr(), base, need), "dagl_fc_grad16")
+        outs.append((d_w.cpu(), d_rows.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # fp64 reference: rows by torch's unfold on the padded map (element order (kh,kw,c))
+    rows = torch.empty(n, 784, dtype=torch.float64)
+    x = pmap.double()
+    idx = 0
+    cols = []
+    for kh in range(7):
+        for kw in range(7):
+            cols.append(x[:, oy + kh: oy + kh + (oh - 1) * stride + 1: stride, ox + kw: ox + kw + (ow - 1) * stride + 1: stride, :])
+    rows = torch.stack(cols, dim=3).reshape(n, 784)                                              # [B,oh,ow,49,16]
+    want_w = dz.double().t() @ rows
+    want_r = dz.double() @ w.double()
+    e_w, e_r = normwise(outs[0][0].numpy(), want_w.numpy()), normwise(outs[0][1].numpy(), want_r.numpy())
+    print(f"[parity] fc_grad16 B={B} {H}x{W} stride {stride} |dz|~{scale:g}: d_w {e_w:.2e}, d_rows {e_r:.2e} (normwise vs fp64)")
+    assert e_w <= 5e-6 and e_r <= 5e-6
+
+
+def test_projection_backward_fast_path_equals_the_fp32_gemm_path():
+    """CE's fc2 layer under autograd: gradients through the split-fp16 gradient GEMM against the fp32 matrix-core GEMM path."""
+    from dagl_amd import train_ops as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 32, 48
+    res = {}
+    for fast in (True, False):
+        T.FAST_FC_BACKWARD = fast
+        try:
+            pmap = torch.zeros(B, H + 6, W + 6, 16)
+            pmap[:, 3:3 + H, 3:3 + W] = torch.randn(B, H, W, 16, generator=torch.Generator().manual_seed(1))
+            pm = pmap.to(dev).requires_grad_(True)
+            w = ((torch.rand(196, 784, generator=torch.Generator().manual_seed(2)) - 0.5) * 0.07).to(dev).requires_grad_(True)
+            b = torch.zeros(196, device=dev, requires_grad=True)
+            y = T.patch_linear(pm, w, b, 7, 1, 0, 0, H, W, relu=True)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev)).sum().backward()
+            res[fast] = (pm.grad.cpu(), w.grad.cpu(), b.grad.cpu())
+        finally:
+            T.FAST_FC_BACKWARD = True
+    for a, c in zip(res[True], res[False]):
+        assert normwise(a.numpy(), c.numpy()) <= 1e-5
