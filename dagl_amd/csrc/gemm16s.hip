@@ -16,7 +16,7 @@
 //       rows -> [896][n] straight from the zero-bordered map (an unfold that transposes: the [n,784] fp32 rows, 411 MB
 //               at this size, are never built for the weight gradient),
 //       W    -> [896][224] (K = outputs);
-//   * gemm16s_kernel: 128 x 128 x 32 tiles, 4 waves of 64 x 64, operands by LDS-DMA into a two-stage ring (64-byte rows, the
+//   * gemm16s_kernel: 128 x 128 x 32 (or 256 x 128 x 32) tiles, waves of 64 x 64, operands by LDS-DMA into a two-stage ring (64-byte rows, the
 //     four 16-byte slots of a row stored at slot ^ ((row >> 2) & 3): conflict-free ds_read_b128 of 32 consecutive rows, the
 //     projection's weight layout), v_mfma_f32_32x32x16_f16, the operands swapped so that a lane ends up with four
 //     consecutive columns of one output row (16-byte stores); split-K with a fixed-order reduce for the weight gradient.
@@ -27,9 +27,7 @@ namespace dagl {
 
 typedef _Float16 g16h8 __attribute__((ext_vector_type(8)));
 
-constexpr int G16_BM = 128, G16_BN = 128, G16_BK = 32;
-constexpr int G16_PART = G16_BM * G16_BK * 2;          // bytes of one operand part (hi or lo) per stage: 128 rows x 64 B = 8 KiB
-constexpr int G16_STAGE = 4 * G16_PART;                // A hi | A lo | B hi | B lo = 32 KiB
+constexpr int G16_BK = 32;                             // K step: rows of 64 bytes in the LDS
 constexpr int FCG_O = 196, FCG_OP = 224, FCG_OM = 256; // outputs, padded to the K step / to the M tile
 constexpr int FCG_P = 784, FCG_PP = 896;               // patch length, padded to the N tile (7 x 128)
 constexpr float FCG_XS = 16.0f, FCG_WS = 1024.0f;      // activation / weight pre-scaling (project16.hip)
@@ -44,7 +42,17 @@ __device__ __forceinline__ void g16_split(float a, unsigned short& hi, unsigned 
 // largest |x| of a tensor -> *word (bits of a non-negative float: integer max = float max, order-independent)
 __global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4* __restrict__ x, unsigned* __restrict__ word) {
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {                           // four loads in flight per thread
+        const float4 v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+        const float a = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+        const float b = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+        const float c = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w)));
+        const float d = fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)));
+        m = fmaxf(m, fmaxf(fmaxf(a, b), fmaxf(c, d)));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = x[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
@@ -161,32 +169,43 @@ struct Gemm16s {
     const unsigned* scale_word; float alpha0;   // alpha = alpha0 / fcg_scale_of(*scale_word)
 };
 
-// C[m][n] = sum_k A[m][k] B[n][k]; block = 128 x 128 outputs, grid.z = K slices
-__global__ __launch_bounds__(256, 2) void gemm16s_kernel(Gemm16s g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G16_STAGE];            // 64 KiB
+// C[m][n] = sum_k A[m][k] B[n][k]; block = (64 WM) x (64 WN) outputs by WM x WN waves of 64 x 64, grid.z = K slices.
+// The operand stream through LDS-DMA is what bounds this kernel (~23 GB/s per CU measured, hi + lo double the bytes of an
+// fp16 GEMM): 256 x 128 tiles fetch 3/4 of the bytes per product of 128 x 128 ones.
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_kernel(Gemm16s g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int PA = BM * 64, PB = BN * 64;                                     // bytes of one part (hi or lo) of an operand tile
+    constexpr int STAGE = 2 * PA + 2 * PB;
+    constexpr int PIECES = STAGE / 1024;
+    static_assert(PIECES % NW == 0, "pieces per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * G16_BM, n0 = blockIdx.x * G16_BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const long long k0 = (long long)blockIdx.z * g.K;
-    const int wm = wave >> 1, wn = wave & 1;                                      // 2 x 2 waves of 64 x 64
+    const int wm = wave / WN, wn = wave % WN;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
     // LDS-DMA: a piece = 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 holds logical slot (l & 3) ^ ((row >> 2) & 3)
     const int prow = lane >> 2, pslot = (lane & 3) ^ ((prow >> 2) & 3);
     auto stage = [&](int buf, long long k) {
-        const unsigned dst = lds0 + (unsigned)buf * G16_STAGE;
+        const unsigned dst = lds0 + (unsigned)buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = wave * 8 + j;                                           // 32 pieces: part (4) x 16-row group (8)
-            const int part = p >> 3, grp = p & 7;
-            const unsigned short* base = part == 0 ? g.a_hi : part == 1 ? g.a_lo : part == 2 ? g.b_hi : g.b_lo;
-            const long long ld = part < 2 ? g.lda : g.ldb;
-            int row = (part < 2 ? m0 : n0) + grp * 16 + prow;
-            const int lim = (part < 2 ? g.a_rows : g.b_rows) - 1;
+        for (int j = 0; j < PIECES / NW; ++j) {
+            const int p = wave * (PIECES / NW) + j;                               // A hi | A lo | B hi | B lo, 16-row groups
+            const bool is_a = p < 2 * (BM / 16);
+            const int q = is_a ? p : p - 2 * (BM / 16);
+            const int per = is_a ? BM / 16 : BN / 16;
+            const int part = q / per, grp = q - part * per;
+            const unsigned short* base = is_a ? (part ? g.a_lo : g.a_hi) : (part ? g.b_lo : g.b_hi);
+            const long long ld = is_a ? g.lda : g.ldb;
+            int row = (is_a ? m0 : n0) + grp * 16 + prow;
+            const int lim = (is_a ? g.a_rows : g.b_rows) - 1;
             if (row > lim) row = lim;
             glds16_asm(reinterpret_cast<const float*>(base + (long long)row * ld + k + 8 * pslot),
-                       __builtin_amdgcn_readfirstlane(dst + (unsigned)part * G16_PART + (unsigned)grp * 1024));
+                       __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
         }
     };
     f32x16 acc[2][2];
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm16s_kernel(Gemm16s g) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) stage(cur ^ 1, k0 + (long long)(t + 1) * G16_BK);
-        const unsigned char* sb = smem + cur * G16_STAGE;
+        const unsigned char* sb = smem + cur * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             g16h8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
@@ -214,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm16s_kernel(Gemm16s g) {
             for (int u = 0; u < 2; ++u) {
                 const int ra = (wm * 64 + u * 32 + i) * 64 + off, rb = (wn * 64 + u * 32 + i) * 64 + off;
                 a_hi[u] = *reinterpret_cast<const g16h8*>(sb + ra);
-                a_lo[u] = *reinterpret_cast<const g16h8*>(sb + G16_PART + ra);
-                b_hi[u] = *reinterpret_cast<const g16h8*>(sb + 2 * G16_PART + rb);
-                b_lo[u] = *reinterpret_cast<const g16h8*>(sb + 3 * G16_PART + rb);
+                a_lo[u] = *reinterpret_cast<const g16h8*>(sb + PA + ra);
+                b_hi[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + rb);
+                b_lo[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + PB + rb);
             }
             // D[row = n (first operand's row)][col = m]: a lane holds four consecutive n of one m per register quad
 #pragma unroll
@@ -270,8 +289,16 @@ __global__ void gemm16s_reduce_kernel(size_t n4, int slices, const float4* __res
 }
 
 static int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
-    dim3 grid((g.N + G16_BN - 1) / G16_BN, (g.M + G16_BM - 1) / G16_BM, g.slices);
-    hipLaunchKernelGGL(gemm16s_kernel, grid, dim3(256), 0, s, g);
+    // tile shape by measurement (tools/time_fc_grad.py, n = 131 072): the weight gradient (one 196-row M tile, long K) is
+    // faster on 256 x 128 tiles / 8 waves / one block per CU (0.55 against 0.59 ms with its producers), d rows (K = 224:
+    // seven steps per block) on 128 x 128 / 4 waves / two blocks per CU (0.42 against 0.49 ms)
+    if (g.M <= 256 && g.slices > 1) {
+        dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices);
+        hipLaunchKernelGGL((gemm16s_kernel<4, 2>), grid, dim3(512), 0, s, g);
+    } else {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.slices);
+        hipLaunchKernelGGL((gemm16s_kernel<2, 2>), grid, dim3(256), 0, s, g);
+    }
     DAGL_LAUNCH_CHECK("gemm16s_kernel");
     if (g.slices > 1) {
         const size_t n4 = (size_t)g.M * g.N / 4;
@@ -294,7 +321,8 @@ static size_t fcg_carve(size_t& off, size_t bytes) { const size_t o = off; off =
 static FcgPlan fcg_plan(size_t n) {
     FcgPlan p;
     p.n = n;
-    // d W has 2 x 7 output tiles: K slices fill the chip (~512 blocks), each a multiple of the 32-deep K step
+    // d W has 1 x 7 output tiles of 256 x 128: K slices fill the chip (one block per CU: 7 x 36 = 252 blocks), each a multiple
+    // of the 32-deep K step
     int slices = 36;
     size_t ks = (n + (size_t)slices - 1) / slices;
     ks = (ks + G16_BK - 1) / G16_BK * G16_BK;
@@ -342,7 +370,7 @@ int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int 
     DAGL_HIP_TRY(hipMemsetAsync(word, 0, 256, s));
     {
         const size_t n4 = n * FCG_O / 4;
-        hipLaunchKernelGGL(fcg_absmax_kernel, dim3(1024), dim3(256), 0, s, n4, reinterpret_cast<const float4*>(dz), word);
+        hipLaunchKernelGGL(fcg_absmax_kernel, dim3(2048), dim3(256), 0, s, n4, reinterpret_cast<const float4*>(dz), word);
         DAGL_LAUNCH_CHECK("fcg_absmax_kernel");
     }
     if (d_rows) {
