@@ -445,6 +445,7 @@ struct Gemm32 {
 int launch_gemm32(hipStream_t s, const Gemm32& g);
 int gemm32_auto_slices(int M, int N, int K);
 
+int launch_col_sum_final(hipStream_t s, int n_part, int cols, const double* part, float* out);   // out[c] = sum of part[p][c], fixed order
 int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, float* dagg);
 int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar);
 // dense neighbourhoods under autograd (dense_train.hip): the dense formulation chunked over queries

@@ -104,6 +104,12 @@ __global__ __launch_bounds__(256) void col_sum_final_kernel(int n_part, int cols
     if (lane == 0) out[c] = (float)a;
 }
 
+int launch_col_sum_final(hipStream_t s, int n_part, int cols, const double* part, float* out) {
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3((cols + 3) / 4), dim3(256), 0, s, n_part > 0 ? n_part : 1, cols, part, out);
+    DAGL_LAUNCH_CHECK("col_sum_final_kernel");
+    return DAGL_OK;
+}
+
 int launch_unfold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
                           const float* map, float* rows) {
     const size_t n = (size_t)oh * ow * k * k * (C / 4);

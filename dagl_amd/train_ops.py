@@ -124,30 +124,29 @@ def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b,
     n = B * oh * ow
     with torch.cuda.device(pmap.device):
         dz = d_y.contiguous().view(n, O).float()
-        if relu:
-            dzr = torch.empty_like(dz)
-            check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
-                  "dagl_relu_backward")
-            dz = dzr
         d_w = d_b = d_map = None
         if fast and (need_w or need_map):
+            # one call: ReLU backward, the split's scale and d bias in one pass over d y, then the two split-fp16 products
             need = lib.dagl_fc_grad16_scratch_bytes(B, oh, ow)
             scratch = torch.empty(need + 256, device=pmap.device, dtype=torch.uint8)
             base = (scratch.data_ptr() + 255) // 256 * 256
             d_w = torch.empty(O, K, device=pmap.device, dtype=torch.float32) if need_w else None
+            d_b = torch.empty(O, device=pmap.device, dtype=torch.float32) if need_b else None
             d_rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32) if need_map else None
             check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pmap.data_ptr(), weight.data_ptr(),
-                                     dz.data_ptr(), d_w.data_ptr() if need_w else None,
-                                     d_rows.data_ptr() if need_map else None, base, need), "dagl_fc_grad16")
-            if need_b:
-                d_b = torch.empty(O, device=pmap.device, dtype=torch.float32)
-                scr = torch.empty(lib.dagl_col_sum_scratch_bytes(n, O), device=pmap.device, dtype=torch.uint8)
-                check(lib.dagl_col_sum(ops._stream(), n, O, dz.data_ptr(), d_b.data_ptr(), scr.data_ptr()), "dagl_col_sum")
+                                     y.data_ptr() if relu else None, dz.data_ptr(), d_w.data_ptr() if need_w else None,
+                                     d_b.data_ptr() if need_b else None, d_rows.data_ptr() if need_map else None, base, need),
+                  "dagl_fc_grad16")
             if need_map:
                 d_map = torch.empty_like(pmap)
                 check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, d_rows.data_ptr(),
                                             d_map.data_ptr()), "dagl_fold_patches")
             return d_map, d_w, d_b
+        if relu:
+            dzr = torch.empty_like(dz)
+            check(lib.dagl_relu_backward(ops._stream(), n * O, y.data_ptr(), dz.data_ptr(), dzr.data_ptr()),
+                  "dagl_relu_backward")
+            dz = dzr
         rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32)          # recomputed, not kept
         check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, k, stride, oy, ox, oh, ow, pmap.data_ptr(),
                                       rows.data_ptr()), "dagl_unfold_patches")

@@ -306,12 +306,15 @@ int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* o
  *   d_w    [196,784]   = dz^T rows            (rows = the 7x7x16 patches of map_nhwc on the grid (stride, oy, ox, oh, ow),
  *                                              element order (kh,kw,c); they are never materialised in fp32)
  *   d_rows [B*oh*ow,784] = dz w_rows          (the caller folds them back: dagl_fold_patches)
- * dz [B*oh*ow,196] = the gradient behind the ReLU; w_rows [196,784] in (kh,kw,c) order; either output may be NULL.
+ *   d_b    [196]       = column sums of dz
+ * dz = dy (y > 0) when the layer's output y is given (ReLU backward, fused with the pass that takes dz's largest magnitude
+ * and its column sums), dz = dy when y is NULL; y, dy [B*oh*ow,196]; w_rows [196,784] in (kh,kw,c) order; any output may be NULL.
  * Holds for |16 map|, |1024 w| < 65504 (the forward projection's own range); dz is rescaled per call by a power of two taken
  * from its largest magnitude.  Fixed summation order (split-K slices added in slice order): bit-reproducible.             */
 size_t dagl_fc_grad16_scratch_bytes(int B, int oh, int ow);
 int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
-                   const float* w_rows, const float* dz, float* d_w, float* d_rows, void* scratch, size_t scratch_bytes);
+                   const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, void* scratch,
+                   size_t scratch_bytes);
 
 /* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
  * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).  `scratch` = 8*B*L floats of

@@ -104,17 +104,26 @@ def test_fc_grad16_matches_fp64(B, H, W, stride, scale):
     n = B * oh * ow
     w = (torch.rand(196, 784, generator=g) - 0.5) * 0.07
     dz = torch.randn(n, 196, generator=g) * scale * torch.rand(n, 1, generator=g) ** 4          # heavy-tailed magnitudes
-    pm, wd, dzd = pmap.to(dev), w.to(dev), dz.to(dev)
+    y = torch.randn(n, 196, generator=g)                                                        # the layer's output: ReLU mask
+    dy = dz
+    dz = dy * (y > 0)
+    pm, wd, dyd, yd = pmap.to(dev), w.to(dev), dy.to(dev), y.to(dev)
+    dzd = dz.to(dev)
     need = lib.dagl_fc_grad16_scratch_bytes(B, oh, ow)
     scratch = torch.empty(need + 256, device=dev, dtype=torch.uint8)
     base = (scratch.data_ptr() + 255) // 256 * 256
     outs = []
-    for _ in range(2):
-        d_w = torch.empty(196, 784, device=dev); d_rows = torch.empty(n, 784, device=dev)
-        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pm.data_ptr(), wd.data_ptr(), dzd.data_ptr(),
-                                      d_w.data_ptr(), d_rows.data_ptr(), base, need), "dagl_fc_grad16")
-        outs.append((d_w.cpu(), d_rows.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for rep in range(3):                      # 0, 1: ReLU backward fused (y given); 2: d z handed in directly -- all bit-identical
+        d_w = torch.empty(196, 784, device=dev); d_rows = torch.empty(n, 784, device=dev); d_b = torch.empty(196, device=dev)
+        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pm.data_ptr(), wd.data_ptr(),
+                                      yd.data_ptr() if rep < 2 else None, dyd.data_ptr() if rep < 2 else dzd.data_ptr(),
+                                      d_w.data_ptr(), d_b.data_ptr(), d_rows.data_ptr(), base, need), "dagl_fc_grad16")
+        outs.append((d_w.cpu(), d_rows.cpu(), d_b.cpu()))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    want_b = dz.double().sum(0)
+    e_b = float((outs[0][2].double() - want_b).abs().max() / dz.double().abs().sum(0).max())
+    assert e_b <= 1e-6, e_b
     # fp64 reference: rows by torch's unfold on the padded map (element order (kh,kw,c))
     rows = torch.empty(n, 784, dtype=torch.float64)
     x = pmap.double()

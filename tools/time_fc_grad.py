@@ -38,8 +38,8 @@ def main():
     d_w = torch.empty(196, 784, device=dev); d_rows = torch.empty(n, 784, device=dev)
 
     def fast(both=True, dw=True):
-        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, H + 6, W + 6, 1, 0, 0, H, W, pmap.data_ptr(), w.data_ptr(), dz.data_ptr(),
-                                      d_w.data_ptr() if (both or dw) else None, d_rows.data_ptr() if (both or not dw) else None,
+        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, H + 6, W + 6, 1, 0, 0, H, W, pmap.data_ptr(), w.data_ptr(), None, dz.data_ptr(),
+                                      d_w.data_ptr() if (both or dw) else None, None, d_rows.data_ptr() if (both or not dw) else None,
                                       base, need), "dagl_fc_grad16")
 
     rows = torch.empty(n, 784, device=dev)
