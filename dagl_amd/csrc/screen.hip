@@ -287,6 +287,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
     unsigned* const flags = reinterpret_cast<unsigned*>(smem + RING_NBUF * STEP_ELEMS);     // ready[0..4] at +0, done[0..4] at +32 bytes
 
     const int tid = threadIdx.x;
+    if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -313,9 +314,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         qvalid[w] = q < a.L;
         const int qc = qvalid[w] ? q : a.L - 1;
         const size_t qlin = (size_t)b * a.L + qc;
-        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
+        // (VAR & 256, ablation: fragments in a lane-linear layout -- 13 KiB per 32-query tile, [t][h][i][8] -- to price the gather below)
+        const unsigned short* qp = (VAR & 256) ? a.wqh + ((size_t)b * a.rows_qh + (size_t)(qc & ~31)) * DSH + lane * 8
+                                               : a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
 #pragma unroll
-        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + ((VAR & 256) ? 512 : 16) * t));
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
         const unsigned tb = __float_as_uint(thq[w]);
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         }
     dma_wait_all();
     __syncthreads();
+    if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 1);
 
     int pend_tile = -1;                              // tile this wave has requested and not yet published (wave-uniform)
     int buf = 0;                                     // it % RING_NBUF
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
     // 2 test + extraction, 3 wait for the tile's ready word, 4 publishing (vmcnt wait)
     unsigned long long ph[5] = {0, 0, 0, 0, 0};
     unsigned long long ph_t = (VAR & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk0 = (VAR & 128) ? __builtin_amdgcn_s_memtime() : 0ull;      // VAR & 128: shader clocks of the loop -> stamp 3
 #define RING_PH(k) do { if (VAR & 64) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); ph[k] += t1_ - ph_t; ph_t = t1_; } } while (0)
     for (int it = 0; it < n_it; ++it) {
         const int step = step0 + it * stride;
@@ -540,6 +545,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         RING_PH(2);
     }
 #undef RING_PH
+    const unsigned long long clk1 = (VAR & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 2);
     if ((VAR & 64) && a.times != nullptr && lane == 0) {
         unsigned long long* o = a.times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 5;
         for (int k = 0; k < 5; ++k) o[k] = ph[k];
@@ -571,7 +578,303 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
         }
     }
+    if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
+#ifdef DAGL_ABLATION
+    if ((VAR & 128) && a.times != nullptr && tid == 0) a.times[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = clk1 - clk0;
+#endif
 }
+
+#ifdef DAGL_ABLATION
+// ---- pipelined form of the ring kernel (ablation builds only, DAGL_SCREEN_RING=3; results identical, 2-7 us SLOWER: kept as the
+// record of that measurement, profiles/r03_ab_screen_pipe.log): a wave's threshold test runs under its OWN multiplies --------------
+// In screen_ring_kernel a wave alternates "26 multiplies" and "tail" (~130 vector instructions when the tile holds candidates,
+// which at 3 candidates per 32 x 32 tile is nearly always); the matrix pipe of a SIMD is busy only while at least one of its
+// four waves is in the first phase, and the waves' waits for tiles and slots line their phases up often enough to leave it
+// idle 40 % of the loop.  Here the step is cut into its two 32-key halves and software-pipelined inside the wave: while the 13
+// multiplies of one half run into one accumulator, the wave tests the OTHER accumulator (the previous half) -- mask of the
+// 16 scores above the threshold, tile maximum, first candidate -- in the issue slots between the multiplies (a 32x32x16 MFMA
+// occupies the pipe for 32 cycles and the issue port for 4: seven vector instructions fit behind each).  The half is ONE basic
+// block: the candidate store is predicated inside an asm statement (exec from a lane flag) instead of a branch; only a lane
+// with a second candidate in the same 16 scores sends the wave through the scalar loop afterwards.  Same ring, same counters,
+// same records in the same order as screen_ring_kernel.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store8_if(const void* p, i32x2 v, int ok) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_ne_u32_e32 0, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep)
+                 : "v"(ok), "v"(p), "v"(v)
+                 : "vcc");
+}
+
+// plain (not interleaved) test of one finished accumulator, for the last half of a block (32 keys x 32 queries; a lane holds 16
+// scores of one query).  PASS 0: group maxima.  PASS 1: the first candidate is stored here; returns the mask of the lane's
+// FURTHER candidates (score r at bit 15 - r).  screen_pipe_kernel's `half` spells the same test out in slices.
+template <int PASS>
+__device__ __forceinline__ unsigned screen_test(const f32x16& acc, float thq, float thlo, int kbase, int2* cseg, int& n_loc, int cap,
+                                                float (&gm)[16], float& sv_out) {
+    if constexpr (PASS == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = fmaxf(gm[r], acc[r]);
+        return 0u;
+    } else {
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(thlo - acc[r]), 31);
+        float m = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+        const float sv = (__popc(mask) == 1) ? m : -m;
+        const int has = mask != 0u ? 1 : 0;
+        const int r = __clz((int)mask) - 16;                       // first candidate (lowest r); 16 when there is none
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        i32x2 rec; rec[0] = key; rec[1] = __float_as_int(sv);
+        store8_if(cseg + n_loc, rec, (has && n_loc < cap) ? 1 : 0);
+        n_loc += has;
+        sv_out = sv;
+        return has ? (mask & ~(0x8000u >> r)) : 0u;
+    }
+}
+__device__ __forceinline__ void screen_rest(unsigned rest, float sv, int kbase, int2* cseg, int& n_loc, int cap) {
+    while (rest) {
+        const int bit = 31 - __clz((int)rest);
+        rest &= ~(1u << bit);
+        const int r = 15 - bit;
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (n_loc < cap) cseg[n_loc] = make_int2(key, __float_as_int(sv));
+        ++n_loc;
+    }
+}
+
+// QW = query tiles of 32 per wave.  2 (8 waves x 64 queries, two per SIMD, 256 registers): every key fragment read from the LDS
+// feeds two multiplies -- half the LDS reads (a co-bottleneck at QW = 1: 26 KiB per wave and step, the LDS pipe busy half the
+// time the matrix pipe is), ring words and tile requests per multiply; the wave hides its own tails, so two waves per SIMD
+// are enough to keep the pipe fed.
+template <int PASS, int WAVES, int VAR = 0, int QW = 1>
+__global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a, int n_qgroups) {
+    // ONE shared object (a second one makes hipcc drain vmcnt(0) in front of every ds_read of the loop)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[RING_NBUF * STEP_ELEMS + RING_FLAG_BYTES / 2];
+    unsigned* const flags = reinterpret_cast<unsigned*>(smem + RING_NBUF * STEP_ELEMS);     // ready[0..4] at +0, done[0..4] at +32 bytes
+
+    const int tid = threadIdx.x;
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 0);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+
+    const int logical = xcd_remap2(blockIdx.x, gridDim.x);
+    const int split = logical / n_qgroups;
+    const int qg = logical % n_qgroups;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.n_steps) step1 = a.n_steps;
+    const int stride = (PASS == 0) ? a.sample : 1;
+
+    // query fragments: QW x 13 x 8 bf16: Wq~[q][16t + 8h .. +7]
+    bf16x8 qf[QW][KB];
+    bool qvalid[QW];
+    float thq[QW], thlo[QW];          // thlo = predecessor of thq:  S~ >= thq  <=>  S~ > thlo  <=>  sign(thlo - S~) set
+    int n_loc[QW];
+    int2* cseg[QW];
+    size_t seg[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const int q = ((qg * WAVES + wave) * QW + w) * QT + i;
+        qvalid[w] = q < a.L;
+        const int qc = qvalid[w] ? q : a.L - 1;
+        const size_t qlin = (size_t)b * a.L + qc;
+        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
+#pragma unroll
+        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        thq[w] = 0.f;
+        if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
+        const unsigned tb = __float_as_uint(thq[w]);
+        thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
+        n_loc[w] = 0;
+        seg[w] = (qlin * a.splits + split) * 2 + h;
+        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
+    }
+    const int cap = a.capseg - 1;
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int t = 0; t < KB; ++t) asm volatile("" : "+v"(qf[w][t]));
+
+    float gm[QW][16];
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[w][r] = -1.0f;
+
+    const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&smem[0]));
+    const int n_it = (step1 > step0) ? (step1 - step0 + stride - 1) / stride : 0;
+
+    // prologue: the first RING_AHEAD tiles are requested by all waves together (one barrier, outside the loop)
+    const unsigned ready0 = lds0 + RING_NBUF * STEP_ELEMS * 2, done0 = ready0 + 32;        // LDS byte addresses of the flag words
+    if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)(tid + 1) : 0u; flags[8 + tid] = 0u; }
+#pragma unroll
+    for (int j = 0; j < RING_AHEAD; ++j)
+        if (j < n_it) {
+            const unsigned dst = lds0 + (unsigned)j * (STEP_ELEMS * 2);
+            const unsigned short* src = xb + (size_t)(step0 + j * stride) * STEP_ELEMS;
+            for (int p = wave; p < STEP_PIECES; p += WAVES)
+                glds16_asm(reinterpret_cast<const float*>(src + p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(dst + p * 1024));
+        }
+    dma_wait_all();
+    __syncthreads();
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 1);
+
+    int pend_tile = -1;                              // tile this wave has requested and not yet published (wave-uniform)
+    int buf = 0;                                     // it % RING_NBUF
+    f32x16 accA[QW], accB[QW];                       // keys 0..31 / 32..63 of a step
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[w][r] = 0.f; accB[w][r] = -__builtin_inff(); }     // (the first half tests an empty predecessor)
+    int kb_prev = 0;                                 // first key of the half whose accumulator awaits its test (+ 4h)
+
+    // one half: 13 (x QW) multiplies of 32 keys into `fresh`, the test of `old` in their shadow.  The interleave is spelled out:
+    // slice t = fragment t + 2 asked for, multiply t, five-odd instructions of the test per query tile, and a scheduling fence
+    // (hipcc's own order puts the test behind the last multiply).  The test starts at slice 2: `old` was completed by the
+    // multiply issued just before.
+    auto half = [&](const unsigned short* kp, f32x16 (&fresh)[QW], const f32x16 (&old)[QW], int kb_old) {
+        f32x16 c[QW];
+#pragma unroll
+        for (int w = 0; w < QW; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[w][r] = 0.f;
+        bf16x8 kf[KB];
+        kf[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp));
+        kf[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp + 16));
+        unsigned mask[QW], rest[QW];
+        float m[QW], sv[QW];
+        int has[QW], r1[QW], key[QW];
+#pragma unroll
+        for (int w = 0; w < QW; ++w) { mask[w] = 0u; rest[w] = 0u; m[w] = 0.f; sv[w] = 0.f; has[w] = 0; r1[w] = 0; key[w] = 0; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < KB; ++t) {
+            if (t + 2 < KB) kf[t + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(kp + 16 * (t + 2)));
+#pragma unroll
+            for (int w = 0; w < QW; ++w) c[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[w][t], c[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < QW; ++w) {
+                if (t >= 2 && t < 10) {
+                    const int r = 2 * (t - 2);
+                    if constexpr (PASS == 0) {
+                        gm[w][r] = fmaxf(gm[w][r], old[w][r]); gm[w][r + 1] = fmaxf(gm[w][r + 1], old[w][r + 1]);
+                    } else {
+                        mask[w] = __builtin_amdgcn_alignbit(mask[w], __float_as_uint(thlo[w] - old[w][r]), 31);
+                        mask[w] = __builtin_amdgcn_alignbit(mask[w], __float_as_uint(thlo[w] - old[w][r + 1]), 31);
+                        m[w] = (t == 2) ? fmaxf(old[w][0], old[w][1]) : fmaxf(fmaxf(m[w], old[w][r]), old[w][r + 1]);
+                    }
+                } else if (PASS == 1 && t == 10) {
+                    // the screened score travels with the key: exact when the lane has one candidate among these 16 (it is their
+                    // maximum), otherwise the maximum with the sign bit set = "upper bound only"
+                    sv[w] = (__popc(mask[w]) == 1) ? m[w] : -m[w];
+                    has[w] = mask[w] != 0u ? 1 : 0;
+                    r1[w] = __clz((int)mask[w]) - 16;                // first candidate (lowest r); 16 when there is none
+                    key[w] = kb_old + (r1[w] & 3) + 8 * (r1[w] >> 2);
+                } else if (PASS == 1 && t == 11) {
+                    i32x2 rec; rec[0] = key[w]; rec[1] = __float_as_int(sv[w]);
+                    store8_if(cseg[w] + n_loc[w], rec, (has[w] && n_loc[w] < cap) ? 1 : 0);
+                    n_loc[w] += has[w];
+                    rest[w] = has[w] ? (mask[w] & ~(0x8000u >> r1[w])) : 0u;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int w = 0; w < QW; ++w) fresh[w] = c[w];
+        if constexpr (PASS == 1) {
+            unsigned any_rest = rest[0];
+#pragma unroll
+            for (int w = 1; w < QW; ++w) any_rest |= rest[w];
+            if (__any(any_rest != 0u)) {
+#pragma unroll
+                for (int w = 0; w < QW; ++w) screen_rest(rest[w], sv[w], kb_old, cseg[w], n_loc[w], cap);
+            }
+        }
+    };
+
+    for (int it = 0; it < n_it; ++it) {
+        const int step = step0 + it * stride;
+        // --- requester duty: tile it + AHEAD belongs to wave (it + AHEAD) % WAVES ---------------------------------------
+        {
+            const int T = it + RING_AHEAD;
+            if (T < n_it && (T % WAVES) == wave && !(VAR & 1)) {
+                const int tb = T % RING_NBUF;
+                const unsigned need = (unsigned)(WAVES * (T / RING_NBUF));        // wave-steps that have used the slot before
+                if (need) {
+                    while (lds_flag_load(done0 + 4 * tb) < need) __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
+                const unsigned long long sa = (unsigned long long)(uintptr_t)(xb + (size_t)(step0 + T * stride) * STEP_ELEMS);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32));
+                glds_tile27_asm(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)lane * 16u,
+                                __builtin_amdgcn_readfirstlane(dst));
+                pend_tile = T;
+            }
+        }
+        // --- tile `it` must have been published -----------------------------------------------------------------------------
+        if (!(VAR & 1))
+            while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
+
+        const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
+        const int kb0 = step * SK + 4 * h;
+        half(kp0, accA, accB, kb_prev);                          // keys 0..31 of this step  | test of keys 32..63 of the previous one
+        half(kp0 + 32 * DSH, accB, accA, kb0);                   // keys 32..63              | test of keys 0..31
+        kb_prev = kb0 + 32;
+        // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
+        if (lane == 0) lds_flag_add(done0 + 4 * buf, 1u);
+        // --- publisher duty: the tile this wave requested a step ago has had ~1.7 steps to land ---------------------------
+        if (pend_tile >= 0 && it > pend_tile - RING_AHEAD) {
+            dma_wait_all();
+            if (lane == 0) lds_flag_store(ready0 + 4 * (pend_tile % RING_NBUF), (unsigned)(pend_tile + 1));
+            pend_tile = -1;
+        }
+        buf = (buf + 1 == RING_NBUF) ? 0 : buf + 1;
+    }
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 2);
+    if (n_it > 0) {                                              // the last half's accumulator
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+            float sv = 0.f;
+            const unsigned rest = screen_test<PASS>(accB[w], thq[w], thlo[w], kb_prev, cseg[w], n_loc[w], cap, gm[w], sv);
+            if (PASS == 1) screen_rest(rest, sv, kb_prev, cseg[w], n_loc[w], cap);
+        }
+    }
+
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        if (PASS == 0) {
+            // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
+            // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
+            float top[GKEEP];
+#pragma unroll
+            for (int u = 0; u < GKEEP; ++u) {
+                float mx = gm[w][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, gm[w][r]);
+                top[u] = mx;
+                bool taken = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool hit = !taken && (gm[w][r] == mx);
+                    gm[w][r] = hit ? -1.0f : gm[w][r];
+                    taken = taken || hit;
+                }
+            }
+            if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
+        } else {
+            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
+        }
+    }
+    dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
+}
+#endif  // DAGL_ABLATION
 
 // theta of the adaptive modes: S~ >= theta  <=  (S~ (1+DELTA) - mean*thr) + bias > 0, with slack for the fp32
 // rounding of either side (dagl.py:256 evaluates (S - mean*thr) + bias in fp32).
@@ -629,12 +932,23 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     ScreenArgs at = a; at.times = (getenv("DAGL_TIMES_FILE") && pass == 1) ? dbg_times_buffer(ring_phases ? n_blk * 20 : n_blk) : nullptr;
 #define a at
     static const int ring_env = [] { const char* e = getenv("DAGL_SCREEN_RING"); return e ? atoi(e) : 1; }();
+    static const int pipe_qw = [] { const char* e = getenv("DAGL_PIPE_QW"); return e ? atoi(e) : 2; }();
+    if (qblock == 512 && ring_env == 3) {
+        if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else if (a.variant == 2) hipLaunchKernelGGL((screen_pipe_kernel<1, 8, 2, 2>), grid, dim3(512), 0, s, a, n_qgroups);
+        else if (pipe_qw == 1) hipLaunchKernelGGL((screen_pipe_kernel<1, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_pipe_kernel<1, 8, 0, 2>), grid, dim3(512), 0, s, a, n_qgroups);
+    } else
     if (qblock == 512 && ring_env) {
 #define SCR_R5(P_, V_) do { if (ring_env == 2) hipLaunchKernelGGL((screen_ring_kernel<P_, 8, V_, 2>), grid, dim3(512), 0, s, a, n_qgroups); \
                             else hipLaunchKernelGGL((screen_ring_kernel<P_, 16, V_>), grid, dim3(1024), 0, s, a, n_qgroups); } while (0)
 #define SCR_RV(P_) switch (a.variant) { case 0: SCR_R5(P_, 0); break; case 1: SCR_R5(P_, 1); break; case 2: SCR_R5(P_, 2); break; case 3: SCR_R5(P_, 3); break; \
                                          case 7: SCR_R5(P_, 7); break; case 15: SCR_R5(P_, 15); break; case 31: SCR_R5(P_, 31); break; case 6: SCR_R5(P_, 6); break; \
-                                         case 18: SCR_R5(P_, 18); break; case 8: SCR_R5(P_, 8); break; case 64: SCR_R5(P_, 64); break; default: SCR_R5(P_, 0); break; }
+                                         case 18: SCR_R5(P_, 18); break; case 8: SCR_R5(P_, 8); break; case 64: SCR_R5(P_, 64); break; \
+                                         case 4: SCR_R5(P_, 4); break; case 16: SCR_R5(P_, 16); break; case 5: SCR_R5(P_, 5); break; case 20: SCR_R5(P_, 20); break; \
+                                         case 17: SCR_R5(P_, 17); break; case 21: SCR_R5(P_, 21); break; \
+                                         case 128: SCR_R5(P_, 128); break; case 159: SCR_R5(P_, 159); break; case 144: SCR_R5(P_, 144); break; case 130: SCR_R5(P_, 130); break; \
+                                         case 145: SCR_R5(P_, 145); break; case 149: SCR_R5(P_, 149); break; case 256: SCR_R5(P_, 256); break; default: SCR_R5(P_, 0); break; }
         if (pass == 0) { SCR_R5(0, 0); } else { SCR_RV(1) }
     } else
     if (qblock == 512) {                                                  // 512-query blocks: a few variants only
@@ -649,7 +963,7 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
     if (qw == 2) { if (pass == 0) { SCR_VARIANTS(0, 2) } else { SCR_VARIANTS(1, 2) } }
     else { if (pass == 0) { SCR_VARIANTS(0, 1) } else { SCR_VARIANTS(1, 1) } }
 #undef a
-    if (at.times) dbg_times_dump(s, ring_phases ? "screen_ring_kernel<1>_phases" : "screen_kernel<1>", at.times, ring_phases ? n_blk * 20 : n_blk);
+    if (at.times) dbg_times_dump(s, ring_phases ? "screen_ring_kernel<1>_phases" : (qblock == 512 && ring_env ? (ring_env == 3 ? "screen_pipe_kernel<1>" : "screen_ring_kernel<1>") : "screen_kernel<1>"), at.times, ring_phases ? n_blk * 20 : n_blk);
 #else
     // blocks that are alone on their CU (512 / 384 queries): the ring form; 256-query blocks (two per CU, small images) keep
     // the barrier form -- two five-deep rings do not fit one CU's LDS
