@@ -279,6 +279,38 @@ def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
             "roofline": gemm_roofline(dev, B * crop * crop)}
 
 
+def mfma_sustained(dev, nominal_tflops):
+    """What the matrix pipes hold on THIS box under the screen's multiply stream alone (dagl_probe_mfma_bf16: 16 waves per CU, 26
+    v_mfma_f32_32x32x16_bf16 per step, operands in registers): TFLOP/s of a launch about as long as the screen kernel, timed with
+    events, and the shader clock of its loop (s_memtime against the 100 MHz counter).  The nominal peak assumes 2.4 GHz."""
+    import ctypes
+    from dagl_amd import _lib, ops
+    lib = _lib.load()
+    blocks, steps = 256, 40                       # 256 x 16 waves x 40 x 26 multiplies ~ the screen's 3.4 M
+    clocks = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        def run():
+            _lib.check(lib.dagl_probe_mfma_bf16(ops._stream(), blocks, steps, clocks.data_ptr(), sink.data_ptr()), "dagl_probe_mfma_bf16")
+        for _ in range(20):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    c = clocks.cpu().numpy().reshape(blocks, 2).astype("float64")
+    ghz = float((c[:, 0] / (c[:, 1] * 10.0)).mean())
+    flop = blocks * 16 * steps * 26 * 32768.0
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"mfma_only_tflops": tf, "frac_of_nominal": tf / nominal_tflops, "shader_clock_ghz": ghz, "ms_per_launch": ms,
+            "what": "dagl_probe_mfma_bf16: the screen's multiply stream alone (256 blocks x 16 waves x 40 steps x 26 v_mfma_f32_32x32x16_bf16, "
+                    "register operands), back-to-back launches timed with events; clock = s_memtime / s_memrealtime over wave 0's loop"}
+
+
 def gemm_roofline(dev, n):
     """The training step's dominant matrix product on its own, hipEvent-bracketed on the launch stream: the fc2 weight gradient
     dW = dZ^T rows, [196 x n] x [n x 784] (n = key patches of the batch) on the fp32 matrix cores."""
@@ -595,6 +627,10 @@ def main():
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": (committed_traffic("screen_ring_kernel<1>") or committed_traffic("screen_kernel<1>")) if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
+        if screened:
+            roofline["sustained"] = mfma_sustained(dev, peak)
+            if roofline["sustained"]:
+                roofline["frac_of_sustained"] = ach / roofline["sustained"]["mfma_only_tflops"]
         if gather is not None and mean_ms[6] > 0:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
             fb = B * L * ((kk + 1) * 4 * P_ROW + 8 * kk)

@@ -42,4 +42,54 @@ void dbg_times_dump(hipStream_t s, const char* kernel, const unsigned long long*
 }
 #endif
 
+// ---- what the matrix pipes sustain: the screen's multiply loop and nothing else ------------------------------------------------
+// The nominal bf16 peak (2.5 PFLOP/s) is 1024 SIMDs x one v_mfma_f32_32x32x16_bf16 per 32 cycles x 2.4 GHz.  Under exactly this
+// instruction stream the part does not hold 2.4 GHz (profiles/r03_screen_ring_clock_and_factors.log: 1.85-1.9 GHz in
+// screen_ring_kernel's loop), so bench.py prices the screen against BOTH: the nominal peak, and the rate this probe reaches on the
+// same box -- one block per CU, 16 waves, two accumulator chains per wave, 26 multiplies per step like the screen, operands in
+// registers, no LDS, no memory.  Per block: shader clocks (s_memtime) and 100 MHz ticks (s_memrealtime) of wave 0's loop.
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short probe_s16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(1024, 1) void mfma_probe_kernel(int steps, unsigned long long* __restrict__ clocks, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    probe_bf16x8 q[13], k0, k1;
+    {
+        probe_s16x8 v;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)(0x3C00 + ((lane * 37 + t * 11 + e * 5) & 0x1FF));       // bf16 in [2^-7, 2^-5)
+            q[t] = __builtin_bit_cast(probe_bf16x8, v);
+        }
+        k0 = q[3]; k1 = q[7];
+    }
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < steps; ++it) {
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q[t], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q[t], a1, 0, 0, 0);
+        }
+        // keep the sums bounded (and the loop from being folded): two instructions per 26 multiplies
+        a0[0] *= 0.5f; a1[0] *= 0.5f;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += a0[r] + a1[r];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (t == 12345.678f) sink[0] = t;                        // (never true in practice; keeps the accumulators alive)
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 }  // namespace dagl
+
+extern "C" int dagl_probe_mfma_bf16(void* stream, int blocks, int steps, unsigned long long* clocks, float* sink) {
+    using namespace dagl;
+    if (blocks < 1 || steps < 1 || !clocks || !sink) { set_error("dagl_probe_mfma_bf16: bad argument"); return DAGL_ERR_INVALID; }
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, steps, clocks, sink);
+    DAGL_LAUNCH_CHECK("mfma_probe_kernel");
+    return DAGL_OK;
+}

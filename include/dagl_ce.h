@@ -127,6 +127,13 @@ int         dagl_version(void);                 /* DAGL_ABI_VERSION of the libra
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
 
+/* Measurement aid (bench.py's roofline line; replaces nothing in the reference): what the matrix pipes SUSTAIN on this device
+ * under the screen's multiply stream alone -- `blocks` blocks of 16 waves, `steps` x 26 v_mfma_f32_32x32x16_bf16 per wave,
+ * operands in registers.  clocks[2*b] = shader clocks, clocks[2*b+1] = 100 MHz ticks of block b's loop (device memory,
+ * 2*blocks uint64); sink = one float of device memory.  FLOP of a launch = blocks * 16 * steps * 26 * 32768; time it with
+ * events on `stream`.                                                                                                      */
+int dagl_probe_mfma_bf16(void* stream, int blocks, int steps, unsigned long long* clocks, float* sink);
+
 /* ---- whole block: replaces dagl.py:216-274 (CE.forward after its prologue convs) -------------- */
 
 /* Bytes of workspace dagl_ce_forward needs for the single-pass / top-k paths (a two-pass CSR
