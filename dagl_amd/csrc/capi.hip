@@ -434,6 +434,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_pack_fc_weight(s, fc2_w, wp2))) return rc;
         }
     }
+    const int q_tiled = (p.screen && p.split16 && !core) ? 1 : 0;   // the projection writes the bf16 queries in the screen's fragment order
     ZeroList zl;
     if (!prepared) {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
@@ -442,7 +443,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         zl.add(Wq + (size_t)g.L * DS, (size_t)(rq - g.L) * DS * sizeof(float), B, (size_t)rq * DS * sizeof(float));
         if (p.screen) {
             zl.add(Xh + (size_t)g.N * DSH, (size_t)(hx - g.N) * DSH * sizeof(uint16_t), B, (size_t)hx * DSH * sizeof(uint16_t));
-            zl.add(Wqh + (size_t)g.L * DSH, (size_t)(hq - g.L) * DSH * sizeof(uint16_t), B, (size_t)hq * DSH * sizeof(uint16_t));
+            // (from the last PARTIAL 32-query tile on: in the fragment order its unused rows sit between the used ones)
+            const int lq = g.L & ~31;
+            zl.add(Wqh + (size_t)lq * DSH, (size_t)(hq - lq) * DSH * sizeof(uint16_t), B, (size_t)hq * DSH * sizeof(uint16_t));
         }
         zl.add(colsum, align_up((size_t)B * DS * sizeof(double), 16));
         zl.add(stats, 4 * sizeof(int64_t));
@@ -465,7 +468,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
                                    at<float>(ws, p.o_colpart), wp1h, b1s,
-                                   Wq, Xh, Wqh, heads, rt))) return rc;
+                                   Wq, Xh, Wqh, heads, rt, q_tiled))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }
@@ -565,7 +568,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     if (p.screen) {
         ScreenArgs sc;
         memset(&sc, 0, sizeof(sc));
-        sc.B = B; sc.L = g.L; sc.N = g.N; sc.mode = mode; sc.wqh = Wqh; sc.xh = Xh;
+        sc.B = B; sc.L = g.L; sc.N = g.N; sc.mode = mode; sc.wqh = Wqh; sc.xh = Xh; sc.q_tiled = q_tiled;
         sc.rows_qh = feat_rows_h(g.L); sc.rows_xh = feat_rows_h(g.N);
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample; sc.qblock = p.s_qblock;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;

@@ -208,7 +208,8 @@ int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool ro
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
-                     uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag());
+                     uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag(),
+                     int q_tiled = 0 /* bf16 query copy in the screen's fragment order (ScreenArgs::q_tiled) */);
 int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat /* [B, feat_rows(n), DS] */, float* rows_out /* [B, n, 196] */,
                          RangeTag range);            // dense copy of the feature rows; NaN when the call left the fp16 range
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
@@ -309,6 +310,10 @@ int launch_row_stats(hipStream_t s, size_t n_rows, const float* nb_wgt, const in
 struct ScreenArgs {
     int B, L, N, mode;
     const uint16_t* wqh; const uint16_t* xh;        // bf16 features [B, rows_*h, DSH]
+    int q_tiled;                                    // wqh in fragment order: per 32 queries [queries 0..15 | 16..31][t 0..12][half][query]
+                                                    // [8 columns] (2 x 6.5 KiB at the tile's row-major place): a wave's 13 fragment
+                                                    // loads are two runs of 512 B each instead of 32 rows x 32 B (1.6 us of the
+                                                    // screen kernels' 4.6 us prologue)
     int rows_qh, rows_xh;
     int splits, steps_per_split, n_steps, sample;
     int qblock;                     // queries per block: 256 (8 waves, two blocks per CU) or 512 (16 waves, one block per CU)

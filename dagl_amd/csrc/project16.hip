@@ -127,6 +127,10 @@ struct Proj16Args {
     int imgs_per_head;                                              // batch index = head * imgs_per_head + image
     float* feat[2];                                                 // [B, rows_alloc, DS]
     uint16_t* feat_h[2];                                            // optional bf16 copies [B, rows_alloc_h, DSH]
+    int tiled_h[2];                                                 // bf16 copy in the screen's FRAGMENT order instead of row-major (queries):
+                                                                    // per 32 rows [rows 0..15 | 16..31][t 0..12][half 0..1][row][8 columns
+                                                                    // 16t + 8half ..], 2 x 6.5 KiB at the tile's row-major place
+                                                                    // (ScreenArgs::q_tiled); an epilogue pass = one contiguous half
     int rows_alloc[2], rows_alloc_h[2];
     int n_items[2], segs[2];                                        // 32-patch work items per image / per grid row
     int lin[2];                                                     // items = 32 consecutive patches in ROW-MAJOR order (across row ends)
@@ -411,13 +415,15 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             }
             if (hb != nullptr) {
                 // bf16 copy: rows of 216 halfs = 27 chunks of 8 columns; columns 196.. are zero
-                const int n8 = rows_here * (DSH / 8);
-                uint4* dh = reinterpret_cast<uint4*>(hb + (size_t)(grid_row_base + 16 * pass) * DSH);
+                const bool tiled = pa.tiled_h[which] != 0;                       // 26 x (16 rows x 16 B) per pass instead of 16 rows x 27
+                const int n8 = tiled ? 26 * 16 : rows_here * (DSH / 8);
+                uint4* dh = reinterpret_cast<uint4*>(hb + (size_t)(grid_row_base + (tiled ? 0 : 16 * pass)) * DSH);
 #pragma unroll
                 for (int j = 0; j < (16 * (DSH / 8) + 63) / 64; ++j) {            // 7
                     const int e = lane + 64 * j;
-                    if (e < n8) {
-                        const int row = e / (DSH / 8), c8 = e - row * (DSH / 8);
+                    const int row = tiled ? (e & 15) : e / (DSH / 8);
+                    const int c8 = tiled ? (e >> 4) : e - row * (DSH / 8);
+                    if (e < n8 && row < rows_here) {
                         // columns 8 c8 .. + 7 of the staged row: two 16-byte reads (row stride 816 B = 51 x 16); past column 203: zeros
                         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                         const float4 lo4 = (8 * c8 < DS) ? *reinterpret_cast<const float4*>(stg + row * DS + 8 * c8) : z4;
@@ -430,8 +436,8 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
                             bits = (bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16;   // fp32 -> bf16, round to nearest even
                             q[u] = (unsigned short)bits;
                         }
-                        dh[e] = make_uint4(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16),
-                                           q[4] | ((unsigned)q[5] << 16), q[6] | ((unsigned)q[7] << 16));
+                        dh[tiled ? 416 * pass + e : e] = make_uint4(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16),
+                                                                               q[4] | ((unsigned)q[5] << 16), q[6] | ((unsigned)q[7] << 16));
                     }
                 }
             }
@@ -454,7 +460,8 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             if (VAR != 3 && ok && hb != nullptr && col < DPAD) {
                 unsigned u = __float_as_uint(v);
                 u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;            // fp32 -> bf16, round to nearest even
-                hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
+                if (pa.tiled_h[which]) hb[(size_t)grid_row_base * DSH + (rr >> 4) * 3328 + ((col >> 3) * 16 + (rr & 15)) * 8 + (col & 7)] = (uint16_t)u;
+                else hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
             }
             s += ok ? v : 0.f;
         }
@@ -532,8 +539,9 @@ int project16_key_blocks(const Grid& g) { return (p16_key_items(g) + P16_BW - 1)
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16, int heads, RangeTag range) {
+                     uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled) {
     Proj16Args pa;
+    pa.tiled_h[0] = 0; pa.tiled_h[1] = q_tiled;
     pa.range = range; pa.heads = heads; pa.times = nullptr;
     pa.imgs_per_head = B / heads;
     for (int h = 0; h < 4; ++h) {

@@ -38,6 +38,20 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     return base + slot;
 }
 
+// A query's 13 fragments of 8 bf16: row-major copy (features 16t + 8h .. of its row: 32 rows x 32 B per wave load) or the fragment
+// order project16 writes (ScreenArgs::q_tiled: [queries 0..15 | 16..31][t][h][query][8] per 32 queries, two runs of 512 B per
+// wave load).  q0 = the wave tile's first query; tiles past L read the last valid one (their thresholds are +inf).
+__device__ __forceinline__ void load_query_fragments(const ScreenArgs& a, int b, int q0, int qc, int lane, bf16x8 (&qf)[KB]) {
+    const int h = lane >> 5;
+    int t0 = q0; if (t0 > ((a.L - 1) & ~31)) t0 = (a.L - 1) & ~31;
+    const int i = lane & 31;
+    const unsigned short* qp = a.q_tiled ? a.wqh + ((size_t)b * a.rows_qh + t0) * DSH + (i >> 4) * 3328 + h * 128 + (i & 15) * 8
+                                         : a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
+    const int qs = a.q_tiled ? 256 : 16;
+#pragma unroll
+    for (int t = 0; t < KB; ++t) qf[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + qs * t));
+}
+
 // PASS 0: group maxima over every `sample`-th step (top-k threshold estimation)
 // PASS 1: candidate filter over every step: key is a candidate of query q iff S~ >= theta[q]
 //         (theta carries the whole conservative test of either mode; +inf for padding queries).
@@ -89,10 +103,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         qvalid[w] = q < a.L;
         const int qc = qvalid[w] ? q : a.L - 1;
         qlin[w] = (size_t)b * a.L + qc;
-        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
-#pragma unroll
-        for (int t = 0; t < KB; ++t)
-            qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        load_query_fragments(a, b, q - i, qc, lane, qf[w]);
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 8)) ? a.theta[qlin[w]] : __builtin_inff();
         {
@@ -314,11 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         qvalid[w] = q < a.L;
         const int qc = qvalid[w] ? q : a.L - 1;
         const size_t qlin = (size_t)b * a.L + qc;
-        // (VAR & 256, ablation: fragments in a lane-linear layout -- 13 KiB per 32-query tile, [t][h][i][8] -- to price the gather below)
-        const unsigned short* qp = (VAR & 256) ? a.wqh + ((size_t)b * a.rows_qh + (size_t)(qc & ~31)) * DSH + lane * 8
-                                               : a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
-#pragma unroll
-        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + ((VAR & 256) ? 512 : 16) * t));
+        load_query_fragments(a, b, q - i, qc, lane, qf[w]);
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
         const unsigned tb = __float_as_uint(thq[w]);
@@ -683,9 +690,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
         qvalid[w] = q < a.L;
         const int qc = qvalid[w] ? q : a.L - 1;
         const size_t qlin = (size_t)b * a.L + qc;
-        const unsigned short* qp = a.wqh + ((size_t)b * a.rows_qh + qc) * DSH + 8 * h;
-#pragma unroll
-        for (int t = 0; t < KB; ++t) qf[w][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s16x8*>(qp + 16 * t));
+        load_query_fragments(a, b, q - i, qc, lane, qf[w]);
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
         const unsigned tb = __float_as_uint(thq[w]);
@@ -948,7 +953,7 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
                                          case 4: SCR_R5(P_, 4); break; case 16: SCR_R5(P_, 16); break; case 5: SCR_R5(P_, 5); break; case 20: SCR_R5(P_, 20); break; \
                                          case 17: SCR_R5(P_, 17); break; case 21: SCR_R5(P_, 21); break; \
                                          case 128: SCR_R5(P_, 128); break; case 159: SCR_R5(P_, 159); break; case 144: SCR_R5(P_, 144); break; case 130: SCR_R5(P_, 130); break; \
-                                         case 145: SCR_R5(P_, 145); break; case 149: SCR_R5(P_, 149); break; case 256: SCR_R5(P_, 256); break; default: SCR_R5(P_, 0); break; }
+                                         case 145: SCR_R5(P_, 145); break; case 149: SCR_R5(P_, 149); break; default: SCR_R5(P_, 0); break; }
         if (pass == 0) { SCR_R5(0, 0); } else { SCR_RV(1) }
     } else
     if (qblock == 512) {                                                  // 512-query blocks: a few variants only
