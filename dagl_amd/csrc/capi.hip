@@ -754,10 +754,16 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             }
         } else {
             sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
-            if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
-            if (!p.screen) prof_mark(prof, s, 5);
             ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
-            if ((rc = launch_edge_softmax(s, ea))) return rc;
+            if (p.screen) {
+                // redo pass behind the screen: scan + merge of the flagged groups in one launch (exits after one load when nothing
+                // is flagged); its grid barrier counts in stats[3] (cleared with the call's counters, unused by the top-k modes)
+                if ((rc = launch_topk_redo(s, sa, ea, mode == DAGL_MODE_TOPK ? 2 : 3, reinterpret_cast<unsigned*>(stats + 3)))) return rc;
+            } else {
+                if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
+                prof_mark(prof, s, 5);
+                if ((rc = launch_edge_softmax(s, ea))) return rc;
+            }
             if (info && !p.screen) { info->path = 2; info->max_degree = k; }
         }
     }

@@ -292,6 +292,8 @@ struct EdgeArgs {
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
 };
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
+// top-k modes behind the screen: exact scan + merge of the FLAGGED query groups in one launch (select.hip); barrier = a zeroed word
+int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass /*2 topk, 3 adaptive-topk*/, unsigned* barrier);
 
 struct AggArgs {
     int B; Grid g;

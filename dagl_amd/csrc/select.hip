@@ -20,6 +20,7 @@
 //   2  top-k: per-lane sorted k-best lists (GReccR2b_3mh_1-checkpoint.py:242-246 semantics)
 //   3  adaptive AND top-k
 #include "dagl_common.h"
+#include "topk_merge.h"
 
 namespace dagl {
 
@@ -275,6 +276,86 @@ int launch_score_select(hipStream_t s, const SelectArgs& a, int pass) {
     set_error("launch_score_select: bad pass %d", pass);
     return DAGL_ERR_INVALID;
 }
+
+// REDO pass of the top-k modes behind the screen, both halves in ONE launch: the exact scan of the flagged query groups
+// (score_select_kernel's redo form: per-(chunk, half) k-best lists) and, behind a grid barrier, the merge of those lists into
+// the neighbour lists (edge_softmax_topk_kernel's redo form).  Almost always nothing is flagged and the launch exits after one
+// load -- as two launches that cost two launch + load latencies (~3 us each) on every forward.  The barrier: at most 256 blocks of
+// 256 threads, two per CU: all resident (blocks of other streams' kernels only delay them); the word is zeroed per call.
+template <int PASS, int K>
+__global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(SelectArgs a, EdgeArgs e, int kslots, int n_qgroups, int n_tiles,
+                                                                         int rows_q, int rows_x, int n_units, unsigned n_merge_blocks,
+                                                                         unsigned* barrier) {
+    __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB; the merge's candidate arrays (32 KiB) reuse it
+    static_assert(sizeof(float) * 2 * TILE_LDS >= (sizeof(float) + sizeof(int)) * 4 * TOPK_MAX_CAND, "merge arrays fit the scan's tiles");
+    if (*a.run_count == 0) return;                                       // nothing flagged anywhere (the usual case)
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform
+        score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, unit);
+        __syncthreads();
+    }
+    // every block's lists are in memory before any block merges
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        atomicAdd(barrier, 1u);
+        unsigned spins = 0;
+        while (atomicAdd(barrier, 0u) < total) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 23)) __builtin_trap();                 // (seconds: a block that never became resident -- fail loudly, do not hang)
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    float (*cv)[TOPK_MAX_CAND] = reinterpret_cast<float (*)[TOPK_MAX_CAND]>(&sK[0][0]);
+    int (*ci)[TOPK_MAX_CAND] = reinterpret_cast<int (*)[TOPK_MAX_CAND]>(&sK[0][0] + 4 * TOPK_MAX_CAND);
+    const int nqg = (e.L + 127) / 128;
+    for (size_t blk = blockIdx.y * gridDim.x + blockIdx.x; blk < n_merge_blocks; blk += (size_t)gridDim.x * gridDim.y) {
+        // block-uniform skip: none of the block's 4 queries sits in a flagged group
+        const size_t q0 = blk * 4, q1 = (q0 + 3 < (size_t)e.B * e.L - 1) ? q0 + 3 : (size_t)e.B * e.L - 1;
+        const size_t b0 = q0 / e.L, b1 = q1 / e.L;
+        if (e.run_flags[b0 * nqg + (q0 - b0 * e.L) / 128] == 0 && e.run_flags[b1 * nqg + (q1 - b1 * e.L) / 128] == 0) continue;
+        edge_softmax_topk_unit(e, kslots, cv, ci, blk);
+        __syncthreads();
+    }
+}
+
+int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass, unsigned* barrier) {
+    if (a.run_flags == nullptr || a.run_count == nullptr || e.run_flags != a.run_flags || barrier == nullptr || (pass != 2 && pass != 3)) {
+        set_error("launch_topk_redo: redo arguments missing");
+        return DAGL_ERR_INVALID;
+    }
+    const int n_qgroups = (a.L + SEL_WAVES * QT - 1) / (SEL_WAVES * QT);
+    const int n_tiles = (a.N + KT - 1) / KT;
+    const int n_units = n_qgroups * a.splits;
+    const int rows_q = feat_rows(a.L), rows_x = feat_rows(a.N);
+    const int ks = topk_slots(a.k);
+    if (e.splits * 2 * ks > TOPK_MAX_CAND) {
+        set_error("edge softmax: %d candidates per query exceed %d", e.splits * 2 * ks, TOPK_MAX_CAND);
+        return DAGL_ERR_INVALID;
+    }
+    const unsigned n_merge = (unsigned)(((size_t)e.B * e.L + 3) / 4);
+    // all blocks resident: 256 at most (K = 64: one block per CU), the batch in grid.y
+    int gx = 256 / (a.B > 0 ? a.B : 1);
+    if (gx > 128) gx = 128;
+    if (gx > n_units) gx = n_units;
+    if (gx < 1 || a.B > 256) {                                            // (a batch this large: the two-launch form)
+        int rc = launch_score_select(s, a, pass);
+        return rc ? rc : launch_edge_softmax(s, e);
+    }
+    const dim3 grid(gx, a.B), block(256);
+#define DAGL_REDO(P_, K_) hipLaunchKernelGGL((topk_redo_kernel<P_, K_>), grid, block, 0, s, a, e, ks, n_qgroups, n_tiles, rows_q, rows_x, \
+                                              n_units, n_merge, barrier)
+#define DAGL_REDO_K(P_) switch (ks) { case 4: DAGL_REDO(P_, 4); break; case 8: DAGL_REDO(P_, 8); break; case 16: DAGL_REDO(P_, 16); break; \
+                                      case 32: DAGL_REDO(P_, 32); break; default: DAGL_REDO(P_, 64); break; }
+    if (pass == 2) { DAGL_REDO_K(2) } else { DAGL_REDO_K(3) }
+#undef DAGL_REDO_K
+#undef DAGL_REDO
+    DAGL_LAUNCH_CHECK("topk_redo_kernel");
+    return DAGL_OK;
+}
+
 
 // ---- dense scores (tests only): S[b,l,n] = Wq[l,:] . X[n,:] -------------------------------------------
 __global__ void scores_dense_kernel(int L, int N, int rows_q, int rows_x, const float* __restrict__ wq,

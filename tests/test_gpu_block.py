@@ -130,6 +130,27 @@ def test_screen_overflow_is_redone_by_the_fp32_scan():
     assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
 
 
+@pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive_topk", 12)])
+def test_redo_of_one_image_of_a_batch(mode, k):
+    """Batch of three where only the middle image is the near-constant map: its query groups are flagged and redone (scan + merge
+    in one launch behind a grid barrier, select.hip topk_redo_kernel), its neighbours' groups are skipped -- same result as the
+    fp32 scan of everything."""
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
+    x = torch.from_numpy(make_features(53, 3, 64, 64, 64))
+    g = torch.Generator().manual_seed(3)
+    x[1] = 0.25 + 1e-2 * torch.randn(64, 64, 64, generator=g)
+    x = x.to(_dev())
+    res = {}
+    for scan in ("screened", "exact"):
+        ce = _module(params, mode, k, scan)
+        res[scan] = _run_debug(ce, x)
+    L = 16 * 16
+    assert res["screened"][1]["path"] == 3 and 0 < res["screened"][1]["redone_queries"] < 3 * L
+    assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
+    assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 128, 128), (2, 72, 90)])
 def test_dense_formulation_equals_csr_lists(B, H, W):
     """Default-initialised thr/bias heads keep ~95 % of the keys: behind the screen that is the streamed dense formulation
