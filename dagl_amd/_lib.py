@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 300          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 301          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196

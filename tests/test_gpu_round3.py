@@ -199,3 +199,33 @@ def test_training_path_range_guard_moves_the_module_to_the_fp32_forward(dense):
     assert torch.isfinite(out).all()
     out.sum().backward()
     assert torch.isfinite(x.grad).all()
+
+
+
+def test_mfma_probe_reports_a_plausible_clock_and_rate():
+    """dagl_probe_mfma_bf16 (bench.py's `roofline.sustained`): the screen's multiply stream alone.  The clock it reports lies between
+    the part's floor and its 2.4 GHz peak, the rate below the nominal 2.5 PFLOP/s and above a third of it."""
+    import torch
+    from dagl_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    blocks, steps = 256, 40
+    clocks = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, device=dev)
+    with torch.cuda.device(dev):
+        for _ in range(5):
+            _lib.check(lib.dagl_probe_mfma_bf16(ops._stream(), blocks, steps, clocks.data_ptr(), sink.data_ptr()), "probe")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            _lib.check(lib.dagl_probe_mfma_bf16(ops._stream(), blocks, steps, clocks.data_ptr(), sink.data_ptr()), "probe")
+        e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    c = clocks.cpu().numpy().reshape(blocks, 2).astype("float64")
+    assert (c > 0).all()
+    ghz = float((c[:, 0] / (c[:, 1] * 10.0)).mean())
+    tf = blocks * 16 * steps * 26 * 32768.0 / (ms * 1e-3) / 1e12
+    print(f"[probe] {tf:.0f} TFLOP/s bf16 at {ghz:.2f} GHz ({ms * 1e3:.1f} us per launch)")
+    assert 0.8 < ghz < 2.6 and 800.0 < tf < 2500.0
+    with pytest.raises(_lib.DaglError):
+        _lib.check(lib.dagl_probe_mfma_bf16(ops._stream(), 0, steps, clocks.data_ptr(), sink.data_ptr()), "probe")

@@ -78,7 +78,9 @@ def main():
                    "cycles (= 32 x the number of v_mfma_f32_32x32x16 issued, summed over all SIMDs); GRBM_GUI_ACTIVE is summed over the 8 "
                    "XCDs (clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
                    "GRBM_GUI_ACTIVE / 8) = fraction of the cycles the matrix pipes are busy AT THE CLOCK THE KERNEL RAN AT; "
-                   "lds_util = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8)"}
+                   "lds_util = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8).  CAUTION: the shader clock read inside the "
+                   "kernels (s_memtime against s_memrealtime: profiles/r03_screen_ring_clock_and_factors.log, bench.py roofline.sustained) is "
+                   "1.8-1.9 GHz under these streams, LOWER than clock_ghz here: mfma_util / lds_util are understated by that ratio"}
     for k in sq:
         sk = short(k)
         if not sk:
