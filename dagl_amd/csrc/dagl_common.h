@@ -323,10 +323,11 @@ struct ScreenArgs {
     const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
     int capseg;
-    // pass 1 out: one record of capseg 8-byte slots per (query, chunk, half) segment: slot 0 = {candidates found, 0}, slot
-    // 1 + e = {key, screened score (sign bit set = upper bound only)} of candidate e -- the count and the first three
-    // candidates share one 32-byte read.  A segment holds capseg - 1 candidates; a larger count means overflow.
-    int2* cand;                     // [B, L, splits*2, capseg]
+    // pass 1 out: capseg 8-byte slots per (query, chunk, half) segment: slot 0 = {candidates found, 0}, slot 1 + e = {key,
+    // screened score (sign bit set = upper bound only)} of candidate e, stored SLOT-MAJOR inside a query ([slot][segment]): the
+    // refine wave (lane = segment) reads a slot of all segments as one contiguous run.  A segment holds capseg - 1 candidates;
+    // a larger count means overflow.
+    int2* cand;                     // [B, L, capseg, splits*2]
     const int32_t* run_flags;
     int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
     unsigned long long* times;      // ablation builds: [blocks][4] 100 MHz stamps (entry, loop start, loop end, exit) or null

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         }
         n_loc[w] = 0;
         seg[w] = (qlin[w] * a.splits + split) * 2 + h;
-        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
+        cseg[w] = a.cand + (qlin[w] * a.capseg + 1) * (size_t)(a.splits * 2) + split * 2 + h;   // slot 1 (slot 0 = header); slots are splits * 2 apart
     }
 #pragma unroll
     for (int w = 0; w < QW; ++w)
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                             mask &= ~(1u << bit);
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
-                            if (n_loc[w] < a.capseg - 1) cseg[w][n_loc[w]] = make_int2(key, __float_as_int(sv));
+                            if (n_loc[w] < a.capseg - 1) cseg[w][(size_t)n_loc[w] * (a.splits * 2)] = make_int2(key, __float_as_int(sv));
                             ++n_loc[w];
                         }
                     }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += gm[w][r];
                 if (t == 12345.f) n_loc[w] = 1; }
-            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
+            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], 0);
         }
     }
     dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
         n_loc[w] = 0;
         seg[w] = (qlin * a.splits + split) * 2 + h;
-        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
+        cseg[w] = a.cand + (qlin * a.capseg + 1) * (size_t)(a.splits * 2) + split * 2 + h;   // slot 1 (slot 0 = header); slots are splits * 2 apart
     }
 #pragma unroll
     for (int w = 0; w < QW; ++w)
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                             mask &= ~(1u << bit);
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
-                            if (n_loc[w] < a.capseg - 1) cseg[w][n_loc[w]] = make_int2(key, __float_as_int(sv));
+                            if (n_loc[w] < a.capseg - 1) cseg[w][(size_t)n_loc[w] * (a.splits * 2)] = make_int2(key, __float_as_int(sv));
                             ++n_loc[w];
                         }
                     }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
         } else {
             if ((VAR & 16) && gm[w][0] == 12345.f) n_loc[w] = 1;      // (keeps the ablated loop's accumulators alive)
-            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
+            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], 0);
         }
     }
     if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -617,7 +617,7 @@ __device__ __forceinline__ void store8_if(const void* p, i32x2 v, int ok) {
 // scores of one query).  PASS 0: group maxima.  PASS 1: the first candidate is stored here; returns the mask of the lane's
 // FURTHER candidates (score r at bit 15 - r).  screen_pipe_kernel's `half` spells the same test out in slices.
 template <int PASS>
-__device__ __forceinline__ unsigned screen_test(const f32x16& acc, float thq, float thlo, int kbase, int2* cseg, int& n_loc, int cap,
+__device__ __forceinline__ unsigned screen_test(const f32x16& acc, float thq, float thlo, int kbase, int2* cseg, int s2, int& n_loc, int cap,
                                                 float (&gm)[16], float& sv_out) {
     if constexpr (PASS == 0) {
 #pragma unroll
@@ -635,19 +635,19 @@ __device__ __forceinline__ unsigned screen_test(const f32x16& acc, float thq, fl
         const int r = __clz((int)mask) - 16;                       // first candidate (lowest r); 16 when there is none
         const int key = kbase + (r & 3) + 8 * (r >> 2);
         i32x2 rec; rec[0] = key; rec[1] = __float_as_int(sv);
-        store8_if(cseg + n_loc, rec, (has && n_loc < cap) ? 1 : 0);
+        store8_if(cseg + (size_t)n_loc * s2, rec, (has && n_loc < cap) ? 1 : 0);
         n_loc += has;
         sv_out = sv;
         return has ? (mask & ~(0x8000u >> r)) : 0u;
     }
 }
-__device__ __forceinline__ void screen_rest(unsigned rest, float sv, int kbase, int2* cseg, int& n_loc, int cap) {
+__device__ __forceinline__ void screen_rest(unsigned rest, float sv, int kbase, int2* cseg, int s2, int& n_loc, int cap) {
     while (rest) {
         const int bit = 31 - __clz((int)rest);
         rest &= ~(1u << bit);
         const int r = 15 - bit;
         const int key = kbase + (r & 3) + 8 * (r >> 2);
-        if (n_loc < cap) cseg[n_loc] = make_int2(key, __float_as_int(sv));
+        if (n_loc < cap) cseg[(size_t)n_loc * s2] = make_int2(key, __float_as_int(sv));
         ++n_loc;
     }
 }
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
         thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
         n_loc[w] = 0;
         seg[w] = (qlin * a.splits + split) * 2 + h;
-        cseg[w] = a.cand + seg[w] * a.capseg + 1;               // slot 0 is the record's header
+        cseg[w] = a.cand + (qlin * a.capseg + 1) * (size_t)(a.splits * 2) + split * 2 + h;   // slot 1 (slot 0 = header); slots are splits * 2 apart
     }
     const int cap = a.capseg - 1;
 #pragma unroll
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
                     key[w] = kb_old + (r1[w] & 3) + 8 * (r1[w] >> 2);
                 } else if (PASS == 1 && t == 11) {
                     i32x2 rec; rec[0] = key[w]; rec[1] = __float_as_int(sv[w]);
-                    store8_if(cseg[w] + n_loc[w], rec, (has[w] && n_loc[w] < cap) ? 1 : 0);
+                    store8_if(cseg[w] + (size_t)n_loc[w] * (a.splits * 2), rec, (has[w] && n_loc[w] < cap) ? 1 : 0);
                     n_loc[w] += has[w];
                     rest[w] = has[w] ? (mask[w] & ~(0x8000u >> r1[w])) : 0u;
                 }
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
             for (int w = 1; w < QW; ++w) any_rest |= rest[w];
             if (__any(any_rest != 0u)) {
 #pragma unroll
-                for (int w = 0; w < QW; ++w) screen_rest(rest[w], sv[w], kb_old, cseg[w], n_loc[w], cap);
+                for (int w = 0; w < QW; ++w) screen_rest(rest[w], sv[w], kb_old, cseg[w], a.splits * 2, n_loc[w], cap);
             }
         }
     };
@@ -847,8 +847,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
 #pragma unroll
         for (int w = 0; w < QW; ++w) {
             float sv = 0.f;
-            const unsigned rest = screen_test<PASS>(accB[w], thq[w], thlo[w], kb_prev, cseg[w], n_loc[w], cap, gm[w], sv);
-            if (PASS == 1) screen_rest(rest, sv, kb_prev, cseg[w], n_loc[w], cap);
+            const unsigned rest = screen_test<PASS>(accB[w], thq[w], thlo[w], kb_prev, cseg[w], a.splits * 2, n_loc[w], cap, gm[w], sv);
+            if (PASS == 1) screen_rest(rest, sv, kb_prev, cseg[w], a.splits * 2, n_loc[w], cap);
         }
     }
 
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
             }
             if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
         } else {
-            if (qvalid[w]) cseg[w][-1] = make_int2(n_loc[w], 0);
+            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], 0);
         }
     }
     dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -1089,11 +1089,10 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
     for (int s0 = 0; s0 < S2; s0 += 64) {
         const int sgi = s0 + lane;
         const bool sv = sgi < S2;
-        const size_t sg = ql * S2 + (sv ? sgi : 0);
-        // one record per segment: {count, -} {key0, s0} {key1, s1} {key2, s2} arrive with two 16-byte loads of one line
-        const int2* rec = a.cand + sg * a.capseg;                // sg is a valid slot also for idle lanes
-        const int4 r0 = *reinterpret_cast<const int4*>(rec);
-        const int4 r1 = *reinterpret_cast<const int4*>(rec + 2);
+        // records are slot-major inside a query -- [slot][segment] -- so that the lanes' reads of one slot are one contiguous run
+        // (8 bytes per lane); the count and the first three candidates are asked for together (one memory round trip)
+        const int2* rec = a.cand + ql * (size_t)a.capseg * S2 + (sv ? sgi : 0);      // slot 0 of this lane's segment
+        const int2 r0 = rec[0], c0 = rec[S2], c1 = rec[2 * (size_t)S2], c2 = rec[3 * (size_t)S2];
         int cnt = sv ? r0.x : 0;
         if (cnt > a.capseg - 1) { overflow = true; cnt = a.capseg - 1; }
         int incl = cnt;
@@ -1101,11 +1100,11 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int off = total + incl - cnt;
         if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
-        if (cnt > 0) { ci[off] = r0.z; cv[off] = __int_as_float(r0.w); }
-        if (cnt > 1) { ci[off + 1] = r1.x; cv[off + 1] = __int_as_float(r1.y); }
-        if (cnt > 2) { ci[off + 2] = r1.z; cv[off + 2] = __int_as_float(r1.w); }
+        if (cnt > 0) { ci[off] = c0.x; cv[off] = __int_as_float(c0.y); }
+        if (cnt > 1) { ci[off + 1] = c1.x; cv[off + 1] = __int_as_float(c1.y); }
+        if (cnt > 2) { ci[off + 2] = c2.x; cv[off + 2] = __int_as_float(c2.y); }
         for (int e = 3; e < cnt; ++e) {
-            const int2 c = rec[1 + e];
+            const int2 c = rec[(size_t)(1 + e) * S2];
             ci[off + e] = c.x; cv[off + e] = __int_as_float(c.y);
         }
         total += __shfl(incl, 63);
