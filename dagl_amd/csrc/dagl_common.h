@@ -94,6 +94,70 @@ __device__ __forceinline__ void lds_flag_add(unsigned byte_addr, unsigned val) {
     asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
 }
 
+// ---- wave-wide reductions / scan on the DPP path -------------------------------------------------------------------------------
+// __shfl_xor / __shfl_up compile to ds_bpermute_b32: every step is a round trip through the LDS crossbar (~100+ cycles of
+// dependent latency); a 64-lane reduction is six of them, a refine wave did ~110 per query.  The same data movement as DPP
+// modifiers of the ALU instruction itself (quad_perm, row_ror, row_bcast -- gfx9 encodings) costs a few cycles per step.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_keep_f(float v) {                 // lanes without a source (or in a masked row) keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_keep_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)h2 << 32) | l2));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_zero_i(int v) {                     // lanes without a source (or in a masked row) get 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+// maximum over the 64 lanes, the same value in every lane
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_keep_f<0xB1>(v));                                // quad_perm 1,0,3,2
+    v = fmaxf(v, dpp_keep_f<0x4E>(v));                                // quad_perm 2,3,0,1
+    v = fmaxf(v, dpp_keep_f<0x124>(v));                               // row_ror 4
+    v = fmaxf(v, dpp_keep_f<0x128>(v));                               // row_ror 8: every lane holds its row's maximum
+    v = fmaxf(v, dpp_keep_f<0x142, 0xa>(v));                          // row_bcast 15 into rows 1, 3
+    v = fmaxf(v, dpp_keep_f<0x143, 0xc>(v));                          // row_bcast 31 into rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_bcast63_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_keep_d<0xB1>(v)); v = fmax(v, dpp_keep_d<0x4E>(v)); v = fmax(v, dpp_keep_d<0x124>(v)); v = fmax(v, dpp_keep_d<0x128>(v));
+    v = fmax(v, dpp_keep_d<0x142, 0xa>(v)); v = fmax(v, dpp_keep_d<0x143, 0xc>(v));
+    return wave_bcast63_d(v);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_zero_d(double v) {              // lanes without a source (or in a masked row) get 0
+    const long long b = __double_as_longlong(v);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)h2 << 32) | l2));
+}
+// sum over the 64 lanes (fixed association: pairs, quads, rows of 16, rows 0+1 / 2+3, all), the same value in every lane
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_zero_d<0xB1>(v); v += dpp_zero_d<0x4E>(v); v += dpp_zero_d<0x124>(v); v += dpp_zero_d<0x128>(v);   // every lane: its row's sum
+    v += dpp_zero_d<0x142, 0xa>(v); v += dpp_zero_d<0x143, 0xc>(v);                                         // lane 63: all four rows
+    return wave_bcast63_d(v);
+}
+// inclusive prefix sum over the lanes
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+    v += dpp_zero_i<0x111>(v);                                        // row_shr 1
+    v += dpp_zero_i<0x112>(v);                                        // row_shr 2
+    v += dpp_zero_i<0x114>(v);                                        // row_shr 4
+    v += dpp_zero_i<0x118>(v);                                        // row_shr 8: inclusive inside each row of 16
+    v += dpp_zero_i<0x142, 0xa>(v);                                   // + row 0 (2) total into rows 1 (3)
+    v += dpp_zero_i<0x143, 0xc>(v);                                   // + rows 0..1 total into rows 2, 3
+    return v;
+}
+
 #endif
 
 // thread-local error text

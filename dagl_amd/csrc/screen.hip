@@ -1005,9 +1005,7 @@ __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, in
         float lm = v[0];
 #pragma unroll
         for (int u = 1; u < THETA_PER_LANE; ++u) lm = fmaxf(lm, v[u]);
-        float wm = lm;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        const float wm = wave_max_f32(lm);
         kth = wm;
         if (wm < 0.f) break;                                   // fewer than k non-empty groups (wave-uniform)
         // the first lane holding the maximum drops one copy of it
@@ -1095,9 +1093,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         const int2 r0 = rec[0], c0 = rec[S2], c1 = rec[2 * (size_t)S2], c2 = rec[3 * (size_t)S2];
         int cnt = sv ? r0.x : 0;
         if (cnt > a.capseg - 1) { overflow = true; cnt = a.capseg - 1; }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int incl = wave_scan_incl_i32(cnt);
         const int off = total + incl - cnt;
         if (off + cnt > RF_MAX_CAND) { overflow = true; cnt = max(0, RF_MAX_CAND - off); }
         if (cnt > 0) { ci[off] = c0.x; cv[off] = __int_as_float(c0.y); }
@@ -1107,7 +1103,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
             const int2 c = rec[(size_t)(1 + e) * S2];
             ci[off + e] = c.x; cv[off + e] = __int_as_float(c.y);
         }
-        total += __shfl(incl, 63);
+        total += __builtin_amdgcn_readlane(incl, 63);
     }
     overflow = __any(overflow);
     if (total > RF_MAX_CAND) total = RF_MAX_CAND;
@@ -1149,9 +1145,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
             float lm = work[0];
 #pragma unroll
             for (int u = 1; u < TU; ++u) lm = fmaxf(lm, work[u]);
-            float wm = lm;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            const float wm = wave_max_f32(lm);
             tk = wm;
             const unsigned long long bal = __ballot(lm == wm);              // the first lane holding it drops one copy
             const int owner = __ffsll((long long)bal) - 1;
@@ -1189,9 +1183,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
                     if (lbv > lm) { lm = lbv; lu = u; }
                 }
             }
-            float wm = lm;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            const float wm = wave_max_f32(lm);
             tk = wm;
             const unsigned long long bal = __ballot(lu >= 0 && lm == wm);
             if (bal != 0ull && lane == __ffsll((long long)bal) - 1) taken |= 1u << lu;
@@ -1236,7 +1228,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
             acc += (double)qv[u].x * (double)xv[u].x + (double)qv[u].y * (double)xv[u].y +
                    (double)qv[u].z * (double)xv[u].z + (double)qv[u].w * (double)xv[u].w;
         }
-        acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+        acc += dpp_zero_d<0xB1>(acc); acc += dpp_zero_d<0x4E>(acc); acc += dpp_zero_d<0x141>(acc);     // pairs, quads, the group's other quad
         if (okc && gl == 0) {
             cv[c] = inb ? (float)acc : -4.0f;
             if (!inb) ci[c] = -1;                          // never selected
@@ -1295,7 +1287,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         }
         int rank = 0;
         for (int j = 0; j < total; ++j) {
-            const float vj = __shfl(v, j); const int kj = __shfl(key, j);
+            const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); const int kj = __builtin_amdgcn_readlane(key, j);
             rank += rf_before(vj, kj, v, key) ? 1 : 0;
         }
         const unsigned long long valid_mask = __ballot(v > -2.0f);
@@ -1337,8 +1329,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         lg[u] = valid ? rf_logit(my_s[u], mtq, bsq, adaptive) : 0.f;
         if (valid) M = fmax(M, (double)lg[u]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
+    M = wave_max_f64(M);
     if (n < a.N) M = fmax(M, 0.0);
     double ev[RU], sum = 0.0;
 #pragma unroll
@@ -1347,8 +1338,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         ev[u] = (e >= 0 && e < n) ? exp((double)lg[u] - M) : 0.0;        // (slots past the first are empty outside the long-tail case)
         sum += ev[u];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_f64(sum);
     sum += (double)(a.N - n) * exp(-M);
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
