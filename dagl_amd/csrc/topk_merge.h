@@ -15,16 +15,9 @@ __device__ __forceinline__ float edge_logit(float s, float mtq, float bsq, bool 
     return __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE);
 }
 
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// (all 64 lanes active at every call site; DPP forms: dagl_common.h)
+__device__ __forceinline__ double wave_max_d(double v) { return wave_max_f64(v); }
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }
 
 // MODE 2/3: merge the per-(chunk, half) k-best candidate lists of a query into its exact k best
 // (value descending, ties -> smaller key index), then weights.  One wave per query; candidates in LDS.
