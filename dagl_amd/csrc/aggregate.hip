@@ -317,6 +317,15 @@ __global__ __launch_bounds__(256) void fold_kernel(Grid g, const float* __restri
 // aggregated value at the pixel's place in the window -- the same fma chain over the neighbours, in list order, that
 // aggregate_direct_kernel runs -- and adds the windows in fold_kernel's order: the result is bit-identical to the two
 // kernels, without the [L,784] rows ever going to memory (12.8 MB written and read back at 256^2) and one launch less.
+// key -> (row, column) of the map: every thread does this for every neighbour of up to four queries (32 per thread, 8.4 M per
+// launch at 256^2), and an integer division by a run-time W is ~25 instructions: float reciprocal + one correction step instead
+// (exact: keys < 2^24, the product is off by less than one)
+__device__ __forceinline__ void key_row_col(int id, int W, float inv_w, int& jy, int& jx) {
+    jy = (int)((float)id * inv_w);
+    jx = id - jy * W;
+    if (jx < 0) { --jy; jx += W; } else if (jx >= W) { ++jy; jx -= W; }
+}
+
 __global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* __restrict__ out, int imgs, int heads,
                                                              RangeTag range) {
     const Grid& g = a.g;
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* _
     int c1 = (x + 3) / QS; if (c1 > g.Lw - 1) c1 = g.Lw - 1;
     const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * g.Hp * g.Wp * CH) + u;
     const int W = g.W, Wp = g.Wp;
+    const float inv_w = 1.0f / (float)W;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = r0; r <= r1; ++r) {
         const int kh = y - (QS * r - 3);
@@ -351,8 +361,8 @@ __global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* _
                 for (int e = 0; e < 4; ++e) { id[e] = ip[j + e]; w[e] = wp[j + e]; }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int jy = id[e] / W, jx = id[e] - jy * W;
-                    v[e] = vm[((size_t)(jy + kh) * Wp + jx + kw) * (CH / 4)];
+                    int jy, jx; key_row_col(id[e], W, inv_w, jy, jx);
+                    v[e] = vm[((jy + kh) * Wp + jx + kw) * (CH / 4)];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -362,8 +372,8 @@ __global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* _
             }
             for (; j < n; ++j) {
                 const int id = ip[j]; const float w = wp[j];
-                const int jy = id / W, jx = id - jy * W;
-                const float4 v = vm[((size_t)(jy + kh) * Wp + jx + kw) * (CH / 4)];
+                int jy, jx; key_row_col(id, W, inv_w, jy, jx);
+                const float4 v = vm[((jy + kh) * Wp + jx + kw) * (CH / 4)];
                 q.x = fmaf(w, v.x, q.x); q.y = fmaf(w, v.y, q.y);
                 q.z = fmaf(w, v.z, q.z); q.w = fmaf(w, v.w, q.w);
             }
