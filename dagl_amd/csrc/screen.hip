@@ -351,13 +351,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 
     // prologue: the first RING_AHEAD tiles are requested by all waves together (one barrier, outside the loop)
     const unsigned ready0 = lds0 + RING_NBUF * STEP_ELEMS * 2, done0 = ready0 + 32;        // LDS byte addresses of the flag words
-#ifdef DAGL_RING_SPREAD
-    // spread form: EVERY wave requests its share of every tile (pieces wave, wave + WAVES, ..) and ready[] counts the waves whose
-    // share has landed: WAVES x (tiles the slot has held)
-    if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)WAVES : 0u; flags[8 + tid] = 0u; }
-#else
     if (tid < RING_NBUF) { flags[tid] = (tid < RING_AHEAD && tid < n_it) ? (unsigned)(tid + 1) : 0u; flags[8 + tid] = 0u; }
-#endif
 #pragma unroll
     for (int j = 0; j < RING_AHEAD; ++j)
         if (j < n_it) {
@@ -380,39 +374,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 #define RING_PH(k) do { if (VAR & 64) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); ph[k] += t1_ - ph_t; ph_t = t1_; } } while (0)
     for (int it = 0; it < n_it; ++it) {
         const int step = step0 + it * stride;
-#ifdef DAGL_RING_SPREAD
-        {
-            // (1) my share of tile it + AHEAD - 1 was requested a whole step ago: it has landed -> one more wave's share is in
-            if (it >= 1 && it + RING_AHEAD - 1 < n_it && !(VAR & 1)) {
-                dma_wait_all();
-                if (lane == 0) lds_flag_add(ready0 + 4 * ((it + RING_AHEAD - 1) % RING_NBUF), 1u);
-            }
-            // (2) one look at the flag words (lane l reads word l): tile `it` complete, and the slot of tile it + AHEAD left by everybody
-            const int T = it + RING_AHEAD;
-            const int tb = T % RING_NBUF;
-            const unsigned need_ready = (unsigned)(WAVES * (it / RING_NBUF + 1));
-            const unsigned need_done = (T < n_it) ? (unsigned)(WAVES * (T / RING_NBUF)) : 0u;
-            if (!(VAR & 1) && !(VAR & 8)) {
-                for (;;) {
-                    unsigned v;
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ready0 + 4u * (unsigned)(lane & 15)) : "memory");
-                    const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, buf);
-                    const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 8 + tb);
-                    if (r >= need_ready && d >= need_done) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            RING_PH(3);
-            // (3) my share of tile it + AHEAD
-            if (T < n_it && !(VAR & 1)) {
-                const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
-                const unsigned short* src = xb + (size_t)(step0 + T * stride) * STEP_ELEMS + lane * 8;
-                for (int p = wave; p < STEP_PIECES; p += WAVES)
-                    glds16_asm(reinterpret_cast<const float*>(src + p * 512), __builtin_amdgcn_readfirstlane(dst + p * 1024));
-            }
-            RING_PH(0);
-        }
-#else
         // --- requester duty: tile it + AHEAD belongs to wave (it + AHEAD) % WAVES ---------------------------------------
         {
             const int T = it + RING_AHEAD;
@@ -423,12 +384,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                     while (lds_flag_load(done0 + 4 * tb) < need) __builtin_amdgcn_s_sleep(1);
                 }
                 const unsigned dst = lds0 + (unsigned)tb * (STEP_ELEMS * 2);
-#ifdef DAGL_RING_PIECEWISE
-                const unsigned short* src = xb + (size_t)(step0 + T * stride) * STEP_ELEMS + lane * 8;
-#pragma unroll
-                for (int p = 0; p < STEP_PIECES; ++p)
-                    glds16_asm(reinterpret_cast<const float*>(src + p * 512), __builtin_amdgcn_readfirstlane(dst + p * 1024));
-#else
                 {
                     const unsigned long long sa = (unsigned long long)(uintptr_t)(xb + (size_t)(step0 + T * stride) * STEP_ELEMS);
                     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa);
@@ -436,7 +391,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                     glds_tile27_asm(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)lane * 16u,
                                     __builtin_amdgcn_readfirstlane(dst));
                 }
-#endif
                 pend_tile = T;
             }
         }
@@ -445,19 +399,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         if (!(VAR & 1) && !(VAR & 8))
             while (lds_flag_load(ready0 + 4 * buf) < (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);
         RING_PH(3);
-#endif
 
         f32x16 acc[QW][2];
 #pragma unroll
         for (int w = 0; w < QW; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[w][0][r] = 0.f; acc[w][1][r] = 0.f; }
-#ifdef DAGL_RING_PRIO
-        __builtin_amdgcn_s_setprio(DAGL_RING_PRIO);
-#endif
-#ifdef DAGL_RING_TAILPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         const unsigned short* kp0 = &smem[buf * STEP_ELEMS + i * DSH + 8 * h];
         const unsigned short* kp1 = kp0 + 32 * DSH;
 #pragma unroll
@@ -489,12 +436,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                 if (t + PF < KB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
-#ifdef DAGL_RING_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef DAGL_RING_TAILPRIO
-        __builtin_amdgcn_s_setprio(DAGL_RING_TAILPRIO);        // tail (and the next step's request / poll) ahead of the other waves' multiplies
-#endif
         // every read of the slot has been issued (LDS executes a wave's operations in order): one more wave-step is through
         if (lane == 0 && !(VAR & 8)) lds_flag_add(done0 + 4 * buf, 1u);
         if (VAR & 64) { asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[0][1][15])); }       // (the multiplies have completed)
