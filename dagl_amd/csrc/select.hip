@@ -289,25 +289,29 @@ __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(Select
     __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB; the merge's candidate arrays (32 KiB) reuse it
     static_assert(sizeof(float) * 2 * TILE_LDS >= (sizeof(float) + sizeof(int)) * 4 * TOPK_MAX_CAND, "merge arrays fit the scan's tiles");
     if (*a.run_count == 0) return;                                       // nothing flagged anywhere (the usual case)
+    bool wrote = false;
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform
         score_select_unit<PASS, K>(a, sK, n_qgroups, n_tiles, rows_q, rows_x, unit);
+        wrote = true;
         __syncthreads();
     }
-    // every block's lists are in memory before any block merges
+    // every block's lists are in memory before any block merges.  A device-scope fence writes back / invalidates the XCD's whole L2
+    // (~0.2 us each, serialised per XCD: 512 of them cost 110 us): release only by blocks that wrote lists, acquire (below) only
+    // by blocks that are about to read some
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        if (wrote) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned total = gridDim.x * gridDim.y;
-        atomicAdd(barrier, 1u);
+        __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (atomicAdd(barrier, 0u) < total) {
+        while (__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1u << 23)) __builtin_trap();                 // (seconds: a block that never became resident -- fail loudly, do not hang)
         }
-        __threadfence();
     }
     __syncthreads();
+    bool acquired = false;
     float (*cv)[TOPK_MAX_CAND] = reinterpret_cast<float (*)[TOPK_MAX_CAND]>(&sK[0][0]);
     int (*ci)[TOPK_MAX_CAND] = reinterpret_cast<int (*)[TOPK_MAX_CAND]>(&sK[0][0] + 4 * TOPK_MAX_CAND);
     const int nqg = (e.L + 127) / 128;
@@ -316,6 +320,11 @@ __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(Select
         const size_t q0 = blk * 4, q1 = (q0 + 3 < (size_t)e.B * e.L - 1) ? q0 + 3 : (size_t)e.B * e.L - 1;
         const size_t b0 = q0 / e.L, b1 = q1 / e.L;
         if (e.run_flags[b0 * nqg + (q0 - b0 * e.L) / 128] == 0 && e.run_flags[b1 * nqg + (q1 - b1 * e.L) / 128] == 0) continue;
+        if (!acquired) {                                                  // (block-uniform)
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            acquired = true;
+        }
         edge_softmax_topk_unit(e, kslots, cv, ci, blk);
         __syncthreads();
     }
