@@ -147,6 +147,17 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     v += dpp_zero_d<0x142, 0xa>(v); v += dpp_zero_d<0x143, 0xc>(v);                                         // lane 63: all four rows
     return wave_bcast63_d(v);
 }
+__device__ __forceinline__ int wave_sum_i32(int v) {                  // the same value in every lane
+    v += dpp_zero_i<0xB1>(v); v += dpp_zero_i<0x4E>(v); v += dpp_zero_i<0x124>(v); v += dpp_zero_i<0x128>(v);
+    v += dpp_zero_i<0x142, 0xa>(v); v += dpp_zero_i<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// sum over each aligned group of four lanes (every lane of the group gets it)
+__device__ __forceinline__ float quad_sum_f32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+    return v;
+}
 // inclusive prefix sum over the lanes
 __device__ __forceinline__ int wave_scan_incl_i32(int v) {
     v += dpp_zero_i<0x111>(v);                                        // row_shr 1

@@ -81,8 +81,7 @@ __global__ __launch_bounds__(256) void ovf_scores_small_kernel(OvfArgs a) {
 #pragma unroll
     for (int r = 0; r < OVF_SMALL; ++r)
         if (r < nf) {
-            float sum = acc[r];
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+            const float sum = quad_sum_f32(acc[r]);
             if (ok && qd == 0) a.scores[((size_t)b * a.cap + r) * a.ldn + key] = sum;
         }
 }
@@ -117,8 +116,7 @@ __global__ __launch_bounds__(256) void ovf_stats_kernel(OvfArgs a) {
             bool pass; const float l = ovf_logit(row[j], mtq, bsq, pass);
             if (pass) { mx = fmaxf(mx, l); ++cnt; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); cnt += __shfl_xor(cnt, o); }
+        mx = wave_max_f32(mx); cnt = wave_sum_i32(cnt);
         if (lane == 0) { shf[w] = mx; wcnt[w] = cnt; }
         __syncthreads();
         if (tid == 0) {
