@@ -280,8 +280,8 @@ int launch_score_select(hipStream_t s, const SelectArgs& a, int pass) {
 // REDO pass of the top-k modes behind the screen, both halves in ONE launch: the exact scan of the flagged query groups
 // (score_select_kernel's redo form: per-(chunk, half) k-best lists) and, behind a grid barrier, the merge of those lists into
 // the neighbour lists (edge_softmax_topk_kernel's redo form).  Almost always nothing is flagged and the launch exits after one
-// load -- as two launches that cost two launch + load latencies (~3 us each) on every forward.  The barrier: at most 256 blocks of
-// 256 threads, two per CU: all resident (blocks of other streams' kernels only delay them); the word is zeroed per call.
+// load -- as two launches that cost two launch + load latencies (~3 us each) on every forward.  The barrier: at most 128 blocks of
+// 256 threads (one or two fit a CU): all resident (blocks of other streams' kernels only delay them); the word is zeroed per call.
 template <int PASS, int K>
 __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(SelectArgs a, EdgeArgs e, int kslots, int n_qgroups, int n_tiles,
                                                                          int rows_q, int rows_x, int n_units, unsigned n_merge_blocks,
@@ -345,11 +345,11 @@ int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int 
         return DAGL_ERR_INVALID;
     }
     const unsigned n_merge = (unsigned)(((size_t)e.B * e.L + 3) / 4);
-    // all blocks resident: 256 at most (K = 64: one block per CU), the batch in grid.y
-    int gx = 256 / (a.B > 0 ? a.B : 1);
-    if (gx > 128) gx = 128;
+    // all blocks resident whatever the device is doing besides: 128 at most (K = 64 takes 407 registers: ONE block per CU), the batch
+    // in grid.y
+    int gx = 128 / (a.B > 0 ? a.B : 1);
     if (gx > n_units) gx = n_units;
-    if (gx < 1 || a.B > 256) {                                            // (a batch this large: the two-launch form)
+    if (gx < 1) {                                                         // (a batch this large: the two-launch form)
         int rc = launch_score_select(s, a, pass);
         return rc ? rc : launch_edge_softmax(s, e);
     }
