@@ -72,6 +72,7 @@ SIGNATURES = {
     "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
                            _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i, _i, _vp]),
     "dagl_probe_mfma_bf16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "dagl_selftest_wave_ops": (_i, [_vp, _vp]),
     "dagl_fc_grad16_scratch_bytes": (_sz, [_i, _i, _i]),
     "dagl_fc_grad16": (_i, [_vp] + [_i] * 8 + [_vp] * 8 + [_sz]),
     "dagl_unfold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),

@@ -84,7 +84,56 @@ __global__ __launch_bounds__(1024, 1) void mfma_probe_kernel(int steps, unsigned
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// ---- self-test of the DPP wave primitives (dagl_common.h) against a serial evaluation through the LDS --------------------------
+__global__ __launch_bounds__(256) void wave_ops_selftest_kernel(unsigned seed, int* __restrict__ mismatches) {
+    __shared__ float sf[256];
+    __shared__ double sd[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x, lane = tid & 63, w0 = tid & ~63;
+    unsigned x = seed * 2654435761u + (blockIdx.x * 256u + tid) * 40503u + 12345u;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    const float f = (float)(int)(x & 0xFFFFu) * 0.37f - 9000.f;
+    const double d = (double)(int)((x >> 8) & 0xFFFFu) * 1.0e-3 - 20.0;
+    const int n = (int)((x >> 20) & 0x3FFu);
+    sf[tid] = f; sd[tid] = d; si[tid] = n;
+    __syncthreads();
+    float rmax = -__builtin_inff(); double dmax = -1e300, dsum = 0.0; int isum = 0, scan = 0;
+    for (int l = 0; l < 64; ++l) {
+        rmax = fmaxf(rmax, sf[w0 + l]); dmax = fmax(dmax, sd[w0 + l]); isum += si[w0 + l];
+        if (l <= lane) scan += si[w0 + l];
+    }
+    // the sum's association: pairs, quads, rows of 16 (ror 4 then ror 8), rows 0+1 | 2+3, halves -- evaluate it the same way
+    double rows[4];
+    for (int r = 0; r < 4; ++r) {
+        double qd[4];
+        for (int q = 0; q < 4; ++q) {
+            const double* p = &sd[w0 + 16 * r + 4 * q];
+            qd[q] = (p[0] + p[1]) + (p[2] + p[3]);
+        }
+        rows[r] = (qd[0] + qd[1]) + (qd[2] + qd[3]);
+    }
+    dsum = (rows[0] + rows[1]) + (rows[2] + rows[3]);
+    const float quad = (sf[tid & ~3] + sf[(tid & ~3) + 1]) + (sf[(tid & ~3) + 2] + sf[(tid & ~3) + 3]);
+    int bad = 0;
+    bad += wave_max_f32(f) != rmax;
+    bad += wave_max_f64(d) != dmax;
+    bad += fabs(wave_sum_f64(d) - dsum) > 1e-9 * (1.0 + fabs(dsum));
+    bad += wave_sum_i32(n) != isum;
+    bad += wave_scan_incl_i32(n) != scan;
+    bad += fabsf(quad_sum_f32(f) - quad) > 1e-3f * (1.f + fabsf(quad));
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace dagl
+
+extern "C" int dagl_selftest_wave_ops(void* stream, int* mismatches_dev) {
+    using namespace dagl;
+    if (!mismatches_dev) { set_error("dagl_selftest_wave_ops: bad argument"); return DAGL_ERR_INVALID; }
+    DAGL_HIP_TRY(hipMemsetAsync(mismatches_dev, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(wave_ops_selftest_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, 20240u, mismatches_dev);
+    DAGL_LAUNCH_CHECK("wave_ops_selftest_kernel");
+    return DAGL_OK;
+}
 
 extern "C" int dagl_probe_mfma_bf16(void* stream, int blocks, int steps, unsigned long long* clocks, float* sink) {
     using namespace dagl;

@@ -133,6 +133,9 @@ int         dagl_device_check(void);            /* OK iff the current HIP device
  * 2*blocks uint64); sink = one float of device memory.  FLOP of a launch = blocks * 16 * steps * 26 * 32768; time it with
  * events on `stream`.                                                                                                      */
 int dagl_probe_mfma_bf16(void* stream, int blocks, int steps, unsigned long long* clocks, float* sink);
+/* Self-test (replaces nothing in the reference): the wave-wide reductions / scan the per-query kernels run on the DPP path
+ * (dagl_amd/csrc/dagl_common.h) against a serial evaluation; *mismatches_dev (one int of device memory) = lanes that disagree. */
+int dagl_selftest_wave_ops(void* stream, int* mismatches_dev);
 
 /* ---- whole block: replaces dagl.py:216-274 (CE.forward after its prologue convs) -------------- */
 

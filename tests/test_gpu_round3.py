@@ -229,3 +229,17 @@ def test_mfma_probe_reports_a_plausible_clock_and_rate():
     assert 0.8 < ghz < 2.6 and 800.0 < tf < 2500.0
     with pytest.raises(_lib.DaglError):
         _lib.check(lib.dagl_probe_mfma_bf16(ops._stream(), 0, steps, clocks.data_ptr(), sink.data_ptr()), "probe")
+
+
+
+def test_dpp_wave_primitives_agree_with_a_serial_evaluation():
+    """wave_max_f32 / wave_max_f64 / wave_sum_f64 / wave_sum_i32 / wave_scan_incl_i32 / quad_sum_f32 (dagl_common.h: quad_perm, row_ror,
+    row_bcast modifiers instead of ds_bpermute chains) on 64 blocks of pseudo-random lanes."""
+    import torch
+    from dagl_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    bad = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dagl_selftest_wave_ops(ops._stream(), bad.data_ptr()), "dagl_selftest_wave_ops")
+    assert int(bad.item()) == 0
