@@ -248,8 +248,49 @@ def extra_configs(dev):
                                           "ms_per_step": ms, "patches_per_s": 4 * 4096 / (ms * 1e-3), "L": 4096, "N": 65536}
         del heads, prm, x, ws
         torch.cuda.empty_cache()
+    out["256x256_topk8_set12_features"] = real_features_extra(dev)
     out["train_rr_topk8_128x128_b8"] = train_extra(dev)
     return out
+
+
+def real_features_extra(dev):
+    """One head, top-k k=8, on REAL features: Set12 image 01 (sigma 50, the reference's test protocol) through the trained
+    checkpoint's head conv and first eight ResBlocks, whole 256x256 map.  Natural-image scores are not spread like the synthetic
+    map's: the threshold sampled from every 8th key tile lets hundreds to thousands of keys through and the call lands on the fp32
+    redo pass; CE.topk_threshold = "auto" notices after the first call and takes the threshold from every key tile."""
+    import numpy as np
+    from dagl_amd.net import RR, set12_protocol_noise
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    try:
+        z = np.load(os.path.join(gdir, "quality_ckpt_fp16.npz"))
+        imgs = np.load(os.path.join(gdir, "set12.npz"))
+    except OSError as e:
+        return {"what": "skipped", "error": str(e)}
+    net = RR().eval()
+    net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
+    net = net.to(dev)
+    name = sorted(n for n in imgs.files if imgs[n].shape[-1] == 256 and imgs[n].shape[-2] == 256)[0]
+    clean = torch.from_numpy(imgs[name].astype(np.float32))
+    clean = clean[None, None] if clean.ndim == 2 else clean
+    res = {"what": f"one head, top-k k=8, on the features of Set12 {name} (sigma 50) after the trained RR's head conv + 8 ResBlocks, "
+                   "whole 256x256 map", "L": 4096, "N": 65536}
+    with torch.no_grad():
+        x = net.head(set12_protocol_noise(clean, 50.0, 1.0).to(dev))
+        for blk in net.body[:8]:
+            x = blk(x)
+        x = x.contiguous()
+        ce = net.body[8].c1_1
+        ce.select_mode, ce.select_k = "topk", 8
+        for thr in ("sparse", "auto"):
+            ce.topk_threshold = thr
+            ce._topk_shape = None                            # (a fresh start for the policy)
+            ms = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
+            res["ms_per_step" if thr == "auto" else "ms_per_step_sampled_threshold"] = ms
+        res["patches_per_s"] = 4096 / (res["ms_per_step"] * 1e-3)
+        res["threshold"] = "full" if ce._topk_tight else "sparse"
+    del net, x
+    torch.cuda.empty_cache()
+    return res
 
 
 def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):

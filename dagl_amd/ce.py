@@ -156,6 +156,16 @@ class CE(nn.Module):
         # all); the device-side verdict NaN-fills a call the in-stream kernels could not serve -- never wrong numbers -- and
         # the sticky word is polled every 16th call, which sends the module back to waiting.
         self.adaptive_sync = "always"
+        # top-k modes: where the candidate threshold comes from.  "sparse" = every 8th key tile (enough on maps whose scores are
+        # spread evenly, e.g. the synthetic benchmark features); "full" = every key tile + four times the candidate slots
+        # (DAGL_FLAG_TIGHT_TOPK: +50 us at 256^2) -- on natural-image features the sampled threshold lets hundreds to thousands
+        # of keys through, the slots overflow and the call lands on the fp32 redo pass (2.6 ms instead of 0.27);
+        # "auto" (default) = start sparse, look at the workspace's verdict after the first call and every 64th (one
+        # synchronisation, together with the range word) and move to "full" for this input shape once a call needed the redo pass.
+        self.topk_threshold = "auto"
+        self._topk_tight = False
+        self._topk_shape = None
+        self._topk_calls = 0
         self._served_streak = 0
         self._served_shape = None
         self._nowait_calls = 0
@@ -179,7 +189,9 @@ class CE(nn.Module):
             self._served_streak = 0
         if bad & 1:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
-        return not bad
+        if (bad & 4) and self.topk_threshold == "auto":
+            self._topk_tight = True                # the sampled threshold let too many keys through: every key tile from now on
+        return not (bad & 3)
 
     def _note_range_violation(self, what):
         import warnings
@@ -366,10 +378,14 @@ class CE(nn.Module):
             self._served_shape, self._served_streak = tuple(b.shape), 0
         no_wait = (self.select_mode == "adaptive" and self.scan != "exact" and not hint and self.adaptive_sync == "auto"
                    and self._served_streak >= 4 and key == self._pack_key and self.profile is None)
+        if self._topk_shape != tuple(b.shape[1:]):
+            self._topk_shape, self._topk_tight, self._topk_calls = tuple(b.shape[1:]), False, 0
+        tight = self.select_mode != "adaptive" and self.scan != "exact" and \
+            (self.topk_threshold == "full" or (self.topk_threshold == "auto" and self._topk_tight))
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
-                                         dense_hint=hint, want_info=want_info, no_wait=no_wait)
+                                         dense_hint=hint, want_info=want_info, no_wait=no_wait, tight_topk=tight)
         self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
         self._last_call = (tuple(b.shape), b.device)
         if no_wait:
@@ -386,7 +402,9 @@ class CE(nn.Module):
             # no host round trip in the top-k modes: look at the range word every 64th call (one synchronisation); a call
             # that left the range has returned NaN (never wrong numbers), the module moves to the fp32 path from here on
             self._calls_since_range_check += 1
-            if self._calls_since_range_check >= 64:
+            self._topk_calls += 1
+            if self._calls_since_range_check >= 64 or (self._topk_calls == 1 and self.topk_threshold == "auto"
+                                                      and not torch.cuda.is_current_stream_capturing()):
                 self.range_ok()
         if info is not None:
             self.last_info = info

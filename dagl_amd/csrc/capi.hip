@@ -100,7 +100,7 @@ struct Plan {
     bool split16;                   // fp16 split-operand projection (default) vs. the fp32 MFMA projection
     int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
     int s_splits, s_steps_per_split, s_steps, s_sample, s_qblock;   // bf16 screen (screen.hip)
-    int capseg;
+    int capseg, capseg_alloc;
     int width;                      // neighbour-list width of the fixed-width paths
     int ovf_cap;                    // adaptive lists behind the screen: queries that may be redone one by one (overflow.hip)
     // byte offsets into the workspace
@@ -124,7 +124,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
@@ -195,6 +195,18 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     // (short key streams): ~1024 slots per query in total
     p.capseg = SCREEN_CAPSEG;
     while (p.capseg < 256 && 2 * p.capseg * p.s_splits * 2 <= 1024) p.capseg *= 2;
+#ifdef DAGL_ABLATION
+    { static const int cs = [] { const char* e = getenv("DAGL_SCREEN_CAPSEG"); return e ? atoi(e) : 0; }(); if (cs >= 4) p.capseg = cs; }
+#endif
+    // DAGL_FLAG_TIGHT_TOPK: the threshold from every key tile, four times the slots per segment (as far as 1 GiB of records goes).
+    // The records are ALWAYS laid out for the larger count, so that a workspace serves both kinds of call with one layout.
+    p.capseg_alloc = p.capseg;
+    if (p.screen && mode != DAGL_MODE_ADAPTIVE) {
+        while (p.capseg_alloc < 4 * p.capseg && p.capseg_alloc < 256 &&
+               (size_t)B * g.L * p.s_splits * 2 * (2 * (size_t)p.capseg_alloc) * sizeof(int2) <= ((size_t)1 << 30))
+            p.capseg_alloc *= 2;
+        if (mode_flags & DAGL_FLAG_TIGHT_TOPK) { p.capseg = p.capseg_alloc; p.s_sample = 1; }
+    }
 
     const size_t BL = (size_t)B * g.L;
     size_t off = 0;
@@ -245,7 +257,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
         p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
-        p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg * sizeof(int2));     // candidate records (count in slot 0)
+        p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg_alloc * sizeof(int2));     // candidate records (count in slot 0)
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
@@ -936,12 +948,15 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
     DAGL_REQUIRE(ws_bytes >= p.o_end && ((uintptr_t)workspace % 256) == 0, "dagl_ce_range_check: not the workspace of such a call");
     *violated = 0;
     if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range (and always waits)
-    int64_t h[2] = {0, 0};
+    int64_t h4[4] = {0, 0, 0, 0};                                          // stats[2..5]: flagged queries of the last call, -, range word, done
     int64_t* st = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + p.o_stats);
-    if ((rc = read_back((hipStream_t)stream, st + 4, 2, h))) return rc;
+    if ((rc = read_back((hipStream_t)stream, st + 2, 4, h4))) return rc;
+    const int64_t* h = h4 + 2;
     // sticky: the word keeps the tag of the last call that left the range until it is read here (calls that reuse a
     // prepared workspace do not clear it), so a poll every n-th call sees a violation of ANY call since the last poll
     *violated = ((int32_t)h[0] != 0) ? 1 : 0;
+    // bit 2 (not sticky: the count is cleared by every call): the last call's redo pass of the top-k modes had work
+    if ((mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen && h4[0] > 0) *violated |= 4;
     if (*violated) DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream));
     if ((mode & 0xff) == DAGL_MODE_ADAPTIVE) {           // bit 1: a DAGL_FLAG_NO_WAIT call was not served in-stream (likewise sticky)
         int64_t v[1] = {0};

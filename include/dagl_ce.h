@@ -73,6 +73,15 @@ extern "C" {
  * beyond required_bytes / path.  Callers use it once a workspace's calls have been served in-stream before (dagl_amd.CE).   */
 #define DAGL_FLAG_NO_WAIT        0x800
 
+/* OR-ed into `mode` (top-k modes behind the bf16 screen): take the candidate threshold from EVERY key tile instead of every 8th
+ * and give a query's candidate segments four times the slots.  The sampled threshold is as good as the true k-th best on maps
+ * whose scores are spread evenly (the synthetic benchmark features); on natural-image features the k-th best of an eighth of the
+ * keys lies 4-25 % below the true one, hundreds to thousands of keys pass it, the slots overflow and most query groups land on
+ * the fp32 redo pass (2.6 ms instead of 0.27 at 256^2, tools/time_real_image.py).  Costs one more full pass of the screen's
+ * matrix work (+50 us at 256^2); the result is the same either way.  dagl_ce_range_check reports (bit 2) whether the last call's
+ * redo pass had work, which is how a caller decides (dagl_amd.CE.topk_threshold = "auto").                                    */
+#define DAGL_FLAG_TIGHT_TOPK     0x1000
+
 #define DAGL_MAX_TOPK            64   /* largest k of the top-k modes (the fixed-k variant defaults to num_edge = 50,
                                          GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
                                          top_k = min(k, N) (:243), the lists are then min(k, N) wide               */
@@ -116,13 +125,14 @@ typedef struct dagl_ce_info {
  *   - the training entry points (dagl_project_patches16, dagl_ce_core_dense_forward) NaN-fill their outputs likewise; the
  *     dense forward re-runs itself in its fp32 form when it reads statistics back (info != NULL, range_fallback = 1).   */
 int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
-                        int* violated /* bit 0: range, bit 1: an unserved DAGL_FLAG_NO_WAIT call */);
+                        int* violated /* bit 0: range, bit 1: an unserved DAGL_FLAG_NO_WAIT call, bit 2 (top-k modes, not sticky):
+                                         the LAST call's redo pass had flagged query groups (see DAGL_FLAG_TIGHT_TOPK) */);
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
  * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 301
+#define DAGL_ABI_VERSION 302
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */

@@ -243,3 +243,58 @@ def test_dpp_wave_primitives_agree_with_a_serial_evaluation():
     with torch.cuda.device(dev):
         _lib.check(lib.dagl_selftest_wave_ops(ops._stream(), bad.data_ptr()), "dagl_selftest_wave_ops")
     assert int(bad.item()) == 0
+
+
+
+@pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive_topk", 12)])
+def test_tight_topk_threshold_same_result(mode, k):
+    """DAGL_FLAG_TIGHT_TOPK (threshold from every key tile, four times the candidate slots) changes which keys reach the exact
+    rescoring, not the result: same neighbours and output as the sampled threshold and as the fp32 scan."""
+    import torch
+    from dagl_amd import ops
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params, make_features
+    dev = torch.device("cuda:0")
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(61, variant="sparse", sparse_gain=2.6).items()}
+    ce = CE(in_channels=64); ce.load_state_dict(params, strict=True); ce = ce.to(dev).eval()
+    ce.select_mode, ce.select_k = mode, k
+    x = torch.from_numpy(make_features(61, 2, 64, 96, 80)).to(dev)
+    outs = {}
+    with torch.no_grad():
+        for thr in ("sparse", "full"):
+            ce.topk_threshold = thr
+            outs[thr] = ce(x).clone()
+        ce.scan = "exact"
+        outs["exact"] = ce(x).clone()
+    assert torch.equal(outs["sparse"], outs["full"])
+    assert normwise(outs["full"].cpu().numpy(), outs["exact"].cpu().numpy()) <= 5e-5
+
+
+def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
+    """A near-constant map sends the sampled-threshold call to the fp32 redo pass; the module (topk_threshold = "auto") sees that in
+    the workspace's verdict after its first call and takes the threshold from every key tile from then on -- same output."""
+    import torch
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params
+    dev = torch.device("cuda:0")
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
+    ce = CE(in_channels=64); ce.load_state_dict(params, strict=True); ce = ce.to(dev).eval()
+    ce.select_mode, ce.select_k = "topk", 8
+    g = torch.Generator().manual_seed(3)
+    x = (0.25 + 1e-2 * torch.randn(1, 64, 64, 64, generator=g)).to(dev)
+    with torch.no_grad():
+        assert ce.topk_threshold == "auto" and not ce._topk_tight
+        y0 = ce(x).clone()
+        assert ce._topk_tight                          # (first call polled: its redo pass had work)
+        y1 = ce(x).clone()
+        ce.scan = "exact"
+        y2 = ce(x)
+    assert torch.equal(y0, y1) or normwise(y0.cpu().numpy(), y1.cpu().numpy()) <= 1e-6
+    assert normwise(y1.cpu().numpy(), y2.cpu().numpy()) <= 5e-5
+    # a map that needs no redo leaves a fresh module on the sampled threshold
+    from dagl_amd.synth import make_features
+    ce2 = CE(in_channels=64); ce2.load_state_dict(params, strict=True); ce2 = ce2.to(dev).eval()
+    ce2.select_mode, ce2.select_k = "topk", 8
+    with torch.no_grad():
+        ce2(torch.from_numpy(make_features(5, 1, 64, 64, 64)).to(dev))
+    assert not ce2._topk_tight
