@@ -92,7 +92,8 @@ class CES(nn.Module):
                 # wrong numbers); the heads move to scan = "exact" (which takes them off the fused path) and this call is redone
                 self._fused_calls[s] += 1
                 self._stage_calls[s] += 1
-                if self._fused_calls[s] >= 64 or (self._stage_calls[s] == 1 and heads[0].topk_threshold == "auto"):
+                if (self._fused_calls[s] >= 64 or (self._stage_calls[s] == 1 and heads[0].topk_threshold == "auto")) \
+                        and not torch.cuda.is_current_stream_capturing():
                     self._fused_calls[s] = 0
                     verdict = ops.ce_range_check((4 * x.shape[0],) + tuple(x.shape[1:]), mode, k_eff, ws, x.device)
                     if (verdict & 4) and heads[0].topk_threshold == "auto":
