@@ -157,9 +157,9 @@ class CE(nn.Module):
         # the sticky word is polled every 16th call, which sends the module back to waiting.
         self.adaptive_sync = "always"
         # top-k modes: where the candidate threshold comes from.  "sparse" = every 8th key tile (enough on maps whose scores are
-        # spread evenly, e.g. the synthetic benchmark features); "full" = every key tile + four times the candidate slots
-        # (DAGL_FLAG_TIGHT_TOPK: +50 us at 256^2) -- on natural-image features the sampled threshold lets hundreds to thousands
-        # of keys through, the slots overflow and the call lands on the fp32 redo pass (2.6 ms instead of 0.27);
+        # spread evenly, e.g. the synthetic benchmark features); "full" = every second key tile + eight times the candidate slots
+        # (DAGL_FLAG_TIGHT_TOPK: +25 us at 256^2) -- on natural-image features the sampled threshold lets hundreds to thousands
+        # of keys through, the slots overflow and the call lands on the fp32 redo pass (2.6 ms instead of 0.25);
         # "auto" (default) = start sparse, look at the workspace's verdict after the first call and every 64th (one
         # synchronisation, together with the range word) and move to "full" for this input shape once a call needed the redo pass.
         self.topk_threshold = "auto"

@@ -198,14 +198,19 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
 #ifdef DAGL_ABLATION
     { static const int cs = [] { const char* e = getenv("DAGL_SCREEN_CAPSEG"); return e ? atoi(e) : 0; }(); if (cs >= 4) p.capseg = cs; }
 #endif
-    // DAGL_FLAG_TIGHT_TOPK: the threshold from every key tile, four times the slots per segment (as far as 1 GiB of records goes).
+    // DAGL_FLAG_TIGHT_TOPK: the threshold from every second key tile and eight times the slots per segment (as far as 1 GiB of
+    // records goes; with fewer slots: from every tile) -- on the Set12 feature maps every 2nd tile + 128 slots serves six of
+    // seven images at 0.25 ms, every tile + 64 slots the same six at 0.27, every 4th tile two (profiles/r03_real_features_topk.log).
     // The records are ALWAYS laid out for the larger count, so that a workspace serves both kinds of call with one layout.
     p.capseg_alloc = p.capseg;
     if (p.screen && mode != DAGL_MODE_ADAPTIVE) {
-        while (p.capseg_alloc < 4 * p.capseg && p.capseg_alloc < 256 &&
+        while (p.capseg_alloc < 8 * p.capseg && p.capseg_alloc < 256 &&
                (size_t)B * g.L * p.s_splits * 2 * (2 * (size_t)p.capseg_alloc) * sizeof(int2) <= ((size_t)1 << 30))
             p.capseg_alloc *= 2;
-        if (mode_flags & DAGL_FLAG_TIGHT_TOPK) { p.capseg = p.capseg_alloc; p.s_sample = 1; }
+        if (mode_flags & DAGL_FLAG_TIGHT_TOPK) {
+            p.s_sample = (p.capseg_alloc >= 8 * p.capseg && p.s_sample >= 2) ? 2 : 1;
+            p.capseg = p.capseg_alloc;
+        }
     }
 
     const size_t BL = (size_t)B * g.L;

@@ -73,12 +73,12 @@ extern "C" {
  * beyond required_bytes / path.  Callers use it once a workspace's calls have been served in-stream before (dagl_amd.CE).   */
 #define DAGL_FLAG_NO_WAIT        0x800
 
-/* OR-ed into `mode` (top-k modes behind the bf16 screen): take the candidate threshold from EVERY key tile instead of every 8th
- * and give a query's candidate segments four times the slots.  The sampled threshold is as good as the true k-th best on maps
+/* OR-ed into `mode` (top-k modes behind the bf16 screen): take the candidate threshold from every SECOND key tile instead of every
+ * 8th and give a query's candidate segments eight times the slots (every tile, where a gigabyte of records does not hold that many).  The sampled threshold is as good as the true k-th best on maps
  * whose scores are spread evenly (the synthetic benchmark features); on natural-image features the k-th best of an eighth of the
  * keys lies 4-25 % below the true one, hundreds to thousands of keys pass it, the slots overflow and most query groups land on
- * the fp32 redo pass (2.6 ms instead of 0.27 at 256^2, tools/time_real_image.py).  Costs one more full pass of the screen's
- * matrix work (+50 us at 256^2); the result is the same either way.  dagl_ce_range_check reports (bit 2) whether the last call's
+ * the fp32 redo pass (2.6 ms instead of 0.25 at 256^2, tools/time_real_image.py).  Costs half a pass more of the screen's
+ * matrix work (+25 us at 256^2); the result is the same either way.  dagl_ce_range_check reports (bit 2) whether the last call's
  * redo pass had work, which is how a caller decides (dagl_amd.CE.topk_threshold = "auto").                                    */
 #define DAGL_FLAG_TIGHT_TOPK     0x1000
 
