@@ -257,7 +257,7 @@ def real_features_extra(dev):
     """One head, top-k k=8, on REAL features: Set12 image 01 (sigma 50, the reference's test protocol) through the trained
     checkpoint's head conv and first eight ResBlocks, whole 256x256 map.  Natural-image scores are not spread like the synthetic
     map's: the threshold sampled from every 8th key tile lets hundreds to thousands of keys through and the call lands on the fp32
-    redo pass; CE.topk_threshold = "auto" notices after the first call and takes the threshold from every key tile."""
+    redo pass; CE.topk_threshold = "auto" notices after the first call and takes the threshold from every second key tile."""
     import numpy as np
     from dagl_amd.net import RR, set12_protocol_noise
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")

@@ -190,7 +190,7 @@ class CE(nn.Module):
         if bad & 1:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
         if (bad & 4) and self.topk_threshold == "auto":
-            self._topk_tight = True                # the sampled threshold let too many keys through: every key tile from now on
+            self._topk_tight = True                # the sampled threshold let too many keys through: every second key tile from now on
         return not (bad & 3)
 
     def _note_range_violation(self, what):

@@ -333,8 +333,8 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     dense formulation (adaptive mode; same result, see DAGL_FLAG_DENSE_HINT); with ``want_info=False`` that path does
     not read its edge statistics back (no host synchronisation) and info is None.  ``no_wait`` (adaptive mode behind the
     screen, DAGL_FLAG_NO_WAIT): the verdict stays on the device, an unserved call is NaN-filled and ``ce_range_check``
-    reports it; info is None.  ``tight_topk`` (top-k modes, DAGL_FLAG_TIGHT_TOPK): candidate threshold from every key tile and
-    four times the candidate slots -- for maps whose sampled threshold lets too many keys through (natural images); same result."""
+    reports it; info is None.  ``tight_topk`` (top-k modes, DAGL_FLAG_TIGHT_TOPK): candidate threshold from every second key tile and
+    eight times the candidate slots -- for maps whose sampled threshold lets too many keys through (natural images); same result."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")

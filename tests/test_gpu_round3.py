@@ -248,7 +248,7 @@ def test_dpp_wave_primitives_agree_with_a_serial_evaluation():
 
 @pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive_topk", 12)])
 def test_tight_topk_threshold_same_result(mode, k):
-    """DAGL_FLAG_TIGHT_TOPK (threshold from every key tile, four times the candidate slots) changes which keys reach the exact
+    """DAGL_FLAG_TIGHT_TOPK (threshold from every second key tile, eight times the candidate slots) changes which keys reach the exact
     rescoring, not the result: same neighbours and output as the sampled threshold and as the fp32 scan."""
     import torch
     from dagl_amd import ops
@@ -272,7 +272,7 @@ def test_tight_topk_threshold_same_result(mode, k):
 
 def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
     """A near-constant map sends the sampled-threshold call to the fp32 redo pass; the module (topk_threshold = "auto") sees that in
-    the workspace's verdict after its first call and takes the threshold from every key tile from then on -- same output."""
+    the workspace's verdict after its first call and takes the threshold from every second key tile from then on -- same output."""
     import torch
     from dagl_amd.ce import CE
     from dagl_amd.synth import make_ce_params

@@ -3,7 +3,7 @@
 and first eight ResBlocks, whole 256x256 map, top-k k=8 -- next to the benchmark's synthetic N(0,1) features: stage times of
 both.  Natural-image scores are not spread like the synthetic map's: the threshold sampled from every 8th key tile lets hundreds to
 thousands of keys through and the call lands on the fp32 redo pass; CE.topk_threshold = "auto" notices after the first call and
-takes the threshold from every key tile (DAGL_FLAG_TIGHT_TOPK)."""
+takes the threshold from every second key tile (DAGL_FLAG_TIGHT_TOPK)."""
 import os
 import sys
 import numpy as np
