@@ -98,6 +98,8 @@ __device__ __forceinline__ void lds_flag_add(unsigned byte_addr, unsigned val) {
 // __shfl_xor / __shfl_up compile to ds_bpermute_b32: every step is a round trip through the LDS crossbar (~100+ cycles of
 // dependent latency); a 64-lane reduction is six of them, a refine wave did ~110 per query.  The same data movement as DPP
 // modifiers of the ALU instruction itself (quad_perm, row_ror, row_bcast -- gfx9 encodings) costs a few cycles per step.
+// ALL 64 lanes of the wave must be active at the call (wave-uniform control flow around it): a disabled source lane hands its
+// neighbour the neutral value, not its own.  dagl_selftest_wave_ops checks the lot against a serial evaluation.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_keep_f(float v) {                 // lanes without a source (or in a masked row) keep their own value
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
