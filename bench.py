@@ -270,7 +270,7 @@ def real_features_extra(dev):
     net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
     net = net.to(dev)
     name = sorted(n for n in imgs.files if imgs[n].shape[-1] == 256 and imgs[n].shape[-2] == 256)[0]
-    clean = torch.from_numpy(imgs[name].astype(np.float32))
+    clean = torch.from_numpy(imgs[name].astype(np.float32) / 255.0)      # uint8 images; the network works on [0, 1] (rgb_range 1)
     clean = clean[None, None] if clean.ndim == 2 else clean
     res = {"what": f"one head, top-k k=8, on the features of Set12 {name} (sigma 50) after the trained RR's head conv + 8 ResBlocks, "
                    "whole 256x256 map", "L": 4096, "N": 65536}

@@ -473,6 +473,7 @@ struct DenseArgs {
     const float* mt; const float* bs;                          // [B,L] mean*thr, bias
     const float* smax;                                         // [B,L] row maximum of the bf16-screened scores
     const float* b2p;                                          // padded NHWC value map
+    const uint16_t *v_hi, *v_lo;                               // the same, split fp16 (16 v = hi + lo), [B,Hp,Wp,16]
     int splits, tiles_per_split, n_tiles, tiles_per_row;       // 32-key tiles (row aligned), key ranges per 64-query group
     float* part_acc; float* part_m; double* part_z; int32_t* part_deg;   // per (split, query) partial results
     int variant;                                               // debug ablations (DAGL_DENSE_VARIANT): 1 no A V, 2 no S, 4 no staging

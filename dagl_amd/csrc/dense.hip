@@ -1,31 +1,37 @@
 // Dense neighbourhoods of the adaptive mask (DN_Gray/model/dagl.py:250-264 when most keys pass, e.g. with
-// default-initialised thr/bias heads ~95 % of them): per-query neighbour lists stop making sense, so this path is the
-// reference's dense formulation, streamed -- S = Wq X^T, mask, softmax over ALL keys, A V -- in one pass over the keys,
-// nothing of size L x N ever stored.
+// default-initialised thr/bias heads ~95 % of them; 0.88-1.0 with every trained weight set this repository has seen): per-query
+// neighbour lists stop making sense, so this path is the reference's dense formulation, streamed -- S = Wq X^T, mask, softmax
+// over ALL keys, A V -- in one pass over the keys, nothing of size L x N ever stored.
 //
-//   block = 64 queries = 2 query tiles x 4 waves; a wave = 32 queries x a share of the 784 output columns (6 / 6 / 7 / 6 column
-//   tiles of 32 = two patch taps x 16 channels; the first two waves of a query tile also form the scores).  Eight waves: two
-//   per SIMD, so that one wave's operand assembly and softmax arithmetic run under the other's matrix instructions (with four
-//   waves -- 13 / 12 tiles each, 208 accumulator registers -- every SIMD had ONE wave and nothing overlapped: 3.96 ms at 256^2)
-//   per 32-key tile (keys = an 8 x 4 pixel block of the map):
-//     S      v_mfma_f32_32x32x16_f16 on split features (64 x = hi + lo, made once per call by feat_split_kernel; three
-//            products per 16 features as in the projection), keys x queries, the 13 K-blocks split between the first two waves
-//            of a query tile and handed to all four through LDS.  The key rows enter the MFMA in a permuted order so that a lane ends
-//            up with scores of 16 keys of ONE query that are two runs of 8 CONSECUTIVE keys -- exactly the K-layout of
-//            the next MFMA's operand;
-//     l, p   the reference's fp32 expression order for m and l = (S m) 10; masked keys keep l = 0 and count in the
-//            denominator (no renormalisation), keys outside the image row count nowhere; p = e^(l - M') with M' an UPPER
-//            bound of the row maximum known before the pass (from the bf16 screen's row maxima, dense_rowmax_kernel): the
-//            softmax is shift invariant, M' is within ~1 % of the true maximum, so nothing is ever rescaled and the
-//            accumulators live in the matrix cores' registers untouched;
-//     A V    v_mfma_f32_32x32x16_f16 with split operands (2^14 p = hi + lo, 16 v = hi + lo, three products, one fp32
-//            accumulator: the projection's recipe): out^T[col][q] += V[key][col] p[q][key].  B = the lane's own weights,
-//            straight from its registers.  A needs 8 consecutive KEYS of one column, i.e. 8 consecutive pixels of one
-//            channel: the value-map region (10 rows x 14 pixels x 16 channels) is staged PLANAR in LDS as fp16 hi / lo, and a
-//            patch tap's kw shift becomes a 2-byte-granular offset: five dwords are read and funnel-shifted (v_alignbyte).
+// Round 4 shape (round 3: three barrier-separated phases per key tile, S exchanged through the LDS, value planes re-laid out by
+// the VALU, 2.07 ms per head at 256^2):
+//   block = 64 queries x 8 waves (two per SIMD), key tiles of 32 keys = an 8 x 4 pixel block, ONE barrier per tile.
+//   per tile t the waves run three mutually independent pieces of work:
+//     S(t+1)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo, feat_split_kernel; three products): wave (qg, kg) forms
+//             the COMPLETE scores of 16 queries x 16 keys (21 multiplies, the query fragments live in its registers), so nothing
+//             about S is exchanged between waves.  A lane ends up with 4 consecutive keys of one query;
+//     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' an UPPER bound of the row maximum known
+//             before the pass (from the bf16 screen's row maxima; the softmax is shift invariant, nothing is ever rescaled),
+//             split 2^14 p = hi + lo and handed to the other waves through the LDS in the K-layout of the next MFMA (the only
+//             exchange of the tile);
+//     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every wave a share of the 25
+//             column tiles for BOTH query tiles.  The value operand: 8 consecutive keys of one column = 8 consecutive pixels of
+//             one channel.  The tile's value-map region (10 rows x 14 pixels) is staged as it lies in memory -- NHWC fp16 hi / lo,
+//             32 B per pixel, by LDS-DMA from maps split once per call -- and ds_read_b64_tr_b16 transposes [4 pixels][16
+//             channels] blocks on the way into the registers: a patch tap's kw shift is a whole-pixel (32-byte) address offset,
+//             no funnel shifts, two 8-byte reads per 16-byte fragment where round 3 took five dwords + four v_alignbyte.
+//   Exactly-zero weights: logits reach hundreds, and 2^14 p rounds to hi = lo = 0 below l < M' - 27; a (32 queries x 16 keys)
+//   granule whose weights are ALL zero contributes exactly nothing to A V, so its multiplies are skipped (a wave-uniform test of
+//   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init 73-82 % of the granules are zero
+//   (profiles/r04_dense_zero_granules.log); with the trained checkpoint's features (logits of 5-70) none are -- that regime runs
+//   every multiply.
+//   Staging: key features hi | lo (2 x 14 KiB) two tiles ahead, value region (2 x 6 KiB) one tile ahead, 40 LDS-DMA pieces per
+//   tile, 4-6 per wave issued under ONE M0 set-up per buffer (the immediate offset advances the LDS and the global address, the
+//   per-lane global offset compensates); key rows at a 28-slot pitch with the low slot bits XORed by a function of the row so that
+//   the S fragments' ds_read_b128 are conflict-free for the 16x16x32 operand pattern.
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
-// Matrix time per 32 x 32 (key, query) tile: 39 + 150 fp16 MFMAs (32 clk) instead of 500 fp32 ones (64 clk).
+// Matrix time per (64 query, 32 key) tile: 8 x 21 multiplies of 16 cycles + 300 of 32 cycles.
 #include <stdlib.h>
 
 #include "dagl_common.h"
@@ -33,22 +39,26 @@
 namespace dagl {
 
 typedef _Float16 dnh8 __attribute__((ext_vector_type(8)));
-typedef unsigned dnu4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dnh4 __attribute__((ext_vector_type(4)));
+typedef short dns4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short dns8 __attribute__((ext_vector_type(8)));
 
-constexpr int DN_XPART = 14 * 512;                    // halfs of one part (hi or lo) of a staged key-feature tile: 32 rows x 216, 14 KiB pieces
-constexpr int DN_XT = 2 * DN_XPART;                   // halfs per tile buffer: hi | lo
-constexpr int DN_KB = 13;                             // K blocks of 16 features (208 >= 196)
+constexpr int DN_KS = 7;                              // k-steps of 32 features (224 >= 196; a feature row holds 216 halfs)
+constexpr int DN_KPITCH = 4 * DN_KS;                  // 16-byte slots per staged key row
+constexpr int DN_KPART_B = 32 * DN_KPITCH * 16;       // bytes of one part (hi or lo) of a staged key tile: 14 pieces of 1 KiB
+constexpr int DN_KTILE_B = 2 * DN_KPART_B;            // hi | lo
 constexpr float DN_FS = 64.0f;                        // pre-scaling of the split features: 64 x = hi + lo
 constexpr int DN_TW = 8, DN_TH = 4;                   // a key tile = 8 x 4 pixels (32 keys): narrow maps waste little of it
 constexpr int DN_RH = DN_TH + KS - 1, DN_RW = DN_TW + KS - 1;   // value-map region of a tile: 10 rows x 14 pixels
-constexpr int DN_XW = 16;                             // staged pixels per plane row (14 used; dword reads run to 15)
-constexpr int DN_CSTR = DN_RH * DN_XW + 2;            // halfs per channel plane: 10 rows x 16 + 2 (81 dwords: odd, the 16 channels
-                                                      // of a column tile hit different banks)
-constexpr int DN_PLANE_H = CH * DN_CSTR;              // halfs per part (hi or lo): [channel][kernel row][pixel]
+constexpr int DN_VPX = 18;                            // staged pixels per region row: 576-byte pitch = 64 B mod 256, so that the two taps
+                                                      // of a column tile that sit on different rows (kw = 6 | 0) use disjoint banks
+constexpr int DN_VPART_B = 6 * 1024;                  // one part of a staged region: 10 x 18 x 32 B = 5760 in 6 pieces
+constexpr int DN_VTILE_B = 2 * DN_VPART_B;
+constexpr int DN_PQ_ENTRY = 80;                       // a lane's weights of a tile: hi[16] | lo[16] halfs + 16 B (odd slot count)
+constexpr int DN_PQ_B = 2 * 64 * DN_PQ_ENTRY;         // both query tiles
 constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
 // A V: every wave takes a share of the 25 column tiles for BOTH query tiles of the block (3 tiles, the last wave 4): a value
-// fragment assembled from the LDS planes (five dword reads + four funnel shifts per 16 bytes -- what this kernel's LDS time
-// consists of) then feeds six multiplies instead of three (round 2: a wave = one query tile x 6-7 column tiles, 2.08 ms)
+// fragment then feeds six multiplies instead of three
 constexpr int DN_CTMAX = 4;
 __host__ __device__ constexpr int dn_ct_start(int w8) { return 3 * w8; }
 __host__ __device__ constexpr int dn_ct_count(int w8) { return w8 == 7 ? 4 : 3; }
@@ -60,48 +70,38 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
     return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;
 }
 
-// column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes i >= 16 ("second") take the odd tap (tap 49 does not exist:
-// those lanes of tile 24 recompute tap 48 and their columns are never stored).
-// A operand of kblock kb: halfs e = 0..7 = V[key 16 kb + 8 h + e][tap][c]; key = pixel (row 2 kb + h, column e) of the tile,
-// so the value is plane[c][2 kb + h + kh][kw + e]
-// One code path for all four column shares (ct0, cnt are wave-uniform): a four-way dispatch on the share made the register
-// allocator keep all four instantiations' fragments alive (128 spills at 256 registers).
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], const unsigned char* planes, int c, int h, bool second,
-                                      const dnh8 (&p_hi)[2][2], const dnh8 (&p_lo)[2][2], int ct0, int cnt, int variant = 0) {
-#pragma unroll
-    for (int t = 0; t < DN_CTMAX; ++t) {
-        if (t >= cnt) continue;                                              // wave-uniform
-        const int ct = ct0 + t;
-        const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
-        const int kh = second ? tapb / KS : tapa / KS, kw = second ? tapb % KS : tapa % KS;
-        // byte offset of (c, row h + kh, pixel kw) inside a part; dword-aligned base + byte shift 0 / 2
-        const int boff = (c * DN_CSTR + (h + kh) * DN_XW + kw) * 2;
-        const unsigned char* base = planes + (boff & ~3);
-        const unsigned shift = (unsigned)(boff & 3);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            dnh8 v_hi, v_lo;
-            if (variant & 8) { v_hi = p_hi[0][kb]; v_lo = p_lo[0][kb]; }       // (ablation: no value-fragment assembly)
-            else
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const unsigned* dp = reinterpret_cast<const unsigned*>(base + part * (DN_PLANE_H * 2) + kb * (2 * DN_XW * 2));
-                const unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4];
-                dnu4 w;
-                w[0] = __builtin_amdgcn_alignbyte(d1, d0, shift);
-                w[1] = __builtin_amdgcn_alignbyte(d2, d1, shift);
-                w[2] = __builtin_amdgcn_alignbyte(d3, d2, shift);
-                w[3] = __builtin_amdgcn_alignbyte(d4, d3, shift);
-                if (part == 0) v_hi = __builtin_bit_cast(dnh8, w); else v_lo = __builtin_bit_cast(dnh8, w);
-            }
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[qq][kb], acc[qq][t], 0, 0, 0);
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[qq][kb], acc[qq][t], 0, 0, 0);
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) acc[qq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[qq][kb], acc[qq][t], 0, 0, 0);
-        }
-    }
+__device__ __forceinline__ dns4 dn_tr16(unsigned lds_byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dns4*)(uintptr_t)lds_byte_addr);
+}
+typedef unsigned dnu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dnu4 dn_lds128(unsigned lds_byte_addr) {
+    return *(const __attribute__((address_space(3))) dnu4*)(uintptr_t)lds_byte_addr;
+}
+
+// N LDS-DMA pieces (1 KiB each, consecutive in the LDS from lds_byte_addr) under one M0 set-up: piece j takes the instruction's
+// immediate offset 1024 j, which advances the LDS AND the global address -- the caller's per-lane byte offsets are relative to
+// src_uniform - 4096 and carry + 4096 - 1024 j (unsigned 32-bit offsets: the bias keeps them from wrapping)
+template <int N>
+__device__ __forceinline__ void dn_glds(const void* src_biased, unsigned lds_byte_addr, unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
+    unsigned keep;
+    if (N == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, %1\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(src_biased), "s"(lds_byte_addr), "v"(o0) : "memory");
+    else if (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, %1\n\tglobal_load_lds_dwordx4 %4, %1 offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(src_biased), "s"(lds_byte_addr), "v"(o0), "v"(o1) : "memory");
+    else if (N == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, %1\n\tglobal_load_lds_dwordx4 %4, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %5, %1 offset:2048\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(src_biased), "s"(lds_byte_addr), "v"(o0), "v"(o1), "v"(o2) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, %1\n\tglobal_load_lds_dwordx4 %4, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %5, %1 offset:2048\n\tglobal_load_lds_dwordx4 %6, %1 offset:3072\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(src_biased), "s"(lds_byte_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
 }
 
 __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CTMAX], float* po, int h, int ct0, int cnt) {
@@ -119,49 +119,76 @@ __device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CTMAX], float* p
     }
 }
 
+// A V of one k-block for this wave's column tiles: Q0 / Q1 = which query tiles have any non-zero weight (compile-time, so that the
+// usual case -- both -- is straight-line code whose fragment reads the compiler can run ahead of the multiplies)
+struct DnFrag { dns4 h0, h1, l0, l1; };
+// region pixel (row kh + 2 kb + h, column kw + 4 j + (lane & 15) / 4): keys 8 h + 4 j .. of a k-block, hi and lo
+__device__ __forceinline__ DnFrag dn_vfrag(unsigned va) {
+    DnFrag f;
+    f.h0 = dn_tr16(va); f.h1 = dn_tr16(va + 128); f.l0 = dn_tr16(va + DN_VPART_B); f.l1 = dn_tr16(va + DN_VPART_B + 128);
+    return f;
+}
+// A V of one k-block for this wave's column tiles; Q0 / Q1 (wave-uniform) = which query tiles have any non-zero weight.  ONE code
+// path with uniform branches around the multiplies: compile-time instantiations per (Q0, Q1) made the register allocator spill
+// 290 registers.
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX], int ctn,
+                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], bool Q0, bool Q1) {
+    // the fragment of column tile t + 1 is requested before tile t's multiplies
+    DnFrag f = dn_vfrag(va_kb + vt_off[0]);
+#pragma unroll
+    for (int t = 0; t < DN_CTMAX; ++t) {
+        if (t >= 3 && t >= ctn) continue;                                   // wave-uniform (every wave has at least 3 tiles)
+        DnFrag fn = f;
+        if (t + 1 < 3 || (t + 1 < DN_CTMAX && t + 1 < ctn)) fn = dn_vfrag(va_kb + vt_off[t + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
+        const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
+        const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
+        if (Q0) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[0], acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[0], acc[0][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[0], acc[0][t], 0, 0, 0);
+        }
+        if (Q1) {
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[1], acc[1][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[1], acc[1][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[1], acc[1][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f = fn;
+    }
+}
+
 constexpr int DN_THREADS = 512;
 __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sm[2][DN_XT];           // 56 KiB: key-feature tiles hi | lo (LDS-DMA)
-    __shared__ __attribute__((aligned(16))) unsigned short spl[2 * DN_PLANE_H + 64]; // 21 KiB: value planes hi | lo of ONE tile
-    __shared__ __attribute__((aligned(16))) unsigned short sq[2][64 * DSH];        // 54 KiB: the block's 64 query rows hi | lo
-    __shared__ float sx[2 * 2 * 16 * 64];                                          // 16 KiB: partial scores exchanged per tile
-    __shared__ __attribute__((aligned(16))) uint4 spq[2][64][5];                   // 10 KiB: a tile's weights as halfs (80 B per lane: odd slot count)
-    __shared__ double szz[2][4][32][2];                                            // 4 KiB: the waves' shares of a query's sums (end of the block)
-    __shared__ int sdg[2][4][32];
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * DN_KTILE_B];     // 56 KiB: key-feature tiles hi | lo, two stages
+    __shared__ __attribute__((aligned(1024))) unsigned char sv[2 * DN_VTILE_B];     // 24 KiB: value regions hi | lo, two stages
+    __shared__ __attribute__((aligned(16))) unsigned char spq[2 * DN_PQ_B];         // 20 KiB: the tiles' weights, two stages
+    __shared__ double szz[8][64][2];                                                // 8 KiB: the lanes' shares of a query's sums (end of the block)
+    __shared__ int sdg[8][64];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const Grid& g = a.g;
     const int n_qblocks = (g.L + 63) / 64;
     const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
-    const int qt = wave >> 2, part = wave & 3;
-    const int ct0 = dn_ct_start(wave), ctn = dn_ct_count(wave);                  // this wave's column tiles (wave-uniform), both query tiles
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
 
-    const int q = qb * 64 + qt * 32 + i;
-    const bool qvalid = q < g.L;
-    const int qc = qvalid ? q : g.L - 1;
-    const size_t qlin = (size_t)b * g.L + qc;
+    // ---- roles ------------------------------------------------------------------------------------------------------------------
+    // S / weights: wave = (query group qg of 16, key group kg of 16); lane = (query c, key quad gk): keys 16 kg + 4 gk + r
+    const int qg = wave & 3, kg = wave >> 2;
+    const int c16 = lane & 15, gk = lane >> 4;
+    // A V: lane = (column / query i, key half h) of the 32x32x16 multiply; wave = column tiles [ct0, ct0 + ctn) of both query tiles
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = dn_ct_start(wave), ctn = dn_ct_count(wave);
 
-    // the 64 query rows (split fp16, 432-byte rows: whole 16-byte pieces; rows past L are zero guard rows) -> LDS
-    for (int pt = 0; pt < 2; ++pt) {
-        const uint4* src = reinterpret_cast<const uint4*>((pt ? a.wq_lo : a.wq_hi) + ((size_t)b * a.rows_qh + (size_t)qb * 64) * DSH);
-        for (int e = tid; e < 64 * DSH / 8; e += DN_THREADS) reinterpret_cast<uint4*>(&sq[pt][0])[e] = src[e];
-    }
-    const unsigned short* qrow = &sq[0][(qt * 32 + i) * DSH + 8 * h];       // B operand of the score MFMAs: Wq[q][16 kb + 8 h ..]
+    const int qs = qb * 64 + 16 * qg + c16;                                        // the query of this lane's scores
+    const int qsc = qs < g.L ? qs : g.L - 1;
+    const size_t qlin = (size_t)b * g.L + qsc;
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
-
-    f32x16 acc[2][DN_CTMAX];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-        for (int t = 0; t < DN_CTMAX; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
     // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
     float m_run;
     {
@@ -170,181 +197,222 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         const float lub = dn_logit(sub, mtq, bsq, ps);
         m_run = fmaxf(lub, 0.f);                       // masked keys have l = 0
     }
-    double z_run = 0.0, zp_run = 0.0;                  // sum over all keys / over passing keys of e^(l - m_run)
+
+    // ---- staging plan (per lane, once) ---------------------------------------------------------------------------------------------
+    // keys: part = wave >> 2 (hi | lo), the part's 14 pieces over its four waves as 4 / 4 / 3 / 3; values: the part's 6 pieces as
+    // 1 / 1 / 2 / 2.  Position p of a piece: 16-byte slot p of the part's LDS image.
+    const int spart = wave >> 2, wl = wave & 3;
+    const int kp0 = wl < 2 ? 4 * wl : 8 + 3 * (wl - 2), kpn = wl < 2 ? 4 : 3;
+    const int vp0 = wl < 2 ? wl : 2 + 2 * (wl - 2), vpn = wl < 2 ? 1 : 2;
+    unsigned k_c[4];                                   // key piece j: bits 0-15 byte offset inside the pixel row's run of keys (+ bias),
+                                                       // bits 16-17 pixel row of the key inside the tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = (kp0 + (j < kpn ? j : 0)) * 64 + lane;
+        const int row = p / DN_KPITCH, phys = p - row * DN_KPITCH;
+        const int logical = (phys & ~3) | ((phys & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3));
+        k_c[j] = (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096 - 1024 * j) | ((unsigned)(row >> 3) << 16);
+    }
+    unsigned v_c[2];                                   // value piece j: bits 0-15 byte offset inside the pixel (+ bias), 16-19 region row, 20-23 pixel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = (vp0 + (j < vpn ? j : 0)) * 64 + lane;
+        int row = p / (2 * DN_VPX); const int c36 = p - row * (2 * DN_VPX);
+        if (row > DN_RH - 1) row = DN_RH - 1;                                    // (slack positions of the last piece: any valid address)
+        int px = c36 >> 1; if (px > DN_RW - 1) px = DN_RW - 1;
+        v_c[j] = (unsigned)(16 * (c36 & 1) + 4096 - 1024 * j) | ((unsigned)row << 16) | ((unsigned)px << 20);
+    }
+    const unsigned lds_sm = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
+    const unsigned lds_sv = __builtin_amdgcn_readfirstlane(lds_addr_of(sv));
+    const unsigned lds_pq = __builtin_amdgcn_readfirstlane(lds_addr_of(spq));
+    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>((spart ? a.x_lo : a.x_hi) + (size_t)b * a.rows_xh * DSH) - 4096;
+    const unsigned char* vsrc = reinterpret_cast<const unsigned char*>((spart ? a.v_lo : a.v_hi) + (size_t)b * g.Hp * g.Wp * CH) - 4096;
+    auto stage_keys = [&](int jy0, int jx0, int buf) {
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int jy = jy0 + (int)(k_c[j] >> 16); if (jy > g.H - 1) jy = g.H - 1;  // ragged bottom: a valid row, keys masked below
+            o[j] = (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
+        }
+        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
+        if (kpn == 4) dn_glds<4>(xsrc, dst, o[0], o[1], o[2], o[3]);
+        else dn_glds<3>(xsrc, dst, o[0], o[1], o[2], o[3]);
+    };
+    auto stage_values = [&](int jy0, int jx0, int buf) {
+        unsigned o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int y = jy0 + (int)((v_c[j] >> 16) & 15u); if (y > g.Hp - 1) y = g.Hp - 1;   // stay inside the padded map
+            int x = jx0 + (int)(v_c[j] >> 20); if (x > g.Wp - 1) x = g.Wp - 1;
+            o[j] = (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
+        }
+        const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
+        if (vpn == 2) dn_glds<2>(vsrc, dst, o[0], o[1], 0, 0);
+        else dn_glds<1>(vsrc, dst, o[0], 0, 0, 0);
+    };
+
+    // tile coordinates (pixels) of the tiles in flight: c0 = the tile being attended, c1 = the next, c2 = the one after
+    int y0 = (tile0 / a.tiles_per_row) * DN_TH, x0 = (tile0 % a.tiles_per_row) * DN_TW, y1, x1, y2, x2;
+    const int xwrap = a.tiles_per_row * DN_TW;
+    auto next_tile = [&](int y, int x, int& yn, int& xn) { xn = x + DN_TW; yn = y; if (xn >= xwrap) { xn = 0; yn = y + DN_TH; } };
+    next_tile(y0, x0, y1, x1);
+    next_tile(y1, x1, y2, x2);
+    if (tile0 < tile1) { stage_keys(y0, x0, 0); stage_values(y0, x0, 0); }
+    if (tile0 + 1 < tile1) stage_keys(y1, x1, 1);
+
+    // ---- the query fragments of S: lane (c16, gk) holds features 32 ks + 8 gk .. + 7 of query qs, hi and lo (rows past L are zero
+    // guard rows; halfs 216.. of a row do not exist: zero, and the staged key rows' slots 26 / 27 meet only these zeros) ----------
+    dnh8 qf_hi[DN_KS], qf_lo[DN_KS];
+    {
+        const uint4* rh = reinterpret_cast<const uint4*>(a.wq_hi + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
+        const uint4* rl = reinterpret_cast<const uint4*>(a.wq_lo + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
+#pragma unroll
+        for (int ks = 0; ks < DN_KS; ++ks) {
+            const bool in = 4 * ks + gk < DSH / 8;
+            const int slot = in ? 4 * ks + gk : DSH / 8 - 1;
+            uint4 vh = rh[slot], vl = rl[slot];
+            if (!in) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            qf_hi[ks] = __builtin_bit_cast(dnh8, vh);
+            qf_lo[ks] = __builtin_bit_cast(dnh8, vl);
+        }
+    }
+
+    f32x16 acc[2][DN_CTMAX];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int t = 0; t < DN_CTMAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
+    double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
     int deg = 0;
 
-    const float* vb = a.b2p + (size_t)b * g.Hp * g.Wp * CH;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sm[0][0]));
-    auto stage_x = [&](int tile, int buf) {            // key features hi | lo: per part 4 pixel rows x 8 keys x 432 B by LDS-DMA
-        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
-        for (int p = wave; p < 32; p += DN_THREADS / 64) {                   // (part, row dy, piece): 3456 B = 3 x 1 KiB + 384 B
-            const int xpart = p >> 4, dy = (p >> 2) & 3, pc = p & 3;
-            int jy = jy0 + dy; if (jy > g.H - 1) jy = g.H - 1;               // ragged bottom: a valid row, keys masked below
-            const unsigned short* xs = (xpart ? a.x_lo : a.x_hi) + ((size_t)b * a.rows_xh + (size_t)jy * g.W + jx0) * DSH;
-            if (pc < 3 || lane < 24)
-                glds16_asm(reinterpret_cast<const float*>(xs + pc * 512 + lane * 8),
-                           __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DN_XT + xpart * DN_XPART + dy * 8 * DSH) * 2 + pc * 1024)));
-        }
-    };
-    // value-map region of a tile: 10 rows x 14 pixels x 16 channels fp32 NHWC -> registers -> planar fp16 hi | lo in LDS.
-    // Work item = (region row, pixel PAIR, channel quad): two float4 loads, then per channel the two pixels' halfs go out
-    // as one 4-byte store.  The index arithmetic does not depend on the tile and is done once.
-    constexpr int DN_ITEMS = DN_RH * (DN_RW / 2) * 4;                        // 280
-    constexpr int DN_NIT = (DN_ITEMS + DN_THREADS - 1) / DN_THREADS;         // 1 per thread
-    float4 rv[DN_NIT][2];
-    int it_row[DN_NIT], it_px[DN_NIT], it_c4[DN_NIT], it_lds[DN_NIT];
+    // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row
+    const unsigned ka_off = (unsigned)((16 * kg + c16) * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
+    // where this lane's four weights go: entry (query tile, key half, query) of the A V lane that multiplies them
+    const unsigned pw_off = (unsigned)((((qg >> 1) * 64 + (gk >> 1) * 32 + 16 * (qg & 1) + c16) * DN_PQ_ENTRY) + kg * 16 + (gk & 1) * 8);
+    const unsigned pr_off = (unsigned)(lane * DN_PQ_ENTRY);
+    // A V operand A: lane t = lane & 15 of a 16-lane group supplies the 8 bytes (pixel t >> 2, channels 4 (t & 3) ..) of the group's
+    // [4 pixels][16 channels] block; the group = (tap parity, key half h)
+    const bool second = (lane & 16) != 0;
+    const unsigned va_lane = (unsigned)(((c16 >> 2) * 32) + (c16 & 3) * 8 + h * (DN_VPX * 32));
+    // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes 16-31 / 48-63 ("second") take the odd tap (tap 49 does not exist:
+    // those lanes of tile 24 recompute tap 48 and their columns are never stored)
+    unsigned vt_off[DN_CTMAX];
 #pragma unroll
-    for (int j = 0; j < DN_NIT; ++j) {
-        int idx = tid + DN_THREADS * j;
-        const bool on = idx < DN_ITEMS;
-        if (!on) idx = DN_ITEMS - 1;
-        const int row = idx / (DN_RW / 2 * 4), rem = idx - row * (DN_RW / 2 * 4);
-        const int pp = rem >> 2, c4 = rem & 3;
-        it_row[j] = row; it_px[j] = 2 * pp; it_c4[j] = 4 * c4;
-        it_lds[j] = on ? (4 * c4) * DN_CSTR + row * DN_XW + 2 * pp : -1;
+    for (int t = 0; t < DN_CTMAX; ++t) {
+        const int ct = ct0 + (t < ctn ? t : 0);
+        const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
+        const int tap = second ? tapb : tapa;
+        const int kh = tap / KS, kw = tap - kh * KS;
+        vt_off[t] = (unsigned)((kh * DN_VPX + kw) * 32) + va_lane;
     }
-    auto load_region = [&](int tile) {
-        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
-        const int limx = g.Wp - 1 - jx0, limy = g.Hp - 1 - jy0;              // stay inside the padded map
+
+    auto scores_weights = [&](int jy0, int jx0, int buf) {
+        f32x4 s_hh = {0.f, 0.f, 0.f, 0.f}, s_hl = {0.f, 0.f, 0.f, 0.f}, s_lh = {0.f, 0.f, 0.f, 0.f};
+        const unsigned kb_addr = lds_sm + (unsigned)(buf * DN_KTILE_B) + ka_off;
+        if (!(a.variant & 2)) {
 #pragma unroll
-        for (int j = 0; j < DN_NIT; ++j) {
-            const int r = it_row[j] > limy ? limy : it_row[j];
-            const int p0 = it_px[j] > limx ? limx : it_px[j], p1 = it_px[j] + 1 > limx ? limx : it_px[j] + 1;
-            const float* rb = vb + ((size_t)(jy0 + r) * g.Wp + jx0) * CH + it_c4[j];
-            rv[j][0] = *reinterpret_cast<const float4*>(rb + p0 * CH);
-            rv[j][1] = *reinterpret_cast<const float4*>(rb + p1 * CH);
-        }
-    };
-    auto store_region = [&]() {
-#pragma unroll
-        for (int j = 0; j < DN_NIT; ++j) {
-            if (it_lds[j] < 0) continue;
-            const float v0[4] = {rv[j][0].x, rv[j][0].y, rv[j][0].z, rv[j][0].w};
-            const float v1[4] = {rv[j][1].x, rv[j][1].y, rv[j][1].z, rv[j][1].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float a0 = v0[u] * DN_VS, a1 = v1[u] * DN_VS;
-                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-                const unsigned hw = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                const unsigned lw = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-                const int o = it_lds[j] + u * DN_CSTR;                       // even half index: 4-byte aligned
-                *reinterpret_cast<unsigned*>(&spl[o]) = hw;
-                *reinterpret_cast<unsigned*>(&spl[DN_PLANE_H + o]) = lw;
+            for (int ks = 0; ks < DN_KS; ++ks) {
+                const dnh8 k_hi = __builtin_bit_cast(dnh8, dn_lds128(kb_addr + 64 * ks));
+                const dnh8 k_lo = __builtin_bit_cast(dnh8, dn_lds128(kb_addr + DN_KPART_B + 64 * ks));
+                s_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], s_hl, 0, 0, 0);
+                s_hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], s_hh, 0, 0, 0);
+                s_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], s_lh, 0, 0, 0);
             }
         }
-    };
-
-    const bool second = i >= 16;
-    // key row fed to MFMA row rho: bits (a b c dd) -> (a c b dd), so that a lane's registers are two runs of 8 consecutive keys
-    const int prow = (i & 0x13) | ((i & 8) >> 1) | ((i & 4) << 1);
-
-    if (tile0 < tile1) { stage_x(tile0, 0); load_region(tile0); }
-    for (int e = tid; e < (2 * DN_PLANE_H + 64) / 2; e += DN_THREADS) reinterpret_cast<unsigned*>(spl)[e] = 0u;   // pad pixels stay zero
-    __syncthreads();
-    if (tile0 < tile1) store_region();
-    dma_wait_all();
-    __syncthreads();
-
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int cur = (tile - tile0) & 1;
-        if (tile + 1 < tile1) { stage_x(tile + 1, cur ^ 1); load_region(tile + 1); }
-        const int ty = tile / a.tiles_per_row, jy0 = ty * DN_TH, jx0 = (tile - ty * a.tiles_per_row) * DN_TW;
-
-        // ---- scores of 32 keys x this lane's query ----------------------------------------------------------------
-        // the first two waves of a query tile split the 13 K-blocks of the 196-term sum and publish their partial sums; all four
-        // waves add them in the same order (identical scores in every wave, no redundant matrix work)
-        f32x16 mine, cross;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mine[r] = 0.f; cross[r] = 0.f; }
-        const unsigned short* kp = &sm[cur][prow * DSH + 8 * h];
-        if (!(a.variant & 2) && part < 2) {
-#pragma unroll
-            for (int kb = 0; kb < DN_KB; ++kb) {
-                if ((kb < 7) != (part == 0)) continue;                       // wave-uniform: K blocks 0-6 / 7-12
-                const dnh8 k_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + 16 * kb));
-                const dnh8 k_lo = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(kp + DN_XPART + 16 * kb));
-                const dnh8 q_hi = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(qrow + 16 * kb));
-                const dnh8 q_lo = __builtin_bit_cast(dnh8, *reinterpret_cast<const uint4*>(qrow + 64 * DSH + 16 * kb));
-                cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_hi, q_lo, cross, 0, 0, 0);
-                mine = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_hi, q_hi, mine, 0, 0, 0);
-                cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_lo, q_hi, cross, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] += cross[r];
-        if (part < 2) {
-            float* ex = sx + ((qt * 2 + part) * 16) * 64 + lane;              // [query tile][K half][register][lane]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ex[r * 64] = mine[r];
-        }
-        __syncthreads();
-        const float* e0 = sx + ((qt * 2 + 0) * 16) * 64 + lane;
-        const float* e1 = sx + ((qt * 2 + 1) * 16) * 64 + lane;
-        // ---- logits, weights: register r holds key 16 (r >> 3) + 8 h + (r & 7) of the tile = pixel (2 (r >> 3) + h, r & 7).
-        // All four waves of a query tile need all 16 weights of a lane; each forms four of them (logit, exponential, fp16
-        // split: ~25 VALU operations per weight) and they are exchanged through LDS as packed halfs -----------------------
+        // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
         float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32, one fp64 add per tile
-        unsigned passmask = 0;
+        int dt = 0;
         _Float16 hq[4], lq[4];
+        const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = 4 * part + u;                                       // wave-uniform
-            const float sc = (e0[r * 64] + e1[r * 64]) * (1.0f / (DN_FS * DN_FS));
-            const bool valid = (jx0 + (r & 7) < g.W) && (jy0 + 2 * (r >> 3) + h < g.H);   // pixel (row 2 (r>>3) + h, column r & 7) of the tile
+        for (int r = 0; r < 4; ++r) {
+            const float sc = (s_hh[r] + (s_hl[r] + s_lh[r])) * (1.0f / (DN_FS * DN_FS));
+            const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
             bool pass;
             const float l = dn_logit(sc, mtq, bsq, pass);
-            const float p = (a.variant & 16) ? 0.5f : (valid ? __expf(fminf(l - m_run, 0.f)) : 0.f);      // (the bound holds; the clamp is a seat belt)
+            const float e = __expf(fminf(l - m_run, 0.f));                        // (the bound holds; the clamp is a seat belt)
+            const float p = valid ? e : 0.f;
             zt += p;
             pass = pass && valid;
             const float pp = pass ? p : 0.f;
             zpt += pp;
-            passmask |= (pass ? 1u : 0u) << u;
+            dt += pass ? 1 : 0;
             const float ps = pp * DN_PS;
-            hq[u] = (_Float16)ps;
-            lq[u] = (_Float16)(ps - (float)hq[u]);
+            hq[r] = (_Float16)ps;
+            lq[r] = (_Float16)(ps - (float)hq[r]);
         }
-        z_run += (double)zt; zp_run += (double)zpt; deg += __popc(passmask);
-        unsigned char* pq = reinterpret_cast<unsigned char*>(&spq[qt][lane][0]);   // 80 B per lane: hi[16] | lo[16] | pad
-        {
-            typedef _Float16 dnh4 __attribute__((ext_vector_type(4)));
-            const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
-            *reinterpret_cast<dnh4*>(pq + 8 * part) = hv;
-            *reinterpret_cast<dnh4*>(pq + 32 + 8 * part) = lv;
-        }
-        __syncthreads();
-        dnh8 p_hi[2][2], p_lo[2][2];                       // the weights of BOTH query tiles (lane = query i, key half h)
+        z_run += (double)zt; zp_run += (double)zpt; deg += dt;
+        const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
+        unsigned char* pq = spq + buf * DN_PQ_B + pw_off;
+        *reinterpret_cast<dnh4*>(pq) = hv;
+        *reinterpret_cast<dnh4*>(pq + 32) = lv;
+    };
+
+    auto attend = [&](int buf) {
+        if (a.variant & 1) return;
+        const unsigned vbase = lds_sv + (unsigned)(buf * DN_VTILE_B);
+        const unsigned pa = lds_pq + (unsigned)(buf * DN_PQ_B) + pr_off;
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const unsigned char* pv = reinterpret_cast<const unsigned char*>(&spq[qq][lane][0]);
-            p_hi[qq][0] = *reinterpret_cast<const dnh8*>(pv);      p_hi[qq][1] = *reinterpret_cast<const dnh8*>(pv + 16);
-            p_lo[qq][0] = *reinterpret_cast<const dnh8*>(pv + 32); p_lo[qq][1] = *reinterpret_cast<const dnh8*>(pv + 48);
+        for (int kb = 0; kb < 2; ++kb) {
+            // the weights of BOTH query tiles for this k-block (lane = query i, keys 16 kb + 8 h ..): hi | lo
+            dnh8 p_hi[2], p_lo[2];
+            bool nz[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const dnu4 wh = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 16 * kb)), wl = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 32 + 16 * kb));
+                p_hi[qq] = __builtin_bit_cast(dnh8, wh); p_lo[qq] = __builtin_bit_cast(dnh8, wl);
+                // a granule (32 queries x 16 keys) whose weights are all exactly zero adds exactly nothing: skipped.  (hi = 0 implies
+                // lo = 0: the split of a number below half the smallest denormal; -0 cannot occur, p >= 0.)
+                nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull;
+            }
+            const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
+            if (nz[0] || nz[1]) dn_pv(acc, va_kb, vt_off, ctn, p_hi, p_lo, nz[0], nz[1]);          // (wave-uniform)
         }
-        // ---- out^T[col][q] += V[key][col] * p[q][key] ------------------------------------------------------------------
-        const unsigned char* planes = reinterpret_cast<const unsigned char*>(spl);
-        if (!(a.variant & 1)) {
-            dn_pv(acc, planes, i & 15, h, second, p_hi, p_lo, ct0, ctn, a.variant);
+    };
+
+    dma_wait_all();
+    __syncthreads();
+    if (tile0 < tile1) scores_weights(y0, x0, 0);
+    __syncthreads();
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        if (!(a.variant & 4)) {
+            if (tile + 2 < tile1) stage_keys(y2, x2, cur);                   // (tile's own features were consumed one iteration ago)
+            if (tile + 1 < tile1) stage_values(y1, x1, cur ^ 1);
         }
+        if (tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
+        attend(cur);
+        y0 = y1; x0 = x1; y1 = y2; x1 = x2;
+        next_tile(y1, x1, y2, x2);
         dma_wait_all();
-        __syncthreads();                                   // everyone is done with this tile's planes and features
-        if (tile + 1 < tile1 && !(a.variant & 4)) store_region();   // published by the next tile's exchange barrier
+        __syncthreads();
     }
 
-    // ---- partial results of this key range ------------------------------------------------------------------------------
-    const size_t orow = ((size_t)split * a.B + b) * g.L + qc;
-    {
-        // every wave summed its quarter of the weights: halves h first, then the four waves of the query tile in wave order
-        const double z2 = z_run + __shfl_xor(z_run, 32), zp2 = zp_run + __shfl_xor(zp_run, 32);
-        const int d2 = deg + __shfl_xor(deg, 32);
-        if (h == 0) { szz[qt][part][i][0] = z2; szz[qt][part][i][1] = zp2; sdg[qt][part][i] = d2; }
-    }
+    // ---- partial results of this key range ------------------------------------------------------------------------------------------
+    szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg;
     __syncthreads();
-    if (qvalid) {
-        if (part == 0 && h == 0) {
-            a.part_m[orow] = m_run;
-            a.part_z[2 * orow] = (szz[qt][0][i][0] + szz[qt][1][i][0]) + (szz[qt][2][i][0] + szz[qt][3][i][0]);
-            a.part_z[2 * orow + 1] = (szz[qt][0][i][1] + szz[qt][1][i][1]) + (szz[qt][2][i][1] + szz[qt][3][i][1]);
-            a.part_deg[orow] = (sdg[qt][0][i] + sdg[qt][1][i]) + (sdg[qt][2][i] + sdg[qt][3][i]);
+    if (tid < 64) {
+        // query tid of the block: its scores lived in waves (qg, kg = 0 | 1), lanes c16 + 16 gk; summed in a fixed order
+        const int q = qb * 64 + tid;
+        if (q < g.L) {
+            const int wq_ = tid >> 4, cq = tid & 15;
+            double z = 0.0, zp = 0.0; int d = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    z += szz[wq_ + 4 * k2][cq + 16 * g4][0]; zp += szz[wq_ + 4 * k2][cq + 16 * g4][1]; d += sdg[wq_ + 4 * k2][cq + 16 * g4];
+                }
+            const size_t orow = ((size_t)split * a.B + b) * g.L + q;
+            const size_t ql = (size_t)b * g.L + q;
+            const float sub = a.smax[ql] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
+            bool ps;
+            const float lub = dn_logit(sub, a.mt[ql], a.bs[ql], ps);
+            a.part_m[orow] = fmaxf(lub, 0.f);
+            a.part_z[2 * orow] = z; a.part_z[2 * orow + 1] = zp; a.part_deg[orow] = d;
         }
     }
 #pragma unroll
@@ -468,12 +536,14 @@ int dense_splits(int B, const Grid& g) {
 }
 
 static size_t dn_feat16_bytes(int B, int rows) { return align_up((size_t)B * feat_rows_h(rows) * DSH * sizeof(uint16_t), 256); }
+// split value maps: whole maps + one staged row of slack (the last piece of a region may start past the map's last pixel)
+static size_t dn_map16_bytes(int B, const Grid& g) { return align_up(((size_t)B * g.Hp * g.Wp * CH + 1024) * sizeof(uint16_t), 256); }
 
 size_t dense_workspace_bytes(int B, const Grid& g) {
     const size_t rows = (size_t)dense_splits(B, g) * B * g.L;
     return align_up(rows * P * sizeof(float), 256) + align_up(rows * sizeof(float), 256) +
            align_up(rows * 2 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256) +
-           2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L);
+           2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L) + 2 * dn_map16_bytes(B, g);
 }
 
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
@@ -501,7 +571,10 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     uint16_t* xh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
     uint16_t* xl = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
     uint16_t* qh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
-    uint16_t* ql = reinterpret_cast<uint16_t*>(p);
+    uint16_t* ql = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
+    uint16_t* vh = reinterpret_cast<uint16_t*>(p); p += dn_map16_bytes(B, g);
+    uint16_t* vl = reinterpret_cast<uint16_t*>(p);
+    a.v_hi = vh; a.v_lo = vl;
     a.x_hi = xh; a.x_lo = xl; a.wq_hi = qh; a.wq_lo = ql;
     a.rows_xh = feat_rows_h(g.N); a.rows_qh = feat_rows_h(g.L);
     {
@@ -510,6 +583,8 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
         DAGL_LAUNCH_CHECK("feat_split_kernel");
         hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql, range);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
+        int rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b2p, vh, vl, range);     // 16 v = hi + lo, borders stay zero
+        if (rc) return rc;
     }
     const int n_qblocks = (g.L + 63) / 64;
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);

@@ -196,29 +196,56 @@ def sparse_heads_state_dict(sd: "OrderedDict[str, torch.Tensor]", seed: int, gai
     return out
 
 
+def tile_boxes(h: int, w: int, shave_scale: int = 4, shave_size_max: int = 24):
+    """Geometry of ONE 4-way split of the reference's ``forward_chop`` (DN_Gray/model/__init__.py:194-198, :222-229) for an
+    h x w tile: the four overlapping corner boxes ``(y0, y1, x0, x1)`` of size (h//2//4*4 + 24) x (w//2//4*4 + 24), and per corner
+    the pair (destination box in the h x w output, source box inside the corner tile's output) that stitches the inner
+    quadrants back.  Every user of the tiling (sequential driver, batched driver, leaf enumeration) takes it from here."""
+    hh, wh = h // 2, w // 2
+    hs = (hh // shave_scale) * shave_scale + shave_size_max
+    ws = (wh // shave_scale) * shave_scale + shave_size_max
+    corners = [(0, hs, 0, ws), (0, hs, w - ws, w), (h - hs, h, 0, ws), (h - hs, h, w - ws, w)]
+    stitch = [((0, hh, 0, wh), (0, hh, 0, wh)),
+              ((0, hh, wh, w), (0, hh, ws - w + wh, ws)),
+              ((hh, h, 0, wh), (hs - h + hh, hs, 0, wh)),
+              ((hh, h, wh, w), (hs - h + hh, hs, ws - w + wh, ws))]
+    return corners, stitch, hs * ws
+
+
+def _stitch(x: torch.Tensor, outs, stitch) -> torch.Tensor:
+    out = x.new_empty(x.shape)
+    for o, ((dy0, dy1, dx0, dx1), (sy0, sy1, sx0, sx1)) in zip(outs, stitch):
+        out[:, :, dy0:dy1, dx0:dx1] = o[:, :, sy0:sy1, sx0:sx1]
+    return out
+
+
+def chop_leaf_boxes(h: int, w: int, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4, y: int = 0, x: int = 0):
+    """The leaf tiles ``(y0, y1, x0, x1)`` (image coordinates, depth-first order) the reference's tiling cuts an h x w image into:
+    256 x 256 -> 64 tiles of 72 x 72."""
+    corners, _, area = tile_boxes(h, w, shave_scale, shave_size_max)
+    boxes = [(y + y0, y + y1, x + x0, x + x1) for (y0, y1, x0, x1) in corners]
+    if area < min_size:
+        return boxes
+    out = []
+    for (y0, y1, x0, x1) in boxes:
+        out.extend(chop_leaf_boxes(y1 - y0, x1 - x0, min_size, shave_size_max, shave_scale, y0, x0))
+    return out
+
+
 def chop_forward(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
                  ensemble: bool = False):
     """Recursive 4-way tiled inference: the reference's ``Model.forward_chop`` for scale 1
-    (DN_Gray/model/__init__.py:179-231); ``ensemble`` = its ``--ensemble`` switch: ``test_x8`` on every leaf (:205-208).  A tile of h x w is split into four overlapping corner tiles of
-    (h//2//4*4 + 24) x (w//2//4*4 + 24) until the corner area drops below ``min_size``; the four leaf tiles of one
-    split form one batch; the outputs' inner quadrants are stitched back."""
-    b, c, h, w = x.shape
-    h_half, w_half = h // 2, w // 2
-    h_size = (h_half // shave_scale) * shave_scale + shave_size_max
-    w_size = (w_half // shave_scale) * shave_scale + shave_size_max
-    tiles = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
-             x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
-    if w_size * h_size < min_size:
+    (DN_Gray/model/__init__.py:179-231); ``ensemble`` = its ``--ensemble`` switch: ``test_x8`` on every leaf (:205-208).  A tile of
+    h x w is split into four overlapping corner tiles (``tile_boxes``) until the corner area drops below ``min_size``; the outputs'
+    inner quadrants are stitched back."""
+    corners, stitch, area = tile_boxes(x.shape[2], x.shape[3], shave_scale, shave_size_max)
+    tiles = [x[:, :, y0:y1, x0:x1] for (y0, y1, x0, x1) in corners]
+    if area < min_size:
         # the reference runs the four leaves one by one with n_GPUs == 1 (__init__.py:203-209)
         outs = [forward_x8(model, t) if ensemble else model(t.contiguous()) for t in tiles]
     else:
         outs = [chop_forward(model, t, min_size, shave_size_max, shave_scale, ensemble) for t in tiles]
-    out = x.new_empty(b, c, h, w)
-    out[:, :, 0:h_half, 0:w_half] = outs[0][:, :, 0:h_half, 0:w_half]
-    out[:, :, 0:h_half, w_half:w] = outs[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
-    out[:, :, h_half:h, 0:w_half] = outs[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
-    out[:, :, h_half:h, w_half:w] = outs[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
-    return out
+    return _stitch(x, outs, stitch)
 
 
 def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
@@ -226,25 +253,10 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
     """Same tiling and stitching as ``chop_forward``, but all leaf tiles (they share one shape) go through the network in
     batches of up to ``max_batch`` instead of one by one: tiles are independent, and a batch is just
     another grid dimension of the HIP block.  Device-side equivalent of the reference's per-leaf loop."""
-    plan = []                                             # (depth-first) leaf views, in the order chop_forward visits them
-
-    def collect(t):
-        b, c, h, w = t.shape
-        h_half, w_half = h // 2, w // 2
-        h_size = (h_half // shave_scale) * shave_scale + shave_size_max
-        w_size = (w_half // shave_scale) * shave_scale + shave_size_max
-        tiles = [t[:, :, 0:h_size, 0:w_size], t[:, :, 0:h_size, (w - w_size):w],
-                 t[:, :, (h - h_size):h, 0:w_size], t[:, :, (h - h_size):h, (w - w_size):w]]
-        if w_size * h_size < min_size:
-            plan.extend(tiles)
-        else:
-            for q in tiles:
-                collect(q)
-
-    collect(x)
-    shapes = {tuple(t.shape) for t in plan}
-    if len(shapes) != 1:                                  # ragged leaves (odd sizes): fall back to the sequential driver
+    boxes = chop_leaf_boxes(x.shape[2], x.shape[3], min_size, shave_size_max, shave_scale)   # the order chop_forward visits them
+    if len({(y1 - y0, x1 - x0) for (y0, y1, x0, x1) in boxes}) != 1:   # ragged leaves (odd sizes): the sequential driver
         return chop_forward(model, x, min_size, shave_size_max, shave_scale, ensemble)
+    plan = [x[:, :, y0:y1, x0:x1] for (y0, y1, x0, x1) in boxes]
     outs = []
     for i in range(0, len(plan), max_batch):
         batch = torch.cat([t for t in plan[i:i + max_batch]], dim=0).contiguous()
@@ -254,24 +266,15 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
         outs.extend(res.split(x.shape[0], dim=0))
     it = iter(outs)
 
-    def stitch(t):
-        b, c, h, w = t.shape
-        h_half, w_half = h // 2, w // 2
-        h_size = (h_half // shave_scale) * shave_scale + shave_size_max
-        w_size = (w_half // shave_scale) * shave_scale + shave_size_max
-        if w_size * h_size < min_size:
+    def stitch_tree(h, w, like):
+        corners, stitch, area = tile_boxes(h, w, shave_scale, shave_size_max)
+        if area < min_size:
             o = [next(it) for _ in range(4)]
         else:
-            o = [stitch(q) for q in (t[:, :, 0:h_size, 0:w_size], t[:, :, 0:h_size, (w - w_size):w],
-                                     t[:, :, (h - h_size):h, 0:w_size], t[:, :, (h - h_size):h, (w - w_size):w])]
-        out = t.new_empty(b, c, h, w)
-        out[:, :, 0:h_half, 0:w_half] = o[0][:, :, 0:h_half, 0:w_half]
-        out[:, :, 0:h_half, w_half:w] = o[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
-        out[:, :, h_half:h, 0:w_half] = o[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
-        out[:, :, h_half:h, w_half:w] = o[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
-        return out
+            o = [stitch_tree(y1 - y0, x1 - x0, like) for (y0, y1, x0, x1) in corners]
+        return _stitch(like.new_empty(like.shape[0], like.shape[1], h, w), o, stitch)
 
-    return stitch(x)
+    return stitch_tree(x.shape[2], x.shape[3], x)
 
 
 # The 8 symmetries of the square in the order the reference enumerates them (``augment_img`` modes 0..7,

@@ -127,14 +127,18 @@ def test_eval_network_under_enabled_autograd_stays_on_the_inference_kernels():
     for m in heads:
         m.select_mode, m.select_k = "topk", 8
     net = net.to(DEV)
-    x = torch.rand(1, 1, 40, 44, device=DEV)
+    # (seeded: the device generator's state depends on what ran before in the process, and a fixed-k selection can flip on the
+    # last bits of the features -- an unseeded draw failed once in ~10 full runs on such a flip between the two launch sets)
+    x = torch.rand(1, 1, 40, 44, generator=torch.Generator().manual_seed(40), device="cpu").to(DEV)
     with torch.no_grad():
         ref = net(x)
     for m in heads:
         m.last_info = None
     y = net(x)                                                       # autograd enabled, eval mode
     # (no_grad runs the fused four-head stage, this call the heads one by one: same numbers up to the last bits of the features)
-    assert y.requires_grad and float((y.detach() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    err = float((y.detach() - ref).abs().max() / ref.abs().max())
+    print(f"[eval under autograd] fused stage vs heads one by one: {err:.2e}; input checksum {float(x.double().sum()):.6f}")
+    assert y.requires_grad and err <= 2e-5, err
     infos = [m.last_info for m in heads]
     assert all(i is not None and i["path"] in (2, 3) for i in infos), infos     # inference paths (screen or fp32 top-k), not the core
     # gradients through the lazily recomputed block == gradients of the train()-mode forward

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Run ON THE GPU BOX: the shipped adaptive semantics on REAL features -- Set12 images (sigma 50, scaled to [0, 1]) through the
+trained checkpoint's head conv and first eight ResBlocks -- (a) one head on the whole 256x256 map, (b) the 64 leaf tiles of 72x72
+the reference's forward_chop makes of a 256^2 image as ONE batch [64,64,72,72] (DN_Gray/model/__init__.py:179-231).  The trained
+heads' masks keep 0.9-1.0 of the keys and their logits stay below ~70: no weight underflows to exactly zero, every multiply of the
+dense formulation runs (the zero-granule skip of dense.hip never fires here)."""
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dagl_amd.net import RR, set12_protocol_noise, chop_leaf_boxes
+
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+dev = torch.device("cuda:0")
+z = np.load(os.path.join(G, "quality_ckpt_fp16.npz"))
+net = RR().eval()
+net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
+net = net.to(dev)
+imgs = np.load(os.path.join(G, "set12.npz"))
+ces = net.body[8]
+
+
+def time_call(fn, n=30, warm=10):
+    with torch.no_grad():
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+names = [n for n in sorted(imgs.files) if imgs[n].shape[-1] == 256 and imgs[n].shape[-2] == 256][:int(os.environ.get("N_IMAGES", "2"))]
+for name in names:
+    clean = torch.from_numpy(imgs[name].astype(np.float32) / 255.0)[None, None]
+    noisy = set12_protocol_noise(clean, 50.0, 1.0).to(dev)
+    with torch.no_grad():
+        x = net.head(noisy)
+        for blk in net.body[:8]:
+            x = blk(x)
+    x = x.contiguous()
+    for hn in ("c1_1", "c1_2", "c1_3", "c1_4"):
+        ce = getattr(ces, hn)
+        ce.select_mode = "adaptive"
+        ms = time_call(lambda: ce(x))
+        with torch.no_grad():
+            ce._dense_calls = 0
+            ce(x)
+        info = ce.last_info or {}
+        print(f"{name} head {hn} whole 256x256 map: {ms:.4f} ms  path {info.get('path')}  "
+              f"mask density {info.get('total_edges', 0) / (4096 * 65536):.3f}  max degree {info.get('max_degree')}", flush=True)
+    # the leaf tiles of the reference's forward_chop as one batch
+    boxes = chop_leaf_boxes(256, 256)
+    with torch.no_grad():
+        tiles = torch.stack([noisy[0, :, y0:y1, x0:x1] for (y0, y1, x0, x1) in boxes])
+        xt = net.head(tiles)
+        for blk in net.body[:8]:
+            xt = blk(xt)
+    xt = xt.contiguous()
+    ce = ces.c1_1
+    ms = time_call(lambda: ce(xt), n=10, warm=4)
+    with torch.no_grad():
+        ce._dense_calls = 0
+        ce(xt)
+    info = ce.last_info or {}
+    B, _, H, W = xt.shape
+    L = -(-H // 4) * -(-W // 4)
+    print(f"{name} head c1_1 leaf tiles {tuple(xt.shape)}: {ms:.4f} ms  path {info.get('path')}  "
+          f"mask density {info.get('total_edges', 0) / (B * L * H * W):.3f}", flush=True)

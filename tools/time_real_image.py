@@ -51,7 +51,7 @@ def time_head(x, label, threshold="auto"):
 
 
 for name in sorted(imgs.files):
-    clean = torch.from_numpy(imgs[name].astype(np.float32))
+    clean = torch.from_numpy(imgs[name].astype(np.float32) / 255.0)      # uint8 images; the network works on [0, 1] (rgb_range 1)
     if clean.ndim == 2:
         clean = clean[None, None]
     if clean.shape[-1] != 256 or clean.shape[-2] != 256:
