@@ -359,8 +359,34 @@ class CE(nn.Module):
         out = self._forward_infer(b, k_eff)
         return out if in_dtype == torch.float32 else out.to(in_dtype)
 
+    def _forward_infer_any_width(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
+        """``CE(in_channels = n_feats)`` for n_feats != 64 (CES builds every head that way, dagl.py:94-109; ``--n_feats``,
+        DN_Gray/option.py:70): the fused prologue kernels are laid out for 64 input channels, so the four prologue convolutions
+        run as unfold + fp32 matrix-core GEMM on the HIP library (train_ops.prologue_forward_any_width) and everything behind
+        them -- projections, selection, edge softmax, gather, fold: the 16-channel maps do not know the input width -- through
+        ``dagl_ce_forward`` (include/dagl_ce.h), the C ABI's channel-agnostic entry point."""
+        from . import train_ops as T
+        p = self._params_f32()
+        heads = self.select_mode != "topk"
+        hw = (p["thr_conv.weight"], p["thr_conv.bias"], p["bias_conv.weight"], p["bias_conv.bias"]) if heads else (None,) * 4
+        b1p, b2p, thr, bias = T.prologue_forward_any_width(b.contiguous(), p["g.weight"], p["g.bias"], p["theta.weight"],
+                                                           p["theta.bias"], *hw)
+        H, W = b.shape[-2:]
+        b1 = b1p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2).contiguous()
+        b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2).contiguous()
+        out, info = ops.ce_forward(b1, b2, thr, bias, p["fc1.0.weight"], p["fc1.0.bias"], p["fc2.0.weight"], p["fc2.0.bias"],
+                                   mode=self.select_mode, k=k_eff, workspace=self._ws, return_info=True,
+                                   exact_scan=(self.scan == "exact"), profile=self.profile)
+        self._last_call = None                     # (this entry point reads its statistics back every call: nothing to poll)
+        self.last_info = info
+        if info.get("range_fallback"):
+            self._note_range_violation("a call left the split-fp16 range and was re-run on the fp32 path")
+        return out
+
     def _forward_infer(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
         """The inference kernels (``dagl_ce_forward_fused``): fp32 [B,64,H,W] in, fp32 [B,16,H,W] out, no autograd."""
+        if self.in_channels != 64:
+            return self._forward_infer_any_width(b, k_eff)
         params = self._params_f32()
         # the packed copies of fc1/fc2 and of the g / theta convolutions live in this module's private workspace: skip
         # repacking while neither the weights (torch bumps ._version on every in-place update) nor the call geometry changed

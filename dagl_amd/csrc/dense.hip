@@ -14,24 +14,31 @@
 //             before the pass (from the bf16 screen's row maxima; the softmax is shift invariant, nothing is ever rescaled),
 //             split 2^14 p = hi + lo and handed to the other waves through the LDS in the K-layout of the next MFMA (the only
 //             exchange of the tile);
-//     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every wave a share of the 25
-//             column tiles for BOTH query tiles.  The value operand: 8 consecutive keys of one column = 8 consecutive pixels of
+//     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every wave three of the 24
+//             32-column tiles (two taps x 16 channels) for BOTH query tiles.  The value operand: 8 consecutive keys of one column = 8 consecutive pixels of
 //             one channel.  The tile's value-map region (10 rows x 14 pixels) is staged as it lies in memory -- NHWC fp16 hi / lo,
 //             32 B per pixel, by LDS-DMA from maps split once per call -- and ds_read_b64_tr_b16 transposes [4 pixels][16
 //             channels] blocks on the way into the registers: a patch tap's kw shift is a whole-pixel (32-byte) address offset,
 //             no funnel shifts, two 8-byte reads per 16-byte fragment where round 3 took five dwords + four v_alignbyte.
-//   Exactly-zero weights: logits reach hundreds, and 2^14 p rounds to hi = lo = 0 below l < M' - 27; a (32 queries x 16 keys)
+//     The 49th tap (16 columns) goes through v_mfma_f32_16x16x32_f16 (16 channels x 16 queries, K = the tile's 32 keys), one
+//     query group of 16 per wave 0-3; the other 48 taps are 24 column tiles of 32, three per wave.
+//   The two waves of a SIMD (w, w + 4) take the tile's two pieces of work in OPPOSITE order -- one forms scores and weights while
+//   the other multiplies -- and the multiplies run at s_setprio 1.
+//   Exactly-zero weights: logits reach hundreds, and 2^14 p rounds to hi = lo = 0 below l < M' - 27; a (64 queries x 16 keys)
 //   granule whose weights are ALL zero contributes exactly nothing to A V, so its multiplies are skipped (a wave-uniform test of
-//   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init 73-82 % of the granules are zero
+//   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init ~60-80 % of the granules are zero
 //   (profiles/r04_dense_zero_granules.log); with the trained checkpoint's features (logits of 5-70) none are -- that regime runs
 //   every multiply.
 //   Staging: key features hi | lo (2 x 14 KiB) two tiles ahead, value region (2 x 6 KiB) one tile ahead, 40 LDS-DMA pieces per
-//   tile, 4-6 per wave issued under ONE M0 set-up per buffer (the immediate offset advances the LDS and the global address, the
-//   per-lane global offset compensates); key rows at a 28-slot pitch with the low slot bits XORed by a function of the row so that
-//   the S fragments' ds_read_b128 are conflict-free for the 16x16x32 operand pattern.
+//   tile, five per wave (the per-lane global offsets are 32-bit, relative to a wave-uniform base); key rows at a 28-slot pitch with
+//   the low slot bits XORed by a function of the row so that the S fragments' ds_read_b128 are conflict-free for the 16x16x32
+//   operand pattern.
+//   Measured (profiles/r04_dense_*): 256^2, one head: 2.07 ms (round 3) -> 0.75 ms on the synthetic default-init map, 1.33 ms on the
+//   trained checkpoint's features; matrix pipes 49 % busy there.  What is left is issue bandwidth: per SIMD and tile 96
+//   32-cycle multiplies share the issue port with ~220 VALU operations, ~100 LDS reads and 10 LDS-DMA pieces of ~100 cycles each.
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
-// Matrix time per (64 query, 32 key) tile: 8 x 21 multiplies of 16 cycles + 300 of 32 cycles.
+// Matrix time per (64 query, 32 key) tile: 8 x 21 + 12 multiplies of 16 cycles + 288 of 32 cycles.
 #include <stdlib.h>
 
 #include "dagl_common.h"
@@ -56,12 +63,14 @@ constexpr int DN_VPART_B = 6 * 1024;                  // one part of a staged re
 constexpr int DN_VTILE_B = 2 * DN_VPART_B;
 constexpr int DN_PQ_ENTRY = 80;                       // a lane's weights of a tile: hi[16] | lo[16] halfs + 16 B (odd slot count)
 constexpr int DN_PQ_B = 2 * 64 * DN_PQ_ENTRY;         // both query tiles
-constexpr int DN_CT = 25;                             // column tiles of 32 (two taps x 16 channels; the 50th tap is a dummy)
-// A V: every wave takes a share of the 25 column tiles for BOTH query tiles of the block (3 tiles, the last wave 4): a value
-// fragment then feeds six multiplies instead of three
-constexpr int DN_CTMAX = 4;
+constexpr int DN_CT = 24;                             // column tiles of 32 = two taps x 16 channels: taps 0-47; tap 48 is a 16-column tile of its own
+// A V: every wave takes 3 of the 24 column tiles for BOTH query tiles of the block (a value fragment then feeds six multiplies
+// instead of three); the 49th tap's 16 columns go through v_mfma_f32_16x16x32_f16 (16 channels x 16 queries, K = the tile's 32
+// keys: three multiplies of 16 cycles per query group of 16, waves 0-3 one group each) -- as a 25th 32-column tile whose second
+// half was a dummy tap it cost wave 7 twelve 32-cycle multiplies per tile and EVERY wave 32 accumulator registers (the array is
+// sized for the largest share)
+constexpr int DN_CTMAX = 3;
 __host__ __device__ constexpr int dn_ct_start(int w8) { return 3 * w8; }
-__host__ __device__ constexpr int dn_ct_count(int w8) { return w8 == 7 ? 4 : 3; }
 constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
@@ -104,23 +113,19 @@ __device__ __forceinline__ void dn_glds(const void* src_biased, unsigned lds_byt
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(src_biased), "s"(lds_byte_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
 }
 
-__device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CTMAX], float* po, int h, int ct0, int cnt) {
+__device__ __forceinline__ void dn_store(const f32x16 (&acc)[DN_CTMAX], float* po, int h, int ct0) {
     constexpr float inv = 1.0f / (DN_PS * DN_VS);
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
-        if (t >= cnt) continue;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int col = 32 * (ct0 + t) + 8 * gq + 4 * h;                 // acc[t][4 gq + u] = out[q][col + u]
-            if (col < P)
-                *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
+            *reinterpret_cast<float4*>(po + col) = make_float4(acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
                                                                    acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv);
         }
     }
 }
 
-// A V of one k-block for this wave's column tiles: Q0 / Q1 = which query tiles have any non-zero weight (compile-time, so that the
-// usual case -- both -- is straight-line code whose fragment reads the compiler can run ahead of the multiplies)
 struct DnFrag { dns4 h0, h1, l0, l1; };
 // region pixel (row kh + 2 kb + h, column kw + 4 j + (lane & 15) / 4): keys 8 h + 4 j .. of a k-block, hi and lo
 __device__ __forceinline__ DnFrag dn_vfrag(unsigned va) {
@@ -128,36 +133,43 @@ __device__ __forceinline__ DnFrag dn_vfrag(unsigned va) {
     f.h0 = dn_tr16(va); f.h1 = dn_tr16(va + 128); f.l0 = dn_tr16(va + DN_VPART_B); f.l1 = dn_tr16(va + DN_VPART_B + 128);
     return f;
 }
-// A V of one k-block for this wave's column tiles; Q0 / Q1 (wave-uniform) = which query tiles have any non-zero weight.  ONE code
-// path with uniform branches around the multiplies: compile-time instantiations per (Q0, Q1) made the register allocator spill
-// 290 registers.
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX], int ctn,
-                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], bool Q0, bool Q1) {
+// A V of one k-block (16 keys) for this wave's three column tiles and BOTH query tiles: per column tile one value fragment, six
+// multiplies, the two accumulators' chains interleaved.  Straight-line code: the zero-granule skip is decided per k-block by the
+// caller (64 queries x 16 keys).  Per-query-tile skipping inside here -- uniform branches around groups of three multiplies --
+// skips 5-10 % more granules on synthetic maps and is 2-3 % slower where nothing is zero; compile-time instantiations per
+// (query tile 0 live, query tile 1 live) made the register allocator spill ~290 registers (profiles/r04_ab_dense_variants.log).
+__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX],
+                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2]) {
     // the fragment of column tile t + 1 is requested before tile t's multiplies
     DnFrag f = dn_vfrag(va_kb + vt_off[0]);
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
-        if (t >= 3 && t >= ctn) continue;                                   // wave-uniform (every wave has at least 3 tiles)
         DnFrag fn = f;
-        if (t + 1 < 3 || (t + 1 < DN_CTMAX && t + 1 < ctn)) fn = dn_vfrag(va_kb + vt_off[t + 1]);
+        if (t + 1 < DN_CTMAX) fn = dn_vfrag(va_kb + vt_off[t + 1]);
         __builtin_amdgcn_sched_barrier(0);
         const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
         const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
         const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
-        if (Q0) {
+        {
             acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[0], acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[0], acc[0][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[0], acc[0][t], 0, 0, 0);
-        }
-        if (Q1) {
             acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[1], acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[0], acc[0][t], 0, 0, 0);
             acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[1], acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[0], acc[0][t], 0, 0, 0);
             acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[1], acc[1][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         f = fn;
     }
 }
+
+#ifdef DAGL_ABLATION
+// phase clocks (DAGL_DENSE_VARIANT & 64): every wave sums shader-clock deltas per phase (s_memtime also waits for the wave's
+// outstanding LDS operations: ~10 % perturbation)
+#define DN_PH(i) do { if (clocks) { const unsigned long long n_ = __builtin_readcyclecounter(); ph[i] += (unsigned)(n_ - t_last); t_last = n_; } } while (0)
+#else
+#define DN_PH(i) do { } while (0)
+#endif
 
 constexpr int DN_THREADS = 512;
 __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
@@ -173,6 +185,11 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const Grid& g = a.g;
     const int n_qblocks = (g.L + 63) / 64;
     const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
+#ifdef DAGL_ABLATION
+    unsigned ph[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const bool clocks = (a.variant & 64) && a.phase_out != nullptr;
+    unsigned long long t_last = clocks ? __builtin_readcyclecounter() : 0ull;
+#endif
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const int c16 = lane & 15, gk = lane >> 4;
     // A V: lane = (column / query i, key half h) of the 32x32x16 multiply; wave = column tiles [ct0, ct0 + ctn) of both query tiles
     const int i = lane & 31, h = lane >> 5;
-    const int ct0 = dn_ct_start(wave), ctn = dn_ct_count(wave);
+    const int ct0 = dn_ct_start(wave);
 
     const int qs = qb * 64 + 16 * qg + c16;                                        // the query of this lane's scores
     const int qsc = qs < g.L ? qs : g.L - 1;
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         const int p = (kp0 + (j < kpn ? j : 0)) * 64 + lane;
         const int row = p / DN_KPITCH, phys = p - row * DN_KPITCH;
         const int logical = (phys & ~3) | ((phys & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3));
-        k_c[j] = (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096 - 1024 * j) | ((unsigned)(row >> 3) << 16);
+        k_c[j] = (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096) | ((unsigned)(row >> 3) << 16);
     }
     unsigned v_c[2];                                   // value piece j: bits 0-15 byte offset inside the pixel (+ bias), 16-19 region row, 20-23 pixel
 #pragma unroll
@@ -220,36 +237,31 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         int row = p / (2 * DN_VPX); const int c36 = p - row * (2 * DN_VPX);
         if (row > DN_RH - 1) row = DN_RH - 1;                                    // (slack positions of the last piece: any valid address)
         int px = c36 >> 1; if (px > DN_RW - 1) px = DN_RW - 1;
-        v_c[j] = (unsigned)(16 * (c36 & 1) + 4096 - 1024 * j) | ((unsigned)row << 16) | ((unsigned)px << 20);
+        v_c[j] = (unsigned)(16 * (c36 & 1) + 4096) | ((unsigned)row << 16) | ((unsigned)px << 20);
     }
     const unsigned lds_sm = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
     const unsigned lds_sv = __builtin_amdgcn_readfirstlane(lds_addr_of(sv));
     const unsigned lds_pq = __builtin_amdgcn_readfirstlane(lds_addr_of(spq));
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>((spart ? a.x_lo : a.x_hi) + (size_t)b * a.rows_xh * DSH) - 4096;
     const unsigned char* vsrc = reinterpret_cast<const unsigned char*>((spart ? a.v_lo : a.v_hi) + (size_t)b * g.Hp * g.Wp * CH) - 4096;
-    auto stage_keys = [&](int jy0, int jx0, int buf) {
-        unsigned o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int jy = jy0 + (int)(k_c[j] >> 16); if (jy > g.H - 1) jy = g.H - 1;  // ragged bottom: a valid row, keys masked below
-            o[j] = (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
-        }
-        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
-        if (kpn == 4) dn_glds<4>(xsrc, dst, o[0], o[1], o[2], o[3]);
-        else dn_glds<3>(xsrc, dst, o[0], o[1], o[2], o[3]);
+    // One LDS-DMA piece at a time (its own M0 set-up).  A wave's five pieces cost it 750-900 cycles per tile, 12-14 % of its time
+    // (profiles/r04_dense_phases.log); issuing them BETWEEN the column-tile blocks of A V, where the wave waits for the matrix
+    // pipe anyway, was measured and is 1-5 % slower than issuing them at the top of the iteration (r04_ab_dense_variants.log, v4).
+    auto key_piece = [&](int j, int jy0, int jx0, int buf) {
+        if (j >= kpn) return;                                                    // wave-uniform
+        int jy = jy0 + (int)(k_c[j] >> 16); if (jy > g.H - 1) jy = g.H - 1;      // ragged bottom: a valid row, keys masked below
+        const unsigned o = (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
+        dn_glds<1>(xsrc, lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + (kp0 + j) * 1024), o, 0, 0, 0);
     };
-    auto stage_values = [&](int jy0, int jx0, int buf) {
-        unsigned o[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int y = jy0 + (int)((v_c[j] >> 16) & 15u); if (y > g.Hp - 1) y = g.Hp - 1;   // stay inside the padded map
-            int x = jx0 + (int)(v_c[j] >> 20); if (x > g.Wp - 1) x = g.Wp - 1;
-            o[j] = (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
-        }
-        const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
-        if (vpn == 2) dn_glds<2>(vsrc, dst, o[0], o[1], 0, 0);
-        else dn_glds<1>(vsrc, dst, o[0], 0, 0, 0);
+    auto value_piece = [&](int j, int jy0, int jx0, int buf) {
+        if (j >= vpn) return;                                                    // wave-uniform
+        int y = jy0 + (int)((v_c[j] >> 16) & 15u); if (y > g.Hp - 1) y = g.Hp - 1;   // stay inside the padded map
+        int x = jx0 + (int)(v_c[j] >> 20); if (x > g.Wp - 1) x = g.Wp - 1;
+        const unsigned o = (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
+        dn_glds<1>(vsrc, lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + (vp0 + j) * 1024), o, 0, 0, 0);
     };
+    auto stage_keys = [&](int jy0, int jx0, int buf) { for (int j = 0; j < 4; ++j) key_piece(j, jy0, jx0, buf); };
+    auto stage_values = [&](int jy0, int jx0, int buf) { for (int j = 0; j < 2; ++j) value_piece(j, jy0, jx0, buf); };
 
     // tile coordinates (pixels) of the tiles in flight: c0 = the tile being attended, c1 = the next, c2 = the one after
     int y0 = (tile0 / a.tiles_per_row) * DN_TH, x0 = (tile0 % a.tiles_per_row) * DN_TW, y1, x1, y2, x2;
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         for (int t = 0; t < DN_CTMAX; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
+    f32x4 acc48 = {0.f, 0.f, 0.f, 0.f};                // tap 48 (waves 0-3): out^T[channel 4 gk + r][query 16 wave + c16]
     double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
     int deg = 0;
 
@@ -296,14 +309,11 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     // [4 pixels][16 channels] block; the group = (tap parity, key half h)
     const bool second = (lane & 16) != 0;
     const unsigned va_lane = (unsigned)(((c16 >> 2) * 32) + (c16 & 3) * 8 + h * (DN_VPX * 32));
-    // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes 16-31 / 48-63 ("second") take the odd tap (tap 49 does not exist:
-    // those lanes of tile 24 recompute tap 48 and their columns are never stored)
+    // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes 16-31 / 48-63 ("second") take the odd tap
     unsigned vt_off[DN_CTMAX];
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
-        const int ct = ct0 + (t < ctn ? t : 0);
-        const int tapa = 2 * ct, tapb = (2 * ct + 1 < KS * KS) ? 2 * ct + 1 : 2 * ct;
-        const int tap = second ? tapb : tapa;
+        const int tap = 2 * (ct0 + t) + (second ? 1 : 0);
         const int kh = tap / KS, kw = tap - kh * KS;
         vt_off[t] = (unsigned)((kh * DN_VPX + kw) * 32) + va_lane;
     }
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                 s_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], s_lh, 0, 0, 0);
             }
         }
+        DN_PH(1);
         // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
         float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32, one fp64 add per tile
         int dt = 0;
@@ -348,27 +359,64 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         unsigned char* pq = spq + buf * DN_PQ_B + pw_off;
         *reinterpret_cast<dnh4*>(pq) = hv;
         *reinterpret_cast<dnh4*>(pq + 32) = lv;
+        DN_PH(2);
     };
 
+    // the weights of BOTH query tiles for a k-block (lane = query i, keys 16 kb + 8 h ..): hi | lo, and whether any is non-zero:
+    // a granule (32 queries x 16 keys) whose weights are all exactly zero adds exactly nothing and is skipped.  (hi = 0 implies
+    // lo = 0: the split of a number below half the smallest denormal; -0 cannot occur, p >= 0.)
+    struct PFrag { dnu4 h[2], l[2]; };
+    auto load_p = [&](int buf, int kb) {
+        PFrag f;
+        const unsigned pa = lds_pq + (unsigned)(buf * DN_PQ_B + 16 * kb) + pr_off;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) { f.h[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY)); f.l[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 32)); }
+        return f;
+    };
+    // staging state of the iteration (set by the loop): keys of tile + 2 -> sm[cur], values of tile + 1 -> sv[cur ^ 1]
+    int st_ky = 0, st_kx = 0, st_vy = 0, st_vx = 0, st_cur = 0; bool st_k = false, st_v = false;
+    auto piece = [&](int slot) {                           // slots 0-3: key pieces, 4-5: value pieces
+        if (slot < 4) { if (st_k) key_piece(slot, st_ky, st_kx, st_cur); }
+        else if (st_v) value_piece(slot - 4, st_vy, st_vx, st_cur ^ 1);
+    };
     auto attend = [&](int buf) {
         if (a.variant & 1) return;
         const unsigned vbase = lds_sv + (unsigned)(buf * DN_VTILE_B);
-        const unsigned pa = lds_pq + (unsigned)(buf * DN_PQ_B) + pr_off;
+        PFrag pf = load_p(buf, 0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            // the weights of BOTH query tiles for this k-block (lane = query i, keys 16 kb + 8 h ..): hi | lo
             dnh8 p_hi[2], p_lo[2];
             bool nz[2];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                const dnu4 wh = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 16 * kb)), wl = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 32 + 16 * kb));
-                p_hi[qq] = __builtin_bit_cast(dnh8, wh); p_lo[qq] = __builtin_bit_cast(dnh8, wl);
-                // a granule (32 queries x 16 keys) whose weights are all exactly zero adds exactly nothing: skipped.  (hi = 0 implies
-                // lo = 0: the split of a number below half the smallest denormal; -0 cannot occur, p >= 0.)
-                nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull;
+                p_hi[qq] = __builtin_bit_cast(dnh8, pf.h[qq]); p_lo[qq] = __builtin_bit_cast(dnh8, pf.l[qq]);
+                nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((pf.h[qq].x | pf.h[qq].y) | (pf.h[qq].z | pf.h[qq].w)) != 0u) != 0ull;
             }
+            if (kb == 0) pf = load_p(buf, 1);              // the second k-block's weights arrive under the first one's multiplies
             const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
-            if (nz[0] || nz[1]) dn_pv(acc, va_kb, vt_off, ctn, p_hi, p_lo, nz[0], nz[1]);          // (wave-uniform)
+            DN_PH(3);
+            if (nz[0] || nz[1])                            // (wave-uniform)
+                dn_pv(acc, va_kb, vt_off, p_hi, p_lo);
+            DN_PH(4);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (wave < 4) {
+            // tap 48 = patch position (6, 6): 16 channels x the 16 queries 16 wave .. of the block, K = the tile's 32 keys.  Lane
+            // (c16, gk): operand B = the weights of query c16 for keys 8 gk .. (k-block gk >> 1, key half gk & 1 of the exchange
+            // layout), operand A = channel c16 of the region pixels (row 6 + gk, columns 6 .. 13) through the transposing read
+            const unsigned pe = lds_pq + (unsigned)(buf * DN_PQ_B + (((wave >> 1) * 64 + (gk & 1) * 32 + 16 * (wave & 1) + c16) * DN_PQ_ENTRY) + 16 * (gk >> 1));
+            const dnu4 wh = dn_lds128(pe), wl = dn_lds128(pe + 32);
+            if ((a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull) {
+                const DnFrag f = dn_vfrag(vbase + (unsigned)(((6 + gk) * DN_VPX + 6 + (c16 >> 2)) * 32 + (c16 & 3) * 8));
+                const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
+                const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
+                const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
+                const dnh8 q_hi = __builtin_bit_cast(dnh8, wh), q_lo = __builtin_bit_cast(dnh8, wl);
+                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_lo, acc48, 0, 0, 0);
+                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_lo, q_hi, acc48, 0, 0, 0);
+                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_hi, acc48, 0, 0, 0);
+            }
         }
     };
 
@@ -379,17 +427,35 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 
     for (int tile = tile0; tile < tile1; ++tile) {
         const int cur = (tile - tile0) & 1;
-        if (!(a.variant & 4)) {
-            if (tile + 2 < tile1) stage_keys(y2, x2, cur);                   // (tile's own features were consumed one iteration ago)
-            if (tile + 1 < tile1) stage_values(y1, x1, cur ^ 1);
-        }
-        if (tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
+        // (tile's own features were consumed one iteration ago: sm[cur] is free)
+        st_k = tile + 2 < tile1 && !(a.variant & 4); st_v = tile + 1 < tile1 && !(a.variant & 4);
+        st_ky = y2; st_kx = x2; st_vy = y1; st_vx = x1; st_cur = cur;
+        for (int sl = 0; sl < 6; ++sl) piece(sl);
+        // The two waves of a SIMD (waves w and w + 4) take the tile's two independent pieces of work in OPPOSITE order: one forms
+        // the next tile's scores and weights (21 short multiplies, then ~110 VALU operations with the matrix pipe idle) while the
+        // other multiplies (A V), then they swap.  In the same order they ran in lockstep from barrier to barrier and nothing
+        // overlapped: the kernel's time was the plain sum of its parts (profiles/r04_dense_ablation.log, first ladder).
+        // (the multiplies stand ONCE in the loop, unconditionally, with the scores / weights code before and after them and each
+        // wave running one of the two copies: with the accumulators inside a two-armed branch the register allocator spilled ~300)
+        const bool first = wave < 4;
+        DN_PH(0);
+        if (first && tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
         attend(cur);
+        if (!first && tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
         y0 = y1; x0 = x1; y1 = y2; x1 = x2;
         next_tile(y1, x1, y2, x2);
+        DN_PH(6);
         dma_wait_all();
         __syncthreads();
+        DN_PH(5);
     }
+#ifdef DAGL_ABLATION
+    if (clocks && lane == 0) {
+        unsigned* po = a.phase_out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) po[e] = ph[e];
+    }
+#endif
 
     // ---- partial results of this key range ------------------------------------------------------------------------------------------
     szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg;
@@ -418,7 +484,12 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {                       // this wave's column tiles of both query tiles
         const int q2 = qb * 64 + qq * 32 + i;
-        if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0, ctn);
+        if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0);
+    }
+    if (wave < 4 && qs < g.L) {                            // tap 48: columns 768 + 4 gk .. of query qs (= qb 64 + 16 wave + c16 for these waves)
+        constexpr float inv = 1.0f / (DN_PS * DN_VS);
+        *reinterpret_cast<float4*>(a.part_acc + (((size_t)split * a.B + b) * g.L + qs) * P + 768 + 4 * gk) =
+            make_float4(acc48[0] * inv, acc48[1] * inv, acc48[2] * inv, acc48[3] * inv);
     }
 }
 
@@ -587,8 +658,39 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
         if (rc) return rc;
     }
     const int n_qblocks = (g.L + 63) / 64;
+    a.phase_out = nullptr;
+#ifdef DAGL_ABLATION
+    const size_t n_blocks = (size_t)n_qblocks * a.splits * B;
+    if ((a.variant & 64) && getenv("DAGL_TIMES_FILE")) a.phase_out = reinterpret_cast<unsigned*>(dbg_times_buffer(n_blocks * 8));
+#endif
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
+#ifdef DAGL_ABLATION
+    if (a.phase_out) {                                    // mean clocks per phase and wave group, appended to DAGL_TIMES_FILE
+        static int budget = 3, skip = 8;
+        if (skip > 0) --skip;
+        else if (budget-- > 0 && hipStreamSynchronize(s) == hipSuccess) {
+            unsigned* h = static_cast<unsigned*>(malloc(n_blocks * 64 * sizeof(unsigned)));
+            if (h && hipMemcpy(h, a.phase_out, n_blocks * 64 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE* f = fopen(getenv("DAGL_TIMES_FILE"), "a")) {
+                    static const char* nm[8] = {"stage", "S", "weights", "p-load", "AV", "wait+barrier", "coords", "-"};
+                    for (int grp = 0; grp < 2; ++grp) {
+                        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+                        for (size_t bl = 0; bl < n_blocks; ++bl)
+                            for (int w = 4 * grp; w < 4 * grp + 4; ++w)
+                                for (int e = 0; e < 8; ++e) sum[e] += h[(bl * 8 + w) * 8 + e];
+                        for (int e = 0; e < 8; ++e) { sum[e] /= (double)(n_blocks * 4); tot += sum[e]; }
+                        fprintf(f, "dense_attend phases, waves %d-%d (clocks per wave, %d tiles per block): total %.0f |", 4 * grp, 4 * grp + 3, a.tiles_per_split, tot);
+                        for (int e = 0; e < 7; ++e) fprintf(f, " %s %.0f (%.1f %%)", nm[e], sum[e], 100.0 * sum[e] / tot);
+                        fprintf(f, "\n");
+                    }
+                    fclose(f);
+                }
+            }
+            free(h);
+        }
+    }
+#endif
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
     // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics)

@@ -178,7 +178,10 @@ class _PrologueConvs(torch.autograd.Function):
         heads = thr_w is not None
         c = lambda t: t.contiguous() if t is not None else None
         with torch.cuda.device(x.device):
-            b1p, b2p, thr, bias = ops.ce_prologue(x, c(g_w), c(g_b), c(th_w), c(th_b), c(thr_w), c(thr_b), c(bias_w), c(bias_b))
+            if x.shape[1] == 64:
+                b1p, b2p, thr, bias = ops.ce_prologue(x, c(g_w), c(g_b), c(th_w), c(th_b), c(thr_w), c(thr_b), c(bias_w), c(bias_b))
+            else:
+                b1p, b2p, thr, bias = prologue_forward_any_width(x, g_w, g_b, th_w, th_b, thr_w, thr_b, bias_w, bias_b)
         ctx.heads = heads
         ctx.save_for_backward(x, g_w, th_w, *( (thr_w, bias_w) if heads else () ))
         if heads:
@@ -247,6 +250,46 @@ class _PrologueConvs(torch.autograd.Function):
                 inner64 = (PAD * Wp + PAD) * C
                 _copy4(d_xp.view(-1)[inner64:], (B, C, H, W), (Hp * Wp * C, 1, Wp * C, C), d_x, (C * H * W, H * W, W, 1))
         return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b)
+
+
+def prologue_forward_any_width(x, g_w, g_b, th_w, th_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None):
+    """The four prologue convolutions (dagl.py:208-215) for ANY input width -- ``CE(in_channels = n_feats)``, dagl.py:94-109 -- as
+    unfold + fp32 matrix-core GEMM on the HIP library (the fused kernels of prologue.hip are laid out for 64 channels): g (3x3)
+    and theta (1x1 = the centre tap) as one 32-output layer over the 3x3 patches, thr / bias as one 2-output layer over the
+    stride-4 SAME 7x7 patches.  Same outputs as ``ops.ce_prologue``: zero-bordered NHWC maps [B,H+6,W+6,16] and [B,L] heads."""
+    from .synth import same_pad_amounts
+    lib = _lib.load()
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    Hp, Wp = H + 2 * PAD, W + 2 * PAD
+    with torch.cuda.device(x.device), torch.no_grad():
+        xp = _ToPaddedNHWC.apply(x.detach(), H, W, False)
+        w32 = torch.zeros(32, 9 * C, device=x.device, dtype=torch.float32)
+        w32[:16] = conv_weight_rows(g_w.detach())
+        w32[16:, 4 * C:5 * C] = th_w.detach().reshape(16, C)
+        b32 = torch.cat([g_b.detach(), th_b.detach()]).contiguous()
+        rows = torch.empty(B * H * W, 9 * C, device=x.device, dtype=torch.float32)
+        check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, xp.data_ptr(), rows.data_ptr()),
+              "dagl_unfold_patches")
+        y32 = ops.gemm_f32(rows, w32, a_k_contiguous=True, b_k_contiguous=True, bias=b32, relu=False, chunk_tiles=7)   # [B*H*W, 32]
+        del rows
+        maps = []
+        for o in (0, 16):
+            m = torch.zeros(B, Hp, Wp, 16, device=x.device, dtype=torch.float32)
+            _copy4(y32.view(-1)[o:], (B, H, W, 16), (H * W * 32, W * 32, 32, 1), m.view(-1)[(PAD * Wp + PAD) * 16:], (Hp * Wp * 16, Wp * 16, 16, 1))
+            maps.append(m)
+        thr = bias = None
+        if thr_w is not None:
+            t, l = same_pad_amounts(H, 7, 4)[0], same_pad_amounts(W, 7, 4)[0]
+            Lh, Lw = -(-H // 4), -(-W // 4)
+            w_tb = torch.cat([conv_weight_rows(thr_w.detach()), conv_weight_rows(bias_w.detach())], dim=0).contiguous()
+            b_tb = torch.cat([thr_b.detach(), bias_b.detach()]).contiguous()
+            rows = torch.empty(B * Lh * Lw, 49 * C, device=x.device, dtype=torch.float32)
+            check(lib.dagl_unfold_patches(ops._stream(), B, Hp, Wp, C, 7, 4, PAD - t, PAD - l, Lh, Lw, xp.data_ptr(), rows.data_ptr()),
+                  "dagl_unfold_patches")
+            y2 = ops.gemm_f32(rows, w_tb, a_k_contiguous=True, b_k_contiguous=True, bias=b_tb, relu=False, chunk_tiles=7).view(B, Lh * Lw, 2)
+            thr, bias = y2[..., 0].contiguous(), y2[..., 1].contiguous()
+    return maps[0], maps[1], thr, bias
 
 
 def prologue_convs(x, g, theta, thr_conv=None, bias_conv=None):

@@ -58,6 +58,12 @@ CASES = [
     ("topk50_64x64",         "TOPK",     25, "default", 2.0, "topk",    50, 1, 64, 64),
     ("topk64_b2_40x36",      "TOPK",     26, "default", 2.0, "topk",    64, 2, 40, 36),
     ("topk50_k_gt_n_6x7",    "TOPK",     27, "default", 2.0, "topk",    50, 1, 6, 7),
+    # CE(in_channels = n_feats) for n_feats != 64 (CES builds every head that way, DN_Gray/model/dagl.py:94-109; --n_feats,
+    # option.py:70): an 11th column = the input channel count
+    ("gray_sparse_c32_40x44",     "DN_Gray", 28, "sparse",  1.7, "adaptive", 0, 1, 40, 44, 32),
+    ("gray_default_c128_b2_24x28", "DN_Gray", 29, "default", 2.0, "adaptive", 0, 2, 24, 28, 128),
+    ("topk8_c32_36x40",           "TOPK",    30, "default", 2.0, "topk",     8, 1, 36, 40, 32),
+    ("car_sparse_c96_33x30",      "CAR",     31, "sparse",  1.6, "adaptive", 0, 1, 33, 30, 96),
 ]
 
 
@@ -83,18 +89,19 @@ def _load_module(task: str):
 
 
 def run_case(case, agg_step=7):
-    name, task, seed, variant, gain, mode, k, B, H, W = case
+    name, task, seed, variant, gain, mode, k, B, H, W = case[:10]
+    Cin = case[10] if len(case) > 10 else 64
     mod = _load_module(task)
-    np_params = make_ce_params(seed, variant=variant, sparse_gain=gain)
-    x = torch.from_numpy(make_features(seed, B, 64, H, W))
+    np_params = make_ce_params(seed, in_channels=Cin, variant=variant, sparse_gain=gain)
+    x = torch.from_numpy(make_features(seed, B, Cin, H, W))
     if task == "TOPK":
-        ce = mod.CE(in_channels=64, num_edge=k)
+        ce = mod.CE(in_channels=Cin, num_edge=k)
         sd = {n: torch.from_numpy(a) for n, a in np_params.items()
               if not n.startswith(("thr_conv", "bias_conv"))}
         missing = ce.load_state_dict(sd, strict=False)
         assert set(missing.missing_keys) <= {"conv33.weight", "conv33.bias"}, missing
     else:
-        ce = mod.CE(in_channels=64)
+        ce = mod.CE(in_channels=Cin)
         ce.load_state_dict({n: torch.from_numpy(a) for n, a in np_params.items()}, strict=True)
     ce.eval()
 
@@ -133,7 +140,7 @@ def run_case(case, agg_step=7):
             rowsums.append(A.sum(1))
             aggs.append((A @ vx[n].t())[::agg_step])
     meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode,
-                k=k, B=B, C=64, H=H, W=W, agg_step=agg_step,
+                k=k, B=B, C=Cin, H=H, W=W, agg_step=agg_step,
                 torch=torch.__version__, threads=torch.get_num_threads())
     np.savez_compressed(os.path.join(HERE, name + ".npz"),
                         out=out.numpy().astype(np.float32),

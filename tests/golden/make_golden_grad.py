@@ -41,6 +41,9 @@ CASES = [
     # dense neighbourhoods: default-initialised heads keep ~95 % of the keys; "longtail": a few queries beyond 64 keys
     ("gray_default_64x64", "DN_Gray", 35, "default", 2.0, "adaptive", 0, 1, 64, 64),
     ("gray_longtail_b2_40x36", "DN_Gray", 36, "sparse", 1.45, "adaptive", 0, 2, 40, 36),
+    # CE(in_channels != 64): an 11th column = the input width (dagl.py:94-109 builds heads as CE(in_channels=n_feats))
+    ("gray_sparse_c32_b2_36x40", "DN_Gray", 37, "sparse", 1.8, "adaptive", 0, 2, 36, 40, 32),
+    ("gray_default_c96_32x36", "DN_Gray", 38, "default", 2.0, "adaptive", 0, 1, 32, 36, 96),
 ]
 FC_STEP = 5
 
@@ -50,16 +53,17 @@ def loss_weights(seed: int, shape):
 
 
 def run_case(case):
-    name, task, seed, variant, gain, mode, k, B, H, W = case
+    name, task, seed, variant, gain, mode, k, B, H, W = case[:10]
+    Cin = case[10] if len(case) > 10 else 64
     mod = _load_module(task)
-    np_params = make_ce_params(seed, variant=variant, sparse_gain=gain)
-    x = torch.from_numpy(make_features(seed, B, 64, H, W)).requires_grad_(True)
+    np_params = make_ce_params(seed, in_channels=Cin, variant=variant, sparse_gain=gain)
+    x = torch.from_numpy(make_features(seed, B, Cin, H, W)).requires_grad_(True)
     if task == "TOPK":
-        ce = mod.CE(in_channels=64, num_edge=k)
+        ce = mod.CE(in_channels=Cin, num_edge=k)
         sd = {n: torch.from_numpy(a) for n, a in np_params.items() if not n.startswith(("thr_conv", "bias_conv"))}
         ce.load_state_dict(sd, strict=False)
     else:
-        ce = mod.CE(in_channels=64)
+        ce = mod.CE(in_channels=Cin)
         ce.load_state_dict({n: torch.from_numpy(a) for n, a in np_params.items()}, strict=True)
     ce.train()
     grabbed = {}
@@ -75,7 +79,7 @@ def run_case(case):
             continue
         g = p.grad.numpy().astype(np.float32)
         arrays["d_" + n] = g.reshape(-1)[::FC_STEP].copy() if n in ("fc1.0.weight", "fc2.0.weight") else g
-    meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode, k=k, B=B, C=64, H=H, W=W,
+    meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode, k=k, B=B, C=Cin, H=H, W=W,
                 fc_step=FC_STEP, torch=torch.__version__)
     np.savez_compressed(os.path.join(HERE, "grad_" + name + ".npz"), meta=json.dumps(meta), **arrays)
     print(name, {n: (a.shape, float(np.abs(a).max())) for n, a in arrays.items()}, flush=True)

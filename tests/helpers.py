@@ -18,7 +18,7 @@ def load_golden(path):
 def case_inputs(meta):
     """Regenerate (x, params) of a golden case from its seed (numpy PCG64)."""
     from dagl_amd.synth import make_ce_params, make_features
-    p = make_ce_params(meta["seed"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
+    p = make_ce_params(meta["seed"], in_channels=meta["C"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
     x = make_features(meta["seed"], meta["B"], meta["C"], meta["H"], meta["W"])
     return torch.from_numpy(x), {n: torch.from_numpy(a) for n, a in p.items()}
 

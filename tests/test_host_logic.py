@@ -60,3 +60,18 @@ def test_module_rejects_cpu_and_foreign_hyperparameters():
     with pytest.raises(DaglError, match="expected"):
         with torch.no_grad():
             ce(torch.zeros(1, 32, 8, 8))
+
+
+def test_network_width_other_than_64_fails_like_the_reference():
+    """``CES(in_channels=n_feats)`` concatenates four 16-channel heads into its ``Conv2d(n_feats, n_feats, 1)`` mix
+    (DN_Gray/model/dagl.py:94-119): the reference's own ``RR(n_feats=32)`` cannot run a forward (a shape error at ``c1_c``),
+    although each ``CE(in_channels=32)`` head is a valid module on its own (goldens ``*_c32_*`` / ``*_c96_*`` / ``*_c128_*``).
+    Same wiring here: the network builds, strict-loads its own state_dict and raises at the mix -- on the CPU already, before any
+    kernel runs, because the heads are never reached with a consistent shape."""
+    import torch
+    from dagl_amd.net import CES
+    ces = CES(32)
+    assert ces.fuse_stage is False
+    assert ces.c1_1.in_channels == 32 and ces.c1_c.weight.shape == (32, 32, 1, 1)
+    with pytest.raises(RuntimeError):
+        ces.c1_c(torch.zeros(1, 64, 8, 8))          # what cat(four 16-channel heads) hands the mix

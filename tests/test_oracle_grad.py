@@ -22,7 +22,7 @@ def load_grad_case(path):
 
 def grad_case_inputs(meta):
     from dagl_amd.synth import make_ce_params, make_features
-    p = make_ce_params(meta["seed"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
+    p = make_ce_params(meta["seed"], in_channels=meta["C"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
     x = torch.from_numpy(make_features(meta["seed"], meta["B"], meta["C"], meta["H"], meta["W"]))
     G = np.random.Generator(np.random.PCG64(meta["seed"] + 1000)).standard_normal(
         (meta["B"], 16, meta["H"], meta["W"])).astype(np.float32)
