@@ -213,7 +213,7 @@ def extra_configs(dev):
     cases = [
         ("512x512_topk8_bf16_io", 512, "default", 2.0, "topk", 8, torch.bfloat16, "BASELINE configs[2]: CAR 512x512, k=8, bf16 feature maps"),
         ("1024x1024_adaptive_topk16", 1024, "sparse", 1.7, "adaptive_topk", 16, torch.float32, "BASELINE configs[3]: 1024x1024, adaptive AND k_max=16, whole-image search window"),
-        ("256x256_adaptive_dense_default_init", 256, "default", 2.0, "adaptive", 0, torch.float32, "shipped semantics at default init (~95 % of the keys pass): streamed dense formulation"),
+        ("256x256_adaptive_dense_default_init", 256, "default", 2.0, "adaptive", 0, torch.float32, "shipped semantics at default init (~95 % of the keys pass): streamed dense formulation; on this synthetic N(0,1) map the logits reach hundreds and ~2/3 of the (64 query x 16 key) weight granules are exactly zero and skipped -- see 256x256_set12_features.adaptive_dense for the regime where none are"),
         ("256x256_adaptive_mean_degree_8", 256, "sparse", 1.95, "adaptive", 0, torch.float32, "adaptive mask tuned to a mean degree of ~8 (7.7; long-tailed: maximum 890) (SURVEY 8d config 2)"),
         ("256x256_adaptive_mean_degree_55", 256, "sparse", 1.8, "adaptive", 0, torch.float32, "adaptive mask at mean degree 55, maximum 4578"),
     ]
@@ -248,18 +248,24 @@ def extra_configs(dev):
                                           "ms_per_step": ms, "patches_per_s": 4 * 4096 / (ms * 1e-3), "L": 4096, "N": 65536}
         del heads, prm, x, ws
         torch.cuda.empty_cache()
-    out["256x256_topk8_set12_features"] = real_features_extra(dev)
+    out["256x256_set12_features"] = real_features_extra(dev)
     out["train_rr_topk8_128x128_b8"] = train_extra(dev)
     return out
 
 
 def real_features_extra(dev):
-    """One head, top-k k=8, on REAL features: Set12 image 01 (sigma 50, the reference's test protocol) through the trained
-    checkpoint's head conv and first eight ResBlocks, whole 256x256 map.  Natural-image scores are not spread like the synthetic
-    map's: the threshold sampled from every 8th key tile lets hundreds to thousands of keys through and the call lands on the fp32
-    redo pass; CE.topk_threshold = "auto" notices after the first call and takes the threshold from every second key tile."""
+    """REAL features: the seven 256 x 256 Set12 images (sigma 50, the reference's test protocol, scaled to [0, 1]) through the
+    trained checkpoint's head conv and first eight ResBlocks, whole 256x256 map, one head.
+    * top-k k = 8: natural-image scores are not spread like the synthetic map's -- the threshold sampled from every 8th key tile
+      lets hundreds of keys per query through and the call lands on the fp32 redo pass; CE.topk_threshold = "auto" notices
+      after the first call and takes the threshold from every second key tile.  All seven maps: worst / median, and the error of
+      64 sampled queries' aggregated patches against the oracle (all 65 536 keys) on the first and the slowest map.
+    * the shipped adaptive semantics on the same features (mask density 0.3-1.0, logits below ~70: no weight underflows to an exact
+      zero, the dense kernel's zero-granule skip never fires): whole map, and the 64 leaf tiles of 72 x 72 that the reference's
+      forward_chop feeds a head (DN_Gray/model/__init__.py:179-231) as one batch."""
     import numpy as np
-    from dagl_amd.net import RR, set12_protocol_noise
+    from dagl_amd import ops
+    from dagl_amd.net import RR, chop_leaf_boxes, set12_protocol_noise
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
     try:
         z = np.load(os.path.join(gdir, "quality_ckpt_fp16.npz"))
@@ -269,34 +275,76 @@ def real_features_extra(dev):
     net = RR().eval()
     net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
     net = net.to(dev)
-    name = sorted(n for n in imgs.files if imgs[n].shape[-1] == 256 and imgs[n].shape[-2] == 256)[0]
-    clean = torch.from_numpy(imgs[name].astype(np.float32) / 255.0)      # uint8 images; the network works on [0, 1] (rgb_range 1)
-    clean = clean[None, None] if clean.ndim == 2 else clean
-    res = {"what": f"one head, top-k k=8, on the features of Set12 {name} (sigma 50) after the trained RR's head conv + 8 ResBlocks, "
-                   "whole 256x256 map", "L": 4096, "N": 65536}
-    with torch.no_grad():
-        x = net.head(set12_protocol_noise(clean, 50.0, 1.0).to(dev))
+    names = sorted(n for n in imgs.files if imgs[n].shape[-1] == 256 and imgs[n].shape[-2] == 256)
+
+    def features(name, leaf=False):
+        clean = torch.from_numpy(imgs[name].astype(np.float32) / 255.0)[None, None]     # uint8 images; the network works on [0, 1]
+        noisy = set12_protocol_noise(clean, 50.0, 1.0).to(dev)
+        if leaf:
+            noisy = torch.stack([noisy[0, :, y0:y1, x0:x1] for (y0, y1, x0, x1) in chop_leaf_boxes(256, 256)])
+        x = net.head(noisy)
         for blk in net.body[:8]:
             x = blk(x)
-        x = x.contiguous()
+        return x.contiguous()
+
+    def parity(ce, x):
+        from oracle.ce_oracle import ce_rows_oracle
+        rows = torch.linspace(0, 4095, 64).long()
+        b1, b2, thr, bias = ce._prologue(x)
+        _, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(), ce.fc1[0].weight,
+                                 ce.fc1[0].bias, ce.fc2[0].weight, ce.fc2[0].bias, mode="topk", k=8, debug=True, tight_topk=True)
+        ref = ce_rows_oracle(x.cpu(), {n: q.detach().cpu() for n, q in ce.named_parameters()}, rows, mode="topk", k=8)
+        agg = info["agg"][0].cpu()[rows].reshape(64, 7, 7, 16).movedim(-1, -3).reshape(64, 784)
+        return float((agg - ref["agg"]).abs().max() / ref["agg"].abs().max())
+
+    res = {"what": "one head on the features of the seven 256x256 Set12 images (sigma 50, [0,1]) after the trained RR's head conv + 8 "
+                   "ResBlocks, whole 256x256 map", "L": 4096, "N": 65536}
+    with torch.no_grad():
         ce = net.body[8].c1_1
         ce.select_mode, ce.select_k = "topk", 8
-        for thr in ("sparse", "auto"):
-            ce.topk_threshold = thr
+        per, feats = {}, {}
+        for n in names:
+            x = feats[n] = features(n)
+            ce.topk_threshold = "auto"
             ce._topk_shape = None                            # (a fresh start for the policy)
-            ms = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
-            res["ms_per_step" if thr == "auto" else "ms_per_step_sampled_threshold"] = ms
-        res["patches_per_s"] = 4096 / (res["ms_per_step"] * 1e-3)
-        res["threshold"] = "full" if ce._topk_tight else "sparse"
-    del net, x
+            per[n] = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
+        ms = sorted(per.values())
+        worst = max(per, key=per.get)
+        ce.topk_threshold, ce._topk_shape = "sparse", None
+        x0 = feats[names[0]]
+        res["topk8"] = {"ms_per_step_by_image": {n: round(v, 4) for n, v in per.items()}, "ms_per_step_worst": ms[-1],
+                        "ms_per_step_median": ms[len(ms) // 2], "worst_image": worst, "patches_per_s_worst": 4096 / (ms[-1] * 1e-3),
+                        "ms_per_step_sampled_threshold": _time_steps(lambda: ce(x0), 5, 2, 0.0),
+                        "threshold": "auto: every 2nd key tile after the first call of a shape",
+                        "parity_err": {names[0]: parity(ce, feats[names[0]]), worst: parity(ce, feats[worst])},
+                        "parity_note": "max|hip - oracle| / max|oracle| of 64 sampled queries' aggregated patches against all keys (bar 1e-4)"}
+        res["ms_per_step"] = ms[-1]                          # (kept: the entry's headline = the WORST of the seven maps)
+        res["patches_per_s"] = 4096 / (ms[-1] * 1e-3)
+        # the shipped adaptive semantics on the same features: dense formulation, nothing skipped
+        ce.select_mode = "adaptive"
+        dper = {}
+        for n in names[:3]:
+            x = feats[n]
+            dper[n] = _time_steps(lambda: ce(x), 8, 3, EXTRA_PREWARM_S)
+        info = ce.last_info or {}
+        res["adaptive_dense"] = {"what": "shipped adaptive semantics, head c1_1, whole map: streamed dense formulation, every multiply runs",
+                                 "ms_per_step_by_image": {n: round(v, 4) for n, v in dper.items()}, "ms_per_step": max(dper.values()),
+                                 "selection_path": info.get("path")}
+        del feats
+        xl = features(names[0], leaf=True)
+        msl = _time_steps(lambda: ce(xl), 8, 3, EXTRA_PREWARM_S)
+        res["adaptive_dense_leaf_tiles"] = {"what": f"the 64 leaf tiles of 72x72 of {names[0]} (forward_chop) as one batch {list(xl.shape)}, head c1_1, adaptive",
+                                            "ms_per_step": msl, "patches_per_s": xl.shape[0] * 324 / (msl * 1e-3), "L": 324, "N": 5184,
+                                            "selection_path": (ce.last_info or {}).get("path")}
+    del net, xl
     torch.cuda.empty_cache()
     return res
 
 
 def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
     """BASELINE configs[4] on one GPU inside the driver-timed command: RR (12 heads, fixed-k 8) fwd + bwd + Adam on synthetic crops
-    [8,3,128,128], plus the roofline of the step's dominant matrix product -- the fc2 weight gradient dW = dZ^T rows,
-    [196 x 131072] x [131072 x 784] on the fp32 matrix cores (gemm32_kernel, split-K, summed in slice order)."""
+    [8,3,128,128], plus the roofline of the step's dominant matrix products -- the fc2 projection's two gradient products on the
+    split-fp16 GEMM (gemm_roofline)."""
     from dagl_amd import ops
     from dagl_amd.ce import CE
     from dagl_amd.net import RR, seeded_state_dict
@@ -317,7 +365,7 @@ def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
     return {"what": "BASELINE configs[4] (sparse regime) on one GPU: RR with 12 CE heads, crops [8,3,128,128], fwd + bwd + Adam, "
                     "fixed-k 8; no RCCL leg here (world size 1) -- `bench.py --train --gpus N` runs it under DDP",
             "ms_per_step": ms, "crops_per_s": B / (ms * 1e-3), "steps": steps, "warmup": warmup,
-            "roofline": gemm_roofline(dev, B * crop * crop)}
+            "roofline": gemm_roofline(dev, B, crop)}
 
 
 def mfma_sustained(dev, nominal_tflops):
@@ -352,31 +400,55 @@ def mfma_sustained(dev, nominal_tflops):
                     "register operands), back-to-back launches timed with events; clock = s_memtime / s_memrealtime over wave 0's loop"}
 
 
-def gemm_roofline(dev, n):
-    """The training step's dominant matrix product on its own, hipEvent-bracketed on the launch stream: the fc2 weight gradient
-    dW = dZ^T rows, [196 x n] x [n x 784] (n = key patches of the batch) on the fp32 matrix cores."""
-    from dagl_amd import ops
+def gemm_roofline(dev, B, crop):
+    """The training step's dominant matrix products on their own, hipEvent-bracketed on the launch stream: the two gradient
+    products of the fc2 projection -- d W = d Z^T rows ([196 x n] x [n x 784]) and d rows = d Z W ([n x 196] x [196 x 784]), n =
+    B * crop^2 key patches -- as the step runs them since round 3: split-fp16 operands on the fp16 matrix cores
+    (dagl_fc_grad16 -> fcg_* producers + gemm16s_kernel, train_ops.FAST_FC_BACKWARD).  `achieved` counts the ALGORITHMIC products
+    (2 x 2 x 196 x 784 x n FLOP); the kernel executes three split products for each (`executed_frac`)."""
+    from dagl_amd import _lib, ops
+    lib = _lib.load()
+    H = W = crop
+    n = B * H * W
     O, K = 196, 784
     g = torch.Generator(device=dev).manual_seed(1)
-    dz = torch.randn(n, O, device=dev, generator=g)
-    rows = torch.randn(n, K, device=dev, generator=g)
-    for _ in range(2):
-        ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
+    pmap = torch.zeros(B, H + 6, W + 6, 16, device=dev)
+    pmap[:, 3:3 + H, 3:3 + W] = torch.randn(B, H, W, 16, device=dev, generator=g)
+    w = (torch.rand(O, K, device=dev, generator=g) - 0.5) * 0.07
+    dz = torch.randn(n, O, device=dev, generator=g) * 1e-4
+    need = lib.dagl_fc_grad16_scratch_bytes(B, H, W)
+    scratch = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    d_w, d_rows = torch.empty(O, K, device=dev), torch.empty(n, K, device=dev)
+
+    def call():
+        _lib.check(lib.dagl_fc_grad16(ops._stream(), B, H + 6, W + 6, 1, 0, 0, H, W, pmap.data_ptr(), w.data_ptr(), None, dz.data_ptr(),
+                                      d_w.data_ptr(), None, d_rows.data_ptr(), base, need), "dagl_fc_grad16")
+    for _ in range(3):
+        call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 8
     e0.record()
     for _ in range(reps):
-        ops.gemm_f32(dz, rows, a_k_contiguous=False, b_k_contiguous=False)
+        call()
     e1.record()
     e1.synchronize()
     g_ms = e0.elapsed_time(e1) / reps
-    flop = 2.0 * O * K * n
+    flop = 2.0 * 2.0 * O * K * n
     ach = flop / (g_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm32_kernel (fc2 weight gradient dW = dZ^T rows, [196 x %d] x [%d x 784], "
-                                                    "v_mfma_f32_32x32x2_f32, split-K)" % (n, n),
-            "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+    return {"bound": "mfma", "kernel": "dagl_fc_grad16 (fc2 backward: d W = d Z^T rows [196 x %d] x [%d x 784] and d rows = d Z W, split-fp16 "
+                                      "operands, gemm16s_kernel v_mfma_f32_32x32x16_f16 + its operand producers)" % (n, n),
+            "achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MATRIX_TFLOPS,
+            "executed_frac": 3.0 * ach / PEAK_BF16_MATRIX_TFLOPS, "fp32_matrix_peak_equivalent": ach / PEAK_F32_MATRIX_TFLOPS,
             "flop_per_launch": flop, "ms_per_launch": g_ms, "traffic": None,
+            "note": "algorithmic FLOP of both products / time of the whole call (producers included); x3 = executed fp16 products "
+                    "against the 2.5 PF fp16 peak; the same FLOP against the 157.3 TF fp32 matrix peak in fp32_matrix_peak_equivalent",
             "calls_per_step": "12 heads x (fc2 on the key rows; fc1 on the query rows is 1/16 of it)"}
+
+
+TRAFFIC_SOURCE = ("HBM bytes per launch read from the newest committed profiles/rNN_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                  "WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes): PMC counters cannot be "
+                  "read inside the timed process, so this field is NOT measured in this run")
 
 
 def committed_traffic(kernel_key):
@@ -483,7 +555,7 @@ def train_bench(args, dev, dist, world, rank):
                                        f"{args.crop},{args.crop}] per GPU, MSE(sum)/(2B) loss, Adam, gradients of "
                                        f"{n_par} parameters all-reduced over RCCL",
                            "parallelism": f"ddp{world}", "select_mode": args.mode, "k": args.k, "batch_per_gpu": B},
-                "roofline": gemm_roofline(dev, B * args.crop * args.crop), "cpu_baseline": None,
+                "roofline": gemm_roofline(dev, B, args.crop), "cpu_baseline": None,
                 "allreduce_ms": allreduce_ms, "allreduce_bytes": 4 * n_par if dist is not None else None,
                 "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None}
         print(json.dumps(line))
@@ -577,6 +649,16 @@ def main():
             ce.profile = profile
             ce(x)
     with torch.no_grad():
+        # the COLD figure first (what --prewarm 0 reports): W warm-up steps on a GPU that sat idle while the case was built, then K
+        # timed steps -- kept beside the sustained figure in the line ("ms_per_step_cold")
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - tc) / max(args.steps, 1) * 1e3
         prewarm_steps = _prewarm(step, args.prewarm)
         for _ in range(args.warmup):
             step()
@@ -668,6 +750,10 @@ def main():
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": (committed_traffic("screen_ring_kernel<1>") or committed_traffic("screen_kernel<1>")) if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
+        if roofline["traffic"] is not None:
+            roofline["traffic_source"] = TRAFFIC_SOURCE
+        if gather is not None and gather.get("traffic") is not None:
+            gather["traffic_source"] = TRAFFIC_SOURCE
         if screened:
             roofline["sustained"] = mfma_sustained(dev, peak)
             if roofline["sustained"]:
@@ -688,6 +774,7 @@ def main():
             "n_ranks_seen": dist.get_world_size() if dist is not None else 1, "devices": devices, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_cold": cold_ms,
             "prewarm": {"seconds": args.prewarm, "untimed_steps": prewarm_steps,
                         "note": "untimed passes of the same step before the W warm-up steps: an idle GPU runs its first tens "
                                 "of ms below the sustained clock (--prewarm 0 shows the cold figure)"},

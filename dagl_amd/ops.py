@@ -237,8 +237,9 @@ class Workspace:
 @_on_device
 def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
                workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False,
-               profile: "StageProfile | None" = None, exact_scan: bool = False):
-    """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W]."""
+               profile: "StageProfile | None" = None, exact_scan: bool = False, tight_topk: bool = False):
+    """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W].  ``tight_topk``:
+    DAGL_FLAG_TIGHT_TOPK (top-k modes behind the screen), as in ``ce_forward_fused``."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -259,6 +260,8 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
     need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
     if need == 0:
         check(-1, "dagl_ce_workspace_bytes")
+    if tight_topk and mode != "adaptive" and not exact_scan:
+        mode_flags |= _lib.FLAG_TIGHT_TOPK
     out = torch.empty(B, 16, H, W, device=b1.device, dtype=torch.float32)
     info = _lib.CeInfo()
     rc = 0

@@ -1,0 +1,88 @@
+"""Top-k mode on NATURAL-IMAGE features against the oracle (round-3 review, weak #1): Set12 images (sigma 50, the reference's test
+protocol, DN_Gray/test.py:55-58, scaled to [0, 1]) through the committed trained checkpoint's head conv and first eight ResBlocks
+-> one head, fixed k = 8, whole 256 x 256 map.  On such maps the threshold sampled from every 8th key tile lets hundreds of
+keys per query through: the candidate slots overflow and nearly every query group takes the exact fp32 redo pass; with
+DAGL_FLAG_TIGHT_TOPK (every 2nd key tile, 8 x the slots) the 127-slot segments serve them.  Both must give the reference's
+neighbours: 64 sampled queries against all 65 536 keys on ``ce_rows_oracle``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_DIR, normwise
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def real_features(img: str):
+    from dagl_amd.net import RR, set12_protocol_noise
+    z = np.load(os.path.join(GOLDEN_DIR, "quality_ckpt_fp16.npz"))
+    net = RR().eval()
+    net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
+    imgs = np.load(os.path.join(GOLDEN_DIR, "set12.npz"))
+    clean = torch.from_numpy(imgs[img].astype(np.float32) / 255.0)[None, None]
+    assert clean.shape[-2:] == (256, 256)
+    noisy = set12_protocol_noise(clean, 50.0, 1.0)
+    net = net.to(DEV)
+    with torch.no_grad():
+        x = net.head(noisy.to(DEV))
+        for blk in net.body[:8]:
+            x = blk(x)
+    ce = net.body[8].c1_1
+    ce.select_mode, ce.select_k = "topk", 8
+    return x.contiguous(), ce
+
+
+def _agg_ckk(agg):
+    s = agg.shape[:-1]
+    return agg.reshape(*s, 7, 7, 16).movedim(-1, -3).reshape(*s, 784)
+
+
+@pytest.mark.parametrize("img", ["img_01", "img_02"])
+def test_topk8_on_set12_features_matches_the_oracle_with_both_thresholds(img):
+    from dagl_amd import ops
+    from oracle.ce_oracle import ce_rows_oracle
+    x, ce = real_features(img)
+    params = {n: p.detach().cpu() for n, p in ce.named_parameters()}
+    L = 64 * 64
+    rows = torch.linspace(0, L - 1, 64).long()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = ce_rows_oracle(x.cpu(), params, rows, mode="topk", k=8)
+        ref64 = ce_rows_oracle(x.cpu(), params, rows, mode="topk", k=8, dtype=torch.float64)
+    e_rs = normwise(ref["rowsum"].numpy(), ref64["rowsum"].float().numpy())
+    e_agg = normwise(ref["agg"].numpy(), ref64["agg"].float().numpy())
+    outs = {}
+    for tight in (False, True):
+        with torch.no_grad():
+            b1, b2, thr, bias = ce._prologue(x)
+            out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(), ce.fc1[0].weight,
+                                       ce.fc1[0].bias, ce.fc2[0].weight, ce.fc2[0].bias, mode="topk", k=8, debug=True, tight_topk=tight)
+        deg = info["deg"][0].cpu()[rows].numpy()
+        assert np.array_equal(deg, ref["deg"].numpy().astype(deg.dtype))
+        rowsum, agg = info["rowsum"][0].cpu()[rows].numpy(), _agg_ckk(info["agg"][0].cpu()[rows]).numpy()
+        e1, e2 = normwise(rowsum, ref64["rowsum"].float().numpy()), normwise(agg, ref64["agg"].float().numpy())
+        print(f"[real features, {img}, {'every 2nd tile + 127 slots' if tight else 'sampled threshold'}] rowsum vs fp64 {e1:.2e} "
+              f"(fp32 oracle {e_rs:.2e}), agg vs fp64 {e2:.2e} (fp32 oracle {e_agg:.2e})")
+        assert e1 <= TOL and e2 <= TOL
+        assert normwise(rowsum, ref["rowsum"].numpy()) <= TOL + e_rs and normwise(agg, ref["agg"].numpy()) <= TOL + e_agg
+        outs[tight] = out
+    # the two thresholds select the same neighbours: the same output up to the summation order of the refine pass
+    assert normwise(outs[True].cpu().numpy(), outs[False].cpu().numpy()) <= 1e-6
+    # the module's three policies (fused split-fp16 prologue): same result; "auto" moves to the tight threshold by itself
+    res = {}
+    for pol in ("sparse", "full", "auto"):
+        ce.topk_threshold = pol
+        ce._topk_shape = None
+        with torch.no_grad():
+            for _ in range(3):
+                y = ce(x)
+        res[pol] = y
+        if pol == "auto":
+            assert ce._topk_tight, "the sampled threshold overflows on natural-image features: auto must have switched"
+    assert normwise(res["full"].cpu().numpy(), res["sparse"].cpu().numpy()) <= 1e-6
+    assert normwise(res["auto"].cpu().numpy(), res["full"].cpu().numpy()) <= 1e-6
+    assert normwise(res["full"].cpu().numpy(), outs[True].cpu().numpy()) <= TOL

@@ -5,7 +5,7 @@
 #   3. --pmc SQ_* counters                           MFMA utilisation / wait breakdown of the matrix-core kernels
 # tools/summarize_profiles.py turns the CSVs into the small JSON / CSV files kept under profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -18,6 +18,8 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTI
 # the dense regime (shipped semantics at default init) and the mean-degree-8 regime: kernel stats only
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense -o k -- python $GRAFT_REPO_ROOT/bench.py --mode adaptive --variant default --steps 10 --warmup 3 --no-cpu-baseline --no-quality --no-extra > $OUT/dense.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/md8 -o k -- python $GRAFT_REPO_ROOT/bench.py --mode adaptive --variant sparse --sparse-gain 1.95 --wseed 41 --fseed 41 --steps 20 --warmup 5 --no-cpu-baseline --no-quality --no-extra > $OUT/md8.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 4 --warmup 2 > $OUT/train.log 2>&1
+# (MIOPEN_FIND_MODE=FAST: without it MIOpen's find phase -- 32 calls x 38 ms of naive_conv_* and Tensile benchmarking inside the
+# first step -- is two thirds of the traced time and the CSV does not show the steady-state step)
+MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 12 --warmup 4 > $OUT/train.log 2>&1
 python $GRAFT_REPO_ROOT/tools/summarize_profiles.py $OUT $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary $TAG
 ls $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary
