@@ -306,11 +306,11 @@ def real_features_extra(dev):
         for n in names:
             x = feats[n] = features(n)
             ce.topk_threshold = "auto"
-            ce._topk_shape = None                            # (a fresh start for the policy)
+            ce.reset_topk_policy()
             per[n] = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
         ms = sorted(per.values())
         worst = max(per, key=per.get)
-        ce.topk_threshold, ce._topk_shape = "sparse", None
+        ce.topk_threshold = "sparse"; ce.reset_topk_policy()
         x0 = feats[names[0]]
         res["topk8"] = {"ms_per_step_by_image": {n: round(v, 4) for n, v in per.items()}, "ms_per_step_worst": ms[-1],
                         "ms_per_step_median": ms[len(ms) // 2], "worst_image": worst, "patches_per_s_worst": 4096 / (ms[-1] * 1e-3),

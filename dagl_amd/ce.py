@@ -166,11 +166,19 @@ class CE(nn.Module):
         self._topk_tight = False
         self._topk_shape = None
         self._topk_calls = 0
+        self._topk_verdicts = {}       # input shape -> (tight, calls): tiled inference alternates between interior and edge tile shapes,
+                                       # and a single slot forgot its verdict at every switch (2.7 ms redo pass + a host poll each time)
         self._served_streak = 0
+        self._served_streaks = {}      # the same for adaptive_sync = "auto"
         self._served_shape = None
         self._nowait_calls = 0
         self.last_info = None
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
+
+    def reset_topk_policy(self):
+        """Forget what ``topk_threshold = "auto"`` has learnt about the input shapes seen so far."""
+        self._topk_shape, self._topk_tight, self._topk_calls = None, False, 0
+        self._topk_verdicts.clear()
 
     def range_ok(self) -> bool:
         """False when the last inference call on this module met operands outside the split-fp16 range (|activation| >=
@@ -401,11 +409,17 @@ class CE(nn.Module):
         self._dense_calls = self._dense_calls + 1 if hint else 0
         want_info = (not hint) or (self._dense_calls % 16 == 1) or self.profile is not None
         if self._served_shape != tuple(b.shape):
-            self._served_shape, self._served_streak = tuple(b.shape), 0
+            if self._served_shape is not None:
+                self._served_streaks[self._served_shape] = self._served_streak
+            self._served_shape = tuple(b.shape)
+            self._served_streak = self._served_streaks.get(self._served_shape, 0)
         no_wait = (self.select_mode == "adaptive" and self.scan != "exact" and not hint and self.adaptive_sync == "auto"
                    and self._served_streak >= 4 and key == self._pack_key and self.profile is None)
         if self._topk_shape != tuple(b.shape[1:]):
-            self._topk_shape, self._topk_tight, self._topk_calls = tuple(b.shape[1:]), False, 0
+            if self._topk_shape is not None:
+                self._topk_verdicts[self._topk_shape] = (self._topk_tight, self._topk_calls)
+            self._topk_shape = tuple(b.shape[1:])
+            self._topk_tight, self._topk_calls = self._topk_verdicts.get(self._topk_shape, (False, 0))
         tight = self.select_mode != "adaptive" and self.scan != "exact" and \
             (self.topk_threshold == "full" or (self.topk_threshold == "auto" and self._topk_tight))
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,

@@ -345,11 +345,40 @@ int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int 
         return DAGL_ERR_INVALID;
     }
     const unsigned n_merge = (unsigned)(((size_t)e.B * e.L + 3) / 4);
-    // all blocks resident whatever the device is doing besides: 128 at most (K = 64 takes 407 registers: ONE block per CU), the batch
-    // in grid.y
-    int gx = 128 / (a.B > 0 ? a.B : 1);
+    // The kernel meets at a grid-wide barrier: EVERY block must be resident.  128 blocks at most (K = 64 takes 407 registers: ONE
+    // block per CU), the batch in grid.y -- and never more than the device (a partition in CPX / QPX mode, a CU-masked stream) can
+    // hold of THIS instantiation: hipOccupancyMaxActiveBlocksPerMultiprocessor x the CU count, asked once per instantiation and
+    // device.  Fewer resident slots than images: the two-launch form (no barrier).
+    int dev = 0, cus = 0;
+    DAGL_HIP_TRY(hipGetDevice(&dev));
+    DAGL_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    auto capacity = [&](const void* fn) -> int {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return per_cu * cus;
+    };
+    int cap = 0;
+#define DAGL_REDO_FN(P_, K_) reinterpret_cast<const void*>(&topk_redo_kernel<P_, K_>)
+#define DAGL_REDO_CAP(P_) switch (ks) { case 4: cap = capacity(DAGL_REDO_FN(P_, 4)); break; case 8: cap = capacity(DAGL_REDO_FN(P_, 8)); break; \
+                                        case 16: cap = capacity(DAGL_REDO_FN(P_, 16)); break; case 32: cap = capacity(DAGL_REDO_FN(P_, 32)); break; \
+                                        default: cap = capacity(DAGL_REDO_FN(P_, 64)); break; }
+    {
+        // (cached: the answer depends on the instantiation and the device only)
+        static thread_local int cached[2][5][16];                              // [pass - 2][slot class][device] = capacity + 1
+        const int kc = ks == 4 ? 0 : ks == 8 ? 1 : ks == 16 ? 2 : ks == 32 ? 3 : 4;
+        int* slot = (dev >= 0 && dev < 16) ? &cached[pass - 2][kc][dev] : nullptr;
+        if (slot && *slot > 0) cap = *slot - 1;
+        else {
+            if (pass == 2) { DAGL_REDO_CAP(2) } else { DAGL_REDO_CAP(3) }
+            if (slot) *slot = cap + 1;
+        }
+    }
+#undef DAGL_REDO_CAP
+#undef DAGL_REDO_FN
+    int limit = cap < 128 ? cap : 128;
+    int gx = limit / (a.B > 0 ? a.B : 1);
     if (gx > n_units) gx = n_units;
-    if (gx < 1) {                                                         // (a batch this large: the two-launch form)
+    if (gx < 1) {                                                         // (a batch this large, or a device this small: the two-launch form)
         int rc = launch_score_select(s, a, pass);
         return rc ? rc : launch_edge_softmax(s, e);
     }

@@ -54,6 +54,7 @@ class CES(nn.Module):
         self._fused_calls = {1: 0, 2: 0, 3: 0}    # fused calls since the stage's range word was last looked at
         self._tight = {1: False, 2: False, 3: False}          # CE.topk_threshold = "auto": the stage moved to the full threshold pass
         self._tight_shape = {1: None, 2: None, 3: None}
+        self._tight_memo = {1: {}, 2: {}, 3: {}}
         self._stage_calls = {1: 0, 2: 0, 3: 0}
 
     def _stage(self, s, x):
@@ -77,7 +78,11 @@ class CES(nn.Module):
             key = (tuple(x.shape), heads[0].select_mode, k_eff, tuple(hd._pack_epoch for hd in heads),
                    tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)
             if self._tight_shape[s] != tuple(x.shape[1:]):
-                self._tight_shape[s], self._tight[s], self._stage_calls[s] = tuple(x.shape[1:]), False, 0
+                # (per-shape memory: tiled inference alternates between tile shapes, a single slot forgot its verdict every time)
+                if self._tight_shape[s] is not None:
+                    self._tight_memo[s][self._tight_shape[s]] = (self._tight[s], self._stage_calls[s])
+                self._tight_shape[s] = tuple(x.shape[1:])
+                self._tight[s], self._stage_calls[s] = self._tight_memo[s].get(self._tight_shape[s], (False, 0))
             tight = mode != "adaptive" and (heads[0].topk_threshold == "full" or (heads[0].topk_threshold == "auto" and self._tight[s]))
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
                                               mix.bias.detach().contiguous(), mode=heads[0].select_mode,

@@ -105,11 +105,14 @@ class TrainStep:
         self.error_last = 1e8
         self.skipped = 0
 
-    def __call__(self, hr: torch.Tensor, lr: "torch.Tensor | None" = None, check_spike: bool = False):
+    def __call__(self, hr: torch.Tensor, lr: "torch.Tensor | None" = None, check_spike: bool = True):
         """hr: clean crops [B,C,H,W] in [0, rgb_range].  lr: degraded input, or None for synthetic Gaussian noise of
         sigma ``noise_sigma``/255 drawn on the device (trainer.py:49).  Returns (loss, psnr) as device scalars.
-        ``check_spike`` reads the loss back (one host sync) to apply the reference's guard; off by default because
-        the shipped ``error_last`` = 1e8 can never trigger it."""
+        ``check_spike`` reads the loss back (one host sync, which the reference pays too: trainer.py:55) and applies the
+        reference's guard ``loss < skip_threshold * error_last``.  On by default since round 4: with the shipped ``error_last`` =
+        1e8 it can only ever trigger on a NON-FINITE loss -- and that is exactly what the block's range guard produces (a forward
+        that left the split-fp16 range is NaN-filled, never wrong): without the test a NaN loss is back-propagated and Adam
+        writes NaN into every weight before the module has moved itself to the fp32 path (round-3 advisory)."""
         o = self.opt
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)

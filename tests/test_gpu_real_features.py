@@ -76,7 +76,7 @@ def test_topk8_on_set12_features_matches_the_oracle_with_both_thresholds(img):
     res = {}
     for pol in ("sparse", "full", "auto"):
         ce.topk_threshold = pol
-        ce._topk_shape = None
+        ce.reset_topk_policy()
         with torch.no_grad():
             for _ in range(3):
                 y = ce(x)

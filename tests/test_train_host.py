@@ -69,6 +69,25 @@ def test_train_step_reduces_loss_and_spike_guard_skips():
     assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
 
 
+def test_train_step_does_not_apply_a_non_finite_loss():
+    """A forward that left the block's split-fp16 range is NaN-filled (never wrong numbers): the step's default guard -- the
+    reference's own ``loss < skip_threshold * error_last`` test, which is false for NaN -- must keep Adam from writing it into
+    the weights (round-3 advisory)."""
+    net = _net()
+    freeze_unused(net)
+    opt = TrainOptions(lr=1e-3)
+    step = TrainStep(net, make_optimizer(net, opt), opt, generator=torch.Generator().manual_seed(5))
+    hr = torch.rand(2, 1, 16, 16)
+    step(hr)
+    before = [p.detach().clone() for p in net.parameters()]
+    bad = hr.clone(); bad[0, 0, 3, 3] = float("nan")
+    loss, _ = step(bad)                                        # defaults: the guard is on
+    assert not torch.isfinite(loss) and step.skipped == 1
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    step(hr)                                                   # and training goes on
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

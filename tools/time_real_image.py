@@ -28,7 +28,7 @@ ce.select_mode = "topk"; ce.select_k = 8
 
 def time_head(x, label, threshold="auto"):
     ce.topk_threshold = threshold
-    ce._topk_shape = None                                    # (a fresh start for the module's policy)
+    ce.reset_topk_policy()
     prof = ops.StageProfile(20)
     with torch.no_grad():
         for _ in range(30):
