@@ -310,12 +310,21 @@ def real_features_extra(dev):
             per[n] = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
         ms = sorted(per.values())
         worst = max(per, key=per.get)
-        ce.topk_threshold = "sparse"; ce.reset_topk_policy()
+        # the first call on a cold workspace under "auto": packs the weights, overflows under the sampled threshold, flips the policy
+        # word and re-runs tight in-stream (round 3: the fp32 redo pass of every query group + a host poll)
         x0 = feats[names[0]]
+        cold = []
+        for _ in range(3):
+            ce.topk_threshold = "auto"; ce.reset_topk_policy()
+            torch.cuda.synchronize(); tcold = time.perf_counter()
+            ce(x0)
+            torch.cuda.synchronize(); cold.append((time.perf_counter() - tcold) * 1e3)
+        ce.topk_threshold = "sparse"; ce.reset_topk_policy()
         res["topk8"] = {"ms_per_step_by_image": {n: round(v, 4) for n, v in per.items()}, "ms_per_step_worst": ms[-1],
                         "ms_per_step_median": ms[len(ms) // 2], "worst_image": worst, "patches_per_s_worst": 4096 / (ms[-1] * 1e-3),
                         "ms_per_step_sampled_threshold": _time_steps(lambda: ce(x0), 5, 2, 0.0),
-                        "threshold": "auto: every 2nd key tile after the first call of a shape",
+                        "ms_first_call_cold_workspace_auto": min(cold),
+                        "threshold": "auto: the workspace's policy word, flipped on the device by the first call (no host poll)",
                         "parity_err": {names[0]: parity(ce, feats[names[0]]), worst: parity(ce, feats[worst])},
                         "parity_note": "max|hip - oracle| / max|oracle| of 64 sampled queries' aggregated patches against all keys (bar 1e-4)"}
         res["ms_per_step"] = ms[-1]                          # (kept: the entry's headline = the WORST of the seven maps)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 302          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 401          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -29,6 +29,7 @@ FLAG_WEIGHTS_PACKED = 0x200
 FLAG_DENSE_HINT = 0x400
 FLAG_NO_WAIT = 0x800
 FLAG_TIGHT_TOPK = 0x1000
+FLAG_SAMPLED_TOPK = 0x2000
 
 
 class DaglError(RuntimeError):

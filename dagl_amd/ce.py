@@ -156,18 +156,13 @@ class CE(nn.Module):
         # all); the device-side verdict NaN-fills a call the in-stream kernels could not serve -- never wrong numbers -- and
         # the sticky word is polled every 16th call, which sends the module back to waiting.
         self.adaptive_sync = "always"
-        # top-k modes: where the candidate threshold comes from.  "sparse" = every 8th key tile (enough on maps whose scores are
-        # spread evenly, e.g. the synthetic benchmark features); "full" = every second key tile + eight times the candidate slots
-        # (DAGL_FLAG_TIGHT_TOPK: +25 us at 256^2) -- on natural-image features the sampled threshold lets hundreds to thousands
-        # of keys through, the slots overflow and the call lands on the fp32 redo pass (2.6 ms instead of 0.25);
-        # "auto" (default) = start sparse, look at the workspace's verdict after the first call and every 64th (one
-        # synchronisation, together with the range word) and move to "full" for this input shape once a call needed the redo pass.
+        # top-k modes: where the candidate threshold comes from.  "sparse" = every 8th key tile (DAGL_FLAG_SAMPLED_TOPK: enough on
+        # maps whose scores are spread evenly, e.g. the synthetic benchmark features); "full" = every second key tile + eight times
+        # the candidate slots (DAGL_FLAG_TIGHT_TOPK: +25 us at 256^2) -- on natural-image features the sampled threshold lets
+        # hundreds of keys per query through, the slots overflow and the call lands on the fp32 redo pass (2.7 ms instead of 0.25);
+        # "auto" (default) = the workspace's own policy word, read by the kernels themselves (round 4: no host poll, valid under
+        # HIP-graph replay): sampled until a call overflows, tight from then on; the first call of a shape re-runs tight in-stream.
         self.topk_threshold = "auto"
-        self._topk_tight = False
-        self._topk_shape = None
-        self._topk_calls = 0
-        self._topk_verdicts = {}       # input shape -> (tight, calls): tiled inference alternates between interior and edge tile shapes,
-                                       # and a single slot forgot its verdict at every switch (2.7 ms redo pass + a host poll each time)
         self._served_streak = 0
         self._served_streaks = {}      # the same for adaptive_sync = "auto"
         self._served_shape = None
@@ -176,9 +171,20 @@ class CE(nn.Module):
         self.profile = None            # optional ops.StageProfile (benchmark instrumentation)
 
     def reset_topk_policy(self):
-        """Forget what ``topk_threshold = "auto"`` has learnt about the input shapes seen so far."""
-        self._topk_shape, self._topk_tight, self._topk_calls = None, False, 0
-        self._topk_verdicts.clear()
+        """Forget what ``topk_threshold = "auto"`` has learnt: the policy word lives in the workspace and starts afresh with a cold
+        one (the next call re-packs the weights there)."""
+        self._pack_key = None
+
+    def topk_policy_is_tight(self) -> bool:
+        """Whether this module's workspace has switched to the tight threshold (bit 3 of ``dagl_ce_range_check``; one host
+        synchronisation; reads -- and clears, if set -- the sticky range word like ``range_ok``)."""
+        if self._last_call is None or self.select_mode == "adaptive" or self.scan == "exact":
+            return False
+        shape, dev = self._last_call
+        bad = ops.ce_range_check(shape, self.select_mode, min(int(self.select_k), shape[2] * shape[3]), self._ws, dev)
+        if bad & 1:
+            self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
+        return bool(bad & 8)
 
     def range_ok(self) -> bool:
         """False when the last inference call on this module met operands outside the split-fp16 range (|activation| >=
@@ -197,8 +203,6 @@ class CE(nn.Module):
             self._served_streak = 0
         if bad & 1:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
-        if (bad & 4) and self.topk_threshold == "auto":
-            self._topk_tight = True                # the sampled threshold let too many keys through: every second key tile from now on
         return not (bad & 3)
 
     def _note_range_violation(self, what):
@@ -415,17 +419,15 @@ class CE(nn.Module):
             self._served_streak = self._served_streaks.get(self._served_shape, 0)
         no_wait = (self.select_mode == "adaptive" and self.scan != "exact" and not hint and self.adaptive_sync == "auto"
                    and self._served_streak >= 4 and key == self._pack_key and self.profile is None)
-        if self._topk_shape != tuple(b.shape[1:]):
-            if self._topk_shape is not None:
-                self._topk_verdicts[self._topk_shape] = (self._topk_tight, self._topk_calls)
-            self._topk_shape = tuple(b.shape[1:])
-            self._topk_tight, self._topk_calls = self._topk_verdicts.get(self._topk_shape, (False, 0))
-        tight = self.select_mode != "adaptive" and self.scan != "exact" and \
-            (self.topk_threshold == "full" or (self.topk_threshold == "auto" and self._topk_tight))
+        if self.topk_threshold not in ("auto", "full", "sparse"):
+            raise DaglError(f"CE.topk_threshold {self.topk_threshold!r}: expected 'auto', 'full' or 'sparse'")
+        topk_screen = self.select_mode != "adaptive" and self.scan != "exact"
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
-                                         dense_hint=hint, want_info=want_info, no_wait=no_wait, tight_topk=tight)
+                                         dense_hint=hint, want_info=want_info, no_wait=no_wait,
+                                         tight_topk=topk_screen and self.topk_threshold == "full",
+                                         sampled_topk=topk_screen and self.topk_threshold == "sparse")
         self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
         self._last_call = (tuple(b.shape), b.device)
         if no_wait:
@@ -442,9 +444,7 @@ class CE(nn.Module):
             # no host round trip in the top-k modes: look at the range word every 64th call (one synchronisation); a call
             # that left the range has returned NaN (never wrong numbers), the module moves to the fp32 path from here on
             self._calls_since_range_check += 1
-            self._topk_calls += 1
-            if self._calls_since_range_check >= 64 or (self._topk_calls == 1 and self.topk_threshold == "auto"
-                                                      and not torch.cuda.is_current_stream_capturing()):
+            if self._calls_since_range_check >= 64 and not torch.cuda.is_current_stream_capturing():
                 self.range_ok()
         if info is not None:
             self.last_info = info

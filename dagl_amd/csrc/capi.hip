@@ -101,6 +101,7 @@ struct Plan {
     int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
     int s_splits, s_steps_per_split, s_steps, s_sample, s_qblock;   // bf16 screen (screen.hip)
     int capseg, capseg_alloc;
+    int s_sample_tight = 0, capseg_tight = 0;             // top-k modes behind the screen: the tight threshold's pair (DAGL_FLAG_TIGHT_TOPK)
     int width;                      // neighbour-list width of the fixed-width paths
     int ovf_cap;                    // adaptive lists behind the screen: queries that may be redone one by one (overflow.hip)
     // byte offsets into the workspace
@@ -124,7 +125,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK | DAGL_FLAG_SAMPLED_TOPK)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE)
@@ -207,10 +208,10 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         while (p.capseg_alloc < 8 * p.capseg && p.capseg_alloc < 256 &&
                (size_t)B * g.L * p.s_splits * 2 * (2 * (size_t)p.capseg_alloc) * sizeof(int2) <= ((size_t)1 << 30))
             p.capseg_alloc *= 2;
-        if (mode_flags & DAGL_FLAG_TIGHT_TOPK) {
-            p.s_sample = (p.capseg_alloc >= 8 * p.capseg && p.s_sample >= 2) ? 2 : 1;
-            p.capseg = p.capseg_alloc;
-        }
+        // the tight pair: forced by the flag, or taken by the kernels themselves once the workspace's policy word says so
+        p.s_sample_tight = (p.capseg_alloc >= 8 * p.capseg && p.s_sample >= 2) ? 2 : 1;
+        p.capseg_tight = p.capseg_alloc;
+        if (mode_flags & DAGL_FLAG_TIGHT_TOPK) { p.s_sample = p.s_sample_tight; p.capseg = p.capseg_tight; }
     }
 
     const size_t BL = (size_t)B * g.L;
@@ -230,7 +231,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.o_rowoff = carve(off, (BL + 1) * sizeof(int64_t));
     p.o_deg = carve(off, BL * sizeof(int32_t));
     p.o_stats = carve(off, 16 * sizeof(int64_t));         // [0..3] per-call counters, [4] range word, [5] tag of the last completed call,
-                                                          // [6] redone rows, [7] their edges, [8] veto word (DAGL_FLAG_NO_WAIT)
+                                                          // [6] redone rows, [7] their edges, [8] veto word (DAGL_FLAG_NO_WAIT),
+                                                          // [9] top-k threshold policy (sticky), [10] gate of the in-call re-run
     if (mode == DAGL_MODE_ADAPTIVE) {
         p.o_lidx = carve(off, BL * DAGL_FAST_CAP * sizeof(int32_t));
         p.o_lval = carve(off, BL * DAGL_FAST_CAP * sizeof(float));
@@ -382,6 +384,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     const bool prepared = fin && p.split16 && (mode_flags & DAGL_FLAG_WEIGHTS_PACKED);
     if (rt.word != nullptr && !prepared) DAGL_HIP_TRY(hipMemsetAsync(stats + 4, 0, 2 * sizeof(int64_t), s));   // fresh workspace
     if (!prepared && mode == DAGL_MODE_ADAPTIVE) DAGL_HIP_TRY(hipMemsetAsync(stats + 8, 0, sizeof(int64_t), s));
+    // top-k modes behind the screen: the threshold policy lives in the workspace (include/dagl_ce.h DAGL_FLAG_TIGHT_TOPK); a cold
+    // workspace starts with the sampled threshold and a closed gate
+    const bool topk_policy = p.screen && mode != DAGL_MODE_ADAPTIVE && !(mode_flags & (DAGL_FLAG_TIGHT_TOPK | DAGL_FLAG_SAMPLED_TOPK)) &&
+                             p.capseg_tight > 0 && (p.capseg_tight != p.capseg || p.s_sample_tight != p.s_sample);
+    int32_t* policy_w = reinterpret_cast<int32_t*>(stats + 9);
+    int32_t* gate_w = reinterpret_cast<int32_t*>(stats + 10);
+    if (topk_policy && !prepared) DAGL_HIP_TRY(hipMemsetAsync(stats + 9, 0, 2 * sizeof(int64_t), s));
     if (core) {
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
     } else if (fin) {
@@ -590,6 +599,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample; sc.qblock = p.s_qblock;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand = at<int2>(ws, p.o_scand);
+        if (topk_policy) { sc.policy = policy_w; sc.sample_tight = p.s_sample_tight; sc.capseg_tight = p.capseg_tight; }
         redo = at<int32_t>(ws, p.o_redo);
 #ifdef DAGL_ABLATION
         { static const int var = [] { const char* e = getenv("DAGL_SCREEN_VARIANT"); return e ? atoi(e) : 0; }(); sc.variant = var; }
@@ -663,7 +673,24 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             ra.heavy_list = at<int32_t>(ws, p.o_heavy); ra.heavy_count = reinterpret_cast<int32_t*>(stats + 3) + 1;   // (cleared with the counters)
             ovf_active = true;
         }
+        if (topk_policy) { ra.policy = policy_w; ra.capseg_tight = p.capseg_tight; }
         if ((rc = launch_refine(s, ra))) return rc;
+        if (topk_policy && !prepared) {
+            // cold workspace: did the sampled threshold overflow most queries' slots (natural-image features)?  Then the policy word
+            // flips here and sampling, threshold, filter and refine run once more, tight, in this very call -- four launches that
+            // exit at once otherwise -- instead of every query group taking the fp32 redo pass (2.7 ms at 256^2)
+            if ((rc = launch_topk_policy(s, stats, policy_w, gate_w, redo, (int)(B * n_qgroups), (long long)BL))) return rc;
+            ScreenArgs sc2 = sc; sc2.gate = gate_w;
+            if ((rc = launch_screen(s, sc2, 0))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc2.gmax, at<float>(ws, p.o_theta), gate_w))) return rc;
+            // (the intersection mode takes the larger of the two thresholds: max(adaptive, theta) is idempotent, so the ungated
+            // kernel is harmless when the re-run did not run)
+            if (mode != DAGL_MODE_TOPK && !fused_theta)
+                if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta), true))) return rc;
+            if ((rc = launch_screen(s, sc2, 1))) return rc;
+            RefineArgs ra2 = ra; ra2.gate = gate_w;
+            if ((rc = launch_refine(s, ra2))) return rc;
+        }
         if (info) info->path = 3;
         if (mode == DAGL_MODE_ADAPTIVE) {
             // Dense neighbourhoods need host-side CSR sizing, so the verdict must be read back.  Everything it consists of
@@ -775,7 +802,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if (p.screen) {
                 // redo pass behind the screen: scan + merge of the flagged groups in one launch (exits after one load when nothing
                 // is flagged); its grid barrier counts in stats[3] (cleared with the call's counters, unused by the top-k modes)
-                if ((rc = launch_topk_redo(s, sa, ea, mode == DAGL_MODE_TOPK ? 2 : 3, reinterpret_cast<unsigned*>(stats + 3)))) return rc;
+                if ((rc = launch_topk_redo(s, sa, ea, mode == DAGL_MODE_TOPK ? 2 : 3, reinterpret_cast<unsigned*>(stats + 3),
+                                           topk_policy ? policy_w : nullptr))) return rc;
             } else {
                 if ((rc = launch_score_select(s, sa, mode == DAGL_MODE_TOPK ? 2 : 3))) return rc;
                 prof_mark(prof, s, 5);
@@ -962,6 +990,11 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
     *violated = ((int32_t)h[0] != 0) ? 1 : 0;
     // bit 2 (not sticky: the count is cleared by every call): the last call's redo pass of the top-k modes had work
     if ((mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen && h4[0] > 0) *violated |= 4;
+    if ((mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen) {            // bit 3: the workspace's threshold policy word says "tight"
+        int64_t v[1] = {0};
+        if ((rc = read_back((hipStream_t)stream, st + 9, 1, v))) return rc;
+        if ((int32_t)v[0] != 0) *violated |= 8;
+    }
     if (*violated) DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream));
     if ((mode & 0xff) == DAGL_MODE_ADAPTIVE) {           // bit 1: a DAGL_FLAG_NO_WAIT call was not served in-stream (likewise sticky)
         int64_t v[1] = {0};

@@ -370,7 +370,8 @@ struct EdgeArgs {
 };
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
 // top-k modes behind the screen: exact scan + merge of the FLAGGED query groups in one launch (select.hip); barrier = a zeroed word
-int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass /*2 topk, 3 adaptive-topk*/, unsigned* barrier);
+int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass /*2 topk, 3 adaptive-topk*/, unsigned* barrier,
+                     int32_t* policy = nullptr /* workspace policy word: set when more than an eighth of the queries are flagged */);
 
 struct AggArgs {
     int B; Grid g;
@@ -408,9 +409,17 @@ struct ScreenArgs {
     const int32_t* run_flags;
     int variant;                    // debug ablations (DAGL_SCREEN_VARIANT): 1 no DMA, 2 no MFMA, 4 no epilogue
     unsigned long long* times;      // ablation builds: [blocks][4] 100 MHz stamps (entry, loop start, loop end, exit) or null
+    // top-k threshold policy kept on the device (include/dagl_ce.h DAGL_FLAG_TIGHT_TOPK): *policy != 0 -> the kernels take
+    // sample_tight / capseg_tight instead of sample / capseg; *gate == 0 -> the launch exits at once (the in-call re-run of a
+    // cold workspace).  Null pointers: the host's values as they are.
+    const int32_t* policy; const int32_t* gate; int sample_tight, capseg_tight;
 };
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
-int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta);
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate = nullptr);
+// top-k modes, cold workspace: after the first refine -- more than an eighth of the queries overflowed their candidate slots under
+// the sampled threshold: switch the workspace's policy word to the tight threshold, open the gate of the re-run launches and
+// clear what the first pass left in the redo flags and counters
+int launch_topk_policy(hipStream_t s, int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags, long long n_queries);
 int launch_adaptive_theta(hipStream_t s, size_t n, const float* mt, const float* bs, float* theta, bool both = false);
 
 struct RefineArgs {
@@ -427,6 +436,7 @@ struct RefineArgs {
     int32_t* ovf_list; int32_t* ovf_count; int ovf_cap;    // adaptive mode: overflowed queries are listed for the per-query redo
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
     int32_t* heavy_list; int32_t* heavy_count;      // adaptive mode: queries with many candidates, refined by a whole block each
+    const int32_t* policy; const int32_t* gate; int capseg_tight;     // as in ScreenArgs
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
 int refine_heavy_cap();

@@ -66,6 +66,8 @@ __device__ __forceinline__ void load_query_fragments(const ScreenArgs& a, int b,
 // fragments from registers, 32 no barrier, 64 accumulators carried across steps.
 template <int PASS, int QW, int VAR, int SCR_QUERIES = 256>
 __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1) void screen_kernel(ScreenArgs a, int n_qgroups) {
+    if (a.gate != nullptr && *a.gate == 0) return;                 // (a re-run launch of a cold workspace that is not needed)
+    if (a.policy != nullptr && *a.policy != 0) { a.capseg = a.capseg_tight; a.sample = a.sample_tight; }   // device-side threshold policy
     constexpr int WAVES = SCR_QUERIES / 32 / QW;
     // key tiles in flight: a tile is requested NBUF-1 steps before it is multiplied.  LDS-DMA lands a tile ~2 us after its
     // request under load, a step's matrix work is 1.45 us: with two buffers (request one step ahead) every step ends waiting
@@ -293,6 +295,8 @@ constexpr int RING_FLAG_BYTES = 64;
 // words per multiply)
 template <int PASS, int WAVES, int VAR = 0, int QW = 1>
 __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a, int n_qgroups) {
+    if (a.gate != nullptr && *a.gate == 0) return;                 // (a re-run launch of a cold workspace that is not needed)
+    if (a.policy != nullptr && *a.policy != 0) { a.capseg = a.capseg_tight; a.sample = a.sample_tight; }   // device-side threshold policy
     // ONE shared object (a second one makes hipcc drain vmcnt(0) in front of every ds_read of the loop)
     __shared__ __attribute__((aligned(16))) unsigned short smem[RING_NBUF * STEP_ELEMS + RING_FLAG_BYTES / 2];
     unsigned* const flags = reinterpret_cast<unsigned*>(smem + RING_NBUF * STEP_ELEMS);     // ready[0..4] at +0, done[0..4] at +32 bytes
@@ -599,6 +603,8 @@ __device__ __forceinline__ void screen_rest(unsigned rest, float sv, int kbase, 
 // are enough to keep the pipe fed.
 template <int PASS, int WAVES, int VAR = 0, int QW = 1>
 __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a, int n_qgroups) {
+    if (a.gate != nullptr && *a.gate == 0) return;                 // (a re-run launch of a cold workspace that is not needed)
+    if (a.policy != nullptr && *a.policy != 0) { a.capseg = a.capseg_tight; a.sample = a.sample_tight; }   // device-side threshold policy
     // ONE shared object (a second one makes hipcc drain vmcnt(0) in front of every ds_read of the loop)
     __shared__ __attribute__((aligned(16))) unsigned short smem[RING_NBUF * STEP_ELEMS + RING_FLAG_BYTES / 2];
     unsigned* const flags = reinterpret_cast<unsigned*>(smem + RING_NBUF * STEP_ELEMS);     // ready[0..4] at +0, done[0..4] at +32 bytes
@@ -931,7 +937,8 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 // ---- theta: k-th largest group maximum per query (one wave per query, values in registers) -------------------
 constexpr int THETA_PER_LANE = 8;                // G <= 512
 __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, int k, const float* __restrict__ gmax,
-                                                           float* __restrict__ theta) {
+                                                           float* __restrict__ theta, const int32_t* gate) {
+    if (gate != nullptr && *gate == 0) return;
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (size_t)n_rows) return;
@@ -964,9 +971,9 @@ __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, in
     if (lane == 0) theta[row] = (kth > 0.f) ? kth * ((1.0f - DELTA) / (1.0f + DELTA)) : 0.0f;
 }
 
-int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta) {
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate) {
     if (G > 64 * THETA_PER_LANE) { set_error("screen_theta: %d groups exceed %d", G, 64 * THETA_PER_LANE); return DAGL_ERR_INVALID; }
-    hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta);
+    hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta, gate);
     DAGL_LAUNCH_CHECK("screen_theta_kernel");
     return DAGL_OK;
 }
@@ -1307,6 +1314,8 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
 __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
     __shared__ int c_idx[4][RF_MAX_CAND];
     __shared__ float c_val[4][RF_MAX_CAND];
+    if (a.gate != nullptr && *a.gate == 0) return;
+    if (a.policy != nullptr && *a.policy != 0) a.capseg = a.capseg_tight;
     const int w = threadIdx.x >> 6;
     dbg_stamp(a.times, blockIdx.x, 0);
     const size_t ql = (size_t)blockIdx.x * 4 + w;
@@ -1377,5 +1386,22 @@ int launch_refine(hipStream_t s, const RefineArgs& a) {
     return DAGL_OK;
 }
 int refine_heavy_cap() { return RF_HEAVY_CAP; }
+
+__global__ __launch_bounds__(256) void topk_policy_kernel(int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags,
+                                                          long long n_queries) {
+    __shared__ int go;
+    if (threadIdx.x == 0) go = (*policy == 0 && stats[2] * 8 > n_queries) ? 1 : 0;
+    __syncthreads();
+    if (!go) return;
+    for (int e = threadIdx.x; e < n_flags; e += blockDim.x) redo_flags[e] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { stats[0] = 0; stats[1] = 0; stats[2] = 0; *policy = 1; *gate = 1; }
+}
+
+int launch_topk_policy(hipStream_t s, int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags, long long n_queries) {
+    hipLaunchKernelGGL(topk_policy_kernel, dim3(1), dim3(256), 0, s, stats, policy, gate, redo_flags, n_flags, n_queries);
+    DAGL_LAUNCH_CHECK("topk_policy_kernel");
+    return DAGL_OK;
+}
 
 }  // namespace dagl

@@ -285,10 +285,13 @@ int launch_score_select(hipStream_t s, const SelectArgs& a, int pass) {
 template <int PASS, int K>
 __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(SelectArgs a, EdgeArgs e, int kslots, int n_qgroups, int n_tiles,
                                                                          int rows_q, int rows_x, int n_units, unsigned n_merge_blocks,
-                                                                         unsigned* barrier) {
+                                                                         unsigned* barrier, int32_t* policy) {
     __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB; the merge's candidate arrays (32 KiB) reuse it
     static_assert(sizeof(float) * 2 * TILE_LDS >= (sizeof(float) + sizeof(int)) * 4 * TOPK_MAX_CAND, "merge arrays fit the scan's tiles");
     if (*a.run_count == 0) return;                                       // nothing flagged anywhere (the usual case)
+    // the workspace's threshold policy (include/dagl_ce.h DAGL_FLAG_TIGHT_TOPK): more than an eighth of the queries flagged under
+    // the sampled threshold -> the tight threshold from the next call on (sticky; this call pays the exact scan once)
+    if (policy != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && *a.run_count * 8 > (long long)a.B * a.L) *policy = 1;
     bool wrote = false;
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(Select
     }
 }
 
-int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass, unsigned* barrier) {
+int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass, unsigned* barrier, int32_t* policy) {
     if (a.run_flags == nullptr || a.run_count == nullptr || e.run_flags != a.run_flags || barrier == nullptr || (pass != 2 && pass != 3)) {
         set_error("launch_topk_redo: redo arguments missing");
         return DAGL_ERR_INVALID;
@@ -384,7 +387,7 @@ int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int 
     }
     const dim3 grid(gx, a.B), block(256);
 #define DAGL_REDO(P_, K_) hipLaunchKernelGGL((topk_redo_kernel<P_, K_>), grid, block, 0, s, a, e, ks, n_qgroups, n_tiles, rows_q, rows_x, \
-                                              n_units, n_merge, barrier)
+                                              n_units, n_merge, barrier, policy)
 #define DAGL_REDO_K(P_) switch (ks) { case 4: DAGL_REDO(P_, 4); break; case 8: DAGL_REDO(P_, 8); break; case 16: DAGL_REDO(P_, 16); break; \
                                       case 32: DAGL_REDO(P_, 32); break; default: DAGL_REDO(P_, 64); break; }
     if (pass == 2) { DAGL_REDO_K(2) } else { DAGL_REDO_K(3) }

@@ -52,10 +52,6 @@ class CES(nn.Module):
         self._pack_key = {1: None, 2: None, 3: None}
         self._skip_fused = {1: 0, 2: 0, 3: 0}     # calls for which a stage stays on the per-head path after it met dense masks
         self._fused_calls = {1: 0, 2: 0, 3: 0}    # fused calls since the stage's range word was last looked at
-        self._tight = {1: False, 2: False, 3: False}          # CE.topk_threshold = "auto": the stage moved to the full threshold pass
-        self._tight_shape = {1: None, 2: None, 3: None}
-        self._tight_memo = {1: {}, 2: {}, 3: {}}
-        self._stage_calls = {1: 0, 2: 0, 3: 0}
 
     def _stage(self, s, x):
         heads = [getattr(self, f"c{s}_{h}") for h in (1, 2, 3, 4)]
@@ -77,17 +73,14 @@ class CES(nn.Module):
             wsb = ws.peek(x.device)
             key = (tuple(x.shape), heads[0].select_mode, k_eff, tuple(hd._pack_epoch for hd in heads),
                    tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)
-            if self._tight_shape[s] != tuple(x.shape[1:]):
-                # (per-shape memory: tiled inference alternates between tile shapes, a single slot forgot its verdict every time)
-                if self._tight_shape[s] is not None:
-                    self._tight_memo[s][self._tight_shape[s]] = (self._tight[s], self._stage_calls[s])
-                self._tight_shape[s] = tuple(x.shape[1:])
-                self._tight[s], self._stage_calls[s] = self._tight_memo[s].get(self._tight_shape[s], (False, 0))
-            tight = mode != "adaptive" and (heads[0].topk_threshold == "full" or (heads[0].topk_threshold == "auto" and self._tight[s]))
+            # the top-k threshold policy ("auto") lives in the stage workspace and is read by the kernels themselves (CE.topk_threshold)
+            thr = heads[0].topk_threshold
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),
                                               mix.bias.detach().contiguous(), mode=heads[0].select_mode,
                                               k=k_eff, workspace=ws,
-                                              weights_packed=(key == self._pack_key[s]), tight_topk=tight)
+                                              weights_packed=(key == self._pack_key[s]),
+                                              tight_topk=(mode != "adaptive" and thr == "full"),
+                                              sampled_topk=(mode != "adaptive" and thr == "sparse"))
             self._pack_key[s] = key[:-1] + (ws.peek(x.device).data_ptr(),) if out is not None else None
             self.last_info = info
             violated = False
@@ -96,13 +89,9 @@ class CES(nn.Module):
                 # fused call -- one synchronisation.  A call that left the split-fp16 range has NaN-filled outputs (never
                 # wrong numbers); the heads move to scan = "exact" (which takes them off the fused path) and this call is redone
                 self._fused_calls[s] += 1
-                self._stage_calls[s] += 1
-                if (self._fused_calls[s] >= 64 or (self._stage_calls[s] == 1 and heads[0].topk_threshold == "auto")) \
-                        and not torch.cuda.is_current_stream_capturing():
+                if self._fused_calls[s] >= 64 and not torch.cuda.is_current_stream_capturing():
                     self._fused_calls[s] = 0
                     verdict = ops.ce_range_check((4 * x.shape[0],) + tuple(x.shape[1:]), mode, k_eff, ws, x.device)
-                    if (verdict & 4) and heads[0].topk_threshold == "auto":
-                        self._tight[s] = True      # the sampled threshold sent the call to the redo pass (CE.topk_threshold)
                     if verdict & 3:
                         for hd in heads:
                             hd._note_range_violation("a fused CES stage call left the split-fp16 range (outputs NaN-filled)")

@@ -237,9 +237,10 @@ class Workspace:
 @_on_device
 def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adaptive", k: int = 0,
                workspace: "Workspace | None" = None, return_info: bool = False, debug: bool = False,
-               profile: "StageProfile | None" = None, exact_scan: bool = False, tight_topk: bool = False):
-    """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W].  ``tight_topk``:
-    DAGL_FLAG_TIGHT_TOPK (top-k modes behind the screen), as in ``ce_forward_fused``."""
+               profile: "StageProfile | None" = None, exact_scan: bool = False, tight_topk: bool = False,
+               sampled_topk: bool = False):
+    """Everything of CE.forward after its prologue convolutions (dagl.py:216-274) -> [B,16,H,W].  ``tight_topk`` /
+    ``sampled_topk``: DAGL_FLAG_TIGHT_TOPK / DAGL_FLAG_SAMPLED_TOPK (top-k modes behind the screen), as in ``ce_forward_fused``."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -260,8 +261,8 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
     need = lib.dagl_ce_workspace_bytes(B, H, W, mode_flags, int(k))
     if need == 0:
         check(-1, "dagl_ce_workspace_bytes")
-    if tight_topk and mode != "adaptive" and not exact_scan:
-        mode_flags |= _lib.FLAG_TIGHT_TOPK
+    if mode != "adaptive" and not exact_scan:
+        mode_flags |= _lib.FLAG_TIGHT_TOPK if tight_topk else (_lib.FLAG_SAMPLED_TOPK if sampled_topk else 0)
     out = torch.empty(B, 16, H, W, device=b1.device, dtype=torch.float32)
     info = _lib.CeInfo()
     rc = 0
@@ -330,14 +331,17 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
 @_on_device
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
                      profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False,
-                     dense_hint: bool = False, want_info: bool = True, no_wait: bool = False, tight_topk: bool = False):
+                     dense_hint: bool = False, want_info: bool = True, no_wait: bool = False, tight_topk: bool = False,
+                     sampled_topk: bool = False):
     """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
     state_dict names to contiguous fp32 GPU tensors.  Returns (out, info).  ``dense_hint``: go straight to the streamed
     dense formulation (adaptive mode; same result, see DAGL_FLAG_DENSE_HINT); with ``want_info=False`` that path does
     not read its edge statistics back (no host synchronisation) and info is None.  ``no_wait`` (adaptive mode behind the
     screen, DAGL_FLAG_NO_WAIT): the verdict stays on the device, an unserved call is NaN-filled and ``ce_range_check``
     reports it; info is None.  ``tight_topk`` (top-k modes, DAGL_FLAG_TIGHT_TOPK): candidate threshold from every second key tile and
-    eight times the candidate slots -- for maps whose sampled threshold lets too many keys through (natural images); same result."""
+    eight times the candidate slots -- for maps whose sampled threshold lets too many keys through (natural images); same result.
+    ``sampled_topk`` (DAGL_FLAG_SAMPLED_TOPK) forces the sampled threshold; with neither the workspace's own policy word decides
+    on the device (sticky switch to the tight threshold once a call overflowed; a cold workspace re-runs tight in the same call)."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -363,8 +367,8 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
         mode_flags |= _lib.FLAG_DENSE_HINT
         if ws.peek(x.device) is not None:
             need = max(need, ws.peek(x.device).numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
-    if tight_topk and mode != "adaptive" and not exact_scan:
-        mode_flags |= _lib.FLAG_TIGHT_TOPK
+    if mode != "adaptive" and not exact_scan:
+        mode_flags |= _lib.FLAG_TIGHT_TOPK if tight_topk else (_lib.FLAG_SAMPLED_TOPK if sampled_topk else 0)
     quiet = dense_hint and not want_info
     if no_wait and mode == "adaptive" and not exact_scan and not dense_hint and H * W >= 2048:
         mode_flags |= _lib.FLAG_NO_WAIT
@@ -408,13 +412,14 @@ def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> 
     out = C.c_int(0)
     with torch.cuda.device(device):
         check(lib.dagl_ce_range_check(_stream(), B, H, W, MODES[mode], int(k), a, nbytes, C.byref(out)), "dagl_ce_range_check")
-    return int(out.value)            # bit 0: range, bit 1: an unserved no-wait adaptive call, bit 2: the last top-k call had a redo pass
+    return int(out.value)            # bit 0: range, bit 1: an unserved no-wait adaptive call, bit 2: the last top-k call had a redo pass,
+                                     # bit 3: the workspace's top-k threshold policy word says "tight"
 
 
 @_on_device
 def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: int = 0,
                       workspace: "Workspace | None" = None, profile: "StageProfile | None" = None,
-                      weights_packed: bool = False, tight_topk: bool = False):
+                      weights_packed: bool = False, tight_topk: bool = False, sampled_topk: bool = False):
     """One CES stage in one launch set: ``conv1x1(cat(head_1(x)..head_4(x))) + x`` (dagl.py:114,116,118).
     ``head_params``: four dicts (state_dict names -> contiguous fp32 GPU tensors).  Returns (out [B,64,H,W], info), or
     (None, info) when a dense adaptive neighbourhood needs the per-head path."""
@@ -442,7 +447,8 @@ def ces_stage_forward(x, head_params, mix_w, mix_b, mode: str = "adaptive", k: i
     aligned = (base + 255) // 256 * 256
     rc = lib.dagl_ces_stage_forward(_stream(), B, H, W, x.data_ptr(), arr, mix_w.data_ptr(), mix_b.data_ptr(),
                                     MODES[mode] | (_lib.FLAG_WEIGHTS_PACKED if weights_packed else 0) |
-                                    (_lib.FLAG_TIGHT_TOPK if (tight_topk and mode != "adaptive") else 0), int(k),
+                                    ((_lib.FLAG_TIGHT_TOPK if tight_topk else (_lib.FLAG_SAMPLED_TOPK if sampled_topk else 0))
+                                     if mode != "adaptive" else 0), int(k),
                                     out.data_ptr(), aligned, buf.numel() - (aligned - base),
                                     C.byref(info), profile._h if profile is not None else None)
     meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges, max_degree=info.max_degree,

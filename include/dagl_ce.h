@@ -78,9 +78,17 @@ extern "C" {
  * whose scores are spread evenly (the synthetic benchmark features); on natural-image features the k-th best of an eighth of the
  * keys lies 4-25 % below the true one, hundreds to thousands of keys pass it, the slots overflow and most query groups land on
  * the fp32 redo pass (2.6 ms instead of 0.25 at 256^2, tools/time_real_image.py).  Costs half a pass more of the screen's
- * matrix work (+25 us at 256^2); the result is the same either way.  dagl_ce_range_check reports (bit 2) whether the last call's
- * redo pass had work, which is how a caller decides (dagl_amd.CE.topk_threshold = "auto").                                    */
+ * matrix work (+25 us at 256^2); the result is the same either way.
+ * Round 4: WITHOUT either flag the choice is made ON THE DEVICE and kept in the workspace ("policy" word): a call whose sampled
+ * threshold let more than an eighth of the queries overflow their candidate slots switches the workspace to the tight threshold
+ * for good (the word is sticky; kernels read it at their start: no host poll, valid under HIP-graph replay).  On a cold
+ * workspace (no DAGL_FLAG_WEIGHTS_PACKED: the first call of a shape) that call re-runs sampling, filter and refine with the
+ * tight threshold in-stream (four gated launches that exit at once otherwise) instead of sending every query group to the fp32
+ * redo pass: ~0.4 ms instead of 2.7 at 256^2.  DAGL_FLAG_TIGHT_TOPK forces the tight threshold, DAGL_FLAG_SAMPLED_TOPK the
+ * sampled one (tests, benchmarks of that path); dagl_ce_range_check's bit 2 still reports whether the last call's redo pass
+ * had work.                                                                                                                    */
 #define DAGL_FLAG_TIGHT_TOPK     0x1000
+#define DAGL_FLAG_SAMPLED_TOPK   0x2000
 
 #define DAGL_MAX_TOPK            64   /* largest k of the top-k modes (the fixed-k variant defaults to num_edge = 50,
                                          GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
@@ -126,13 +134,15 @@ typedef struct dagl_ce_info {
  *     dense forward re-runs itself in its fp32 form when it reads statistics back (info != NULL, range_fallback = 1).   */
 int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
                         int* violated /* bit 0: range, bit 1: an unserved DAGL_FLAG_NO_WAIT call, bit 2 (top-k modes, not sticky):
-                                         the LAST call's redo pass had flagged query groups (see DAGL_FLAG_TIGHT_TOPK) */);
+                                         the LAST call's redo pass had flagged query groups (see DAGL_FLAG_TIGHT_TOPK), bit 3 (top-k
+                                         modes): the workspace's threshold policy word has switched to the tight threshold */);
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
- * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64).  A caller compares
+ * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64; round 4: DAGL_FLAG_SAMPLED_TOPK,
+ * the workspace layout carries the top-k policy words).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 302
+#define DAGL_ABI_VERSION 401
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */

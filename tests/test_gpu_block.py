@@ -32,14 +32,16 @@ def _module(params, mode="adaptive", k=0, scan="screened"):
     return ce.to(_dev()).eval()
 
 
-def _run_debug(ce, x):
-    """Module prologue + debug forward: out, info with deg / rowsum / agg."""
+def _run_debug(ce, x, sampled_topk=False):
+    """Module prologue + debug forward: out, info with deg / rowsum / agg.  ``sampled_topk``: DAGL_FLAG_SAMPLED_TOPK (keep the
+    sampled threshold: the workspace's own policy would re-run an overflowing cold call with the tight one)."""
     from dagl_amd import ops
     with torch.no_grad():
         b1, b2, thr, bias = ce._prologue(x)
         out, info = ops.ce_forward(b1.contiguous(), b2.contiguous(), thr.contiguous(), bias.contiguous(),
                                    ce.fc1[0].weight, ce.fc1[0].bias, ce.fc2[0].weight, ce.fc2[0].bias,
-                                   mode=ce.select_mode, k=ce.select_k, debug=True, exact_scan=(ce.scan == "exact"))
+                                   mode=ce.select_mode, k=ce.select_k, debug=True, exact_scan=(ce.scan == "exact"),
+                                   sampled_topk=sampled_topk)
     return out, info
 
 
@@ -124,10 +126,16 @@ def test_screen_overflow_is_redone_by_the_fp32_scan():
     res = {}
     for scan in ("screened", "exact"):
         ce = _module(params, "topk", 8, scan)
-        res[scan] = _run_debug(ce, x)
+        res[scan] = _run_debug(ce, x, sampled_topk=True)
     assert res["screened"][1]["path"] == 3 and res["screened"][1]["redone_queries"] > 0
     assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
     assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
+    # the workspace's own policy (no flag): this cold call flips to the tight threshold and re-runs in-stream -- eight times the
+    # slots hold a 64 x 64 map's candidates, nothing is left for the fp32 pass -- with the same neighbours and numbers
+    out_p, info_p = _run_debug(_module(params, "topk", 8, "screened"), x)
+    assert info_p["path"] == 3 and info_p["redone_queries"] == 0
+    assert torch.equal(info_p["deg"], res["exact"][1]["deg"])
+    assert normwise(out_p.cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
 
 
 @pytest.mark.parametrize("mode,k", [("topk", 8), ("adaptive_topk", 12)])
@@ -144,7 +152,7 @@ def test_redo_of_one_image_of_a_batch(mode, k):
     res = {}
     for scan in ("screened", "exact"):
         ce = _module(params, mode, k, scan)
-        res[scan] = _run_debug(ce, x)
+        res[scan] = _run_debug(ce, x, sampled_topk=True)
     L = 16 * 16
     assert res["screened"][1]["path"] == 3 and 0 < res["screened"][1]["redone_queries"] < 3 * L
     assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])

@@ -197,8 +197,17 @@ def _oracle_ce_cls():
 
         def forward(self, b):
             prm = {n: p for n, p in self.named_parameters() if not n.startswith("W.")}
-            return ce_forward_oracle(b, prm, mode=self.select_mode, k=self.select_k if self.select_mode != "adaptive" else None,
-                                     dtype=b.dtype)
+            if self.select_mode == "adaptive":
+                return ce_forward_oracle(b, prm, mode="adaptive", k=None, dtype=b.dtype)
+            out, st = ce_forward_oracle(b, prm, mode=self.select_mode, k=self.select_k, dtype=b.dtype, stages=True)
+            # how close this head comes to a tie between its k-th and (k+1)-th neighbour: a fixed-k selection is discontinuous there,
+            # and two evaluations that differ in the last bits of a score may resolve it differently
+            with torch.no_grad():
+                S = st["S"].detach()
+                kk = min(int(self.select_k), S.shape[-1] - 1)
+                top = S.topk(kk + 1, dim=-1).values
+                self.min_topk_gap = float(((top[..., kk - 1] - top[..., kk]) / top[..., kk - 1].abs().clamp_min(1e-30)).min())
+            return out
     return OracleCE
 
 
@@ -247,9 +256,30 @@ def test_config5_whole_network_gradients_match_oracle_autograd(mode, k):
                   if p.requires_grad and gref[n].grad is not None), reverse=True)[:5]
     print(f"[config5 gradients, {mode}] median {float(np.median(errs)):.2e}; worst tensors: " + ", ".join(f"{n} {e:.2e}" for e, n in top))
     if mode == "topk":
-        # fixed-k selection is discontinuous: one near-tie between an 8th and a 9th neighbour in one of the 12 heads, resolved
-        # differently by fp64 and fp32 scores, moves that head's gradients by ~1e-2 while everything else agrees
-        assert float(np.median(errs)) <= 1e-3 and worst[1] <= 5e-2, (worst, float(np.median(errs)))
+        # fixed-k selection is discontinuous: a near-tie between an 8th and a 9th neighbour in one of the 12 heads, resolved
+        # differently by fp64 and fp32 scores, moves THAT head's gradients by ~1e-2 while everything else agrees.  The oracle heads
+        # report their closest call (relative gap between the k-th and (k+1)-th score over all queries, fp64): only the parameters
+        # of heads that come within 1e-6 of a tie get the loose bound, every other tensor of the network the tight one
+        near_tie = {n for n, m in ref.named_modules() if getattr(m, "min_topk_gap", 1.0) < 1e-6}
+        print(f"[config5 gradients, topk] heads within 1e-6 of a k-th / (k+1)-th tie: {sorted(near_tie)}")
+        # a flipped neighbour changes that head's output, hence the gradient that flows BACK through it: the head's own parameters
+        # and everything upstream of it in the forward graph (trunk before the CES, earlier stages, the ResBlocks between them) see
+        # it; the head's siblings and everything downstream (the stage's mix, the trunk behind, the tail) do not
+        loose_prefixes = set()
+        for h in near_tie:                                  # e.g. "body.8.c3_2"
+            ces, stage = h.rsplit(".", 1)[0], int(h.rsplit(".", 1)[1][1])
+            loose_prefixes |= {h + ".", "head."} | {f"body.{i}." for i in range(int(ces.split(".")[1]))}
+            for t in range(1, stage):
+                loose_prefixes |= {f"{ces}.c{t}_", f"{ces}.RBS{t}."}
+        for name, p in net.named_parameters():
+            if not p.requires_grad or gref[name].grad is None:
+                continue
+            e = normwise(p.grad.cpu().numpy(), gref[name].grad.numpy())
+            loose = any(name.startswith(pre) for pre in loose_prefixes)
+            # (everything else still sees the flip at second order -- the activations behind that head move a little, and with them
+            # the gradient that reaches its siblings: 2.1e-3 on one sibling's bias in the committed draw, 3e-4 typical)
+            assert e <= (5e-2 if loose else 3e-3), (name, e, "touched by a near-tie head" if loose else "")
+        assert float(np.median(errs)) <= 1e-3, float(np.median(errs))
     else:
         # dense regime at default-like init: logits of several hundred, so the ~8e-8 relative rounding noise of a score (split-fp16
         # or fp32 alike, tools/mfma_precision.hip) reaches the stage-3 heads' gradients amplified ~1e4 times; which tensor catches it

@@ -82,7 +82,7 @@ def test_topk8_on_set12_features_matches_the_oracle_with_both_thresholds(img):
                 y = ce(x)
         res[pol] = y
         if pol == "auto":
-            assert ce._topk_tight, "the sampled threshold overflows on natural-image features: auto must have switched"
+            assert ce.topk_policy_is_tight(), "the sampled threshold overflows on natural-image features: the device policy must have switched"
     assert normwise(res["full"].cpu().numpy(), res["sparse"].cpu().numpy()) <= 1e-6
     assert normwise(res["auto"].cpu().numpy(), res["full"].cpu().numpy()) <= 1e-6
     assert normwise(res["full"].cpu().numpy(), outs[True].cpu().numpy()) <= TOL

@@ -275,8 +275,9 @@ def test_tight_topk_threshold_same_result(mode, k):
 
 
 def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
-    """A near-constant map sends the sampled-threshold call to the fp32 redo pass; the module (topk_threshold = "auto") sees that in
-    the workspace's verdict after its first call and takes the threshold from every second key tile from then on -- same output."""
+    """A near-constant map overflows the candidate slots under the sampled threshold; with topk_threshold = "auto" the workspace's
+    policy word flips ON THE DEVICE (round 4: no host poll) -- in the very first call, which re-runs tight in-stream -- and every
+    later call takes the threshold from every second key tile: same output."""
     import torch
     from dagl_amd.ce import CE
     from dagl_amd.synth import make_ce_params
@@ -287,9 +288,9 @@ def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
     g = torch.Generator().manual_seed(3)
     x = (0.25 + 1e-2 * torch.randn(1, 64, 64, 64, generator=g)).to(dev)
     with torch.no_grad():
-        assert ce.topk_threshold == "auto" and not ce._topk_tight
+        assert ce.topk_threshold == "auto" and not ce.topk_policy_is_tight()
         y0 = ce(x).clone()
-        assert ce._topk_tight                          # (first call polled: its redo pass had work)
+        assert ce.topk_policy_is_tight()               # (the cold call flipped the word and re-ran tight)
         y1 = ce(x).clone()
         ce.scan = "exact"
         y2 = ce(x)
@@ -301,4 +302,4 @@ def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
     ce2.select_mode, ce2.select_k = "topk", 8
     with torch.no_grad():
         ce2(torch.from_numpy(make_features(5, 1, 64, 64, 64)).to(dev))
-    assert not ce2._topk_tight
+    assert not ce2.topk_policy_is_tight()
