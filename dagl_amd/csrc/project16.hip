@@ -11,12 +11,17 @@
 // the block output: 1.2e-5 normwise against fp64 -- inside the reference's own fp32 noise of 2e-5..6e-5.
 // Range: |16 a| and |1024 w| must stay below 65504 (fp16); the exact scan (project.hip) has no such limit.
 //
-// Tiling: one wave = 32 consecutive patches of a row x 224 (= 7 x 32, 196 real) outputs, 7 accumulators.
-//   A (patches): keys -- per wave a 2-row ring of the hi / lo map rows its patches touch (38 pixels), by LDS-DMA: each
+// Tiling (round 4; project16_body2): a work unit = 8 items of 32 consecutive patches (row-major order) = 256 patches, done by TWO
+// blocks of 4 waves -- one per tile group (output tiles 0-3 / 4-6 of the 7 x 32 = 224 >= 196 outputs) --, a wave = 2 items x the
+// group's tiles (8 or 6 accumulators): a weight fragment read from the LDS feeds two multiply chains, and a block fetches only its
+// group's rows of a tap's weight slice.  (Round 3: a wave = 32 patches x all 7 tiles; per SIMD and tap 6.5 LDS-DMA pieces and 32
+// fragment reads beside 42 multiplies; now 3.5 and 22.)  The overhang of the grid over one resident round is cut into single-tile
+// blocks of 4 items (project16_body<1>).
+//   A (patches): keys -- per item a 2-row ring of the hi / lo map rows its patches touch (38 pixels), by LDS-DMA: each
 //                input pixel is fetched once per kernel ROW, not once per tap; queries (stride-4 grid) -- per tap each lane
 //                DMA-copies the 16 bytes it reads back
-//   B (weights): per tap the [224 outs][hi 16 | lo 16] fp16 slice (14 KiB) is shared by the 4 waves of a block through a
-//                4-stage LDS ring filled by LDS-DMA; the four 16-byte slots of a 64-byte row are stored at
+//   B (weights): per tap the group's rows of the [224 outs][hi 16 | lo 16] fp16 slice (8 / 6 KiB) are shared by the 4 waves of a
+//                block through a 4-stage LDS ring filled by LDS-DMA; the four 16-byte slots of a 64-byte row are stored at
 //                slot ^ ((row >> 2) & 3), which makes the ds_read_b128 of 32 consecutive rows conflict-free unpadded
 #include <stdlib.h>
 
@@ -136,7 +141,8 @@ struct Proj16Args {
     int lin[2];                                                     // items = 32 consecutive patches in ROW-MAJOR order (across row ends)
                                                                     // instead of 32 patches of one row: no idle slots at the row ends
                                                                     // (a 72-pixel row used to cost 3 items = 96 slots)
-    int n_blocks_q, n_blocks_k;
+    int n_blocks_q, n_blocks_k;                                     // 4-item blocks (the rows of colpart; the single-tile blocks)
+    int units_q, units_k;                                           // 8-item units (two blocks each: tile groups 0-3 / 4-6)
     int n_full, n_split_groups, batch;                              // 1-D grid: full blocks, then 7 single-tile blocks per split group
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
     RangeTag range; int heads;                                      // range guard: the packed weights' flags feed the call's word
@@ -490,12 +496,294 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     }
 }
 
+
+// ---- round 4: 64 patches x (4 | 3) output tiles per wave ------------------------------------------------------------------------
+// The round-3 shape (a wave = 32 patches x all 7 output tiles, two 4-wave blocks per CU, each streaming the WHOLE 13 KiB weight
+// slice of a tap) spent as many issue cycles on LDS-DMA pieces and weight-fragment reads as on its multiplies: per SIMD and tap 42
+// multiplies (1344 cycles) beside 6.5 DMA pieces (~110 cycles each) and 32 LDS reads -- 1.13 us per tap against 0.61 of matrix work.
+// Here a wave carries TWO 32-patch items and the tiles of ONE tile group (0-3 or 4-6): a weight fragment feeds two multiplies
+// chains, a block fetches only its group's rows of the slice (8 / 6 KiB), and the two blocks of a CU -- one per group in the usual
+// dispatch -- fetch the slice ONCE between them: 3.5 pieces and 22 reads per SIMD and tap for the same 42 multiplies.
+// 2 x 4 x 16 = 128 accumulator registers: two blocks per CU stay resident (independent barriers, as before).
+constexpr int P16_PW = 2;                                   // 32-patch items per wave
+constexpr int P16_UNIT = P16_BW * P16_PW;                   // items per block (a "unit" = 8 items = 256 patches)
+constexpr int P16_G0 = 4, P16_G1 = P16_NT - P16_G0;         // tiles of the two groups
+constexpr int P16_STAGE2_B = P16_G0 * 2048;                 // bytes per weight stage (the larger group)
+constexpr int P16_OFF_A2 = P16_RING * P16_STAGE2_B;         // 32 KiB: patch region behind the weight ring
+constexpr int P16_LDS2 = P16_OFF_A2 + P16_QRING * P16_BW * P16_PW * 2048;      // 80 KiB (keys use 32 + 8 x 5.5 = 76)
+static_assert(P16_BW * P16_PW * 2 * P16_AROW <= P16_QRING * P16_BW * P16_PW * 2048, "key row rings must fit the patch region");
+static_assert(2 * P16_LDS2 <= 160 * 1024 && P16_LDS2 <= P16_LDS, "two resident blocks per CU, inside the kernel's allocation");
+static_assert(P16_BW * 16 * P16_G0 * 32 * 4 <= P16_OFF_A2, "the epilogue stages 16 rows x its columns per wave in the dead weight ring");
+
+template <int NT, bool KEYS>
+__device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned char* smem, int n0, int unit, int b) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const Grid& gr = pa.gr;
+    constexpr int which = KEYS ? 0 : 1;
+    constexpr int PW = P16_PW;
+    const int head = b / pa.imgs_per_head;
+    const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)head * P16_PACKED_HALFS + (size_t)n0 * 32 * P16_ROWH;
+    const int n_items = pa.n_items[which];
+    const int segs_per_row = pa.segs[which];
+    constexpr int PD = KEYS ? P16_PD_KEYS : P16_PD_Q;
+    constexpr int PIECES = NT * 2;                                           // KiB of the group's rows of a tap slice (tiles 4-6: rows
+                                                                              // 128-223, of which 208-223 are padding never stored)
+    constexpr int PBASE = PIECES / P16_BW;
+    const bool extra = wave < (PIECES % P16_BW);
+    const int row_len = KEYS ? gr.W : gr.Lw;
+    const bool lin = pa.lin[which] != 0;
+
+    int gy[PW], gx0[PW], nA[PW], base_row[PW], lim[PW], off_i[PW];
+    bool item_valid[PW];
+#pragma unroll
+    for (int it = 0; it < PW; ++it) {
+        int item = (unit * P16_BW + wave) * PW + it;
+        item_valid[it] = item < n_items;
+        if (!item_valid[it]) item = n_items - 1;
+        if (lin) {
+            base_row[it] = item * 32;
+            gy[it] = base_row[it] / row_len; gx0[it] = base_row[it] - gy[it] * row_len;
+            nA[it] = row_len - gx0[it] < 32 ? row_len - gx0[it] : 32;
+            lim[it] = (KEYS ? gr.N : gr.L) - base_row[it];
+        } else {
+            gy[it] = item / segs_per_row; gx0[it] = (item % segs_per_row) * 32;
+            nA[it] = 32; base_row[it] = gy[it] * row_len + gx0[it]; lim[it] = row_len - gx0[it];
+        }
+        off_i[it] = (i < nA[it]) ? i : i + 6;        // keys: the patch's pixel position in the staged row (segment B behind A's halo)
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+    f32x16 hh[PW][NT];
+#pragma unroll
+    for (int it = 0; it < PW; ++it)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[it][n][r] = 0.f;
+
+    auto issue_w = [&](int t) {                        // the group's rows of tap t's weight slice -> ring stage t % RING
+        const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE2_B;
+        const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
+#pragma unroll
+        for (int j = 0; j < PBASE; ++j) {
+            const int p = wave + P16_BW * j;
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
+        if (extra) {
+            const int p = wave + P16_BW * PBASE;
+            glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
+    };
+    // ---- patch operand plumbing (per item) ---------------------------------------------------------------------------------------
+    const unsigned short* ahi[PW]; const unsigned short* alo[PW];                // queries: this lane's patch corner
+    const size_t krow0 = (size_t)b * gr.Hp * gr.Wp * CH;                          // keys: halfs offset of the image's map
+#pragma unroll
+    for (int it = 0; it < PW; ++it) {
+        ahi[it] = alo[it] = nullptr;
+        if (!KEYS) {
+            int qy = gy[it], gx = gx0[it] + i;
+            if (lin) { int q = base_row[it] + i; if (q > gr.L - 1) q = gr.L - 1; qy = q / row_len; gx = q - qy * row_len; }
+            else if (gx >= row_len) gx = row_len - 1;
+            const int py = QS * qy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
+            const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
+            ahi[it] = pa.map_hi + aoff; alo[it] = pa.map_lo + aoff;
+        }
+    }
+    auto issue_row = [&](int r) {                      // keys: kernel row r of both items (44 pixels, hi | lo) -> row buffer r & 1
+#pragma unroll
+        for (int it = 0; it < PW; ++it) {
+            const unsigned dst = lds0 + P16_OFF_A2 + (wave * PW + it) * (2 * P16_AROW) + (r & 1) * P16_AROW;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {              // pieces: hi px 0-31, hi px 32-43 (24 lanes), lo px 0-31, lo px 32-43
+                const int p = (j & 1) * 32 + (lane >> 1);
+                int row = gy[it] + r, px = gx0[it] + p;
+                if (p >= nA[it] + 6) { row += 1; px = p - (nA[it] + 6); }
+                if (px > gr.Wp - 1) px = gr.Wp - 1;                                   // stay inside the map
+                if (row > gr.Hp - 1) row = gr.Hp - 1;
+                const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
+                const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
+                if ((j & 1) == 0 || lane < 2 * (P16_APX - 32)) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
+            }
+        }
+    };
+    auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back, both items
+        const int kh = t / KS, kw = t - kh * KS;
+        const size_t o = ((size_t)kh * gr.Wp + kw) * CH;
+#pragma unroll
+        for (int it = 0; it < PW; ++it) {
+            const unsigned sa = lds0 + P16_OFF_A2 + (unsigned)(t % P16_QRING) * (P16_BW * PW * 2048) + (wave * PW + it) * 2048;
+            glds16_asm(reinterpret_cast<const float*>(ahi[it] + o), __builtin_amdgcn_readfirstlane(sa));
+            glds16_asm(reinterpret_cast<const float*>(alo[it] + o), __builtin_amdgcn_readfirstlane(sa + 1024));
+        }
+    };
+    constexpr int PER_Q = KEYS ? 0 : 2 * PW;
+#define P16_WAIT2(P) do { if (extra) dma_wait_le<(P) * (PBASE + 1 + PER_Q)>(); else dma_wait_le<(P) * (PBASE + PER_Q)>(); } while (0)
+
+    const int swz = (i >> 2) & 3;                                       // slot swizzle of row n*32 + i (n*32 does not change it)
+    const int boff_hi = i * (P16_ROWH * 2) + ((h ^ swz) << 4);          // bytes: B fragment row n*32 + i, hi half h
+    const int boff_lo = i * (P16_ROWH * 2) + (((2 + h) ^ swz) << 4);
+
+    if (KEYS) issue_row(0);
+#pragma unroll
+    for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
+    P16_WAIT2(PD - 1);
+    __syncthreads();
+
+    auto compute = [&](int step) {
+        const int kh = step / KS, kw = step - kh * KS;
+        f16x8 fa_hi[PW], fa_lo[PW];
+#pragma unroll
+        for (int it = 0; it < PW; ++it) {
+            const unsigned char* sa;
+            int lo_off;
+            if (KEYS) { sa = smem + P16_OFF_A2 + (wave * PW + it) * (2 * P16_AROW) + (kh & 1) * P16_AROW + (off_i[it] + kw) * 32 + 16 * h; lo_off = P16_APART; }
+            else { sa = smem + P16_OFF_A2 + (step % P16_QRING) * (P16_BW * PW * 2048) + (wave * PW + it) * 2048 + lane * 16; lo_off = 1024; }
+            fa_hi[it] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
+            fa_lo[it] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
+        }
+        const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE2_B;
+        f16x8 w_hi[NT], w_lo[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            w_hi[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_hi));
+            w_lo[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_lo));
+        }
+        // the two cross terms (2^-11 of the main one) go into the same accumulator: small terms first; a weight fragment feeds both items
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[it], w_lo[n], hh[it][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[it], w_hi[n], hh[it][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[it], w_hi[n], hh[it][n], 0, 0, 0);
+    };
+    for (int step = 0; step < P16_STEPS - PD; ++step) {
+        if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
+        issue_w(step + PD);
+        if (!KEYS) issue_q(step + PD);
+        compute(step);
+        P16_WAIT2(PD - 1);
+        __syncthreads();
+    }
+    if (PD == 3) { compute(P16_STEPS - 3); P16_WAIT2(1); __syncthreads(); }
+    compute(P16_STEPS - 2); P16_WAIT2(0); __syncthreads();
+    compute(P16_STEPS - 1);
+    __syncthreads();
+#undef P16_WAIT2
+
+    // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i]: this block's columns [c0, c0 + cw) of the rows ----
+    float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
+    uint16_t* hb = pa.feat_h[which] ? pa.feat_h[which] + (size_t)b * pa.rows_alloc_h[which] * DSH : nullptr;
+    const float* __restrict__ fbias = pa.bias[which][head];
+    constexpr int SEG = NT * 32;                                        // staged columns per row
+    const int c0 = n0 * 32;
+    const int cw = (c0 + SEG <= DS) ? SEG : DS - c0;                    // fp32 columns stored (tiles 4-6: 128 .. 203)
+    const int cwh = (c0 + SEG <= DPAD) ? SEG : DPAD - c0;               // bf16 columns with data (.. 207; the row-major copy pads to 216)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * SEG);    // [16 rows][SEG] floats in the dead weight ring
+    float colsum_r[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) colsum_r[n] = 0.f;
+#pragma unroll
+    for (int it = 0; it < PW; ++it) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = c0 + n * 32 + i;
+                const float bv = (col < D) ? fbias[col] : 0.0f;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = 8 * pass + r8;
+                    const int rl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;              // row inside the pass: 0..15
+                    const int rr = rl + 16 * pass;
+                    float v = hh[it][n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
+                    v = v > 0.f ? v : 0.f;
+                    if (col >= D) v = 0.f;
+                    stg[rl * SEG + n * 32 + i] = v;
+                    colsum_r[n] += (item_valid[it] && rr < lim[it]) ? v : 0.f;
+                }
+            }
+            // (the wave only reads back what it wrote itself: LDS operations of a wave execute in order, no barrier)
+            const int rows_here = item_valid[it] ? (lim[it] - 16 * pass < 16 ? (lim[it] - 16 * pass < 0 ? 0 : lim[it] - 16 * pass) : 16) : 0;
+            {
+                const int cpr = cw / 4;                                          // float4 chunks per row: 32 or 19
+                float* dst = fb + (size_t)(base_row[it] + 16 * pass) * DS + c0;
+#pragma unroll
+                for (int j = 0; j < (16 * (SEG / 4) + 63) / 64; ++j) {
+                    const int e = lane + 64 * j;
+                    const int row = e / cpr, c4 = e - row * cpr;
+                    if (row < rows_here)
+                        *reinterpret_cast<float4*>(dst + (size_t)row * DS + 4 * c4) = *reinterpret_cast<const float4*>(stg + row * SEG + 4 * c4);
+                }
+            }
+            if (hb != nullptr) {
+                const bool tiled = pa.tiled_h[which] != 0;
+                // bf16 copy, 8-column chunks: row-major rows of 216 halfs (chunks c0/8 .. ; columns 196.. zero, the last group pads to
+                // 216) or the screen's fragment order (26 chunks of 16 rows per 16-row half, ScreenArgs::q_tiled)
+                const int ch0 = c0 / 8;
+                const int nch = tiled ? cwh / 8 : ((c0 + SEG >= DPAD) ? (DSH / 8 - ch0) : SEG / 8);      // 16 | 10 (tiled) / 16 | 11
+#pragma unroll
+                for (int j = 0; j < (16 * (SEG / 8) + 63) / 64; ++j) {
+                    const int e = lane + 64 * j;
+                    const int row = tiled ? (e & 15) : e / nch;
+                    const int c8 = tiled ? (e >> 4) : e - row * nch;
+                    if (c8 < nch && row < rows_here) {
+                        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 lo4 = (8 * c8 < SEG) ? *reinterpret_cast<const float4*>(stg + row * SEG + 8 * c8) : z4;
+                        const float4 hi4 = (8 * c8 + 4 < SEG) ? *reinterpret_cast<const float4*>(stg + row * SEG + 8 * c8 + 4) : z4;
+                        const float f8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                        unsigned short q[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            unsigned bits = __float_as_uint(f8[u]);
+                            bits = (bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16;   // fp32 -> bf16, round to nearest even
+                            q[u] = (unsigned short)bits;
+                        }
+                        const uint4 pk = make_uint4(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16),
+                                                    q[4] | ((unsigned)q[5] << 16), q[6] | ((unsigned)q[7] << 16));
+                        if (tiled) reinterpret_cast<uint4*>(hb + (size_t)base_row[it] * DSH)[416 * pass + (ch0 + c8) * 16 + row] = pk;
+                        else reinterpret_cast<uint4*>(hb + (size_t)(base_row[it] + 16 * pass + row) * DSH)[ch0 + c8] = pk;
+                    }
+                }
+            }
+        }
+    }
+    if (KEYS && pa.colpart != nullptr) {
+        // fixed-order block reduction of the key column sums (no atomics: the row mean must be reproducible); the unit's sums go
+        // to the first of its two rows of colpart (rows count 4-item blocks, as the single-tile blocks write them), the second is zero
+        float* csum = reinterpret_cast<float*>(smem);
+        __syncthreads();                                                // the staging regions are about to be overwritten
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float sacc = colsum_r[n];
+            sacc += __shfl_xor(sacc, 32);                             // the two row halves of the tile
+            if (h == 0) csum[wave * SEG + n * 32 + i] = sacc;
+        }
+        __syncthreads();
+        if (tid < SEG) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < P16_BW; ++w) t += csum[w * SEG + tid];
+            pa.colpart[((size_t)b * pa.n_blocks_k + 2 * unit) * P16_OUT + c0 + tid] = t;
+            pa.colpart[((size_t)b * pa.n_blocks_k + 2 * unit + 1) * P16_OUT + c0 + tid] = 0.f;
+        }
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kernel(Proj16Args pa) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[P16_LDS];
-    // 1-D grid.  Full blocks first: per image [query blocks][key blocks], every wave owns 32 patches x all 7 output
-    // tiles.  The last n_split_groups key blocks of the last image come last, cut into 7 single-tile blocks each: a grid
-    // that overhangs the resident-block capacity by a few blocks would otherwise cost a whole extra round.
+    // 1-D grid.  Full blocks first (project16_body2: a wave owns 64 patches x the 4 or 3 output tiles of its block's tile group); a
+    // grid that overhangs the resident-block capacity by a few blocks would cost a whole extra round, so the overhang comes last,
+    // cut into single-tile blocks (project16_body<1>).
     const int bid = blockIdx.x;
     dbg_stamp(pa.times, bid, 0);
     if (bid == 0 && threadIdx.x < 2 * pa.heads && pa.range.word != nullptr) {        // weights packed from out-of-range values?
@@ -504,15 +792,36 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
             *reinterpret_cast<const int32_t*>(wpk + (size_t)(threadIdx.x >> 1) * P16_PACKED_HALFS + P16_PACKED_HALFS - 2) != 0)
             *pa.range.word = pa.range.tag;
     }
-    const int per = pa.n_blocks_q + pa.n_blocks_k;
+    // units of 8 items (256 patches), two blocks each (tile groups 0-3 / 4-6), per image [query units][key units]; the last
+    // n_split_groups key units of the last image come last, cut into 2 x 7 single-tile blocks of 4 items each (round-3 body)
+    const int per_units = pa.units_q + pa.units_k;
     if (bid < pa.n_full) {
-        const int b = bid / per, local = bid - b * per;
-        if (local < pa.n_blocks_q) project16_body<P16_NT, false, VAR>(pa, smem, 0, local, b);
-        else project16_body<P16_NT, true, VAR>(pa, smem, 0, local - pa.n_blocks_q, b);
+        // block -> (unit, tile group).  The 4-tile blocks carry 4/7 of the work: block b runs on XCD b % 8 (observed; used for speed
+        // only), so "even ids = group 0" would hand the even XCDs nothing but 4-tile blocks.  Per XCD x the q-th block takes unit
+        // 8 (q / 2) + x (the two groups of a unit back to back on ONE XCD: they read the same map rows through one L2), group
+        // (q & 1) ^ ((q >> 5) & 1) -- the flip every 32 blocks so that the second wave of blocks lands a 3-tile block beside a
+        // 4-tile one where CUs are filled round-robin.  Ids past the last multiple of 16: unit = id / 2, group = id & 1.
+        int vunit, grp;
+        if (bid < (pa.n_full & ~15)) {
+            const int xcd = bid & 7, q = bid >> 3;
+            vunit = 8 * (q >> 1) + xcd; grp = (q ^ (q >> 5)) & 1;
+        } else { vunit = bid >> 1; grp = bid & 1; }
+        const int b = vunit / per_units, unit = vunit - b * per_units;
+        if (VAR != 0) {                                   // ablation builds keep the round-3 body for their variants
+            if (unit < pa.units_q) { project16_body<P16_NT, false, VAR>(pa, smem, 0, 2 * unit + grp, b); }
+            else { project16_body<P16_NT, true, VAR>(pa, smem, 0, 2 * (unit - pa.units_q) + grp, b); }
+        } else if (unit < pa.units_q) {
+            if (grp == 0) project16_body2<P16_G0, false>(pa, smem, 0, unit, b);
+            else project16_body2<P16_G1, false>(pa, smem, P16_G0, unit, b);
+        } else {
+            if (grp == 0) project16_body2<P16_G0, true>(pa, smem, 0, unit - pa.units_q, b);
+            else project16_body2<P16_G1, true>(pa, smem, P16_G0, unit - pa.units_q, b);
+        }
     } else {
         const int sb = bid - pa.n_full;
-        const int grp = sb / P16_NT, tile = sb - grp * P16_NT;
-        project16_body<1, true, VAR>(pa, smem, tile, pa.n_blocks_k - pa.n_split_groups + grp, pa.batch - 1);
+        const int grp = sb / (2 * P16_NT), rest = sb - grp * (2 * P16_NT);
+        const int half = rest / P16_NT, tile = rest - half * P16_NT;
+        project16_body<1, true, VAR>(pa, smem, tile, 2 * (pa.units_k - pa.n_split_groups + grp) + half, pa.batch - 1);
     }
     dbg_stamp(pa.times, bid, 3);
 }
@@ -534,7 +843,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(int n_blocks_k, cons
 
 static inline bool p16_keys_linear(const Grid& g) { return g.W >= 32; }       // a wrapped item ends inside the NEXT row
 static inline int p16_key_items(const Grid& g) { return p16_keys_linear(g) ? (g.N + 31) / 32 : ((g.W + 31) / 32) * g.H; }
-int project16_key_blocks(const Grid& g) { return (p16_key_items(g) + P16_BW - 1) / P16_BW; }
+int project16_key_blocks(const Grid& g) { return 2 * ((p16_key_items(g) + P16_UNIT - 1) / P16_UNIT); }   // rows of colpart: two per unit
 
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
@@ -556,8 +865,10 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     pa.segs[0] = (g.W + 31) / 32; pa.segs[1] = (g.Lw + 31) / 32;
     pa.lin[0] = p16_keys_linear(g) ? 1 : 0; pa.lin[1] = 1;           // (queries gather per lane: any row length)
     pa.n_items[0] = p16_key_items(g); pa.n_items[1] = (g.L + 31) / 32;
-    const int nbq = (which & 2) ? (pa.n_items[1] + P16_BW - 1) / P16_BW : 0;
-    const int nbk = (which & 1) ? project16_key_blocks(g) : 0;
+    const int uq = (which & 2) ? (pa.n_items[1] + P16_UNIT - 1) / P16_UNIT : 0;
+    const int uk = (which & 1) ? (pa.n_items[0] + P16_UNIT - 1) / P16_UNIT : 0;
+    const int nbq = 2 * uq, nbk = 2 * uk;
+    pa.units_q = uq; pa.units_k = uk;
     pa.n_blocks_q = nbq; pa.n_blocks_k = nbk;
     pa.colpart = (colsum != nullptr) ? colpart : nullptr;
     // resident capacity: two blocks per CU.  A remainder of at most half a round is cut into single-tile blocks.
@@ -566,11 +877,11 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    const int cap = P16_BLOCKS_PER_CU * cus, total = B * (nbq + nbk), rem = total % cap;
-    int groups = (rem > 0 && rem <= cap / 2) ? rem : 0;
-    if (groups > nbk) groups = nbk;
-    pa.n_split_groups = groups; pa.n_full = total - groups; pa.batch = B;
-    const dim3 grid(pa.n_full + P16_NT * groups), block(64 * P16_BW);
+    const int cap = P16_BLOCKS_PER_CU * cus, total = 2 * B * (uq + uk), rem = total % cap;
+    int groups = (rem > 0 && rem <= cap / 2) ? (rem + 1) / 2 : 0;        // units whose two blocks overhang the last full round
+    if (groups > uk) groups = uk;
+    pa.n_split_groups = groups; pa.n_full = total - 2 * groups; pa.batch = B;
+    const dim3 grid(pa.n_full + 2 * P16_NT * groups), block(64 * P16_BW);
 #ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
     if (getenv("DAGL_TIMES_FILE")) pa.times = dbg_times_buffer(grid.x);
     static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
