@@ -81,6 +81,9 @@ SIGNATURES = {
     "dagl_fold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),
     "dagl_copy4": (_i, [_vp, _i, _i, _i, _i, _vp] + [C.c_longlong] * 4 + [_vp] + [C.c_longlong] * 4),
     "dagl_relu_backward": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "dagl_prelu_forward": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "dagl_prelu_scratch_bytes": (_sz, [_sz]),
+    "dagl_prelu_backward": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dagl_col_sum_scratch_bytes": (_sz, [_sz, _i]),
     "dagl_col_sum": (_i, [_vp, _sz, _i, _vp, _vp, _vp]),
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),

@@ -64,6 +64,56 @@ __global__ void copy4_kernel(int n0, int n1, int n2, int n3, const float* __rest
     dst[i0 * d0 + i1 * d1 + i2 * d2 + i3 * d3] = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
 }
 
+// ---- single-parameter PReLU of the trunk's ResBlocks (common.py:59-79, act = nn.PReLU()) ---------------------------------------
+// torch's own backward (unrolled_elementwise_kernel_for_multi_outputs + a reduce) ran at 0.44 TB/s: 24 calls x 307 us + 2.6 ms of
+// reductions = 10 ms of the 62 ms training step (profiles/r04_kernel_stats_train.csv, first pass).  Forward y = x > 0 ? x : a x;
+// backward dx = dy (x > 0 ? 1 : a), da = sum dy x [x <= 0]: 16-byte accesses, per-block fp64 partials of da, a fixed-order final
+// sum (deterministic: the same bits every run).
+constexpr int PRELU_BLOCK = 256, PRELU_VEC_PER_THREAD = 8;
+__global__ __launch_bounds__(PRELU_BLOCK) void prelu_forward_kernel(size_t n4, const float4* __restrict__ x, const float* __restrict__ a,
+                                                                    float4* __restrict__ y) {
+    const float s = a[0];
+    const size_t base = (size_t)blockIdx.x * (PRELU_BLOCK * PRELU_VEC_PER_THREAD) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < PRELU_VEC_PER_THREAD; ++u) {
+        const size_t i = base + (size_t)u * PRELU_BLOCK;
+        if (i < n4) {
+            const float4 v = x[i];
+            y[i] = make_float4(v.x > 0.f ? v.x : s * v.x, v.y > 0.f ? v.y : s * v.y, v.z > 0.f ? v.z : s * v.z, v.w > 0.f ? v.w : s * v.w);
+        }
+    }
+}
+__global__ __launch_bounds__(PRELU_BLOCK) void prelu_backward_kernel(size_t n4, const float4* __restrict__ x, const float4* __restrict__ dy,
+                                                                     const float* __restrict__ a, float4* __restrict__ dx,
+                                                                     double* __restrict__ part) {
+    __shared__ double sh[PRELU_BLOCK / 64];
+    const float s = a[0];
+    const size_t base = (size_t)blockIdx.x * (PRELU_BLOCK * PRELU_VEC_PER_THREAD) + threadIdx.x;
+    float acc = 0.f;                                                    // 32 products per thread in fp32, then fp64
+#pragma unroll
+    for (int u = 0; u < PRELU_VEC_PER_THREAD; ++u) {
+        const size_t i = base + (size_t)u * PRELU_BLOCK;
+        if (i < n4) {
+            const float4 v = x[i], g = dy[i];
+            dx[i] = make_float4(v.x > 0.f ? g.x : s * g.x, v.y > 0.f ? g.y : s * g.y, v.z > 0.f ? g.z : s * g.z, v.w > 0.f ? g.w : s * g.w);
+            acc += (v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y) + (v.z > 0.f ? 0.f : g.z * v.z) + (v.w > 0.f ? 0.f : g.w * v.w);
+        }
+    }
+    const double w = wave_sum_f64((double)acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void prelu_final_kernel(int n_part, const double* __restrict__ part, float* __restrict__ da) {
+    __shared__ double sh[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) t += part[i];       // fixed assignment of partials to threads
+    const double w = wave_sum_f64(t);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) da[0] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
 __global__ void relu_backward_kernel(size_t n, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dz[i] = y[i] > 0.f ? dy[i] : 0.f;
@@ -182,6 +232,37 @@ int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* o
     hipLaunchKernelGGL(col_sum_final_kernel, dim3((cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_part > 0 ? n_part : 1, cols,
                        static_cast<const double*>(scratch), out);
     DAGL_LAUNCH_CHECK("col_sum_final_kernel");
+    return DAGL_OK;
+}
+
+size_t dagl_prelu_scratch_bytes(size_t n) {
+    const size_t n4 = (n + 3) / 4, per = (size_t)PRELU_BLOCK * PRELU_VEC_PER_THREAD;
+    return ((n4 + per - 1) / per) * sizeof(double);
+}
+
+int dagl_prelu_forward(void* stream, size_t n, const float* x, const float* a, float* y) {
+    DAGL_REQUIRE(x && a && y && (n % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                 "dagl_prelu_forward: null pointer, n not a multiple of 4 or unaligned tensors");
+    if (n == 0) return DAGL_OK;
+    const size_t n4 = n / 4, per = (size_t)PRELU_BLOCK * PRELU_VEC_PER_THREAD;
+    hipLaunchKernelGGL(prelu_forward_kernel, dim3((unsigned)((n4 + per - 1) / per)), dim3(PRELU_BLOCK), 0, (hipStream_t)stream, n4,
+                       reinterpret_cast<const float4*>(x), a, reinterpret_cast<float4*>(y));
+    DAGL_LAUNCH_CHECK("prelu_forward_kernel");
+    return DAGL_OK;
+}
+
+int dagl_prelu_backward(void* stream, size_t n, const float* x, const float* dy, const float* a, float* dx, float* da, void* scratch) {
+    DAGL_REQUIRE(x && dy && a && dx && da && scratch && (n % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                 ((uintptr_t)dx % 16) == 0, "dagl_prelu_backward: null pointer, n not a multiple of 4 or unaligned tensors");
+    const size_t n4 = n / 4, per = (size_t)PRELU_BLOCK * PRELU_VEC_PER_THREAD;
+    const int n_part = (int)((n4 + per - 1) / per);
+    if (n_part > 0) {
+        hipLaunchKernelGGL(prelu_backward_kernel, dim3(n_part), dim3(PRELU_BLOCK), 0, (hipStream_t)stream, n4, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<const float4*>(dy), a, reinterpret_cast<float4*>(dx), static_cast<double*>(scratch));
+        DAGL_LAUNCH_CHECK("prelu_backward_kernel");
+    }
+    hipLaunchKernelGGL(prelu_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_part, static_cast<const double*>(scratch), da);
+    DAGL_LAUNCH_CHECK("prelu_final_kernel");
     return DAGL_OK;
 }
 

@@ -2,7 +2,8 @@
 HIP block can be exercised the way the reference exercises ``CE``: inside the 3-stage x 4-head ``CES`` module
 of the EDSR-style trunk ``RR`` and under the recursive 4-way tiling of ``forward_chop``.
 
-Everything here except ``CE`` is stock PyTorch-ROCm (convs, PReLU).  Module / parameter names and registration order
+Everything here except ``CE`` and the ResBlocks' PReLU (train_ops.PReLU: torch's backward for it was a sixth of the training
+step) is stock PyTorch-ROCm convolutions.  Module / parameter names and registration order
 follow the reference (``RR`` DN_Gray/model/dagl.py:11-54, ``CES`` :74-119, ``ResBlock`` DN_Gray/model/common.py:59-79),
 so a reference ``state_dict`` loads strictly.
 """
@@ -27,7 +28,8 @@ class ResBlock(nn.Module):
 
     def __init__(self, n_feats, res_scale=1.0):
         super().__init__()
-        self.body = nn.Sequential(_conv(n_feats, n_feats, 3), nn.PReLU(), _conv(n_feats, n_feats, 3))
+        from .train_ops import PReLU                      # nn.PReLU() whose fp32 GPU calls run on the HIP library (same state_dict)
+        self.body = nn.Sequential(_conv(n_feats, n_feats, 3), PReLU(), _conv(n_feats, n_feats, 3))
         self.res_scale = res_scale
 
     def forward(self, x):

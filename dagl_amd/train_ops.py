@@ -252,6 +252,45 @@ class _PrologueConvs(torch.autograd.Function):
         return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b)
 
 
+class _PReLU1(torch.autograd.Function):
+    """Single-parameter PReLU on the HIP library (``dagl_prelu_forward`` / ``_backward``): the activation of every ResBlock of the
+    trunk (DN_Gray/model/common.py:59-79 with ``act = nn.PReLU()``, dagl.py:27-35,76-90).  torch's own backward for it ran at a
+    tenth of the memory bandwidth and was 10 ms of the 62 ms training step (24 activations of [8,64,128,128])."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(_lib.load().dagl_prelu_forward(ops._stream(), x.numel(), x.data_ptr(), weight.data_ptr(), y.data_ptr()), "dagl_prelu_forward")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x)
+            da = torch.empty_like(weight)
+            scratch = torch.empty(max(8, lib.dagl_prelu_scratch_bytes(x.numel())), device=x.device, dtype=torch.uint8)
+            check(lib.dagl_prelu_backward(ops._stream(), x.numel(), x.data_ptr(), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(),
+                                          da.data_ptr(), scratch.data_ptr()), "dagl_prelu_backward")
+        return dx, da
+
+
+class PReLU(torch.nn.PReLU):
+    """``nn.PReLU()`` (one shared slope; same parameter name, shape and initial value, so reference checkpoints load unchanged) whose
+    fp32 GPU calls run on the HIP library; anything else (CPU, half precision, per-channel slopes, odd sizes) takes torch's path."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.weight.numel() == 1 and self.weight.dtype == torch.float32
+                and x.numel() % 4 == 0 and x.numel() > 0):
+            return _PReLU1.apply(x, self.weight)
+        return super().forward(x)
+
+
 def prologue_forward_any_width(x, g_w, g_b, th_w, th_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None):
     """The four prologue convolutions (dagl.py:208-215) for ANY input width -- ``CE(in_channels = n_feats)``, dagl.py:94-109 -- as
     unfold + fp32 matrix-core GEMM on the HIP library (the fused kernels of prologue.hip are laid out for 64 channels): g (3x3)

@@ -328,6 +328,12 @@ int dagl_fold_patches(void* stream, int B, int Hp, int Wp, int C, int k, int str
 int dagl_copy4(void* stream, int n0, int n1, int n2, int n3, const float* src, long long s0, long long s1, long long s2,
                long long s3, float* dst, long long d0, long long d1, long long d2, long long d3);
 int dagl_relu_backward(void* stream, size_t n, const float* y, const float* dy, float* dz);   /* dz = dy * (y > 0)   */
+/* single-parameter PReLU of the trunk's ResBlocks (DN_Gray/model/common.py:59-79, act = nn.PReLU(); DN_Gray/model/dagl.py:27-35,
+ * 76-90): y = x > 0 ? x : a x; backward dx = dy (x > 0 ? 1 : a), da = sum dy x [x <= 0] with a fixed-order fp64 reduction
+ * (deterministic).  n = element count, a multiple of 4; tensors contiguous and 16-byte aligned.                            */
+int    dagl_prelu_forward(void* stream, size_t n, const float* x, const float* a, float* y);
+size_t dagl_prelu_scratch_bytes(size_t n);
+int    dagl_prelu_backward(void* stream, size_t n, const float* x, const float* dy, const float* a, float* dx, float* da, void* scratch);
 size_t dagl_col_sum_scratch_bytes(size_t rows, int cols);
 int dagl_col_sum(void* stream, size_t rows, int cols, const float* src, float* out, void* scratch);   /* out[c] = sum_r src[r,c], cols <= 256 */
 

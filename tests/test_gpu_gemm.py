@@ -162,3 +162,32 @@ def test_projection_backward_fast_path_equals_the_fp32_gemm_path():
             T.FAST_FC_BACKWARD = True
     for a, c in zip(res[True], res[False]):
         assert normwise(a.numpy(), c.numpy()) <= 1e-5
+
+
+def test_prelu_on_the_library_matches_torch_forward_and_backward():
+    """train_ops.PReLU (the ResBlocks' activation) against nn.PReLU: forward bit-equal, gradients equal up to the order of the
+    slope gradient's sum (fp64 partials here), deterministic across runs; odd sizes / half precision take torch's path."""
+    import torch
+    from dagl_amd.train_ops import PReLU
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 40, 44, generator=g).to(dev)
+    gy = torch.randn(2, 64, 40, 44, generator=g).to(dev)
+    ours, ref = PReLU().to(dev), torch.nn.PReLU().to(dev)
+    with torch.no_grad():
+        ours.weight.fill_(0.2); ref.weight.fill_(0.2)
+    outs = []
+    for m in (ours, ref, ours):
+        xi = x.clone().requires_grad_(True)
+        m.weight.grad = None
+        y = m(xi)
+        y.backward(gy)
+        outs.append((y.detach(), xi.grad.clone(), m.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref64 = float((gy.double() * x.double() * (x <= 0)).sum())
+    assert abs(float(outs[0][2]) - ref64) <= 1e-6 * abs(ref64) + 1e-6
+    assert abs(float(outs[1][2]) - ref64) <= 1e-4 * abs(ref64) + 1e-4          # (torch's own fp32 reduction, for scale)
+    assert torch.equal(outs[0][2], outs[2][2])                                 # same bits on a repeated call
+    assert sorted(ours.state_dict()) == sorted(ref.state_dict()) and ours.weight.shape == ref.weight.shape
+    y_odd = ours(torch.randn(3, 5, 7, device=dev))                             # 105 elements: torch's path
+    assert y_odd.shape == (3, 5, 7)
