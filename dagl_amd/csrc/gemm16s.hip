@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4
 // gradient): four separate passes over 103 MB per projection before (ReLU backward, maximum, column sums at 1.7 TB/s, split).
 // Block = FCG_SROWS rows; thread = (row phase 0..4, float4 column 0..48); per-block sums in fp64, phases added in a fixed
 // order, blocks added in a fixed order by col_sum_final_kernel.
-constexpr int FCG_SROWS = 640;
+constexpr int FCG_SROWS = 160;                        // (640 rows = 205 blocks for 131 072 rows: fewer blocks than CUs, 2.2 TB/s; 160: 4.3)
 __global__ __launch_bounds__(256) void fcg_relu_stats_kernel(size_t n, const float4* __restrict__ y, const float4* __restrict__ dy,
                                                              float4* __restrict__ dz, double* __restrict__ part,
                                                              unsigned* __restrict__ max_word) {
