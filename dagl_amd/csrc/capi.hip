@@ -461,7 +461,18 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
     }
     const int q_tiled = (p.screen && p.split16 && !core) ? 1 : 0;   // the projection writes the bf16 queries in the screen's fragment order
+    // a call that goes straight to the streamed dense formulation (DAGL_FLAG_DENSE_HINT): the projection writes the split-fp16
+    // features dense.hip consumes as well -- no separate splitting pass over the fp32 rows
+    Split16Out split_out;
+    const Split16Out* split_p = nullptr;
+    if (!core && p.split16 && p.screen && mode == DAGL_MODE_ADAPTIVE && (mode_flags & DAGL_FLAG_DENSE_HINT)) {
+        size_t off_dn = p.o_end;
+        const size_t o_dn = carve(off_dn, dense_workspace_bytes(B, g));
+        if (ws_bytes >= off_dn) { split_out = dense_split_buffers(at<char>(ws, o_dn), B, g); split_p = &split_out; }
+    }
     ZeroList zl;
+    if (split_p) dense_guard_rows(zl, B, g, split_out);
+    if (prepared && split_p) { if ((rc = launch_zero_regions(s, zl))) return rc; }
     if (!prepared) {   // rows past the last patch (partial tile + guard tile) are streamed by the scans: keep them zero
         const int rx = feat_rows(g.N), rq = feat_rows(g.L);
         const int hx = feat_rows_h(g.N), hq = feat_rows_h(g.L);
@@ -494,7 +505,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
                                    at<float>(ws, p.o_colpart), wp1h, b1s,
-                                   Wq, Xh, Wqh, heads, rt, q_tiled))) return rc;
+                                   Wq, Xh, Wqh, heads, rt, q_tiled, split_p))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }
@@ -608,7 +619,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         // there; stream the dense formulation instead (dense.hip).  Reached after the screen found out, or directly when
         // the caller passes DAGL_FLAG_DENSE_HINT (its previous call on this module ended here): always correct, only
         // slower than the lists when the neighbourhoods are in fact sparse.
-        auto run_dense = [&]() -> int {
+        auto run_dense = [&](bool features_split) -> int {
             size_t off = p.o_end;
             const size_t o_dn = carve(off, dense_workspace_bytes(B, g));
             if (info) { info->required_bytes = (int64_t)off; info->path = 4; }
@@ -629,7 +640,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             float* smax = at<float>(ws, p.o_theta);
             if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
             if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt,
-                                          core ? core->lse : nullptr))) return rc;
+                                          core ? core->lse : nullptr, features_split))) return rc;
             prof_mark(prof, s, 7);
             if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
@@ -649,7 +660,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         };
         if (mode == DAGL_MODE_ADAPTIVE && (mode_flags & DAGL_FLAG_DENSE_HINT) && (!core || core->lse)) {
             prof_mark(prof, s, 3); prof_mark(prof, s, 4); prof_mark(prof, s, 5);
-            return run_dense();
+            return run_dense(split_p != nullptr);
         }
         prof_mark(prof, s, 3);
         if (mode != DAGL_MODE_ADAPTIVE) {                       // top-k threshold from the sampling pass
@@ -735,7 +746,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 return DAGL_OK;
             }
             ovf_active = false;
-            if (mostly) return run_dense();
+            if (mostly) return run_dense(false);
             need_exact = true;                                   // redo everything with the fp32 scan (CSR capable)
         } else {
             // top-k modes: query groups whose candidate slots overflowed are redone by the fp32 scan below; it

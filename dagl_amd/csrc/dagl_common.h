@@ -282,11 +282,16 @@ int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, 
 // fp16 split-operand projection (project16.hip)
 int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range = RangeTag());
 int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool rows_order = false /* [196][tap][c] instead of [196][c][tap] */);
+// optional extra outputs of project16: the features once more as split fp16 (64 x = hi + lo, rows of 216 halfs, columns 196.. zero) --
+// what the streamed dense formulation (dense.hip) consumes; index 0 = keys, 1 = queries; [B, rows_alloc, 216]
+constexpr float DN_FS = 64.0f;                        // pre-scaling of the split features: 64 x = hi + lo
+struct Split16Out { uint16_t* hi[2]; uint16_t* lo[2]; int rows_alloc[2]; };
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys /*[heads]*/, float* feat_keys, double* colsum,
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
                      uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag(),
-                     int q_tiled = 0 /* bf16 query copy in the screen's fragment order (ScreenArgs::q_tiled) */);
+                     int q_tiled = 0 /* bf16 query copy in the screen's fragment order (ScreenArgs::q_tiled) */,
+                     const Split16Out* split = nullptr);
 int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat /* [B, feat_rows(n), DS] */, float* rows_out /* [B, n, 196] */,
                          RangeTag range);            // dense copy of the feature rows; NaN when the call left the fp16 range
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats
@@ -491,11 +496,14 @@ struct DenseArgs {
     unsigned* phase_out;                                       // ablation builds: [blocks][8 waves][8] shader clocks per phase, or null
 };
 size_t dense_workspace_bytes(int B, const Grid& g);
+Split16Out dense_split_buffers(void* dense_ws, int B, const Grid& g);    // where launch_dense_attend expects the split features
+void dense_guard_rows(ZeroList& zl, int B, const Grid& g, const Split16Out& so);   // the rows past N / L (guard tiles) must be zero
 int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
                         float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag(),
-                        float* lse_out = nullptr /* [B,L,2] {shift M, sum Z} for the backward */);
+                        float* lse_out = nullptr /* [B,L,2] {shift M, sum Z} for the backward */,
+                        bool features_split = false /* the projection already wrote dense_split_buffers() */);
 
 // graph-core backward (backward.hip)
 struct BwdArgs {

@@ -54,7 +54,6 @@ constexpr int DN_KS = 7;                              // k-steps of 32 features 
 constexpr int DN_KPITCH = 4 * DN_KS;                  // 16-byte slots per staged key row
 constexpr int DN_KPART_B = 32 * DN_KPITCH * 16;       // bytes of one part (hi or lo) of a staged key tile: 14 pieces of 1 KiB
 constexpr int DN_KTILE_B = 2 * DN_KPART_B;            // hi | lo
-constexpr float DN_FS = 64.0f;                        // pre-scaling of the split features: 64 x = hi + lo
 constexpr int DN_TW = 8, DN_TH = 4;                   // a key tile = 8 x 4 pixels (32 keys): narrow maps waste little of it
 constexpr int DN_RH = DN_TH + KS - 1, DN_RW = DN_TW + KS - 1;   // value-map region of a tile: 10 rows x 14 pixels
 constexpr int DN_VPX = 18;                            // staged pixels per region row: 576-byte pitch = 64 B mod 256, so that the two taps
@@ -617,9 +616,47 @@ size_t dense_workspace_bytes(int B, const Grid& g) {
            2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L) + 2 * dn_map16_bytes(B, g);
 }
 
+// carve of the dense workspace (shared by launch_dense_attend and dense_split_buffers)
+struct DnCarve { float* part_acc; float* part_m; double* part_z; int32_t* part_deg; uint16_t *xh, *xl, *qh, *ql, *vh, *vl; };
+static DnCarve dn_carve(void* ws, int B, const Grid& g) {
+    const size_t rows = (size_t)dense_splits(B, g) * B * g.L;                // carve with the planned (upper) split count
+    DnCarve c;
+    char* p = static_cast<char*>(ws);
+    c.part_acc = reinterpret_cast<float*>(p); p += align_up(rows * P * sizeof(float), 256);
+    c.part_m = reinterpret_cast<float*>(p); p += align_up(rows * sizeof(float), 256);
+    c.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 2 * sizeof(double), 256);
+    c.part_deg = reinterpret_cast<int32_t*>(p); p += align_up(rows * sizeof(int32_t), 256);
+    c.xh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
+    c.xl = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
+    c.qh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
+    c.ql = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
+    c.vh = reinterpret_cast<uint16_t*>(p); p += dn_map16_bytes(B, g);
+    c.vl = reinterpret_cast<uint16_t*>(p);
+    return c;
+}
+
+Split16Out dense_split_buffers(void* dense_ws, int B, const Grid& g) {
+    const DnCarve c = dn_carve(dense_ws, B, g);
+    Split16Out so;
+    so.hi[0] = c.xh; so.lo[0] = c.xl; so.hi[1] = c.qh; so.lo[1] = c.ql;
+    so.rows_alloc[0] = feat_rows_h(g.N); so.rows_alloc[1] = feat_rows_h(g.L);
+    return so;
+}
+
+// rows past the last key / query of the split features: the kernel's LDS-DMA and its query fragments run into them
+void dense_guard_rows(ZeroList& zl, int B, const Grid& g, const Split16Out& so) {
+    const int rn[2] = {g.N, g.L};
+    for (int w = 0; w < 2; ++w) {
+        const size_t row_b = (size_t)DSH * sizeof(uint16_t);
+        const size_t img = (size_t)so.rows_alloc[w] * row_b, tail = (size_t)(so.rows_alloc[w] - rn[w]) * row_b;
+        zl.add(reinterpret_cast<char*>(so.hi[w]) + (size_t)rn[w] * row_b, tail, B, img);
+        zl.add(reinterpret_cast<char*>(so.lo[w]) + (size_t)rn[w] * row_b, tail, B, img);
+    }
+}
+
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats, RangeTag range, float* lse_out) {
+                        float* rowsum_out, int64_t* stats, RangeTag range, float* lse_out, bool features_split) {
     DenseArgs a;
     a.smax = smax;
     a.variant = 0;
@@ -633,27 +670,20 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.n_tiles = ((g.H + DN_TH - 1) / DN_TH) * a.tiles_per_row;
     a.tiles_per_split = (a.n_tiles + a.splits - 1) / a.splits;
     a.splits = (a.n_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
-    const size_t rows = (size_t)dense_splits(B, g) * B * g.L;                // carve with the planned (upper) split count
-    char* p = static_cast<char*>(ws);
-    a.part_acc = reinterpret_cast<float*>(p); p += align_up(rows * P * sizeof(float), 256);
-    a.part_m = reinterpret_cast<float*>(p); p += align_up(rows * sizeof(float), 256);
-    a.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 2 * sizeof(double), 256);
-    a.part_deg = reinterpret_cast<int32_t*>(p); p += align_up(rows * sizeof(int32_t), 256);
-    uint16_t* xh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
-    uint16_t* xl = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
-    uint16_t* qh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
-    uint16_t* ql = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
-    uint16_t* vh = reinterpret_cast<uint16_t*>(p); p += dn_map16_bytes(B, g);
-    uint16_t* vl = reinterpret_cast<uint16_t*>(p);
+    const DnCarve c = dn_carve(ws, B, g);
+    a.part_acc = c.part_acc; a.part_m = c.part_m; a.part_z = c.part_z; a.part_deg = c.part_deg;
+    uint16_t *xh = c.xh, *xl = c.xl, *qh = c.qh, *ql = c.ql, *vh = c.vh, *vl = c.vl;
     a.v_hi = vh; a.v_lo = vl;
     a.x_hi = xh; a.x_lo = xl; a.wq_hi = qh; a.wq_lo = ql;
     a.rows_xh = feat_rows_h(g.N); a.rows_qh = feat_rows_h(g.L);
     {
         const size_t nx = (size_t)a.rows_xh * (DSH / 8), nq8 = (size_t)a.rows_qh * (DSH / 8);
+        if (!features_split) {
         hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl, range);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
         hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql, range);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
+        }
         int rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b2p, vh, vl, range);     // 16 v = hi + lo, borders stay zero
         if (rc) return rc;
     }

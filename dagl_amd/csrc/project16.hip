@@ -123,6 +123,16 @@ int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool ro
     return DAGL_OK;
 }
 
+// two features -> packed fp16 pairs of the split copy: DN_FS x = hi + lo (x >= 0: after the ReLU)
+__device__ __forceinline__ void p16_split_pair(float a, float b, unsigned& hi, unsigned& lo, bool& bad) {
+    const float v0 = a * DN_FS, v1 = b * DN_FS;
+    bad |= !(v0 < RANGE_LIMIT) | !(v1 < RANGE_LIMIT);
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
 struct Proj16Args {
     Grid gr;
     const unsigned short* map_hi; const unsigned short* map_lo;     // [B,Hp,Wp,16] fp16
@@ -136,6 +146,8 @@ struct Proj16Args {
                                                                     // per 32 rows [rows 0..15 | 16..31][t 0..12][half 0..1][row][8 columns
                                                                     // 16t + 8half ..], 2 x 6.5 KiB at the tile's row-major place
                                                                     // (ScreenArgs::q_tiled); an epilogue pass = one contiguous half
+    unsigned short* split_hi[2]; unsigned short* split_lo[2];       // optional split-fp16 copies [B, rows_alloc_s, DSH] (Split16Out)
+    int rows_alloc_s[2];
     int rows_alloc[2], rows_alloc_h[2];
     int n_items[2], segs[2];                                        // 32-patch work items per image / per grid row
     int lin[2];                                                     // items = 32 consecutive patches in ROW-MAJOR order (across row ends)
@@ -469,6 +481,14 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
                 if (pa.tiled_h[which]) hb[(size_t)grid_row_base * DSH + (rr >> 4) * 3328 + ((col >> 3) * 16 + (rr & 15)) * 8 + (col & 7)] = (uint16_t)u;
                 else hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
             }
+            if (VAR == 0 && ok && pa.split_hi[which] != nullptr && col < DPAD) {          // split-fp16 copy (see project16_body2)
+                const float vs = v * DN_FS;
+                if (!(vs < RANGE_LIMIT) && pa.range.word != nullptr) *pa.range.word = pa.range.tag;
+                const _Float16 hv = (_Float16)vs;
+                const size_t o = ((size_t)b * pa.rows_alloc_s[which] + grid_row_base + rr) * DSH + col;
+                pa.split_hi[which][o] = __builtin_bit_cast(unsigned short, hv);
+                pa.split_lo[which][o] = __builtin_bit_cast(unsigned short, (_Float16)(vs - (float)hv));
+            }
             s += ok ? v : 0.f;
         }
         colsum_r[n] = s;
@@ -754,6 +774,32 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
                     }
                 }
             }
+            if (pa.split_hi[which] != nullptr) {
+                // split-fp16 copy for the streamed dense formulation: DN_FS x = hi + lo, row-major rows of 216 halfs like the
+                // bf16 copy (the same chunks of the staged rows; what dense.hip's feat_split_kernel would produce)
+                unsigned short* sh = pa.split_hi[which] + (size_t)b * pa.rows_alloc_s[which] * DSH;
+                unsigned short* sl = pa.split_lo[which] + (size_t)b * pa.rows_alloc_s[which] * DSH;
+                const int ch0 = c0 / 8;
+                const int nch = (c0 + SEG >= DPAD) ? (DSH / 8 - ch0) : SEG / 8;
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < (16 * (SEG / 8) + 63) / 64; ++j) {
+                    const int e = lane + 64 * j;
+                    const int row = e / nch, c8 = e - row * nch;
+                    if (row < rows_here) {
+                        // (c8 < SEG / 8 here: the pad chunk 26 lies inside the last group's staged columns 128..223)
+                        const float4 lo4 = *reinterpret_cast<const float4*>(stg + row * SEG + 8 * c8);
+                        const float4 hi4 = *reinterpret_cast<const float4*>(stg + row * SEG + 8 * c8 + 4);
+                        unsigned h01, l01, h23, l23, h45, l45, h67, l67;
+                        p16_split_pair(lo4.x, lo4.y, h01, l01, bad); p16_split_pair(lo4.z, lo4.w, h23, l23, bad);
+                        p16_split_pair(hi4.x, hi4.y, h45, l45, bad); p16_split_pair(hi4.z, hi4.w, h67, l67, bad);
+                        const size_t o = (size_t)(base_row[it] + 16 * pass + row) * (DSH / 8) + ch0 + c8;
+                        reinterpret_cast<uint4*>(sh)[o] = make_uint4(h01, h23, h45, h67);
+                        reinterpret_cast<uint4*>(sl)[o] = make_uint4(l01, l23, l45, l67);
+                    }
+                }
+                if (bad && pa.range.word != nullptr) *pa.range.word = pa.range.tag;
+            }
         }
     }
     if (KEYS && pa.colpart != nullptr) {
@@ -848,8 +894,12 @@ int project16_key_blocks(const Grid& g) { return 2 * ((p16_key_items(g) + P16_UN
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled) {
+                     uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled, const Split16Out* split) {
     Proj16Args pa;
+    for (int w = 0; w < 2; ++w) {
+        pa.split_hi[w] = split ? split->hi[w] : nullptr; pa.split_lo[w] = split ? split->lo[w] : nullptr;
+        pa.rows_alloc_s[w] = split ? split->rows_alloc[w] : 0;
+    }
     pa.tiled_h[0] = 0; pa.tiled_h[1] = q_tiled;
     pa.range = range; pa.heads = heads; pa.times = nullptr;
     pa.imgs_per_head = B / heads;
