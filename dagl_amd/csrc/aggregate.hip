@@ -8,6 +8,7 @@
 //                  V_j read on the fly from the padded NHWC value map (7 x 448-B segments per neighbour)
 //   fold           out = fold(agg) / fold(unfold(1))                     (dagl.py:265-272)
 #include "dagl_common.h"
+#include "aggregate_direct.h"
 #include "topk_merge.h"
 
 namespace dagl {
@@ -98,6 +99,7 @@ __global__ void row_stats_kernel(size_t n_rows, const float* __restrict__ nb_wgt
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int n = nb_cnt[r];
+    if (n < 0) return;                                   // a query redone on its own: overflow.hip has written both already
     const float* w = nb_wgt + (row_off ? (size_t)row_off[r] : r * width);
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += (double)w[j];
@@ -143,58 +145,10 @@ int launch_edge_softmax(hipStream_t s, const EdgeArgs& a) {
 // aggregate_fold_kernel.  A few queries of a long-tailed degree distribution come close to their 256 slots and set the
 // kernel's duration: batches of 16 first, then batches of 8 with the slots past the list's end predicated off (clamped
 // reads, no fma).  The fma order is the list order.
-constexpr int AGG_STAGE = 256;                                 // list entries staged at a time
 __global__ __launch_bounds__(256) void aggregate_direct_kernel(AggArgs a) {
     __shared__ int sh_of[AGG_STAGE];
     __shared__ float sh_w[AGG_STAGE];
-    const int b = blockIdx.y, q = blockIdx.x, r = threadIdx.x;
-    const int C4 = P / 4;                                      // 196
-    const size_t ql = (size_t)b * a.g.L + q;
-    const int n = a.nb_cnt[ql];
-    const size_t lo = a.row_off ? (size_t)a.row_off[ql] : ql * a.width;
-    const int32_t* ip = a.nb_idx + lo;
-    const float* wp = a.nb_wgt + lo;
-    const int W = a.g.W, Wp = a.g.Wp;
-    const int rc = r < C4 ? r : C4 - 1;                        // (threads 196..255 stage entries, then idle along)
-    const int kh = rc / 28, rem = rc % 28;
-    const float4* vm = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH) + (size_t)kh * Wp * (CH / 4) + rem;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < n; base += AGG_STAGE) {
-        const int m = min(n - base, AGG_STAGE);
-        if (base > 0) __syncthreads();
-        for (int e = r; e < m; e += 256) {
-            const int id = ip[base + e];
-            const int jy = id / W, jx = id - jy * W;
-            sh_of[e] = (jy * Wp + jx) * (CH / 4);
-            sh_w[e] = wp[base + e];
-        }
-        __syncthreads();
-        int j = 0;
-        constexpr int AL = 16;
-        for (; j + AL <= m; j += AL) {
-            float w[AL]; float4 v[AL];
-#pragma unroll
-            for (int u = 0; u < AL; ++u) { v[u] = vm[sh_of[j + u]]; w[u] = sh_w[j + u]; }
-#pragma unroll
-            for (int u = 0; u < AL; ++u) {
-                acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
-                acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
-            }
-        }
-        constexpr int AU = 8;
-        for (; j < m; j += AU) {
-            float w[AU]; float4 v[AU];
-#pragma unroll
-            for (int u = 0; u < AU; ++u) { const int e = min(j + u, m - 1); v[u] = vm[sh_of[e]]; w[u] = sh_w[e]; }
-#pragma unroll
-            for (int u = 0; u < AU; ++u) {
-                const bool ok = j + u < m;
-                acc.x = ok ? fmaf(w[u], v[u].x, acc.x) : acc.x; acc.y = ok ? fmaf(w[u], v[u].y, acc.y) : acc.y;
-                acc.z = ok ? fmaf(w[u], v[u].z, acc.z) : acc.z; acc.w = ok ? fmaf(w[u], v[u].w, acc.w) : acc.w;
-            }
-        }
-    }
-    if (r < C4) reinterpret_cast<float4*>(a.agg)[ql * C4 + r] = acc;
+    aggregate_direct_block(a, blockIdx.y, blockIdx.x, sh_of, sh_w);
 }
 
 int launch_aggregate_direct(hipStream_t s, const AggArgs& a) {

@@ -541,6 +541,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
 
+    bool agg_done = false;           // the gather + weighted sum over the lists ran inside the overflow launches (adaptive, screened)
     bool ovf_active = false;         // set once the refine kernel has listed its overflowed queries (adaptive, screened)
     // the statistics read-back of the adaptive modes also carries the range word: a call that left the split-fp16 range is
     // re-run on the fp32 path right here (same arguments, DAGL_FLAG_EXACT_SCAN); without a read-back (top-k modes) the
@@ -564,11 +565,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     auto overflow_args = [&]() {
         OvfArgs oa;
         memset(&oa, 0, sizeof(oa));
-        oa.B = B; oa.g = g; oa.wq = Wq; oa.x = X; oa.rows_q = feat_rows(g.L); oa.rows_x = feat_rows(g.N);
+        oa.B = B; oa.g = g; oa.x = X; oa.rows_x = feat_rows(g.N);
         oa.mt = mt; oa.bs = bias; oa.b2p = b2p; oa.list = at<int32_t>(ws, p.o_ovflist);
-        oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap; oa.eff = reinterpret_cast<int32_t*>(stats + 6);
+        oa.count = reinterpret_cast<const int32_t*>(stats + 3); oa.cap = p.ovf_cap;
         oa.qrows = at<float>(ws, p.o_ovfq); oa.scores = at<float>(ws, p.o_ovfscores); oa.ldn = (g.N + 31) / 32 * 32; oa.part = at<float>(ws, p.o_ovfpart);
         oa.agg = agg; oa.nb_cnt = nbcnt; oa.dbg_deg = dbg_deg; oa.dbg_rowsum = dbg_rowsum;
+        oa.edges_run = stats;            // (stats[0]: zero since the start of the call, overwritten with the total by the statistics block)
         oa.flagged_edges = stats + 7; oa.edge_limit = ovf_edge_limit;
         return oa;
     };
@@ -584,14 +586,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             prof_mark(prof, s, 8);
             return DAGL_OK;
         }
-        if ((r = launch_aggregate_direct(s, ag2))) return r;
-        if (ovf_active) {
-            // the few queries whose neighbourhood overflowed the lists are redone one by one (dense rows); their aggregated
-            // rows, degrees and softmax mass replace what the clipped lists gave.  Exits at once when nothing is flagged.
-            // (their scores and per-chunk statistics were queued ahead of the verdict read-back)
-            const OvfArgs oa = overflow_args();
-            if ((r = launch_overflow_apply(s, oa))) return r;
-        }
+        // (the few queries whose neighbourhood overflowed the lists were redone one by one ahead of the verdict read-back --
+        // dense rows, overflow.hip: their aggregated rows, degrees and softmax mass are in place, this gather skips them)
+        if (!agg_done && (r = launch_aggregate_direct(s, ag2))) return r;
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((r = launch_fold(s, B, g, agg, out, heads, rt))) return r;
@@ -681,6 +678,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if (p.ovf_cap > 0) {
             ra.ovf_list = at<int32_t>(ws, p.o_ovflist); ra.ovf_count = reinterpret_cast<int32_t*>(stats + 3); ra.ovf_cap = p.ovf_cap;
+            ra.ovf_qrows = at<float>(ws, p.o_ovfq);
             ra.heavy_list = at<int32_t>(ws, p.o_heavy); ra.heavy_count = reinterpret_cast<int32_t*>(stats + 3) + 1;   // (cleared with the counters)
             ovf_active = true;
         }
@@ -708,7 +706,6 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             // is known once the flagged queries' chunk statistics exist (their true degrees): the copy is queued there,
             // the optimistic gather, the flagged rows' weighted sums and the fold behind it, and the host waits for the
             // copy alone -- the device works through the round trip and through the caller's next launches.
-            if (ovf_active) { const OvfArgs oa = overflow_args(); if ((rc = launch_overflow_scores(s, oa))) return rc; }
             // DAGL_FLAG_NO_WAIT: the verdict is formed on the device, the call returns without reading it (no host round trip:
             // the adaptive forward can be captured into a HIP graph); an unserved call is NaN-filled, never wrong
             const bool no_wait = (mode_flags & DAGL_FLAG_NO_WAIT) && ovf_active && !dbg_deg && !dbg_rowsum && !dbg_agg && !core && heads == 1;
@@ -716,10 +713,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if (rt.tag == 0) rt.tag = next_call_tag();
                 rt.veto = reinterpret_cast<const int32_t*>(stats + 8);
             }
-            {
-                const OvfArgs oa = ovf_active ? overflow_args() : OvfArgs();
-                if ((rc = launch_degree_stats(s, BL, nbcnt, stats, ovf_active ? &oa : nullptr, 0,
-                                              no_wait ? reinterpret_cast<int32_t*>(stats + 8) : nullptr, rt.tag))) return rc;
+            if (ovf_active) {           // the flagged rows redone (three launches that exit at once when there are none) + the call's statistics
+                const OvfArgs oa = overflow_args();
+                if ((rc = launch_overflow_rows(s, oa, ag, BL, stats, no_wait ? reinterpret_cast<int32_t*>(stats + 8) : nullptr, rt.tag))) return rc;
+                agg_done = true;
+            } else {
+                if ((rc = launch_degree_stats(s, BL, nbcnt, stats))) return rc;
             }
             if (no_wait) {
                 if ((rc = run_tail(ag))) return rc;
@@ -745,7 +744,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
                 return DAGL_OK;
             }
-            ovf_active = false;
+            ovf_active = false; agg_done = false;
             if (mostly) return run_dense(false);
             need_exact = true;                                   // redo everything with the fp32 scan (CSR capable)
         } else {

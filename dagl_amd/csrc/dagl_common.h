@@ -439,40 +439,39 @@ struct RefineArgs {
     int n_qgroups_exact;
     int64_t* stats;                 // [3]: total edges, max degree, overflowed queries
     int32_t* ovf_list; int32_t* ovf_count; int ovf_cap;    // adaptive mode: overflowed queries are listed for the per-query redo
+    float* ovf_qrows;               // ... and their feature rows copied to [ovf_cap, DS] (OvfArgs::qrows)
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
     int32_t* heavy_list; int32_t* heavy_count;      // adaptive mode: queries with many candidates, refined by a whole block each
     const int32_t* policy; const int32_t* gate; int capseg_tight;     // as in ScreenArgs
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
 int refine_heavy_cap();
-struct OvfArgs;
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
-                        const OvfArgs* flagged = nullptr /* rows whose true degree is in their chunk statistics (overflow.hip) */,
-                        int count_over = 0 /* > 0: stats[2] = rows with a larger degree */,
-                        int32_t* veto = nullptr, int32_t tag = 0 /* flagged form: *veto = tag when the host would have had to
-                                                                    send the call elsewhere (dense formulation / CSR redo) */);
+                        int count_over = 0 /* > 0: stats[2] = rows with a larger degree */);
 
 // per-query dense redo of the queries that overflowed the screened adaptive lists (overflow.hip)
 struct OvfArgs {
     int B; Grid g;
-    const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
+    const float* x; int rows_x;                                // fp32 key features [B, rows, DS]
     const float* mt; const float* bs; const float* b2p;
     const int32_t* list; const int32_t* count; int cap;        // flagged queries (b*L + l), how many (device), list capacity
-    int32_t* eff;                                              // two device words: rows actually redone (0 when count > cap); rows of the matrix-core product
-    float* qrows;                                              // [cap, DS] feature rows of the flagged queries
-    float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys
-    float* agg; int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;
+    const float* qrows;                                        // [cap, DS] feature rows of the flagged queries (written by the refine kernels)
+    float* scores; long long ldn;                              // [B, cap, ldn] scores of the flagged queries against all keys (many rows only)
+    float* agg; const int32_t* nb_cnt; int32_t* dbg_deg; float* dbg_rowsum;
     float* part;                                               // [cap, OVF_CHUNKS, OVF_PART_FLOATS] per-chunk partial results
-    int64_t* flagged_edges; long long edge_limit;              // device word: sum of the flagged rows' degrees (degree_stats_flagged);
+    int64_t* edges_run;                                        // device word, zero at the start of the call: edges gathered so far
+    int64_t* flagged_edges; long long edge_limit;              // device word: sum of the flagged rows' degrees (the statistics block);
                                                                // beyond the limit the weighted sums are NOT formed (the host sees the
                                                                // same word and sends the call to the dense formulation)
 };
-constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (one block each)
+constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (many flagged rows)
 constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}
-int launch_overflow_scores(hipStream_t s, const OvfArgs& a);    // flagged rows: scores against all keys + per-chunk statistics
-int launch_overflow_apply(hipStream_t s, const OvfArgs& a);     // ... weighted sums, combined rows and degrees written back
-int launch_degree_stats_flagged(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs& a,
-                                int32_t* veto = nullptr, int32_t tag = 0);
+// flagged rows: scores, masks, weighted sums, combined rows -- and, sharing a launch with the scores, the gather + weighted sum
+// over every query's list (`ag`: what launch_aggregate_direct does; flagged rows are skipped); then total edges / largest degree
+// of the call (stats[0], [1]) and, for the calls that do not wait, *veto = tag when the host would have had to send the call elsewhere
+struct AggArgs;
+int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs& ag, size_t n_rows, int64_t* stats, int32_t* veto = nullptr,
+                         int32_t tag = 0);
 int overflow_cap(int N, int B);
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
@@ -545,7 +544,8 @@ struct Gemm32 {
     int chunk_tiles = 0;                              // > 0: partial sums of chunk_tiles * 16 products, added in fp32
     int slices = 1; float* scratch = nullptr;         // split-K (batch == 1): slices * M * N floats of scratch, fixed-order sum
     int k_total = 0;                                  // (set by launch_gemm32)
-    const int32_t* m_limit = nullptr;                 // optional device word: only rows < *m_limit are computed
+    const int32_t* m_limit = nullptr;                 // optional device word: only rows < *m_limit are computed ...
+    int m_limit_floor = 0, m_limit_ceil = 0x7fffffff; // ... and none at all when the word is <= floor or > ceil
     int variant = 0;                                  // ablation builds (DAGL_GEMM_VARIANT): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
 };
 int launch_gemm32(hipStream_t s, const Gemm32& g);

@@ -724,7 +724,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
     // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics)
-    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats, nullptr, DAGL_LIST_CAP);
+    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats, DAGL_LIST_CAP);
 }
 
 }  // namespace dagl

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, in
     const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
     const long long bz = blockIdx.z;
     if (g.m_limit != nullptr) {                     // row count known on the device only: blocks past it have nothing to do
-        const int ml = *g.m_limit;
+        int ml = *g.m_limit;
+        if (ml <= g.m_limit_floor || ml > g.m_limit_ceil) ml = 0;
         if (m0 >= ml) return;
         if (ml < g.M) g.M = ml;
     }

@@ -481,7 +481,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
                 if (pa.tiled_h[which]) hb[(size_t)grid_row_base * DSH + (rr >> 4) * 3328 + ((col >> 3) * 16 + (rr & 15)) * 8 + (col & 7)] = (uint16_t)u;
                 else hb[(size_t)(grid_row_base + rr) * DSH + col] = (uint16_t)u;
             }
-            if (VAR == 0 && ok && pa.split_hi[which] != nullptr && col < DPAD) {          // split-fp16 copy (see project16_body2)
+            if (VAR == 0 && ok && pa.split_hi[which] != nullptr && col < DSH) {           // split-fp16 copy (see project16_body2): columns 196 .. 215 zero
                 const float vs = v * DN_FS;
                 if (!(vs < RANGE_LIMIT) && pa.range.word != nullptr) *pa.range.word = pa.range.tag;
                 const _Float16 hv = (_Float16)vs;

@@ -1297,17 +1297,24 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
             if (a.nb_s != nullptr) a.nb_s[ql * a.width + e] = my_s[u];
         }
     }
+    int ovf_pos = -1;
     if (lane == 0) {
-        a.nb_cnt[ql] = n;
+        // (a row that goes to the per-query redo: count -1 = "not from the list": the gather leaves its aggregated row alone)
+        a.nb_cnt[ql] = (overflow && a.ovf_list != nullptr) ? -1 : n;
         if (overflow) {
             const size_t qg = (size_t)b * a.n_qgroups_exact + (size_t)(ql - (size_t)b * a.L) / 128;
             a.redo_flags[qg] = 1;
             atomicAdd(reinterpret_cast<unsigned long long*>(&a.stats[2]), 1ull);
             if (a.ovf_list != nullptr) {                  // adaptive: this query is redone on its own (overflow.hip)
-                const int pos = atomicAdd(a.ovf_count, 1);
-                if (pos < a.ovf_cap) a.ovf_list[pos] = (int32_t)ql;
+                ovf_pos = atomicAdd(a.ovf_count, 1);
+                if (ovf_pos < a.ovf_cap) a.ovf_list[ovf_pos] = (int32_t)ql;
             }
         }
+    }
+    if (overflow && a.ovf_list != nullptr && a.ovf_qrows != nullptr) {      // wave-uniform: its feature row, compacted for the redo's product
+        ovf_pos = __shfl(ovf_pos, 0);
+        if (ovf_pos < a.ovf_cap)
+            for (int c = lane; c < DS; c += 64) a.ovf_qrows[(size_t)ovf_pos * DS + c] = qrow[c];
     }
 }
 
@@ -1358,9 +1365,7 @@ __global__ __launch_bounds__(1024) void degree_stats_kernel(size_t n_rows, const
     }
 }
 
-int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, const OvfArgs* flagged, int count_over,
-                        int32_t* veto, int32_t tag) {
-    if (flagged != nullptr && flagged->cap > 0) return launch_degree_stats_flagged(s, n_rows, nb_cnt, stats, *flagged, veto, tag);
+int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats, int count_over) {
     hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, s, n_rows, nb_cnt, stats, count_over);
     DAGL_LAUNCH_CHECK("degree_stats_kernel");
     return DAGL_OK;

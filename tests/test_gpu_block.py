@@ -216,6 +216,26 @@ def test_dense_hint_skips_the_list_attempt_and_recovers():
         assert torch.equal(again, want)
 
 
+def test_dense_hint_on_a_dirty_workspace():
+    """DAGL_FLAG_DENSE_HINT on a workspace whose bytes are all 0xFF (NaN in every format): a hinted call gets its split-fp16
+    features from the projection's epilogue, pad columns and guard rows included -- nothing may be left to what the buffer held."""
+    from dagl_amd import ops
+    from dagl_amd.synth import make_ce_params, make_features
+    prm = {n: torch.from_numpy(a).to(_dev()).contiguous() for n, a in make_ce_params(54, variant="default").items()}
+    prm = {n: t for n, t in prm.items() if not n.startswith("W.")}
+    for shape in ((2, 64, 72, 72), (1, 64, 96, 80), (3, 64, 52, 44)):
+        x = torch.from_numpy(make_features(54, *shape)).to(_dev())
+        want, info = ops.ce_forward_fused(x, prm, mode="adaptive", workspace=ops.Workspace())
+        assert info["path"] == 4
+        ws = ops.Workspace()
+        ops.ce_forward_fused(x, prm, mode="adaptive", workspace=ws)          # sizes the buffer for the dense formulation
+        ws.buf.fill_(0xFF)
+        got, _ = ops.ce_forward_fused(x, prm, mode="adaptive", workspace=ws, dense_hint=True)
+        assert torch.equal(got, want), shape
+        again, _ = ops.ce_forward_fused(x, prm, mode="adaptive", workspace=ws, dense_hint=True, weights_packed=True)
+        assert torch.equal(again, want), shape
+
+
 def test_adaptive_topk_mode_matches_oracle():
     from oracle.ce_oracle import ce_forward_oracle
     path = [p for p in CASES if "gray_sparse_64x64" in p][0]
