@@ -134,7 +134,7 @@ class CE(nn.Module):
         # variant (GReccR2b_3mh_1-checkpoint.py:242-250) and the intersection available:
         #   "adaptive" | "topk" | "adaptive_topk", with k = ``select_k``.
         self.select_mode = "adaptive"
-        self.select_k = num_edge       # the fixed-k variant's own default is 50; k > MAX_TOPK raises in the top-k modes
+        self.select_k = num_edge       # the fixed-k variant's own default is 50; k > MAX_TOPK: inference only (row-wise dense form)
         # "screened": bf16 matrix-core screen of all L*N scores + exact refinement of the survivors (default);
         # "exact": every score on the fp32 matrix cores.  Same neighbours either way.
         self.scan = "screened"
@@ -343,10 +343,11 @@ class CE(nn.Module):
         k_eff = 0
         if self.select_mode != "adaptive":
             # no silent clamp: the fixed-k variant takes exactly min(num_edge, N) neighbours (GReccR2b_3mh_1-checkpoint.py:243)
-            if not 1 <= int(self.select_k) <= MAX_TOPK:
-                raise DaglError(f"CE: select_k={self.select_k} outside [1, {MAX_TOPK}] (include/dagl_ce.h DAGL_MAX_TOPK); "
-                                "the top-k modes keep per-query lists of that width")
+            if int(self.select_k) < 1:
+                raise DaglError(f"CE: select_k={self.select_k} < 1")
             k_eff = min(int(self.select_k), b.shape[2] * b.shape[3])
+            # k_eff > MAX_TOPK (include/dagl_ce.h DAGL_MAX_TOPK): no per-query lists -- the inference entry points take every
+            # query's score row in the dense form (csrc/topk_wide.hip); the differentiable path keeps lists and raises below
         in_dtype = b.dtype
         if in_dtype in (torch.bfloat16, torch.float16):
             # reduced-precision feature maps (BASELINE config 3): the block itself computes in fp32 with the bf16
@@ -362,6 +363,9 @@ class CE(nn.Module):
         # differentiable path then -- same gradients, paid only when used.
         if torch.is_grad_enabled():
             if self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
+                if k_eff > MAX_TOPK:
+                    raise DaglError(f"CE: select_k={self.select_k} > {MAX_TOPK} under autograd: the differentiable path keeps "
+                                    f"per-query lists of at most {MAX_TOPK} neighbours (include/dagl_ce.h DAGL_MAX_TOPK)")
                 out = self._forward_train(b.contiguous())
                 return out if in_dtype == torch.float32 else out.to(in_dtype)
             if b.requires_grad:

@@ -104,6 +104,8 @@ struct Plan {
     int s_sample_tight = 0, capseg_tight = 0;             // top-k modes behind the screen: the tight threshold's pair (DAGL_FLAG_TIGHT_TOPK)
     int width;                      // neighbour-list width of the fixed-width paths
     int ovf_cap;                    // adaptive lists behind the screen: queries that may be redone one by one (overflow.hip)
+    bool wide = false;              // top-k modes, k > DAGL_MAX_TOPK: row-wise dense form (topk_wide.hip), no lists
+    size_t o_wide = 0;
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
@@ -128,15 +130,18 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK | DAGL_FLAG_SAMPLED_TOPK)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
-    if (mode != DAGL_MODE_ADAPTIVE)
-        DAGL_REQUIRE(k >= 1 && k <= DAGL_MAX_TOPK, "dagl: k=%d outside [1,%d]", k, DAGL_MAX_TOPK);
+    if (mode != DAGL_MODE_ADAPTIVE) DAGL_REQUIRE(k >= 1, "dagl: k=%d < 1", k);
     DAGL_REQUIRE((int64_t)H * W < (1ll << 30), "dagl: image too large");
     if (mode != DAGL_MODE_ADAPTIVE && (int64_t)k > (int64_t)H * W) k = H * W;     // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
+    // neighbourhoods wider than the lists: every query in the row-wise dense form (inference entry points only)
+    p.wide = mode != DAGL_MODE_ADAPTIVE && k > DAGL_MAX_TOPK;
+    if (p.wide) DAGL_REQUIRE(!core, "dagl_ce_core_forward: k=%d > %d: the differentiable path keeps lists of at most %d neighbours", k,
+                             DAGL_MAX_TOPK, DAGL_MAX_TOPK);
     p.g = make_grid(H, W);
     p.B = B; p.mode = mode; p.k = k;
-    p.kslots = (mode == DAGL_MODE_ADAPTIVE) ? 0 : topk_slots(k);
+    p.kslots = (mode == DAGL_MODE_ADAPTIVE || p.wide) ? 0 : topk_slots(k);
     const Grid& g = p.g;
-    p.screen = !exact && g.N >= SCREEN_MIN_KEYS;
+    p.screen = !exact && !p.wide && g.N >= SCREEN_MIN_KEYS;
     p.split16 = !exact;
     p.n_tiles = (g.N + KT - 1) / KT;
     const int n_qgroups = (g.L + 127) / 128;
@@ -150,7 +155,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.splits = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
     // adaptive lists: 256 slots behind the screen (mean degrees of ~8 come with maxima of ~100), 64 for the exact scan and for
     // the training entry point (its backward keeps one neighbour per lane)
-    p.width = (mode == DAGL_MODE_ADAPTIVE) ? ((core || exact || g_N_small(H, W)) ? DAGL_FAST_CAP : DAGL_LIST_CAP) : k;
+    p.width = (mode == DAGL_MODE_ADAPTIVE) ? ((core || exact || g_N_small(H, W)) ? DAGL_FAST_CAP : DAGL_LIST_CAP) : (p.wide ? 1 : k);
     // bf16 screen: the key stream from L2 into LDS is what bounds it (LDS-DMA lands ~25 GB/s per CU, 6.4 TB/s over the chip;
     // at 256^2 sixteen groups of 256 queries stream the 28 MB of bf16 keys 16 times = 453 MB = 71 us against 46 us of matrix
     // work), so a block covers 512 queries (16 waves, one block per CU: every key tile is fetched half as often) whenever
@@ -276,6 +281,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_ovfscores = carve(off, (size_t)B * p.ovf_cap * ((g.N + 31) / 32 * 32) * sizeof(float));
         p.o_ovfpart = carve(off, (size_t)p.ovf_cap * OVF_CHUNKS * OVF_PART_FLOATS * sizeof(float));
     }
+    if (p.wide) p.o_wide = carve(off, topk_wide_workspace_bytes(g.N, g.L));
     p.o_end = off;
     return DAGL_OK;
 }
@@ -595,6 +601,28 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         prof_mark(prof, s, 8);
         return DAGL_OK;
     };
+
+    if (p.wide) {
+        // fixed-k neighbourhoods wider than the lists: scores, k-th largest, mask, softmax and weighted sum row by row
+        prof_mark(prof, s, 3); prof_mark(prof, s, 4); prof_mark(prof, s, 5);
+        if (heads > 1) { set_error("dagl_ces_stage_forward: k=%d > %d: use the per-head entry point", k, DAGL_MAX_TOPK); return DAGL_ERR_UNSUPPORTED; }
+        if ((rc = launch_topk_wide(s, B, g, mode, p.k, Wq, X, mt, bias, b2p, at<char>(ws, p.o_wide), agg, deg, dbg_rowsum))) return rc;
+        prof_mark(prof, s, 6);
+        if (dbg_deg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_deg, deg, BL * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+        prof_mark(prof, s, 7);
+        if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
+        prof_mark(prof, s, 8);
+        if (info) {
+            if ((rc = launch_degree_stats(s, BL, deg, stats))) return rc;
+            int64_t hs[5] = {0, 0, 0, 0, 0};
+            if ((rc = read_back(s, stats, 5, hs))) return rc;
+            if (rt.word != nullptr && (int32_t)hs[4] == rt.tag) return rerun_exact();
+            info->path = 6; info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1];
+        }
+        if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
+        return DAGL_OK;
+    }
 
     // ---- stages 3-5: neighbour selection + edge softmax ------------------------------------------------------
     bool need_exact = !p.screen;

@@ -464,8 +464,8 @@ struct OvfArgs {
                                                                // beyond the limit the weighted sums are NOT formed (the host sees the
                                                                // same word and sends the call to the dense formulation)
 };
-constexpr int OVF_CHUNKS = 32;                                 // key chunks a flagged query's row is cut into (many flagged rows)
-constexpr int OVF_PART_FLOATS = P + 8;                         // partial weighted sum (784) + {max logit, count, z (double), -}
+constexpr int OVF_CHUNKS = 32;                                 // = ROW_CHUNKS, ROW_PART_FLOATS (row_attend.h): per (row, chunk) a partial
+constexpr int OVF_PART_FLOATS = P + 8;                         // weighted sum (784) + {max logit, count, z (double), -}
 // flagged rows: scores, masks, weighted sums, combined rows -- and, sharing a launch with the scores, the gather + weighted sum
 // over every query's list (`ag`: what launch_aggregate_direct does; flagged rows are skipped); then total edges / largest degree
 // of the call (stats[0], [1]) and, for the calls that do not wait, *veto = tag when the host would have had to send the call elsewhere
@@ -473,6 +473,21 @@ struct AggArgs;
 int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs& ag, size_t n_rows, int64_t* stats, int32_t* veto = nullptr,
                          int32_t tag = 0);
 int overflow_cap(int N, int B);
+
+// fixed-k neighbourhoods wider than the lists (k > DAGL_MAX_TOPK, topk_wide.hip): row-wise dense form, a batch of queries at a time
+struct WideArgs {
+    Grid g; int mode, k;
+    const float* mt; const float* bs; const float* b2p;
+    float* scores; long long ldn;                              // [R, ldn] scores of the batch against all keys of its image
+    float* part;                                               // [R, ROW_CHUNKS, ROW_PART_FLOATS]
+    int32_t* sel; int32_t* eq_before;                          // [R, 4] threshold key + ties to take; [R, 128] ties before each key range
+    float* agg; int32_t* deg; float* rowsum;                   // [B*L, 784], [B*L], [B*L] or null
+    int b, r0, R;                                              // image, first query and number of queries of the batch
+};
+size_t topk_wide_workspace_bytes(int N, int L);
+int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq /* [B, rows, DS] */, const float* x,
+                     const float* mt, const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum);
+
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
                       int32_t* deg, int64_t* stats /* [2]: total edges, max degree */);

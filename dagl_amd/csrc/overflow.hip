@@ -12,6 +12,7 @@
 // All kernels read the number of flagged queries from device memory and exit at once when it is zero.
 #include "dagl_common.h"
 #include "aggregate_direct.h"
+#include "row_attend.h"
 
 namespace dagl {
 
@@ -30,64 +31,6 @@ constexpr int OVF_GRID_B = 256;         // combine: fixed small grid (an empty c
 __device__ __forceinline__ int ovf_rows_served(const OvfArgs& a) { const int nf = *a.count; return nf > a.cap ? 0 : nf; }
 __device__ __forceinline__ int ovf_small_limit(const OvfArgs& a) { return a.cap < OVF_SMALL ? a.cap : OVF_SMALL; }
 
-__device__ __forceinline__ void ovf_chunk_range(int N, int chunk, int& j0, int& j1) {
-    const int per = ((N + OVF_CHUNKS - 1) / OVF_CHUNKS + 255) / 256 * 256;
-    j0 = chunk * per; j1 = j0 + per;
-    if (j0 > N) j0 = N;
-    if (j1 > N) j1 = N;
-}
-
-// One wave, one flagged query, keys [j0, j1) of its score row (`row[j - jbase]`): mask, weights against the running maximum of
-// THIS key range (the rows are combined with e^(m - M) afterwards: ovf_combine_kernel), weighted sum of the value patches straight
-// from the value map.  Lane l owns the float4 columns l + 64 u of the 784-float row; the passing keys of 64 are taken in
-// ascending order, two at a time so that their loads are in flight together.
-struct OvfAcc { float4 acc[4]; float m; double z; int cnt; };
-__device__ __forceinline__ void ovf_take(const OvfArgs& a, const float4* vmb, const int (&kh)[4], const int (&rem)[4], const bool (&cv)[4],
-                                         int key, float wv, OvfAcc& o) {
-    const int jy = key / a.g.W, jx = key - jy * a.g.W;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (!cv[u]) continue;
-        const float4 v = vmb[((size_t)(jy + kh[u]) * a.g.Wp + jx) * (CH / 4) + rem[u]];
-        o.acc[u].x = fmaf(wv, v.x, o.acc[u].x); o.acc[u].y = fmaf(wv, v.y, o.acc[u].y);
-        o.acc[u].z = fmaf(wv, v.z, o.acc[u].z); o.acc[u].w = fmaf(wv, v.w, o.acc[u].w);
-    }
-}
-template <typename RowFn>
-__device__ __forceinline__ void ovf_wave_range(const OvfArgs& a, const float4* vmb, const int (&kh)[4], const int (&rem)[4], const bool (&cv)[4],
-                                               int lane, int j0, int j1, float mtq, float bsq, bool gather, RowFn score_at, OvfAcc& o) {
-    for (int c0 = j0; c0 < j1; c0 += 64) {
-        const int j = c0 + lane;
-        bool pass = false; float l = 0.f;
-        if (j < j1) l = ovf_logit(score_at(j), mtq, bsq, pass);
-        unsigned long long bal = __ballot(pass);
-        if (!bal) continue;
-        o.cnt += __popcll(bal);
-        const float mx = wave_max_f32(pass ? l : -1.f);
-        if (mx > o.m) {                                              // wave-uniform: what has been summed so far shrinks
-            const float sc = (o.m < 0.f) ? 0.f : expf(o.m - mx);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { o.acc[u].x *= sc; o.acc[u].y *= sc; o.acc[u].z *= sc; o.acc[u].w *= sc; }
-            o.z *= (double)sc;
-            o.m = mx;
-        }
-        const float wgt = pass ? expf(l - o.m) : 0.f;
-        if (!gather) continue;
-        while (bal) {
-            const int b0 = __ffsll((long long)bal) - 1; bal &= bal - 1;
-            const float w0 = __shfl(wgt, b0);
-            if (bal) {
-                const int b1 = __ffsll((long long)bal) - 1; bal &= bal - 1;
-                const float w1 = __shfl(wgt, b1);
-                ovf_take(a, vmb, kh, rem, cv, c0 + b0, w0, o); ovf_take(a, vmb, kh, rem, cv, c0 + b1, w1, o);
-                o.z += (double)w0; o.z += (double)w1;
-            } else {
-                ovf_take(a, vmb, kh, rem, cv, c0 + b0, w0, o);
-                o.z += (double)w0;
-            }
-        }
-    }
-}
 
 // Few flagged queries (<= OVF_SMALL; 10 at 256^2 mean degree 8): a 128-row matrix-core tile would be 90 % padding (45 us);
 // instead four lanes share a key, each sums a quarter of the 49 float4 products per flagged row (query rows broadcast from
@@ -157,23 +100,16 @@ __global__ __launch_bounds__(256) void ovf_scores_aggregate_kernel(OvfArgs a, Ag
 // statistics block; the host reads the same word) sends the call to the dense formulation and these rows are never used -- a
 // value patch per edge costs ~1 ns here, the dense formulation 9 ps per PAIR.
 __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
-    __shared__ float4 part[4][P / 4];                                           // 12.25 KiB: the four waves' partial rows
-    __shared__ double shz[4]; __shared__ float shm[4]; __shared__ int shc[4]; __shared__ int sh_over;
+    __shared__ RowBlockShared sh;
+    __shared__ int shc[4]; __shared__ int sh_over;
     const int nf = ovf_rows_served(a);
     if (nf == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int C4 = P / 4;
-    int kh[4], rem[4]; bool cv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int r = lane + 64 * u;
-        cv[u] = r < C4;
-        const int rc = cv[u] ? r : 0;
-        kh[u] = rc / 28; rem[u] = rc % 28;
-    }
+    const RowCols cols = row_cols(lane);
     unsigned long long* edges_run = reinterpret_cast<unsigned long long*>(a.edges_run);
     const int chunk = blockIdx.x;
-    int j0c, j1c; ovf_chunk_range(a.g.N, chunk, j0c, j1c);
+    int j0c, j1c; row_chunk_range(a.g.N, chunk, j0c, j1c);
+    int j0, j1; row_wave_range(j0c, j1c, w, j0, j1);
     bool gather = true;
     for (int slot = blockIdx.y; slot < nf; slot += gridDim.y) {
         const size_t ql = (size_t)a.list[slot];
@@ -181,9 +117,6 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
         const float* row = a.scores + ((size_t)b * a.cap + slot) * a.ldn;
         const float mtq = a.mt[ql], bsq = a.bs[ql];
         const float4* vmb = reinterpret_cast<const float4*>(a.b2p + (size_t)b * a.g.Hp * a.g.Wp * CH);
-        const int per_wave = ((j1c - j0c + 3) / 4 + 63) / 64 * 64;
-        const int j0 = min(j0c + w * per_wave, j1c);
-        const int j1 = (j0 + per_wave < j1c) ? j0 + per_wave : j1c;
         // the block's count for this (query, chunk) first, charged to the call's edge budget
         int cnt = 0;
         for (int c0 = j0; c0 < j1; c0 += 64) {
@@ -199,86 +132,21 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
             (long long)(atomicAdd(edges_run, (unsigned long long)cnt_blk) + (unsigned long long)cnt_blk) > a.edge_limit) sh_over = 1;
         __syncthreads();
         if (sh_over) gather = false;
-        OvfAcc o;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o.acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        o.m = -1.f; o.z = 0.0; o.cnt = 0;
+        RowAcc o; row_acc_clear(o);
         if (cnt_blk > 0)                                                         // block-uniform
-            ovf_wave_range(a, vmb, kh, rem, cv, lane, j0, j1, mtq, bsq, gather, [&](int j) { return row[j]; }, o);
-        // the four waves' partial rows, brought to the block's maximum and added in wave order
-        if (lane == 0) { shm[w] = o.m; shz[w] = o.z; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (cv[u]) part[w][lane + 64 * u] = o.acc[u];
-        __syncthreads();
-        const float mb = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
-        float scw[4];
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) scw[ww] = (shm[ww] < 0.f) ? 0.f : expf(shm[ww] - mb);
-        float* pr = a.part + ((size_t)slot * OVF_CHUNKS + chunk) * OVF_PART_FLOATS;
-        if (tid < C4 && cnt_blk > 0) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const float4 v = part[ww][tid];
-                t.x = fmaf(scw[ww], v.x, t.x); t.y = fmaf(scw[ww], v.y, t.y); t.z = fmaf(scw[ww], v.z, t.z); t.w = fmaf(scw[ww], v.w, t.w);
-            }
-            reinterpret_cast<float4*>(pr)[tid] = t;
-        }
-        if (tid == 0) {
-            double z = 0.0;
-            for (int ww = 0; ww < 4; ++ww) z += shz[ww] * (double)scw[ww];
-            pr[P] = mb; reinterpret_cast<int*>(pr + P)[1] = cnt_blk; *reinterpret_cast<double*>(pr + P + 2) = z;
-        }
-        __syncthreads();
+            row_wave_walk(a.g, vmb, cols, lane, j0, j1, gather,
+                          [&](int j, bool in, float& l) { bool pass = false; if (in) l = ovf_logit(row[j], mtq, bsq, pass); return pass; }, o);
+        row_block_store(sh, cols, o, cnt_blk, a.part + ((size_t)slot * ROW_CHUNKS + chunk) * ROW_PART_FLOATS);
     }
-}
-
-// A flagged row from its chunks (thread-parallel over the chunks, fixed-order sums): M = largest logit (0 joins in when a key is
-// masked), degree, Z = sum of z_c e^(m_c - M) + (N - degree) e^(-M)  (masked keys count e^0 each, dagl.py:259-261)
-struct OvfRow { double M, Z, zs; int deg; };
-__device__ __forceinline__ OvfRow ovf_row_reduce(const OvfArgs& a, int slot, int n_chunks, float* sh_scale /* [256] */, double* sh_d /* [256] */,
-                                                 int* sh_i /* [256] */) {
-    const int tid = threadIdx.x;
-    float m = -1.f; int cnt = 0; double z = 0.0;
-    if (tid < n_chunks) {
-        const float* pr = a.part + ((size_t)slot * n_chunks + tid) * OVF_PART_FLOATS + P;
-        m = pr[0]; cnt = reinterpret_cast<const int*>(pr)[1]; z = *reinterpret_cast<const double*>(pr + 2);
-    }
-    __syncthreads();                                                             // (the arrays' previous use)
-    sh_scale[tid] = m; sh_i[tid] = cnt;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {                                       // max and integer sum: order-free
-        if (tid < st) { sh_scale[tid] = fmaxf(sh_scale[tid], sh_scale[tid + st]); sh_i[tid] += sh_i[tid + st]; }
-        __syncthreads();
-    }
-    OvfRow r;
-    r.deg = sh_i[0];
-    r.M = (double)sh_scale[0];
-    if (r.deg < a.g.N) r.M = fmax(r.M, 0.0);
-    __syncthreads();
-    const float sc = (m < 0.f) ? 0.f : (float)exp((double)m - r.M);
-    sh_scale[tid] = sc;
-    sh_d[tid] = z * (double)sc;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {                                       // fixed tree: the same sum on every run
-        if (tid < st) sh_d[tid] += sh_d[tid + st];
-        __syncthreads();
-    }
-    r.zs = sh_d[0];
-    r.Z = r.zs + (double)(a.g.N - r.deg) * exp(-r.M);
-    return r;                                                                    // sh_scale[c] = e^(m_c - M) stays valid for the caller
 }
 
 // blocks 0 .. gridDim.x - 2: the flagged rows, combined from their chunks (row = sum of the chunks' partial rows, scaled, in chunk
 // order, / Z); overwrites the aggregated row.  Last block: the call's statistics -- total edges and largest degree (the lists'
 // counts, a flagged row counted with its true degree), the flagged rows' edges, and the verdict of the calls that do not wait.
 __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_rows, int64_t* __restrict__ stats, int32_t* veto, int32_t tag) {
-    __shared__ float sh_scale[256];
-    __shared__ double sh_d[256];
-    __shared__ int sh_i[256];
+    __shared__ RowReduceShared sh;
     __shared__ long long sh_l[4][3];
     const int nf = ovf_rows_served(a);
-    constexpr int n_chunks = OVF_CHUNKS;
     const int tid = threadIdx.x;
     const int C4 = P / 4;
     if (blockIdx.x == gridDim.x - 1) {
@@ -286,13 +154,12 @@ __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_ro
         for (size_t r = tid; r < n_rows; r += 256) { const int d = max(a.nb_cnt[r], 0); sum += d; mx = max(mx, d); }
         for (int slot = tid; slot < nf; slot += 256) {                           // a flagged row counts with its true degree
             int deg = 0;
-            for (int c = 0; c < n_chunks; ++c)
-                deg += reinterpret_cast<const int*>(a.part + ((size_t)slot * n_chunks + c) * OVF_PART_FLOATS + P)[1];
+            for (int c = 0; c < ROW_CHUNKS; ++c)
+                deg += reinterpret_cast<const int*>(a.part + ((size_t)slot * ROW_CHUNKS + c) * ROW_PART_FLOATS + P)[1];
             sum += deg; mx = max(mx, deg); fl += deg;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, __shfl_xor(mx, o)); fl += __shfl_xor(fl, o); }
-        __syncthreads();
         if ((tid & 63) == 0) { sh_l[tid >> 6][0] = sum; sh_l[tid >> 6][1] = mx; sh_l[tid >> 6][2] = fl; }
         __syncthreads();
         if (tid == 0) {
@@ -314,19 +181,9 @@ __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_ro
     }
     for (int slot = blockIdx.x; slot < nf; slot += gridDim.x - 1) {
         const size_t ql = (size_t)a.list[slot];
-        const OvfRow row = ovf_row_reduce(a, slot, n_chunks, sh_scale, sh_d, sh_i);
-        const float inv = (float)(1.0 / row.Z);
-        if (tid < C4) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int c = 0; c < n_chunks; ++c) {
-                const float sc = sh_scale[c];
-                if (sc == 0.f) continue;                                         // (no passing key there, or all of it underflows: block-uniform)
-                const float4 v = reinterpret_cast<const float4*>(a.part + ((size_t)slot * n_chunks + c) * OVF_PART_FLOATS)[tid];
-                t.x = fmaf(sc, v.x, t.x); t.y = fmaf(sc, v.y, t.y); t.z = fmaf(sc, v.z, t.z); t.w = fmaf(sc, v.w, t.w);
-            }
-            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
-            reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = t;
-        }
+        const float* part_row = a.part + (size_t)slot * ROW_CHUNKS * ROW_PART_FLOATS;
+        const RowSum row = row_reduce(part_row, a.g.N, sh);
+        if (tid < C4) reinterpret_cast<float4*>(a.agg)[ql * C4 + tid] = row_combine(part_row, row, sh);
         if (tid == 0) {
             if (a.dbg_deg) a.dbg_deg[ql] = row.deg;
             if (a.dbg_rowsum) a.dbg_rowsum[ql] = (float)(row.zs / row.Z);
@@ -369,7 +226,7 @@ int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs& ag, siz
     hipLaunchKernelGGL(ovf_scores_aggregate_kernel, dim3((unsigned)(score_blocks * a.B + a.g.L * a.B)), dim3(256), 0, s, a, ag, score_blocks);
     DAGL_LAUNCH_CHECK("ovf_scores_aggregate_kernel");
     const int gy = a.cap < 32 ? a.cap : 32;                               // flagged queries are strided over grid.y
-    hipLaunchKernelGGL(ovf_attend_kernel, dim3(OVF_CHUNKS, gy), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ovf_attend_kernel, dim3(ROW_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_attend_kernel");
     hipLaunchKernelGGL(ovf_combine_kernel, dim3((a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B) + 1), dim3(256), 0, s, a, n_rows, stats, veto, tag);
     DAGL_LAUNCH_CHECK("ovf_combine_kernel");

@@ -90,9 +90,15 @@ extern "C" {
 #define DAGL_FLAG_TIGHT_TOPK     0x1000
 #define DAGL_FLAG_SAMPLED_TOPK   0x2000
 
-#define DAGL_MAX_TOPK            64   /* largest k of the top-k modes (the fixed-k variant defaults to num_edge = 50,
-                                         GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
-                                         top_k = min(k, N) (:243), the lists are then min(k, N) wide               */
+#define DAGL_MAX_TOPK            64   /* widest per-query neighbour LIST of the top-k modes (the fixed-k variant defaults to
+                                         num_edge = 50, GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
+                                         top_k = min(k, N) (:243), the lists are then min(k, N) wide.  min(k, N) beyond it
+                                         (a stray sibling uses min(500, N), CA_model-checkpoint.py:134-143): the inference entry
+                                         points take every query's score row in the dense form instead -- scores of 2048 queries
+                                         at a time on the fp32 matrix cores, k-th largest per row by radix selection (ties to the
+                                         lower key index, as in the lists), mask / softmax / weighted sum row-wise (info.path 6;
+                                         ~5 ms per head at 256^2, k = 500); the training entry points (dagl_ce_core_forward,
+                                         lists handed to the backward) and dagl_ces_stage_forward return an error for it      */
 #define DAGL_FAST_CAP            64   /* per-query slots of the single-pass adaptive path (fp32 scan, training lists) */
 #define DAGL_LIST_CAP           256   /* per-query slots of the screened adaptive path (inference): long-tailed degrees */
 
@@ -116,7 +122,8 @@ typedef struct dagl_ce_info {
     int32_t path;             /* 0 = fp32 scan, single-pass lists, 1 = fp32 scan, two-pass CSR (some degree >
                                  FAST_CAP), 2 = fp32 scan, per-lane top-k lists, 3 = bf16 screen + refine,
                                  4 = dense neighbourhoods: streamed dense formulation (no lists),
-                                 5 = dense formulation under autograd (dagl_ce_core_dense_forward)        */
+                                 5 = dense formulation under autograd (dagl_ce_core_dense_forward),
+                                 6 = top-k modes with min(k, N) > DAGL_MAX_TOPK: row-wise dense form (no lists) */
     int32_t range_fallback;   /* 1 = an operand left the range of the split-fp16 kernels (|activation| >= 3750, see
                                  below) and the call was re-run on the fp32 path (DAGL_FLAG_EXACT_SCAN)  */
     int32_t reserved;

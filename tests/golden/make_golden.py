@@ -64,6 +64,11 @@ CASES = [
     ("gray_default_c128_b2_24x28", "DN_Gray", 29, "default", 2.0, "adaptive", 0, 2, 24, 28, 128),
     ("topk8_c32_36x40",           "TOPK",    30, "default", 2.0, "topk",     8, 1, 36, 40, 32),
     ("car_sparse_c96_33x30",      "CAR",     31, "sparse",  1.6, "adaptive", 0, 1, 33, 30, 96),
+    # num_edge beyond the 64 the per-query lists hold (a stray sibling of the fixed-k variant uses min(500, N),
+    # CA_model-checkpoint.py:134-143): the row-wise dense form (csrc/topk_wide.hip)
+    ("topk100_64x64",        "TOPK",     32, "default", 2.0, "topk",   100, 1, 64, 64),
+    ("topk500_b2_40x36",     "TOPK",     33, "default", 2.0, "topk",   500, 2, 40, 36),
+    ("topk500_k_gt_n_20x24", "TOPK",     34, "default", 2.0, "topk",   500, 1, 20, 24),
 ]
 
 

@@ -129,6 +129,37 @@ def test_config3_config4_query_sample_against_all_keys(H, W, mode, k, in_dtype):
     assert normwise(out.float().cpu().numpy(), out_d.cpu().numpy()) <= (2.0 ** -8 if in_dtype == torch.bfloat16 else TOL)
 
 
+def test_topk500_at_256_query_sample_against_all_keys():
+    """num_edge = 500 (CA_model-checkpoint.py:134-143) at 256^2: the row-wise form in two batches of 2048 queries; 64 queries
+    spread over the image, each against all 65 536 keys, on the oracle."""
+    import time
+    from dagl_amd.synth import make_features
+    from oracle.ce_oracle import ce_rows_oracle
+    params = _params(61, "default", 2.0)
+    x = torch.from_numpy(make_features(61, 1, 64, 256, 256))
+    rows = torch.linspace(0, 4095, 64).long()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = ce_rows_oracle(x, params, rows, mode="topk", k=500)
+    ce = _module(params, "topk", 500)
+    out_d, info = _debug(ce, x.to(_dev()))
+    assert info["path"] == 6 and info["max_degree"] == 500 and info["total_edges"] == 500 * 4096
+    deg = info["deg"][0].cpu()[rows].numpy()
+    assert np.array_equal(deg, ref["deg"].numpy().astype(deg.dtype))
+    assert normwise(info["rowsum"][0].cpu()[rows].numpy(), ref["rowsum"].numpy()) <= TOL
+    agg = _agg_ckk(info["agg"][0].cpu()[rows])
+    err = normwise(agg.numpy(), ref["agg"].numpy())
+    with torch.no_grad():
+        out = ce(x.to(_dev()))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            ce(x.to(_dev()))
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(f"[parity] topk k=500 256x256: aggregated patches of 64 sampled queries vs the oracle, normwise {err:.2e}; {ms:.2f} ms per call")
+    assert err <= TOL
+    assert normwise(out.cpu().numpy(), out_d.cpu().numpy()) <= TOL
+
+
 def test_adaptive_with_more_flagged_queries_than_the_redo_holds_takes_the_csr_lists():
     """512^2, adaptive at a density where ~10 % of the queries overflow their lists: more than the per-query redo holds at
     this size (512 score rows of 1 MiB), fewer than half -- the call is redone by the fp32 scan with two-pass CSR lists
