@@ -216,6 +216,7 @@ def extra_configs(dev):
         ("256x256_adaptive_dense_default_init", 256, "default", 2.0, "adaptive", 0, torch.float32, "shipped semantics at default init (~95 % of the keys pass): streamed dense formulation; on this synthetic N(0,1) map the logits reach hundreds and ~2/3 of the (64 query x 16 key) weight granules are exactly zero and skipped -- see 256x256_set12_features.adaptive_dense for the regime where none are"),
         ("256x256_adaptive_mean_degree_8", 256, "sparse", 1.95, "adaptive", 0, torch.float32, "adaptive mask tuned to a mean degree of ~8 (7.7; long-tailed: maximum 890) (SURVEY 8d config 2)"),
         ("256x256_adaptive_mean_degree_55", 256, "sparse", 1.8, "adaptive", 0, torch.float32, "adaptive mask at mean degree 55, maximum 4578"),
+        ("256x256_topk500", 256, "default", 2.0, "topk", 500, torch.float32, "num_edge = 500 (CA_model-checkpoint.py:134-143): beyond the 64-entry lists, every query's score row in the dense form (csrc/topk_wide.hip)"),
     ]
     seeds = {"256x256_adaptive_mean_degree_8": (41, 41), "256x256_adaptive_mean_degree_55": (41, 41)}       # (weights, features): the pair tests/test_gpu_configs.py checks against the oracle
     with torch.no_grad():
