@@ -5,37 +5,41 @@
 //
 // Round 4 shape (round 3: three barrier-separated phases per key tile, S exchanged through the LDS, value planes re-laid out by
 // the VALU, 2.07 ms per head at 256^2):
-//   block = 64 queries x 8 waves (two per SIMD), key tiles of 32 keys = an 8 x 4 pixel block, ONE barrier per tile.
-//   per tile t the waves run three mutually independent pieces of work:
-//     S(t+1)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo, feat_split_kernel; three products): wave (qg, kg) forms
-//             the COMPLETE scores of 16 queries x 16 keys (21 multiplies, the query fragments live in its registers), so nothing
-//             about S is exchanged between waves.  A lane ends up with 4 consecutive keys of one query;
+//   block = 64 queries x 12 waves (three per SIMD), key tiles of 32 keys = an 8 x 4 pixel block, ONE barrier per tile, two kinds of
+//   wave that work on different tiles between two barriers:
+//   producers (waves 0-3, one per SIMD, s_setprio 2): query group qg = wave (16 queries, fragments in registers)
+//     S(t+2)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo; three products): the COMPLETE scores of 16 queries x
+//             32 keys (42 multiplies), nothing about S is exchanged between waves.  A lane ends up with 2 x 4 consecutive keys of
+//             one query;
 //     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' an UPPER bound of the row maximum known
 //             before the pass (from the bf16 screen's row maxima; the softmax is shift invariant, nothing is ever rescaled),
-//             split 2^14 p = hi + lo and handed to the other waves through the LDS in the K-layout of the next MFMA (the only
-//             exchange of the tile);
-//     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every wave three of the 24
-//             32-column tiles (two taps x 16 channels) for BOTH query tiles.  The value operand: 8 consecutive keys of one column = 8 consecutive pixels of
-//             one channel.  The tile's value-map region (10 rows x 14 pixels) is staged as it lies in memory -- NHWC fp16 hi / lo,
-//             32 B per pixel, by LDS-DMA from maps split once per call -- and ds_read_b64_tr_b16 transposes [4 pixels][16
-//             channels] blocks on the way into the registers: a patch tap's kw shift is a whole-pixel (32-byte) address offset,
-//             no funnel shifts, two 8-byte reads per 16-byte fragment where round 3 took five dwords + four v_alignbyte.
+//             split 2^14 p = hi + lo and handed to the consumers through the LDS in the K-layout of the next MFMA (the only
+//             exchange of the tile).  The ~250 VALU operations of w(t+1) are issued BETWEEN the multiplies of S(t+2) (fenced
+//             slots: fragment reads two slots ahead, three multiplies, a fourteenth of the weights): a short multiply waits ~50
+//             cycles for the pipe behind the consumers' long ones, and scores-then-weights was a 5 000-cycle chain per tile;
+//     the key tiles' LDS-DMA requests (7 pieces per producer under two M0 set-ups), three tiles ahead.
+//   consumers (waves 4-11, two per SIMD):
+//     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every consumer three of the 24
+//             32-column tiles (two taps x 16 channels) for BOTH query tiles.  The value operand: 8 consecutive keys of one column =
+//             8 consecutive pixels of one channel.  The tile's value-map region (10 rows x 14 pixels) is staged as it lies in
+//             memory -- NHWC fp16 hi / lo, 32 B per pixel, by LDS-DMA from maps split once per call (the consumers' 1.5 pieces
+//             each) -- and ds_read_b64_tr_b16 transposes [4 pixels][16 channels] blocks on the way into the registers: a patch
+//             tap's kw shift is a whole-pixel (32-byte) address offset, no funnel shifts.
 //     The 49th tap (16 columns) goes through v_mfma_f32_16x16x32_f16 (16 channels x 16 queries, K = the tile's 32 keys), one
-//     query group of 16 per wave 0-3; the other 48 taps are 24 column tiles of 32, three per wave.
-//   The two waves of a SIMD (w, w + 4) take the tile's two pieces of work in OPPOSITE order -- one forms scores and weights while
-//   the other multiplies -- and the multiplies run at s_setprio 1.
+//     query group of 16 per consumer 0-3.
+//   Two loops, one per role, with the same barriers: the query fragments are live in one, the 100 accumulator registers in the
+//   other (168 registers per wave at three waves per SIMD).
+//   The first round-4 shape had both kinds of work in every wave (8 waves, the two of a SIMD in opposite order): the pipes were
+//   55 % busy -- every wave spent half its time in code that does not multiply.  This one: 63 % (trained features, 1.38 -> 1.28 ms),
+//   synthetic map 0.71 -> 0.62 ms, leaf-tile batch 0.69 -> 0.65 ms (profiles/r04_pmc_dense_*.json, r04_ab_dense_roles.log).
 //   Exactly-zero weights: logits reach hundreds, and 2^14 p rounds to hi = lo = 0 below l < M' - 27; a (64 queries x 16 keys)
 //   granule whose weights are ALL zero contributes exactly nothing to A V, so its multiplies are skipped (a wave-uniform test of
 //   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init ~60-80 % of the granules are zero
 //   (profiles/r04_dense_zero_granules.log); with the trained checkpoint's features (logits of 5-70) none are -- that regime runs
 //   every multiply.
-//   Staging: key features hi | lo (2 x 14 KiB) two tiles ahead, value region (2 x 6 KiB) one tile ahead, 40 LDS-DMA pieces per
-//   tile, five per wave (the per-lane global offsets are 32-bit, relative to a wave-uniform base); key rows at a 28-slot pitch with
+//   Staging: key features hi | lo (3 x 28 KiB), value region (2 x 12 KiB), weights (2 x 10 KiB); key rows at a 28-slot pitch with
 //   the low slot bits XORed by a function of the row so that the S fragments' ds_read_b128 are conflict-free for the 16x16x32
 //   operand pattern.
-//   Measured (profiles/r04_dense_*): 256^2, one head: 2.07 ms (round 3) -> 0.75 ms on the synthetic default-init map, 1.33 ms on the
-//   trained checkpoint's features; matrix pipes 49 % busy there.  What is left is issue bandwidth: per SIMD and tile 96
-//   32-cycle multiplies share the issue port with ~220 VALU operations, ~100 LDS reads and 10 LDS-DMA pieces of ~100 cycles each.
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
 //
 // Matrix time per (64 query, 32 key) tile: 8 x 21 + 12 multiplies of 16 cycles + 288 of 32 cycles.
@@ -62,7 +66,6 @@ constexpr int DN_VPART_B = 6 * 1024;                  // one part of a staged re
 constexpr int DN_VTILE_B = 2 * DN_VPART_B;
 constexpr int DN_PQ_ENTRY = 80;                       // a lane's weights of a tile: hi[16] | lo[16] halfs + 16 B (odd slot count)
 constexpr int DN_PQ_B = 2 * 64 * DN_PQ_ENTRY;         // both query tiles
-constexpr int DN_CT = 24;                             // column tiles of 32 = two taps x 16 channels: taps 0-47; tap 48 is a 16-column tile of its own
 // A V: every wave takes 3 of the 24 column tiles for BOTH query tiles of the block (a value fragment then feeds six multiplies
 // instead of three); the 49th tap's 16 columns go through v_mfma_f32_16x16x32_f16 (16 channels x 16 queries, K = the tile's 32
 // keys: three multiplies of 16 cycles per query group of 16, waves 0-3 one group each) -- as a 25th 32-column tile whose second
@@ -138,9 +141,8 @@ __device__ __forceinline__ DnFrag dn_vfrag(unsigned va) {
 // skips 5-10 % more granules on synthetic maps and is 2-3 % slower where nothing is zero; compile-time instantiations per
 // (query tile 0 live, query tile 1 live) made the register allocator spill ~290 registers (profiles/r04_ab_dense_variants.log).
 __device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX],
-                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2]) {
-    // the fragment of column tile t + 1 is requested before tile t's multiplies
-    DnFrag f = dn_vfrag(va_kb + vt_off[0]);
+                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], DnFrag f /* = dn_vfrag(va_kb + vt_off[0]) */) {
+    // the fragment of column tile t + 1 is requested before tile t's multiplies (the first one by the caller, together with the weights)
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
         DnFrag fn = f;
@@ -170,13 +172,13 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb
 #define DN_PH(i) do { } while (0)
 #endif
 
-constexpr int DN_THREADS = 512;
+constexpr int DN_THREADS = 768;                    // 12 waves: 4 form scores / weights (one per SIMD), 8 multiply (two per SIMD)
 __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * DN_KTILE_B];     // 56 KiB: key-feature tiles hi | lo, two stages
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[3 * DN_KTILE_B];     // 84 KiB: key-feature tiles hi | lo, three stages
     __shared__ __attribute__((aligned(1024))) unsigned char sv[2 * DN_VTILE_B];     // 24 KiB: value regions hi | lo, two stages
     __shared__ __attribute__((aligned(16))) unsigned char spq[2 * DN_PQ_B];         // 20 KiB: the tiles' weights, two stages
-    __shared__ double szz[8][64][2];                                                // 8 KiB: the lanes' shares of a query's sums (end of the block)
-    __shared__ int sdg[8][64];
+    __shared__ double szz[4][64][2];                                                // 4 KiB: the lanes' shares of a query's sums (end of the block)
+    __shared__ int sdg[4][64];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -194,12 +196,18 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
 
     // ---- roles ------------------------------------------------------------------------------------------------------------------
-    // S / weights: wave = (query group qg of 16, key group kg of 16); lane = (query c, key quad gk): keys 16 kg + 4 gk + r
-    const int qg = wave & 3, kg = wave >> 2;
+    // waves 0-3 ("producers", one per SIMD): scores and weights of query group qg = wave (16 queries) against the tile's 32 keys
+    // (two key groups of 16, one after the other), and the key tiles' LDS-DMA requests.  lane = (query c16, key quad gk): keys
+    // 16 kg + 4 gk + r.
+    // waves 4-11 ("consumers", two per SIMD): A V.  lane = (column / query i, key half h) of the 32x32x16 multiply; consumer cw =
+    // column tiles [3 cw, 3 cw + 3) of both query tiles; consumers 0-3 also the 49th tap of query group cw; they request the value
+    // regions.
+    const bool producer = wave < 4;
+    const int cw = producer ? 0 : wave - 4;
+    const int qg = producer ? wave : (cw & 3);
     const int c16 = lane & 15, gk = lane >> 4;
-    // A V: lane = (column / query i, key half h) of the 32x32x16 multiply; wave = column tiles [ct0, ct0 + ctn) of both query tiles
     const int i = lane & 31, h = lane >> 5;
-    const int ct0 = dn_ct_start(wave);
+    const int ct0 = dn_ct_start(cw);
 
     const int qs = qb * 64 + 16 * qg + c16;                                        // the query of this lane's scores
     const int qsc = qs < g.L ? qs : g.L - 1;
@@ -215,16 +223,18 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     }
 
     // ---- staging plan (per lane, once) ---------------------------------------------------------------------------------------------
-    // keys: part = wave >> 2 (hi | lo), the part's 14 pieces over its four waves as 4 / 4 / 3 / 3; values: the part's 6 pieces as
-    // 1 / 1 / 2 / 2.  Position p of a piece: 16-byte slot p of the part's LDS image.
-    const int spart = wave >> 2, wl = wave & 3;
-    const int kp0 = wl < 2 ? 4 * wl : 8 + 3 * (wl - 2), kpn = wl < 2 ? 4 : 3;
+    // keys by the producers: part = wave >> 1 (hi | lo), the part's 14 pieces over its two waves, 7 each, under two M0 set-ups; values by
+    // the consumers: part = cw >> 2, the part's 6 pieces over its four waves as 1 / 1 / 2 / 2.
+    // Position p of a piece: 16-byte slot p of the part's LDS image.
+    const int spart = producer ? (wave >> 1) : (cw >> 2), wl = cw & 3;
+    const int kp0 = 7 * (wave & 1);
+    constexpr int kpn = 7;
     const int vp0 = wl < 2 ? wl : 2 + 2 * (wl - 2), vpn = wl < 2 ? 1 : 2;
-    unsigned k_c[4];                                   // key piece j: bits 0-15 byte offset inside the pixel row's run of keys (+ bias),
+    unsigned k_c[kpn];                                 // key piece j: bits 0-15 byte offset inside the pixel row's run of keys (+ bias),
                                                        // bits 16-17 pixel row of the key inside the tile
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = (kp0 + (j < kpn ? j : 0)) * 64 + lane;
+    for (int j = 0; j < kpn; ++j) {
+        const int p = (kp0 + j) * 64 + lane;
         const int row = p / DN_KPITCH, phys = p - row * DN_KPITCH;
         const int logical = (phys & ~3) | ((phys & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3));
         k_c[j] = (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096) | ((unsigned)(row >> 3) << 16);
@@ -243,38 +253,46 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const unsigned lds_pq = __builtin_amdgcn_readfirstlane(lds_addr_of(spq));
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>((spart ? a.x_lo : a.x_hi) + (size_t)b * a.rows_xh * DSH) - 4096;
     const unsigned char* vsrc = reinterpret_cast<const unsigned char*>((spart ? a.v_lo : a.v_hi) + (size_t)b * g.Hp * g.Wp * CH) - 4096;
-    // One LDS-DMA piece at a time (its own M0 set-up).  A wave's five pieces cost it 750-900 cycles per tile, 12-14 % of its time
-    // (profiles/r04_dense_phases.log); issuing them BETWEEN the column-tile blocks of A V, where the wave waits for the matrix
-    // pipe anyway, was measured and is 1-5 % slower than issuing them at the top of the iteration (r04_ab_dense_variants.log, v4).
-    auto key_piece = [&](int j, int jy0, int jx0, int buf) {
-        if (j >= kpn) return;                                                    // wave-uniform
+    auto key_off = [&](int j, int jy0, int jx0) {
         int jy = jy0 + (int)(k_c[j] >> 16); if (jy > g.H - 1) jy = g.H - 1;      // ragged bottom: a valid row, keys masked below
-        const unsigned o = (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
-        dn_glds<1>(xsrc, lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + (kp0 + j) * 1024), o, 0, 0, 0);
+        return (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
     };
-    auto value_piece = [&](int j, int jy0, int jx0, int buf) {
-        if (j >= vpn) return;                                                    // wave-uniform
+    auto value_off = [&](int j, int jy0, int jx0) {
         int y = jy0 + (int)((v_c[j] >> 16) & 15u); if (y > g.Hp - 1) y = g.Hp - 1;   // stay inside the padded map
         int x = jx0 + (int)(v_c[j] >> 20); if (x > g.Wp - 1) x = g.Wp - 1;
-        const unsigned o = (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
-        dn_glds<1>(vsrc, lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + (vp0 + j) * 1024), o, 0, 0, 0);
+        return (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
     };
-    auto stage_keys = [&](int jy0, int jx0, int buf) { for (int j = 0; j < 4; ++j) key_piece(j, jy0, jx0, buf); };
-    auto stage_values = [&](int jy0, int jx0, int buf) { for (int j = 0; j < 2; ++j) value_piece(j, jy0, jx0, buf); };
+    // (several pieces under one M0 set-up: piece jj of a group carries the immediate offset 1024 jj, which advances the LDS AND the
+    // global address -- its lane offset is taken back by as much; one piece per set-up cost the wave ~200 cycles a piece)
+    auto stage_keys = [&](int jy0, int jx0, int buf) {
+        if (!producer) return;                                                   // wave-uniform
+        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
+        dn_glds<4>(xsrc, dst, key_off(0, jy0, jx0), key_off(1, jy0, jx0) - 1024u, key_off(2, jy0, jx0) - 2048u, key_off(3, jy0, jx0) - 3072u);
+        dn_glds<3>(xsrc, dst + 4096u, key_off(4, jy0, jx0), key_off(5, jy0, jx0) - 1024u, key_off(6, jy0, jx0) - 2048u, 0);
+    };
+    auto stage_values = [&](int jy0, int jx0, int buf) {
+        if (producer) return;
+        const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
+        // (one piece per statement here: with several offsets live at once the allocator spilled the consumers' accumulators)
+        dn_glds<1>(vsrc, dst, value_off(0, jy0, jx0), 0, 0, 0);
+        if (vpn > 1) dn_glds<1>(vsrc, dst + 1024u, value_off(1, jy0, jx0), 0, 0, 0);     // wave-uniform
+    };
 
     // tile coordinates (pixels) of the tiles in flight: c0 = the tile being attended, c1 = the next, c2 = the one after
-    int y0 = (tile0 / a.tiles_per_row) * DN_TH, x0 = (tile0 % a.tiles_per_row) * DN_TW, y1, x1, y2, x2;
+    int y0 = (tile0 / a.tiles_per_row) * DN_TH, x0 = (tile0 % a.tiles_per_row) * DN_TW, y1, x1, y2, x2, y3, x3;
     const int xwrap = a.tiles_per_row * DN_TW;
     auto next_tile = [&](int y, int x, int& yn, int& xn) { xn = x + DN_TW; yn = y; if (xn >= xwrap) { xn = 0; yn = y + DN_TH; } };
     next_tile(y0, x0, y1, x1);
     next_tile(y1, x1, y2, x2);
+    next_tile(y2, x2, y3, x3);
     if (tile0 < tile1) { stage_keys(y0, x0, 0); stage_values(y0, x0, 0); }
     if (tile0 + 1 < tile1) stage_keys(y1, x1, 1);
+    if (tile0 + 2 < tile1) stage_keys(y2, x2, 2);
 
     // ---- the query fragments of S: lane (c16, gk) holds features 32 ks + 8 gk .. + 7 of query qs, hi and lo (rows past L are zero
     // guard rows; halfs 216.. of a row do not exist: zero, and the staged key rows' slots 26 / 27 meet only these zeros) ----------
     dnh8 qf_hi[DN_KS], qf_lo[DN_KS];
-    {
+    if (producer) {
         const uint4* rh = reinterpret_cast<const uint4*>(a.wq_hi + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
         const uint4* rl = reinterpret_cast<const uint4*>(a.wq_lo + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
 #pragma unroll
@@ -288,21 +306,16 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         }
     }
 
-    f32x16 acc[2][DN_CTMAX];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-        for (int t = 0; t < DN_CTMAX; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
-    f32x4 acc48 = {0.f, 0.f, 0.f, 0.f};                // tap 48 (waves 0-3): out^T[channel 4 gk + r][query 16 wave + c16]
+    f32x16 acc[2][DN_CTMAX];                           // (consumers; cleared in front of their loop)
+    f32x4 acc48;                                       // tap 48 (consumers 0-3): out^T[channel 4 gk + r][query 16 cw + c16]
     double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
     int deg = 0;
 
-    // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row
-    const unsigned ka_off = (unsigned)((16 * kg + c16) * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
-    // where this lane's four weights go: entry (query tile, key half, query) of the A V lane that multiplies them
-    const unsigned pw_off = (unsigned)((((qg >> 1) * 64 + (gk >> 1) * 32 + 16 * (qg & 1) + c16) * DN_PQ_ENTRY) + kg * 16 + (gk & 1) * 8);
+    // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row (kg = 1: + 16 rows)
+    const unsigned ka_off = (unsigned)(c16 * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
+    // where this lane's four weights of key group kg go: entry (query tile, key half, query) of the A V lane that multiplies them
+    // (kg = 1: + 16 bytes)
+    const unsigned pw_off = (unsigned)((((qg >> 1) * 64 + (gk >> 1) * 32 + 16 * (qg & 1) + c16) * DN_PQ_ENTRY) + (gk & 1) * 8);
     const unsigned pr_off = (unsigned)(lane * DN_PQ_ENTRY);
     // A V operand A: lane t = lane & 15 of a 16-lane group supplies the 8 bytes (pixel t >> 2, channels 4 (t & 3) ..) of the group's
     // [4 pixels][16 channels] block; the group = (tap parity, key half h)
@@ -317,48 +330,56 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         vt_off[t] = (unsigned)((kh * DN_VPX + kw) * 32) + va_lane;
     }
 
-    auto scores_weights = [&](int jy0, int jx0, int buf) {
-        f32x4 s_hh = {0.f, 0.f, 0.f, 0.f}, s_hl = {0.f, 0.f, 0.f, 0.f}, s_lh = {0.f, 0.f, 0.f, 0.f};
-        const unsigned kb_addr = lds_sm + (unsigned)(buf * DN_KTILE_B) + ka_off;
-        if (!(a.variant & 2)) {
+    // raw scores of the 32 keys staged in sm[kbuf] against this wave's 16 queries: three split products per key group, 42 multiplies
+    struct SAcc { f32x4 hh[2], hl[2], lh[2]; };
+    auto scores = [&](int kbuf, SAcc& sa) {
 #pragma unroll
-            for (int ks = 0; ks < DN_KS; ++ks) {
-                const dnh8 k_hi = __builtin_bit_cast(dnh8, dn_lds128(kb_addr + 64 * ks));
-                const dnh8 k_lo = __builtin_bit_cast(dnh8, dn_lds128(kb_addr + DN_KPART_B + 64 * ks));
-                s_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], s_hl, 0, 0, 0);
-                s_hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], s_hh, 0, 0, 0);
-                s_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], s_lh, 0, 0, 0);
+        for (int kg = 0; kg < 2; ++kg) { sa.hh[kg] = f32x4{0.f, 0.f, 0.f, 0.f}; sa.hl[kg] = sa.hh[kg]; sa.lh[kg] = sa.hh[kg]; }
+        const unsigned kb_addr = lds_sm + (unsigned)(kbuf * DN_KTILE_B) + ka_off;
+#pragma unroll
+        for (int ks = 0; ks < DN_KS; ++ks)
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                const unsigned ad = kb_addr + (unsigned)(kg * 16 * (DN_KPITCH * 16) + 64 * ks);
+                const dnh8 k_hi = __builtin_bit_cast(dnh8, dn_lds128(ad));
+                const dnh8 k_lo = __builtin_bit_cast(dnh8, dn_lds128(ad + DN_KPART_B));
+                sa.hl[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], sa.hl[kg], 0, 0, 0);
+                sa.hh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], sa.hh[kg], 0, 0, 0);
+                sa.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], sa.lh[kg], 0, 0, 0);
             }
-        }
-        DN_PH(1);
-        // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
-        float zt = 0.f, zpt = 0.f;                         // this tile's sums in fp32, one fp64 add per tile
-        int dt = 0;
-        _Float16 hq[4], lq[4];
-        const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
+    };
+    // logits, weights and their sums from a tile's raw scores; the split weights go to spq[pbuf]
+    auto weights = [&](int jy0, int jx0, int pbuf, const SAcc& sa) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float sc = (s_hh[r] + (s_hl[r] + s_lh[r])) * (1.0f / (DN_FS * DN_FS));
-            const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
-            bool pass;
-            const float l = dn_logit(sc, mtq, bsq, pass);
-            const float e = __expf(fminf(l - m_run, 0.f));                        // (the bound holds; the clamp is a seat belt)
-            const float p = valid ? e : 0.f;
-            zt += p;
-            pass = pass && valid;
-            const float pp = pass ? p : 0.f;
-            zpt += pp;
-            dt += pass ? 1 : 0;
-            const float ps = pp * DN_PS;
-            hq[r] = (_Float16)ps;
-            lq[r] = (_Float16)(ps - (float)hq[r]);
+        for (int kg = 0; kg < 2; ++kg) {
+            // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
+            float zt = 0.f, zpt = 0.f;                     // this tile's sums in fp32, one fp64 add per tile
+            int dt = 0;
+            _Float16 hq[4], lq[4];
+            const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = (sa.hh[kg][r] + (sa.hl[kg][r] + sa.lh[kg][r])) * (1.0f / (DN_FS * DN_FS));
+                const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
+                bool pass;
+                const float l = dn_logit(sc, mtq, bsq, pass);
+                const float e = __expf(fminf(l - m_run, 0.f));                    // (the bound holds; the clamp is a seat belt)
+                const float p = valid ? e : 0.f;
+                zt += p;
+                pass = pass && valid;
+                const float pp = pass ? p : 0.f;
+                zpt += pp;
+                dt += pass ? 1 : 0;
+                const float ps = pp * DN_PS;
+                hq[r] = (_Float16)ps;
+                lq[r] = (_Float16)(ps - (float)hq[r]);
+            }
+            z_run += (double)zt; zp_run += (double)zpt; deg += dt;
+            const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
+            unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
+            *reinterpret_cast<dnh4*>(pq) = hv;
+            *reinterpret_cast<dnh4*>(pq + 32) = lv;
         }
-        z_run += (double)zt; zp_run += (double)zpt; deg += dt;
-        const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
-        unsigned char* pq = spq + buf * DN_PQ_B + pw_off;
-        *reinterpret_cast<dnh4*>(pq) = hv;
-        *reinterpret_cast<dnh4*>(pq + 32) = lv;
-        DN_PH(2);
     };
 
     // the weights of BOTH query tiles for a k-block (lane = query i, keys 16 kb + 8 h ..): hi | lo, and whether any is non-zero:
@@ -372,19 +393,15 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         for (int qq = 0; qq < 2; ++qq) { f.h[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY)); f.l[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 32)); }
         return f;
     };
-    // staging state of the iteration (set by the loop): keys of tile + 2 -> sm[cur], values of tile + 1 -> sv[cur ^ 1]
-    int st_ky = 0, st_kx = 0, st_vy = 0, st_vx = 0, st_cur = 0; bool st_k = false, st_v = false;
-    auto piece = [&](int slot) {                           // slots 0-3: key pieces, 4-5: value pieces
-        if (slot < 4) { if (st_k) key_piece(slot, st_ky, st_kx, st_cur); }
-        else if (st_v) value_piece(slot - 4, st_vy, st_vx, st_cur ^ 1);
-    };
     auto attend = [&](int buf) {
         if (a.variant & 1) return;
         const unsigned vbase = lds_sv + (unsigned)(buf * DN_VTILE_B);
         PFrag pf = load_p(buf, 0);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // (the k-block's first value fragment is requested before the weights are looked at: one LDS round trip, not two)
+            const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
+            const DnFrag f0 = dn_vfrag(va_kb + vt_off[0]);
             dnh8 p_hi[2], p_lo[2];
             bool nz[2];
 #pragma unroll
@@ -393,18 +410,16 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                 nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((pf.h[qq].x | pf.h[qq].y) | (pf.h[qq].z | pf.h[qq].w)) != 0u) != 0ull;
             }
             if (kb == 0) pf = load_p(buf, 1);              // the second k-block's weights arrive under the first one's multiplies
-            const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
             DN_PH(3);
             if (nz[0] || nz[1])                            // (wave-uniform)
-                dn_pv(acc, va_kb, vt_off, p_hi, p_lo);
+                dn_pv(acc, va_kb, vt_off, p_hi, p_lo, f0);
             DN_PH(4);
         }
-        __builtin_amdgcn_s_setprio(0);
-        if (wave < 4) {
-            // tap 48 = patch position (6, 6): 16 channels x the 16 queries 16 wave .. of the block, K = the tile's 32 keys.  Lane
+        if (cw < 4) {
+            // tap 48 = patch position (6, 6): 16 channels x the 16 queries 16 cw .. of the block, K = the tile's 32 keys.  Lane
             // (c16, gk): operand B = the weights of query c16 for keys 8 gk .. (k-block gk >> 1, key half gk & 1 of the exchange
             // layout), operand A = channel c16 of the region pixels (row 6 + gk, columns 6 .. 13) through the transposing read
-            const unsigned pe = lds_pq + (unsigned)(buf * DN_PQ_B + (((wave >> 1) * 64 + (gk & 1) * 32 + 16 * (wave & 1) + c16) * DN_PQ_ENTRY) + 16 * (gk >> 1));
+            const unsigned pe = lds_pq + (unsigned)(buf * DN_PQ_B + (((cw >> 1) * 64 + (gk & 1) * 32 + 16 * (cw & 1) + c16) * DN_PQ_ENTRY) + 16 * (gk >> 1));
             const dnu4 wh = dn_lds128(pe), wl = dn_lds128(pe + 32);
             if ((a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull) {
                 const DnFrag f = dn_vfrag(vbase + (unsigned)(((6 + gk) * DN_VPX + 6 + (c16 >> 2)) * 32 + (c16 & 3) * 8));
@@ -421,56 +436,148 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 
     dma_wait_all();
     __syncthreads();
-    if (tile0 < tile1) scores_weights(y0, x0, 0);
+    float sc_next[2][4];                                   // (producers) scores of the tile AFTER the one the consumers multiply next
+    auto final_scores = [&](const SAcc& sa) {
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) sc_next[kg][rr] = (sa.hh[kg][rr] + (sa.hl[kg][rr] + sa.lh[kg][rr])) * (1.0f / (DN_FS * DN_FS));
+    };
+    if (producer) {
+        SAcc s0;
+        if (tile0 < tile1) { scores(0, s0); weights(y0, x0, 0, s0); }
+        if (tile0 + 1 < tile1) { scores(1, s0); final_scores(s0); }
+    }
     __syncthreads();
 
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int cur = (tile - tile0) & 1;
-        // (tile's own features were consumed one iteration ago: sm[cur] is free)
-        st_k = tile + 2 < tile1 && !(a.variant & 4); st_v = tile + 1 < tile1 && !(a.variant & 4);
-        st_ky = y2; st_kx = x2; st_vy = y1; st_vx = x1; st_cur = cur;
-        for (int sl = 0; sl < 6; ++sl) piece(sl);
-        // The two waves of a SIMD (waves w and w + 4) take the tile's two independent pieces of work in OPPOSITE order: one forms
-        // the next tile's scores and weights (21 short multiplies, then ~110 VALU operations with the matrix pipe idle) while the
-        // other multiplies (A V), then they swap.  In the same order they ran in lockstep from barrier to barrier and nothing
-        // overlapped: the kernel's time was the plain sum of its parts (profiles/r04_dense_ablation.log, first ladder).
-        // (the multiplies stand ONCE in the loop, unconditionally, with the scores / weights code before and after them and each
-        // wave running one of the two copies: with the accumulators inside a two-armed branch the register allocator spilled ~300)
-        const bool first = wave < 4;
-        DN_PH(0);
-        if (first && tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
-        attend(cur);
-        if (!first && tile + 1 < tile1) scores_weights(y1, x1, cur ^ 1);
-        y0 = y1; x0 = x1; y1 = y2; x1 = x2;
-        next_tile(y1, x1, y2, x2);
-        DN_PH(6);
-        dma_wait_all();
-        __syncthreads();
-        DN_PH(5);
+    // One barrier per tile; between two barriers the two kinds of wave work on different tiles.  With r = tile - tile0: the producers
+    // request the key features of tile r + 3 (-> sm[r % 3]: tile r's were consumed two iterations ago), turn the raw scores of tile
+    // r + 1 (in their registers since the last iteration) into weights (-> spq[(r + 1) & 1]) and form the raw scores of tile r + 2
+    // (sm[(r + 2) % 3]); the consumers request the value region of tile r + 1 (-> sv[(r + 1) & 1]) and multiply tile r (spq[r & 1],
+    // sv[r & 1]).  A multiplying wave issues nothing but fragment reads and multiplies (and 1.5 LDS-DMA pieces): with both kinds of
+    // work in every wave (the first round-4 shape: 8 waves, the two of a SIMD in opposite order) the pipes were 55 % busy.
+    // Two loops, one per role (the same number of barriers in both): the query fragments are live in one, the accumulators in the
+    // other -- in one loop with a branch inside both would hold their registers in every wave.
+    // The producer's multiplies wait for the matrix pipe behind the consumers' (a 32-cycle multiply is not pre-empted: ~50 cycles
+    // per short multiply, 42 of them): its ~250 VALU operations of the weights are issued BETWEEN them -- scores of one tile,
+    // weights of the previous one, no dependence -- instead of after them (scores, then weights: the chain was 5 000 cycles per tile
+    // for 3 000 of matrix work per SIMD, profiles/r04_dense_pc_phases.log).
+    if (producer) {
+        __builtin_amdgcn_s_setprio(2);
+        for (int tile = tile0; tile < tile1; ++tile) {
+            const int r = tile - tile0;
+            DN_PH(0);
+            if (tile + 3 < tile1 && !(a.variant & 4)) stage_keys(y3, x3, r % 3);
+            DN_PH(1);
+            if (tile + 1 < tile1) {
+                // One basic block, 14 slots = (k-step, key group): per slot the fragment pair of slot + 2 is requested, the slot's
+                // three multiplies are issued (tile r + 2; past the last tile: on whatever the stage holds, never used) and one
+                // fourteenth of the weights' VALU work is done (tile r + 1, from the scores formed one iteration ago).  Fences keep
+                // the order: left to the scheduler, every multiply sat behind its own fragment read and a full LDS round trip.
+                constexpr int PF = 2, NSL = 2 * DN_KS;
+                const unsigned kb_addr = lds_sm + (unsigned)(((r + 2) % 3) * DN_KTILE_B) + ka_off;
+                dnh8 fh[PF + 1], fl[PF + 1];
+                auto kfrag = [&](int sl) {
+                    const unsigned ad = kb_addr + (unsigned)((sl & 1) * 16 * (DN_KPITCH * 16) + 64 * (sl >> 1));
+                    fh[sl % (PF + 1)] = __builtin_bit_cast(dnh8, dn_lds128(ad));
+                    fl[sl % (PF + 1)] = __builtin_bit_cast(dnh8, dn_lds128(ad + DN_KPART_B));
+                };
+                SAcc s_new;
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) { s_new.hh[kg] = f32x4{0.f, 0.f, 0.f, 0.f}; s_new.hl[kg] = s_new.hh[kg]; s_new.lh[kg] = s_new.hh[kg]; }
+                dnh4 hq[2], lq[2];
+                float zt[2] = {0.f, 0.f}, zpt[2] = {0.f, 0.f};
+                int dt[2] = {0, 0};
+                const int jy0 = y1, jx0 = x1, pbuf = (r + 1) & 1;
+#pragma unroll
+                for (int sl = 0; sl < PF; ++sl) kfrag(sl);
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    if (sl + PF < NSL) kfrag(sl + PF);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const int kg = sl & 1, ks = sl >> 1;
+                        const dnh8 k_hi = fh[sl % (PF + 1)], k_lo = fl[sl % (PF + 1)];
+                        s_new.hl[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], s_new.hl[kg], 0, 0, 0);
+                        s_new.hh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], s_new.hh[kg], 0, 0, 0);
+                        s_new.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], s_new.lh[kg], 0, 0, 0);
+                    }
+                    if (sl < 8) {
+                        // register rr of key group kg holds key 16 kg + 4 gk + rr of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + rr)
+                        const int kg = sl >> 2, rr = sl & 3;
+                        const float sc = sc_next[kg][rr];
+                        const bool valid = (jy0 + 2 * kg + (gk >> 1) < g.H) && (jx0 + 4 * (gk & 1) + rr < g.W);
+                        bool pass;
+                        const float l = dn_logit(sc, mtq, bsq, pass);
+                        const float e = __expf(fminf(l - m_run, 0.f));            // (the bound holds; the clamp is a seat belt)
+                        const float p = valid ? e : 0.f;
+                        zt[kg] += p;
+                        pass = pass && valid;
+                        const float pp = pass ? p : 0.f;
+                        zpt[kg] += pp;
+                        dt[kg] += pass ? 1 : 0;
+                        const float ps = pp * DN_PS;
+                        const _Float16 hp = (_Float16)ps;
+                        hq[kg][rr] = hp;
+                        lq[kg][rr] = (_Float16)(ps - (float)hp);
+                    } else if (sl < 10) {
+                        const int kg = sl - 8;
+                        z_run += (double)zt[kg]; zp_run += (double)zpt[kg]; deg += dt[kg];     // (fp32 per tile and key group, one fp64 add each)
+                        unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
+                        *reinterpret_cast<dnh4*>(pq) = hq[kg];
+                        *reinterpret_cast<dnh4*>(pq + 32) = lq[kg];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                final_scores(s_new);
+            }
+            y0 = y1; x0 = x1; y1 = y2; x1 = x2; y2 = y3; x2 = x3;
+            next_tile(y2, x2, y3, x3);
+            DN_PH(6);
+            dma_wait_all();
+            __syncthreads();
+            DN_PH(5);
+        }
+    } else {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int t = 0; t < DN_CTMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
+        acc48 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = tile0; tile < tile1; ++tile) {
+            const int cur = (tile - tile0) & 1;
+            DN_PH(0);
+            if (tile + 1 < tile1 && !(a.variant & 4)) stage_values(y1, x1, cur ^ 1);
+            attend(cur);
+            y0 = y1; x0 = x1; y1 = y2; x1 = x2; y2 = y3; x2 = x3;
+            next_tile(y2, x2, y3, x3);
+            DN_PH(6);
+            dma_wait_all();
+            __syncthreads();
+            DN_PH(5);
+        }
     }
 #ifdef DAGL_ABLATION
     if (clocks && lane == 0) {
-        unsigned* po = a.phase_out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        unsigned* po = a.phase_out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 12 + wave) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) po[e] = ph[e];
     }
 #endif
 
     // ---- partial results of this key range ------------------------------------------------------------------------------------------
-    szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg;
+    if (producer) { szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; }
     __syncthreads();
     if (tid < 64) {
-        // query tid of the block: its scores lived in waves (qg, kg = 0 | 1), lanes c16 + 16 gk; summed in a fixed order
+        // query tid of the block: its scores lived in producer wave tid / 16, lanes c16 + 16 gk; summed in a fixed order
         const int q = qb * 64 + tid;
         if (q < g.L) {
             const int wq_ = tid >> 4, cq = tid & 15;
             double z = 0.0, zp = 0.0; int d = 0;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    z += szz[wq_ + 4 * k2][cq + 16 * g4][0]; zp += szz[wq_ + 4 * k2][cq + 16 * g4][1]; d += sdg[wq_ + 4 * k2][cq + 16 * g4];
-                }
+            for (int g4 = 0; g4 < 4; ++g4) { z += szz[wq_][cq + 16 * g4][0]; zp += szz[wq_][cq + 16 * g4][1]; d += sdg[wq_][cq + 16 * g4]; }
             const size_t orow = ((size_t)split * a.B + b) * g.L + q;
             const size_t ql = (size_t)b * g.L + q;
             const float sub = a.smax[ql] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
@@ -480,15 +587,17 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             a.part_z[2 * orow] = z; a.part_z[2 * orow + 1] = zp; a.part_deg[orow] = d;
         }
     }
+    if (!producer) {
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {                       // this wave's column tiles of both query tiles
-        const int q2 = qb * 64 + qq * 32 + i;
-        if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0);
-    }
-    if (wave < 4 && qs < g.L) {                            // tap 48: columns 768 + 4 gk .. of query qs (= qb 64 + 16 wave + c16 for these waves)
-        constexpr float inv = 1.0f / (DN_PS * DN_VS);
-        *reinterpret_cast<float4*>(a.part_acc + (((size_t)split * a.B + b) * g.L + qs) * P + 768 + 4 * gk) =
-            make_float4(acc48[0] * inv, acc48[1] * inv, acc48[2] * inv, acc48[3] * inv);
+        for (int qq = 0; qq < 2; ++qq) {                   // this wave's column tiles of both query tiles
+            const int q2 = qb * 64 + qq * 32 + i;
+            if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0);
+        }
+        if (cw < 4 && qs < g.L) {                          // tap 48: columns 768 + 4 gk .. of query qs (= qb 64 + 16 cw + c16 for these waves)
+            constexpr float inv = 1.0f / (DN_PS * DN_VS);
+            *reinterpret_cast<float4*>(a.part_acc + (((size_t)split * a.B + b) * g.L + qs) * P + 768 + 4 * gk) =
+                make_float4(acc48[0] * inv, acc48[1] * inv, acc48[2] * inv, acc48[3] * inv);
+        }
     }
 }
 
@@ -691,7 +800,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.phase_out = nullptr;
 #ifdef DAGL_ABLATION
     const size_t n_blocks = (size_t)n_qblocks * a.splits * B;
-    if ((a.variant & 64) && getenv("DAGL_TIMES_FILE")) a.phase_out = reinterpret_cast<unsigned*>(dbg_times_buffer(n_blocks * 8));
+    if ((a.variant & 64) && getenv("DAGL_TIMES_FILE")) a.phase_out = reinterpret_cast<unsigned*>(dbg_times_buffer(n_blocks * 12));
 #endif
     hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
@@ -700,15 +809,15 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
         static int budget = 3, skip = 8;
         if (skip > 0) --skip;
         else if (budget-- > 0 && hipStreamSynchronize(s) == hipSuccess) {
-            unsigned* h = static_cast<unsigned*>(malloc(n_blocks * 64 * sizeof(unsigned)));
-            if (h && hipMemcpy(h, a.phase_out, n_blocks * 64 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned* h = static_cast<unsigned*>(malloc(n_blocks * 96 * sizeof(unsigned)));
+            if (h && hipMemcpy(h, a.phase_out, n_blocks * 96 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
                 if (FILE* f = fopen(getenv("DAGL_TIMES_FILE"), "a")) {
                     static const char* nm[8] = {"stage", "S", "weights", "p-load", "AV", "wait+barrier", "coords", "-"};
-                    for (int grp = 0; grp < 2; ++grp) {
+                    for (int grp = 0; grp < 3; ++grp) {               // waves 0-3: producers, 4-11: consumers
                         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
                         for (size_t bl = 0; bl < n_blocks; ++bl)
                             for (int w = 4 * grp; w < 4 * grp + 4; ++w)
-                                for (int e = 0; e < 8; ++e) sum[e] += h[(bl * 8 + w) * 8 + e];
+                                for (int e = 0; e < 8; ++e) sum[e] += h[(bl * 12 + w) * 8 + e];
                         for (int e = 0; e < 8; ++e) { sum[e] /= (double)(n_blocks * 4); tot += sum[e]; }
                         fprintf(f, "dense_attend phases, waves %d-%d (clocks per wave, %d tiles per block): total %.0f |", 4 * grp, 4 * grp + 3, a.tiles_per_split, tot);
                         for (int e = 0; e < 7; ++e) fprintf(f, " %s %.0f (%.1f %%)", nm[e], sum[e], 100.0 * sum[e] / tot);

@@ -40,7 +40,7 @@ def short(name):
         if key in name:
             return out
     for key in ("screen_kernel<1", "screen_kernel<0", "project16_kernel", "refine_kernel", "conv_pair16_kernel", "gather_rows_kernel",
-                "aggregate_direct_kernel", "aggregate_fold_kernel", "fold_kernel", "ovf_attend_kernel", "ovf_scores_small_kernel", "screen_theta_kernel", "dense_attend_kernel", "gemm32_kernel", "gemm16s_kernel",
+                "aggregate_direct_kernel", "aggregate_fold_kernel", "fold_kernel", "ovf_attend_kernel", "ovf_scores_aggregate_kernel", "ovf_combine_kernel", "screen_theta_kernel", "dense_attend_kernel", "gemm32_kernel", "gemm16s_kernel",
                 "score_select_kernel", "edge_softmax_topk_kernel", "thr_bias_kernel"):
         if key in name:
             return key + (">" if key.endswith(("<1", "<0")) else "")
