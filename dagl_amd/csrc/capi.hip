@@ -592,9 +592,17 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             prof_mark(prof, s, 8);
             return DAGL_OK;
         }
-        // (the few queries whose neighbourhood overflowed the lists were redone one by one ahead of the verdict read-back --
-        // dense rows, overflow.hip: their aggregated rows, degrees and softmax mass are in place, this gather skips them)
-        if (!agg_done && (r = launch_aggregate_direct(s, ag2))) return r;
+        // (the few queries whose neighbourhood overflowed the lists are redone one by one, dense rows, overflow.hip; the list gather
+        // skips them.  A call that does not wait had both done in the overflow launches; one that waits has its statistics on their
+        // way to the host by now and queues the gathers here, under the round trip)
+        if (!agg_done) {
+            if ((r = launch_aggregate_direct(s, ag2))) return r;
+            if (ovf_active) {           // (a call that waited for its verdict: the flagged rows' gathers behind the read-back)
+                OvfArgs oa = overflow_args();
+                oa.edges_run = nullptr;                     // (their edges are known: ovf_attend_kernel looks at flagged_edges)
+                if ((r = launch_overflow_apply(s, oa))) return r;
+            }
+        }
         prof_mark(prof, s, 7);
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((r = launch_fold(s, B, g, agg, out, heads, rt))) return r;
@@ -743,8 +751,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             }
             if (ovf_active) {           // the flagged rows redone (three launches that exit at once when there are none) + the call's statistics
                 const OvfArgs oa = overflow_args();
-                if ((rc = launch_overflow_rows(s, oa, ag, BL, stats, no_wait ? reinterpret_cast<int32_t*>(stats + 8) : nullptr, rt.tag))) return rc;
-                agg_done = true;
+                // (a call that does not wait shares the scores' launch with the gather over the lists; one that waits keeps the gather
+                // behind the read-back: the host round trip runs under it)
+                if ((rc = launch_overflow_rows(s, oa, no_wait ? &ag : nullptr, BL, stats, no_wait ? reinterpret_cast<int32_t*>(stats + 8) : nullptr,
+                                               rt.tag))) return rc;
+                agg_done = no_wait;
             } else {
                 if ((rc = launch_degree_stats(s, BL, nbcnt, stats))) return rc;
             }

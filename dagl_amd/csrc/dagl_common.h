@@ -470,8 +470,9 @@ constexpr int OVF_PART_FLOATS = P + 8;                         // weighted sum (
 // over every query's list (`ag`: what launch_aggregate_direct does; flagged rows are skipped); then total edges / largest degree
 // of the call (stats[0], [1]) and, for the calls that do not wait, *veto = tag when the host would have had to send the call elsewhere
 struct AggArgs;
-int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs& ag, size_t n_rows, int64_t* stats, int32_t* veto = nullptr,
-                         int32_t tag = 0);
+int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs* ag /* null: the caller gathers, then launch_overflow_apply */,
+                         size_t n_rows, int64_t* stats, int32_t* veto = nullptr, int32_t tag = 0);
+int launch_overflow_apply(hipStream_t s, const OvfArgs& a);     // (calls that wait for their verdict: attend + combine behind the read-back)
 int overflow_cap(int N, int B);
 
 // fixed-k neighbourhoods wider than the lists (k > DAGL_MAX_TOPK, topk_wide.hip): row-wise dense form, a batch of queries at a time

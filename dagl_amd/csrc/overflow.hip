@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void ovf_scores_aggregate_kernel(OvfArgs a, Ag
     aggregate_direct_block(ag, q / ag.g.L, q % ag.g.L, sh_of, sh_w);
 }
 
+// Passing keys per (flagged query, key chunk), nothing else: what the call's statistics need.  A call that WAITS for its verdict
+// runs this and the statistics block first, queues the read-back, and only then the gathers (list gather, attend, combine): the
+// host round trip and the enqueueing of the caller's next launches run under them.
+__global__ __launch_bounds__(256) void ovf_count_kernel(OvfArgs a) {
+    __shared__ int shc[4];
+    const int nf = ovf_rows_served(a);
+    if (nf == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int j0c, j1c; row_chunk_range(a.g.N, blockIdx.x, j0c, j1c);
+    int j0, j1; row_wave_range(j0c, j1c, w, j0, j1);
+    for (int slot = blockIdx.y; slot < nf; slot += gridDim.y) {
+        const size_t ql = (size_t)a.list[slot];
+        const int b = (int)(ql / a.g.L);
+        const float* row = a.scores + ((size_t)b * a.cap + slot) * a.ldn;
+        const float mtq = a.mt[ql], bsq = a.bs[ql];
+        int cnt = 0;
+        for (int c0 = j0; c0 < j1; c0 += 64) {
+            const int j = c0 + lane; bool pass = false;
+            if (j < j1) (void)ovf_logit(row[j], mtq, bsq, pass);
+            cnt += __popcll(__ballot(pass));
+        }
+        if (lane == 0) shc[w] = cnt;
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<int*>(a.part + ((size_t)slot * ROW_CHUNKS + blockIdx.x) * ROW_PART_FLOATS + P)[1] = shc[0] + shc[1] + shc[2] + shc[3];
+        __syncthreads();
+    }
+}
+
 // Mask, softmax statistics and weighted sums of the flagged queries from their score rows.  A row is cut into OVF_CHUNKS key
 // chunks: block (chunk c, lane y of 32) takes the flagged queries y, y + 32, ..; its four waves split the chunk (a row with
 // hundreds of passing keys is a latency chain of value-patch gathers; one block per query left it at 290 us).
@@ -104,6 +132,9 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
     __shared__ int shc[4]; __shared__ int sh_over;
     const int nf = ovf_rows_served(a);
     if (nf == 0) return;
+    // (a call that waits for its verdict knows the flagged rows' edges before this launch: beyond the limit the host, looking at
+    // the same word, runs the dense formulation instead)
+    if (a.edges_run == nullptr && a.flagged_edges != nullptr && *a.flagged_edges > a.edge_limit) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const RowCols cols = row_cols(lane);
     unsigned long long* edges_run = reinterpret_cast<unsigned long long*>(a.edges_run);
@@ -143,13 +174,14 @@ __global__ __launch_bounds__(256) void ovf_attend_kernel(OvfArgs a) {
 // blocks 0 .. gridDim.x - 2: the flagged rows, combined from their chunks (row = sum of the chunks' partial rows, scaled, in chunk
 // order, / Z); overwrites the aggregated row.  Last block: the call's statistics -- total edges and largest degree (the lists'
 // counts, a flagged row counted with its true degree), the flagged rows' edges, and the verdict of the calls that do not wait.
-__global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_rows, int64_t* __restrict__ stats, int32_t* veto, int32_t tag) {
+__global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_rows, int64_t* __restrict__ stats, int32_t* veto, int32_t tag,
+                                                          int what /* 1: the rows, 2: the statistics block, 3: both */) {
     __shared__ RowReduceShared sh;
     __shared__ long long sh_l[4][3];
     const int nf = ovf_rows_served(a);
     const int tid = threadIdx.x;
     const int C4 = P / 4;
-    if (blockIdx.x == gridDim.x - 1) {
+    if ((what & 2) && blockIdx.x == gridDim.x - 1) {
         long long sum = 0, fl = 0; int mx = 0;
         for (size_t r = tid; r < n_rows; r += 256) { const int d = max(a.nb_cnt[r], 0); sum += d; mx = max(mx, d); }
         for (int slot = tid; slot < nf; slot += 256) {                           // a flagged row counts with its true degree
@@ -179,7 +211,9 @@ __global__ __launch_bounds__(256) void ovf_combine_kernel(OvfArgs a, size_t n_ro
         }
         return;
     }
-    for (int slot = blockIdx.x; slot < nf; slot += gridDim.x - 1) {
+    if (!(what & 1)) return;
+    const int row_blocks = (what & 2) ? gridDim.x - 1 : gridDim.x;
+    for (int slot = blockIdx.x; slot < nf; slot += row_blocks) {
         const size_t ql = (size_t)a.list[slot];
         const float* part_row = a.part + (size_t)slot * ROW_CHUNKS * ROW_PART_FLOATS;
         const RowSum row = row_reduce(part_row, a.g.N, sh);
@@ -203,32 +237,60 @@ int overflow_cap(int N, int B) {
 }
 
 // The redo of the flagged queries, queued right behind the refine kernels: (matrix-core scores when there are many,) VALU scores
-// when there are few -- in one launch with the gather + weighted sum over everybody's lists (`ag`) --, rows, combine + statistics.
-// Every kernel reads the number of flagged queries from device memory and exits at once when it is zero.
-int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs& ag, size_t n_rows, int64_t* stats, int32_t* veto, int32_t tag) {
-    if (a.cap <= 0) return DAGL_ERR_INVALID;
+// when there are few, rows, combine + statistics.  Every kernel reads the number of flagged queries from device memory and exits
+// at once when it is zero.  Two orders:
+//   ag given (a call that does not wait for its verdict): scores in one launch with the gather + weighted sum over everybody's
+//     lists, attend, combine + statistics -- four launches;
+//   ag null (a call that waits): scores, counts, statistics -- then the caller queues its read-back, the list gather, and
+//     launch_overflow_apply (attend, combine): everything that gathers runs under the host's round trip.
+static int ovf_scores(hipStream_t s, const OvfArgs& a, const AggArgs* ag) {
     // scores of the flagged queries against all keys when they are many: one product [flagged, 196] x [196, N] on the fp32 matrix
     // cores (chains of 48 products, partial sums added in fp32), batched over the images: every image's keys against ALL flagged
     // rows (a flagged query only reads the row block of its own image); the query rows were compacted by the refine kernels
-    {
-        Gemm32 g;
-        g.M = a.cap; g.N = a.g.N; g.K = D; g.batch = a.B;
-        g.A = a.qrows; g.lda = DS; g.sA = 0; g.a_kc = 1;                          // the same flagged rows for every image
-        g.B = a.x; g.ldb = DS; g.sB = (long long)a.rows_x * DS; g.b_kc = 1;
-        g.C = a.scores; g.ldc = a.ldn; g.sC = (long long)a.cap * a.ldn;
-        g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3;
-        g.m_limit = a.count;                                                       // few rows (VALU form) or more than the list holds: none
-        g.m_limit_floor = a.cap < OVF_SMALL ? a.cap : OVF_SMALL; g.m_limit_ceil = a.cap;
-        const int rc = launch_gemm32(s, g);
-        if (rc) return rc;
-    }
+    Gemm32 g;
+    g.M = a.cap; g.N = a.g.N; g.K = D; g.batch = a.B;
+    g.A = a.qrows; g.lda = DS; g.sA = 0; g.a_kc = 1;                          // the same flagged rows for every image
+    g.B = a.x; g.ldb = DS; g.sB = (long long)a.rows_x * DS; g.b_kc = 1;
+    g.C = a.scores; g.ldc = a.ldn; g.sC = (long long)a.cap * a.ldn;
+    g.alpha = 1.f; g.beta = 0.f; g.bias = nullptr; g.relu = 0; g.chunk_tiles = 3;
+    g.m_limit = a.count;                                                       // few rows (VALU form) or more than the list holds: none
+    g.m_limit_floor = a.cap < OVF_SMALL ? a.cap : OVF_SMALL; g.m_limit_ceil = a.cap;
+    const int rc = launch_gemm32(s, g);
+    if (rc) return rc;
     const int score_blocks = (a.g.N + 63) / 64;
-    hipLaunchKernelGGL(ovf_scores_aggregate_kernel, dim3((unsigned)(score_blocks * a.B + a.g.L * a.B)), dim3(256), 0, s, a, ag, score_blocks);
+    hipLaunchKernelGGL(ovf_scores_aggregate_kernel, dim3((unsigned)(score_blocks * a.B + (ag ? a.g.L * a.B : 0))), dim3(256), 0, s, a,
+                       ag ? *ag : AggArgs(), score_blocks);
     DAGL_LAUNCH_CHECK("ovf_scores_aggregate_kernel");
+    return DAGL_OK;
+}
+
+int launch_overflow_rows(hipStream_t s, const OvfArgs& a, const AggArgs* ag, size_t n_rows, int64_t* stats, int32_t* veto, int32_t tag) {
+    if (a.cap <= 0) return DAGL_ERR_INVALID;
+    int rc = ovf_scores(s, a, ag);
+    if (rc) return rc;
     const int gy = a.cap < 32 ? a.cap : 32;                               // flagged queries are strided over grid.y
+    const int rb = a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B;
+    if (ag != nullptr) {
+        hipLaunchKernelGGL(ovf_attend_kernel, dim3(ROW_CHUNKS, gy), dim3(256), 0, s, a);
+        DAGL_LAUNCH_CHECK("ovf_attend_kernel");
+        hipLaunchKernelGGL(ovf_combine_kernel, dim3(rb + 1), dim3(256), 0, s, a, n_rows, stats, veto, tag, 3);
+        DAGL_LAUNCH_CHECK("ovf_combine_kernel");
+    } else {
+        hipLaunchKernelGGL(ovf_count_kernel, dim3(ROW_CHUNKS, gy), dim3(256), 0, s, a);
+        DAGL_LAUNCH_CHECK("ovf_count_kernel");
+        hipLaunchKernelGGL(ovf_combine_kernel, dim3(1), dim3(256), 0, s, a, n_rows, stats, veto, tag, 2);
+        DAGL_LAUNCH_CHECK("ovf_combine_kernel");
+    }
+    return DAGL_OK;
+}
+
+// (the second half of the order for calls that wait: behind the read-back and the list gather)
+int launch_overflow_apply(hipStream_t s, const OvfArgs& a) {
+    if (a.cap <= 0) return DAGL_ERR_INVALID;
+    const int gy = a.cap < 32 ? a.cap : 32;
     hipLaunchKernelGGL(ovf_attend_kernel, dim3(ROW_CHUNKS, gy), dim3(256), 0, s, a);
     DAGL_LAUNCH_CHECK("ovf_attend_kernel");
-    hipLaunchKernelGGL(ovf_combine_kernel, dim3((a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B) + 1), dim3(256), 0, s, a, n_rows, stats, veto, tag);
+    hipLaunchKernelGGL(ovf_combine_kernel, dim3(a.cap < OVF_GRID_B ? a.cap : OVF_GRID_B), dim3(256), 0, s, a, (size_t)0, nullptr, nullptr, 0, 1);
     DAGL_LAUNCH_CHECK("ovf_combine_kernel");
     return DAGL_OK;
 }

@@ -1,5 +1,5 @@
 """Run ON THE GPU BOX: one CE head, adaptive mask in the sparse regime (the benchmark's mean-degree-8 / -55 cases), ms per call.
-   python tools/sparse_case.py <gain: 1.95 | 1.8> [calls]"""
+   python tools/sparse_case.py <gain: 1.95 | 1.8> [calls] [always | auto]  (adaptive_sync; default auto)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ prm = {n: torch.from_numpy(a) for n, a in make_ce_params(41, variant="sparse", s
 ce = CE(in_channels=64)
 ce.load_state_dict(prm, strict=True)
 ce.select_mode = "adaptive"
-ce.adaptive_sync = "auto"
+ce.adaptive_sync = sys.argv[3] if len(sys.argv) > 3 else "auto"
 ce = ce.to(dev).eval()
 x = torch.from_numpy(make_features(41, 1, 64, 256, 256)).to(dev)
 with torch.no_grad():
@@ -26,4 +26,4 @@ with torch.no_grad():
         ce(x)
     e1.record()
     torch.cuda.synchronize()
-print(f"sparse_case gain {gain}: {e0.elapsed_time(e1) / calls:.4f} ms per call (path {(ce.last_info or {}).get('path')})")
+print(f"sparse_case gain {gain} sync={ce.adaptive_sync}: {e0.elapsed_time(e1) / calls:.4f} ms per call (path {(ce.last_info or {}).get('path')})")
