@@ -14,6 +14,8 @@ the device memory and the stream.  There is no eager fallback.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -110,10 +112,12 @@ class CE(nn.Module):
     def __init__(self, ksize=7, stride_1=4, stride_2=1, softmax_scale=10, shape=64, p_len=64, in_channels=64,
                  inter_channels=16, use_multiple_size=False, use_topk=False, add_SE=False, num_edge=50):
         super().__init__()
-        if (ksize, stride_1, stride_2, softmax_scale, inter_channels) != (7, 4, 1, 10, 16):
+        if (ksize, stride_1, stride_2, inter_channels) != (7, 4, 1, 16):
             raise DaglError(
-                "dagl_amd.CE implements the hyper-parameters the reference ships and never overrides "
-                "(ksize=7, stride_1=4, stride_2=1, softmax_scale=10, inter_channels=16; dagl.py:175-176)")
+                "dagl_amd.CE implements the patch geometry the reference ships and never overrides "
+                "(ksize=7, stride_1=4, stride_2=1, inter_channels=16; dagl.py:175-176)")
+        if not float(softmax_scale) > 0.0:
+            raise DaglError(f"CE: softmax_scale={softmax_scale} must be positive")
         self.ksize, self.shape, self.p_len = ksize, shape, p_len
         self.stride_1, self.stride_2 = stride_1, stride_2
         self.softmax_scale = softmax_scale
@@ -142,7 +146,8 @@ class CE(nn.Module):
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
         self._pack_epoch = 0           # bumped by invalidate_packed()
-        self._f32_cache = {}           # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
+        self._f32_cache = {}
+        self._scaled_cache = {}           # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
         self._train_calls = 0
         self._last_call = None
         self._calls_since_range_check = 0
@@ -231,6 +236,17 @@ class CE(nn.Module):
     def extra_repr(self):
         return f"select_mode={self.select_mode!r}, select_k={self.select_k}"
 
+    def _scale_c(self) -> float:
+        """softmax_scale other than the kernels' 10 (dagl.py:175, 260), without touching a kernel: the logits are
+        softmax_scale * S * m with m = relu(S - mean(S) thr + bias) (top-k variant: m in {0, 1}).  Scaling the query features by c
+        (fc1's weight and bias: ReLU is positively homogeneous) scales S and mean(S) thr by c; scaling the bias head by c as well
+        scales m by c, the mask (m > 0) and the top-k order do not move, and the kernels' 10 * S' * m' is 10 c^2 S m (10 c S for the
+        top-k variant).  So c = sqrt(softmax_scale / 10), or softmax_scale / 10 in "topk" mode."""
+        r = float(self.softmax_scale) / 10.0
+        if r == 1.0:
+            return 1.0
+        return r if self.select_mode == "topk" else math.sqrt(r)
+
     def _params_f32(self):
         """The block's parameters as contiguous fp32 tensors.  fp32 modules: the parameters themselves.  ``model.half()`` /
         ``.bfloat16()`` modules (the reference's ``--precision half`` test path, DN_Gray/model/__init__.py:98-99,
@@ -252,6 +268,16 @@ class CE(nn.Module):
                 hit = (tag, t.float().contiguous())
                 self._f32_cache[n] = hit
             out[n] = hit[1]
+        c = self._scale_c()
+        if c != 1.0:                    # (see _scale_c; scaled copies kept until the parameter or the factor changes)
+            for n in ("fc1.0.weight", "fc1.0.bias") + (() if self.select_mode == "topk" else ("bias_conv.weight", "bias_conv.bias")):
+                src = out[n]
+                tag = (src.data_ptr(), src._version, c)
+                hit = self._scaled_cache.get(n)
+                if hit is None or hit[0] != tag:
+                    hit = (tag, (src * c).contiguous())
+                    self._scaled_cache[n] = hit
+                out[n] = hit[1]
         return out
 
     def _prologue(self, b):
@@ -296,6 +322,11 @@ class CE(nn.Module):
                                  T.PAD - t, T.PAD - l, Lh, Lw, relu=True, allow_fast=self.scan != "exact")   # [B,L,196]
         x_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc2[0].weight, c, ks), self.fc2[0].bias, ks, self.stride_2,
                                 0, 0, H, W, relu=True, allow_fast=self.scan != "exact")             # [B,N,196]
+        sc = self._scale_c()
+        if sc != 1.0:                   # softmax_scale != 10: see _scale_c (plain torch ops: autograd carries the factor)
+            wq_rows = wq_rows * sc
+            if bias is not None:
+                bias = bias * sc
         info = {}
         self._pack_key = None          # the shared workspace is reused with another layout
         out = None
@@ -408,7 +439,7 @@ class CE(nn.Module):
         # repacking while neither the weights (torch bumps ._version on every in-place update) nor the call geometry changed
         wsb = self._ws.peek(b.device)
         src = dict(self.named_parameters())       # (keyed on the module's own tensors: the fp32 copies of half weights follow them)
-        key = (tuple(b.shape), self.select_mode, k_eff, self.scan, self._pack_epoch,
+        key = (tuple(b.shape), self.select_mode, k_eff, self.scan, self._pack_epoch, self._scale_c(),
                tuple((src[n].data_ptr(), src[n]._version) for n in ("fc1.0.weight", "fc2.0.weight", "g.weight", "theta.weight")),
                wsb.data_ptr() if wsb is not None else 0)
         # dense regime: the edge statistics (and with them a host synchronisation) are only fetched every 16th call, to

@@ -66,6 +66,7 @@ class CES(nn.Module):
         if self.fuse_stage and all(isinstance(hd, CE) for hd in heads) and x.is_cuda and x.dtype == torch.float32 \
                 and no_grad and len({(hd.select_mode, hd.select_k, hd.scan) for hd in heads}) == 1 \
                 and heads[0].scan == "screened" and self._skip_fused[s] == 0 and 0 <= k_eff <= MAX_TOPK \
+                and all(float(hd.softmax_scale) == 10.0 for hd in heads) \
                 and all(p.dtype == torch.float32 for hd in heads for p in hd.parameters()):
             # the four heads share x: one launch set with the heads as a batch dimension + the 1x1 mix + residual
             from . import ops

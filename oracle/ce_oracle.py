@@ -69,7 +69,7 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
                       mode: str = "adaptive", k: Optional[int] = None,
                       dtype: torch.dtype = torch.float32,
                       zero_guard: bool = True,
-                      stages: bool = False):
+                      stages: bool = False, softmax_scale: float = 10.0):
     """Dense restatement of ``CE.forward``.
 
     x       [B, C, H, W]
@@ -118,7 +118,7 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     for n in range(B):                                                # dagl.py:245
         Wq = F.relu(F.linear(q_rows[n], P["fc1.0.weight"], P["fc1.0.bias"]))  # [L,196] :248
         X = F.relu(F.linear(k_rows[n], P["fc2.0.weight"], P["fc2.0.bias"]))   # [N,196] :249
-        z, c = _graph_core(Wq, X, thr[n], bias[n], v_rows[n], mode, k, H, W, fold_pad)
+        z, c = _graph_core(Wq, X, thr[n], bias[n], v_rows[n], mode, k, H, W, fold_pad, softmax_scale)
         outs.append(z / cnt)                                                   # :272
         if stages:
             st["Wq"].append(Wq); st["X"].append(X)
@@ -132,7 +132,7 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     return out
 
 
-def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad):
+def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax_scale=SOFTMAX_SCALE):
     """One sample of dagl.py:250-267 from its feature rows: similarity, mask, edge softmax, aggregate, fold
     (not yet divided by the overlap count).  Returns (folded [1,c,H,W], dict of intermediates)."""
     dtype = Wq.dtype
@@ -152,7 +152,7 @@ def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad):
             keep = torch.zeros_like(S)
             keep.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
             m, mb = m * keep, mb * keep
-    A = F.softmax(S * m * SOFTMAX_SCALE, dim=1) * mb                           # :259-261
+    A = F.softmax(S * m * softmax_scale, dim=1) * mb                           # :259-261 (self.softmax_scale, 10 unless the ctor says otherwise: :175)
     agg = A @ v_rows_n                                                         # [L,784] :263-264
     z = None
     if fold_pad is not None:                          # (None: a sample of the queries, nothing to fold)
@@ -190,7 +190,7 @@ def ce_core_oracle(wq_rows: torch.Tensor, x_rows: torch.Tensor, b2: torch.Tensor
 
 
 def ce_rows_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], rows: torch.Tensor, *, mode: str = "adaptive",
-                   k: Optional[int] = None, dtype: torch.dtype = torch.float32):
+                   k: Optional[int] = None, dtype: torch.dtype = torch.float32, softmax_scale: float = 10.0):
     """``ce_forward_oracle`` restricted to the query patches ``rows`` (indices into the L queries) of ONE image
     ``x [1,C,H,W]``: every row of S is independent of the others (the mean of dagl.py:256 runs over the keys), so a
     sample of queries can be checked against all N keys at sizes where the full ``[L,N]`` matrix does not fit the host
@@ -210,7 +210,7 @@ def ce_rows_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], rows: torch
     X = F.relu(F.linear(patch_rows(b1, KSIZE, STRIDE_KV)[0], P["fc2.0.weight"], P["fc2.0.bias"]))
     v_rows = patch_rows(b2, KSIZE, STRIDE_KV)[0]
     H, W = x.shape[2:]
-    _, c = _graph_core(Wq, X, thr, bias, v_rows, mode, k, H, W, None)
+    _, c = _graph_core(Wq, X, thr, bias, v_rows, mode, k, H, W, None, softmax_scale)
     return c
 
 

@@ -15,7 +15,14 @@ def pytest_configure(config):
 def golden_cases():
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*.npz")))
-    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol", "quality_"))]      # CE block cases only
+    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol", "quality_"))      # CE block cases only
+            and "_scale" not in os.path.basename(f)]                        # (softmax_scale != 10: scale_cases())
+
+
+def scale_cases():
+    """Goldens minted with a softmax_scale other than the default 10 (meta["softmax_scale"])."""
+    import glob
+    return sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*_scale*.npz")))
 
 
 @pytest.fixture(scope="session")

@@ -69,6 +69,11 @@ CASES = [
     ("topk100_64x64",        "TOPK",     32, "default", 2.0, "topk",   100, 1, 64, 64),
     ("topk500_b2_40x36",     "TOPK",     33, "default", 2.0, "topk",   500, 2, 40, 36),
     ("topk500_k_gt_n_20x24", "TOPK",     34, "default", 2.0, "topk",   500, 1, 20, 24),
+    # softmax_scale other than the default 10 (a ctor argument of every fork's CE, dagl.py:175; never passed by the reference's own
+    # builders): a 12th column
+    ("gray_sparse_scale4_48x40",  "DN_Gray", 35, "sparse",  1.6, "adaptive", 0, 1, 48, 40, 64, 4),
+    ("gray_default_scale25_b2_24x28", "DN_Gray", 36, "default", 2.0, "adaptive", 0, 2, 24, 28, 64, 25),
+    ("topk8_scale3_36x40",        "TOPK",    37, "default", 2.0, "topk",     8, 1, 36, 40, 64, 3),
 ]
 
 
@@ -96,17 +101,18 @@ def _load_module(task: str):
 def run_case(case, agg_step=7):
     name, task, seed, variant, gain, mode, k, B, H, W = case[:10]
     Cin = case[10] if len(case) > 10 else 64
+    scale = case[11] if len(case) > 11 else 10
     mod = _load_module(task)
     np_params = make_ce_params(seed, in_channels=Cin, variant=variant, sparse_gain=gain)
     x = torch.from_numpy(make_features(seed, B, Cin, H, W))
     if task == "TOPK":
-        ce = mod.CE(in_channels=Cin, num_edge=k)
+        ce = mod.CE(in_channels=Cin, num_edge=k, softmax_scale=scale)
         sd = {n: torch.from_numpy(a) for n, a in np_params.items()
               if not n.startswith(("thr_conv", "bias_conv"))}
         missing = ce.load_state_dict(sd, strict=False)
         assert set(missing.missing_keys) <= {"conv33.weight", "conv33.bias"}, missing
     else:
-        ce = mod.CE(in_channels=Cin)
+        ce = mod.CE(in_channels=Cin, softmax_scale=scale)
         ce.load_state_dict({n: torch.from_numpy(a) for n, a in np_params.items()}, strict=True)
     ce.eval()
 
@@ -140,12 +146,12 @@ def run_case(case, agg_step=7):
             else:
                 m = torch.relu(S - S.mean(dim=1, keepdim=True) * thr[n].unsqueeze(1) + bia[n].unsqueeze(1))
                 mb = (m != 0).float()
-            A = torch.softmax(S * m * 10, dim=1) * mb
+            A = torch.softmax(S * m * scale, dim=1) * mb
             degs.append(mb.sum(1).to(torch.int32))
             rowsums.append(A.sum(1))
             aggs.append((A @ vx[n].t())[::agg_step])
     meta = dict(name=name, task=task, seed=seed, variant=variant, sparse_gain=gain, mode=mode,
-                k=k, B=B, C=Cin, H=H, W=W, agg_step=agg_step,
+                k=k, B=B, C=Cin, H=H, W=W, agg_step=agg_step, softmax_scale=scale,
                 torch=torch.__version__, threads=torch.get_num_threads())
     np.savez_compressed(os.path.join(HERE, name + ".npz"),
                         out=out.numpy().astype(np.float32),

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden_cases
+from tests.conftest import golden_cases, scale_cases
 from tests.helpers import case_inputs, load_golden, normwise
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +38,52 @@ def test_shipped_forward_matches_reference_golden_directly(path):
     err = normwise(out, g["out"])
     print(f"[parity] {meta['name']}: ce(x) vs reference golden, normwise {err:.2e} (bar 1e-4), path {ce.last_info['path']}")
     assert out.shape == g["out"].shape and err <= 1e-4, err
+
+
+SCALE_CASES = scale_cases()
+
+
+@pytest.mark.parametrize("path", SCALE_CASES, ids=[os.path.basename(p)[:-4] for p in SCALE_CASES])
+def test_other_softmax_scales_match_the_reference_golden(path):
+    """``CE(softmax_scale=s)``: the kernels keep their 10; the module scales fc1 and the bias head (CE._scale_c) -- against the
+    reference's own output for s = 3, 4, 25, both scans, and the gradients of the training path against autograd on the oracle."""
+    from dagl_amd.ce import CE
+    from oracle.ce_oracle import ce_forward_oracle
+    meta, g = load_golden(path)
+    x, params = case_inputs(meta)
+    sc = float(meta["softmax_scale"])
+    for scan in ("screened", "exact"):
+        ce = CE(in_channels=meta["C"], softmax_scale=meta["softmax_scale"])
+        ce.load_state_dict(params, strict=True)
+        ce.select_mode, ce.scan = meta["mode"], scan
+        if meta["k"]:
+            ce.select_k = meta["k"]
+        ce = ce.to(DEV).eval()
+        with torch.no_grad():
+            out = ce(x.to(DEV)).cpu().numpy()
+        err = normwise(out, g["out"])
+        print(f"[parity] {meta['name']} scan={scan}: ce(x) vs reference golden, normwise {err:.2e} (bar 1e-4)")
+        assert err <= 1e-4, (scan, err)
+    # training path: d loss / d (input, fc1 weight, bias head) against autograd through the fp64 oracle
+    ce = CE(in_channels=meta["C"], softmax_scale=meta["softmax_scale"])
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode = meta["mode"]
+    if meta["k"]:
+        ce.select_k = meta["k"]
+    ce = ce.to(DEV).train()
+    xg = x.to(DEV).clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(5)
+    wgt = torch.randn(g["out"].shape, generator=gen)
+    (ce(xg) * wgt.to(DEV)).sum().backward()
+    p64 = {n: t.double().clone().requires_grad_(True) for n, t in params.items()}
+    x64 = x.double().clone().requires_grad_(True)
+    (ce_forward_oracle(x64, p64, mode=meta["mode"], k=meta["k"] or None, dtype=torch.float64, softmax_scale=sc) * wgt.double()).sum().backward()
+    names = ["fc1.0.weight", "fc2.0.weight", "g.weight"] + ([] if meta["mode"] == "topk" else ["bias_conv.weight", "thr_conv.weight"])
+    worst = normwise(xg.grad.cpu().numpy(), x64.grad.numpy())
+    for n in names:
+        worst = max(worst, normwise(dict(ce.named_parameters())[n].grad.cpu().numpy(), p64[n].grad.numpy()))
+    print(f"[parity] {meta['name']}: gradients vs fp64 autograd on the oracle, worst tensor {worst:.2e}")
+    assert worst <= 2e-3
 
 
 def _run_debug(ce, x):

@@ -53,6 +53,17 @@ def test_module_rejects_cpu_and_foreign_hyperparameters():
     from dagl_amd.ce import CE
     with pytest.raises(DaglError):
         CE(ksize=5)
+    with pytest.raises(DaglError, match="softmax_scale"):
+        CE(softmax_scale=0)
+    # softmax_scale is served by scaling fc1 (and the bias head) on the module side: c^2 = scale / 10, c = scale / 10 in top-k mode
+    ce = CE(softmax_scale=40)
+    assert ce._scale_c() == 2.0
+    ce.select_mode = "topk"
+    assert ce._scale_c() == 4.0
+    assert CE()._scale_c() == 1.0
+    prm = ce._params_f32()
+    assert torch.equal(prm["fc1.0.weight"], ce.fc1[0].weight.detach() * 4.0) and prm["fc2.0.weight"] is not None
+    assert torch.equal(prm["bias_conv.weight"], ce.bias_conv.weight.detach())          # (no bias head in the fixed-k variant)
     ce = CE(in_channels=64)
     with pytest.raises(DaglError, match="GPU"):
         with torch.no_grad():

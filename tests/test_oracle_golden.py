@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden_cases
+from tests.conftest import golden_cases, scale_cases
 from tests.helpers import case_inputs, load_golden, normwise
 from oracle.ce_oracle import ce_forward_oracle
 
@@ -34,6 +34,23 @@ def test_oracle_matches_reference(path):
     # fp64 evaluation differs by 2e-5..6e-5 normwise on these very cases).  The bar
     # is north_star's 1e-4 relative, evaluated normwise.
     assert out.shape == g["out"].shape
+    assert normwise(out.numpy(), g["out"]) <= 1e-4
+    np.testing.assert_array_equal(st["deg"].numpy().astype(np.int32), g["deg"])
+    assert normwise(st["rowsum"].numpy(), g["rowsum"]) <= 5e-5
+    assert normwise(st["agg"][:, ::meta["agg_step"]].numpy(), g["agg_sub"]) <= 5e-5
+
+
+SCALE_CASES = scale_cases()
+
+
+@pytest.mark.parametrize("path", SCALE_CASES, ids=[os.path.basename(p)[:-4] for p in SCALE_CASES])
+def test_oracle_matches_reference_at_other_softmax_scales(path):
+    """``CE(softmax_scale=...)`` of the reference (dagl.py:175, 260) -- minted with 3, 4 and 25 instead of the default 10."""
+    meta, g = load_golden(path)
+    assert meta["softmax_scale"] != 10
+    x, params = case_inputs(meta)
+    out, st = ce_forward_oracle(x, params, mode=meta["mode"], k=meta["k"] or None, zero_guard=(meta["task"] == "DN_Gray"),
+                                stages=True, softmax_scale=float(meta["softmax_scale"]))
     assert normwise(out.numpy(), g["out"]) <= 1e-4
     np.testing.assert_array_equal(st["deg"].numpy().astype(np.int32), g["deg"])
     assert normwise(st["rowsum"].numpy(), g["rowsum"]) <= 5e-5
