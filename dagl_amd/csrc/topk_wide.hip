@@ -46,9 +46,24 @@ __global__ __launch_bounds__(256) void wide_select_kernel(WideArgs a) {
         hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = sh_prefix;
-        for (int j = tid; j < N; j += 256) {
-            const unsigned key = wide_key(row[j], adaptive, mtq, bsq);
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        // (the high digit -- sign and seven exponent bits -- is the same for nearly every score of a row: 64 lanes adding to one LDS
+        // word serialise, 65 536 times.  There the wave counts its lanes per distinct digit first: one add per digit.  For the second
+        // digit, with ~100 distinct values per wave, that loop was 3.6x SLOWER than the plain adds.)
+        for (int j0 = 0; j0 < N; j0 += 256) {
+            const int j = j0 + tid;
+            unsigned key = 0u; bool act = false;
+            if (j < N) { key = wide_key(row[j], adaptive, mtq, bsq); act = pass == 0 || (key >> (shift + 8)) == prefix; }
+            const unsigned bin = (key >> shift) & 255u;
+            if (pass == 0) {
+                unsigned long long todo = __ballot(act);
+                while (todo) {                                                  // wave-uniform loop: one round per distinct digit
+                    const int first = __ffsll((long long)todo) - 1;
+                    const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, first);
+                    const unsigned long long same = __ballot(act && bin == b0);
+                    if ((tid & 63) == first) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (act) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
         if (tid == 0) {
