@@ -137,6 +137,9 @@ def test_k_beyond_64_against_the_fp64_oracle(k, B, H, W, mode, variant):
         out = ce(x.to(DEV)).cpu()
         assert ce.last_info["path"] == (6 if min(k, H * W) > 64 else ce.last_info["path"])
         _, info = _run_debug(ce, x.to(DEV))
+        if k == 200:                                       # the fp32 projections in front of the same rows (scan = "exact")
+            out_x = _module(params, mode, k, "exact")(x.to(DEV)).cpu()
+            assert normwise(out_x.numpy(), want.float().numpy()) <= 1e-4
     err = normwise(out.numpy(), want.float().numpy())
     deg = info["deg"].cpu().numpy().reshape(-1)
     d_ref = st["deg"].numpy().reshape(-1)
