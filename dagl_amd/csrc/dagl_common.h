@@ -506,6 +506,8 @@ struct DenseArgs {
     const uint16_t *v_hi, *v_lo;                               // the same, split fp16 (16 v = hi + lo), [B,Hp,Wp,16]
     int splits, tiles_per_split, n_tiles, tiles_per_row;       // 32-key tiles (row aligned), key ranges per 64-query group
     float* part_acc; float* part_m; double* part_z; int32_t* part_deg;   // per (split, query) partial results
+    float* m_exact; int32_t* redo_blk; int pass;               // [B,L] exact largest logit of a row (written by the first combine), [B, ceil(L/64)]
+                                                               // blocks of 64 queries to run again with it as their shift; pass 0 | 1
     int variant;                                               // debug ablations (DAGL_DENSE_VARIANT): 1 no A V, 2 no S, 4 no staging, 16 constant
                                                                // weights, 32 no zero-granule skip, 64 phase clocks
     unsigned* phase_out;                                       // ablation builds: [blocks][8 waves][8] shader clocks per phase, or null

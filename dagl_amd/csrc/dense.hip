@@ -13,7 +13,7 @@
 //             one query;
 //     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' an UPPER bound of the row maximum known
 //             before the pass (from the bf16 screen's row maxima; the softmax is shift invariant, nothing is ever rescaled),
-//             split 2^14 p = hi + lo and handed to the consumers through the LDS in the K-layout of the next MFMA (the only
+//             split 2^15 p = hi + lo and handed to the consumers through the LDS in the K-layout of the next MFMA (the only
 //             exchange of the tile).  The ~250 VALU operations of w(t+1) are issued BETWEEN the multiplies of S(t+2) (fenced
 //             slots: fragment reads two slots ahead, three multiplies, a fourteenth of the weights): a short multiply waits ~50
 //             cycles for the pipe behind the consumers' long ones, and scores-then-weights was a 5 000-cycle chain per tile;
@@ -32,7 +32,7 @@
 //   The first round-4 shape had both kinds of work in every wave (8 waves, the two of a SIMD in opposite order): the pipes were
 //   55 % busy -- every wave spent half its time in code that does not multiply.  This one: 63 % (trained features, 1.38 -> 1.28 ms),
 //   synthetic map 0.71 -> 0.62 ms, leaf-tile batch 0.69 -> 0.65 ms (profiles/r04_pmc_dense_*.json, r04_ab_dense_roles.log).
-//   Exactly-zero weights: logits reach hundreds, and 2^14 p rounds to hi = lo = 0 below l < M' - 27; a (64 queries x 16 keys)
+//   Exactly-zero weights: logits reach hundreds, and 2^15 p rounds to hi = lo = 0 below l < M' - 27.7; a (64 queries x 16 keys)
 //   granule whose weights are ALL zero contributes exactly nothing to A V, so its multiplies are skipped (a wave-uniform test of
 //   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init ~60-80 % of the granules are zero
 //   (profiles/r04_dense_zero_granules.log); with the trained checkpoint's features (logits of 5-70) none are -- that regime runs
@@ -73,12 +73,29 @@ constexpr int DN_PQ_B = 2 * 64 * DN_PQ_ENTRY;         // both query tiles
 // sized for the largest share)
 constexpr int DN_CTMAX = 3;
 __host__ __device__ constexpr int dn_ct_start(int w8) { return 3 * w8; }
-constexpr float DN_PS = 16384.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands
+constexpr float DN_PS = 32768.0f, DN_VS = 16.0f;      // power-of-two pre-scaling of the split operands (weights are <= 1: 2^15 is the
+                                                      // largest power of two fp16 holds)
+#ifndef DAGL_DN_SLACK
+#define DAGL_DN_SLACK 18.5f
+#endif
+// largest tolerated (shift M' - largest logit of a row) of the first pass: a weight is stored to 2^-24 / 2^15 = 2^-39 absolute (hi + lo,
+// the lo part denormal), i.e. to 2^-40 e^slack relative to the row's largest one: 1e-4 at 18.5 for a row that ONE key dominates
+// (rows with many comparable keys average it down)
+constexpr float DN_SHIFT_SLACK = DAGL_DN_SLACK;
 
 __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& pass) {
     const float m = (s - mtq) + bsq;                  // same expression order as dagl.py:256
     pass = m > 0.f;
     return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;
+}
+
+// the softmax shift of a row.  First pass: an UPPER bound of its largest logit -- S <= S~max / (1 - DELTA) for the bf16 screen's row
+// maximum S~max, and l grows with S; masked keys have l = 0.  Second pass: the largest logit itself, as the first pass formed it.
+__device__ __forceinline__ float dn_shift(const DenseArgs& a, size_t ql) {
+    if (a.pass == 1) return a.m_exact[ql];
+    const float sub = a.smax[ql] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
+    bool ps;
+    return fmaxf(dn_logit(sub, a.mt[ql], a.bs[ql], ps), 0.f);
 }
 
 __device__ __forceinline__ dns4 dn_tr16(unsigned lds_byte_addr) {
@@ -179,6 +196,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char spq[2 * DN_PQ_B];         // 20 KiB: the tiles' weights, two stages
     __shared__ double szz[4][64][2];                                                // 4 KiB: the lanes' shares of a query's sums (end of the block)
     __shared__ int sdg[4][64];
+    __shared__ float slt[4][64];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -214,13 +232,10 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const size_t qlin = (size_t)b * g.L + qsc;
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
     // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
-    float m_run;
-    {
-        const float sub = a.smax[qlin] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
-        bool ps;
-        const float lub = dn_logit(sub, mtq, bsq, ps);
-        m_run = fmaxf(lub, 0.f);                       // masked keys have l = 0
-    }
+    // second pass (see dense_combine_kernel): only the blocks of 64 queries flagged by the first one, shifted by their rows' EXACT largest logit
+    if (a.pass == 1 && a.redo_blk[b * n_qblocks + qb] == 0) return;
+    if (a.pass == 0 && split == 0 && tid == 0) a.redo_blk[b * n_qblocks + qb] = 0;      // (set by the first combine, behind this launch)
+    const float m_run = dn_shift(a, qlin);
 
     // ---- staging plan (per lane, once) ---------------------------------------------------------------------------------------------
     // keys by the producers: part = wave >> 1 (hi | lo), the part's 14 pieces over its two waves, 7 each, under two M0 set-ups; values by
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     f32x16 acc[2][DN_CTMAX];                           // (consumers; cleared in front of their loop)
     f32x4 acc48;                                       // tap 48 (consumers 0-3): out^T[channel 4 gk + r][query 16 cw + c16]
     double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
+    float l_top = 0.f;                                 // largest logit among this lane's passing keys (the guard of dense_combine_kernel)
     int deg = 0;
 
     // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row (kg = 1: + 16 rows)
@@ -367,6 +383,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                 const float p = valid ? e : 0.f;
                 zt += p;
                 pass = pass && valid;
+                l_top = fmaxf(l_top, pass ? l : 0.f);
                 const float pp = pass ? p : 0.f;
                 zpt += pp;
                 dt += pass ? 1 : 0;
@@ -513,6 +530,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                         const float p = valid ? e : 0.f;
                         zt[kg] += p;
                         pass = pass && valid;
+                        l_top = fmaxf(l_top, pass ? l : 0.f);
                         const float pp = pass ? p : 0.f;
                         zpt[kg] += pp;
                         dt[kg] += pass ? 1 : 0;
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 #endif
 
     // ---- partial results of this key range ------------------------------------------------------------------------------------------
-    if (producer) { szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; }
+    if (producer) { szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; slt[wave][lane] = l_top; }
     __syncthreads();
     if (tid < 64) {
         // query tid of the block: its scores lived in producer wave tid / 16, lanes c16 + 16 gk; summed in a fixed order
@@ -576,15 +594,13 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         if (q < g.L) {
             const int wq_ = tid >> 4, cq = tid & 15;
             double z = 0.0, zp = 0.0; int d = 0;
+            float lt = 0.f;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) { z += szz[wq_][cq + 16 * g4][0]; zp += szz[wq_][cq + 16 * g4][1]; d += sdg[wq_][cq + 16 * g4]; }
+            for (int g4 = 0; g4 < 4; ++g4) { z += szz[wq_][cq + 16 * g4][0]; zp += szz[wq_][cq + 16 * g4][1]; d += sdg[wq_][cq + 16 * g4]; lt = fmaxf(lt, slt[wq_][cq + 16 * g4]); }
             const size_t orow = ((size_t)split * a.B + b) * g.L + q;
             const size_t ql = (size_t)b * g.L + q;
-            const float sub = a.smax[ql] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
-            bool ps;
-            const float lub = dn_logit(sub, a.mt[ql], a.bs[ql], ps);
-            a.part_m[orow] = fmaxf(lub, 0.f);
-            a.part_z[2 * orow] = z; a.part_z[2 * orow + 1] = zp; a.part_deg[orow] = d;
+            a.part_m[orow] = dn_shift(a, ql);
+            a.part_z[3 * orow] = z; a.part_z[3 * orow + 1] = zp; a.part_z[3 * orow + 2] = (double)lt; a.part_deg[orow] = d;
         }
     }
     if (!producer) {
@@ -616,11 +632,27 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
     const float wl = (has && ms != -__builtin_inff()) ? __expf(ms - M) : 0.f;
-    double z = has ? a.part_z[2 * (lane * nq + ql)] * (double)wl : 0.0;
-    double zp = has ? a.part_z[2 * (lane * nq + ql) + 1] * (double)wl : 0.0;
+    double z = has ? a.part_z[3 * (lane * nq + ql)] * (double)wl : 0.0;
+    double zp = has ? a.part_z[3 * (lane * nq + ql) + 1] * (double)wl : 0.0;
+    float ltop = has ? (float)a.part_z[3 * (lane * nq + ql) + 2] : 0.f;
     int deg = has ? a.part_deg[lane * nq + ql] : 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); zp += __shfl_xor(zp, o); deg += __shfl_xor(deg, o); }
+    for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); zp += __shfl_xor(zp, o); deg += __shfl_xor(deg, o); ltop = fmaxf(ltop, __shfl_xor(ltop, o)); }
+    // The weights went through the matrix cores as 2^14 e^(l - M') = hi + lo in fp16, M' an UPPER bound of the row's largest logit
+    // from the bf16 scan (within ~2 x 0.8 % of it).  With logits in the thousands that slack alone is tens of units: the largest
+    // weight of the row drops towards the fp16 denormals (2^15 e^-16 = 2^-8 still has 16 significant bits in hi + lo, e^-20 has 10,
+    // below e^-27 every weight is exactly zero and the row would come out as zeros -- measured before this guard: 6e-3 at logits
+    // of 1 700, rows of zeros at 3 300, tools/dense_large_logits.py).  The first pass therefore records every row's largest logit
+    // (the producers form it anyway) and flags the blocks of 64 queries in which some row's slack exceeds DN_SHIFT_SLACK; a second,
+    // gated launch runs exactly those blocks again with the exact maxima as shifts (largest weight = 1: full precision) -- two
+    // launches that exit at once when nothing is flagged.
+    const int n_qblocks = (a.g.L + 63) / 64;
+    const int bq = (int)(ql / a.g.L), qin = (int)(ql - (size_t)bq * a.g.L);
+    if (a.pass == 1 && a.redo_blk[bq * n_qblocks + qin / 64] == 0) return;      // (second combine: the rows of re-run blocks only)
+    if (a.pass == 0 && lane == 0) {
+        a.m_exact[ql] = ltop;                                                      // (>= 0: masked keys have l = 0, and so has an empty row)
+        if (deg > 0 && M - ltop > DN_SHIFT_SLACK) a.redo_blk[bq * n_qblocks + qin / 64] = 1;
+    }
     const float invz = (float)(1.0 / z);
     float4 acc[4];
 #pragma unroll
@@ -721,26 +753,29 @@ static size_t dn_map16_bytes(int B, const Grid& g) { return align_up(((size_t)B 
 size_t dense_workspace_bytes(int B, const Grid& g) {
     const size_t rows = (size_t)dense_splits(B, g) * B * g.L;
     return align_up(rows * P * sizeof(float), 256) + align_up(rows * sizeof(float), 256) +
-           align_up(rows * 2 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256) +
-           2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L) + 2 * dn_map16_bytes(B, g);
+           align_up(rows * 3 * sizeof(double), 256) + align_up(rows * sizeof(int32_t), 256) +
+           2 * dn_feat16_bytes(B, g.N) + 2 * dn_feat16_bytes(B, g.L) + 2 * dn_map16_bytes(B, g) +
+           align_up((size_t)B * g.L * sizeof(float), 256) + align_up((size_t)B * ((g.L + 63) / 64) * sizeof(int32_t), 256);
 }
 
 // carve of the dense workspace (shared by launch_dense_attend and dense_split_buffers)
-struct DnCarve { float* part_acc; float* part_m; double* part_z; int32_t* part_deg; uint16_t *xh, *xl, *qh, *ql, *vh, *vl; };
+struct DnCarve { float* part_acc; float* part_m; double* part_z; int32_t* part_deg; uint16_t *xh, *xl, *qh, *ql, *vh, *vl; float* m_exact; int32_t* redo_blk; };
 static DnCarve dn_carve(void* ws, int B, const Grid& g) {
     const size_t rows = (size_t)dense_splits(B, g) * B * g.L;                // carve with the planned (upper) split count
     DnCarve c;
     char* p = static_cast<char*>(ws);
     c.part_acc = reinterpret_cast<float*>(p); p += align_up(rows * P * sizeof(float), 256);
     c.part_m = reinterpret_cast<float*>(p); p += align_up(rows * sizeof(float), 256);
-    c.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 2 * sizeof(double), 256);
+    c.part_z = reinterpret_cast<double*>(p); p += align_up(rows * 3 * sizeof(double), 256);
     c.part_deg = reinterpret_cast<int32_t*>(p); p += align_up(rows * sizeof(int32_t), 256);
     c.xh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
     c.xl = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.N);
     c.qh = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
     c.ql = reinterpret_cast<uint16_t*>(p); p += dn_feat16_bytes(B, g.L);
     c.vh = reinterpret_cast<uint16_t*>(p); p += dn_map16_bytes(B, g);
-    c.vl = reinterpret_cast<uint16_t*>(p);
+    c.vl = reinterpret_cast<uint16_t*>(p); p += dn_map16_bytes(B, g);
+    c.m_exact = reinterpret_cast<float*>(p); p += align_up((size_t)B * g.L * sizeof(float), 256);
+    c.redo_blk = reinterpret_cast<int32_t*>(p);
     return c;
 }
 
@@ -781,6 +816,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     a.splits = (a.n_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
     const DnCarve c = dn_carve(ws, B, g);
     a.part_acc = c.part_acc; a.part_m = c.part_m; a.part_z = c.part_z; a.part_deg = c.part_deg;
+    a.m_exact = c.m_exact; a.redo_blk = c.redo_blk; a.pass = 0;
     uint16_t *xh = c.xh, *xl = c.xl, *qh = c.qh, *ql = c.ql, *vh = c.vh, *vl = c.vl;
     a.v_hi = vh; a.v_lo = vl;
     a.x_hi = xh; a.x_lo = xl; a.wq_hi = qh; a.wq_lo = ql;
@@ -830,6 +866,13 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
         }
     }
 #endif
+    hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
+    DAGL_LAUNCH_CHECK("dense_combine_kernel");
+    // second pass: the blocks whose rows' weights came too close to the fp16 denormals, shifted by their exact row maxima (both
+    // launches exit at once when the first combine flagged nothing)
+    a.pass = 1; a.phase_out = nullptr;
+    hipLaunchKernelGGL(dense_attend_kernel, dim3(n_qblocks * a.splits, B), dim3(DN_THREADS), 0, s, a);
+    DAGL_LAUNCH_CHECK("dense_attend_kernel");
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
     // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics)

@@ -236,6 +236,32 @@ def test_dense_hint_on_a_dirty_workspace():
         assert torch.equal(again, want), shape
 
 
+def test_dense_rows_whose_weights_would_underflow_get_an_exact_shift():
+    """Logits in the thousands: the streamed dense formulation shifts by an UPPER bound of the row maximum (bf16 scan, within
+    ~1.6 % of it) and its weights go through fp16 -- the slack alone would push every weight of a row below the fp16 denormals
+    (6e-3 off at logits of 1 700, rows of zeros at 3 300: tools/dense_large_logits.py on the library before this guard).  The
+    first pass records every row's largest logit and flags the blocks of 64 queries whose slack is too large; a gated second pass
+    runs them again with the exact maxima as shifts.  Same entry point, same path, no host involvement."""
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(57, variant="default").items()}
+    x = torch.from_numpy(make_features(57, 1, 64, 48, 52))
+    for scale in (1.0, 1.2, 1.6, 2.5):
+        xs = x * scale
+        want, st = ce_forward_oracle(xs, params, mode="adaptive", dtype=torch.float64, stages=True)
+        top = float((10.0 * st["S"] * torch.relu(st["S"] - st["T"].unsqueeze(-1))).max())
+        ce = _module(params, "adaptive", 0)
+        with torch.no_grad():
+            out = ce(xs.to(_dev())).cpu()
+            again = ce(xs.to(_dev())).cpu()                # (hinted: straight to the dense formulation)
+        info = ce.last_info
+        err = normwise(out.numpy(), want.float().numpy())
+        print(f"[parity] dense, input x {scale}: largest logit {top:.0f}, path {info['path']}, range_fallback {info['range_fallback']}, "
+              f"normwise {err:.2e}")
+        assert info["path"] == 4 and not info["range_fallback"], info
+        assert err <= TOL_OUT and torch.equal(out, again)
+
+
 def test_adaptive_topk_mode_matches_oracle():
     from oracle.ce_oracle import ce_forward_oracle
     path = [p for p in CASES if "gray_sparse_64x64" in p][0]
