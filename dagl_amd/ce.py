@@ -312,10 +312,16 @@ class CE(nn.Module):
         # dagl.py:208-215  g (3x3, pad 1), theta (1x1), thr_conv / bias_conv (7x7 stride 4 on the SAME-padded input): one forward
         # call of the library's fp32 prologue kernels, layer-by-layer unfold / GEMM backward (train_ops._PrologueConvs)
         thr = bias = None
+        convs = (self.g, self.theta, self.thr_conv, self.bias_conv)
+        padc = (-self.in_channels) % 4                  # (float4 channel groups: zero channels, zero weight columns -- autograd slices them off)
+        if padc:
+            from types import SimpleNamespace
+            b = F.pad(b, (0, 0, 0, 0, 0, padc))
+            convs = tuple(SimpleNamespace(weight=F.pad(m.weight, (0, 0, 0, 0, 0, padc)), bias=m.bias) for m in convs)
         if self.select_mode != "topk":                 # (the fixed-k variant has no threshold heads)
-            b1p, b2p, thr, bias = T.prologue_convs(b, self.g, self.theta, self.thr_conv, self.bias_conv)
+            b1p, b2p, thr, bias = T.prologue_convs(b, *convs)
         else:
-            b1p, b2p = T.prologue_convs(b, self.g, self.theta)
+            b1p, b2p = T.prologue_convs(b, convs[0], convs[1])
         b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2)                  # NCHW view of the value map
         # dagl.py:216-249  patches of b1 (stride 4 SAME / stride 1) through fc1 / fc2 + ReLU
         wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, self.stride_1,
@@ -415,6 +421,12 @@ class CE(nn.Module):
         from . import train_ops as T
         p = self._params_f32()
         heads = self.select_mode != "topk"
+        padc = (-self.in_channels) % 4          # the library's unfold works on float4 channel groups: zero channels change nothing
+        if padc:
+            b = F.pad(b, (0, 0, 0, 0, 0, padc))
+            p = dict(p)
+            for n in ("g.weight", "theta.weight", "thr_conv.weight", "bias_conv.weight"):
+                p[n] = F.pad(p[n], (0, 0, 0, 0, 0, padc)).contiguous()
         hw = (p["thr_conv.weight"], p["thr_conv.bias"], p["bias_conv.weight"], p["bias_conv.bias"]) if heads else (None,) * 4
         b1p, b2p, thr, bias = T.prologue_forward_any_width(b.contiguous(), p["g.weight"], p["g.bias"], p["theta.weight"],
                                                            p["theta.bias"], *hw)
