@@ -236,6 +236,26 @@ def test_dense_hint_on_a_dirty_workspace():
         assert torch.equal(again, want), shape
 
 
+@pytest.mark.parametrize("mode,k,variant", [("adaptive", 0, "sparse"), ("adaptive", 0, "default"), ("topk", 8, "default"),
+                                            ("adaptive_topk", 16, "sparse"), ("topk", 300, "default")])
+def test_cold_calls_do_not_depend_on_what_the_workspace_held(mode, k, variant):
+    """Every byte of the workspace set to 0xFF (NaN in every format) before a cold call (no DAGL_FLAG_WEIGHTS_PACKED): guard rows,
+    borders, counters, flags and list slots a call relies on are written by that call."""
+    from dagl_amd import ops
+    from dagl_amd.synth import make_ce_params, make_features
+    prm = {n: torch.from_numpy(a).to(_dev()).contiguous() for n, a in make_ce_params(58, variant=variant, sparse_gain=1.7).items()}
+    prm = {n: t for n, t in prm.items() if not n.startswith("W.")}
+    for shape in ((2, 64, 72, 72), (1, 64, 50, 46)):
+        x = torch.from_numpy(make_features(58, *shape)).to(_dev())
+        want, _ = ops.ce_forward_fused(x, prm, mode=mode, k=k, workspace=ops.Workspace())
+        ws = ops.Workspace()
+        ops.ce_forward_fused(x, prm, mode=mode, k=k, workspace=ws)                 # sizes the buffer (whatever path the call ends on)
+        for _ in range(2):
+            ws.buf.fill_(0xFF)
+            got, _ = ops.ce_forward_fused(x, prm, mode=mode, k=k, workspace=ws)
+            assert torch.equal(got, want), (mode, shape)
+
+
 def test_dense_rows_whose_weights_would_underflow_get_an_exact_shift():
     """Logits in the thousands: the streamed dense formulation shifts by an UPPER bound of the row maximum (bf16 scan, within
     ~1.6 % of it) and its weights go through fp16 -- the slack alone would push every weight of a row below the fp16 denormals
