@@ -73,6 +73,27 @@ def test_input_widths_that_are_not_multiples_of_16(C):
     assert gerr <= 2e-3
 
 
+@pytest.mark.parametrize("kind", ["zeros", "ones", "row ramp", "checkerboard", "one pixel"])
+def test_degenerate_inputs_against_the_fp64_oracle(kind):
+    """Maps on which nearly every score ties (constant, periodic, all but one pixel zero): every mode against the oracle -- the
+    selection may pick other members of a tie than torch.topk does, the output does not depend on it."""
+    from dagl_amd.synth import make_ce_params
+    from oracle.ce_oracle import ce_forward_oracle
+    s = (1, 64, 52, 60)
+    x = {"zeros": lambda: torch.zeros(s), "ones": lambda: torch.ones(s),
+         "row ramp": lambda: (torch.arange(s[2]).float().view(1, 1, -1, 1) * 0.01).expand(s).contiguous(),
+         "checkerboard": lambda: ((torch.arange(s[2]).view(-1, 1) + torch.arange(s[3]).view(1, -1)) % 2).float().expand(s).contiguous(),
+         "one pixel": lambda: torch.zeros(s).index_put_(tuple(torch.tensor([v]) for v in (0, 5, 20, 31)), torch.tensor(50.0))}[kind]()
+    for mode, k, variant in (("adaptive", 0, "sparse"), ("adaptive", 0, "default"), ("topk", 8, "default"), ("adaptive_topk", 16, "sparse"),
+                             ("topk", 100, "default")):
+        params = {n: torch.from_numpy(a) for n, a in make_ce_params(91, variant=variant, sparse_gain=1.7).items()}
+        want = ce_forward_oracle(x, params, mode=mode, k=k or None, dtype=torch.float64).float().numpy()
+        ce = _module(params, mode, k)
+        with torch.no_grad():
+            out = ce(x.to(DEV)).cpu().numpy()
+        assert np.isfinite(out).all() and normwise(out, want) <= 1e-4, (kind, mode, variant, k, normwise(out, want))
+
+
 SCALE_CASES = scale_cases()
 
 
