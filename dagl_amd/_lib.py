@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 401          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 402          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -85,6 +85,9 @@ SIGNATURES = {
     "dagl_prelu_scratch_bytes": (_sz, [_sz]),
     "dagl_prelu_backward": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dagl_col_sum_scratch_bytes": (_sz, [_sz, _i]),
+    "dagl_conv_pair_backward_supported": (_i, [_i, _i, _i]),
+    "dagl_conv_pair_backward_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dagl_conv_pair_backward": (_i, [_vp, _i, _i, _i] + [_vp] * 11),
     "dagl_col_sum": (_i, [_vp, _sz, _i, _vp, _vp, _vp]),
     "dagl_profile_create": (_i, [_i, C.POINTER(_vp)]),
     "dagl_profile_destroy": (_i, [_vp]),

@@ -6,6 +6,8 @@ block when it trains; torch keeps the parameters, the autograd tape and trivial 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -166,6 +168,10 @@ def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b,
     return d_map, d_w, d_b
 
 
+# tests / A-B runs: the unfold + GEMM + fold backward of g / theta on every shape (DAGL_PROLOGUE_BACKWARD=unfold)
+_FORCE_UNFOLD_BACKWARD = os.environ.get("DAGL_PROLOGUE_BACKWARD", "") == "unfold"
+
+
 class _PrologueConvs(torch.autograd.Function):
     """The four prologue convolutions of dagl.py:208-215 in one forward call of the library's fp32 prologue kernels
     (``dagl_ce_prologue``: zero-bordered NHWC maps of g(b) and theta(b), thr / bias per query) -- as unfold + GEMM a 64 -> 16
@@ -199,7 +205,6 @@ class _PrologueConvs(torch.autograd.Function):
         Lh, Lw = -(-H // 4), -(-W // 4)
         need_x = ctx.needs_input_grad[0]
         with torch.cuda.device(x.device):
-            xp = _ToPaddedNHWC.apply(x.detach(), H, W, False)                              # [B,H+6,W+6,64], recomputed
             inner = (PAD * Wp + PAD) * 16
 
             def crop_rows(d_map):                      # padded NHWC gradient -> rows [B, H*W, 16]
@@ -209,23 +214,48 @@ class _PrologueConvs(torch.autograd.Function):
                 return rows
 
             d_xp = None
-            # g (3x3) and theta (1x1 = the centre tap of the 3x3 window) share their patch rows: ONE 32-output layer over the
-            # 3x3 patches, theta's weights sitting in the centre tap (a 16-output product fills an eighth of the GEMM's tile)
-            w32 = torch.zeros(32, 9 * C, device=x.device, dtype=torch.float32)
-            w32[:16] = conv_weight_rows(g_w.detach())
-            w32[16:, 4 * C:5 * C] = th_w.detach().reshape(16, C)
-            d32 = torch.cat([crop_rows(d_b1p), crop_rows(d_b2p)], dim=-1)                   # [B, H*W, 32]
-            geom = (B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, False, 32, 9 * C)
-            need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
-            need_b = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
-            d_xp, d_w32, d_b32 = _patch_linear_backward(xp, w32, None, geom, d32, need_x, need_w, need_b)
+            lib = _lib.load()
+            direct = (C == 64 and bool(lib.dagl_conv_pair_backward_supported(B, H, W)) and x.dtype == torch.float32
+                      and not _FORCE_UNFOLD_BACKWARD)
+            d_x_direct = None
             grads = {"g": (None, None), "theta": (None, None)}
-            if d_w32 is not None:
-                grads["g"] = (d_w32[:16].view(16, 3, 3, C).permute(0, 3, 1, 2).contiguous(), None)
-                grads["theta"] = (d_w32[16:, 4 * C:5 * C].reshape(th_w.shape).contiguous(), None)
-            if d_b32 is not None:
-                grads["g"] = (grads["g"][0], d_b32[:16].contiguous())
-                grads["theta"] = (grads["theta"][0], d_b32[16:].contiguous())
+            if direct:
+                # g and theta on the maps themselves (conv_grad.hip): no patch rows, no layout copies
+                need_p = any(ctx.needs_input_grad[1:5])
+                d1, d2 = d_b1p.contiguous(), d_b2p.contiguous()
+                gw, tw = g_w.detach().contiguous(), th_w.detach().contiguous()
+                if need_x:
+                    d_x_direct = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+                if need_p:
+                    d_gw, d_gb = torch.empty_like(gw), torch.empty(16, device=x.device, dtype=torch.float32)
+                    d_tw, d_tb = torch.empty_like(tw), torch.empty(16, device=x.device, dtype=torch.float32)
+                    scr = torch.empty(max(16, lib.dagl_conv_pair_backward_scratch_bytes(B, H, W)), device=x.device, dtype=torch.uint8)
+                    grads = {"g": (d_gw, d_gb), "theta": (d_tw, d_tb)}
+                if need_x or need_p:
+                    check(lib.dagl_conv_pair_backward(ops._stream(), B, H, W, x.data_ptr(), d1.data_ptr(), d2.data_ptr(), gw.data_ptr(),
+                                                      tw.data_ptr(), d_x_direct.data_ptr() if need_x else None,
+                                                      d_gw.data_ptr() if need_p else None, d_gb.data_ptr() if need_p else None,
+                                                      d_tw.data_ptr() if need_p else None, d_tb.data_ptr() if need_p else None,
+                                                      scr.data_ptr() if need_p else None), "dagl_conv_pair_backward")
+            if not direct or ctx.heads:
+                xp = _ToPaddedNHWC.apply(x.detach(), H, W, False)                              # [B,H+6,W+6,64], recomputed
+            if not direct:
+              # g (3x3) and theta (1x1 = the centre tap of the 3x3 window) share their patch rows: ONE 32-output layer over the
+              # 3x3 patches, theta's weights sitting in the centre tap (a 16-output product fills an eighth of the GEMM's tile)
+              w32 = torch.zeros(32, 9 * C, device=x.device, dtype=torch.float32)
+              w32[:16] = conv_weight_rows(g_w.detach())
+              w32[16:, 4 * C:5 * C] = th_w.detach().reshape(16, C)
+              d32 = torch.cat([crop_rows(d_b1p), crop_rows(d_b2p)], dim=-1)                   # [B, H*W, 32]
+              geom = (B, Hp, Wp, C, 3, 1, PAD - 1, PAD - 1, H, W, False, 32, 9 * C)
+              need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+              need_b = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
+              d_xp, d_w32, d_b32 = _patch_linear_backward(xp, w32, None, geom, d32, need_x, need_w, need_b)
+              if d_w32 is not None:
+                  grads["g"] = (d_w32[:16].view(16, 3, 3, C).permute(0, 3, 1, 2).contiguous(), None)
+                  grads["theta"] = (d_w32[16:, 4 * C:5 * C].reshape(th_w.shape).contiguous(), None)
+              if d_b32 is not None:
+                  grads["g"] = (grads["g"][0], d_b32[:16].contiguous())
+                  grads["theta"] = (grads["theta"][0], d_b32[16:].contiguous())
             d_thr_w = d_thr_b = d_bias_w = d_bias_b = None
             if ctx.heads:
                 thr_w, bias_w = saved[3], saved[4]
@@ -249,6 +279,8 @@ class _PrologueConvs(torch.autograd.Function):
                 d_x = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
                 inner64 = (PAD * Wp + PAD) * C
                 _copy4(d_xp.view(-1)[inner64:], (B, C, H, W), (Hp * Wp * C, 1, Wp * C, C), d_x, (C * H * W, H * W, W, 1))
+            if d_x_direct is not None:
+                d_x = d_x_direct if d_x is None else d_x_direct.add_(d_x)
         return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b)
 
 

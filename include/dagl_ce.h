@@ -149,7 +149,7 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
  * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64; round 4: DAGL_FLAG_SAMPLED_TOPK,
  * the workspace layout carries the top-k policy words).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 401
+#define DAGL_ABI_VERSION 402
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
@@ -358,6 +358,20 @@ size_t dagl_fc_grad16_scratch_bytes(int B, int oh, int ow);
 int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
                    const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, void* scratch,
                    size_t scratch_bytes);
+
+/* Backward of the first two convolutions of the block (g 3x3 and theta 1x1, 64 -> 16: dagl.py:208-209 under loss.backward(),
+ * DN_Gray/trainer.py:48-57) straight on the maps -- no patch rows (conv_grad.hip): tap-wise products on the fp32 matrix cores,
+ * fixed summation order (bit-reproducible).
+ *   x [B,64,H,W] (the forward's input), d_b1p / d_b2p [B,H+6,W+6,16] = gradients of the zero-bordered NHWC maps (interior read),
+ *   g_w [16,64,3,3], th_w [16,64] (needed for d_x only)
+ *   d_x [B,64,H,W] or NULL;  d_g_w [16,64,3,3], d_g_b [16], d_th_w [16,64], d_th_b [16]: all four or all NULL
+ *   scratch: dagl_conv_pair_backward_scratch_bytes(B,H,W) bytes (parameter gradients only)
+ * dagl_conv_pair_backward_supported: W a multiple of 4 and <= 256 (rows are staged whole); other shapes: unfold + dagl_gemm_f32. */
+int    dagl_conv_pair_backward_supported(int B, int H, int W);
+size_t dagl_conv_pair_backward_scratch_bytes(int B, int H, int W);
+int    dagl_conv_pair_backward(void* stream, int B, int H, int W, const float* x, const float* d_b1p, const float* d_b2p,
+                               const float* g_w, const float* th_w, float* d_x, float* d_g_w, float* d_g_b, float* d_th_w,
+                               float* d_th_b, void* scratch);
 
 /* The four prologue convolutions alone (dagl.py:208-215): b1/b2 as zero-bordered NHWC maps
  * [B,H+6,W+6,16], thr/bias [B,L] (both NULL = skip the two 7x7 heads).  `scratch` = 8*B*L floats of

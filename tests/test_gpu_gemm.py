@@ -191,3 +191,83 @@ def test_prelu_on_the_library_matches_torch_forward_and_backward():
     assert sorted(ours.state_dict()) == sorted(ref.state_dict()) and ours.weight.shape == ref.weight.shape
     y_odd = ours(torch.randn(3, 5, 7, device=dev))                             # 105 elements: torch's path
     assert y_odd.shape == (3, 5, 7)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 24), (1, 37, 64), (3, 9, 4), (1, 5, 256), (8, 128, 128)])
+def test_conv_pair_backward_on_the_maps_matches_fp64_autograd(B, H, W):
+    """``dagl_conv_pair_backward`` (conv_grad.hip: the gradients of g 3x3 and theta 1x1, dagl.py:208-209, as tap-wise products
+    on the maps) against torch's fp64 autograd of the same two convolutions, every output; the border of the padded gradient
+    maps is filled with garbage (it belongs to constants of the forward and must not be read); same bits on a repeated call."""
+    import torch.nn.functional as F
+    from dagl_amd import _lib, ops
+    from dagl_amd._lib import check
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    assert lib.dagl_conv_pair_backward_supported(B, H, W) == 1
+    g = torch.Generator().manual_seed(H * 131 + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    gw = torch.randn(16, 64, 3, 3, generator=g) * 0.1
+    tw = torch.randn(16, 64, 1, 1, generator=g) * 0.2
+    d1 = torch.randn(B, H, W, 16, generator=g)
+    d2 = torch.randn(B, H, W, 16, generator=g)
+    # fp64 reference
+    xr = x.double().requires_grad_(True); gwr = gw.double().requires_grad_(True); twr = tw.double().requires_grad_(True)
+    gb = torch.zeros(16, dtype=torch.float64, requires_grad=True); tb = torch.zeros(16, dtype=torch.float64, requires_grad=True)
+    b1 = F.conv2d(xr, gwr, gb, padding=1); b2 = F.conv2d(xr, twr, tb)
+    (b1 * d1.double().permute(0, 3, 1, 2)).sum().add((b2 * d2.double().permute(0, 3, 1, 2)).sum()).backward()
+    # padded NHWC gradient maps with a poisoned border
+    def padded(d):
+        p = torch.full((B, H + 6, W + 6, 16), 1e30)
+        p[:, 3:3 + H, 3:3 + W] = d
+        return p.to(dev)
+    d1p, d2p = padded(d1), padded(d2)
+    xd, gwd, twd = x.to(dev), gw.to(dev), tw.to(dev)
+    outs = []
+    for _ in range(2):
+        dx = torch.empty(B, 64, H, W, device=dev); dgw = torch.empty(16, 64, 3, 3, device=dev); dgb = torch.empty(16, device=dev)
+        dtw = torch.empty(16, 64, 1, 1, device=dev); dtb = torch.empty(16, device=dev)
+        scr = torch.empty(max(16, lib.dagl_conv_pair_backward_scratch_bytes(B, H, W)), device=dev, dtype=torch.uint8)
+        check(lib.dagl_conv_pair_backward(ops._stream(), B, H, W, xd.data_ptr(), d1p.data_ptr(), d2p.data_ptr(), gwd.data_ptr(),
+                                          twd.data_ptr(), dx.data_ptr(), dgw.data_ptr(), dgb.data_ptr(), dtw.data_ptr(),
+                                          dtb.data_ptr(), scr.data_ptr()), "dagl_conv_pair_backward")
+        outs.append([t.cpu() for t in (dx, dgw, dgb, dtw, dtb)])
+    for got, want, name in zip(outs[0], (xr.grad, gwr.grad, gb.grad, twr.grad, tb.grad), ("d_x", "d_g_w", "d_g_b", "d_th_w", "d_th_b")):
+        err = normwise(got.numpy(), want.numpy())
+        print(f"conv_pair_backward [{B},64,{H},{W}] {name}: normwise {err:.2e}")
+        assert err <= 2e-6, name
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # input gradient alone / parameter gradients alone
+    dx2 = torch.empty(B, 64, H, W, device=dev)
+    check(lib.dagl_conv_pair_backward(ops._stream(), B, H, W, xd.data_ptr(), d1p.data_ptr(), d2p.data_ptr(), gwd.data_ptr(), twd.data_ptr(),
+                                      dx2.data_ptr(), None, None, None, None, None), "dagl_conv_pair_backward")
+    assert torch.equal(dx2.cpu(), outs[0][0])
+    assert lib.dagl_conv_pair_backward_supported(1, 8, 30) == 0 and lib.dagl_conv_pair_backward_supported(1, 8, 260) == 0
+
+
+def test_prologue_backward_direct_and_unfold_routes_agree():
+    """The module's prologue under autograd: the direct backward of g / theta against the unfold + GEMM + fold route it replaces
+    (still taken for widths that are no multiple of 4, and for other channel counts)."""
+    from dagl_amd import train_ops as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 36, 40, generator=g).to(dev)
+    conv = lambda ci, co, k: torch.nn.Conv2d(ci, co, k, padding=k // 2).to(dev)
+    gm, th, thr, bia = conv(64, 16, 3), conv(64, 16, 1), torch.nn.Conv2d(64, 1, 7, stride=4).to(dev), torch.nn.Conv2d(64, 1, 7, stride=4).to(dev)
+    res = {}
+    for heads in (False, True):
+        for force in (False, True):
+            T._FORCE_UNFOLD_BACKWARD = force
+            try:
+                xi = x.clone().requires_grad_(True)
+                for m in (gm, th, thr, bia):
+                    m.zero_grad()
+                outs = T.prologue_convs(xi, gm, th, thr if heads else None, bia if heads else None)
+                gen = torch.Generator().manual_seed(9)
+                loss = sum((o * torch.randn(o.shape, generator=gen).to(dev)).sum() for o in outs)
+                loss.backward()
+                res[(heads, force)] = [xi.grad.cpu()] + [p.grad.cpu().clone() for m in (gm, th) for p in m.parameters()]
+            finally:
+                T._FORCE_UNFOLD_BACKWARD = False
+        for a, b in zip(res[(heads, False)], res[(heads, True)]):
+            assert normwise(a.numpy(), b.numpy()) <= 2e-6
