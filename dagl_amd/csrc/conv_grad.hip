@@ -208,26 +208,35 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_pair_wgrad_kernel(ConvGrad
     }
 }
 
-// partial sums -> the parameters' gradients in PyTorch's layouts; one thread per element, blocks' partials in index order
+// partial sums -> the parameters' gradients in PyTorch's layouts.  Block = 64 consecutive sums x 4 interleaved quarters of the blocks'
+// partials (p = q, q + 4, ..: 256-byte loads), the quarters added in order: the same bits on every call
 __global__ __launch_bounds__(256) void conv_pair_wgrad_reduce_kernel(int n_part, const float* __restrict__ part,
                                                                      float* __restrict__ d_g_w, float* __restrict__ d_g_b,
                                                                      float* __restrict__ d_th_w, float* __restrict__ d_th_b) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    constexpr int NW = 4 * CG_PART;                       // 10240 weight sums
+    __shared__ float sq[4][64];
+    constexpr int NW = 4 * CG_PART;                       // 10240 weight sums, then 32 bias sums
+    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + j;
+    float s = 0.f;
+    if (i < NW) {
+        for (int p = q; p < n_part; p += 4) s += part[(size_t)p * NW + i];
+    } else if (i < NW + 32) {
+        const float* bp = part + (size_t)n_part * NW + (i - NW);
+        for (int p = q; p < n_part; p += 4) s += bp[(size_t)p * 32];
+    }
+    sq[q][j] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = ((sq[0][j] + sq[1][j]) + sq[2][j]) + sq[3][j];
     if (i < NW) {
         // i = ((cb * 10 + t) * 16 + cl) * 16 + o
         const int o = i & 15, cl = (i >> 4) & 15, t = (i >> 8) % CG_ACC, cb = (i >> 8) / CG_ACC;
-        float s = 0.f;
-        for (int p = 0; p < n_part; ++p) s += part[(size_t)p * NW + i];
         const int c = cb * CG_CB + cl;
         if (t < 9) d_g_w[(o * CG_C + c) * 9 + t] = s;
         else d_th_w[o * CG_C + c] = s;
     } else if (i < NW + 32) {
-        const int j = i - NW;
-        const float* bp = part + (size_t)n_part * NW;
-        float s = 0.f;
-        for (int p = 0; p < n_part; ++p) s += bp[(size_t)p * 32 + j];
-        if (j < 16) d_g_b[j] = s; else d_th_b[j - 16] = s;
+        const int b = i - NW;
+        if (b < 16) d_g_b[b] = s; else d_th_b[b - 16] = s;
     }
 }
 
@@ -404,7 +413,7 @@ int dagl_conv_pair_backward(void* stream, int B, int H, int W, const float* x, c
         hipLaunchKernelGGL(conv_pair_wgrad_kernel, dim3(a.n_strips, 4, B), dim3(CG_THREADS), lds, s, a);
         DAGL_LAUNCH_CHECK("conv_pair_wgrad_kernel");
         const int n_part = B * a.n_strips;
-        hipLaunchKernelGGL(conv_pair_wgrad_reduce_kernel, dim3((4 * CG_PART + 32 + 255) / 256), dim3(256), 0, s, n_part,
+        hipLaunchKernelGGL(conv_pair_wgrad_reduce_kernel, dim3((4 * CG_PART + 32 + 63) / 64), dim3(256), 0, s, n_part,
                            static_cast<const float*>(scratch), d_g_w, d_g_b, d_th_w, d_th_b);
         DAGL_LAUNCH_CHECK("conv_pair_wgrad_reduce_kernel");
     }
