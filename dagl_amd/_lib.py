@@ -69,7 +69,7 @@ SIGNATURES = {
     "dagl_ce_core_backward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 17 + [_sz]),
     "dagl_ce_core_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
-    "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i] + [_vp] * 14 + [_sz]),
+    "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 14 + [_sz]),
     "dagl_gemm_f32_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
                            _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i, _i, _vp]),

@@ -62,8 +62,9 @@ class _GraphCore(torch.autograd.Function):
 
 class _GraphCoreDense(torch.autograd.Function):
     """dagl.py:250-272 for dense neighbourhoods (adaptive masks that keep more keys than a fixed-width list holds --
-    default-initialised heads keep ~95 %): the dense formulation chunked over the queries, forward and backward on the
-    fp32 matrix cores (``dagl_ce_core_dense_forward`` / ``_backward``, dense_train.hip)."""
+    default-initialised heads keep ~95 %): the dense formulation (``dagl_ce_core_dense_forward`` / ``_backward``): the forward
+    on the streamed split-fp16 kernel, the backward's matrix products on the fp16 matrix cores with split operands
+    (``exact``: both on the fp32 matrix cores; dense_train.hip)."""
 
     @staticmethod
     def forward(ctx, wq_rows, x_rows, b2, thr, bias, ws_f, ws_b, sink, want_info, exact=False):
@@ -71,7 +72,7 @@ class _GraphCoreDense(torch.autograd.Function):
         thr_c, bias_c = thr.contiguous(), bias.contiguous()
         out, saved = ops.ce_core_dense_forward(wq_rows, x_rows, b2, thr_c, bias_c, workspace=ws_f, want_info=want_info,
                                                exact=exact)
-        ctx.ws_b, ctx.thr_shape = ws_b, thr.shape
+        ctx.ws_b, ctx.thr_shape, ctx.exact = ws_b, thr.shape, bool(exact)
         ctx.save_for_backward(wq_rows, x_rows, b2, thr_c, bias_c, saved["lse"], saved["mu"])
         if sink is not None and saved["info"] is not None:
             sink.update(saved["info"])
@@ -81,7 +82,7 @@ class _GraphCoreDense(torch.autograd.Function):
     def backward(ctx, d_out):
         wq_rows, x_rows, b2, thr, bias, lse, mu = ctx.saved_tensors
         d_wq, d_x, d_b2, d_thr, d_bias = ops.ce_core_dense_backward(d_out.contiguous().float(), wq_rows, x_rows, b2, thr, bias,
-                                                                    dict(lse=lse, mu=mu), workspace=ctx.ws_b)
+                                                                    dict(lse=lse, mu=mu), workspace=ctx.ws_b, exact=ctx.exact)
         return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None, None
 
 

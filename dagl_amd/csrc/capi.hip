@@ -1199,15 +1199,15 @@ int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, int flags, con
     return DAGL_OK;
 }
 
-int dagl_ce_core_dense_backward(void* stream, int B, int H, int W, const float* wq_rows, const float* x_rows, const float* b2,
+int dagl_ce_core_dense_backward(void* stream, int B, int H, int W, int flags, const float* wq_rows, const float* x_rows, const float* b2,
                                 const float* thr, const float* bias, const float* lse, const float* mu, const float* d_out,
                                 float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias, void* workspace,
                                 size_t ws_bytes) {
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && thr && bias && lse && mu && d_out && d_wq_rows &&
-                 d_x_rows && d_b2 && d_thr && d_bias, "dagl_ce_core_dense_backward: bad argument");
+                 d_x_rows && d_b2 && d_thr && d_bias && (flags & ~DAGL_FLAG_EXACT_SCAN) == 0, "dagl_ce_core_dense_backward: bad argument");
     DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_dense_backward: workspace must be 256-byte aligned");
     return launch_dense_train_backward((hipStream_t)stream, B, make_grid(H, W), wq_rows, x_rows, b2, thr, bias, lse, mu, d_out,
-                                       d_wq_rows, d_x_rows, d_b2, d_thr, d_bias, workspace, ws_bytes);
+                                       d_wq_rows, d_x_rows, d_b2, d_thr, d_bias, workspace, ws_bytes, (flags & DAGL_FLAG_EXACT_SCAN) != 0);
 }
 
 size_t dagl_gemm_f32_scratch_floats(int batch, int M, int N, int K) {

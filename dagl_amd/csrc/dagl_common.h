@@ -569,7 +569,44 @@ struct Gemm32 {
 int launch_gemm32(hipStream_t s, const Gemm32& g);
 int gemm32_auto_slices(int M, int N, int K);
 
-int launch_col_sum_final(hipStream_t s, int n_part, int cols, const double* part, float* out);   // out[c] = sum of part[p][c], fixed order
+int launch_col_sum_final(hipStream_t s, int n_part, int cols, const double* part, float* out);
+// ---- split-fp16 GEMM of the training products (gemm16s.hip): C[m][n] = alpha sum_k A[m][k] B[n][k], both operands K-contiguous
+// fp16 pairs (s x = hi + lo), hi*hi + hi*lo + lo*hi in one fp32 accumulator ---------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ void g16_split(float a, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h = (_Float16)a;
+    const _Float16 l = (_Float16)(a - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+// power of two that brings a tensor's largest magnitude into [2^13, 2^14): s = 2^(13 - floor(log2 max)); 1 for an all-zero tensor
+__host__ __device__ __forceinline__ float fcg_scale_of(unsigned max_bits) {
+    if (max_bits == 0u || max_bits >= 0x7f800000u) return 1.0f;          // zero (or no word), inf / NaN: nothing to rescue
+    const int e = (int)(max_bits >> 23) - 127;                          // floor(log2 max) for normal numbers
+    int se = 13 - e;
+    if (se > 120) se = 120;
+    if (se < -120) se = -120;
+    union { unsigned u; float f; } cv; cv.u = (unsigned)(se + 127) << 23;
+    return cv.f;
+}
+#endif
+struct Gemm16s {
+    int M, N;                                   // real output extent (stores are clipped to it)
+    int K;                                      // contraction length of ONE slice (multiple of 32)
+    const unsigned short *a_hi, *a_lo;          // [>= M rounded up to 128][lda] halfs, K-contiguous
+    const unsigned short *b_hi, *b_lo;          // [>= N rounded up to 128][ldb]
+    long long lda, ldb;                         // leading dimensions in halfs (multiples of 8)
+    int a_rows, b_rows;                         // rows that exist: a tile's loads are clamped to them (clipped outputs only)
+    float* C; long long ldc;                    // slices == 1: C[m][n] = alpha acc
+    float* part;                                // slices > 1: part[slice][batch][M][N] raw accumulators
+    int slices;
+    const unsigned* scale_word; float alpha0;   // alpha = alpha0 / (fcg_scale_of(*scale_word) fcg_scale_of(*scale_word_b)); a null word = 1
+    const unsigned* scale_word_b = nullptr;
+    int batch = 1; long long sA = 0, sB = 0, sC = 0;   // batch > 1: operand strides in halfs, output stride in floats (grid.z = batch x slices)
+};
+int launch_gemm16s(hipStream_t s, const Gemm16s& g);
+int launch_absmax(hipStream_t s, size_t n, const float* x, unsigned* word);     // *word = max(*word, bits of max |x|); n % 4 == 0
+   // out[c] = sum of part[p][c], fixed order
 int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, float* dagg);
 int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar);
 // dense neighbourhoods under autograd (dense_train.hip): the dense formulation chunked over queries
@@ -579,7 +616,8 @@ int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float*
                                void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */);
 int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                 const float* thr, const float* bias, const float* lse, const float* mu, const float* dout,
-                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes);
+                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes,
+                                bool fp32_products = false);     // false: the five products on the fp16 matrix cores, split operands (one-chunk shapes)
 int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum);              // per-lane list length used for a requested k (4/8/16/32)
 
 }  // namespace dagl

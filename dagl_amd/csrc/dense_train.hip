@@ -25,7 +25,18 @@ struct DtPlan {
     int Lc, n_chunks, Bc;            // queries per chunk, chunks per image, images per group
     long long ldn;                   // leading dimension of the [L,N] chunk matrices (N rounded up to 32)
     size_t o_sbuf, o_abuf, o_vrows, o_dvrows, o_dagg, o_agg, o_b2p, o_colsum, o_mt, o_dmu, o_dxbar, o_deg, o_rowsum, o_end;
+    // split-fp16 backward (one chunk per image group only): hi / lo operand copies, each `..._h` halfs long (lo follows hi)
+    bool h16;
+    int Lp, kslices;                 // L rounded up to 32; split-K of d Wq
+    long long ldl, ldk;              // leading dimensions (halfs) of the copies whose rows run over the queries / the keys: extent + 64 -- a
+                                     // power-of-two row stride (L = 1024: 2 KiB, N = 16384: 32 KiB) sends the 16 rows of every LDS-DMA piece
+                                     // to the same memory channel (the products ran at a third of the fp32 ones' rate)
+    size_t o_words, o_dgk, o_dgt, o_vk, o_xk, o_xt, o_wqk, o_wqt, o_dsk, o_dst, o_at, o_part;
+    size_t dgk_h, dgt_h, vk_h, xk_h, xt_h, wqk_h, wqt_h, dsk_h, dst_h, at_h;
 };
+
+constexpr int DT_PK = 800;           // value-patch length 784 rounded up to the K step (50 taps of 16)
+constexpr int DT_DK = 224;           // feature length 196 rounded up to the K step
 
 static DtPlan dt_plan(int B, const Grid& g, bool backward) {
     DtPlan p;
@@ -55,6 +66,24 @@ static DtPlan dt_plan(int B, const Grid& g, bool backward) {
     p.o_dxbar = carve((size_t)B * D * sizeof(float));
     p.o_deg = carve((size_t)B * g.L * sizeof(int32_t));
     p.o_rowsum = carve((size_t)B * g.L * sizeof(float));
+    p.h16 = backward && p.n_chunks == 1;
+    p.Lp = (g.L + 31) / 32 * 32;
+    p.ldl = p.Lp + 64; p.ldk = p.ldn + 64;
+    p.kslices = 1;
+    if (p.h16) {
+        const size_t bc = (size_t)p.Bc;
+        p.dgk_h = bc * g.L * DT_PK; p.dgt_h = bc * P * p.ldl; p.vk_h = bc * g.N * DT_PK;
+        p.xk_h = bc * g.N * DT_DK; p.xt_h = bc * D * p.ldk; p.wqk_h = bc * g.L * DT_DK; p.wqt_h = bc * D * p.ldl;
+        p.dsk_h = bc * p.Lc * p.ldk; p.dst_h = bc * g.N * p.ldl; p.at_h = bc * g.N * p.ldl;
+        p.o_words = carve(256);
+        p.o_dgk = carve(2 * p.dgk_h * 2); p.o_dgt = carve(2 * p.dgt_h * 2); p.o_vk = carve(2 * p.vk_h * 2);
+        p.o_xk = carve(2 * p.xk_h * 2); p.o_xt = carve(2 * p.xt_h * 2); p.o_wqk = carve(2 * p.wqk_h * 2); p.o_wqt = carve(2 * p.wqt_h * 2);
+        p.o_dsk = carve(2 * p.dsk_h * 2); p.o_dst = carve(2 * p.dst_h * 2); p.o_at = carve(2 * p.at_h * 2);
+        // d Wq = d S X: (L / 128) x 2 output tiles per image -- split K (the keys) until the launch fills the chip
+        const long long tiles = (long long)((g.L + 127) / 128) * 2 * p.Bc;
+        while (p.kslices < 8 && tiles * p.kslices < 512 && (p.ldn % (64 * p.kslices)) == 0) p.kslices *= 2;
+        p.o_part = carve((size_t)p.kslices * bc * g.L * D * sizeof(float));
+    }
     p.o_end = off;
     return p;
 }
@@ -159,12 +188,14 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
                                                                 const float* __restrict__ mt, const float* __restrict__ bs,
                                                                 const float* __restrict__ lse, const float* __restrict__ mu,
                                                                 const float* __restrict__ thr, float* __restrict__ dthr,
-                                                                float* __restrict__ dbias, float* __restrict__ dmu, int b0) {
+                                                                float* __restrict__ dbias, float* __restrict__ dmu, int b0,
+                                                                unsigned* __restrict__ ds_word) {
     __shared__ double shd[4];
     const int lr = blockIdx.x, bi = blockIdx.y;
     const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
     float* srow = sbuf + ((size_t)bi * Lc + lr) * ldn;
     float* arow = abuf + ((size_t)bi * Lc + lr) * ldn;
+    float ds_max = 0.f;
     const float mtq = mt[ql], bsq = bs[ql];
     // The softmax's shift and denominator are formed HERE, from the recomputed scores -- not taken from the forward: the
     // forward may have run on the streamed split-fp16 kernel, whose scores differ from these in the last bits; logits of
@@ -201,12 +232,19 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
         const float l = dt_logit(s, mtq, bsq, pass, m);
         const float a = pass ? expf(l - M) * invz : 0.f;
         const float dl = a * (arow[j] - cf);           // non-neighbours: A = 0 and their logit is the constant 0
-        srow[j] = SOFTMAX_SCALE * (m + s) * dl;        // d S  (a = 0 -> 0)
+        const float ds = SOFTMAX_SCALE * (m + s) * dl; // d S  (a = 0 -> 0)
+        srow[j] = ds;
+        ds_max = fmaxf(ds_max, fabsf(ds));
         arow[j] = a;
         sdm += (double)(SOFTMAX_SCALE * s * dl);       // d m
     }
     for (int j = N + threadIdx.x; j < ldn; j += 256) { srow[j] = 0.f; arow[j] = 0.f; }
     const float S = (float)dt_block_sum(sdm, shd);
+    if (ds_word != nullptr) {                          // the split-fp16 products' scale for d S (order-independent integer maximum)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ds_max = fmaxf(ds_max, __shfl_xor(ds_max, o));
+        if ((threadIdx.x & 63) == 0 && ds_max > 0.f && ds_max < __builtin_inff()) atomicMax(ds_word, __float_as_uint(ds_max));
+    }
     if (threadIdx.x == 0) {
         dbias[ql] = S;
         dthr[ql] = -mu[ql] * S;
@@ -315,10 +353,188 @@ int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float*
     return DAGL_OK;
 }
 
+
+// ---- split-fp16 operands of the backward's five products (gemm16s.hip) --------------------------------------------------------
+// src fp32 [R][C] (leading dimension ld) -> hi / lo [R][Cp] halfs (row stride ldo), s x = hi + lo, pad columns zero; s from *word (largest magnitude
+// of the tensor, fcg_scale_of) or `fixed` when word is null.  Thread = (row, octet of columns).
+__global__ __launch_bounds__(256) void dt_split_rows_kernel(size_t R, int C, long long ld, int Cp, long long ldo, const float* __restrict__ src,
+                                                            const unsigned* __restrict__ word, float fixed,
+                                                            unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int o8 = Cp / 8;
+    if (t >= R * o8) return;
+    const size_t r = t / o8; const int c0 = 8 * (int)(t - r * o8);
+    const float sc = word ? fcg_scale_of(*word) : fixed;
+    const float* p = src + r * ld + c0;
+    unsigned short vh[8], vl[8];
+    if (c0 + 8 <= C) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        g16_split(a.x * sc, vh[0], vl[0]); g16_split(a.y * sc, vh[1], vl[1]); g16_split(a.z * sc, vh[2], vl[2]); g16_split(a.w * sc, vh[3], vl[3]);
+        g16_split(b.x * sc, vh[4], vl[4]); g16_split(b.y * sc, vh[5], vl[5]); g16_split(b.z * sc, vh[6], vl[6]); g16_split(b.w * sc, vh[7], vl[7]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g16_split((c0 + u < C) ? p[u] * sc : 0.f, vh[u], vl[u]);
+    }
+    *reinterpret_cast<uint4*>(hi + r * ldo + c0) = *reinterpret_cast<const uint4*>(vh);
+    *reinterpret_cast<uint4*>(lo + r * ldo + c0) = *reinterpret_cast<const uint4*>(vl);
+}
+
+// src fp32 [batch][R][C] (ld, batch stride ss) -> transposed hi / lo [batch][C][Rp] halfs (row stride ldo; Rp >= R a multiple of 32, pad zero).
+// Block = 64 rows x 64 columns: 256-byte row reads, transposed in LDS, 128-byte runs written.
+__global__ __launch_bounds__(256) void dt_split_transpose_kernel(int R, int C, long long ld, long long ss, int Rp, long long ldo, long long sd,
+                                                                 const float* __restrict__ src, const unsigned* __restrict__ word,
+                                                                 float fixed, unsigned short* __restrict__ hi,
+                                                                 unsigned short* __restrict__ lo) {
+    __shared__ __attribute__((aligned(16))) unsigned short th[64][64 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short tl[64][64 + 8];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const float sc = word ? fcg_scale_of(*word) : fixed;
+    const float* sb = src + (long long)b * ss;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const float v = (r0 + r < R && c0 + c < C) ? sb[(long long)(r0 + r) * ld + c0 + c] * sc : 0.f;
+        g16_split(v, th[c][r], tl[c][r]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {                        // (column, octet of rows)
+        const int c = e >> 3, r8 = e & 7;
+        if (c0 + c >= C || r0 + 8 * r8 >= Rp) continue;
+        const long long o = (long long)b * sd + (long long)(c0 + c) * ldo + r0 + 8 * r8;
+        *reinterpret_cast<uint4*>(hi + o) = *reinterpret_cast<const uint4*>(&th[c][8 * r8]);
+        *reinterpret_cast<uint4*>(lo + o) = *reinterpret_cast<const uint4*>(&tl[c][8 * r8]);
+    }
+}
+
+// value patches of the zero-bordered map, split: out[b][n][(kh,kw,c)] (50 taps of 16 halfs: tap 49 = zero pad); thread = (key, tap)
+__global__ __launch_bounds__(256) void dt_unfold_values_split_kernel(int H, int W, size_t total, const float* __restrict__ mp,
+                                                                     const unsigned* __restrict__ word,
+                                                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;                                                  // total = nb * N * 50
+    const int Wp = W + 2 * PADPIX, Hp = H + 2 * PADPIX;
+    const size_t key = t / 50; const int tap = (int)(t - key * 50);
+    const size_t b = key / ((size_t)H * W); const int n = (int)(key - b * (size_t)H * W);
+    const int y = n / W, x = n - y * W;
+    const float sc = fcg_scale_of(*word);
+    unsigned short vh[16], vl[16];
+    if (tap < KS * KS) {
+        const int kh = tap / KS, kw = tap - kh * KS;
+        const float4* src = reinterpret_cast<const float4*>(mp + ((b * Hp + y + kh) * (size_t)Wp + x + kw) * CH);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = src[q];
+            g16_split(v.x * sc, vh[4 * q], vl[4 * q]); g16_split(v.y * sc, vh[4 * q + 1], vl[4 * q + 1]);
+            g16_split(v.z * sc, vh[4 * q + 2], vl[4 * q + 2]); g16_split(v.w * sc, vh[4 * q + 3], vl[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { vh[u] = 0; vl[u] = 0; }
+    }
+    uint4* oh = reinterpret_cast<uint4*>(hi + t * 16); uint4* ol = reinterpret_cast<uint4*>(lo + t * 16);
+    oh[0] = reinterpret_cast<const uint4*>(vh)[0]; oh[1] = reinterpret_cast<const uint4*>(vh)[1];
+    ol[0] = reinterpret_cast<const uint4*>(vl)[0]; ol[1] = reinterpret_cast<const uint4*>(vl)[1];
+}
+
+static int dt_split_rows(hipStream_t s, size_t R, int C, long long ld, int Cp, long long ldo, const float* src, const unsigned* word,
+                         float fixed, unsigned short* hi, size_t halfs) {
+    const size_t items = R * (size_t)(Cp / 8);
+    hipLaunchKernelGGL(dt_split_rows_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, R, C, ld, Cp, ldo, src, word, fixed, hi, hi + halfs);
+    DAGL_LAUNCH_CHECK("dt_split_rows_kernel");
+    return DAGL_OK;
+}
+
+static int dt_split_transpose(hipStream_t s, int nb, int R, int C, long long ld, long long ss, int Rp, long long ldo, const float* src,
+                              const unsigned* word, float fixed, unsigned short* hi, size_t halfs) {
+    hipLaunchKernelGGL(dt_split_transpose_kernel, dim3((Rp + 63) / 64, (C + 63) / 64, nb), dim3(256), 0, s, R, C, ld, ss, Rp, ldo,
+                       (long long)C * ldo, src, word, fixed, hi, hi + halfs);
+    DAGL_LAUNCH_CHECK("dt_split_transpose_kernel");
+    return DAGL_OK;
+}
+
+static Gemm16s dt_gemm16(int M, int N, int K, int nb, const unsigned short* a, size_t a_halfs, long long lda, long long sA,
+                         const unsigned short* b, size_t b_halfs, long long ldb, long long sB, float* C, long long ldc, long long sC,
+                         const unsigned* wa, const unsigned* wb, float alpha0) {
+    Gemm16s g;
+    g.M = M; g.N = N; g.K = K; g.a_hi = a; g.a_lo = a + a_halfs; g.b_hi = b; g.b_lo = b + b_halfs; g.lda = lda; g.ldb = ldb;
+    g.a_rows = M; g.b_rows = N; g.C = C; g.ldc = ldc; g.part = nullptr; g.slices = 1; g.scale_word = wa; g.scale_word_b = wb;
+    g.alpha0 = alpha0; g.batch = nb; g.sA = sA; g.sB = sB; g.sC = sC;
+    return g;
+}
+
+// The backward of one image group (all queries in one chunk) with its five products on the fp16 matrix cores, split operands:
+// 580 GFLOP per head at [8, 128 x 128] ran at 85 TFLOP/s on the fp32 matrix cores (54 % of their peak) -- 6.8 ms per head and
+// step, half of the adaptive-mode training step.  Operand copies: K-contiguous rows for both sides of every product, i.e.
+// d agg, V, Wq, X by rows, and d agg, X, Wq, d S, A transposed; every tensor scaled by a power of two taken from its largest
+// magnitude (A <= 1: 2^13).  The softmax backward between the products stays in fp32 on fp32 S and d A.
+static int dt_backward_group16(hipStream_t s, const Grid& g, const DtPlan& p, void* ws, int b0, int nb, const float* wq_rows,
+                               const float* x_rows, const float* thr, const float* bias, const float* lse, const float* mu,
+                               float* dwq_rows, float* dx_rows, float* dthr, float* dbias) {
+    int rc;
+    unsigned* words = dt_at<unsigned>(ws, p.o_words);          // 0 d agg, 1 values, 2 X, 3 Wq, 4 d S
+    float* sbuf = dt_at<float>(ws, p.o_sbuf);
+    float* abuf = dt_at<float>(ws, p.o_abuf);
+    float* dvrows = dt_at<float>(ws, p.o_dvrows);
+    const float* dagg = dt_at<float>(ws, p.o_dagg) + (size_t)b0 * g.L * P;
+    const float* b2p = dt_at<float>(ws, p.o_b2p) + (size_t)b0 * g.Hp * g.Wp * CH;
+    const float* mt = dt_at<float>(ws, p.o_mt);
+    float* dmu = dt_at<float>(ws, p.o_dmu);
+    const float* wq = wq_rows + (size_t)b0 * g.L * D;
+    const float* xr = x_rows + (size_t)b0 * g.N * D;
+    auto H = [&](size_t o) { return dt_at<unsigned short>(ws, o); };
+    const int L = g.L, N = g.N, Lp = p.Lp;
+    const long long ldn = p.ldn, ldl = p.ldl, ldk = p.ldk;
+    DAGL_HIP_TRY(hipMemsetAsync(words, 0, 256, s));
+    if ((rc = launch_absmax(s, (size_t)nb * L * P, dagg, words + 0))) return rc;
+    if ((rc = launch_absmax(s, (size_t)nb * g.Hp * g.Wp * CH, b2p, words + 1))) return rc;
+    if ((rc = launch_absmax(s, (size_t)nb * N * D, xr, words + 2))) return rc;
+    if ((rc = launch_absmax(s, (size_t)nb * L * D, wq, words + 3))) return rc;
+    // operand copies that do not depend on the softmax
+    if ((rc = dt_split_rows(s, (size_t)nb * L, P, P, DT_PK, DT_PK, dagg, words + 0, 1.f, H(p.o_dgk), p.dgk_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, L, P, P, (long long)L * P, Lp, ldl, dagg, words + 0, 1.f, H(p.o_dgt), p.dgt_h))) return rc;
+    {
+        const size_t total = (size_t)nb * N * 50;
+        hipLaunchKernelGGL(dt_unfold_values_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.H, g.W, total, b2p,
+                           words + 1, H(p.o_vk), H(p.o_vk) + p.vk_h);
+        DAGL_LAUNCH_CHECK("dt_unfold_values_split_kernel");
+    }
+    if ((rc = dt_split_rows(s, (size_t)nb * N, D, D, DT_DK, DT_DK, xr, words + 2, 1.f, H(p.o_xk), p.xk_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, N, D, D, (long long)N * D, (int)ldn, ldk, xr, words + 2, 1.f, H(p.o_xt), p.xt_h))) return rc;
+    if ((rc = dt_split_rows(s, (size_t)nb * L, D, D, DT_DK, DT_DK, wq, words + 3, 1.f, H(p.o_wqk), p.wqk_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, L, D, D, (long long)L * D, Lp, ldl, wq, words + 3, 1.f, H(p.o_wqt), p.wqt_h))) return rc;
+    const long long sS = (long long)p.Lc * ldn;
+    // d A = d agg V^T ; S = Wq X^T
+    if ((rc = launch_gemm16s(s, dt_gemm16(L, N, DT_PK, nb, H(p.o_dgk), p.dgk_h, DT_PK, (long long)L * DT_PK, H(p.o_vk), p.vk_h, DT_PK,
+                                          (long long)N * DT_PK, abuf, ldn, sS, words + 0, words + 1, 1.f)))) return rc;
+    if ((rc = launch_gemm16s(s, dt_gemm16(L, N, DT_DK, nb, H(p.o_wqk), p.wqk_h, DT_DK, (long long)L * DT_DK, H(p.o_xk), p.xk_h, DT_DK,
+                                          (long long)N * DT_DK, sbuf, ldn, sS, words + 3, words + 2, 1.f)))) return rc;
+    hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(L, nb), dim3(256), 0, s, N, ldn, L, 0, p.Lc, sbuf, abuf, mt, bias, lse, mu, thr,
+                       dthr, dbias, dmu, b0, words + 4);
+    DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+    // d S by rows and transposed, A transposed
+    if ((rc = dt_split_rows(s, (size_t)nb * p.Lc, (int)ldn, ldn, (int)ldn, ldk, sbuf, words + 4, 1.f, H(p.o_dsk), p.dsk_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, L, N, ldn, sS, Lp, ldl, sbuf, words + 4, 1.f, H(p.o_dst), p.dst_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, L, N, ldn, sS, Lp, ldl, abuf, nullptr, 8192.f, H(p.o_at), p.at_h))) return rc;
+    // d Wq = d S X (split over the keys)
+    {
+        Gemm16s q = dt_gemm16(L, D, (int)(ldn / p.kslices), nb, H(p.o_dsk), p.dsk_h, ldk, (long long)p.Lc * ldk, H(p.o_xt), p.xt_h, ldk, (long long)D * ldk,
+                              dwq_rows + (size_t)b0 * L * D, D, (long long)L * D, words + 4, words + 2, 1.f);
+        q.slices = p.kslices; q.part = dt_at<float>(ws, p.o_part);
+        if ((rc = launch_gemm16s(s, q))) return rc;
+    }
+    // d X = d S^T Wq ; d V = A^T d agg
+    if ((rc = launch_gemm16s(s, dt_gemm16(N, D, Lp, nb, H(p.o_dst), p.dst_h, ldl, (long long)N * ldl, H(p.o_wqt), p.wqt_h, ldl,
+                                          (long long)D * ldl, dx_rows + (size_t)b0 * N * D, D, (long long)N * D, words + 4, words + 3, 1.f)))) return rc;
+    if ((rc = launch_gemm16s(s, dt_gemm16(N, P, Lp, nb, H(p.o_at), p.at_h, ldl, (long long)N * ldl, H(p.o_dgt), p.dgt_h, ldl,
+                                          (long long)P * ldl, dvrows, P, (long long)N * P, nullptr, words + 0, 1.f / 8192.f)))) return rc;
+    return DAGL_OK;
+}
+
 int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                 const float* thr, const float* bias, const float* lse, const float* mu_saved, const float* dout,
-                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes) {
+                                float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes,
+                                bool fp32_products) {
     const DtPlan p = dt_plan(B, g, true);
+    const bool h16 = p.h16 && !fp32_products;
     if (ws_bytes < p.o_end) { set_error("dense backward: workspace %zu B < required %zu B", ws_bytes, p.o_end); return DAGL_ERR_WORKSPACE; }
     int rc;
     float* mu = dt_at<float>(ws, p.o_rowsum);                    // recomputed with the thresholds (same values as the forward's)
@@ -337,6 +553,9 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
     if ((rc = launch_unfold_dout(s, B, g, dout, dagg))) return rc;
     for (int b0 = 0; b0 < B; b0 += p.Bc) {
         const int nb = (B - b0 < p.Bc) ? B - b0 : p.Bc;
+        if (h16) {
+            if ((rc = dt_backward_group16(s, g, p, ws, b0, nb, wq_rows, x_rows, thr, bias, lse, mu, dwq_rows, dx_rows, dthr, dbias))) return rc;
+        } else {
         if ((rc = launch_unfold_values(s, nb, g, b2p + (size_t)b0 * g.Hp * g.Wp * CH, vrows))) return rc;
         for (int l0 = 0; l0 < g.L; l0 += p.Lc) {
             const int lc = (g.L - l0 < p.Lc) ? g.L - l0 : p.Lc;
@@ -350,7 +569,7 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_c, D, (long long)g.L * D, 1,
                                                x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1, sbuf, p.ldn, sS, 0.f)))) return rc;
             hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias,
-                               lse, mu, thr, dthr, dbias, dmu, b0);
+                               lse, mu, thr, dthr, dbias, dmu, b0, nullptr);
             DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
             // d Wq = d S X
             if ((rc = launch_gemm32(s, dt_gemm(lc, D, g.N, nb, sbuf, p.ldn, sS, 1, x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 0,
@@ -361,6 +580,7 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
             // d V (+)= A^T d agg
             if ((rc = launch_gemm32(s, dt_gemm(g.N, P, lc, nb, abuf, p.ldn, sS, 0, dagg_c, P, (long long)g.L * P, 0,
                                                dvrows, P, (long long)g.N * P, beta, true)))) return rc;
+        }
         }
         {
             const size_t n = (size_t)nb * g.N;

@@ -32,13 +32,6 @@ constexpr int FCG_O = 196, FCG_OP = 224, FCG_OM = 256; // outputs, padded to the
 constexpr int FCG_P = 784, FCG_PP = 896;               // patch length, padded to the N tile (7 x 128)
 constexpr float FCG_XS = 16.0f, FCG_WS = 1024.0f;      // activation / weight pre-scaling (project16.hip)
 
-__device__ __forceinline__ void g16_split(float a, unsigned short& hi, unsigned short& lo) {
-    const _Float16 h = (_Float16)a;
-    const _Float16 l = (_Float16)(a - (float)h);
-    hi = __builtin_bit_cast(unsigned short, h);
-    lo = __builtin_bit_cast(unsigned short, l);
-}
-
 // largest |x| of a tensor -> *word (bits of a non-negative float: integer max = float max, order-independent)
 __global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4* __restrict__ x, unsigned* __restrict__ word) {
     float m = 0.f;
@@ -59,6 +52,16 @@ __global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __float_as_uint(m));
+}
+
+int launch_absmax(hipStream_t s, size_t n, const float* x, unsigned* word) {
+    const size_t n4 = n / 4;                      // (n a multiple of 4, x 16-byte aligned: every caller's tensors are rows of 4 k floats)
+    if (n4 == 0) return DAGL_OK;
+    size_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fcg_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n4, reinterpret_cast<const float4*>(x), word);
+    DAGL_LAUNCH_CHECK("fcg_absmax_kernel");
+    return DAGL_OK;
 }
 
 // d Z = d Y (Y > 0) and, in the same pass over it, its largest magnitude (the split's scale) and its column sums (the bias
@@ -94,16 +97,6 @@ __global__ __launch_bounds__(256) void fcg_relu_stats_kernel(size_t n, const flo
     if ((t & 63) == 0 && m > 0.f) atomicMax(max_word, __float_as_uint(m));
     __syncthreads();
     if (t < FCG_O) part[(size_t)blockIdx.x * FCG_O + t] = (((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t]) + sh[4][t];
-}
-
-// power of two that brings a tensor's largest magnitude into [2^13, 2^14): s = 2^(13 - floor(log2 max)); 1 for an all-zero tensor
-__device__ __forceinline__ float fcg_scale_of(unsigned max_bits) {
-    if (max_bits == 0u || max_bits >= 0x7f800000u) return 1.0f;          // zero, inf / NaN: nothing to rescue
-    const int e = (int)(max_bits >> 23) - 127;                          // floor(log2 max) for normal numbers
-    int se = 13 - e;
-    if (se > 120) se = 120;
-    if (se < -120) se = -120;
-    return __uint_as_float((unsigned)(se + 127) << 23);
 }
 
 // d Z [n, 196] fp32 -> hi / lo [n_pad][224] halfs (pad columns and pad rows zero), scaled by the call's power of two
@@ -191,19 +184,6 @@ __global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigne
     g16_split(v, hi[t], lo[t]);
 }
 
-struct Gemm16s {
-    int M, N;                                   // real output extent (stores are clipped to it)
-    int K;                                      // contraction length of ONE slice (multiple of 32)
-    const unsigned short *a_hi, *a_lo;          // [>= M rounded up to 128][lda] halfs, K-contiguous
-    const unsigned short *b_hi, *b_lo;          // [>= N rounded up to 128][ldb]
-    long long lda, ldb;                         // leading dimensions in halfs (multiples of 8)
-    int a_rows, b_rows;                         // rows that exist: a tile's loads are clamped to them (clipped outputs only)
-    float* C; long long ldc;                    // slices == 1: C[m][n] = alpha acc
-    float* part;                                // slices > 1: part[slice][M][N] raw accumulators
-    int slices;
-    const unsigned* scale_word; float alpha0;   // alpha = alpha0 / fcg_scale_of(*scale_word)
-};
-
 // C[m][n] = sum_k A[m][k] B[n][k]; block = (64 WM) x (64 WN) outputs by WM x WN waves of 64 x 64, grid.z = K slices.
 // The operand stream through LDS-DMA is what bounds this kernel (~23 GB/s per CU measured, hi + lo double the bytes of an
 // fp16 GEMM): 256 x 128 tiles fetch 3/4 of the bytes per product of 128 x 128 ones.
@@ -219,7 +199,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const long long k0 = (long long)blockIdx.z * g.K;
+    const int bz = (g.batch > 1) ? (int)blockIdx.z / g.slices : 0;             // batch index; slice = blockIdx.z % slices
+    const long long k0 = (long long)((g.batch > 1) ? (int)blockIdx.z - bz * g.slices : (int)blockIdx.z) * g.K;
+    const long long boff_a = (long long)bz * g.sA, boff_b = (long long)bz * g.sB;       // (offsets, not pointers: a table of four local
+                                                                                        // pointers indexed by the piece number lands in scratch)
     const int wm = wave / WN, wn = wave % WN;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
@@ -235,11 +218,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
             const int per = is_a ? BM / 16 : BN / 16;
             const int part = q / per, grp = q - part * per;
             const unsigned short* base = is_a ? (part ? g.a_lo : g.a_hi) : (part ? g.b_lo : g.b_hi);
+            const long long boff = is_a ? boff_a : boff_b;
             const long long ld = is_a ? g.lda : g.ldb;
             int row = (is_a ? m0 : n0) + grp * 16 + prow;
             const int lim = (is_a ? g.a_rows : g.b_rows) - 1;
             if (row > lim) row = lim;
-            glds16_asm(reinterpret_cast<const float*>(base + (long long)row * ld + k + 8 * pslot),
+            glds16_asm(reinterpret_cast<const float*>(base + boff + (long long)row * ld + k + 8 * pslot),
                        __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
         }
     };
@@ -289,8 +273,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
         dma_wait_all();
         __syncthreads();
     }
-    const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / fcg_scale_of(g.scale_word ? *g.scale_word : 0u);
-    float* out = (g.slices > 1) ? g.part + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
+                                                               fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
+    // split-K partials: [slice][batch][M][N] (the batches' outputs must then be dense: sC = M N, ldc = N)
+    float* out = (g.slices > 1) ? g.part + ((size_t)(blockIdx.z - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
+                                : g.C + (long long)bz * g.sC;
     const long long ldo = (g.slices > 1) ? g.N : g.ldc;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -311,10 +298,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
 
 // C[i] = alpha * (part[0][i] + part[1][i] + ...) in slice order
 __global__ void gemm16s_reduce_kernel(size_t n4, int slices, const float4* __restrict__ part, float4* __restrict__ C,
-                                      const unsigned* __restrict__ scale_word, float alpha0) {
+                                      const unsigned* __restrict__ scale_word, const unsigned* __restrict__ scale_word_b, float alpha0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const float alpha = alpha0 / fcg_scale_of(scale_word ? *scale_word : 0u);
+    const float alpha = alpha0 / (fcg_scale_of(scale_word ? *scale_word : 0u) * fcg_scale_of(scale_word_b ? *scale_word_b : 0u));
     float4 s = part[i];
     for (int k = 1; k < slices; ++k) {
         const float4 v = part[(size_t)k * n4 + i];
@@ -323,22 +310,23 @@ __global__ void gemm16s_reduce_kernel(size_t n4, int slices, const float4* __res
     C[i] = make_float4(s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha);
 }
 
-static int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
+int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
+    const int nb = g.batch > 1 ? g.batch : 1;
     // tile shape by measurement (tools/time_fc_grad.py, n = 131 072): the weight gradient (one 196-row M tile, long K) is
     // faster on 256 x 128 tiles / 8 waves / one block per CU (0.55 against 0.59 ms with its producers), d rows (K = 224:
     // seven steps per block) on 128 x 128 / 4 waves / two blocks per CU (0.42 against 0.49 ms)
     if (g.M <= 256 && g.slices > 1) {
-        dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices);
+        dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
         hipLaunchKernelGGL((gemm16s_kernel<4, 2>), grid, dim3(512), 0, s, g);
     } else {
-        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.slices);
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.slices * nb);
         hipLaunchKernelGGL((gemm16s_kernel<2, 2>), grid, dim3(256), 0, s, g);
     }
     DAGL_LAUNCH_CHECK("gemm16s_kernel");
     if (g.slices > 1) {
-        const size_t n4 = (size_t)g.M * g.N / 4;
+        const size_t n4 = (size_t)nb * g.M * g.N / 4;
         hipLaunchKernelGGL(gemm16s_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n4, g.slices,
-                           reinterpret_cast<const float4*>(g.part), reinterpret_cast<float4*>(g.C), g.scale_word, g.alpha0);
+                           reinterpret_cast<const float4*>(g.part), reinterpret_cast<float4*>(g.C), g.scale_word, g.scale_word_b, g.alpha0);
         DAGL_LAUNCH_CHECK("gemm16s_reduce_kernel");
     }
     return DAGL_OK;

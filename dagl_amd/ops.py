@@ -7,6 +7,7 @@ freshly allocated outputs.  They mirror the stages of the reference method one t
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -616,8 +617,11 @@ def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace 
 
 
 @_on_device
-def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, workspace: "Workspace | None" = None):
-    """Gradients of the dense graph core (``dagl_ce_core_dense_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias)."""
+def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, workspace: "Workspace | None" = None,
+                           exact: bool = False):
+    """Gradients of the dense graph core (``dagl_ce_core_dense_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias).
+    ``exact``: the five matrix products on the fp32 matrix cores instead of the fp16 ones with split operands."""
+    exact = exact or os.environ.get("DAGL_DENSE_BACKWARD", "") == "fp32"
     lib = _lib.load()
     for n, t in (("d_out", d_out), ("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2), ("thr", thr), ("bias", bias)):
         _need(t, n)
@@ -629,7 +633,7 @@ def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, w
     d_thr = torch.empty(B, wq_rows.shape[1], device=dev, dtype=torch.float32)
     d_bias = torch.empty_like(d_thr)
     a, nbytes = _aligned(ws.get(need, dev))
-    check(lib.dagl_ce_core_dense_backward(_stream(), B, H, W, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+    check(lib.dagl_ce_core_dense_backward(_stream(), B, H, W, _lib.FLAG_EXACT_SCAN if exact else 0, wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
                                           thr.data_ptr(), bias.data_ptr(), saved["lse"].data_ptr(), saved["mu"].data_ptr(),
                                           d_out.data_ptr(), d_wq.data_ptr(), d_x.data_ptr(), d_b2.data_ptr(),
                                           d_thr.data_ptr(), d_bias.data_ptr(), a, nbytes), "dagl_ce_core_dense_backward")

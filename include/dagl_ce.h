@@ -286,7 +286,8 @@ int    dagl_ce_core_backward(void* stream, int B, int H, int W, int mode, int k,
 /* Dense neighbourhoods under autograd (an adaptive mask that keeps more than DAGL_FAST_CAP keys for some query -- the
  * regime of default-initialised thr/bias heads, i.e. where a training run starts): the reference's dense formulation
  * (dagl.py:250-264) and the gradients autograd derives from it, chunked over the queries so that the [L,N] matrices
- * exist one chunk at a time; all matrix products on the fp32 matrix cores (bitwise fmaf chains).  Adaptive mode only
+ * exist one chunk at a time; matrix products on the fp32 matrix cores (bitwise fmaf chains) or, by default in the backward, on
+ * the fp16 ones with split operands.  Adaptive mode only
  * (the top-k modes always have fixed-width lists).  Same operands as dagl_ce_core_forward / _backward; instead of
  * neighbour lists the forward hands back `lse` [B,L,2] = (softmax shift, denominator) per query and `mu` [B,L].
  * info (may be NULL; non-NULL costs one host synchronisation): path 5, total_edges, max_degree.
@@ -298,7 +299,10 @@ int    dagl_ce_core_dense_forward(void* stream, int B, int H, int W, int flags /
                                   const float* wq_rows, const float* x_rows, const float* b2,
                                   const float* thr, const float* bias, float* out, float* lse, float* mu,
                                   void* workspace, size_t ws_bytes, dagl_ce_info* info);
-int    dagl_ce_core_dense_backward(void* stream, int B, int H, int W,
+/* backward flags: 0 = the five matrix products of the gradients on the fp16 matrix cores with split operands (every tensor scaled
+ * by a power of two from its own largest magnitude: no range limit; shapes whose [L,N] matrices fit one chunk, else fp32);
+ * DAGL_FLAG_EXACT_SCAN = on the fp32 matrix cores.                                                                         */
+int    dagl_ce_core_dense_backward(void* stream, int B, int H, int W, int flags,
                                    const float* wq_rows, const float* x_rows, const float* b2,
                                    const float* thr, const float* bias, const float* lse, const float* mu,
                                    const float* d_out,
