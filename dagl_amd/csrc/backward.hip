@@ -113,23 +113,38 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(BwdArgs a) {
     }
 }
 
-// d Xbar[b,:] = sum_l d mu_l Wq_l[:]   (adaptive modes): one block per (b, column quad group); fixed-order partials
-__global__ __launch_bounds__(256) void dxbar_kernel(int L, const float* __restrict__ wq_rows, const float* __restrict__ dmu,
-                                                    float* __restrict__ dxbar) {
-    __shared__ float part[4][D];
+// d Xbar[b,:] = sum_l d mu_l Wq_l[:]   (adaptive modes): one block of 16 waves per image, a wave takes rows w, w + 16, .. four at a
+// time; fixed-order partials (four waves walking 256 rows each, one row in flight: 135 us for 0.8 MB)
+__global__ __launch_bounds__(1024) void dxbar_kernel(int L, const float* __restrict__ wq_rows, const float* __restrict__ dmu,
+                                                     float* __restrict__ dxbar) {
+    __shared__ float part[16][D];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};                                  // columns lane + 64 u
-    for (int l = w; l < L; l += 4) {
-        const float g = dmu[(size_t)b * L + l];
-        const float* q = wq_rows + ((size_t)b * L + l) * D;
+    for (int l0 = w; l0 < L; l0 += 64) {
+        float g[4], q[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) acc[u] += g * q[c]; }
+        for (int r = 0; r < 4; ++r) {
+            const int l = l0 + 16 * r;
+            g[r] = (l < L) ? dmu[(size_t)b * L + l] : 0.f;
+            const float* qr = wq_rows + ((size_t)b * L + (l < L ? l : 0)) * D;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; q[r][u] = (c < D) ? qr[c] : 0.f; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += g[r] * q[r][u];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = lane + 64 * u; if (c < D) part[w][c] = acc[u]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) dxbar[(size_t)b * D + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    for (int c = threadIdx.x; c < D; c += 1024) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][c];
+        dxbar[(size_t)b * D + c] = t;
+    }
 }
 
 // ---- edges sorted by key ------------------------------------------------------------------------------------------
@@ -338,7 +353,7 @@ int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, f
 }
 
 int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar) {
-    hipLaunchKernelGGL(dxbar_kernel, dim3(B), dim3(256), 0, s, L, wq_rows, dmu, dxbar);
+    hipLaunchKernelGGL(dxbar_kernel, dim3(B), dim3(1024), 0, s, L, wq_rows, dmu, dxbar);
     DAGL_LAUNCH_CHECK("dxbar_kernel");
     return DAGL_OK;
 }
@@ -494,7 +509,7 @@ int launch_core_backward(hipStream_t s, const BwdArgs& a, const BwdSortWs& w, fl
     }
     const bool adaptive = (a.mode != DAGL_MODE_TOPK);
     if (adaptive) {
-        hipLaunchKernelGGL(dxbar_kernel, dim3(a.B), dim3(256), 0, s, g.L, a.wq_rows, a.dmu, dxbar_ws);
+        hipLaunchKernelGGL(dxbar_kernel, dim3(a.B), dim3(1024), 0, s, g.L, a.wq_rows, a.dmu, dxbar_ws);
         DAGL_LAUNCH_CHECK("dxbar_kernel");
     }
     {
@@ -534,22 +549,32 @@ int launch_rows_to_feat(hipStream_t s, int B, int rows, const float* src, float*
     return DAGL_OK;
 }
 
-// column sums of dense rows [B,N,196] -> fp64 [B,204] (fixed order: per-wave strided partials + butterfly + 4-way add)
+// column sums of dense rows [B,N,196] -> fp64 [B,204] (fixed order: per-thread strided partials + butterfly + 4-way add).
+// Block = (image, four columns): a thread reads 16 bytes of a row (one column per block and 4 bytes per row and thread was 172 us
+// for 103 MB at [8, 16384 x 196]: 196 blocks per image asking the L2 for the same lines).
 __global__ __launch_bounds__(256) void colsum_rows_kernel(int N, const float* __restrict__ rows, double* __restrict__ colsum) {
-    __shared__ double part[4];
-    const int b = blockIdx.y, c = blockIdx.x;
+    __shared__ double part[4][4];
+    const int b = blockIdx.y, c4 = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double t = 0.0;
-    for (int j = threadIdx.x; j < N; j += 256) t += (double)rows[((size_t)b * N + j) * D + c];
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    const float4* base = reinterpret_cast<const float4*>(rows + (size_t)b * N * D) + c4;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float4 v = base[(size_t)j * (D / 4)];
+        t0 += (double)v.x; t1 += (double)v.y; t2 += (double)v.z; t3 += (double)v.w;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane == 0) part[w] = t;
+    for (int o = 32; o > 0; o >>= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); t3 += __shfl_xor(t3, o); }
+    if (lane == 0) { part[w][0] = t0; part[w][1] = t1; part[w][2] = t2; part[w][3] = t3; }
     __syncthreads();
-    if (threadIdx.x == 0) colsum[(size_t)b * DS + c] = (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x < 4) {
+        const int u = threadIdx.x;
+        colsum[(size_t)b * DS + 4 * c4 + u] = (part[0][u] + part[1][u]) + (part[2][u] + part[3][u]);
+    }
 }
 
 int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum) {
-    hipLaunchKernelGGL(colsum_rows_kernel, dim3(D, B), dim3(256), 0, s, N, rows, colsum);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(D / 4, B), dim3(256), 0, s, N, rows, colsum);
     DAGL_LAUNCH_CHECK("colsum_rows_kernel");
     return DAGL_OK;
 }

@@ -28,6 +28,7 @@ struct DtPlan {
     // split-fp16 backward (one chunk per image group only): hi / lo operand copies, each `..._h` halfs long (lo follows hi)
     bool h16;
     int Lp, kslices;                 // L rounded up to 32; split-K of d Wq
+    int nk;                          // N rounded up to 32 kslices: the K extent of the copies whose rows run over the keys
     long long ldl, ldk;              // leading dimensions (halfs) of the copies whose rows run over the queries / the keys: extent + 64 -- a
                                      // power-of-two row stride (L = 1024: 2 KiB, N = 16384: 32 KiB) sends the 16 rows of every LDS-DMA piece
                                      // to the same memory channel (the products ran at a third of the fp32 ones' rate)
@@ -41,6 +42,7 @@ constexpr int DT_DK = 224;           // feature length 196 rounded up to the K s
 static DtPlan dt_plan(int B, const Grid& g, bool backward) {
     DtPlan p;
     p.ldn = (g.N + 31) / 32 * 32;
+    // (measured: skewing rows that are a multiple of 2 KiB long by 128 bytes does nothing for the row-per-block softmax kernels)
     long long lc = (long long)(DT_CHUNK_FLOATS / (size_t)p.ldn) / 128 * 128;
     if (lc < 128) lc = 128;
     p.Lc = (int)(lc < g.L ? lc : g.L);
@@ -68,8 +70,14 @@ static DtPlan dt_plan(int B, const Grid& g, bool backward) {
     p.o_rowsum = carve((size_t)B * g.L * sizeof(float));
     p.h16 = backward && p.n_chunks == 1;
     p.Lp = (g.L + 31) / 32 * 32;
-    p.ldl = p.Lp + 64; p.ldk = p.ldn + 64;
     p.kslices = 1;
+    {
+        // d Wq = d S X: (L / 128) x 2 output tiles per image -- split K (the keys) until the launch fills the chip
+        const long long tiles = (long long)((g.L + 127) / 128) * 2 * p.Bc;
+        while (p.kslices < 8 && tiles * p.kslices < 512 && g.N >= 512 * p.kslices) p.kslices *= 2;
+    }
+    p.nk = (g.N + 32 * p.kslices - 1) / (32 * p.kslices) * (32 * p.kslices);
+    p.ldl = p.Lp + 64; p.ldk = p.nk + 64;
     if (p.h16) {
         const size_t bc = (size_t)p.Bc;
         p.dgk_h = bc * g.L * DT_PK; p.dgt_h = bc * P * p.ldl; p.vk_h = bc * g.N * DT_PK;
@@ -79,9 +87,6 @@ static DtPlan dt_plan(int B, const Grid& g, bool backward) {
         p.o_dgk = carve(2 * p.dgk_h * 2); p.o_dgt = carve(2 * p.dgt_h * 2); p.o_vk = carve(2 * p.vk_h * 2);
         p.o_xk = carve(2 * p.xk_h * 2); p.o_xt = carve(2 * p.xt_h * 2); p.o_wqk = carve(2 * p.wqk_h * 2); p.o_wqt = carve(2 * p.wqt_h * 2);
         p.o_dsk = carve(2 * p.dsk_h * 2); p.o_dst = carve(2 * p.dst_h * 2); p.o_at = carve(2 * p.at_h * 2);
-        // d Wq = d S X: (L / 128) x 2 output tiles per image -- split K (the keys) until the launch fills the chip
-        const long long tiles = (long long)((g.L + 127) / 128) * 2 * p.Bc;
-        while (p.kslices < 8 && tiles * p.kslices < 512 && (p.ldn % (64 * p.kslices)) == 0) p.kslices *= 2;
         p.o_part = carve((size_t)p.kslices * bc * g.L * D * sizeof(float));
     }
     p.o_end = off;
@@ -250,6 +255,17 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
         dthr[ql] = -mu[ql] * S;
         dmu[ql] = -thr[ql] * S;
     }
+}
+
+// (Measured and dropped: the row in registers -- S and d A read once, one expf per weight, 16-byte accesses; 512 threads x 32
+// elements, 1 or 2 blocks per CU: 832 us against this kernel's 867 at [8, 1024 x 16384], whatever the variant.  2.1 GB in 0.83 ms.)
+static int launch_dense_softmax_bwd(hipStream_t s, int rows, int nb, int N, long long ldn, int L, int l0, int Lc, float* sbuf, float* abuf,
+                                    const float* mt, const float* bs, const float* lse, const float* mu, const float* thr, float* dthr,
+                                    float* dbias, float* dmu, int b0, unsigned* ds_word) {
+    hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(rows, nb), dim3(256), 0, s, N, ldn, L, l0, Lc, sbuf, abuf, mt, bs, lse, mu, thr, dthr,
+                       dbias, dmu, b0, ds_word);
+    DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+    return DAGL_OK;
 }
 
 // out[r, c] += rs[r] * v[c] * scale   (the rank-one terms of the dense row mean)
@@ -498,7 +514,7 @@ static int dt_backward_group16(hipStream_t s, const Grid& g, const DtPlan& p, vo
         DAGL_LAUNCH_CHECK("dt_unfold_values_split_kernel");
     }
     if ((rc = dt_split_rows(s, (size_t)nb * N, D, D, DT_DK, DT_DK, xr, words + 2, 1.f, H(p.o_xk), p.xk_h))) return rc;
-    if ((rc = dt_split_transpose(s, nb, N, D, D, (long long)N * D, (int)ldn, ldk, xr, words + 2, 1.f, H(p.o_xt), p.xt_h))) return rc;
+    if ((rc = dt_split_transpose(s, nb, N, D, D, (long long)N * D, p.nk, ldk, xr, words + 2, 1.f, H(p.o_xt), p.xt_h))) return rc;
     if ((rc = dt_split_rows(s, (size_t)nb * L, D, D, DT_DK, DT_DK, wq, words + 3, 1.f, H(p.o_wqk), p.wqk_h))) return rc;
     if ((rc = dt_split_transpose(s, nb, L, D, D, (long long)L * D, Lp, ldl, wq, words + 3, 1.f, H(p.o_wqt), p.wqt_h))) return rc;
     const long long sS = (long long)p.Lc * ldn;
@@ -507,16 +523,14 @@ static int dt_backward_group16(hipStream_t s, const Grid& g, const DtPlan& p, vo
                                           (long long)N * DT_PK, abuf, ldn, sS, words + 0, words + 1, 1.f)))) return rc;
     if ((rc = launch_gemm16s(s, dt_gemm16(L, N, DT_DK, nb, H(p.o_wqk), p.wqk_h, DT_DK, (long long)L * DT_DK, H(p.o_xk), p.xk_h, DT_DK,
                                           (long long)N * DT_DK, sbuf, ldn, sS, words + 3, words + 2, 1.f)))) return rc;
-    hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(L, nb), dim3(256), 0, s, N, ldn, L, 0, p.Lc, sbuf, abuf, mt, bias, lse, mu, thr,
-                       dthr, dbias, dmu, b0, words + 4);
-    DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+    if ((rc = launch_dense_softmax_bwd(s, L, nb, N, ldn, L, 0, p.Lc, sbuf, abuf, mt, bias, lse, mu, thr, dthr, dbias, dmu, b0, words + 4))) return rc;
     // d S by rows and transposed, A transposed
-    if ((rc = dt_split_rows(s, (size_t)nb * p.Lc, (int)ldn, ldn, (int)ldn, ldk, sbuf, words + 4, 1.f, H(p.o_dsk), p.dsk_h))) return rc;
+    if ((rc = dt_split_rows(s, (size_t)nb * p.Lc, (int)ldn, ldn, p.nk, ldk, sbuf, words + 4, 1.f, H(p.o_dsk), p.dsk_h))) return rc;
     if ((rc = dt_split_transpose(s, nb, L, N, ldn, sS, Lp, ldl, sbuf, words + 4, 1.f, H(p.o_dst), p.dst_h))) return rc;
     if ((rc = dt_split_transpose(s, nb, L, N, ldn, sS, Lp, ldl, abuf, nullptr, 8192.f, H(p.o_at), p.at_h))) return rc;
     // d Wq = d S X (split over the keys)
     {
-        Gemm16s q = dt_gemm16(L, D, (int)(ldn / p.kslices), nb, H(p.o_dsk), p.dsk_h, ldk, (long long)p.Lc * ldk, H(p.o_xt), p.xt_h, ldk, (long long)D * ldk,
+        Gemm16s q = dt_gemm16(L, D, p.nk / p.kslices, nb, H(p.o_dsk), p.dsk_h, ldk, (long long)p.Lc * ldk, H(p.o_xt), p.xt_h, ldk, (long long)D * ldk,
                               dwq_rows + (size_t)b0 * L * D, D, (long long)L * D, words + 4, words + 2, 1.f);
         q.slices = p.kslices; q.part = dt_at<float>(ws, p.o_part);
         if ((rc = launch_gemm16s(s, q))) return rc;
@@ -568,9 +582,8 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
                                                abuf, p.ldn, sS, 0.f, true)))) return rc;
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_c, D, (long long)g.L * D, 1,
                                                x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1, sbuf, p.ldn, sS, 0.f)))) return rc;
-            hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias,
-                               lse, mu, thr, dthr, dbias, dmu, b0, nullptr);
-            DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+            if ((rc = launch_dense_softmax_bwd(s, lc, nb, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias, lse, mu, thr, dthr, dbias, dmu, b0,
+                                               nullptr))) return rc;
             // d Wq = d S X
             if ((rc = launch_gemm32(s, dt_gemm(lc, D, g.N, nb, sbuf, p.ldn, sS, 1, x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 0,
                                                dwq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 0.f, true)))) return rc;

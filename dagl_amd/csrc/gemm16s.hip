@@ -315,6 +315,7 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
     // tile shape by measurement (tools/time_fc_grad.py, n = 131 072): the weight gradient (one 196-row M tile, long K) is
     // faster on 256 x 128 tiles / 8 waves / one block per CU (0.55 against 0.59 ms with its producers), d rows (K = 224:
     // seven steps per block) on 128 x 128 / 4 waves / two blocks per CU (0.42 against 0.49 ms)
+    // (the dense backward's batched products, K = 800 / 1024, M >= 1024: 256 x 128 tiles +-0 -- 124.1 against 123.6 ms per step)
     if (g.M <= 256 && g.slices > 1) {
         dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
         hipLaunchKernelGGL((gemm16s_kernel<4, 2>), grid, dim3(512), 0, s, g);
