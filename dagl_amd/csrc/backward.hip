@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(int N, const float* __
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     const float4* base = reinterpret_cast<const float4*>(rows + (size_t)b * N * D) + c4;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = threadIdx.x; j < N; j += 256) {
         const float4 v = base[(size_t)j * (D / 4)];
         t0 += (double)v.x; t1 += (double)v.y; t2 += (double)v.z; t3 += (double)v.w;

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     (void)lse;
     __shared__ float shf[4];
     float mx = 0.f;
+#pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
         const float l = dt_logit(srow[j], mtq, bsq, pass, m);
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     }
     const float M = dt_block_max(mx, shf);
     double zz = 0.0;
+#pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
         const float l = dt_logit(srow[j], mtq, bsq, pass, m);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     }
     const float invz = (float)(1.0 / dt_block_sum(zz, shd));
     double c = 0.0;
+#pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
         const float l = dt_logit(srow[j], mtq, bsq, pass, m);
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     }
     const float cf = (float)dt_block_sum(c, shd);
     double sdm = 0.0;
+#pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
         const float s = srow[j];
@@ -258,7 +262,9 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
 }
 
 // (Measured and dropped: the row in registers -- S and d A read once, one expf per weight, 16-byte accesses; 512 threads x 32
-// elements, 1 or 2 blocks per CU: 832 us against this kernel's 867 at [8, 1024 x 16384], whatever the variant.  2.1 GB in 0.83 ms.)
+// elements, 1 or 2 blocks per CU: 832 us against this kernel's 867 at [8, 1024 x 16384], whatever the variant.  2.1 GB in 0.83 ms;
+// this kernel without its stores: 666 us -- one load in flight per thread and pass; the register form has all of a row's loads in
+// flight but one block per CU, whose load / reduce / store phases do not overlap with anything: ~26 us per row and CU either way.)
 static int launch_dense_softmax_bwd(hipStream_t s, int rows, int nb, int N, long long ldn, int L, int l0, int Lc, float* sbuf, float* abuf,
                                     const float* mt, const float* bs, const float* lse, const float* mu, const float* thr, float* dthr,
                                     float* dbias, float* dmu, int b0, unsigned* ds_word) {
@@ -406,10 +412,16 @@ __global__ __launch_bounds__(256) void dt_split_transpose_kernel(int R, int C, l
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const float sc = word ? fcg_scale_of(*word) : fixed;
     const float* sb = src + (long long)b * ss;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        const float v = (r0 + r < R && c0 + c < C) ? sb[(long long)(r0 + r) * ld + c0 + c] * sc : 0.f;
-        g16_split(v, th[c][r], tl[c][r]);
+    float v[16];                                                             // all of a thread's 16 loads in flight, then the splits
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = threadIdx.x + 256 * u, r = e >> 6, c = e & 63;
+        v[u] = (r0 + r < R && c0 + c < C) ? sb[(long long)(r0 + r) * ld + c0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = threadIdx.x + 256 * u, r = e >> 6, c = e & 63;
+        g16_split(v[u] * sc, th[c][r], tl[c][r]);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 8; e += 256) {                        // (column, octet of rows)

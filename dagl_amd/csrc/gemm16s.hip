@@ -128,10 +128,16 @@ __global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size
     const size_t r0 = (size_t)blockIdx.x * 128;
     const int c0 = blockIdx.y * 32;
     const float s = fcg_scale_of(*max_word);
-    for (int e = threadIdx.x; e < 128 * 32; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        const float v = (r0 + r < n && c0 + c < FCG_O) ? dz[(r0 + r) * FCG_O + c0 + c] * s : 0.f;
-        g16_split(v, th[c][r], tl[c][r]);
+    float v[16];                                                             // (all 16 loads of a thread in flight, then the splits)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
+        v[u] = (r0 + r < n && c0 + c < FCG_O) ? dz[(r0 + r) * FCG_O + c0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
+        g16_split(v[u] * s, th[c][r], tl[c][r]);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 32 * 16; e += 256) {                        // (column, octet of rows)
