@@ -251,6 +251,7 @@ def extra_configs(dev):
         torch.cuda.empty_cache()
     out["256x256_set12_features"] = real_features_extra(dev)
     out["train_rr_topk8_128x128_b8"] = train_extra(dev)
+    out["train_rr_adaptive_128x128_b8"] = train_extra(dev, steps=4, warmup=2, mode="adaptive")
     return out
 
 
@@ -351,10 +352,11 @@ def real_features_extra(dev):
     return res
 
 
-def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
-    """BASELINE configs[4] on one GPU inside the driver-timed command: RR (12 heads, fixed-k 8) fwd + bwd + Adam on synthetic crops
+def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2, mode="topk"):
+    """BASELINE configs[4] on one GPU inside the driver-timed command: RR (12 heads) fwd + bwd + Adam on synthetic crops
     [8,3,128,128], plus the roofline of the step's dominant matrix products -- the fc2 projection's two gradient products on the
-    split-fp16 GEMM (gemm_roofline)."""
+    split-fp16 GEMM (gemm_roofline).  mode "topk": fixed-k 8 (neighbour lists); "adaptive": the shipped semantics from the seeded
+    initialisation -- dense neighbourhoods, i.e. the streamed dense forward and the dense backward (dense_train.hip)."""
     from dagl_amd import ops
     from dagl_amd.ce import CE
     from dagl_amd.net import RR, seeded_state_dict
@@ -363,15 +365,25 @@ def train_extra(dev, B=8, crop=128, colors=3, steps=5, warmup=2):
     net.load_state_dict(seeded_state_dict(net.state_dict(), 7), strict=True)
     for m in net.modules():
         if isinstance(m, CE):
-            m.select_mode, m.select_k = "topk", 8
+            if mode == "topk":
+                m.select_mode, m.select_k = "topk", 8
+            else:
+                m.select_mode = mode
     net = net.to(dev)
     freeze_unused(net)
     opt = TrainOptions(task="dn_real", lr=1e-4)
     step = TrainStep(net, make_optimizer(net, opt), opt, generator=torch.Generator(device=dev).manual_seed(300))
     hr = torch.rand(B, colors, crop, crop, generator=torch.Generator().manual_seed(200)).to(dev)
     ms = _time_steps(lambda: step(hr), steps, warmup)
+    infos = [m.last_info or {} for m in net.modules() if isinstance(m, CE)]
     del net, step
     torch.cuda.empty_cache()
+    if mode != "topk":
+        return {"what": "the same step with the shipped adaptive semantics from the seeded initialisation (every head in the dense "
+                        "regime: streamed split-fp16 forward, dense backward with its five matrix products on the fp16 matrix cores, "
+                        "split operands)",
+                "ms_per_step": ms, "crops_per_s": B / (ms * 1e-3), "steps": steps, "warmup": warmup,
+                "selection_paths": sorted({i.get("path") for i in infos if i.get("path") is not None})}
     return {"what": "BASELINE configs[4] (sparse regime) on one GPU: RR with 12 CE heads, crops [8,3,128,128], fwd + bwd + Adam, "
                     "fixed-k 8; no RCCL leg here (world size 1) -- `bench.py --train --gpus N` runs it under DDP",
             "ms_per_step": ms, "crops_per_s": B / (ms * 1e-3), "steps": steps, "warmup": warmup,

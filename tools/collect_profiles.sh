@@ -21,5 +21,6 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/md8 -o 
 # (MIOPEN_FIND_MODE=FAST: without it MIOpen's find phase -- 32 calls x 38 ms of naive_conv_* and Tensile benchmarking inside the
 # first step -- is two thirds of the traced time and the CSV does not show the steady-state step)
 MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 12 --warmup 4 > $OUT/train.log 2>&1
+MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_adaptive -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode adaptive --steps 8 --warmup 3 > $OUT/train_adaptive.log 2>&1
 python $GRAFT_REPO_ROOT/tools/summarize_profiles.py $OUT $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary $TAG
 ls $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary

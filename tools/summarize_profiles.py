@@ -50,7 +50,8 @@ def short(name):
 def main():
     src, dst, tag = sys.argv[1:4]
     os.makedirs(dst, exist_ok=True)
-    for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("md8", "adaptive_mean_degree_8_256"), ("train", "train")):
+    for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("md8", "adaptive_mean_degree_8_256"), ("train", "train"),
+                      ("train_adaptive", "train_adaptive")):
         f = find(os.path.join(src, sub), "*kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
