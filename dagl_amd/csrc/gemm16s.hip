@@ -193,14 +193,17 @@ __global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigne
 // C[m][n] = sum_k A[m][k] B[n][k]; block = (64 WM) x (64 WN) outputs by WM x WN waves of 64 x 64, grid.z = K slices.
 // The operand stream through LDS-DMA is what bounds this kernel (~23 GB/s per CU measured, hi + lo double the bytes of an
 // fp16 GEMM): 256 x 128 tiles fetch 3/4 of the bytes per product of 128 x 128 ones.
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_kernel(Gemm16s g) {
+// NS = stages of the operand ring: 2 = the tile of step t + 1 is requested at the start of step t and awaited at its end (a step is
+// ~0.7 us of multiplies per SIMD: less than the request's latency); 3 = two steps ahead, awaited with a counted vmcnt.
+template <int WM, int WN, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) void gemm16s_kernel(Gemm16s g) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
     constexpr int PA = BM * 64, PB = BN * 64;                                     // bytes of one part (hi or lo) of an operand tile
     constexpr int STAGE = 2 * PA + 2 * PB;
     constexpr int PIECES = STAGE / 1024;
     static_assert(PIECES % NW == 0, "pieces per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int PPW = PIECES / NW;                                              // requests per wave and stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -242,13 +245,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = g.K / G16_BK;
-    stage(0, k0);
-    dma_wait_all();
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) stage(st, k0 + (long long)st * G16_BK);
+    if (NS > 2 && nk > 1) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
     __syncthreads();
     const int swz = (i >> 2) & 3;
+    int cur = 0, nxt = NS - 1;                                                    // buffer of step t, buffer of step t + NS - 1
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(cur ^ 1, k0 + (long long)(t + 1) * G16_BK);
+        if (t + NS - 1 < nk) stage(nxt, k0 + (long long)(t + NS - 1) * G16_BK);   // (the buffer step t - 1 read: behind that step's barrier)
         const unsigned char* sb = smem + cur * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -276,8 +281,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm16s_
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_hi[a], acc[a][b], 0, 0, 0);
         }
-        dma_wait_all();
+        // step t + 1's tile must have landed; the requests of the steps after it may stay in flight (a wave's requests complete in order)
+        if (NS > 2 && t + NS - 1 < nk) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
         __syncthreads();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
     const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
                                                                fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
@@ -321,10 +329,13 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
     // tile shape by measurement (tools/time_fc_grad.py, n = 131 072): the weight gradient (one 196-row M tile, long K) is
     // faster on 256 x 128 tiles / 8 waves / one block per CU (0.55 against 0.59 ms with its producers), d rows (K = 224:
     // seven steps per block) on 128 x 128 / 4 waves / two blocks per CU (0.42 against 0.49 ms)
-    // (the dense backward's batched products, K = 800 / 1024, M >= 1024: 256 x 128 tiles +-0 -- 124.1 against 123.6 ms per step)
-    if (g.M <= 256 && g.slices > 1) {
+    // 256 x 128 tiles / 8 waves / one block per CU with the three-stage ring: the weight gradient (one M tile, split K) and the dense
+    // backward's batched products (K >= 512, M >= 1024): 114.5 -> 113.0 ms per adaptive-mode step, 47.6 -> 47.1 top-k; the 128 x 128
+    // kernel with three stages (one block per CU instead of two): 123.6.  d rows (K = 224: seven steps per block): 128 x 128.
+    const bool small_m = g.M <= 256 && g.slices > 1;
+    if (small_m || (g.K >= 512 && g.M >= 1024)) {
         dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
-        hipLaunchKernelGGL((gemm16s_kernel<4, 2>), grid, dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, g);
     } else {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.slices * nb);
         hipLaunchKernelGGL((gemm16s_kernel<2, 2>), grid, dim3(256), 0, s, g);
