@@ -216,20 +216,22 @@ def extra_configs(dev):
         ("256x256_adaptive_dense_default_init", 256, "default", 2.0, "adaptive", 0, torch.float32, "shipped semantics at default init (~95 % of the keys pass): streamed dense formulation; on this synthetic N(0,1) map the logits reach hundreds and ~2/3 of the (64 query x 16 key) weight granules are exactly zero and skipped -- see 256x256_set12_features.adaptive_dense for the regime where none are"),
         ("256x256_adaptive_mean_degree_8", 256, "sparse", 1.95, "adaptive", 0, torch.float32, "adaptive mask tuned to a mean degree of ~8 (7.7; long-tailed: maximum 890) (SURVEY 8d config 2)"),
         ("256x256_adaptive_mean_degree_55", 256, "sparse", 1.8, "adaptive", 0, torch.float32, "adaptive mask at mean degree 55, maximum 4578"),
+        ("256x256_topk8_batch8", 256, "default", 2.0, "topk", 8, torch.float32, "the headline configuration with EIGHT images per call ([8,64,256,256]; batch = grid dimension): what the fixed per-launch costs of the one-image step are worth", 8),
         ("256x256_topk500", 256, "default", 2.0, "topk", 500, torch.float32, "num_edge = 500 (CA_model-checkpoint.py:134-143): beyond the 64-entry lists, every query's score row in the dense form (csrc/topk_wide.hip)"),
     ]
     seeds = {"256x256_adaptive_mean_degree_8": (41, 41), "256x256_adaptive_mean_degree_55": (41, 41)}       # (weights, features): the pair tests/test_gpu_configs.py checks against the oracle
     with torch.no_grad():
-        for name, size, variant, gain, mode, k, dt, what in cases:
+        for name, size, variant, gain, mode, k, dt, what, *rest in cases:
+            nb = rest[0] if rest else 1
             ws, fs = seeds.get(name, (2024, 100))
             ce = head(ws, variant, gain, mode, k)
             if name == "256x256_adaptive_mean_degree_8":
                 ce.adaptive_sync = "auto"        # steady sparse workload: stops waiting for the verdict after four served calls (ce.py)
-            x = torch.from_numpy(make_features(fs, 1, 64, size, size)).to(dev).to(dt)
+            x = torch.from_numpy(make_features(fs, nb, 64, size, size)).to(dev).to(dt)
             ms = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
-            L = (size // 4) ** 2
+            L = nb * (size // 4) ** 2
             info = ce.last_info or {}
-            out[name] = {"what": what, "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": size * size,
+            out[name] = {"what": what, "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": size * size, "batch": nb,
                          "selection_path": info.get("path"), "max_degree": info.get("max_degree"),
                          "mean_degree": (info.get("total_edges", -1) / L) if info.get("total_edges", -1) >= 0 else None}
             del ce, x

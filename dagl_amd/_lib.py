@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 402          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 403          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dagl_ce_core_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dagl_ce_core_dense_forward": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9 + [_sz, C.POINTER(CeInfo)]),
     "dagl_ce_core_dense_backward": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 14 + [_sz]),
+    "dagl_ce_core_wide_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 7 + [_sz, C.POINTER(CeInfo)]),
+    "dagl_ce_core_wide_backward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 12 + [_sz]),
     "dagl_gemm_f32_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "dagl_gemm_f32": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp, C.c_longlong, C.c_longlong, _i,
                            _vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, _vp, _i, _i, _vp]),

@@ -86,6 +86,35 @@ class _GraphCoreDense(torch.autograd.Function):
         return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None, None
 
 
+class _GraphCoreWide(torch.autograd.Function):
+    """dagl.py:250-272 in the top-k modes when min(k, N) exceeds the lists' width (the fixed-k variant takes any num_edge,
+    GReccR2b_3mh_1-checkpoint.py:242-250; CA_model-checkpoint.py:134-143 uses 500): the dense formulation with the row-wise
+    selection of the k best scores as its mask (``dagl_ce_core_wide_forward`` / ``_backward``; dense_train.hip, wide_select.h)."""
+
+    @staticmethod
+    def forward(ctx, wq_rows, x_rows, b2, thr, bias, mode, k, ws_f, ws_b, sink):
+        wq_rows, x_rows, b2 = wq_rows.contiguous(), x_rows.contiguous(), b2.contiguous()
+        heads = mode != "topk"
+        thr_c, bias_c = (thr.contiguous(), bias.contiguous()) if heads else (None, None)
+        out, info = ops.ce_core_wide_forward(wq_rows, x_rows, b2, thr_c, bias_c, mode, k, workspace=ws_f, want_info=sink is not None)
+        ctx.ws_b, ctx.mode, ctx.k, ctx.heads = ws_b, mode, k, heads
+        ctx.thr_shape = thr.shape if heads else None
+        ctx.save_for_backward(*([wq_rows, x_rows, b2] + ([thr_c, bias_c] if heads else [])))
+        if sink is not None and info is not None:
+            sink.update(info)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        wq_rows, x_rows, b2, *tb = ctx.saved_tensors
+        thr, bias = tb if ctx.heads else (None, None)
+        d_wq, d_x, d_b2, d_thr, d_bias = ops.ce_core_wide_backward(d_out.contiguous().float(), wq_rows, x_rows, b2, thr, bias,
+                                                                   ctx.mode, ctx.k, workspace=ctx.ws_b)
+        if ctx.heads:
+            d_thr, d_bias = d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape)
+        return d_wq, d_x, d_b2, d_thr, d_bias, None, None, None, None, None
+
+
 class _EvalLazyGrad(torch.autograd.Function):
     """An eval() block inside an autograd-enabled forward (the reference's test loop, DN_Gray/trainer.py:128-140, builds a
     graph it never uses): forward on the inference kernels, nothing saved but the input; a backward -- rare -- recomputes
@@ -139,7 +168,7 @@ class CE(nn.Module):
         # variant (GReccR2b_3mh_1-checkpoint.py:242-250) and the intersection available:
         #   "adaptive" | "topk" | "adaptive_topk", with k = ``select_k``.
         self.select_mode = "adaptive"
-        self.select_k = num_edge       # the fixed-k variant's own default is 50; k > MAX_TOPK: inference only (row-wise dense form)
+        self.select_k = num_edge       # the fixed-k variant's own default is 50; k > MAX_TOPK: row-wise dense form (no lists)
         # "screened": bf16 matrix-core screen of all L*N scores + exact refinement of the survivors (default);
         # "exact": every score on the fp32 matrix cores.  Same neighbours either way.
         self.scan = "screened"
@@ -337,7 +366,13 @@ class CE(nn.Module):
         info = {}
         self._pack_key = None          # the shared workspace is reused with another layout
         out = None
-        if self.select_mode == "adaptive" and self._train_dense:
+        k_eff = min(int(self.select_k), H * W) if self.select_mode != "adaptive" else 0
+        if k_eff > MAX_TOPK:
+            # more neighbours than the lists hold: the dense formulation with the row-wise selection as its mask
+            want = self._train_calls % 64 == 0          # (statistics cost a host synchronisation: every 64th call)
+            out = _GraphCoreWide.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, k_eff, self._ws, self._ws_bwd,
+                                       info if want else None)
+        elif self.select_mode == "adaptive" and self._train_dense:
             # the last training call met dense neighbourhoods: start in the dense formulation; every 16th call reads the
             # degrees back (one host synchronisation) to notice when the masks have become sparse enough for the lists
             self._train_dense_calls += 1
@@ -385,7 +420,8 @@ class CE(nn.Module):
                 raise DaglError(f"CE: select_k={self.select_k} < 1")
             k_eff = min(int(self.select_k), b.shape[2] * b.shape[3])
             # k_eff > MAX_TOPK (include/dagl_ce.h DAGL_MAX_TOPK): no per-query lists -- the inference entry points take every
-            # query's score row in the dense form (csrc/topk_wide.hip); the differentiable path keeps lists and raises below
+            # query's score row in the dense form (csrc/topk_wide.hip), the differentiable path the dense formulation with the
+            # row-wise selection as its mask (_GraphCoreWide)
         in_dtype = b.dtype
         if in_dtype in (torch.bfloat16, torch.float16):
             # reduced-precision feature maps (BASELINE config 3): the block itself computes in fp32 with the bf16
@@ -401,9 +437,6 @@ class CE(nn.Module):
         # differentiable path then -- same gradients, paid only when used.
         if torch.is_grad_enabled():
             if self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
-                if k_eff > MAX_TOPK:
-                    raise DaglError(f"CE: select_k={self.select_k} > {MAX_TOPK} under autograd: the differentiable path keeps "
-                                    f"per-query lists of at most {MAX_TOPK} neighbours (include/dagl_ce.h DAGL_MAX_TOPK)")
                 out = self._forward_train(b.contiguous())
                 return out if in_dtype == torch.float32 else out.to(in_dtype)
             if b.requires_grad:

@@ -1210,6 +1210,51 @@ int dagl_ce_core_dense_backward(void* stream, int B, int H, int W, int flags, co
                                        d_wq_rows, d_x_rows, d_b2, d_thr, d_bias, workspace, ws_bytes, (flags & DAGL_FLAG_EXACT_SCAN) != 0);
 }
 
+// ---- top-k modes whose neighbourhoods exceed the lists (min(k, N) > DAGL_MAX_TOPK) under autograd: the dense formulation of
+// dense_train.hip with the row-wise selection of topk_wide.hip as its mask ------------------------------------------------------
+int dagl_ce_core_wide_forward(void* stream, int B, int H, int W, int mode, int k, const float* wq_rows, const float* x_rows,
+                              const float* b2, const float* thr, const float* bias, float* out, void* workspace, size_t ws_bytes,
+                              dagl_ce_info* info) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && out && k >= 1 &&
+                 (mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK), "dagl_ce_core_wide_forward: bad argument");
+    DAGL_REQUIRE(mode == DAGL_MODE_TOPK || (thr && bias), "dagl_ce_core_wide_forward: the intersection mode needs thr and bias");
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_wide_forward: workspace must be 256-byte aligned");
+    const Grid g = make_grid(H, W);
+    if (k > g.N) k = g.N;                                              // top_k = min(num_edge, N)
+    const size_t need = dense_train_workspace_bytes(B, g, false) + 256;
+    if (info) { info->required_bytes = (int64_t)need; info->total_edges = -1; info->max_degree = -1; info->redone_queries = -1;
+                info->path = 5; info->range_fallback = 0; info->reserved = 0; }
+    if (ws_bytes < need) { set_error("dagl_ce_core_wide_forward: workspace %zu B < required %zu B", ws_bytes, need); return DAGL_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* stats = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + need - 256);
+    const bool heads = mode != DAGL_MODE_TOPK;
+    int rc = launch_dense_train_forward(s, B, g, wq_rows, x_rows, b2, heads ? thr : nullptr, heads ? bias : nullptr, out, nullptr, nullptr,
+                                        workspace, need - 256, info ? stats : nullptr, mode, k);
+    if (rc) return rc;
+    if (info) {
+        int64_t hs[2] = {0, 0};
+        if ((rc = read_back(s, stats, 2, hs))) return rc;
+        info->total_edges = hs[0]; info->max_degree = (int32_t)hs[1];
+    }
+    return DAGL_OK;
+}
+
+int dagl_ce_core_wide_backward(void* stream, int B, int H, int W, int mode, int k, const float* wq_rows, const float* x_rows,
+                               const float* b2, const float* thr, const float* bias, const float* d_out, float* d_wq_rows,
+                               float* d_x_rows, float* d_b2, float* d_thr, float* d_bias, void* workspace, size_t ws_bytes) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && wq_rows && x_rows && b2 && d_out && d_wq_rows && d_x_rows && d_b2 && k >= 1 &&
+                 (mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK), "dagl_ce_core_wide_backward: bad argument");
+    DAGL_REQUIRE(mode == DAGL_MODE_TOPK || (thr && bias && d_thr && d_bias),
+                 "dagl_ce_core_wide_backward: the intersection mode needs thr, bias and their gradients");
+    DAGL_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0, "dagl_ce_core_wide_backward: workspace must be 256-byte aligned");
+    const Grid g = make_grid(H, W);
+    if (k > g.N) k = g.N;
+    const bool heads = mode != DAGL_MODE_TOPK;
+    return launch_dense_train_backward((hipStream_t)stream, B, g, wq_rows, x_rows, b2, heads ? thr : nullptr, heads ? bias : nullptr, nullptr,
+                                       nullptr, d_out, d_wq_rows, d_x_rows, d_b2, heads ? d_thr : nullptr, heads ? d_bias : nullptr,
+                                       workspace, ws_bytes, true, mode, k);
+}
+
 size_t dagl_gemm_f32_scratch_floats(int batch, int M, int N, int K) {
     if (batch != 1 || M < 1 || N < 1 || K < 1) return 0;
     const int sl = gemm32_auto_slices(M, N, K);

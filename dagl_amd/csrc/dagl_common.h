@@ -613,11 +613,14 @@ int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float*
 size_t dense_train_workspace_bytes(int B, const Grid& g, bool backward);
 int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                const float* thr, const float* bias, float* out, float* lse /*[B,L,2]*/, float* mu /*[B,L]*/,
-                               void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */);
+                               void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */,
+                               int mode = DAGL_MODE_ADAPTIVE, int k = 0 /* the wide top-k modes: DAGL_MODE_TOPK (thr / bias null) / _ADAPTIVE_TOPK;
+                                                                          lse / mu may be null (kept in the workspace) */);
 int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                 const float* thr, const float* bias, const float* lse, const float* mu, const float* dout,
                                 float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes,
-                                bool fp32_products = false);     // false: the five products on the fp16 matrix cores, split operands (one-chunk shapes)
+                                bool fp32_products = false,      // false: the five products on the fp16 matrix cores, split operands (one-chunk shapes)
+                                int mode = DAGL_MODE_ADAPTIVE, int k = 0);
 int launch_colsum_rows(hipStream_t s, int B, int N, const float* rows, double* colsum);              // per-lane list length used for a requested k (4/8/16/32)
 
 }  // namespace dagl

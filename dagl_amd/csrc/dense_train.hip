@@ -16,6 +16,7 @@
 // inference paths never do); d V is folded back onto the 16-channel map by a gather (49 taps per pixel, no atomics).
 // All sums run in a fixed order: bit-reproducible gradients.
 #include "dagl_common.h"
+#include "wide_select.h"
 
 namespace dagl {
 
@@ -24,7 +25,7 @@ constexpr size_t DT_CHUNK_FLOATS = (size_t)128 << 20;      // floats per [chunk,
 struct DtPlan {
     int Lc, n_chunks, Bc;            // queries per chunk, chunks per image, images per group
     long long ldn;                   // leading dimension of the [L,N] chunk matrices (N rounded up to 32)
-    size_t o_sbuf, o_abuf, o_vrows, o_dvrows, o_dagg, o_agg, o_b2p, o_colsum, o_mt, o_dmu, o_dxbar, o_deg, o_rowsum, o_end;
+    size_t o_sbuf, o_abuf, o_vrows, o_dvrows, o_dagg, o_agg, o_b2p, o_colsum, o_mt, o_dmu, o_dxbar, o_deg, o_rowsum, o_sel, o_lse, o_mu, o_end;
     // split-fp16 backward (one chunk per image group only): hi / lo operand copies, each `..._h` halfs long (lo follows hi)
     bool h16;
     int Lp, kslices;                 // L rounded up to 32; split-K of d Wq
@@ -68,6 +69,9 @@ static DtPlan dt_plan(int B, const Grid& g, bool backward) {
     p.o_dxbar = carve((size_t)B * D * sizeof(float));
     p.o_deg = carve((size_t)B * g.L * sizeof(int32_t));
     p.o_rowsum = carve((size_t)B * g.L * sizeof(float));
+    p.o_sel = carve((size_t)B * g.L * 2 * sizeof(int32_t));      // wide top-k modes: (sort key of the k-th best score, last key index taken at it)
+    p.o_lse = carve((size_t)B * g.L * 2 * sizeof(float));        // (their entry points keep the softmax statistics and the row means here)
+    p.o_mu = carve((size_t)B * g.L * sizeof(float));
     p.h16 = backward && p.n_chunks == 1;
     p.Lp = (g.L + 31) / 32 * 32;
     p.kslices = 1;
@@ -135,28 +139,82 @@ __device__ __forceinline__ float dt_block_max(float v, float* sh) {
     return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
-__device__ __forceinline__ float dt_logit(float s, float mtq, float bsq, bool& pass, float& m) {
+// MODE 0: the adaptive mask (dagl.py:256-261).  MODE 1: the k best scores of the row, a 0/1 mask: logits 10 S on them
+// (GReccR2b_3mh_1-checkpoint.py:242-250).  MODE 2: both tests, m = relu(S - mean thr + bias) on the k best of the keys that pass.
+// (T, jt) = sort key of the k-th best score and the last key index taken AT that key (ties go to the lower index): dt_select_kernel.
+template <int MODE>
+__device__ __forceinline__ float dt_logit(float s, int j, float mtq, float bsq, unsigned T, int jt, bool& pass, float& m) {
+    if (MODE == 1) {
+        const unsigned key = wide_key(s, false, 0.f, 0.f);
+        pass = key > T || (key == T && j <= jt);
+        m = 1.f;
+        return pass ? __fmul_rn(s, SOFTMAX_SCALE) : 0.f;
+    }
     m = (s - mtq) + bsq;                               // expression order of dagl.py:256
     pass = m > 0.f;
+    if (MODE == 2) {
+        const unsigned key = pass ? __float_as_uint(fmaxf(s, 0.f)) + 1u : 0u;
+        pass = key != 0u && (key > T || (key == T && j <= jt));
+    }
     return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;       // (S m) 10, dagl.py:259-260
 }
 
+// wide top-k modes: one block per query row of the chunk -> sel[ql] = (T, jt)
+template <bool ADAPTIVE>
+__global__ __launch_bounds__(256) void dt_select_kernel(int N, long long ldn, int L, int l0, int Lc, int k, const float* __restrict__ sbuf,
+                                                        const float* __restrict__ mt, const float* __restrict__ bs,
+                                                        int32_t* __restrict__ sel, int b0) {
+    __shared__ WideSelShared shs;
+    __shared__ int sh_cnt[4];
+    __shared__ int sh_jt;
+    const int lr = blockIdx.x, bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
+    const float* row = sbuf + ((size_t)bi * Lc + lr) * ldn;
+    const float mtq = ADAPTIVE ? mt[ql] : 0.f, bsq = ADAPTIVE ? bs[ql] : 0.f;
+    unsigned T, need, bin_count;
+    wide_radix_select(row, N, k, ADAPTIVE, mtq, bsq, shs, T, need, bin_count);
+    int jt = 0x7fffffff;
+    if (need < bin_count) {                                        // block-uniform: a tie at the k-th place, the `need` lowest key indices win
+        int run = 0;
+        for (int j0 = 0; j0 < N; j0 += 256) {
+            const int j = j0 + tid;
+            const bool eq = j < N && wide_key(row[j], ADAPTIVE, mtq, bsq) == T;
+            const unsigned long long eqb = __ballot(eq);
+            if (lane == 0) sh_cnt[w] = __popcll(eqb);
+            __syncthreads();
+            int before = run;
+            for (int u = 0; u < w; ++u) before += sh_cnt[u];
+            const int rank = before + __popcll(eqb & ((1ull << lane) - 1ull));
+            if (eq && rank == (int)need - 1) sh_jt = j;
+            run += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+            __syncthreads();
+            if (run >= (int)need) break;
+        }
+        jt = sh_jt;
+    }
+    if (tid == 0) { sel[2 * ql] = (int32_t)T; sel[2 * ql + 1] = jt; }
+}
+
 // one block per query row: S row -> A row in place (dagl.py:256-261); saves the softmax shift and denominator
+template <int MODE>
 __global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(int N, long long ldn, int L, int l0, int Lc,
                                                                 float* __restrict__ sbuf, const float* __restrict__ mt,
                                                                 const float* __restrict__ bs, float* __restrict__ lse,
-                                                                int32_t* __restrict__ deg, float* __restrict__ rowsum, int b0) {
+                                                                int32_t* __restrict__ deg, float* __restrict__ rowsum, int b0,
+                                                                const int32_t* __restrict__ sel) {
     __shared__ double shd[4];
     __shared__ float shf[4];
     const int lr = blockIdx.x, bi = blockIdx.y;
     const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
     float* row = sbuf + ((size_t)bi * Lc + lr) * ldn;
-    const float mtq = mt[ql], bsq = bs[ql];
+    const float mtq = MODE == 1 ? 0.f : mt[ql], bsq = MODE == 1 ? 0.f : bs[ql];
+    const unsigned T = MODE == 0 ? 0u : (unsigned)sel[2 * ql];
+    const int jt = MODE == 0 ? 0 : sel[2 * ql + 1];
     float mx = 0.f;                                    // masked keys have logit 0 (N > deg) -- and if all pass, max >= ... handled below
     int cnt = 0;
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(row[j], j, mtq, bsq, T, jt, pass, m);
         cnt += pass ? 1 : 0;
         mx = pass ? fmaxf(mx, l) : mx;
     }
@@ -165,7 +223,7 @@ __global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(int N, long long
     double z = 0.0;
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(row[j], j, mtq, bsq, T, jt, pass, m);
         z += (double)expf(l - M);
     }
     const double Z = dt_block_sum(z, shd);
@@ -173,7 +231,7 @@ __global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(int N, long long
     double rs = 0.0;
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(row[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(row[j], j, mtq, bsq, T, jt, pass, m);
         const float a = pass ? expf(l - M) * invz : 0.f;
         row[j] = a;
         rs += (double)a;
@@ -188,20 +246,23 @@ __global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(int N, long long
 }
 
 // one block per query row: sbuf = recomputed S row, abuf = d A row  ->  sbuf = d S row, abuf = A row
+template <int MODE>
 __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long ldn, int L, int l0, int Lc,
                                                                 float* __restrict__ sbuf, float* __restrict__ abuf,
                                                                 const float* __restrict__ mt, const float* __restrict__ bs,
                                                                 const float* __restrict__ lse, const float* __restrict__ mu,
                                                                 const float* __restrict__ thr, float* __restrict__ dthr,
                                                                 float* __restrict__ dbias, float* __restrict__ dmu, int b0,
-                                                                unsigned* __restrict__ ds_word) {
+                                                                unsigned* __restrict__ ds_word, const int32_t* __restrict__ sel) {
     __shared__ double shd[4];
     const int lr = blockIdx.x, bi = blockIdx.y;
     const size_t ql = (size_t)(b0 + bi) * L + l0 + lr;
     float* srow = sbuf + ((size_t)bi * Lc + lr) * ldn;
     float* arow = abuf + ((size_t)bi * Lc + lr) * ldn;
     float ds_max = 0.f;
-    const float mtq = mt[ql], bsq = bs[ql];
+    const float mtq = MODE == 1 ? 0.f : mt[ql], bsq = MODE == 1 ? 0.f : bs[ql];
+    const unsigned T = MODE == 0 ? 0u : (unsigned)sel[2 * ql];
+    const int jt = MODE == 0 ? 0 : sel[2 * ql + 1];
     // The softmax's shift and denominator are formed HERE, from the recomputed scores -- not taken from the forward: the
     // forward may have run on the streamed split-fp16 kernel, whose scores differ from these in the last bits; logits of
     // several hundred turn that into ~1e-3 of every weight of the row, and the head biases' gradients (sums over all
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
 #pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(srow[j], j, mtq, bsq, T, jt, pass, m);
         mx = pass ? fmaxf(mx, l) : mx;
     }
     const float M = dt_block_max(mx, shf);
@@ -220,7 +281,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
 #pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(srow[j], j, mtq, bsq, T, jt, pass, m);
         zz += (double)expf(l - M);
     }
     const float invz = (float)(1.0 / dt_block_sum(zz, shd));
@@ -228,7 +289,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
 #pragma unroll 16
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
-        const float l = dt_logit(srow[j], mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(srow[j], j, mtq, bsq, T, jt, pass, m);
         const float a = pass ? expf(l - M) * invz : 0.f;
         c += (double)a * (double)arow[j];
     }
@@ -238,10 +299,11 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
     for (int j = threadIdx.x; j < N; j += 256) {
         bool pass; float m;
         const float s = srow[j];
-        const float l = dt_logit(s, mtq, bsq, pass, m);
+        const float l = dt_logit<MODE>(s, j, mtq, bsq, T, jt, pass, m);
         const float a = pass ? expf(l - M) * invz : 0.f;
         const float dl = a * (arow[j] - cf);           // non-neighbours: A = 0 and their logit is the constant 0
-        const float ds = SOFTMAX_SCALE * (m + s) * dl; // d S  (a = 0 -> 0)
+        const float ds = MODE == 1 ? SOFTMAX_SCALE * dl          // the 0/1 mask is a constant: d (10 S) / d S
+                                   : SOFTMAX_SCALE * (m + s) * dl; // d S  (a = 0 -> 0)
         srow[j] = ds;
         ds_max = fmaxf(ds_max, fabsf(ds));
         arow[j] = a;
@@ -254,7 +316,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
         for (int o = 32; o > 0; o >>= 1) ds_max = fmaxf(ds_max, __shfl_xor(ds_max, o));
         if ((threadIdx.x & 63) == 0 && ds_max > 0.f && ds_max < __builtin_inff()) atomicMax(ds_word, __float_as_uint(ds_max));
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && MODE != 1) {
         dbias[ql] = S;
         dthr[ql] = -mu[ql] * S;
         dmu[ql] = -thr[ql] * S;
@@ -267,10 +329,24 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(int N, long long
 // flight but one block per CU, whose load / reduce / store phases do not overlap with anything: ~26 us per row and CU either way.)
 static int launch_dense_softmax_bwd(hipStream_t s, int rows, int nb, int N, long long ldn, int L, int l0, int Lc, float* sbuf, float* abuf,
                                     const float* mt, const float* bs, const float* lse, const float* mu, const float* thr, float* dthr,
-                                    float* dbias, float* dmu, int b0, unsigned* ds_word) {
-    hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(rows, nb), dim3(256), 0, s, N, ldn, L, l0, Lc, sbuf, abuf, mt, bs, lse, mu, thr, dthr,
-                       dbias, dmu, b0, ds_word);
+                                    float* dbias, float* dmu, int b0, unsigned* ds_word, int mode = DAGL_MODE_ADAPTIVE,
+                                    const int32_t* sel = nullptr) {
+#define DT_BWD(M_) hipLaunchKernelGGL(dense_softmax_bwd_kernel<M_>, dim3(rows, nb), dim3(256), 0, s, N, ldn, L, l0, Lc, sbuf, abuf, mt, bs, lse, \
+                                      mu, thr, dthr, dbias, dmu, b0, ds_word, sel)
+    if (mode == DAGL_MODE_TOPK) DT_BWD(1); else if (mode == DAGL_MODE_ADAPTIVE_TOPK) DT_BWD(2); else DT_BWD(0);
+#undef DT_BWD
     DAGL_LAUNCH_CHECK("dense_softmax_bwd_kernel");
+    return DAGL_OK;
+}
+
+// wide top-k modes: the rows' (T, jt) from the chunk's scores
+static int launch_dt_select(hipStream_t s, int rows, int nb, int N, long long ldn, int L, int l0, int Lc, int k, int mode, const float* sbuf,
+                            const float* mt, const float* bs, int32_t* sel, int b0) {
+    if (mode == DAGL_MODE_ADAPTIVE_TOPK)
+        hipLaunchKernelGGL(dt_select_kernel<true>, dim3(rows, nb), dim3(256), 0, s, N, ldn, L, l0, Lc, k, sbuf, mt, bs, sel, b0);
+    else
+        hipLaunchKernelGGL(dt_select_kernel<false>, dim3(rows, nb), dim3(256), 0, s, N, ldn, L, l0, Lc, k, sbuf, mt, bs, sel, b0);
+    DAGL_LAUNCH_CHECK("dt_select_kernel");
     return DAGL_OK;
 }
 
@@ -331,6 +407,7 @@ static int dt_prepare(hipStream_t s, int B, const Grid& g, const DtPlan& p, void
                       const float* b2, const float* thr, float* mu) {
     int rc;
     if ((rc = launch_pad_nhwc(s, B, g.H, g.W, b2, dt_at<float>(ws, p.o_b2p)))) return rc;
+    if (thr == nullptr) return DAGL_OK;                  // (the fixed-k mode has no threshold heads)
     if ((rc = launch_colsum_rows(s, B, g.N, x_rows, dt_at<double>(ws, p.o_colsum)))) return rc;
     hipLaunchKernelGGL(dt_thresholds_kernel, dim3((g.L + 3) / 4, B), dim3(256), 0, s, g.L, g.N, wq_rows,
                        dt_at<double>(ws, p.o_colsum), thr, dt_at<float>(ws, p.o_mt), mu);
@@ -340,8 +417,11 @@ static int dt_prepare(hipStream_t s, int B, const Grid& g, const DtPlan& p, void
 
 int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                const float* thr, const float* bias, float* out, float* lse, float* mu, void* ws, size_t ws_bytes,
-                               int64_t* stats_dev) {
+                               int64_t* stats_dev, int mode, int k) {
     const DtPlan p = dt_plan(B, g, false);
+    if (lse == nullptr) lse = dt_at<float>(ws, p.o_lse);
+    if (mu == nullptr) mu = dt_at<float>(ws, p.o_mu);
+    int32_t* sel = dt_at<int32_t>(ws, p.o_sel);
     if (ws_bytes < p.o_end) { set_error("dense forward: workspace %zu B < required %zu B", ws_bytes, p.o_end); return DAGL_ERR_WORKSPACE; }
     int rc;
     if ((rc = dt_prepare(s, B, g, p, ws, wq_rows, x_rows, b2, thr, mu))) return rc;
@@ -361,8 +441,12 @@ int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float*
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 1,
                                                x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1,
                                                sbuf, p.ldn, (long long)p.Lc * p.ldn, 0.f)))) return rc;
-            hipLaunchKernelGGL(dense_softmax_fwd_kernel, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, mt, bias,
-                               lse, deg, rowsum, b0);
+            if (mode != DAGL_MODE_ADAPTIVE)
+                if ((rc = launch_dt_select(s, lc, nb, g.N, p.ldn, g.L, l0, p.Lc, k, mode, sbuf, mt, bias, sel, b0))) return rc;
+#define DT_FWD(M_) hipLaunchKernelGGL(dense_softmax_fwd_kernel<M_>, dim3(lc, nb), dim3(256), 0, s, g.N, p.ldn, g.L, l0, p.Lc, sbuf, mt, bias, \
+                                      lse, deg, rowsum, b0, sel)
+            if (mode == DAGL_MODE_TOPK) DT_FWD(1); else if (mode == DAGL_MODE_ADAPTIVE_TOPK) DT_FWD(2); else DT_FWD(0);
+#undef DT_FWD
             DAGL_LAUNCH_CHECK("dense_softmax_fwd_kernel");
             // agg = A V
             if ((rc = launch_gemm32(s, dt_gemm(lc, P, g.N, nb, sbuf, p.ldn, (long long)p.Lc * p.ldn, 1,
@@ -558,9 +642,12 @@ static int dt_backward_group16(hipStream_t s, const Grid& g, const DtPlan& p, vo
 int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                 const float* thr, const float* bias, const float* lse, const float* mu_saved, const float* dout,
                                 float* dwq_rows, float* dx_rows, float* db2, float* dthr, float* dbias, void* ws, size_t ws_bytes,
-                                bool fp32_products) {
+                                bool fp32_products, int mode, int k) {
     const DtPlan p = dt_plan(B, g, true);
-    const bool h16 = p.h16 && !fp32_products;
+    // the wide top-k modes re-select from the recomputed scores: the fp32 product of the forward, bit for bit (a split-fp16 S could
+    // order two near-equal scores the other way round)
+    const bool h16 = p.h16 && !fp32_products && mode == DAGL_MODE_ADAPTIVE;
+    int32_t* sel = dt_at<int32_t>(ws, p.o_sel);
     if (ws_bytes < p.o_end) { set_error("dense backward: workspace %zu B < required %zu B", ws_bytes, p.o_end); return DAGL_ERR_WORKSPACE; }
     int rc;
     float* mu = dt_at<float>(ws, p.o_rowsum);                    // recomputed with the thresholds (same values as the forward's)
@@ -594,8 +681,10 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
                                                abuf, p.ldn, sS, 0.f, true)))) return rc;
             if ((rc = launch_gemm32(s, dt_gemm(lc, g.N, D, nb, wq_c, D, (long long)g.L * D, 1,
                                                x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 1, sbuf, p.ldn, sS, 0.f)))) return rc;
+            if (mode != DAGL_MODE_ADAPTIVE)
+                if ((rc = launch_dt_select(s, lc, nb, g.N, p.ldn, g.L, l0, p.Lc, k, mode, sbuf, mt, bias, sel, b0))) return rc;
             if ((rc = launch_dense_softmax_bwd(s, lc, nb, g.N, p.ldn, g.L, l0, p.Lc, sbuf, abuf, mt, bias, lse, mu, thr, dthr, dbias, dmu, b0,
-                                               nullptr))) return rc;
+                                               nullptr, mode, sel))) return rc;
             // d Wq = d S X
             if ((rc = launch_gemm32(s, dt_gemm(lc, D, g.N, nb, sbuf, p.ldn, sS, 1, x_rows + (size_t)b0 * g.N * D, D, (long long)g.N * D, 0,
                                                dwq_rows + ((size_t)b0 * g.L + l0) * D, D, (long long)g.L * D, 0.f, true)))) return rc;
@@ -614,8 +703,8 @@ int launch_dense_train_backward(hipStream_t s, int B, const Grid& g, const float
             DAGL_LAUNCH_CHECK("dt_fold_dv_kernel");
         }
     }
-    // dense mean term: d Wq_l += d mu_l Xbar ;  d X_j += (sum_l d mu_l Wq_l) / N
-    {
+    // dense mean term: d Wq_l += d mu_l Xbar ;  d X_j += (sum_l d mu_l Wq_l) / N   (the fixed-k mode has no threshold)
+    if (mode != DAGL_MODE_TOPK) {
         const size_t nq = (size_t)B * g.L * D, nk = (size_t)B * g.N * D;
         hipLaunchKernelGGL(dt_rank1_add_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (size_t)B * g.L, g.L, dmu, nullptr,
                            colsum, DS, 1.0f / (float)g.N, dwq_rows);

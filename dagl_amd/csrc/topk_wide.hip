@@ -7,19 +7,16 @@
 //   attend   mask = the k best (AND the adaptive test in the intersection mode), softmax over all N keys (masked keys count e^0),
 //            weighted sum of the value patches, in 32 key chunks with softmax statistics of their own
 //   combine  the chunks -> the query's aggregated row, degree, softmax mass
-// and the fold over everything at the end.  Inference only (the differentiable path keeps lists of <= DAGL_MAX_TOPK entries).
+// and the fold over everything at the end.  Inference; the differentiable path of these modes is the dense formulation of
+// dense_train.hip with the same selection (wide_select.h) as its mask.
 #include <string.h>
 
 #include "dagl_common.h"
 #include "row_attend.h"
+#include "wide_select.h"
 
 namespace dagl {
 
-// sort key of a score: 0 = "not a candidate" (fails the adaptive test of the intersection mode), else bits + 1
-__device__ __forceinline__ unsigned wide_key(float s, bool adaptive, float mtq, float bsq) {
-    if (adaptive && !(((s - mtq) + bsq) > 0.f)) return 0u;
-    return __float_as_uint(fmaxf(s, 0.f)) + 1u;
-}
 __device__ __forceinline__ float wide_logit(float s, bool adaptive, float mtq, float bsq) {
     // top-k: softmax(10 S mask), mask in {0, 1} (GReccR2b_3mh_1-checkpoint.py:248-250); intersection: 10 S m, m = relu(S - mt + bs)
     return adaptive ? __fmul_rn(__fmul_rn(s, (s - mtq) + bsq), SOFTMAX_SCALE) : __fmul_rn(s, SOFTMAX_SCALE);
@@ -30,8 +27,7 @@ constexpr int WIDE_RANGES = ROW_CHUNKS * 4;          // (chunk, wave) key ranges
 // block = one row.  sel[slot] = {threshold key T, keys to take with key == T (0x7fffffff: all of them), -, -};
 // eq_before[slot][r] = keys == T in the (chunk, wave) ranges before range r (only when not all are taken)
 __global__ __launch_bounds__(256) void wide_select_kernel(WideArgs a) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_remaining, sh_bin_count;
+    __shared__ WideSelShared shs;
     __shared__ int sh_eq[WIDE_RANGES];
     const int slot = blockIdx.x, tid = threadIdx.x;
     const size_t ql = (size_t)a.b * a.g.L + a.r0 + slot;
@@ -39,46 +35,8 @@ __global__ __launch_bounds__(256) void wide_select_kernel(WideArgs a) {
     const bool adaptive = a.mode == DAGL_MODE_ADAPTIVE_TOPK;
     const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
     const int N = a.g.N;
-    if (tid == 0) { sh_prefix = 0u; sh_remaining = (unsigned)a.k; }
-    unsigned bin_count = 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[tid] = 0u;
-        __syncthreads();
-        const unsigned prefix = sh_prefix;
-        // (the high digit -- sign and seven exponent bits -- is the same for nearly every score of a row: 64 lanes adding to one LDS
-        // word serialise, 65 536 times.  There the wave counts its lanes per distinct digit first: one add per digit.  For the second
-        // digit, with ~100 distinct values per wave, that loop was 3.6x SLOWER than the plain adds.)
-        for (int j0 = 0; j0 < N; j0 += 256) {
-            const int j = j0 + tid;
-            unsigned key = 0u; bool act = false;
-            if (j < N) { key = wide_key(row[j], adaptive, mtq, bsq); act = pass == 0 || (key >> (shift + 8)) == prefix; }
-            const unsigned bin = (key >> shift) & 255u;
-            if (pass == 0) {
-                unsigned long long todo = __ballot(act);
-                while (todo) {                                                  // wave-uniform loop: one round per distinct digit
-                    const int first = __ffsll((long long)todo) - 1;
-                    const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, first);
-                    const unsigned long long same = __ballot(act && bin == b0);
-                    if ((tid & 63) == first) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-                    todo &= ~same;
-                }
-            } else if (act) atomicAdd(&hist[bin], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned rem = sh_remaining, cum = 0; int bin = 0;
-            for (int bq = 255; bq >= 0; --bq) {
-                if (cum + hist[bq] >= rem) { bin = bq; break; }
-                cum += hist[bq];
-            }
-            // (fewer than k keys in all: bin 0 is reached with cum + hist[0] = N >= rem, k <= N by construction)
-            sh_remaining = rem - cum; sh_prefix = (prefix << 8) | (unsigned)bin; sh_bin_count = hist[bin];
-        }
-        __syncthreads();
-        bin_count = sh_bin_count;
-    }
-    const unsigned T = sh_prefix, need = sh_remaining;            // `need` of the `bin_count` keys equal to T are taken
+    unsigned T, need, bin_count;
+    wide_radix_select(row, N, a.k, adaptive, mtq, bsq, shs, T, need, bin_count);    // `need` of the `bin_count` keys equal to T are taken
     const bool all = need >= bin_count;
     if (tid == 0) {
         int32_t* o = a.sel + (size_t)slot * 4;

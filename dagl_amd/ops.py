@@ -638,3 +638,58 @@ def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, w
                                           d_out.data_ptr(), d_wq.data_ptr(), d_x.data_ptr(), d_b2.data_ptr(),
                                           d_thr.data_ptr(), d_bias.data_ptr(), a, nbytes), "dagl_ce_core_dense_backward")
     return d_wq, d_x, d_b2, d_thr, d_bias
+
+
+@_on_device
+def ce_core_wide_forward(wq_rows, x_rows, b2, thr, bias, mode: str, k: int, workspace: "Workspace | None" = None,
+                         want_info: bool = False):
+    """Graph core of the top-k modes whose neighbourhoods exceed the lists (min(k, N) > MAX_TOPK) under autograd
+    (``dagl_ce_core_wide_forward``): the dense formulation with the row-wise selection of the k best scores as its mask
+    (GReccR2b_3mh_1-checkpoint.py:242-250; CA_model-checkpoint.py:134-143 takes 500) -> (out [B,16,H,W], info | None).
+    ``thr`` / ``bias`` are None in mode "topk"."""
+    lib = _lib.load()
+    if mode not in ("topk", "adaptive_topk"):
+        raise DaglError(f"ce_core_wide_forward: mode {mode!r}: expected 'topk' or 'adaptive_topk'")
+    for n, t in (("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2)) + ((("thr", thr), ("bias", bias)) if mode != "topk" else ()):
+        _need(t, n)
+    B, c, H, W = b2.shape
+    Lh, Lw = query_grid(H, W)
+    L, N = Lh * Lw, H * W
+    if c != 16 or tuple(wq_rows.shape) != (B, L, 196) or tuple(x_rows.shape) != (B, N, 196):
+        raise DaglError("ce_core_wide_forward: expected wq_rows [B,L,196], x_rows [B,H*W,196], b2 [B,16,H,W]")
+    need = lib.dagl_ce_core_dense_workspace_bytes(B, H, W, 0) + 256
+    ws = workspace if workspace is not None else Workspace()
+    out = torch.empty(B, 16, H, W, device=b2.device, dtype=torch.float32)
+    info = _lib.CeInfo()
+    a, nbytes = _aligned(ws.get(need, b2.device))
+    heads = mode != "topk"
+    check(lib.dagl_ce_core_wide_forward(_stream(), B, H, W, MODES[mode], int(k), wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+                                        thr.data_ptr() if heads else None, bias.data_ptr() if heads else None, out.data_ptr(),
+                                        a, nbytes, C.byref(info) if want_info else None), "dagl_ce_core_wide_forward")
+    meta = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=5, redone_queries=-1,
+                range_fallback=0) if want_info else None
+    return out, meta
+
+
+@_on_device
+def ce_core_wide_backward(d_out, wq_rows, x_rows, b2, thr, bias, mode: str, k: int, workspace: "Workspace | None" = None):
+    """Gradients of ``ce_core_wide_forward`` (``dagl_ce_core_wide_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias);
+    the last two are None in mode "topk" (a 0/1 mask has no threshold heads)."""
+    lib = _lib.load()
+    for n, t in (("d_out", d_out), ("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2)):
+        _need(t, n)
+    B, _, H, W = b2.shape
+    need = lib.dagl_ce_core_dense_workspace_bytes(B, H, W, 1)
+    ws = workspace if workspace is not None else Workspace()
+    dev = b2.device
+    heads = mode != "topk"
+    d_wq, d_x, d_b2 = torch.empty_like(wq_rows), torch.empty_like(x_rows), torch.empty_like(b2)
+    d_thr = torch.empty(B, wq_rows.shape[1], device=dev, dtype=torch.float32) if heads else None
+    d_bias = torch.empty_like(d_thr) if heads else None
+    a, nbytes = _aligned(ws.get(need, dev))
+    check(lib.dagl_ce_core_wide_backward(_stream(), B, H, W, MODES[mode], int(k), wq_rows.data_ptr(), x_rows.data_ptr(), b2.data_ptr(),
+                                         thr.data_ptr() if heads else None, bias.data_ptr() if heads else None, d_out.data_ptr(),
+                                         d_wq.data_ptr(), d_x.data_ptr(), d_b2.data_ptr(),
+                                         d_thr.data_ptr() if heads else None, d_bias.data_ptr() if heads else None, a, nbytes),
+          "dagl_ce_core_wide_backward")
+    return d_wq, d_x, d_b2, d_thr, d_bias

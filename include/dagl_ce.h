@@ -147,9 +147,9 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
  * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64; round 4: DAGL_FLAG_SAMPLED_TOPK,
- * the workspace layout carries the top-k policy words).  A caller compares
+ * the workspace layout carries the top-k policy words; 403: dagl_ce_core_wide_forward / _backward).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 402
+#define DAGL_ABI_VERSION 403
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
@@ -308,6 +308,23 @@ int    dagl_ce_core_dense_backward(void* stream, int B, int H, int W, int flags,
                                    const float* d_out,
                                    float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias,
                                    void* workspace, size_t ws_bytes);
+
+/* The top-k modes with min(k, N) > DAGL_MAX_TOPK under autograd (the fixed-k variant takes any num_edge: top_k = min(num_edge, N),
+ * GReccR2b_3mh_1-checkpoint.py:242-250; CA_model-checkpoint.py:134-143 uses 500): no lists -- the dense formulation above with
+ * the row-wise selection as its mask: per query the k best scores (ties at the k-th place to the lower key index, as everywhere),
+ * DAGL_MODE_TOPK: logits 10 S on them, a 0/1 mask (thr / bias and their gradients may be NULL); DAGL_MODE_ADAPTIVE_TOPK: the k best of
+ * the keys that pass the adaptive test, m = relu(S - mean thr + bias).  Matrix products on the fp32 matrix cores (the backward
+ * re-selects from the recomputed scores, which are the forward's bit for bit).  Workspace: dagl_ce_core_dense_workspace_bytes.
+ * info (may be NULL; non-NULL costs one host synchronisation): path 5, total_edges, max_degree.                                    */
+int    dagl_ce_core_wide_forward(void* stream, int B, int H, int W, int mode, int k,
+                                 const float* wq_rows, const float* x_rows, const float* b2,
+                                 const float* thr, const float* bias, float* out,
+                                 void* workspace, size_t ws_bytes, dagl_ce_info* info);
+int    dagl_ce_core_wide_backward(void* stream, int B, int H, int W, int mode, int k,
+                                  const float* wq_rows, const float* x_rows, const float* b2,
+                                  const float* thr, const float* bias, const float* d_out,
+                                  float* d_wq_rows, float* d_x_rows, float* d_b2, float* d_thr, float* d_bias,
+                                  void* workspace, size_t ws_bytes);
 
 /* ---- stages (each callable on its own: unit parity tests and the benchmark use them) --------- */
 

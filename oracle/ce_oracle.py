@@ -132,6 +132,13 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     return out
 
 
+def _k_best(S: torch.Tensor, kk: int) -> torch.Tensor:
+    """Indices of each row's kk largest scores (``torch.topk(S, kk, dim=1)``, GReccR2b_3mh_1-checkpoint.py:243-244).  torch.topk
+    leaves the choice among EQUAL scores at the kk-th place unspecified; the oracle pins it -- the lower key index wins (a stable
+    descending sort) -- so that outputs AND gradients are defined on degenerate maps; without such ties it is torch.topk's set."""
+    return torch.sort(S, dim=1, descending=True, stable=True).indices[:, :kk]
+
+
 def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax_scale=SOFTMAX_SCALE):
     """One sample of dagl.py:250-267 from its feature rows: similarity, mask, edge softmax, aggregate, fold
     (not yet divided by the overlap count).  Returns (folded [1,c,H,W], dict of intermediates)."""
@@ -141,7 +148,7 @@ def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax
     if mode == "topk":
         kk = min(k, S.shape[1])
         sel = torch.zeros_like(S)
-        sel.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
+        sel.scatter_(1, _k_best(S, kk), 1.0)
         m, mb = sel, sel
     else:
         m = F.relu(S - S.mean(dim=1, keepdim=True) * thr_n.unsqueeze(1)
@@ -150,7 +157,7 @@ def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax
         if mode == "adaptive_topk":
             kk = min(k, S.shape[1])
             keep = torch.zeros_like(S)
-            keep.scatter_(1, S.topk(kk, dim=1).indices, 1.0)
+            keep.scatter_(1, _k_best(S, kk), 1.0)
             m, mb = m * keep, mb * keep
     A = F.softmax(S * m * softmax_scale, dim=1) * mb                           # :259-261 (self.softmax_scale, 10 unless the ctor says otherwise: :175)
     agg = A @ v_rows_n                                                         # [L,784] :263-264

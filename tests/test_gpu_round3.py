@@ -150,9 +150,9 @@ def _run_debug(ce, x):
                               ce.fc2[0].bias, mode=ce.select_mode, k=ce.select_k, debug=True)
 
 
-def test_num_edge_beyond_the_list_width_is_served_row_wise_and_raises_under_autograd():
+def test_num_edge_beyond_the_list_width_is_served_row_wise_and_trains():
     """k > DAGL_MAX_TOPK: nothing is clamped -- the inference kernels take every query's score row in the dense form
-    (csrc/topk_wide.hip), the differentiable path (per-query lists) says so and raises."""
+    (csrc/topk_wide.hip), the differentiable path the dense formulation with that selection as its mask (tests/test_gpu_wide_train.py)."""
     from dagl_amd._lib import MAX_TOPK, DaglError
     from dagl_amd.ce import CE
     assert MAX_TOPK == 64
@@ -170,8 +170,10 @@ def test_num_edge_beyond_the_list_width_is_served_row_wise_and_raises_under_auto
         assert ce(x).shape == (1, 16, 32, 32)
     ce.select_k = 500
     ce.train()
-    with pytest.raises(DaglError, match="under autograd"):
-        ce(x.requires_grad_(True))
+    xg = x.clone().requires_grad_(True)
+    out = ce(xg)
+    out.sum().backward()
+    assert ce.last_info["max_degree"] == 500 and torch.isfinite(xg.grad).all() and ce.fc1[0].weight.grad is not None
 
 
 @pytest.mark.parametrize("k,B,H,W", [(65, 1, 23, 30), (200, 2, 48, 52), (1000, 1, 72, 72), (5000, 1, 40, 44)])
