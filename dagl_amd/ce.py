@@ -179,6 +179,7 @@ class CE(nn.Module):
         self._f32_cache = {}
         self._scaled_cache = {}           # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
         self._train_calls = 0
+        self._wide_calls = 0
         self._last_call = None
         self._calls_since_range_check = 0
         self._train_dense = False      # the differentiable path met dense neighbourhoods last time (dense_train.hip)
@@ -369,7 +370,8 @@ class CE(nn.Module):
         k_eff = min(int(self.select_k), H * W) if self.select_mode != "adaptive" else 0
         if k_eff > MAX_TOPK:
             # more neighbours than the lists hold: the dense formulation with the row-wise selection as its mask
-            want = self._train_calls % 64 == 0          # (statistics cost a host synchronisation: every 64th call)
+            want = self._wide_calls % 64 == 0           # (statistics cost a host synchronisation: every 64th call)
+            self._wide_calls += 1
             out = _GraphCoreWide.apply(wq_rows, x_rows, b2, thr, bias, self.select_mode, k_eff, self._ws, self._ws_bwd,
                                        info if want else None)
         elif self.select_mode == "adaptive" and self._train_dense:
