@@ -16,6 +16,15 @@ static int32_t next_call_tag() {
     return (int32_t)(t ? t : 1u);
 }
 
+// A call captured into a HIP graph carries its tag as a kernel argument: every replay has the SAME tag, and a sticky word that holds
+// it (one replay left the fp16 range / was not served in-stream) would poison every later replay.  The first launch of a captured call
+// therefore turns "this tag" into "some earlier call" -- still non-zero: the poll still reports it -- before the call's own kernels run.
+constexpr int32_t STALE_TAG = 0x7ffffffe;
+__global__ void retag_kernel(int32_t* word, int32_t* veto, int32_t tag) {
+    if (word != nullptr && *word == tag) *word = STALE_TAG;
+    if (veto != nullptr && *veto == tag) *veto = STALE_TAG;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -379,6 +388,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     if (p.split16 || core) {        // (training entry points: the streamed dense core splits the features into fp16 halves too, and
                                     //  non-finite feature rows -- a poisoned projection upstream -- must not vanish in the selection)
         rt.word = reinterpret_cast<int32_t*>(stats + 4); rt.done = reinterpret_cast<int32_t*>(stats + 5); rt.tag = next_call_tag();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusActive) {
+            hipLaunchKernelGGL(retag_kernel, dim3(1), dim3(1), 0, s, rt.word,
+                               mode == DAGL_MODE_ADAPTIVE ? reinterpret_cast<int32_t*>(stats + 8) : nullptr, rt.tag);
+            DAGL_LAUNCH_CHECK("retag_kernel");
+        }
     }
 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------

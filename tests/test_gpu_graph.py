@@ -120,3 +120,42 @@ def test_unserved_no_wait_call_is_nan_filled_and_reported():
     assert ce.last_info["path"] == 4
     want = ce_forward_oracle(x_dense, params, mode="adaptive", dtype=torch.float64).float()
     assert normwise(out.numpy(), want.numpy()) <= 1e-4
+
+
+def test_one_out_of_range_replay_does_not_poison_the_later_ones():
+    """A captured call carries its range-guard tag as a kernel argument: every replay has the same one.  A replay that leaves the
+    split-fp16 range (|activation| >= 3750) is NaN-filled and leaves the tag in the sticky word; before round 4's last fix every LATER
+    replay found its own tag there and was NaN-filled too.  Now the first launch of a captured call re-labels the word ("an earlier
+    call", still non-zero): the next replay is served, the poll still reports the violation."""
+    import warnings
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params, make_features
+    dev = torch.device("cuda:0")
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(75, variant="default").items()}
+    ce = CE(in_channels=64)
+    ce.load_state_dict(params, strict=True)
+    ce.select_mode, ce.select_k = "topk", 8
+    ce = ce.to(dev).eval()
+    good = torch.from_numpy(make_features(75, 2, 64, 48, 48)).to(dev)
+    x_static = good.clone()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                want = ce(x_static).clone()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out_static = ce(x_static)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(out_static, want)
+        x_static.copy_(good * 3.0e4)                         # far outside the range of the split-fp16 kernels
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.isnan(out_static).all()                 # never numbers computed from inf halves
+        x_static.copy_(good)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.equal(out_static, want)                 # (was: NaN from here on)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            assert not ce.range_ok()                         # the sticky report survives the re-labelling
