@@ -1394,8 +1394,19 @@ int refine_heavy_cap() { return RF_HEAVY_CAP; }
 
 __global__ __launch_bounds__(256) void topk_policy_kernel(int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags,
                                                           long long n_queries) {
-    __shared__ int go;
-    if (threadIdx.x == 0) go = (*policy == 0 && stats[2] * 8 > n_queries) ? 1 : 0;
+    // the re-run pays when the redo pass would scan more than a sixteenth of the query GROUPS (a flagged query sends its whole
+    // 128-query group through the fp32 scan; a few hundred flagged queries of a natural-image map are spread over most groups)
+    __shared__ int go, n_groups;
+    if (threadIdx.x == 0) n_groups = 0;
+    __syncthreads();
+    if (*policy == 0 && stats[2] > 0) {
+        int loc = 0;
+        for (int e = threadIdx.x; e < n_flags; e += blockDim.x) loc += redo_flags[e] != 0 ? 1 : 0;
+        if (loc) atomicAdd(&n_groups, loc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) go = (*policy == 0 && (long long)n_groups * 16 > (long long)n_flags) ? 1 : 0;
+    (void)n_queries;
     __syncthreads();
     if (!go) return;
     for (int e = threadIdx.x; e < n_flags; e += blockDim.x) redo_flags[e] = 0;

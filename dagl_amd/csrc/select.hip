@@ -289,9 +289,13 @@ __global__ __launch_bounds__(256, (K > 32) ? 1 : 2) void topk_redo_kernel(Select
     __shared__ __attribute__((aligned(16))) float sK[2][TILE_LDS];      // 52 KiB; the merge's candidate arrays (32 KiB) reuse it
     static_assert(sizeof(float) * 2 * TILE_LDS >= (sizeof(float) + sizeof(int)) * 4 * TOPK_MAX_CAND, "merge arrays fit the scan's tiles");
     if (*a.run_count == 0) return;                                       // nothing flagged anywhere (the usual case)
-    // the workspace's threshold policy (include/dagl_ce.h DAGL_FLAG_TIGHT_TOPK): more than an eighth of the queries flagged under
-    // the sampled threshold -> the tight threshold from the next call on (sticky; this call pays the exact scan once)
-    if (policy != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && *a.run_count * 8 > (long long)a.B * a.L) *policy = 1;
+    // the workspace's threshold policy (include/dagl_ce.h DAGL_FLAG_TIGHT_TOPK): this pass has work under the sampled threshold -> the
+    // tight threshold from the next call on (sticky; this call pays the exact scan of its flagged groups once).  ANY flagged query is
+    // enough: it sends its whole 128-query group through the fp32 scan of all keys (84 us per group at 256^2, 0.3 ms at 512^2) where the
+    // tight threshold costs 25 us per call at 256^2 and nothing on smaller or larger maps.  (Up to round 4's last day the test was "more
+    // than an eighth of the QUERIES": natural-image maps whose few hundred flagged queries are spread over most groups -- two of the
+    // five 512^2 Set12 maps, leaf-tile batches -- stayed on the redo pass for good: 36.7 ms instead of 2.4, 1.1-2.0 instead of 0.64.)
+    if (policy != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *policy = 1;
     bool wrote = false;
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         if (a.run_flags[blockIdx.y * n_qgroups + unit % n_qgroups] == 0) continue;  // block-uniform

@@ -80,11 +80,12 @@ extern "C" {
  * the fp32 redo pass (2.6 ms instead of 0.25 at 256^2, tools/time_real_image.py).  Costs half a pass more of the screen's
  * matrix work (+25 us at 256^2); the result is the same either way.
  * Round 4: WITHOUT either flag the choice is made ON THE DEVICE and kept in the workspace ("policy" word): a call whose sampled
- * threshold let more than an eighth of the queries overflow their candidate slots switches the workspace to the tight threshold
- * for good (the word is sticky; kernels read it at their start: no host poll, valid under HIP-graph replay).  On a cold
- * workspace (no DAGL_FLAG_WEIGHTS_PACKED: the first call of a shape) that call re-runs sampling, filter and refine with the
- * tight threshold in-stream (four gated launches that exit at once otherwise) instead of sending every query group to the fp32
- * redo pass: ~0.4 ms instead of 2.7 at 256^2.  DAGL_FLAG_TIGHT_TOPK forces the tight threshold, DAGL_FLAG_SAMPLED_TOPK the
+ * threshold let ANY query overflow its candidate slots (its whole 128-query group takes the fp32 redo pass: 84 us per group at
+ * 256^2) switches the workspace to the tight threshold for good (the word is sticky; kernels read it at their start: no host
+ * poll, valid under HIP-graph replay).  On a cold workspace (no DAGL_FLAG_WEIGHTS_PACKED: the first call of a shape) a call with
+ * more than a sixteenth of its query GROUPS flagged re-runs sampling, filter and refine with the tight threshold in-stream (four
+ * gated launches that exit at once otherwise) instead of sending those groups to the fp32 redo pass: ~0.4 ms instead of 2.7 at
+ * 256^2.  DAGL_FLAG_TIGHT_TOPK forces the tight threshold, DAGL_FLAG_SAMPLED_TOPK the
  * sampled one (tests, benchmarks of that path); dagl_ce_range_check's bit 2 still reports whether the last call's redo pass
  * had work.                                                                                                                    */
 #define DAGL_FLAG_TIGHT_TOPK     0x1000

@@ -17,14 +17,14 @@ DEV = "cuda:0"
 TOL = 1e-4
 
 
-def real_features(img: str):
+def real_features(img: str, side: int = 256):
     from dagl_amd.net import RR, set12_protocol_noise
     z = np.load(os.path.join(GOLDEN_DIR, "quality_ckpt_fp16.npz"))
     net = RR().eval()
     net.load_state_dict({k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}, strict=True)
     imgs = np.load(os.path.join(GOLDEN_DIR, "set12.npz"))
     clean = torch.from_numpy(imgs[img].astype(np.float32) / 255.0)[None, None]
-    assert clean.shape[-2:] == (256, 256)
+    assert clean.shape[-2:] == (side, side)
     noisy = set12_protocol_noise(clean, 50.0, 1.0)
     net = net.to(DEV)
     with torch.no_grad():
@@ -86,3 +86,26 @@ def test_topk8_on_set12_features_matches_the_oracle_with_both_thresholds(img):
     assert normwise(res["full"].cpu().numpy(), res["sparse"].cpu().numpy()) <= 1e-6
     assert normwise(res["auto"].cpu().numpy(), res["full"].cpu().numpy()) <= 1e-6
     assert normwise(res["full"].cpu().numpy(), outs[True].cpu().numpy()) <= TOL
+
+
+def test_a_few_overflowing_queries_spread_over_most_groups_switch_the_policy():
+    """Set12 img_11 (512 x 512): under the sampled threshold a few hundred of the 16 384 queries overflow their candidate slots -- far
+    fewer than the eighth the policy used to ask for, but spread over most 128-query groups, each of which the redo pass scans against
+    all 262 144 keys in fp32: 36.7 ms per call, for good (profiles/r04_topk_policy_real_features.log).  ANY flagged query now moves the
+    workspace to the tight threshold: the next call has no redo work (2.5 ms), same output as with the threshold forced."""
+    from dagl_amd import ops
+    x, ce = real_features("img_11", side=512)
+    ce.topk_threshold = "auto"
+    ce.reset_topk_policy()
+    with torch.no_grad():
+        for _ in range(3):
+            y = ce(x)
+    shape, dev = ce._last_call
+    bad = ops.ce_range_check(shape, "topk", 8, ce._ws, dev)
+    assert bad & 8, "the policy word must have switched to the tight threshold"
+    assert not bad & 4, "the last call's redo pass still had work"
+    ce.topk_threshold = "full"
+    ce.reset_topk_policy()
+    with torch.no_grad():
+        z = ce(x)
+    assert normwise(y.cpu().numpy(), z.cpu().numpy()) <= 1e-6

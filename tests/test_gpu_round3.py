@@ -453,7 +453,7 @@ def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
     ce = CE(in_channels=64); ce.load_state_dict(params, strict=True); ce = ce.to(dev).eval()
     ce.select_mode, ce.select_k = "topk", 8
     g = torch.Generator().manual_seed(3)
-    x = (0.25 + 1e-2 * torch.randn(1, 64, 64, 64, generator=g)).to(dev)
+    x = (0.25 + 1e-2 * torch.randn(1, 64, 136, 136, generator=g)).to(dev)       # (N > 16 384 keys: smaller maps start tight)
     with torch.no_grad():
         assert ce.topk_threshold == "auto" and not ce.topk_policy_is_tight()
         y0 = ce(x).clone()
@@ -468,5 +468,11 @@ def test_topk_threshold_auto_moves_to_the_full_pass_after_a_redo():
     ce2 = CE(in_channels=64); ce2.load_state_dict(params, strict=True); ce2 = ce2.to(dev).eval()
     ce2.select_mode, ce2.select_k = "topk", 8
     with torch.no_grad():
-        ce2(torch.from_numpy(make_features(5, 1, 64, 64, 64)).to(dev))
+        ce2(torch.from_numpy(make_features(5, 1, 64, 136, 136)).to(dev))
     assert not ce2.topk_policy_is_tight()
+    # ... and maps of up to 16 384 keys start on the tight threshold (it costs nothing there)
+    ce3 = CE(in_channels=64); ce3.load_state_dict(params, strict=True); ce3 = ce3.to(dev).eval()
+    ce3.select_mode, ce3.select_k = "topk", 8
+    with torch.no_grad():
+        ce3(torch.from_numpy(make_features(5, 1, 64, 64, 64)).to(dev))
+    assert ce3.topk_policy_is_tight()
