@@ -117,7 +117,7 @@ struct Plan {
     size_t o_wide = 0;
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
-        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand,
+        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand, o_spill, o_spillcnt,
         o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
@@ -279,6 +279,11 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg_alloc * sizeof(int2));     // candidate records (count in slot 0)
+        p.o_spill = p.o_spillcnt = 0;
+        if (mode != DAGL_MODE_ADAPTIVE) {       // top-k modes: a query's shared area behind its segments (ScreenArgs::spill)
+            p.o_spill = carve(off, BL * SCREEN_SPILL * sizeof(int2));
+            p.o_spillcnt = carve(off, BL * sizeof(unsigned));
+        }
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
@@ -666,6 +671,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample; sc.qblock = p.s_qblock;
         sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand = at<int2>(ws, p.o_scand);
+        if (mode != DAGL_MODE_ADAPTIVE) { sc.spill = at<int2>(ws, p.o_spill); sc.spill_cnt = at<unsigned>(ws, p.o_spillcnt); }
         if (topk_policy) { sc.policy = policy_w; sc.sample_tight = p.s_sample_tight; sc.capseg_tight = p.capseg_tight; }
         redo = at<int32_t>(ws, p.o_redo);
 #ifdef DAGL_ABLATION
@@ -721,7 +727,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         prof_mark(prof, s, 3);
         if (mode != DAGL_MODE_ADAPTIVE) {                       // top-k threshold from the sampling pass
             if ((rc = launch_screen(s, sc, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta)))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta), nullptr, sc.spill_cnt))) return rc;
         }
         if (mode != DAGL_MODE_TOPK && !fused_theta)             // adaptive threshold; the intersection mode takes the larger
             if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta), mode == DAGL_MODE_ADAPTIVE_TOPK))) return rc;
@@ -732,7 +738,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         memset(&ra, 0, sizeof(ra));
         ra.B = B; ra.L = g.L; ra.N = g.N; ra.mode = mode; ra.k = k; ra.splits = p.s_splits; ra.capseg = p.capseg;
         ra.width = p.width; ra.wq = Wq; ra.x = X; ra.rows_q = feat_rows(g.L); ra.rows_x = feat_rows(g.N);
-        ra.mt = mt; ra.bs = bias; ra.cand = sc.cand; ra.theta = sc.theta;
+        ra.mt = mt; ra.bs = bias; ra.cand = sc.cand; ra.theta = sc.theta; ra.spill = sc.spill; ra.spill_cnt = sc.spill_cnt;
         ra.nb_idx = nbidx; ra.nb_wgt = nbwgt; ra.nb_cnt = nbcnt; ra.redo_flags = redo; ra.n_qgroups_exact = n_qgroups;
         ra.stats = stats; ra.nb_s = core ? core->nb_s : nullptr;
         if (p.ovf_cap > 0) {
@@ -750,7 +756,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_topk_policy(s, stats, policy_w, gate_w, redo, (int)(B * n_qgroups), (long long)BL))) return rc;
             ScreenArgs sc2 = sc; sc2.gate = gate_w;
             if ((rc = launch_screen(s, sc2, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc2.gmax, at<float>(ws, p.o_theta), gate_w))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc2.gmax, at<float>(ws, p.o_theta), gate_w, sc2.spill_cnt))) return rc;
             // (the intersection mode takes the larger of the two thresholds: max(adaptive, theta) is idempotent, so the ungated
             // kernel is harmless when the re-run did not run)
             if (mode != DAGL_MODE_TOPK && !fused_theta)

@@ -418,9 +418,15 @@ struct ScreenArgs {
     // sample_tight / capseg_tight instead of sample / capseg; *gate == 0 -> the launch exits at once (the in-call re-run of a
     // cold workspace).  Null pointers: the host's values as they are.
     const int32_t* policy; const int32_t* gate; int sample_tight, capseg_tight;
+    // top-k modes: a segment that is full spills into its QUERY's shared area (one atomic per spilled record -- the rare path): natural
+    // images give a few queries one hot segment (a 128-slot segment asked for 160-200) while the query's total stays in the hundreds;
+    // without the spill such a query sent its whole 128-query group through the fp32 redo pass (k = 50 at 256^2: 7.2 ms a call)
+    int2* spill; unsigned* spill_cnt;       // [B, L, SCREEN_SPILL] records, [B, L] counts (zeroed by screen_theta_kernel); null: none
 };
+constexpr int SCREEN_SPILL = 256;
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
-int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate = nullptr);
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate = nullptr,
+                        unsigned* spill_cnt = nullptr);
 // top-k modes, cold workspace: after the first refine -- more than an eighth of the queries overflowed their candidate slots under
 // the sampled threshold: switch the workspace's policy word to the tight threshold, open the gate of the re-run launches and
 // clear what the first pass left in the redo flags and counters
@@ -443,6 +449,7 @@ struct RefineArgs {
     float* nb_s;                    // optional [B,L,width]: raw scores of the kept neighbours (saved for backward)
     int32_t* heavy_list; int32_t* heavy_count;      // adaptive mode: queries with many candidates, refined by a whole block each
     const int32_t* policy; const int32_t* gate; int capseg_tight;     // as in ScreenArgs
+    const int2* spill; const unsigned* spill_cnt;                     // as in ScreenArgs
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
 int refine_heavy_cap();

@@ -38,6 +38,13 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     return base + slot;
 }
 
+// a full segment's further candidates go to the query's shared spill area (ScreenArgs::spill); past its end they are dropped and the
+// count tells refine so (-> the exact redo pass, as before)
+__device__ __forceinline__ void screen_spill(const ScreenArgs& a, size_t qlin, int key, float sv) {
+    const unsigned pos = atomicAdd(a.spill_cnt + qlin, 1u);
+    if (pos < (unsigned)SCREEN_SPILL) a.spill[qlin * SCREEN_SPILL + pos] = make_int2(key, __float_as_int(sv));
+}
+
 // A query's 13 fragments of 8 bf16: row-major copy (features 16t + 8h .. of its row: 32 rows x 32 B per wave load) or the fragment
 // order project16 writes (ScreenArgs::q_tiled: [queries 0..15 | 16..31][t][h][query][8] per 32 queries, two runs of 512 B per
 // wave load).  q0 = the wave tile's first query; tiles past L read the last valid one (their thresholds are +inf).
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
                             if (n_loc[w] < a.capseg - 1) cseg[w][(size_t)n_loc[w] * (a.splits * 2)] = make_int2(key, __float_as_int(sv));
+                            else if (a.spill != nullptr) screen_spill(a, (size_t)b * a.L + (size_t)((qg * (SCR_QUERIES / (QW * QT)) + wave) * QW + w) * QT + i, key, sv);
                             ++n_loc[w];
                         }
                     }
@@ -487,6 +495,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                             const int r = 15 - bit;
                             const int key = kbase + (r & 3) + 8 * (r >> 2);
                             if (n_loc[w] < a.capseg - 1) cseg[w][(size_t)n_loc[w] * (a.splits * 2)] = make_int2(key, __float_as_int(sv));
+                            else if (a.spill != nullptr) screen_spill(a, (size_t)b * a.L + (size_t)((qg * WAVES + wave) * QW + w) * QT + i, key, sv);
                             ++n_loc[w];
                         }
                     }
@@ -937,11 +946,12 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 // ---- theta: k-th largest group maximum per query (one wave per query, values in registers) -------------------
 constexpr int THETA_PER_LANE = 8;                // G <= 512
 __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, int k, const float* __restrict__ gmax,
-                                                           float* __restrict__ theta, const int32_t* gate) {
+                                                           float* __restrict__ theta, const int32_t* gate, unsigned* __restrict__ spill_cnt) {
     if (gate != nullptr && *gate == 0) return;
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (size_t)n_rows) return;
+    if (spill_cnt != nullptr && lane == 0) spill_cnt[row] = 0u;          // (the filter pass behind this launch counts from zero)
     float v[THETA_PER_LANE];
 #pragma unroll
     for (int u = 0; u < THETA_PER_LANE; ++u) {
@@ -971,9 +981,9 @@ __global__ __launch_bounds__(256) void screen_theta_kernel(int n_rows, int G, in
     if (lane == 0) theta[row] = (kth > 0.f) ? kth * ((1.0f - DELTA) / (1.0f + DELTA)) : 0.0f;
 }
 
-int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate) {
+int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate, unsigned* spill_cnt) {
     if (G > 64 * THETA_PER_LANE) { set_error("screen_theta: %d groups exceed %d", G, 64 * THETA_PER_LANE); return DAGL_ERR_INVALID; }
-    hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta, gate);
+    hipLaunchKernelGGL(screen_theta_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, n_rows, G, k, gmax, theta, gate, spill_cnt);
     DAGL_LAUNCH_CHECK("screen_theta_kernel");
     return DAGL_OK;
 }
@@ -1054,6 +1064,23 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         total += __builtin_amdgcn_readlane(incl, 63);
     }
     overflow = __any(overflow);
+    if (lead && a.spill != nullptr) {
+        // the records that did not fit their segments (ScreenArgs::spill): as long as the query's shared area and the candidate
+        // arrays hold them all, nothing was dropped -- no redo.  Their order is whatever the atomics made it; everything behind
+        // this point works on the SET (selections by (score, key), sums in rank order).
+        const unsigned sc_n = a.spill_cnt[ql];
+        if (sc_n > 0u) {
+            if (sc_n <= (unsigned)SCREEN_SPILL && total + (int)sc_n <= RF_MAX_CAND) {
+                const bool seg_only = !(total >= RF_MAX_CAND);               // (the only overflow so far was full segments)
+                for (unsigned e = lane; e < sc_n; e += 64) {
+                    const int2 c = a.spill[ql * SCREEN_SPILL + e];
+                    ci[total + e] = c.x; cv[total + e] = __int_as_float(c.y);
+                }
+                total += (int)sc_n;
+                if (seg_only) overflow = false;
+            } else overflow = true;
+        }
+    }
     if (total > RF_MAX_CAND) total = RF_MAX_CAND;
     // adaptive lists with the per-query redo behind them: twice as many candidates as the list is wide will not fit it
     // (nearly every candidate of this mode passes the exact test) -- the row is redone on its own anyway (overflow.hip),

@@ -123,11 +123,21 @@ def test_screen_overflow_is_redone_by_the_fp32_scan():
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
     g = torch.Generator().manual_seed(3)
     x = (0.25 + 1e-2 * torch.randn(1, 64, 64, 64, generator=g)).to(_dev())
+    # (round 4: a full segment spills into its query's shared area first -- 256 records --, which serves the 1e-2 map above
+    # without any redo; a map flatter still puts thousands of keys per query inside the band: beyond segments, spill and the
+    # refine pass's 1024 candidates)
+    x_flat = (0.25 + 2e-4 * torch.randn(1, 64, 64, 64, generator=g)).to(_dev())
+    flat = {}
+    for scan in ("screened", "exact"):
+        flat[scan] = _run_debug(_module(params, "topk", 8, scan), x_flat, sampled_topk=True)
+    assert flat["screened"][1]["path"] == 3 and flat["screened"][1]["redone_queries"] > 0
+    assert torch.equal(flat["screened"][1]["deg"], flat["exact"][1]["deg"])
+    assert normwise(flat["screened"][0].cpu().numpy(), flat["exact"][0].cpu().numpy()) <= TOL_OUT
     res = {}
     for scan in ("screened", "exact"):
         ce = _module(params, "topk", 8, scan)
         res[scan] = _run_debug(ce, x, sampled_topk=True)
-    assert res["screened"][1]["path"] == 3 and res["screened"][1]["redone_queries"] > 0
+    assert res["screened"][1]["path"] == 3                  # (120 of its 256 queries overflowed a segment before the spill area existed)
     assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
     assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
     # the workspace's own policy (no flag): this cold call flips to the tight threshold and re-runs in-stream -- eight times the
@@ -147,7 +157,7 @@ def test_redo_of_one_image_of_a_batch(mode, k):
     params = {n: torch.from_numpy(a) for n, a in make_ce_params(52, variant="default").items()}
     x = torch.from_numpy(make_features(53, 3, 64, 64, 64))
     g = torch.Generator().manual_seed(3)
-    x[1] = 0.25 + 1e-2 * torch.randn(64, 64, 64, generator=g)
+    x[1] = 0.25 + 2e-4 * torch.randn(64, 64, 64, generator=g)      # (flat enough for thousands of candidates per query: past the spill area)
     x = x.to(_dev())
     res = {}
     for scan in ("screened", "exact"):
