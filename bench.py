@@ -333,6 +333,25 @@ def real_features_extra(dev):
                         "parity_note": "max|hip - oracle| / max|oracle| of 64 sampled queries' aggregated patches against all keys (bar 1e-4)"}
         res["ms_per_step"] = ms[-1]                          # (kept: the entry's headline = the WORST of the seven maps)
         res["patches_per_s"] = 4096 / (ms[-1] * 1e-3)
+        # the fixed-k variant's OWN default, num_edge = 50 (GReccR2b_3mh_1-checkpoint.py:176): a few queries of a natural-image map
+        # have one hot candidate segment; until the spill area (ScreenArgs::spill) their 128-query groups took the fp32 redo pass
+        # every call (7.2 ms)
+        ce.select_k = 50
+        ce.topk_threshold = "auto"
+        per50 = {}
+        for n in names[:3]:
+            x = feats[n]
+            ce.reset_topk_policy()
+            per50[n] = _time_steps(lambda: ce(x), 8, 3, EXTRA_PREWARM_S)
+        res["topk50"] = {"what": "k = 50 (the variant's default num_edge) on the same features", "ms_per_step_by_image": {n: round(v, 4) for n, v in per50.items()},
+                         "ms_per_step": max(per50.values())}
+        ce.select_k = 8
+        xl8 = features(names[1], leaf=True)
+        ce.reset_topk_policy()
+        msl8 = _time_steps(lambda: ce(xl8), 8, 3, EXTRA_PREWARM_S)
+        res["topk8_leaf_tiles"] = {"what": f"the 64 leaf tiles of 72x72 of {names[1]} as one batch {list(xl8.shape)}, top-k 8 (maps of <= 16 384 keys start on the tight threshold)",
+                                   "ms_per_step": msl8, "patches_per_s": xl8.shape[0] * 324 / (msl8 * 1e-3)}
+        del xl8
         # the shipped adaptive semantics on the same features: dense formulation, nothing skipped
         ce.select_mode = "adaptive"
         dper = {}

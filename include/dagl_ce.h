@@ -85,7 +85,9 @@ extern "C" {
  * poll, valid under HIP-graph replay).  On a cold workspace (no DAGL_FLAG_WEIGHTS_PACKED: the first call of a shape) a call with
  * more than a sixteenth of its query GROUPS flagged re-runs sampling, filter and refine with the tight threshold in-stream (four
  * gated launches that exit at once otherwise) instead of sending those groups to the fp32 redo pass: ~0.4 ms instead of 2.7 at
- * 256^2.  DAGL_FLAG_TIGHT_TOPK forces the tight threshold, DAGL_FLAG_SAMPLED_TOPK the
+ * 256^2.  Maps of up to 16 384 keys start on the tight threshold (it costs nothing there).  A segment whose slots are full spills
+ * into its query's shared area (256 records) before the query is flagged: the redo pass is left to maps flat enough for
+ * thousands of candidates per query.  DAGL_FLAG_TIGHT_TOPK forces the tight threshold, DAGL_FLAG_SAMPLED_TOPK the
  * sampled one (tests, benchmarks of that path); dagl_ce_range_check's bit 2 still reports whether the last call's redo pass
  * had work.                                                                                                                    */
 #define DAGL_FLAG_TIGHT_TOPK     0x1000
