@@ -109,6 +109,7 @@ struct Plan {
     bool split16;                   // fp16 split-operand projection (default) vs. the fp32 MFMA projection
     int splits, tiles_per_split, n_tiles;                 // fp32 scan (select.hip)
     int s_splits, s_steps_per_split, s_steps, s_sample, s_qblock;   // bf16 screen (screen.hip)
+    int s_gkeep = 4;                                      // group maxima per (query, chunk, half) segment handed to the threshold kernel (ScreenArgs::gkeep)
     int capseg, capseg_alloc;
     int s_sample_tight = 0, capseg_tight = 0;             // top-k modes behind the screen: the tight threshold's pair (DAGL_FLAG_TIGHT_TOPK)
     int width;                      // neighbour-list width of the fixed-width paths
@@ -276,7 +277,8 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
-        p.o_gmax = carve(off, BL * p.s_splits * 2 * 4 * sizeof(float));
+        p.s_gkeep = (p.s_splits * 2 * 16 <= 512) ? 16 : 4;       // (screen_theta_kernel takes up to 512 values per query)
+        p.o_gmax = carve(off, BL * p.s_splits * 2 * p.s_gkeep * sizeof(float));
         p.o_theta = carve(off, BL * sizeof(float));
         p.o_scand = carve(off, BL * p.s_splits * 2 * p.capseg_alloc * sizeof(int2));     // candidate records (count in slot 0)
         p.o_spill = p.o_spillcnt = 0;
@@ -669,7 +671,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         sc.B = B; sc.L = g.L; sc.N = g.N; sc.mode = mode; sc.wqh = Wqh; sc.xh = Xh; sc.q_tiled = q_tiled;
         sc.rows_qh = feat_rows_h(g.L); sc.rows_xh = feat_rows_h(g.N);
         sc.splits = p.s_splits; sc.steps_per_split = p.s_steps_per_split; sc.n_steps = p.s_steps; sc.sample = p.s_sample; sc.qblock = p.s_qblock;
-        sc.gmax = at<float>(ws, p.o_gmax); sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
+        sc.gmax = at<float>(ws, p.o_gmax); sc.gkeep = p.s_gkeep; sc.theta = at<float>(ws, p.o_theta); sc.mt = mt; sc.bs = bias;
         sc.capseg = p.capseg; sc.cand = at<int2>(ws, p.o_scand);
         if (mode != DAGL_MODE_ADAPTIVE) { sc.spill = at<int2>(ws, p.o_spill); sc.spill_cnt = at<unsigned>(ws, p.o_spillcnt); }
         if (topk_policy) { sc.policy = policy_w; sc.sample_tight = p.s_sample_tight; sc.capseg_tight = p.capseg_tight; }
@@ -700,7 +702,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             sc.sample = 1;
             if ((rc = launch_screen(s, sc, 0))) return rc;
             float* smax = at<float>(ws, p.o_theta);
-            if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * 4, sc.gmax, smax))) return rc;
+            if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * p.s_gkeep, sc.gmax, smax))) return rc;
             if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt,
                                           core ? core->lse : nullptr, features_split))) return rc;
             prof_mark(prof, s, 7);
@@ -727,7 +729,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         prof_mark(prof, s, 3);
         if (mode != DAGL_MODE_ADAPTIVE) {                       // top-k threshold from the sampling pass
             if ((rc = launch_screen(s, sc, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc.gmax, at<float>(ws, p.o_theta), nullptr, sc.spill_cnt))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * p.s_gkeep, k, sc.gmax, at<float>(ws, p.o_theta), nullptr, sc.spill_cnt))) return rc;
         }
         if (mode != DAGL_MODE_TOPK && !fused_theta)             // adaptive threshold; the intersection mode takes the larger
             if ((rc = launch_adaptive_theta(s, BL, mt, bias, at<float>(ws, p.o_theta), mode == DAGL_MODE_ADAPTIVE_TOPK))) return rc;
@@ -756,7 +758,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_topk_policy(s, stats, policy_w, gate_w, redo, (int)(B * n_qgroups), (long long)BL))) return rc;
             ScreenArgs sc2 = sc; sc2.gate = gate_w;
             if ((rc = launch_screen(s, sc2, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * 4, k, sc2.gmax, at<float>(ws, p.o_theta), gate_w, sc2.spill_cnt))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * p.s_gkeep, k, sc2.gmax, at<float>(ws, p.o_theta), gate_w, sc2.spill_cnt))) return rc;
             // (the intersection mode takes the larger of the two thresholds: max(adaptive, theta) is idempotent, so the ungated
             // kernel is harmless when the re-run did not run)
             if (mode != DAGL_MODE_TOPK && !fused_theta)

@@ -402,7 +402,8 @@ struct ScreenArgs {
     int rows_qh, rows_xh;
     int splits, steps_per_split, n_steps, sample;
     int qblock;                     // queries per block: 256 (8 waves, two blocks per CU) or 512 (16 waves, one block per CU)
-    float* gmax;                    // pass 0 out: [B, L, splits*2, 4] largest group maxima of S~ per segment
+    float* gmax;                    // pass 0 out: [B, L, splits*2, gkeep] largest group maxima of S~ per segment
+    int gkeep;                      // 4 (the lane's four largest) or 16 (all of them: queries with <= 32 segments)
     const float* theta;             // pass 1 in (top-k): per-query candidate threshold on S~
     const float* mt; const float* bs;               // pass 1 in (adaptive modes)
     int capseg;

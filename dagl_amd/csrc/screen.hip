@@ -249,6 +249,17 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         if (PASS == 0) {
+            if (a.gkeep == 16) {
+                // few segments per query (small maps, large batches): ALL sixteen group maxima of the lane go to the threshold kernel --
+                // with four of them per segment a query had 8 * chunks values to take its k-th largest from: fewer than k = 50 on a
+                // batch of 64 leaf tiles (theta = 0, every key a candidate, every query group on the fp32 redo pass: 12 ms a call)
+                if (qvalid[w]) {
+                    float4* o = reinterpret_cast<float4*>(a.gmax + seg[w] * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = make_float4(gm[w][4 * u], gm[w][4 * u + 1], gm[w][4 * u + 2], gm[w][4 * u + 3]);
+                }
+                continue;
+            }
             // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
             // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
             float top[GKEEP];
@@ -516,6 +527,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         if (PASS == 0) {
+            if (a.gkeep == 16) {
+                // few segments per query (small maps, large batches): ALL sixteen group maxima of the lane go to the threshold kernel --
+                // with four of them per segment a query had 8 * chunks values to take its k-th largest from: fewer than k = 50 on a
+                // batch of 64 leaf tiles (theta = 0, every key a candidate, every query group on the fp32 redo pass: 12 ms a call)
+                if (qvalid[w]) {
+                    float4* o = reinterpret_cast<float4*>(a.gmax + seg[w] * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = make_float4(gm[w][4 * u], gm[w][4 * u + 1], gm[w][4 * u + 2], gm[w][4 * u + 3]);
+                }
+                continue;
+            }
             // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
             // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
             float top[GKEEP];
@@ -811,6 +833,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_pipe_kernel(ScreenArgs a
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         if (PASS == 0) {
+            if (a.gkeep == 16) {
+                // few segments per query (small maps, large batches): ALL sixteen group maxima of the lane go to the threshold kernel --
+                // with four of them per segment a query had 8 * chunks values to take its k-th largest from: fewer than k = 50 on a
+                // batch of 64 leaf tiles (theta = 0, every key a candidate, every query group on the fp32 redo pass: 12 ms a call)
+                if (qvalid[w]) {
+                    float4* o = reinterpret_cast<float4*>(a.gmax + seg[w] * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = make_float4(gm[w][4 * u], gm[w][4 * u + 1], gm[w][4 * u + 2], gm[w][4 * u + 3]);
+                }
+                continue;
+            }
             // keep the lane's GKEEP largest group maxima: GKEEP distinct keys, so still a valid pool for the
             // k-th-largest lower bound, at a quarter of the traffic into the theta kernel
             float top[GKEEP];
