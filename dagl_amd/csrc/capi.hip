@@ -192,6 +192,11 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
 #endif
         const int nqg = (g.L + qb - 1) / qb;
         int sp = (target + nqg * B - 1) / (nqg * B);
+        // top-k modes: the threshold is the k-th largest of chunks x 2 x 16 group maxima per query -- large batches of small maps
+        // (256 leaf tiles: ONE chunk) left fewer values than k = 50 (theta = 0: every key a candidate, every group on the redo pass)
+        // -- and the fewer keys a group holds, the closer its maximum lies to the query's best keys: k / 4 chunks (k = 50: 416 groups
+        // of a dozen keys on a 72 x 72 tile instead of 128 groups of forty: a third of the candidates)
+        if (mode != DAGL_MODE_ADAPTIVE && sp < (k + 3) / 4) sp = (k + 3) / 4;
         if (sp > mx) sp = mx;
         if (sp < 1) sp = 1;
         p.s_qblock = qb;
@@ -214,14 +219,14 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
 #ifdef DAGL_ABLATION
     { static const int cs = [] { const char* e = getenv("DAGL_SCREEN_CAPSEG"); return e ? atoi(e) : 0; }(); if (cs >= 4) p.capseg = cs; }
 #endif
-    // DAGL_FLAG_TIGHT_TOPK: the threshold from every second key tile and eight times the slots per segment (as far as 1 GiB of
-    // records goes; with fewer slots: from every tile) -- on the Set12 feature maps every 2nd tile + 128 slots serves six of
+    // DAGL_FLAG_TIGHT_TOPK: the threshold from every second key tile and eight times the slots per segment (as far as 2 GiB of
+    // records go; with fewer slots: from every tile) -- on the Set12 feature maps every 2nd tile + 128 slots serves six of
     // seven images at 0.25 ms, every tile + 64 slots the same six at 0.27, every 4th tile two (profiles/r03_real_features_topk.log).
     // The records are ALWAYS laid out for the larger count, so that a workspace serves both kinds of call with one layout.
     p.capseg_alloc = p.capseg;
     if (p.screen && mode != DAGL_MODE_ADAPTIVE) {
         while (p.capseg_alloc < 8 * p.capseg && p.capseg_alloc < 256 &&
-               (size_t)B * g.L * p.s_splits * 2 * (2 * (size_t)p.capseg_alloc) * sizeof(int2) <= ((size_t)1 << 30))
+               (size_t)B * g.L * p.s_splits * 2 * (2 * (size_t)p.capseg_alloc) * sizeof(int2) <= ((size_t)2 << 30))
             p.capseg_alloc *= 2;
         // the tight pair: forced by the flag, or taken by the kernels themselves once the workspace's policy word says so
         p.s_sample_tight = (p.capseg_alloc >= 8 * p.capseg && p.s_sample >= 2) ? 2 : 1;
