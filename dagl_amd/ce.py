@@ -197,7 +197,8 @@ class CE(nn.Module):
         # the candidate slots (DAGL_FLAG_TIGHT_TOPK: +25 us at 256^2) -- on natural-image features the sampled threshold lets
         # hundreds of keys per query through, the slots overflow and the call lands on the fp32 redo pass (2.7 ms instead of 0.25);
         # "auto" (default) = the workspace's own policy word, read by the kernels themselves (round 4: no host poll, valid under
-        # HIP-graph replay): sampled until a call overflows, tight from then on; the first call of a shape re-runs tight in-stream.
+        # HIP-graph replay): sampled until any query of a call overflows (a full segment spills into the query's shared area first),
+        # tight from then on; the first call of a shape re-runs tight in-stream; maps of <= 16 384 keys start tight.
         self.topk_threshold = "auto"
         self._served_streak = 0
         self._served_streaks = {}      # the same for adaptive_sync = "auto"
