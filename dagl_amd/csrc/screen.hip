@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void refine_query(const RefineArgs& a, const size_t q
         total += __builtin_amdgcn_readlane(incl, 63);
     }
     overflow = __any(overflow);
-    if (lead && a.spill != nullptr) {
+    if (lead && a.spill != nullptr && overflow) {                             // (records are spilled by full segments only)
         // the records that did not fit their segments (ScreenArgs::spill): as long as the query's shared area and the candidate
         // arrays hold them all, nothing was dropped -- no redo.  Their order is whatever the atomics made it; everything behind
         // this point works on the SET (selections by (score, key), sums in rank order).

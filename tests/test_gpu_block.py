@@ -515,3 +515,20 @@ def test_packed_conv_weights_follow_inplace_updates():
         b2 = fresh(xd)
     assert not torch.equal(a1, b1)
     assert torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("mode,k", [("topk", 50), ("topk", 64), ("adaptive_topk", 40)])
+def test_large_k_on_a_large_batch_of_small_maps_needs_no_redo(mode, k):
+    """A batch of 96 maps of 48 x 52 (the tiled driver's leaf tiles are such a batch): a query has few key chunks, and with four
+    group maxima per (chunk, half) lane the threshold kernel had fewer values than k to take its k-th largest from -- theta = 0,
+    every key a candidate, every query group on the fp32 redo pass (12.4 ms per head on 64 leaf tiles at k = 50, found on round 4's
+    last day).  Now: all sixteen group maxima per lane, at least k / 4 chunks.  Same neighbours as the fp32 scan, no redo work."""
+    from dagl_amd.synth import make_ce_params, make_features
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(57, variant="default" if mode == "topk" else "allpass").items()}
+    x = torch.from_numpy(make_features(58, 96, 64, 48, 52)).to(_dev())          # (2 496 keys: behind the bf16 screen)
+    res = {}
+    for scan in ("screened", "exact"):
+        res[scan] = _run_debug(_module(params, mode, k, scan), x)
+    assert res["screened"][1]["path"] == 3 and res["screened"][1]["redone_queries"] == 0
+    assert torch.equal(res["screened"][1]["deg"], res["exact"][1]["deg"])
+    assert normwise(res["screened"][0].cpu().numpy(), res["exact"][0].cpu().numpy()) <= TOL_OUT
