@@ -254,6 +254,8 @@ def extra_configs(dev):
     out["256x256_set12_features"] = real_features_extra(dev)
     out["train_rr_topk8_128x128_b8"] = train_extra(dev)
     out["train_rr_adaptive_128x128_b8"] = train_extra(dev, steps=4, warmup=2, mode="adaptive")
+    # the reference trainer's own default shape: DN_Gray --patch_size 64 --batch_size 32 (option.py:42,88), shipped adaptive semantics
+    out["train_rr_adaptive_64x64_b32_gray"] = train_extra(dev, B=32, crop=64, colors=1, steps=4, warmup=2, mode="adaptive")
     return out
 
 
