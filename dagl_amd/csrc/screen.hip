@@ -1454,8 +1454,9 @@ int refine_heavy_cap() { return RF_HEAVY_CAP; }
 
 __global__ __launch_bounds__(256) void topk_policy_kernel(int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags,
                                                           long long n_queries) {
-    // the re-run pays when the redo pass would scan more than a sixteenth of the query GROUPS (a flagged query sends its whole
-    // 128-query group through the fp32 scan; a few hundred flagged queries of a natural-image map are spread over most groups)
+    // the re-run pays when the redo pass would scan more than a fiftieth of the query GROUPS (a flagged query sends its whole
+    // 128-query group through the fp32 scan, ~50x the screen's price per pair: 84 us per group at 256^2, 5 ms at 1024^2 where the
+    // tight re-run of everything is 37; a few hundred flagged queries of a natural-image map are spread over most groups)
     __shared__ int go, n_groups;
     if (threadIdx.x == 0) n_groups = 0;
     __syncthreads();
@@ -1465,7 +1466,7 @@ __global__ __launch_bounds__(256) void topk_policy_kernel(int64_t* stats, int32_
         if (loc) atomicAdd(&n_groups, loc);
     }
     __syncthreads();
-    if (threadIdx.x == 0) go = (*policy == 0 && (long long)n_groups * 16 > (long long)n_flags) ? 1 : 0;
+    if (threadIdx.x == 0) go = (*policy == 0 && (long long)n_groups * 50 > (long long)n_flags) ? 1 : 0;
     (void)n_queries;
     __syncthreads();
     if (!go) return;

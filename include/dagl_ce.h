@@ -83,7 +83,7 @@ extern "C" {
  * threshold let ANY query overflow its candidate slots (its whole 128-query group takes the fp32 redo pass: 84 us per group at
  * 256^2) switches the workspace to the tight threshold for good (the word is sticky; kernels read it at their start: no host
  * poll, valid under HIP-graph replay).  On a cold workspace (no DAGL_FLAG_WEIGHTS_PACKED: the first call of a shape) a call with
- * more than a sixteenth of its query GROUPS flagged re-runs sampling, filter and refine with the tight threshold in-stream (four
+ * more than a fiftieth of its query GROUPS flagged re-runs sampling, filter and refine with the tight threshold in-stream (four
  * gated launches that exit at once otherwise) instead of sending those groups to the fp32 redo pass: ~0.4 ms instead of 2.7 at
  * 256^2.  Maps of up to 16 384 keys start on the tight threshold (it costs nothing there).  A segment whose slots are full spills
  * into its query's shared area (256 records) before the query is flagged: the redo pass is left to maps flat enough for
