@@ -376,7 +376,7 @@ struct EdgeArgs {
 int launch_edge_softmax(hipStream_t s, const EdgeArgs& a);
 // top-k modes behind the screen: exact scan + merge of the FLAGGED query groups in one launch (select.hip); barrier = a zeroed word
 int launch_topk_redo(hipStream_t s, const SelectArgs& a, const EdgeArgs& e, int pass /*2 topk, 3 adaptive-topk*/, unsigned* barrier,
-                     int32_t* policy = nullptr /* workspace policy word: set when more than an eighth of the queries are flagged */);
+                     int32_t* policy = nullptr /* workspace policy word: set when the pass has work (any flagged query) */);
 
 struct AggArgs {
     int B; Grid g;
@@ -428,7 +428,7 @@ constexpr int SCREEN_SPILL = 256;
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
 int launch_screen_theta(hipStream_t s, int n_rows, int G, int k, const float* gmax, float* theta, const int32_t* gate = nullptr,
                         unsigned* spill_cnt = nullptr);
-// top-k modes, cold workspace: after the first refine -- more than an eighth of the queries overflowed their candidate slots under
+// top-k modes, cold workspace: after the first refine -- more than a fiftieth of the query GROUPS are flagged (overflowed candidate slots) under
 // the sampled threshold: switch the workspace's policy word to the tight threshold, open the gate of the re-run launches and
 // clear what the first pass left in the redo flags and counters
 int launch_topk_policy(hipStream_t s, int64_t* stats, int32_t* policy, int32_t* gate, int32_t* redo_flags, int n_flags, long long n_queries);
