@@ -62,6 +62,10 @@ def parse():
                     help="secondary workload (BASELINE configs[4]): one optimisation step of the whole RR network on "
                          "--crop x --crop crops, --batch crops per GPU, DDP gradient all-reduce over RCCL")
     ap.add_argument("--crop", type=int, default=128)
+    ap.add_argument("--dense-backward", choices=["f16", "fp32"], default="f16",
+                    help="--train A/B: the dense graph core's backward products on the fp16 (split operands, default) or fp32 matrix cores")
+    ap.add_argument("--prologue-backward", choices=["direct", "unfold"], default="direct",
+                    help="--train A/B: gradients of g / theta as tap-wise products on the maps (default) or through unfold + GEMM + fold")
     ap.add_argument("--colors", type=int, default=3)
     ap.add_argument("--wseed", type=int, default=2024, help="seed of the synthetic head weights")
     ap.add_argument("--fseed", type=int, default=None, help="seed of the synthetic feature maps (+ rank); default: the per-rank stream of seed 100")
@@ -192,6 +196,28 @@ def _time_steps(step, steps, warmup, prewarm_s=0.0):
 EXTRA_PREWARM_S = 0.15
 
 
+def dense_roofline(stage_ms, B, L, N, info, source):
+    """`roofline` block of a call that ran the streamed dense formulation (info.path 4): dense_attend_kernel (dense.hip).
+    Algorithmic work = S (2 L N 196) + A V (2 L N 784) per image; executed on the fp16 matrix cores = three split products of
+    each, S on 224 padded columns.  `stage_ms` = hipEvent-bracketed time of the call's stage "gather" (value-map split 6 us +
+    dense_attend_kernel + combine 9 us + the two gated launches of the second pass) on the launch stream."""
+    flops = 2.0 * B * L * N * (D_FEAT + P_ROW)
+    executed = 3.0 * 2.0 * B * L * N * (224 + P_ROW)
+    ach = flops / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
+    rerun = int((info or {}).get("dense_rerun_blocks", 0) or 0)
+    return {"bound": "mfma", "kernel": "dense_attend_kernel (fp16 v_mfma_f32_16x16x32_f16 scores + v_mfma_f32_32x32x16_f16 A V, split "
+                                       "operands hi + lo: three products each)",
+            "achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MATRIX_TFLOPS,
+            "executed_frac": executed / (stage_ms * 1e-3) / 1e12 / PEAK_BF16_MATRIX_TFLOPS if stage_ms > 0 else 0.0,
+            "executed_note": "upper figure: exact-zero weight granules (64 queries x 16 keys) are skipped, so fewer multiplies than "
+                             "this run on maps whose logits reach hundreds (synthetic N(0,1) features); none are on trained features",
+            "traffic": None, "flop_per_launch": flops, "ms_per_launch": stage_ms,
+            "launches_per_call": 1 if rerun == 0 else 2, "dense_rerun_blocks": rerun,
+            "launches_note": "dense_attend_kernel launches of a call that do work (the second, gated pass exits at once unless the "
+                             "first flagged blocks of 64 queries: rows the top-1 screen could not give an exact shift)",
+            "timing": source}
+
+
 def extra_configs(dev):
     """The other BASELINE configurations and regimes, each a short run (0.15 s of untimed passes for the clock -- see
     --prewarm --, 3 warm-ups + 10 timed steps) inside the one driver-timed command, so that their numbers are measured by
@@ -214,12 +240,14 @@ def extra_configs(dev):
         ("512x512_topk8_bf16_io", 512, "default", 2.0, "topk", 8, torch.bfloat16, "BASELINE configs[2]: CAR 512x512, k=8, bf16 feature maps"),
         ("1024x1024_adaptive_topk16", 1024, "sparse", 1.7, "adaptive_topk", 16, torch.float32, "BASELINE configs[3]: 1024x1024, adaptive AND k_max=16, whole-image search window"),
         ("256x256_adaptive_dense_default_init", 256, "default", 2.0, "adaptive", 0, torch.float32, "shipped semantics at default init (~95 % of the keys pass): streamed dense formulation; on this synthetic N(0,1) map the logits reach hundreds and ~2/3 of the (64 query x 16 key) weight granules are exactly zero and skipped -- see 256x256_set12_features.adaptive_dense for the regime where none are"),
+        ("256x256_adaptive_dense_default_init_bench_map", 256, "default", 2.0, "adaptive", 0, torch.float32, "the same configuration on the map `bench.py --mode adaptive --variant default` itself times (features seed rank_seed(100, 0) = 100000): in round 4 every block of THIS map took the dense kernel's second pass (1.52 ms a call) while the entry above (features seed 100) did not"),
         ("256x256_adaptive_mean_degree_8", 256, "sparse", 1.95, "adaptive", 0, torch.float32, "adaptive mask tuned to a mean degree of ~8 (7.7; long-tailed: maximum 890) (SURVEY 8d config 2)"),
         ("256x256_adaptive_mean_degree_55", 256, "sparse", 1.8, "adaptive", 0, torch.float32, "adaptive mask at mean degree 55, maximum 4578"),
         ("256x256_topk8_batch8", 256, "default", 2.0, "topk", 8, torch.float32, "the headline configuration with EIGHT images per call ([8,64,256,256]; batch = grid dimension): what the fixed per-launch costs of the one-image step are worth", 8),
         ("256x256_topk500", 256, "default", 2.0, "topk", 500, torch.float32, "num_edge = 500 (CA_model-checkpoint.py:134-143): beyond the 64-entry lists, every query's score row in the dense form (csrc/topk_wide.hip)"),
     ]
-    seeds = {"256x256_adaptive_mean_degree_8": (41, 41), "256x256_adaptive_mean_degree_55": (41, 41)}       # (weights, features): the pair tests/test_gpu_configs.py checks against the oracle
+    seeds = {"256x256_adaptive_mean_degree_8": (41, 41), "256x256_adaptive_mean_degree_55": (41, 41),       # (weights, features): the pair tests/test_gpu_configs.py checks against the oracle
+             "256x256_adaptive_dense_default_init_bench_map": (2024, 100000)}
     with torch.no_grad():
         for name, size, variant, gain, mode, k, dt, what, *rest in cases:
             nb = rest[0] if rest else 1
@@ -234,6 +262,19 @@ def extra_configs(dev):
             out[name] = {"what": what, "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": size * size, "batch": nb,
                          "selection_path": info.get("path"), "max_degree": info.get("max_degree"),
                          "mean_degree": (info.get("total_edges", -1) / L) if info.get("total_edges", -1) >= 0 else None}
+            if info.get("path") == 4:              # dense regime: its dominant kernel's roofline, event-bracketed in 10 more calls
+                pr = ops.StageProfile(10)
+                pr.select_stage("gather")
+                ce.profile = pr
+                for _ in range(10):
+                    ce(x)
+                torch.cuda.synchronize()
+                ce.profile = None
+                g_ms = [c[6] for c in pr.read()]
+                out[name]["roofline"] = dense_roofline(sum(g_ms) / max(len(g_ms), 1), nb, L // nb, size * size, ce.last_info,
+                                                       "mean of 10 calls, two hipEvents around the stage on the launch stream (these "
+                                                       "calls also read their statistics back: not the calls of ms_per_step)")
+                del pr
             del ce, x
             torch.cuda.empty_cache()
         # one CES stage: 4 heads sharing x + 1x1 mix + residual
@@ -636,6 +677,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI: used for the barriers/max only
 
     if args.train:
+        from dagl_amd import ops as _ops, train_ops as _train_ops
+        _ops.DENSE_BACKWARD_FP32 = args.dense_backward == "fp32"                    # A/B switches of the training routes
+        _train_ops._FORCE_UNFOLD_BACKWARD = args.prologue_backward == "unfold"
         train_bench(args, dev, dist, world, rank)
         if dist is not None:
             dist.destroy_process_group()
@@ -709,7 +753,8 @@ def main():
             step()
         # timed region: only the dominant kernel is bracketed by hipEvents (on the launch stream); an event record costs
         # ~4 us of stream time, so the full nine-boundary stage profile is taken in a separate pass below
-        prof.select_stage("select")
+        dense_regime = (not args.stage) and mode == "adaptive" and (ce.last_info or {}).get("path") == 4
+        prof.select_stage("gather" if dense_regime else "select")
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -720,7 +765,7 @@ def main():
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        dominant_ms = [c[4] for c in prof.read()]
+        dominant_ms = [c[6 if dense_regime else 4] for c in prof.read()]
         prof.select_stage(-1)
         for _ in range(min(args.steps, 20)):
             step(prof)
@@ -787,7 +832,7 @@ def main():
         sel_ms = float(np.mean(dominant_ms)) if len(dominant_ms) else float(mean_ms[4])     # from the timed steps
         flops = 2.0 * heads_per_step * B * L * N * D_FEAT                # algorithmic: 2*L*N*D per image and head
         ach = flops / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
-        screened = (info or {}).get("path") == 3
+        screened = (info or {}).get("path") == 3 and not dense_regime
         peak = PEAK_BF16_MATRIX_TFLOPS if screened else PEAK_F32_MATRIX_TFLOPS
         roofline = {"bound": "mfma",
                     "kernel": "screen_ring_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter; screen_kernel<1> for "
@@ -796,6 +841,8 @@ def main():
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": (committed_traffic("screen_ring_kernel<1>") or committed_traffic("screen_kernel<1>")) if (screened and (H, mode, k, B) == (256, "topk", 8, 1)) else None,
                     "flop_per_launch": flops, "ms_per_launch": sel_ms}
+        if dense_regime:
+            roofline = dense_roofline(sel_ms, B, L, N, info, "mean over the timed steps, two hipEvents around the stage on the launch stream")
         if roofline["traffic"] is not None:
             roofline["traffic_source"] = TRAFFIC_SOURCE
         if gather is not None and gather.get("traffic") is not None:
@@ -804,7 +851,7 @@ def main():
             roofline["sustained"] = mfma_sustained(dev, peak)
             if roofline["sustained"]:
                 roofline["frac_of_sustained"] = ach / roofline["sustained"]["mfma_only_tflops"]
-        if gather is not None and mean_ms[6] > 0:
+        if gather is not None and mean_ms[6] > 0 and not dense_regime:
             kk = k or max(1, int(round((info or {}).get("total_edges", 0) / max(1, B * L))))
             fb = B * L * ((kk + 1) * 4 * P_ROW + 8 * kk)
             gather["fused_in_block"] = {"kernel": "aggregate_fold_kernel (top-k: gather + weighted sum + fold in one kernel; value patches "

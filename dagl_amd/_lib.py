@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 403          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 404          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -38,7 +38,7 @@ class DaglError(RuntimeError):
 
 class CeInfo(C.Structure):
     _fields_ = [("required_bytes", C.c_int64), ("total_edges", C.c_int64), ("redone_queries", C.c_int64),
-                ("max_degree", C.c_int32), ("path", C.c_int32), ("range_fallback", C.c_int32), ("reserved", C.c_int32)]
+                ("max_degree", C.c_int32), ("path", C.c_int32), ("range_fallback", C.c_int32), ("dense_rerun_blocks", C.c_int32)]
 
 
 class CeWeights(C.Structure):

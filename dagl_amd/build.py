@@ -25,6 +25,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
         os.path.join(os.path.dirname(CSRC), "..", "include", "dagl_ce.h")]
+    if not force and not _stale(LIB, srcs + hdrs) and not os.environ.get("DAGL_EXTRA_FLAGS"):
+        return LIB                # the library is newer than every source: nothing to do (the objects do not travel to the GPU box)
     objs = []
     jobs = []
     for s in srcs:

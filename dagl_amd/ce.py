@@ -176,8 +176,8 @@ class CE(nn.Module):
         self._ws_bwd = ops.Workspace()
         self._pack_key = None
         self._pack_epoch = 0           # bumped by invalidate_packed()
-        self._f32_cache = {}
-        self._scaled_cache = {}           # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
+        self._f32_cache = {}              # fp32 copies of half-precision parameters (model.half(), DN_Gray/model/__init__.py:98-99)
+        self._scaled_cache = {}           # softmax_scale != 10: scaled copies of fc1 / the bias head (_scale_c)
         self._train_calls = 0
         self._wide_calls = 0
         self._last_call = None
@@ -256,6 +256,7 @@ class CE(nn.Module):
         self._pack_epoch += 1
         self._pack_key = None
         self._f32_cache = {}
+        self._scaled_cache = {}
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
@@ -301,10 +302,14 @@ class CE(nn.Module):
                 self._f32_cache[n] = hit
             out[n] = hit[1]
         c = self._scale_c()
-        if c != 1.0:                    # (see _scale_c; scaled copies kept until the parameter or the factor changes)
+        if c == 1.0:
+            self._scaled_cache = {}
+        else:                           # (see _scale_c; scaled copies kept until the PARAMETER -- not its fp32 copy, whose version
+                                        # counter never moves -- or the factor changes)
+            own = dict(self.named_parameters())
             for n in ("fc1.0.weight", "fc1.0.bias") + (() if self.select_mode == "topk" else ("bias_conv.weight", "bias_conv.bias")):
                 src = out[n]
-                tag = (src.data_ptr(), src._version, c)
+                tag = (own[n].data_ptr(), own[n]._version, own[n].dtype, own[n].device, c)
                 hit = self._scaled_cache.get(n)
                 if hit is None or hit[0] != tag:
                     hit = (tag, (src * c).contiguous())
@@ -470,9 +475,14 @@ class CE(nn.Module):
         H, W = b.shape[-2:]
         b1 = b1p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2).contiguous()
         b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2).contiguous()
+        if self.topk_threshold not in ("auto", "full", "sparse"):
+            raise DaglError(f"CE.topk_threshold {self.topk_threshold!r}: expected 'auto', 'full' or 'sparse'")
+        topk_screen = self.select_mode != "adaptive" and self.scan != "exact"
         out, info = ops.ce_forward(b1, b2, thr, bias, p["fc1.0.weight"], p["fc1.0.bias"], p["fc2.0.weight"], p["fc2.0.bias"],
                                    mode=self.select_mode, k=k_eff, workspace=self._ws, return_info=True,
-                                   exact_scan=(self.scan == "exact"), profile=self.profile)
+                                   exact_scan=(self.scan == "exact"), profile=self.profile,
+                                   tight_topk=topk_screen and self.topk_threshold == "full",
+                                   sampled_topk=topk_screen and self.topk_threshold == "sparse")
         self._last_call = None                     # (this entry point reads its statistics back every call: nothing to poll)
         self.last_info = info
         if info.get("range_fallback"):

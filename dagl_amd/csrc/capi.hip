@@ -25,6 +25,15 @@ __global__ void retag_kernel(int32_t* word, int32_t* veto, int32_t tag) {
     if (veto != nullptr && *veto == tag) *veto = STALE_TAG;
 }
 
+// Top-k threshold policy words of a workspace (stats[9] policy, stats[10] gate, stats[12] owner cookie).  A call that is not
+// "prepared" (first call, another shape, a train / eval alternation) used to clear the policy: a module that alternates between
+// two shapes forgot "tight" on every call and paid sampled pass + policy kernel + tight re-run each time.  The learnt word now
+// survives as long as the workspace still carries the cookie of this very geometry (a fresh or re-used buffer does not).
+__global__ void policy_init_kernel(int64_t* stats, int64_t cookie, int32_t start_tight) {
+    if (stats[12] != cookie) { stats[9] = start_tight; stats[12] = cookie; }
+    stats[10] = 0;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -118,7 +127,7 @@ struct Plan {
     size_t o_wide = 0;
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
-        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_scand, o_spill, o_spillcnt,
+        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_smax, o_scand, o_spill, o_spillcnt,
         o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
@@ -278,7 +287,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_convw = carve(off, 4 * CONV_W16_BYTES);                                       // packed g / theta weights per head
         p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
-    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
+    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_smax = p.o_spill = p.o_spillcnt = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
@@ -291,6 +300,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
             p.o_spill = carve(off, BL * SCREEN_SPILL * sizeof(int2));
             p.o_spillcnt = carve(off, BL * sizeof(unsigned));
         }
+        p.o_smax = (mode == DAGL_MODE_ADAPTIVE) ? carve(off, BL * sizeof(float)) : 0;      // dense formulation: the rows' shifts (as scores)
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
@@ -350,7 +360,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     const int mode = p.mode;
     k = p.k;                                                     // (clamped to the number of keys)
     if (info) { info->required_bytes = (int64_t)p.o_end; info->total_edges = -1; info->max_degree = -1; info->path = 0;
-                info->redone_queries = -1; info->range_fallback = 0; info->reserved = 0; }
+                info->redone_queries = -1; info->range_fallback = 0; info->dense_rerun_blocks = 0; }
     DAGL_REQUIRE(out && (core || (fc1_w && fc1_b && fc2_w && fc2_b)), "dagl_ce_forward: null tensor pointer");
     if (core) {
         DAGL_REQUIRE(core->wq_rows && core->x_rows && b2 && (core->lse || (core->nb_idx && core->nb_wgt && core->nb_s && core->nb_cnt)),
@@ -425,12 +435,14 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     int32_t* policy_w = reinterpret_cast<int32_t*>(stats + 9);
     int32_t* gate_w = reinterpret_cast<int32_t*>(stats + 10);
     if (topk_policy && !prepared) {
-        DAGL_HIP_TRY(hipMemsetAsync(stats + 9, 0, 2 * sizeof(int64_t), s));
         // maps of up to 16 384 keys (128^2; the 72 x 72 leaf tiles of the tiled driver) START on the tight threshold: there it costs
         // nothing measurable on synthetic maps (sampling every second key tile of <= 256 is a few steps) and its better threshold
         // saves 12 % on natural-image leaf tiles even when nothing overflows (0.64 against 0.73 ms per batch of 64 tiles,
-        // profiles/r04_topk_policy_real_features.log)
-        if (g.N <= 16384) DAGL_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(policy_w), 1, 1, s));
+        // profiles/r04_topk_policy_real_features.log).  The word is kept while the workspace carries this geometry's cookie.
+        uint64_t ck = 0x5DA6ull;
+        for (const int v : {B, H, W, mode, k, p.s_splits, p.capseg, p.capseg_tight}) ck = ck * 0x100000001B3ull ^ (uint64_t)(uint32_t)v;
+        hipLaunchKernelGGL(policy_init_kernel, dim3(1), dim3(1), 0, s, stats, (int64_t)(ck | 1ull), g.N <= 16384 ? 1 : 0);
+        DAGL_LAUNCH_CHECK("policy_init_kernel");
     }
     if (core) {
         if ((rc = launch_pad_nhwc(s, B, H, W, b2, b2p))) return rc;
@@ -702,12 +714,24 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                 set_error("dagl_ce_forward: dense neighbourhoods need workspace %zu B, have %zu B", off, ws_bytes);
                 return DAGL_ERR_WORKSPACE;
             }
-            prof_mark(prof, s, 6);
-            // row maxima of the screened scores (full bf16 scan, ~0.1 ms at 256^2): the softmax's shift, known up front
-            sc.sample = 1;
-            if ((rc = launch_screen(s, sc, 0))) return rc;
-            float* smax = at<float>(ws, p.o_theta);
-            if ((rc = launch_dense_rowmax(s, BL, p.s_splits * 2 * p.s_gkeep, sc.gmax, smax))) return rc;
+            // the softmax's shift, known up front: every row's largest score, exactly -- a top-1 screen (sampled pass -> theta = the
+            // largest sampled S~ less the band -> filter pass) and the exact scores of its few candidates (rowmax_exact_kernel).  Up to
+            // round 4: an upper bound from one full bf16 scan, whose 1.6 % became > 18 units of a logit beyond ~580 and sent whole
+            // blocks through dense_attend_kernel a second time (every block of bench.py's default map: 1.52 ms for 0.81)
+            ScreenArgs s1 = sc;
+            s1.mode = DAGL_MODE_TOPK; s1.mt = nullptr; s1.bs = nullptr; s1.policy = nullptr; s1.gate = nullptr;
+            s1.spill = nullptr; s1.spill_cnt = nullptr; s1.seg_max = 1;      // (no spill: a row with more candidates than slots keeps its upper bound)
+            if ((rc = launch_screen(s, s1, 0))) return rc;
+            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * p.s_gkeep, 1, s1.gmax, at<float>(ws, p.o_theta), nullptr, nullptr))) return rc;
+            if ((rc = launch_screen(s, s1, 1))) return rc;
+            float* smax = at<float>(ws, p.o_smax);
+            RefineArgs r1;
+            memset(&r1, 0, sizeof(r1));
+            r1.B = B; r1.L = g.L; r1.N = g.N; r1.mode = DAGL_MODE_TOPK; r1.k = 1; r1.splits = p.s_splits; r1.capseg = p.capseg;
+            r1.wq = Wq; r1.x = X; r1.rows_q = feat_rows(g.L); r1.rows_x = feat_rows(g.N);
+            r1.cand = s1.cand; r1.theta = s1.theta; r1.mt = mt; r1.bs = bias;
+            if ((rc = launch_rowmax_exact(s, r1, smax))) return rc;
+            prof_mark(prof, s, 6);          // (stage "gather" of a dense call = value-map split + dense_attend_kernel + combine)
             if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt,
                                           core ? core->lse : nullptr, features_split))) return rc;
             prof_mark(prof, s, 7);
@@ -715,14 +739,15 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
             prof_mark(prof, s, 8);
             if (info) {
-                int64_t hd[5] = {0, 0, 0, 0, 0};
-                if ((rc = read_back(s, stats, 5, hd))) return rc;
+                int64_t hd[DENSE_RERUN_STAT + 1] = {0};
+                if ((rc = read_back(s, stats, DENSE_RERUN_STAT + 1, hd))) return rc;
                 if (rt.word != nullptr && (int32_t)hd[4] == rt.tag) {
                     if (core) { info->range_fallback = 1; return DAGL_OK; }      // (output NaN-filled; dagl_ce_core_dense_forward re-runs the GEMM form)
                     return rerun_exact();
                 }
                 info->total_edges = hd[0]; info->max_degree = (int32_t)hd[1];
                 info->redone_queries = hd[2];                       // queries whose degree exceeds the lists' width
+                info->dense_rerun_blocks = (int32_t)hd[DENSE_RERUN_STAT];       // blocks of 64 queries dense_attend_kernel ran a second time
             }
             if (prof && prof->n_calls < prof->max_calls) ++prof->n_calls;
             return DAGL_OK;
@@ -1217,7 +1242,7 @@ int dagl_ce_core_dense_forward(void* stream, int B, int H, int W, int flags, con
         left_range = true;
     }
     if (info) { info->required_bytes = (int64_t)dense_train_workspace_bytes(B, g, false); info->total_edges = -1;
-                info->max_degree = -1; info->redone_queries = -1; info->path = 5; info->range_fallback = 0; info->reserved = 0; }
+                info->max_degree = -1; info->redone_queries = -1; info->path = 5; info->range_fallback = 0; info->dense_rerun_blocks = 0; }
     // the two statistics words live at the very end of the caller's buffer (past the plan)
     const size_t need = dense_train_workspace_bytes(B, g, false) + 256;
     if (ws_bytes < need) { set_error("dagl_ce_core_dense_forward: workspace %zu B < required %zu B", ws_bytes, need);
@@ -1259,7 +1284,7 @@ int dagl_ce_core_wide_forward(void* stream, int B, int H, int W, int mode, int k
     if (k > g.N) k = g.N;                                              // top_k = min(num_edge, N)
     const size_t need = dense_train_workspace_bytes(B, g, false) + 256;
     if (info) { info->required_bytes = (int64_t)need; info->total_edges = -1; info->max_degree = -1; info->redone_queries = -1;
-                info->path = 5; info->range_fallback = 0; info->reserved = 0; }
+                info->path = 5; info->range_fallback = 0; info->dense_rerun_blocks = 0; }
     if (ws_bytes < need) { set_error("dagl_ce_core_wide_forward: workspace %zu B < required %zu B", ws_bytes, need); return DAGL_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     int64_t* stats = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + need - 256);

@@ -423,6 +423,7 @@ struct ScreenArgs {
     // images give a few queries one hot segment (a 128-slot segment asked for 160-200) while the query's total stays in the hundreds;
     // without the spill such a query sent its whole 128-query group through the fp32 redo pass (k = 50 at 256^2: 7.2 ms a call)
     int2* spill; unsigned* spill_cnt;       // [B, L, SCREEN_SPILL] records, [B, L] counts (zeroed by screen_theta_kernel); null: none
+    int seg_max;                            // pass 1: slot 0 of a segment = {candidates found, largest screened score among them (float bits)}
 };
 constexpr int SCREEN_SPILL = 256;
 int launch_screen(hipStream_t s, const ScreenArgs& a, int pass);
@@ -453,6 +454,10 @@ struct RefineArgs {
     const int2* spill; const unsigned* spill_cnt;                     // as in ScreenArgs
 };
 int launch_refine(hipStream_t s, const RefineArgs& a);
+// dense formulation: per row a score whose logit is the softmax shift of dense_attend_kernel -- the exact row maximum where the
+// bf16 bounds are too far apart, their upper bound otherwise (screen.hip rowmax_exact_kernel).  Uses B, L, N, splits, capseg, wq, x,
+// rows_q, rows_x, mt, bs, cand (of a filter pass with ScreenArgs::seg_max), theta of the arguments.
+int launch_rowmax_exact(hipStream_t s, const RefineArgs& a, float* smax);
 int refine_heavy_cap();
 int launch_degree_stats(hipStream_t s, size_t n_rows, const int32_t* nb_cnt, int64_t* stats,
                         int count_over = 0 /* > 0: stats[2] = rows with a larger degree */);
@@ -509,13 +514,14 @@ struct DenseArgs {
     const float* wq; const float* x; int rows_q, rows_x;       // fp32 features [B, rows, DS]
     const uint16_t *x_hi, *x_lo, *wq_hi, *wq_lo; int rows_xh, rows_qh;   // the same, split fp16 [B, rows_h, DSH] (64 x = hi + lo)
     const float* mt; const float* bs;                          // [B,L] mean*thr, bias
-    const float* smax;                                         // [B,L] row maximum of the bf16-screened scores
+    const float* smax;                                         // [B,L] the score whose logit is the row's shift (rowmax_exact_kernel)
     const float* b2p;                                          // padded NHWC value map
     const uint16_t *v_hi, *v_lo;                               // the same, split fp16 (16 v = hi + lo), [B,Hp,Wp,16]
     int splits, tiles_per_split, n_tiles, tiles_per_row;       // 32-key tiles (row aligned), key ranges per 64-query group
     float* part_acc; float* part_m; double* part_z; int32_t* part_deg;   // per (split, query) partial results
     float* m_exact; int32_t* redo_blk; int pass;               // [B,L] exact largest logit of a row (written by the first combine), [B, ceil(L/64)]
                                                                // blocks of 64 queries to run again with it as their shift; pass 0 | 1
+    int32_t* redo_count;                                       // how many blocks the first combine flagged (stats[DENSE_RERUN_STAT])
     int variant;                                               // debug ablations (DAGL_DENSE_VARIANT): 1 no A V, 2 no S, 4 no staging, 16 constant
                                                                // weights, 32 no zero-granule skip, 64 phase clocks
     unsigned* phase_out;                                       // ablation builds: [blocks][8 waves][8] shader clocks per phase, or null
@@ -523,7 +529,7 @@ struct DenseArgs {
 size_t dense_workspace_bytes(int B, const Grid& g);
 Split16Out dense_split_buffers(void* dense_ws, int B, const Grid& g);    // where launch_dense_attend expects the split features
 void dense_guard_rows(ZeroList& zl, int B, const Grid& g, const Split16Out& so);   // the rows past N / L (guard tiles) must be zero
-int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax);
+constexpr int DENSE_RERUN_STAT = 11;                                     // word of the call's statistics block that counts the re-run blocks
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
                         float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag(),

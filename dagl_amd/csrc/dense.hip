@@ -11,8 +11,8 @@
 //     S(t+2)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo; three products): the COMPLETE scores of 16 queries x
 //             32 keys (42 multiplies), nothing about S is exchanged between waves.  A lane ends up with 2 x 4 consecutive keys of
 //             one query;
-//     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' an UPPER bound of the row maximum known
-//             before the pass (from the bf16 screen's row maxima; the softmax is shift invariant, nothing is ever rescaled),
+//     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' the row's largest logit, known
+//             before the pass (rowmax_exact_kernel: a top-1 screen + exact rescoring; the softmax is shift invariant, nothing is ever rescaled),
 //             split 2^15 p = hi + lo and handed to the consumers through the LDS in the K-layout of the next MFMA (the only
 //             exchange of the tile).  The ~250 VALU operations of w(t+1) are issued BETWEEN the multiplies of S(t+2) (fenced
 //             slots: fragment reads two slots ahead, three multiplies, a fourteenth of the weights): a short multiply waits ~50
@@ -89,11 +89,14 @@ __device__ __forceinline__ float dn_logit(float s, float mtq, float bsq, bool& p
     return pass ? __fmul_rn(__fmul_rn(s, m), SOFTMAX_SCALE) : 0.f;
 }
 
-// the softmax shift of a row.  First pass: an UPPER bound of its largest logit -- S <= S~max / (1 - DELTA) for the bf16 screen's row
-// maximum S~max, and l grows with S; masked keys have l = 0.  Second pass: the largest logit itself, as the first pass formed it.
+// the softmax shift of a row.  First pass: the logit of smax[q] (rowmax_exact_kernel, screen.hip): the row's largest score -- exact
+// (fp64-accumulated from the fp32 features) where the bf16 bounds of the screen lie more than DN_BOUND_OK logit units apart, their
+// upper bound otherwise -- inflated by 6e-6, more than the split-fp16 products of this kernel can differ from the exact score (three
+// products of 22-bit operands accumulated in fp32: <= 2e-6), so that no weight exceeds 1; l grows with S and masked keys have l = 0.
+// Second pass: the largest logit itself, as the first pass formed it.
 __device__ __forceinline__ float dn_shift(const DenseArgs& a, size_t ql) {
     if (a.pass == 1) return a.m_exact[ql];
-    const float sub = a.smax[ql] * (1.0f / (1.0f - SCREEN_DELTA)) * (1.0f + 1e-6f);
+    const float sub = a.smax[ql] * (1.0f + 6e-6f);
     bool ps;
     return fmaxf(dn_logit(sub, a.mt[ql], a.bs[ql], ps), 0.f);
 }
@@ -231,10 +234,13 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const int qsc = qs < g.L ? qs : g.L - 1;
     const size_t qlin = (size_t)b * g.L + qsc;
     const float mtq = a.mt[qlin], bsq = a.bs[qlin];
-    // upper bound of the row's largest logit: S <= S~max / (1 - DELTA) for the bf16 screen's row maximum S~max, and l grows with S
+    // first pass: the row's shift from rowmax_exact_kernel's score (dn_shift);
     // second pass (see dense_combine_kernel): only the blocks of 64 queries flagged by the first one, shifted by their rows' EXACT largest logit
     if (a.pass == 1 && a.redo_blk[b * n_qblocks + qb] == 0) return;
-    if (a.pass == 0 && split == 0 && tid == 0) a.redo_blk[b * n_qblocks + qb] = 0;      // (set by the first combine, behind this launch)
+    if (a.pass == 0 && split == 0 && tid == 0) {
+        a.redo_blk[b * n_qblocks + qb] = 0;                                              // (set by the first combine, behind this launch)
+        if (blockIdx.x == 0 && b == 0) *a.redo_count = 0;                                // blocks the first combine flags (info->dense_rerun_blocks)
+    }
     const float m_run = dn_shift(a, qlin);
 
     // ---- staging plan (per lane, once) ---------------------------------------------------------------------------------------------
@@ -638,20 +644,21 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
     int deg = has ? a.part_deg[lane * nq + ql] : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); zp += __shfl_xor(zp, o); deg += __shfl_xor(deg, o); ltop = fmaxf(ltop, __shfl_xor(ltop, o)); }
-    // The weights went through the matrix cores as 2^14 e^(l - M') = hi + lo in fp16, M' an UPPER bound of the row's largest logit
-    // from the bf16 scan (within ~2 x 0.8 % of it).  With logits in the thousands that slack alone is tens of units: the largest
-    // weight of the row drops towards the fp16 denormals (2^15 e^-16 = 2^-8 still has 16 significant bits in hi + lo, e^-20 has 10,
-    // below e^-27 every weight is exactly zero and the row would come out as zeros -- measured before this guard: 6e-3 at logits
-    // of 1 700, rows of zeros at 3 300, tools/dense_large_logits.py).  The first pass therefore records every row's largest logit
-    // (the producers form it anyway) and flags the blocks of 64 queries in which some row's slack exceeds DN_SHIFT_SLACK; a second,
-    // gated launch runs exactly those blocks again with the exact maxima as shifts (largest weight = 1: full precision) -- two
-    // launches that exit at once when nothing is flagged.
+    // The weights went through the matrix cores as 2^15 e^(l - M') = hi + lo in fp16.  With the exact row maximum as the shift (round 5)
+    // the largest weight of a row is 1 to rounding.  A shift far ABOVE the maximum pushes the row's weights towards the fp16 denormals
+    // (2^15 e^-16 = 2^-8 still has 16 significant bits in hi + lo, e^-20 has 10, below e^-27 every weight is exactly zero and the row
+    // would come out as zeros; rounds 3-4 used an upper bound from a bf16 scan, ~3 % above a logit in the thousands: 6e-3 off at logits
+    // of 1 700, rows of zeros at 3 300, tools/dense_large_logits.py) -- that only happens to rows with large logits whose candidates
+    // rowmax_exact_kernel could not hold (flat maps).  The guard of round 4 stays as their path: the first pass records every row's largest logit (the producers form
+    // it anyway) and flags the blocks of 64 queries in which some row's slack exceeds DN_SHIFT_SLACK; a second, gated launch runs
+    // exactly those blocks again with the recorded maxima as shifts -- two launches that exit at once when nothing is flagged.
     const int n_qblocks = (a.g.L + 63) / 64;
     const int bq = (int)(ql / a.g.L), qin = (int)(ql - (size_t)bq * a.g.L);
     if (a.pass == 1 && a.redo_blk[bq * n_qblocks + qin / 64] == 0) return;      // (second combine: the rows of re-run blocks only)
     if (a.pass == 0 && lane == 0) {
         a.m_exact[ql] = ltop;                                                      // (>= 0: masked keys have l = 0, and so has an empty row)
-        if (deg > 0 && M - ltop > DN_SHIFT_SLACK) a.redo_blk[bq * n_qblocks + qin / 64] = 1;
+        // (an empty row too: its masked keys' e^(0 - M) must not vanish either)
+        if (M - ltop > DN_SHIFT_SLACK && atomicExch(&a.redo_blk[bq * n_qblocks + qin / 64], 1) == 0) atomicAdd(a.redo_count, 1);
     }
     const float invz = (float)(1.0 / z);
     float4 acc[4];
@@ -703,24 +710,6 @@ __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const flo
     const size_t o = (((size_t)b * rows_out + r) * DSH + 8 * c8) / 8;
     reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(vh);
     reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(vl);
-}
-
-// row maximum of the screened scores: gmax holds, per query, the 4 largest values of each of its G/4 scan segments
-__global__ void dense_rowmax_kernel(size_t n_rows, int G, const float* __restrict__ gmax, float* __restrict__ smax) {
-    const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    float m = 0.f;
-    for (int t = lane; t < G; t += 64) m = fmaxf(m, gmax[row * G + t]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) smax[row] = m;
-}
-
-int launch_dense_rowmax(hipStream_t s, size_t n_rows, int G, const float* gmax, float* smax) {
-    hipLaunchKernelGGL(dense_rowmax_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, n_rows, G, gmax, smax);
-    DAGL_LAUNCH_CHECK("dense_rowmax_kernel");
-    return DAGL_OK;
 }
 
 int dense_splits(int B, const Grid& g) {
@@ -817,6 +806,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     const DnCarve c = dn_carve(ws, B, g);
     a.part_acc = c.part_acc; a.part_m = c.part_m; a.part_z = c.part_z; a.part_deg = c.part_deg;
     a.m_exact = c.m_exact; a.redo_blk = c.redo_blk; a.pass = 0;
+    a.redo_count = reinterpret_cast<int32_t*>(stats + DENSE_RERUN_STAT);
     uint16_t *xh = c.xh, *xl = c.xl, *qh = c.qh, *ql = c.ql, *vh = c.vh, *vl = c.vl;
     a.v_hi = vh; a.v_lo = vl;
     a.x_hi = xh; a.x_lo = xl; a.wq_hi = qh; a.wq_lo = ql;

@@ -71,7 +71,10 @@ __device__ __forceinline__ void load_query_fragments(const ScreenArgs& a, int b,
 // DESIGN.md section 7 lists what was tried to close that gap.
 // VAR (ablation builds only, results wrong by construction): 1 no tile DMA, 2 no MFMA, 4 no test, 8 theta = inf, 16 key
 // fragments from registers, 32 no barrier, 64 accumulators carried across steps.
-template <int PASS, int QW, int VAR, int SCR_QUERIES = 256>
+// SMAX (filter pass only): the segment's header also carries the largest screened score among its candidates (ScreenArgs::seg_max:
+// the dense formulation's row maxima, rowmax_exact_kernel) -- a template parameter so that the top-k / adaptive filters keep their
+// register budget untouched
+template <int PASS, int QW, int VAR, int SCR_QUERIES = 256, bool SMAX = false>
 __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1) void screen_kernel(ScreenArgs a, int n_qgroups) {
     if (a.gate != nullptr && *a.gate == 0) return;                 // (a re-run launch of a cold workspace that is not needed)
     if (a.policy != nullptr && *a.policy != 0) { a.capseg = a.capseg_tight; a.sample = a.sample_tight; }   // device-side threshold policy
@@ -133,6 +136,9 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
     for (int w = 0; w < QW; ++w)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gm[w][r] = -1.0f;
+    float smx[QW];                                    // SMAX: largest screened score among this lane's (= this segment's) candidates
+#pragma unroll
+    for (int w = 0; w < QW; ++w) smx[w] = -1.0f;
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&sK[0][0]));
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
                 if (__any(fmaxf(mxt[0], mxt[1]) >= thq[w])) {
                     // ~3 of 4 wave-steps hold a candidate somewhere in their 2048 scores, so this path matters: one tile at a
                     // time, two VALU per score (sign of thlo - S~, shifted into the lane's mask by v_alignbit)
+                    if (SMAX) smx[w] = fmaxf(smx[w], fmaxf(mxt[0], mxt[1]));       // (a tile maximum below theta is below every candidate)
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) {
                         if (!__any(mxt[tl] >= thq[w])) continue;
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += gm[w][r];
                 if (t == 12345.f) n_loc[w] = 1; }
-            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], 0);
+            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], SMAX ? __float_as_int(smx[w]) : 0);
         }
     }
     dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -312,7 +319,7 @@ constexpr int RING_FLAG_BYTES = 64;
 // QW = query tiles of 32 per wave: 1 = 16 waves x 32 queries (four waves per SIMD, 128 registers), 2 = 8 waves x 64 queries (two per
 // SIMD, 256 registers: every key fragment read from the LDS feeds two multiplies -- half the LDS traffic, requests and flag
 // words per multiply)
-template <int PASS, int WAVES, int VAR = 0, int QW = 1>
+template <int PASS, int WAVES, int VAR = 0, int QW = 1, bool SMAX = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a, int n_qgroups) {
     if (a.gate != nullptr && *a.gate == 0) return;                 // (a re-run launch of a cold workspace that is not needed)
     if (a.policy != nullptr && *a.policy != 0) { a.capseg = a.capseg_tight; a.sample = a.sample_tight; }   // device-side threshold policy
@@ -367,6 +374,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
     for (int w = 0; w < QW; ++w)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gm[w][r] = -1.0f;
+    float smx[QW];                                    // SMAX: largest screened score among this lane's (= this segment's) candidates
+#pragma unroll
+    for (int w = 0; w < QW; ++w) smx[w] = -1.0f;
 
     const unsigned short* xb = a.xh + (size_t)b * a.rows_xh * DSH;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(&smem[0]));
@@ -489,6 +499,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                     mxt[tl] = m;
                 }
                 if (__any(fmaxf(mxt[0], mxt[1]) >= thq[w])) {
+                    if (SMAX) smx[w] = fmaxf(smx[w], fmaxf(mxt[0], mxt[1]));       // (a tile maximum below theta is below every candidate)
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) {
                         if (!__any(mxt[tl] >= thq[w])) continue;
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
             if (qvalid[w]) *reinterpret_cast<float4*>(a.gmax + seg[w] * GKEEP) = make_float4(top[0], top[1], top[2], top[3]);
         } else {
             if ((VAR & 16) && gm[w][0] == 12345.f) n_loc[w] = 1;      // (keeps the ablated loop's accumulators alive)
-            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], 0);
+            if (qvalid[w]) cseg[w][-(a.splits * 2)] = make_int2(n_loc[w], SMAX ? __float_as_int(smx[w]) : 0);
         }
     }
     if (!(VAR & 64)) dbg_stamp(a.times, blockIdx.y * gridDim.x + blockIdx.x, 3);
@@ -920,6 +931,13 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
         case 72: SCR_LAUNCH(P_, Q_, 72); break;                          \
         default: SCR_LAUNCH(P_, Q_, 7); break;                           \
     }
+    if (pass == 1 && a.seg_max) {
+        if (qblock == 512) hipLaunchKernelGGL((screen_ring_kernel<1, 16, 0, 1, true>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else if (qblock == 384) hipLaunchKernelGGL((screen_ring_kernel<1, 12, 0, 1, true>), grid, dim3(768), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 256, true>), grid, dim3(512), 0, s, a, n_qgroups);
+        DAGL_LAUNCH_CHECK("screen_kernel");
+        return DAGL_OK;
+    }
     static const int qw = [] { const char* e = getenv("DAGL_SCREEN_QW"); return e ? atoi(e) : 1; }();
     const size_t n_blk = (size_t)grid.x * grid.y;
     const bool ring_phases = a.variant == 64 && qblock == 512;             // per-wave phase clocks: 16 waves x 5 sums per block
@@ -961,6 +979,11 @@ int launch_screen(hipStream_t s, const ScreenArgs& a, int pass) {
 #else
     // blocks that are alone on their CU (512 / 384 queries): the ring form; 256-query blocks (two per CU, small images) keep
     // the barrier form -- two five-deep rings do not fit one CU's LDS
+    if (pass == 1 && a.seg_max) {                    // (the dense formulation's top-1 screen: segment headers carry their maxima)
+        if (qblock == 512) hipLaunchKernelGGL((screen_ring_kernel<1, 16, 0, 1, true>), grid, dim3(1024), 0, s, a, n_qgroups);
+        else if (qblock == 384) hipLaunchKernelGGL((screen_ring_kernel<1, 12, 0, 1, true>), grid, dim3(768), 0, s, a, n_qgroups);
+        else hipLaunchKernelGGL((screen_kernel<1, 1, 0, 256, true>), grid, dim3(512), 0, s, a, n_qgroups);
+    } else
     if (qblock == 512) {
         if (pass == 0) hipLaunchKernelGGL((screen_ring_kernel<0, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
         else hipLaunchKernelGGL((screen_ring_kernel<1, 16>), grid, dim3(1024), 0, s, a, n_qgroups);
@@ -1437,6 +1460,133 @@ __global__ __launch_bounds__(64 * RF_HEAVY_WAVES) void refine_heavy_kernel(Refin
         refine_query<true>(a, (size_t)a.heavy_list[slot], c_idx, c_val, &sh_total);
         __syncthreads();                                     // wave 0 is done with the candidate arrays
     }
+}
+
+// ---- dense formulation: the softmax shift of every row (dense_attend_kernel), tight -------------------------------------------
+// The streamed dense formulation needs each row's shift before its pass over the keys, and its weights e^(l - shift) travel as fp16
+// pairs: the shift may exceed the row's largest logit by ~18 units at most (dense.hip DN_SHIFT_SLACK).  Up to round 4 it was an
+// upper bound from a full bf16 scan -- within 2 x 0.8 % of the largest SCORE, i.e. ~3 % of a logit that is quadratic in S: fine for
+// logits of tens (trained features), beyond ~580 the rows' weights sank towards the fp16 denormals and whole 64-query blocks were
+// run a second time (every block of bench.py's own default map: 1.52 ms for the advertised 0.81).
+// Now: a top-1 screen -- sampled pass -> theta = the largest sampled S~ less the band (screen_theta_kernel, k = 1) -> filter pass
+// with ScreenArgs::seg_max -- gives, per row, the largest screened score of ALL keys (every key above theta is seen by the filter,
+// recorded or not, and the row maximum is above theta) and the candidates near it.  One wave per query:
+//   * bounds  S~max / (1 + DELTA) <= max S <= S~max / (1 - DELTA)  ->  logit bounds; when they lie within DN_BOUND_OK units the upper
+//     bound IS the shift (nothing to rescore: natural-image rows have thousands of keys inside the band and logits of tens);
+//   * otherwise the candidates whose upper bound reaches the best lower bound x (1 - DELTA) / (1 + DELTA) (the true arg-max is among
+//     them: DESIGN.md "The bf16 screen is conservative") are rescored from the fp32 features with fp64 accumulation: the exact maximum;
+//   * a row with large logits whose candidates did not fit (flat maps) keeps the upper bound -- the first pass records its exact
+//     maximum and dense_combine_kernel flags its block for the second pass: the round-4 mechanism, now the fallback of the fallback.
+// Output: smax[q] = a score whose logit (dense.hip dn_shift) is the row's shift.
+constexpr float DN_BOUND_OK = 12.0f;
+__device__ __forceinline__ float rm_logit(float sc, float mtq, float bsq) {
+    const float m = (sc - mtq) + bsq;                     // dagl.py:256, the expression order of dense.hip dn_logit
+    return m > 0.f ? __fmul_rn(__fmul_rn(sc, m), SOFTMAX_SCALE) : 0.f;
+}
+__global__ __launch_bounds__(256) void rowmax_exact_kernel(RefineArgs a, float* __restrict__ smax) {
+    __shared__ int c_idx[4][RF_MAX_CAND];
+    __shared__ float c_val[4][RF_MAX_CAND];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t ql = (size_t)blockIdx.x * 4 + w;
+    if (ql >= (size_t)a.B * a.L) return;                   // no block-level sync below
+    int* ci = c_idx[w]; float* cv = c_val[w];
+    const int b = (int)(ql / a.L);
+    const int S2 = a.splits * 2;
+    const float thq = a.theta[ql];
+    // 1. segment headers: candidate counts and the segments' largest screened scores
+    float sm = 0.f;
+    bool overflow = false;
+    int total = 0;
+    for (int s0 = 0; s0 < S2; s0 += 64) {
+        const int sgi = s0 + lane;
+        const int2 hdr = (sgi < S2) ? a.cand[ql * (size_t)a.capseg * S2 + sgi] : make_int2(0, 0);
+        if (hdr.x > 0) sm = fmaxf(sm, __int_as_float(hdr.y));
+        if (hdr.x > a.capseg - 1) overflow = true;          // (the filter ran without a spill area: further records are lost)
+        total += wave_sum_i32(min(hdr.x, a.capseg - 1));
+    }
+    sm = wave_max_f32(sm);
+    overflow = __any(overflow) || total > RF_MAX_CAND;
+    const float s_hi = sm * (1.0f / (1.0f - DELTA)) * (1.0f + 1e-6f), s_lo = sm * (1.0f / (1.0f + DELTA));
+    const float mtq = a.mt[ql], bsq = a.bs[ql];
+    if (overflow || rm_logit(s_hi, mtq, bsq) - rm_logit(s_lo, mtq, bsq) <= DN_BOUND_OK) {      // (wave-uniform)
+        if (lane == 0) smax[ql] = s_hi;
+        return;
+    }
+    // 2. the candidates, segment by segment (lane <-> segment)
+    const int grp = lane >> 3, gl = lane & 7;
+    const float* qrow = a.wq + ((size_t)b * a.rows_q + (ql - (size_t)b * a.L)) * DS;
+    float4 qv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int c4 = gl + 8 * u;
+        const float4 raw = *reinterpret_cast<const float4*>(qrow + 4 * (c4 < D / 4 ? c4 : D / 4 - 1));
+        qv[u] = (c4 < D / 4) ? raw : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    total = 0;
+    for (int s0 = 0; s0 < S2; s0 += 64) {
+        const int sgi = s0 + lane;
+        const bool sv = sgi < S2;
+        const int2* rec = a.cand + ql * (size_t)a.capseg * S2 + (sv ? sgi : 0);
+        const int cnt = sv ? rec[0].x : 0;
+        const int incl = wave_scan_incl_i32(cnt);
+        const int off = total + incl - cnt;
+        for (int e = 0; e < cnt; ++e) {
+            const int2 c = rec[(size_t)(1 + e) * S2];
+            ci[off + e] = c.x; cv[off + e] = __int_as_float(c.y);
+        }
+        total += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __threadfence_block();
+    // 3. the best lower bound among the candidates; those whose upper bound cannot reach it are dropped before any row is fetched
+    float lb = -1.0f;
+    for (int c = lane; c < total; c += 64) { const float sv = cv[c]; lb = fmaxf(lb, (sv >= 0.f) ? sv : thq); }
+    lb = wave_max_f32(lb);
+    const float cut = lb * ((1.0f - DELTA) / (1.0f + DELTA)) * (1.0f - 1e-6f);
+    int base = 0;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + lane;
+        const bool have = c < total;
+        const int key = have ? ci[c] : -1;
+        const bool keep = have && fabsf(cv[c]) >= cut && key < a.N;          // (zero rows past N may pass a degenerate theta)
+        const unsigned long long bal = __ballot(keep);
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) ci[pos] = key;                                             // pos <= c: only slots that have been read
+        base += __popcll(bal);
+    }
+    total = base;
+    __threadfence_block();
+    // 4. exact scores: 8 groups of 8 lanes, one candidate per group per round, fp64 accumulation; the largest
+    const float* xb = a.x + (size_t)b * a.rows_x * DS;
+    double best = 0.0;                                     // (scores are >= 0: post-ReLU features)
+#pragma unroll 2
+    for (int c0 = 0; c0 < total; c0 += 8) {
+        const int c = c0 + grp;
+        const bool okc = c < total;
+        const float* xrow = xb + (size_t)(okc ? ci[c] : 0) * DS;
+        float4 xv[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int c4 = gl + 8 * u;
+            xv[u] = *reinterpret_cast<const float4*>(xrow + 4 * (c4 < D / 4 ? c4 : 0));
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+            acc += (double)qv[u].x * (double)xv[u].x + (double)qv[u].y * (double)xv[u].y +
+                   (double)qv[u].z * (double)xv[u].z + (double)qv[u].w * (double)xv[u].w;
+        acc += dpp_zero_d<0xB1>(acc); acc += dpp_zero_d<0x4E>(acc); acc += dpp_zero_d<0x141>(acc);
+        if (okc && gl == 0) best = fmax(best, acc);
+    }
+    best = wave_max_f64(best);
+    if (lane == 0) smax[ql] = (float)best;
+}
+
+int launch_rowmax_exact(hipStream_t s, const RefineArgs& a, float* smax) {
+    if (a.splits * 2 > RF_MAX_CAND) { set_error("rowmax_exact: too many segments"); return DAGL_ERR_INVALID; }
+    const size_t nq = (size_t)a.B * a.L;
+    hipLaunchKernelGGL(rowmax_exact_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, a, smax);
+    DAGL_LAUNCH_CHECK("rowmax_exact_kernel");
+    return DAGL_OK;
 }
 
 // total / max degree over all queries: one block (a same-address atomic per query would serialise ~12 ns each)

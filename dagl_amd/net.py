@@ -147,6 +147,33 @@ class RR(nn.Module):
     def forward(self, x):
         return x + self.tail(self.body(self.head(x)))
 
+    def load_state_dict(self, state_dict, strict=True):
+        """The reference network's own loader rule (``dagl.py:56-73``), which is NOT torch's: checkpoint entries are
+        copied in place into the tensors this network owns; an entry whose shape does not fit raises ``RuntimeError``
+        and an entry this network does not know raises ``KeyError`` (``strict`` only) -- unless its name contains
+        ``tail``: the reference fine-tunes a gray checkpoint into an ``n_colors = 3`` network (and back) that way, so
+        anything about the last convolution is tolerated.  Keys the checkpoint lacks are never an error.  Returns
+        ``None`` like the reference."""
+        own = self.state_dict()
+        for name, value in state_dict.items():
+            tolerated = "tail" in name
+            if name not in own:
+                if strict and not tolerated:
+                    raise KeyError(f'unexpected key "{name}" in state_dict')
+                continue
+            src = value.data if isinstance(value, nn.Parameter) else value
+            try:
+                with torch.no_grad():
+                    own[name].copy_(src)          # shares storage (and version counter) with the parameter / buffer
+            except Exception:
+                if not tolerated:
+                    raise RuntimeError(
+                        f"While copying the parameter named {name}, whose dimensions in the model are "
+                        f"{tuple(own[name].shape)} and whose dimensions in the checkpoint are {tuple(src.shape)}.")
+        for m in self.modules():                  # packed / converted weight copies of the heads follow the new values
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
+
 
 def seeded_state_dict(template: "OrderedDict[str, torch.Tensor]", seed: int) -> "OrderedDict[str, torch.Tensor]":
     """Regenerable stand-in for a trained checkpoint (none ships with the reference): every tensor of ``template`` in

@@ -15,6 +15,11 @@ from . import _lib
 from ._lib import DS, MODES, P, DaglError, check
 
 
+# A/B switch (tests, bench.py --dense-backward fp32): the dense graph core's backward with its five matrix products on the fp32
+# matrix cores.  An explicit attribute, not an environment variable: nothing outside the process can change gradient bits.
+DENSE_BACKWARD_FP32 = False
+
+
 def _stream() -> int:
     """torch's current stream ON THE CURRENT DEVICE -- every entry point below runs under ``_on_device`` which makes the
     tensors' device current first (the C ABI launches on the current HIP device)."""
@@ -296,7 +301,7 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
     check(rc, "dagl_ce_forward")
     meta = dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
                 max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries,
-                range_fallback=info.range_fallback)
+                range_fallback=info.range_fallback, dense_rerun_blocks=info.dense_rerun_blocks)
     if dbg is not None:
         meta.update(dbg)
     if return_info or debug:
@@ -397,7 +402,7 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
         return out, None
     return out, dict(required_bytes=info.required_bytes, total_edges=info.total_edges,
                      max_degree=info.max_degree, path=info.path, redone_queries=info.redone_queries,
-                     range_fallback=info.range_fallback)
+                     range_fallback=info.range_fallback, dense_rerun_blocks=info.dense_rerun_blocks)
 
 
 def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> int:
@@ -511,7 +516,8 @@ def ce_core_forward(wq_rows, x_rows, b2, thr, bias, mode: str = "adaptive", k: i
                                   saved["mu"].data_ptr() if adaptive else None, a, nbytes, C.byref(info))
     check(rc, "dagl_ce_core_forward")
     saved["info"] = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=info.path,
-                         redone_queries=info.redone_queries, range_fallback=info.range_fallback)
+                         redone_queries=info.redone_queries, range_fallback=info.range_fallback,
+                         dense_rerun_blocks=info.dense_rerun_blocks)
     return out, saved
 
 
@@ -612,7 +618,7 @@ def ce_core_dense_forward(wq_rows, x_rows, b2, thr, bias, workspace: "Workspace 
                                          lse.data_ptr(), mu.data_ptr(), a, nbytes, C.byref(info) if want_info else None),
           "dagl_ce_core_dense_forward")
     meta = dict(total_edges=info.total_edges, max_degree=info.max_degree, path=5, redone_queries=-1,
-                range_fallback=info.range_fallback) if want_info else None
+                range_fallback=info.range_fallback, dense_rerun_blocks=info.dense_rerun_blocks) if want_info else None
     return out, dict(lse=lse, mu=mu, info=meta)
 
 
@@ -621,7 +627,7 @@ def ce_core_dense_backward(d_out, wq_rows, x_rows, b2, thr, bias, saved: dict, w
                            exact: bool = False):
     """Gradients of the dense graph core (``dagl_ce_core_dense_backward``) -> (d_wq_rows, d_x_rows, d_b2, d_thr, d_bias).
     ``exact``: the five matrix products on the fp32 matrix cores instead of the fp16 ones with split operands."""
-    exact = exact or os.environ.get("DAGL_DENSE_BACKWARD", "") == "fp32"
+    exact = exact or DENSE_BACKWARD_FP32
     lib = _lib.load()
     for n, t in (("d_out", d_out), ("wq_rows", wq_rows), ("x_rows", x_rows), ("b2", b2), ("thr", thr), ("bias", bias)):
         _need(t, n)

@@ -168,8 +168,9 @@ def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b,
     return d_map, d_w, d_b
 
 
-# tests / A-B runs: the unfold + GEMM + fold backward of g / theta on every shape (DAGL_PROLOGUE_BACKWARD=unfold)
-_FORCE_UNFOLD_BACKWARD = os.environ.get("DAGL_PROLOGUE_BACKWARD", "") == "unfold"
+# tests / A-B runs (bench.py --prologue-backward unfold): the unfold + GEMM + fold backward of g / theta on every shape.  An explicit
+# attribute, not an environment variable: nothing outside the process can change gradient bits.
+_FORCE_UNFOLD_BACKWARD = False
 
 
 class _PrologueConvs(torch.autograd.Function):
@@ -302,6 +303,8 @@ class _PReLU1(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
+        if dy.data_ptr() % 16:                     # (a contiguous view at an odd storage offset: the kernel moves float4s)
+            dy = dy.clone()
         lib = _lib.load()
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x)
@@ -317,8 +320,9 @@ class PReLU(torch.nn.PReLU):
     fp32 GPU calls run on the HIP library; anything else (CPU, half precision, per-channel slopes, odd sizes) takes torch's path."""
 
     def forward(self, x):
+        # (the kernels move float4s: contiguous views at an odd storage offset take torch's path like any other unsupported input)
         if (x.is_cuda and x.dtype == torch.float32 and self.weight.numel() == 1 and self.weight.dtype == torch.float32
-                and x.numel() % 4 == 0 and x.numel() > 0):
+                and x.numel() % 4 == 0 and x.numel() > 0 and x.is_contiguous() and x.data_ptr() % 16 == 0):
             return _PReLU1.apply(x, self.weight)
         return super().forward(x)
 

@@ -129,7 +129,8 @@ typedef struct dagl_ce_info {
                                  6 = top-k modes with min(k, N) > DAGL_MAX_TOPK: row-wise dense form (no lists) */
     int32_t range_fallback;   /* 1 = an operand left the range of the split-fp16 kernels (|activation| >= 3750, see
                                  below) and the call was re-run on the fp32 path (DAGL_FLAG_EXACT_SCAN)  */
-    int32_t reserved;
+    int32_t dense_rerun_blocks; /* path 4 / 5: blocks of 64 queries the streamed dense formulation ran a second time (rows whose
+                                 exact maximum the top-1 screen could not serve: flat maps); 0 otherwise (ABI 404; was `reserved`) */
 } dagl_ce_info;
 
 /* Range of the default (split-fp16) path: |x|, |b1| < 3750, |w_conv| < 234, |w_fc| < 58, |features| < 937 in the dense
@@ -150,9 +151,10 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
  * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64; round 4: DAGL_FLAG_SAMPLED_TOPK,
- * the workspace layout carries the top-k policy words; 403: dagl_ce_core_wide_forward / _backward).  A caller compares
+ * the workspace layout carries the top-k policy words; 403: dagl_ce_core_wide_forward / _backward; 404:
+ * dagl_ce_info.dense_rerun_blocks in the place of `reserved`).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 403
+#define DAGL_ABI_VERSION 404
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */

@@ -89,3 +89,41 @@ def test_forward_x8_is_exact_for_an_equivariant_network():
     seen = []
     forward_x8(lambda t: (seen.append(tuple(t.shape[-2:])), t)[1], x)
     assert len(seen) == 8 and seen.count((12, 20)) == 4 and seen.count((20, 12)) == 4
+
+
+def test_rr_load_state_dict_follows_the_reference_rule_for_tail_keys():
+    """``RR.load_state_dict`` is the reference's own loader (DN_Gray/model/dagl.py:56-73), not torch's: a gray
+    checkpoint loads into an ``n_colors = 3`` network (the fine-tune route: the ``tail.*`` shapes differ and are
+    skipped, ``head.*`` is NOT tolerated), unknown ``tail`` keys pass even under ``strict``, other unknown keys raise
+    ``KeyError`` only under ``strict``, keys the checkpoint lacks never raise, the return value is ``None``."""
+    import pytest
+    from dagl_amd.net import RR, seeded_state_dict
+    gray = RR(n_resblocks=2, n_colors=1, ce_cls=_StubCE)
+    ckpt = seeded_state_dict(gray.state_dict(), 3)
+    color = RR(n_resblocks=2, n_colors=3, ce_cls=_StubCE)
+    before = {k: v.clone() for k, v in color.state_dict().items()}
+
+    # head.0.weight is [64,1,3,3] in the checkpoint and [64,3,3,3] here: copy_ broadcasts it (as in the reference);
+    # tail.0.weight [1,64,3,3] -> [3,64,3,3] broadcasts too; tail.0.bias [1] -> [3] as well.  A shape that cannot be
+    # broadcast is what the rule is about:
+    bad = dict(ckpt)
+    bad["tail.0.weight"] = torch.zeros(5, 64, 3, 3)
+    bad["tail.9.extra"] = torch.zeros(2)                     # unknown, but a tail key: tolerated under strict
+    assert color.load_state_dict(bad, strict=True) is None
+    after = color.state_dict()
+    assert torch.equal(after["tail.0.weight"], before["tail.0.weight"])          # skipped, left as it was
+    assert torch.equal(after["body.0.body.0.weight"], ckpt["body.0.body.0.weight"])
+    assert torch.equal(after["head.0.weight"], ckpt["head.0.weight"].expand(64, 3, 3, 3))
+
+    worse = dict(ckpt)
+    worse["head.0.weight"] = torch.zeros(5, 1, 3, 3)          # a mismatch anywhere else raises
+    with pytest.raises(RuntimeError, match="head.0.weight"):
+        color.load_state_dict(worse)
+    extra = dict(ckpt)
+    extra["body.77.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError, match="body.77.weight"):
+        color.load_state_dict(extra, strict=True)
+    assert color.load_state_dict(extra, strict=False) is None
+    partial = {k: v for k, v in ckpt.items() if not k.startswith("body.1.")}    # missing keys: never an error
+    assert color.load_state_dict(partial, strict=True) is None
+    assert gray.load_state_dict({k: nn.Parameter(v) for k, v in ckpt.items()}) is None      # Parameters are accepted

@@ -52,7 +52,8 @@ for name in names:
             ce(x)
         info = ce.last_info or {}
         print(f"{name} head {hn} whole 256x256 map: {ms:.4f} ms  path {info.get('path')}  "
-              f"mask density {info.get('total_edges', 0) / (4096 * 65536):.3f}  max degree {info.get('max_degree')}", flush=True)
+              f"mask density {info.get('total_edges', 0) / (4096 * 65536):.3f}  max degree {info.get('max_degree')}  "
+              f"re-run blocks {info.get('dense_rerun_blocks')}", flush=True)
     # the leaf tiles of the reference's forward_chop as one batch
     boxes = chop_leaf_boxes(256, 256)
     with torch.no_grad():
@@ -70,4 +71,4 @@ for name in names:
     B, _, H, W = xt.shape
     L = -(-H // 4) * -(-W // 4)
     print(f"{name} head c1_1 leaf tiles {tuple(xt.shape)}: {ms:.4f} ms  path {info.get('path')}  "
-          f"mask density {info.get('total_edges', 0) / (B * L * H * W):.3f}", flush=True)
+          f"mask density {info.get('total_edges', 0) / (B * L * H * W):.3f}  re-run blocks {info.get('dense_rerun_blocks')}", flush=True)
