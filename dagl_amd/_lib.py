@@ -30,6 +30,7 @@ FLAG_DENSE_HINT = 0x400
 FLAG_NO_WAIT = 0x800
 FLAG_TIGHT_TOPK = 0x1000
 FLAG_SAMPLED_TOPK = 0x2000
+FLAG_NO_REDO = 0x4000
 
 
 class DaglError(RuntimeError):

@@ -200,6 +200,15 @@ class CE(nn.Module):
         # HIP-graph replay): sampled until any query of a call overflows (a full segment spills into the query's shared area first),
         # tight from then on; the first call of a shape re-runs tight in-stream; maps of <= 16 384 keys start tight.
         self.topk_threshold = "auto"
+        # Top-k modes behind the screen: "always" = every call queues the fp32 redo pass for query groups whose candidate slots
+        # overflowed (a launch that finds nothing on a warm workspace: 4.7 us of a 0.23 ms call); "auto" (default) = once a poll of
+        # the workspace (every 64th call, as for the range word) has found the last call without redo work, identical calls (same
+        # shape, weights, workspace) go without the launch (DAGL_FLAG_NO_REDO) and the workspace is polled every 32nd call; a call
+        # that flags a group after all returns NaN -- never wrong numbers --, the next poll reports it and the module queues the
+        # pass again from then on.  Not under HIP-graph capture (a replayed graph is never polled).
+        self.topk_redo = "auto"
+        self._redo_skip = False        # the last poll found no redo work
+        self._redo_banned = False      # a no-redo call went unserved once: never again on this module
         self._served_streak = 0
         self._served_streaks = {}      # the same for adaptive_sync = "auto"
         self._served_shape = None
@@ -233,6 +242,14 @@ class CE(nn.Module):
         shape, dev = self._last_call
         bad = ops.ce_range_check(shape, self.select_mode, min(int(self.select_k), shape[2] * shape[3]) if self.select_mode != "adaptive" else 0,
                                  self._ws, dev)
+        if self.select_mode != "adaptive":
+            if bad & 16:
+                import warnings
+                warnings.warn("dagl_amd.CE: a top-k call that went without the fp32 redo pass (topk_redo = 'auto') met query groups whose "
+                              "candidate slots overflowed: its output is NaN-filled; this module queues the pass again from now on")
+                self._redo_banned, self._redo_skip = True, False
+            else:
+                self._redo_skip = not (bad & 4) and not self._redo_banned
         if bad & 2:
             import warnings
             warnings.warn("dagl_amd.CE: an adaptive call that did not wait for its verdict met neighbourhoods the in-stream kernels "
@@ -240,7 +257,7 @@ class CE(nn.Module):
             self._served_streak = 0
         if bad & 1:
             self._note_range_violation("a call left the split-fp16 range (its output is NaN-filled)")
-        return not (bad & 3)
+        return not (bad & 19)
 
     def _note_range_violation(self, what):
         import warnings
@@ -516,12 +533,18 @@ class CE(nn.Module):
         if self.topk_threshold not in ("auto", "full", "sparse"):
             raise DaglError(f"CE.topk_threshold {self.topk_threshold!r}: expected 'auto', 'full' or 'sparse'")
         topk_screen = self.select_mode != "adaptive" and self.scan != "exact"
+        if self.topk_redo not in ("auto", "always"):
+            raise DaglError(f"CE.topk_redo {self.topk_redo!r}: expected 'auto' or 'always'")
+        no_redo = (topk_screen and self.topk_redo == "auto" and self._redo_skip and not self._redo_banned and key == self._pack_key
+                   and not torch.cuda.is_current_stream_capturing())
+        if key != self._pack_key:
+            self._redo_skip = False                # another shape / weights / workspace: what the last poll saw no longer applies
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),
                                          dense_hint=hint, want_info=want_info, no_wait=no_wait,
                                          tight_topk=topk_screen and self.topk_threshold == "full",
-                                         sampled_topk=topk_screen and self.topk_threshold == "sparse")
+                                         sampled_topk=topk_screen and self.topk_threshold == "sparse", no_redo=no_redo)
         self._pack_key = key[:-1] + (self._ws.peek(b.device).data_ptr(),)
         self._last_call = (tuple(b.shape), b.device)
         if no_wait:
@@ -538,7 +561,7 @@ class CE(nn.Module):
             # no host round trip in the top-k modes: look at the range word every 64th call (one synchronisation); a call
             # that left the range has returned NaN (never wrong numbers), the module moves to the fp32 path from here on
             self._calls_since_range_check += 1
-            if self._calls_since_range_check >= 64 and not torch.cuda.is_current_stream_capturing():
+            if self._calls_since_range_check >= (32 if no_redo else 64) and not torch.cuda.is_current_stream_capturing():
                 self.range_ok()
         if info is not None:
             self.last_info = info

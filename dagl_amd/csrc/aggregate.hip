@@ -287,8 +287,12 @@ __global__ __launch_bounds__(256) void aggregate_fold_kernel(AggArgs a, float* _
     // pixels in row-major order over the whole map (a block per row left 44 % of the lanes idle on a 72-pixel leaf tile)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int pix = t >> 2, u = t & 3;
-    const bool poisoned = range.word != nullptr && *range.word == range.tag;
+    bool poisoned = range.word != nullptr && *range.word == range.tag;
     if (range.done != nullptr && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) *range.done = range.tag;
+    if (a.unserved != nullptr && *a.unserved != 0) {        // DAGL_FLAG_NO_REDO: flagged query groups and no redo pass behind them
+        poisoned = true;
+        if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) *a.unserved_sticky = 1;
+    }
     if (pix >= g.N) return;
     const int y = pix / g.W, x = pix - y * g.W;
     int r0 = (y - 3 + QS - 1) / QS; if (y - 3 < 0) r0 = 0;

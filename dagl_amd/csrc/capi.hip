@@ -30,7 +30,7 @@ __global__ void retag_kernel(int32_t* word, int32_t* veto, int32_t tag) {
 // two shapes forgot "tight" on every call and paid sampled pass + policy kernel + tight re-run each time.  The learnt word now
 // survives as long as the workspace still carries the cookie of this very geometry (a fresh or re-used buffer does not).
 __global__ void policy_init_kernel(int64_t* stats, int64_t cookie, int32_t start_tight) {
-    if (stats[12] != cookie) { stats[9] = start_tight; stats[12] = cookie; }
+    if (stats[12] != cookie) { stats[9] = start_tight; stats[12] = cookie; stats[13] = 0; }     // ([13]: sticky "a DAGL_FLAG_NO_REDO call went unserved")
     stats[10] = 0;
 }
 
@@ -127,7 +127,7 @@ struct Plan {
     size_t o_wide = 0;
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
-        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_smax, o_scand, o_spill, o_spillcnt,
+        o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_smax, o_traw, o_scand, o_spill, o_spillcnt,
         o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
@@ -146,7 +146,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     const int mode = mode_flags & 0xff;
     const bool exact = (mode_flags & DAGL_FLAG_EXACT_SCAN) != 0;
     DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl: bad shape B=%d H=%d W=%d", B, H, W);
-    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK | DAGL_FLAG_SAMPLED_TOPK)) == 0 &&
+    DAGL_REQUIRE((mode_flags & ~(0xff | DAGL_FLAG_EXACT_SCAN | DAGL_FLAG_WEIGHTS_PACKED | DAGL_FLAG_DENSE_HINT | DAGL_FLAG_NO_WAIT | DAGL_FLAG_TIGHT_TOPK | DAGL_FLAG_SAMPLED_TOPK | DAGL_FLAG_NO_REDO)) == 0 &&
                  (mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK),
                  "dagl: unknown mode 0x%x", mode_flags);
     if (mode != DAGL_MODE_ADAPTIVE) DAGL_REQUIRE(k >= 1, "dagl: k=%d < 1", k);
@@ -287,7 +287,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
         p.o_convw = carve(off, 4 * CONV_W16_BYTES);                                       // packed g / theta weights per head
         p.o_colpart = carve(off, (size_t)B * project16_key_blocks(g) * 224 * sizeof(float));
     }
-    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_smax = p.o_spill = p.o_spillcnt = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
+    p.o_xh = p.o_wqh = p.o_gmax = p.o_theta = p.o_smax = p.o_traw = p.o_spill = p.o_spillcnt = p.o_scand = p.o_scandv = p.o_ssegcnt = p.o_redo = 0;
     if (p.screen) {
         p.o_xh = carve(off, (size_t)B * feat_rows_h(g.N) * DSH * sizeof(uint16_t));
         p.o_wqh = carve(off, (size_t)B * feat_rows_h(g.L) * DSH * sizeof(uint16_t));
@@ -301,6 +301,7 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
             p.o_spillcnt = carve(off, BL * sizeof(unsigned));
         }
         p.o_smax = (mode == DAGL_MODE_ADAPTIVE) ? carve(off, BL * sizeof(float)) : 0;      // dense formulation: the rows' shifts (as scores)
+        p.o_traw = (mode == DAGL_MODE_ADAPTIVE) ? carve(off, BL * sizeof(float)) : 0;      // ... and their largest sampled screened scores
         p.o_redo = carve(off, (size_t)B * n_qgroups * sizeof(int32_t));
     }
     p.ovf_cap = 0; p.o_ovflist = p.o_heavy = p.o_ovfq = p.o_ovfscores = p.o_ovfpart = 0;
@@ -434,7 +435,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                              p.capseg_tight > 0 && (p.capseg_tight != p.capseg || p.s_sample_tight != p.s_sample);
     int32_t* policy_w = reinterpret_cast<int32_t*>(stats + 9);
     int32_t* gate_w = reinterpret_cast<int32_t*>(stats + 10);
-    if (topk_policy && !prepared) {
+    if (p.screen && mode != DAGL_MODE_ADAPTIVE && !prepared) {
+        // (forced thresholds -- DAGL_FLAG_TIGHT_TOPK / _SAMPLED_TOPK -- do not read the policy word; the cookie and the sticky words are kept all the same)
         // maps of up to 16 384 keys (128^2; the 72 x 72 leaf tiles of the tiled driver) START on the tight threshold: there it costs
         // nothing measurable on synthetic maps (sampling every second key tile of <= 256 is a few steps) and its better threshold
         // saves 12 % on natural-image leaf tiles even when nothing overflows (0.64 against 0.73 ms per batch of 64 tiles,
@@ -590,6 +592,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         fused_theta = p.screen && mode == DAGL_MODE_ADAPTIVE;
         if (fused_theta) tf.theta_out = at<float>(ws, p.o_theta);
+        if (p.screen && mode == DAGL_MODE_ADAPTIVE) tf.zero_out = at<float>(ws, p.o_traw);     // (run_dense's sampled pass takes maxima into it)
         if ((rc = launch_query_thresholds(s, B, g.L, g.N, Wq, colsum, thr, mt, core ? core->mu : nullptr, &tf))) return rc;
         sa.mt = mt; sa.bs = bias; ea.mt = mt; ea.bs = bias;
     }
@@ -721,8 +724,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             ScreenArgs s1 = sc;
             s1.mode = DAGL_MODE_TOPK; s1.mt = nullptr; s1.bs = nullptr; s1.policy = nullptr; s1.gate = nullptr;
             s1.spill = nullptr; s1.spill_cnt = nullptr; s1.seg_max = 1;      // (no spill: a row with more candidates than slots keeps its upper bound)
+            s1.theta_max = at<int>(ws, p.o_traw); s1.theta = at<float>(ws, p.o_traw);     // (zeroed by query_thresholds_kernel)
             if ((rc = launch_screen(s, s1, 0))) return rc;
-            if ((rc = launch_screen_theta(s, (int)BL, p.s_splits * 2 * p.s_gkeep, 1, s1.gmax, at<float>(ws, p.o_theta), nullptr, nullptr))) return rc;
             if ((rc = launch_screen(s, s1, 1))) return rc;
             float* smax = at<float>(ws, p.o_smax);
             RefineArgs r1;
@@ -733,7 +736,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             if ((rc = launch_rowmax_exact(s, r1, smax))) return rc;
             prof_mark(prof, s, 6);          // (stage "gather" of a dense call = value-map split + dense_attend_kernel + combine)
             if ((rc = launch_dense_attend(s, B, g, Wq, X, mt, bias, smax, b2p, at<char>(ws, o_dn), agg, dbg_deg, dbg_rowsum, stats, rt,
-                                          core ? core->lse : nullptr, features_split))) return rc;
+                                          core ? core->lse : nullptr, features_split, info != nullptr))) return rc;
             prof_mark(prof, s, 7);
             if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = launch_fold(s, B, g, agg, out, heads, rt))) return rc;
@@ -909,7 +912,12 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         } else {
             sa.cand_idx = at<int32_t>(ws, p.o_cidx); sa.cand_val = at<float>(ws, p.o_cval);
             ea.cand_idx = sa.cand_idx; ea.cand_val = sa.cand_val;
-            if (p.screen) {
+            // DAGL_FLAG_NO_REDO: the caller has seen this workspace's recent calls without redo work and does without the launch (4.7 us
+            // that find nothing); a call that flagged a group after all is NaN-filled by the gather kernel and reported (sticky)
+            const bool no_redo = p.screen && (mode_flags & DAGL_FLAG_NO_REDO) && fin && heads == 1 && !core && !dbg_deg && !dbg_rowsum && !dbg_agg;
+            if (no_redo) {
+                ag.unserved = stats + 2; ag.unserved_sticky = reinterpret_cast<int32_t*>(stats + 13);
+            } else if (p.screen) {
                 // redo pass behind the screen: scan + merge of the flagged groups in one launch (exits after one load when nothing
                 // is flagged); its grid barrier counts in stats[3] (cleared with the call's counters, unused by the top-k modes)
                 if ((rc = launch_topk_redo(s, sa, ea, mode == DAGL_MODE_TOPK ? 2 : 3, reinterpret_cast<unsigned*>(stats + 3),
@@ -1091,25 +1099,23 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
     DAGL_REQUIRE(ws_bytes >= p.o_end && ((uintptr_t)workspace % 256) == 0, "dagl_ce_range_check: not the workspace of such a call");
     *violated = 0;
     if (mode & DAGL_FLAG_EXACT_SCAN) return DAGL_OK;                      // the fp32 path has no such range (and always waits)
-    int64_t h4[4] = {0, 0, 0, 0};                                          // stats[2..5]: flagged queries of the last call, -, range word, done
+    // ONE read-back (one synchronisation) of stats[2..13]: [2] flagged queries of the last call, [4] range word, [8] veto word, [9] top-k
+    // policy, [13] unserved DAGL_FLAG_NO_REDO call
+    int64_t hw[12] = {0};
     int64_t* st = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + p.o_stats);
-    if ((rc = read_back((hipStream_t)stream, st + 2, 4, h4))) return rc;
-    const int64_t* h = h4 + 2;
+    if ((rc = read_back((hipStream_t)stream, st + 2, 12, hw))) return rc;
+    const bool topk_screen = (mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen;
     // sticky: the word keeps the tag of the last call that left the range until it is read here (calls that reuse a
     // prepared workspace do not clear it), so a poll every n-th call sees a violation of ANY call since the last poll
-    *violated = ((int32_t)h[0] != 0) ? 1 : 0;
+    if ((int32_t)hw[2] != 0) { *violated |= 1; DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream)); }
     // bit 2 (not sticky: the count is cleared by every call): the last call's redo pass of the top-k modes had work
-    if ((mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen && h4[0] > 0) *violated |= 4;
-    if ((mode & 0xff) != DAGL_MODE_ADAPTIVE && p.screen) {            // bit 3: the workspace's threshold policy word says "tight"
-        int64_t v[1] = {0};
-        if ((rc = read_back((hipStream_t)stream, st + 9, 1, v))) return rc;
-        if ((int32_t)v[0] != 0) *violated |= 8;
-    }
-    if (*violated) DAGL_HIP_TRY(hipMemsetAsync(st + 4, 0, sizeof(int64_t), (hipStream_t)stream));
-    if ((mode & 0xff) == DAGL_MODE_ADAPTIVE) {           // bit 1: a DAGL_FLAG_NO_WAIT call was not served in-stream (likewise sticky)
-        int64_t v[1] = {0};
-        if ((rc = read_back((hipStream_t)stream, st + 8, 1, v))) return rc;
-        if ((int32_t)v[0] != 0) { *violated |= 2; DAGL_HIP_TRY(hipMemsetAsync(st + 8, 0, sizeof(int64_t), (hipStream_t)stream)); }
+    if (topk_screen && hw[0] > 0) *violated |= 4;
+    if (topk_screen && (int32_t)hw[7] != 0) *violated |= 8;            // bit 3: the workspace's threshold policy word says "tight"
+    // bit 4 (sticky): a DAGL_FLAG_NO_REDO call had flagged groups (its output is NaN-filled)
+    if (topk_screen && (int32_t)hw[11] != 0) { *violated |= 16; DAGL_HIP_TRY(hipMemsetAsync(st + 13, 0, sizeof(int64_t), (hipStream_t)stream)); }
+    // bit 1: a DAGL_FLAG_NO_WAIT call was not served in-stream (likewise sticky)
+    if ((mode & 0xff) == DAGL_MODE_ADAPTIVE && (int32_t)hw[6] != 0) {
+        *violated |= 2; DAGL_HIP_TRY(hipMemsetAsync(st + 8, 0, sizeof(int64_t), (hipStream_t)stream));
     }
     return DAGL_OK;
 }

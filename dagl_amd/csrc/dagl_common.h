@@ -306,6 +306,7 @@ struct ThrFuse {
     int imgs_per_head = 1;
     float* thr_out = nullptr; float* bias_out = nullptr;     // [B,L] final values (written when part != null)
     float* theta_out = nullptr;             // [B,L] adaptive candidate threshold on the screened scores, or null
+    float* zero_out = nullptr;              // [B,L] words to clear (the dense formulation's sampled row maxima: ScreenArgs::theta_max), or null
 };
 // Relative band of the bf16-screened scores (screen.hip): bf16 keeps 8 significant bits, so round-to-nearest moves a value
 // by up to 2^-8 relative (attained just above a power of two) and a product of two rounded operands by up to
@@ -385,6 +386,9 @@ struct AggArgs {
     const int64_t* row_off;         // CSR offsets or NULL (fixed width)
     int width;
     float* agg;                     // [B,L,784] (kh,kw,c)
+    // DAGL_FLAG_NO_REDO (aggregate_fold_kernel): the call's count of flagged queries -- non-zero: the lists of their groups were never
+    // redone, the output is NaN-filled and the sticky word set -- or null
+    const int64_t* unserved; int32_t* unserved_sticky;
 };
 int launch_aggregate_direct(hipStream_t s, const AggArgs& a);
 int launch_aggregate_fold(hipStream_t s, const AggArgs& a, float* out, int heads, RangeTag range);   // both at once (fixed-width lists)
@@ -423,6 +427,8 @@ struct ScreenArgs {
     // images give a few queries one hot segment (a 128-slot segment asked for 160-200) while the query's total stays in the hundreds;
     // without the spill such a query sent its whole 128-query group through the fp32 redo pass (k = 50 at 256^2: 7.2 ms a call)
     int2* spill; unsigned* spill_cnt;       // [B, L, SCREEN_SPILL] records, [B, L] counts (zeroed by screen_theta_kernel); null: none
+    int* theta_max;                         // pass 0, top-1 use: [B, L] words (zeroed) that take the query's largest sampled score by an integer
+                                            // atomicMax instead of the group maxima going to gmax; pass 1 with seg_max then reads `theta` raw
     int seg_max;                            // pass 1: slot 0 of a segment = {candidates found, largest screened score among them (float bits)}
 };
 constexpr int SCREEN_SPILL = 256;
@@ -534,7 +540,8 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
                         float* rowsum_out, int64_t* stats /* [0] += edges, [1] = max degree */, RangeTag range = RangeTag(),
                         float* lse_out = nullptr /* [B,L,2] {shift M, sum Z} for the backward */,
-                        bool features_split = false /* the projection already wrote dense_split_buffers() */);
+                        bool features_split = false /* the projection already wrote dense_split_buffers() */,
+                        bool want_stats = true /* stats[0..2]: total edges, largest degree, rows beyond the lists' width */);
 
 // graph-core backward (backward.hip)
 struct BwdArgs {

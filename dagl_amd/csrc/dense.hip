@@ -789,7 +789,7 @@ void dense_guard_rows(ZeroList& zl, int B, const Grid& g, const Split16Out& so) 
 
 int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, const float* x, const float* mt,
                         const float* bs, const float* smax, const float* b2p, void* ws, float* agg, int32_t* deg_out,
-                        float* rowsum_out, int64_t* stats, RangeTag range, float* lse_out, bool features_split) {
+                        float* rowsum_out, int64_t* stats, RangeTag range, float* lse_out, bool features_split, bool want_stats) {
     DenseArgs a;
     a.smax = smax;
     a.variant = 0;
@@ -865,8 +865,8 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     DAGL_LAUNCH_CHECK("dense_attend_kernel");
     hipLaunchKernelGGL(dense_combine_kernel, dim3((unsigned)(((size_t)B * g.L + 3) / 4)), dim3(256), 0, s, a, agg, deg_out, rowsum_out, lse_out);
     DAGL_LAUNCH_CHECK("dense_combine_kernel");
-    // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics)
-    return launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats, DAGL_LIST_CAP);
+    // total edges, max degree, queries beyond the neighbour lists' width (no per-query atomics) -- only for a call that reads them back
+    return want_stats ? launch_degree_stats(s, (size_t)B * g.L, a.part_deg, stats, DAGL_LIST_CAP) : DAGL_OK;
 }
 
 }  // namespace dagl

@@ -266,6 +266,7 @@ __global__ void query_thresholds_kernel(int L, int N, int rows_alloc, const floa
         mt[ql] = m;
         if (mu_out != nullptr) mu_out[ql] = mean;
         if (f.theta_out != nullptr) f.theta_out[ql] = adaptive_theta_of(m, bv);
+        if (f.zero_out != nullptr) f.zero_out[ql] = 0.f;
     }
 }
 

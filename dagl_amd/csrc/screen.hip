@@ -38,6 +38,10 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     return base + slot;
 }
 
+// top-1 screen: candidate threshold from the largest SAMPLED screened score (one key reaches it, so the row's best key has
+// S~ >= this; 0 = nothing sampled: pass everything) -- what screen_theta_kernel computes for k = 1
+__device__ __forceinline__ float theta_of_sampled_max(float m) { return m > 0.f ? m * ((1.0f - SCREEN_DELTA) / (1.0f + SCREEN_DELTA)) : 0.f; }
+
 // a full segment's further candidates go to the query's shared spill area (ScreenArgs::spill); past its end they are dropped and the
 // count tells refine so (-> the exact redo pass, as before)
 __device__ __forceinline__ void screen_spill(const ScreenArgs& a, size_t qlin, int key, float sv) {
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
         load_query_fragments(a, b, q - i, qc, lane, qf[w]);
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 8)) ? a.theta[qlin[w]] : __builtin_inff();
+        if (PASS == 1 && SMAX && qvalid[w]) thq[w] = theta_of_sampled_max(thq[w]);      // (a.theta holds the raw sampled maximum)
         {
             const unsigned tb = __float_as_uint(thq[w]);
             thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
@@ -256,6 +261,16 @@ __global__ __launch_bounds__(SCR_QUERIES / QW * 2, (SCR_QUERIES == 256) ? QW : 1
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         if (PASS == 0) {
+            if (a.theta_max != nullptr) {
+                // top-1 use (the dense formulation's row maxima): the threshold is the query's LARGEST sampled score -- an integer
+                // maximum over the lanes' values (scores are >= 0: their bit patterns order like the values; the word was zeroed by
+                // query_thresholds_kernel), no separate threshold kernel
+                float m = gm[w][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[w][r]);
+                if (qvalid[w] && m > 0.f) atomicMax(a.theta_max + (seg[w] >> 1) / a.splits, __float_as_int(m));
+                continue;
+            }
             if (a.gkeep == 16) {
                 // few segments per query (small maps, large batches): ALL sixteen group maxima of the lane go to the threshold kernel --
                 // with four of them per segment a query had 8 * chunks values to take its k-th largest from: fewer than k = 50 on a
@@ -358,6 +373,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
         load_query_fragments(a, b, q - i, qc, lane, qf[w]);
         thq[w] = 0.f;
         if (PASS == 1) thq[w] = (qvalid[w] && !(VAR & 2)) ? a.theta[qlin] : __builtin_inff();
+        if (PASS == 1 && SMAX && qvalid[w]) thq[w] = theta_of_sampled_max(thq[w]);      // (a.theta holds the raw sampled maximum)
         const unsigned tb = __float_as_uint(thq[w]);
         thlo[w] = __uint_as_float(thq[w] > 0.f ? tb - 1u : (thq[w] == 0.f ? 0x80000001u : tb + 1u));
         n_loc[w] = 0;
@@ -538,6 +554,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
         if (PASS == 0) {
+            if (a.theta_max != nullptr) {
+                // top-1 use (the dense formulation's row maxima): the threshold is the query's LARGEST sampled score -- an integer
+                // maximum over the lanes' values (scores are >= 0: their bit patterns order like the values; the word was zeroed by
+                // query_thresholds_kernel), no separate threshold kernel
+                float m = gm[w][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, gm[w][r]);
+                if (qvalid[w] && m > 0.f) atomicMax(a.theta_max + (seg[w] >> 1) / a.splits, __float_as_int(m));
+                continue;
+            }
             if (a.gkeep == 16) {
                 // few segments per query (small maps, large batches): ALL sixteen group maxima of the lane go to the threshold kernel --
                 // with four of them per segment a query had 8 * chunks values to take its k-th largest from: fewer than k = 50 on a
@@ -1492,7 +1518,7 @@ __global__ __launch_bounds__(256) void rowmax_exact_kernel(RefineArgs a, float* 
     int* ci = c_idx[w]; float* cv = c_val[w];
     const int b = (int)(ql / a.L);
     const int S2 = a.splits * 2;
-    const float thq = a.theta[ql];
+    const float thq = theta_of_sampled_max(a.theta[ql]);      // (a.theta: the raw sampled maximum, as the filter pass read it)
     // 1. segment headers: candidate counts and the segments' largest screened scores
     float sm = 0.f;
     bool overflow = false;

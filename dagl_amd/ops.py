@@ -338,7 +338,7 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
 def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, workspace: "Workspace | None" = None,
                      profile: "StageProfile | None" = None, exact_scan: bool = False, weights_packed: bool = False,
                      dense_hint: bool = False, want_info: bool = True, no_wait: bool = False, tight_topk: bool = False,
-                     sampled_topk: bool = False):
+                     sampled_topk: bool = False, no_redo: bool = False):
     """Whole CE.forward (dagl.py:207-275) from the block input ``x`` [B,64,H,W]; ``params`` maps the block's
     state_dict names to contiguous fp32 GPU tensors.  Returns (out, info).  ``dense_hint``: go straight to the streamed
     dense formulation (adaptive mode; same result, see DAGL_FLAG_DENSE_HINT); with ``want_info=False`` that path does
@@ -347,7 +347,9 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
     reports it; info is None.  ``tight_topk`` (top-k modes, DAGL_FLAG_TIGHT_TOPK): candidate threshold from every second key tile and
     eight times the candidate slots -- for maps whose sampled threshold lets too many keys through (natural images); same result.
     ``sampled_topk`` (DAGL_FLAG_SAMPLED_TOPK) forces the sampled threshold; with neither the workspace's own policy word decides
-    on the device (sticky switch to the tight threshold once a call overflowed; a cold workspace re-runs tight in the same call)."""
+    on the device (sticky switch to the tight threshold once a call overflowed; a cold workspace re-runs tight in the same call).
+    ``no_redo`` (top-k modes, DAGL_FLAG_NO_REDO): the fp32 redo pass behind the refine kernel is not queued; a call that flagged a
+    query group anyway is NaN-filled and ``ce_range_check`` reports it (bit 4, sticky)."""
     lib = _lib.load()
     if mode not in MODES:
         raise DaglError(f"unknown mode {mode!r}")
@@ -375,6 +377,8 @@ def ce_forward_fused(x, params: dict, mode: str = "adaptive", k: int = 0, worksp
             need = max(need, ws.peek(x.device).numel() - 4096)      # keep the (larger) buffer the dense path asked for earlier
     if mode != "adaptive" and not exact_scan:
         mode_flags |= _lib.FLAG_TIGHT_TOPK if tight_topk else (_lib.FLAG_SAMPLED_TOPK if sampled_topk else 0)
+        if no_redo and (mode_flags & _lib.FLAG_WEIGHTS_PACKED):
+            mode_flags |= _lib.FLAG_NO_REDO
     quiet = dense_hint and not want_info
     if no_wait and mode == "adaptive" and not exact_scan and not dense_hint and H * W >= 2048:
         mode_flags |= _lib.FLAG_NO_WAIT
@@ -419,7 +423,7 @@ def ce_range_check(shape, mode: str, k: int, workspace: "Workspace", device) -> 
     with torch.cuda.device(device):
         check(lib.dagl_ce_range_check(_stream(), B, H, W, MODES[mode], int(k), a, nbytes, C.byref(out)), "dagl_ce_range_check")
     return int(out.value)            # bit 0: range, bit 1: an unserved no-wait adaptive call, bit 2: the last top-k call had a redo pass,
-                                     # bit 3: the workspace's top-k threshold policy word says "tight"
+                                     # bit 3: the workspace's top-k threshold policy word says "tight", bit 4: a no-redo call went unserved
 
 
 @_on_device

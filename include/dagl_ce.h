@@ -92,6 +92,13 @@ extern "C" {
  * had work.                                                                                                                    */
 #define DAGL_FLAG_TIGHT_TOPK     0x1000
 #define DAGL_FLAG_SAMPLED_TOPK   0x2000
+/* OR-ed into `mode` (top-k modes behind the bf16 screen, dagl_ce_forward_fused): do NOT queue the fp32 redo pass behind the refine
+ * kernel.  On a warm workspace that pass is one launch that finds nothing flagged and exits (4.7 us of a 0.23 ms call at 256^2:
+ * the launch, not the grid).  Without it a call whose screen DID flag a query group (candidate slots and spill area full: maps flat
+ * enough for thousands of candidates per query) cannot be served: its output is NaN-filled by the last kernel -- never wrong
+ * numbers -- and dagl_ce_range_check reports it (bit 4, sticky) like a range violation.  For callers that poll: dagl_amd.CE sets it
+ * once a poll has found the workspace's recent calls without redo work and drops it for good when a poll reports bit 4.       */
+#define DAGL_FLAG_NO_REDO        0x4000
 
 #define DAGL_MAX_TOPK            64   /* widest per-query neighbour LIST of the top-k modes (the fixed-k variant defaults to
                                          num_edge = 50, GReccR2b_3mh_1-checkpoint.py:155,243); k > N = H*W means every key:
@@ -146,7 +153,8 @@ typedef struct dagl_ce_info {
 int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void* workspace, size_t ws_bytes,
                         int* violated /* bit 0: range, bit 1: an unserved DAGL_FLAG_NO_WAIT call, bit 2 (top-k modes, not sticky):
                                          the LAST call's redo pass had flagged query groups (see DAGL_FLAG_TIGHT_TOPK), bit 3 (top-k
-                                         modes): the workspace's threshold policy word has switched to the tight threshold */);
+                                         modes): the workspace's threshold policy word has switched to the tight threshold, bit 4 (sticky):
+                                         a DAGL_FLAG_NO_REDO call had flagged query groups (its output is NaN-filled) */);
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
