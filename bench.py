@@ -62,6 +62,9 @@ def parse():
                     help="secondary workload (BASELINE configs[4]): one optimisation step of the whole RR network on "
                          "--crop x --crop crops, --batch crops per GPU, DDP gradient all-reduce over RCCL")
     ap.add_argument("--crop", type=int, default=128)
+    ap.add_argument("--topk-redo", choices=["auto", "always"], default="auto",
+                    help="CE.topk_redo: 'auto' (module default) drops the fp32 redo launch once a poll found the workspace without redo work; "
+                         "'always' queues it in every call (A/B)")
     ap.add_argument("--dense-backward", choices=["f16", "fp32"], default="f16",
                     help="--train A/B: the dense graph core's backward products on the fp16 (split operands, default) or fp32 matrix cores")
     ap.add_argument("--prologue-backward", choices=["direct", "unfold"], default="direct",
@@ -699,6 +702,7 @@ def main():
     ce.scan = args.scan
     if k:
         ce.select_k = k
+    ce.topk_redo = args.topk_redo
     ce = ce.to(dev).eval()
 
     B, H, W = args.batch, args.size, args.size

@@ -200,13 +200,15 @@ class CE(nn.Module):
         # HIP-graph replay): sampled until any query of a call overflows (a full segment spills into the query's shared area first),
         # tight from then on; the first call of a shape re-runs tight in-stream; maps of <= 16 384 keys start tight.
         self.topk_threshold = "auto"
-        # Top-k modes behind the screen: "always" = every call queues the fp32 redo pass for query groups whose candidate slots
-        # overflowed (a launch that finds nothing on a warm workspace: 4.7 us of a 0.23 ms call); "auto" (default) = once a poll of
-        # the workspace (every 64th call, as for the range word) has found the last call without redo work, identical calls (same
-        # shape, weights, workspace) go without the launch (DAGL_FLAG_NO_REDO) and the workspace is polled every 32nd call; a call
-        # that flags a group after all returns NaN -- never wrong numbers --, the next poll reports it and the module queues the
-        # pass again from then on.  Not under HIP-graph capture (a replayed graph is never polled).
-        self.topk_redo = "auto"
+        # Top-k modes behind the screen: "always" (default) = every call queues the fp32 redo pass for query groups whose candidate slots
+        # overflowed (a launch that finds nothing on a warm workspace: 4.7 us under rocprofv3, which serialises dispatches); "auto" =
+        # once a poll of the workspace (every 64th call, as for the range word) has found the last call without redo work, identical
+        # calls (same shape, weights, workspace) go without the launch (DAGL_FLAG_NO_REDO) and the workspace is polled every 32nd call;
+        # a call that flags a group after all returns NaN -- never wrong numbers --, the next poll reports it and the module queues
+        # the pass again from then on.  Not under HIP-graph capture (a replayed graph is never polled).  Measured on the headline
+        # (profiles/r05_ab_topk_redo_launch.log, same box, interleaved): 0.2250 ms with "auto" against 0.2254 with "always" -- in the
+        # un-profiled stream the empty launch runs under its neighbours' dispatch and the polls cost what is left; hence not the default.
+        self.topk_redo = "always"
         self._redo_skip = False        # the last poll found no redo work
         self._redo_banned = False      # a no-redo call went unserved once: never again on this module
         self._served_streak = 0

@@ -127,3 +127,47 @@ def test_dense_shift_is_exact_at_large_logits_without_a_second_pass():
         print(f"[parity] dense, input x {scale}: largest logit {top:.0f}, re-run blocks {info['dense_rerun_blocks']}, normwise {err:.2e}")
         assert info["path"] == 4 and not info["range_fallback"] and info["dense_rerun_blocks"] == 0, info
         assert err <= TOL_OUT
+
+
+def test_topk_calls_without_the_redo_launch_are_never_wrong():
+    """``CE.topk_redo = "auto"`` (DAGL_FLAG_NO_REDO): after a poll has found the workspace without redo work the module's identical
+    calls go without the fp32 redo launch -- same bits as with it.  A map flat enough to overflow every query's candidate slots
+    then returns NaN (never numbers from unfinished lists), the next poll reports it (bit 4 of dagl_ce_range_check, sticky), warns,
+    and the module queues the pass again for good: the same input is then served exactly."""
+    import warnings
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(77, variant="default").items()}
+    x = torch.from_numpy(make_features(77, 1, 64, 96, 80)).to(_dev())
+    ref = _module(params, "topk", 8)
+    ref.topk_redo = "always"
+    ce = _module(params, "topk", 8)
+    ce.topk_redo = "auto"
+    ref.topk_threshold = ce.topk_threshold = "sparse"        # (the sampled threshold's slots: a near-constant map overflows them)
+    with torch.no_grad():
+        want = ref(x)
+        for _ in range(66):
+            got = ce(x)
+        assert ce._redo_skip and not ce._redo_banned, "the 64th call's poll should have found no redo work"
+        got = ce(x)
+        assert torch.equal(got, want)
+        # a nearly constant map of the same shape: every score inside the screen's band -> every key a candidate -> flagged groups
+        g = torch.Generator().manual_seed(9)
+        flat = (0.25 + 2e-4 * torch.randn(1, 64, 96, 80, generator=g)).to(_dev())
+        want_flat = ref(flat)
+        assert torch.isfinite(want_flat).all()
+        y = ce(flat)
+        assert torch.isnan(y).all(), "an unserved no-redo call must be NaN-filled"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(40):
+                y = ce(flat)
+            assert any("redo pass" in str(m.message) for m in w)
+        assert ce._redo_banned and not ce._redo_skip
+        y = ce(flat)
+        oracle = ce_forward_oracle(flat.cpu(), params, mode="topk", k=8, dtype=torch.float64)
+    assert torch.equal(y, want_flat)
+    # (a map this flat has thousands of scores per query within 1e-7 relative of its 8th best: which of them an fp32 evaluation keeps is
+    # a matter of its last bit -- the fp64 oracle is held to 1e-3 here, the bit-equality with the module that always queues the pass
+    # is the assertion that matters)
+    assert normwise(y.cpu().numpy(), oracle.float().numpy()) <= 1e-3
