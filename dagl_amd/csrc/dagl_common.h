@@ -202,6 +202,16 @@ int hip_fail(hipError_t e, const char* what);
 // that meets a larger value stores the call's tag into the workspace's range word; the last kernel of the call (fold) then
 // writes NaN instead of numbers computed from inf / NaN halves, and the host side re-runs the call on the fp32 path where
 // it reads statistics back anyway (adaptive modes) or on request (dagl_ce_range_check).
+// Blocks are handed to the 8 XCDs round-robin by their linear id (observed; used for speed only): block `bid` of `nblk` -> a logical
+// index such that every XCD owns one CONTIGUOUS range of logical indices and walks it in order -- blocks that share an operand
+// (the key chunk of the screen, the A tile of a GEMM's column tiles) meet in one L2.  Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
 struct RangeTag {
     int32_t* word = nullptr;     // workspace word: tag of the last call that left the fp16 range
     int32_t* done = nullptr;     // workspace word: tag of the last completed call (written by the fold)

@@ -207,9 +207,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = (g.batch > 1) ? (int)blockIdx.z / g.slices : 0;             // batch index; slice = blockIdx.z % slices
-    const long long k0 = (long long)((g.batch > 1) ? (int)blockIdx.z - bz * g.slices : (int)blockIdx.z) * g.K;
+    // block -> (column tile, row tile, slice): the column tiles of one (row tile, slice) share its A tile -- in dispatch order they sat on
+    // 7 different XCDs and each fetched it for itself (round 5 counters on the fc2 backward: 1.53 GB / 1.45 GB of HBM traffic per launch
+    // for 0.53 GB of operands + results, profiles/r05_pmc_gemm16.json); remapped so that they run side by side on ONE XCD
+    const int lin_id = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    const int logical = xcd_remap2(lin_id, (int)(gridDim.x * gridDim.y * gridDim.z));
+    const int bx = logical % (int)gridDim.x, byz = logical / (int)gridDim.x;
+    const int by = byz % (int)gridDim.y, bzz = byz / (int)gridDim.y;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int bz = (g.batch > 1) ? bzz / g.slices : 0;                          // batch index; slice = bzz % slices
+    const long long k0 = (long long)((g.batch > 1) ? bzz - bz * g.slices : bzz) * g.K;
     const long long boff_a = (long long)bz * g.sA, boff_b = (long long)bz * g.sB;       // (offsets, not pointers: a table of four local
                                                                                         // pointers indexed by the piece number lands in scratch)
     const int wm = wave / WN, wn = wave % WN;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
                                                                fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
     // split-K partials: [slice][batch][M][N] (the batches' outputs must then be dense: sC = M N, ldc = N)
-    float* out = (g.slices > 1) ? g.part + ((size_t)(blockIdx.z - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
+    float* out = (g.slices > 1) ? g.part + ((size_t)(bzz - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
                                 : g.C + (long long)bz * g.sC;
     const long long ldo = (g.slices > 1) ? g.N : g.ldc;
 #pragma unroll

@@ -850,7 +850,15 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
         int vunit, grp;
         if (bid < (pa.n_full & ~15)) {
             const int xcd = bid & 7, q = bid >> 3;
+#ifndef DAGL_P16_BAND_UNITS
             vunit = 8 * (q >> 1) + xcd; grp = (q ^ (q >> 5)) & 1;
+#else
+            // (round 5, measured and not shipped: profiles/r05_ab_project16_band.log) an XCD owns a BAND of consecutive units =
+            // consecutive image rows: a unit of row-major key patches needs 7 map rows, 6 of which its neighbour needs too -- with units
+            // dealt round-robin every map row is fetched by 7 of the 8 L2s.  Fewer fetches, but +1 us: the re-fetches come from the
+            // Infinity Cache and the band puts the 16 query units' blocks on one XCD
+            vunit = xcd * ((pa.n_full & ~15) >> 4) + (q >> 1); grp = (q ^ (q >> 5)) & 1;
+#endif
         } else { vunit = bid >> 1; grp = bid & 1; }
         const int b = vunit / per_units, unit = vunit - b * per_units;
         if (VAR != 0) {                                   // ablation builds keep the round-3 body for their variants

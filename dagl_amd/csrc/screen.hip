@@ -31,13 +31,6 @@ constexpr int KB = 13;                           // MFMAs (K=16 each) per 32x32 
 constexpr float DELTA = SCREEN_DELTA;
 constexpr int GKEEP = 4;                         // group maxima kept per (query, chunk, half) segment
 
-__device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + slot;
-}
-
 // top-1 screen: candidate threshold from the largest SAMPLED screened score (one key reaches it, so the row's best key has
 // S~ >= this; 0 = nothing sampled: pass everything) -- what screen_theta_kernel computes for k = 1
 __device__ __forceinline__ float theta_of_sampled_max(float m) { return m > 0.f ? m * ((1.0f - SCREEN_DELTA) / (1.0f + SCREEN_DELTA)) : 0.f; }
