@@ -646,6 +646,19 @@ def train_bench(args, dev, dist, world, rank):
                            "parallelism": f"ddp{world}", "select_mode": args.mode, "k": args.k, "batch_per_gpu": B},
                 "roofline": gemm_roofline(dev, B, args.crop), "cpu_baseline": None,
                 "allreduce_ms": allreduce_ms, "allreduce_bytes": 4 * n_par if dist is not None else None,
+                "ddp": {"what": "dagl_amd.train.wrap_ddp: torch DistributedDataParallel over RCCL, one process per GPU",
+                        "bucket_cap_mb": 12, "gradient_as_bucket_view": True, "broadcast_buffers": False,
+                        "find_unused_parameters": False,
+                        "why": "every trainable parameter gets a gradient in every step: freeze_unused() takes the heads' never-applied "
+                               "`W` convolution (dagl.py:199-201; registered for checkpoint compatibility) and, in the fixed-k mode, "
+                               "the unused thr / bias heads out of the reducer (requires_grad = False), so no unused-parameter scan; "
+                               "the gradients travel in ~2 buckets of <= 12 MB (xGMI rings are per-link bound: few large messages), "
+                               "the first while the backward of the first half of the trunk is still running",
+                        "gradient_bytes": 4 * n_par,
+                        "expected_allreduce_ms_at_8_gpus": round(2.0 * (7.0 / 8.0) * 4 * n_par / 153e9 * 1e3, 3),
+                        "expected_note": "ring all-reduce over xGMI: 2 (N-1)/N x bytes over one ~153 GB/s link direction per hop, N = 8, "
+                                         "latency terms ignored -- an expectation, NOT a measurement: no multi-GPU node was available to "
+                                         "this repository's rounds; `allreduce_ms` above is the live figure of THIS run's world size"},
                 "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None}
         print(json.dumps(line))
 
