@@ -634,6 +634,9 @@ struct Gemm16s {
     const unsigned* scale_word; float alpha0;   // alpha = alpha0 / (fcg_scale_of(*scale_word) fcg_scale_of(*scale_word_b)); a null word = 1
     const unsigned* scale_word_b = nullptr;
     int batch = 1; long long sA = 0, sB = 0, sC = 0;   // batch > 1: operand strides in halfs, output stride in floats (grid.z = batch x slices)
+    int n_loop = 1;                             // column tiles a block walks one after the other (slices == 1; set by launch_gemm16s): short
+                                                // contractions (d rows of the projections: K = 224 = 7 steps) are one operand pipeline of
+                                                // n_loop x K / 32 steps per block instead of a request latency + 7 steps + 64 KiB of stores
 };
 int launch_gemm16s(hipStream_t s, const Gemm16s& g);
 int launch_absmax(hipStream_t s, size_t n, const float* x, unsigned* word);     // *word = max(*word, bits of max |x|); n % 4 == 0

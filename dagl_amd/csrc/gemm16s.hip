@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     const int logical = xcd_remap2(lin_id, (int)(gridDim.x * gridDim.y * gridDim.z));
     const int bx = logical % (int)gridDim.x, byz = logical / (int)gridDim.x;
     const int by = byz % (int)gridDim.y, bzz = byz / (int)gridDim.y;
-    const int m0 = by * BM, n0 = bx * BN;
+    const int nl = g.n_loop > 1 ? g.n_loop : 1;
+    const int m0 = by * BM, n0 = bx * nl * BN;
     const int bz = (g.batch > 1) ? bzz / g.slices : 0;                          // batch index; slice = bzz % slices
     const long long k0 = (long long)((g.batch > 1) ? bzz - bz * g.slices : bzz) * g.K;
     const long long boff_a = (long long)bz * g.sA, boff_b = (long long)bz * g.sB;       // (offsets, not pointers: a table of four local
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
 
     // LDS-DMA: a piece = 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 holds logical slot (l & 3) ^ ((row >> 2) & 3)
     const int prow = lane >> 2, pslot = (lane & 3) ^ ((prow >> 2) & 3);
-    auto stage = [&](int buf, long long k) {
+    auto stage = [&](int buf, int nt, long long k) {        // operand tiles of column tile nt of this block, contraction offset k
         const unsigned dst = lds0 + (unsigned)buf * STAGE;
 #pragma unroll
         for (int j = 0; j < PIECES / NW; ++j) {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
             const unsigned short* base = is_a ? (part ? g.a_lo : g.a_hi) : (part ? g.b_lo : g.b_hi);
             const long long boff = is_a ? boff_a : boff_b;
             const long long ld = is_a ? g.lda : g.ldb;
-            int row = (is_a ? m0 : n0) + grp * 16 + prow;
+            int row = (is_a ? m0 : n0 + nt * BN) + grp * 16 + prow;
             const int lim = (is_a ? g.a_rows : g.b_rows) - 1;
             if (row > lim) row = lim;
             glds16_asm(reinterpret_cast<const float*>(base + boff + (long long)row * ld + k + 8 * pslot),
@@ -251,16 +252,49 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = g.K / G16_BK;
+    const int nk1 = g.K / G16_BK;                                                 // steps of one column tile
+    const int nk = nk1 * nl;                                                      // steps of the block: column tile s / nk1, k-step s % nk1
+    const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
+                                                               fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
+    // split-K partials: [slice][batch][M][N] (the batches' outputs must then be dense: sC = M N, ldc = N)
+    float* out = (g.slices > 1) ? g.part + ((size_t)(bzz - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
+                                : g.C + (long long)bz * g.sC;
+    const long long ldo = (g.slices > 1) ? g.N : g.ldc;
+    auto store_tile = [&](int nt) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int m = m0 + wm * 64 + a * 32 + i;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + nt * BN + wn * 64 + b * 32 + 8 * q + 4 * h;
+#ifdef DAGL_G16_NOSTORE                       // (timing experiment only: results wrong)
+                    if (m < g.M && n < g.N && acc[a][b][4 * q] == 12345.678f) {
+#else
+                    if (m < g.M && n < g.N) {                                      // (N is a multiple of 4: whole quads)
+#endif
+                        *reinterpret_cast<float4*>(out + (long long)m * ldo + n) =
+                            make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
+                                        acc[a][b][4 * q + 3] * alpha);
+                    }
+                }
+        }
+    };
+    auto stage_step = [&](int buf, int sidx) {
+        const int nt = (nl > 1) ? sidx / nk1 : 0;
+        stage(buf, nt, k0 + (long long)(sidx - nt * nk1) * G16_BK);
+    };
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st)
-        if (st < nk) stage(st, k0 + (long long)st * G16_BK);
+        if (st < nk) stage_step(st, st);
     if (NS > 2 && nk > 1) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
     __syncthreads();
     const int swz = (i >> 2) & 3;
     int cur = 0, nxt = NS - 1;                                                    // buffer of step t, buffer of step t + NS - 1
+    int kin = 0, ntile = 0;                                                       // k-step inside the column tile, the column tile
     for (int t = 0; t < nk; ++t) {
-        if (t + NS - 1 < nk) stage(nxt, k0 + (long long)(t + NS - 1) * G16_BK);   // (the buffer step t - 1 read: behind that step's barrier)
+        if (t + NS - 1 < nk) stage_step(nxt, t + NS - 1);                         // (the buffer step t - 1 read: behind that step's barrier)
         const unsigned char* sb = smem + cur * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -293,27 +327,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
         __syncthreads();
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-    }
-    const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
-                                                               fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
-    // split-K partials: [slice][batch][M][N] (the batches' outputs must then be dense: sC = M N, ldc = N)
-    float* out = (g.slices > 1) ? g.part + ((size_t)(bzz - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
-                                : g.C + (long long)bz * g.sC;
-    const long long ldo = (g.slices > 1) ? g.N : g.ldc;
+        if (++kin == nk1) {                    // a column tile is complete: out it goes (under the next tile's requests), accumulators cleared
+            store_tile(ntile);
+            if (t + 1 < nk) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int m = m0 + wm * 64 + a * 32 + i;
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + b * 32 + 8 * q + 4 * h;
-                if (m < g.M && n < g.N) {                                          // (N is a multiple of 4: whole quads)
-                    *reinterpret_cast<float4*>(out + (long long)m * ldo + n) =
-                        make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
-                                    acc[a][b][4 * q + 3] * alpha);
-                }
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
             }
+            kin = 0; ++ntile;
+        }
     }
 }
 
@@ -344,8 +369,21 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
         dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
         hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, g);
     } else {
-        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.slices * nb);
-        hipLaunchKernelGGL((gemm16s_kernel<2, 2>), grid, dim3(256), 0, s, g);
+        // short contraction, many column tiles (d rows of the patch projections: K = 224, N = 784): a block walks ALL column tiles of
+        // its row tile -- one pipeline of 49 steps instead of seven blocks of 7 (each: request latency, 7 steps, 64 KiB of stores)
+        Gemm16s gl = g;
+        const int nt = (g.N + 127) / 128;
+        gl.n_loop = (g.slices == 1 && g.K <= 256 && nt > 1 && nt <= 8 && (long long)((g.M + 127) / 128) * nb >= 512) ? nt : 1;
+#ifdef DAGL_G16_NLOOP_256
+        if (gl.n_loop > 1) {                  // the same walk on 256 x 128 tiles / 8 waves / three stages: 2/3 of the operand bytes per product
+            dim3 grid2((nt + gl.n_loop - 1) / gl.n_loop, (g.M + 255) / 256, g.slices * nb);
+            hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid2, dim3(512), 0, s, gl);
+        } else
+#endif
+        {
+        dim3 grid((nt + gl.n_loop - 1) / gl.n_loop, (g.M + 127) / 128, g.slices * nb);
+        hipLaunchKernelGGL((gemm16s_kernel<2, 2>), grid, dim3(256), 0, s, gl);
+        }
     }
     DAGL_LAUNCH_CHECK("gemm16s_kernel");
     if (g.slices > 1) {
