@@ -252,93 +252,100 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk1 = g.K / G16_BK;                                                 // steps of one column tile
-    const int nk = nk1 * nl;                                                      // steps of the block: column tile s / nk1, k-step s % nk1
+    const int nk = g.K / G16_BK;                                                  // steps of one column tile
     const float alpha = (g.slices > 1) ? 1.0f : g.alpha0 / (fcg_scale_of(g.scale_word ? *g.scale_word : 0u) *
                                                                fcg_scale_of(g.scale_word_b ? *g.scale_word_b : 0u));
     // split-K partials: [slice][batch][M][N] (the batches' outputs must then be dense: sC = M N, ldc = N)
     float* out = (g.slices > 1) ? g.part + ((size_t)(bzz - bz * g.slices) * (g.batch > 1 ? g.batch : 1) + bz) * g.M * g.N
                                 : g.C + (long long)bz * g.sC;
     const long long ldo = (g.slices > 1) ? g.N : g.ldc;
+    // Results: a lane holds four consecutive columns of ONE row per register quad -- stored from the registers a wave instruction
+    // touched 32 rows with 32 bytes each (round 5, -DDAGL_G16_NOSTORE experiment: a third of the d rows product was its 411 MB of
+    // results leaving that way).  The wave's 64 x 64 tile goes through the LDS instead (the operand ring is dead behind the last
+    // step's barrier: two passes of 32 rows, 8.5 KiB per wave) and leaves as whole 256-byte row segments, four rows per instruction.
+    constexpr int SPITCH = 68;                                                    // floats per staged row (64 + 4: rows 8 apart share a bank)
+    static_assert(NW * 32 * SPITCH * 4 <= NS * STAGE, "the result staging must fit the operand ring");
     auto store_tile = [&](int nt) {
+        float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SPITCH);       // 32 rows x 64 columns at a time (the wave's upper / lower half)
+        const int nw = n0 + nt * BN + wn * 64;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int m = m0 + wm * 64 + a * 32 + i;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + nt * BN + wn * 64 + b * 32 + 8 * q + 4 * h;
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(stg + i * SPITCH + b * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
+                                    acc[a][b][4 * q + 3] * alpha);
+            // (the wave reads back only what it wrote itself: LDS operations of a wave execute in order, no barrier)
+            const int mw = m0 + wm * 64 + a * 32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = lane + 64 * j;
+                const int row = e >> 4, c4 = e & 15;
+                const int m = mw + row, n = nw + 4 * c4;
 #ifdef DAGL_G16_NOSTORE                       // (timing experiment only: results wrong)
-                    if (m < g.M && n < g.N && acc[a][b][4 * q] == 12345.678f) {
+                if (m < g.M && n < g.N && stg[0] == 12345.678f)
 #else
-                    if (m < g.M && n < g.N) {                                      // (N is a multiple of 4: whole quads)
+                if (m < g.M && n < g.N)                                           // (N is a multiple of 4: whole quads)
 #endif
-                        *reinterpret_cast<float4*>(out + (long long)m * ldo + n) =
-                            make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
-                                        acc[a][b][4 * q + 3] * alpha);
-                    }
-                }
-        }
-    };
-    auto stage_step = [&](int buf, int sidx) {
-        const int nt = (nl > 1) ? sidx / nk1 : 0;
-        stage(buf, nt, k0 + (long long)(sidx - nt * nk1) * G16_BK);
-    };
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
-        if (st < nk) stage_step(st, st);
-    if (NS > 2 && nk > 1) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
-    __syncthreads();
-    const int swz = (i >> 2) & 3;
-    int cur = 0, nxt = NS - 1;                                                    // buffer of step t, buffer of step t + NS - 1
-    int kin = 0, ntile = 0;                                                       // k-step inside the column tile, the column tile
-    for (int t = 0; t < nk; ++t) {
-        if (t + NS - 1 < nk) stage_step(nxt, t + NS - 1);                         // (the buffer step t - 1 read: behind that step's barrier)
-        const unsigned char* sb = smem + cur * STAGE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            g16h8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
-            const int off = (((2 * kb + h) ^ swz) << 4);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ra = (wm * 64 + u * 32 + i) * 64 + off, rb = (wn * 64 + u * 32 + i) * 64 + off;
-                a_hi[u] = *reinterpret_cast<const g16h8*>(sb + ra);
-                a_lo[u] = *reinterpret_cast<const g16h8*>(sb + PA + ra);
-                b_hi[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + rb);
-                b_lo[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + PB + rb);
+                    *reinterpret_cast<float4*>(out + (long long)m * ldo + n) = *reinterpret_cast<const float4*>(stg + row * SPITCH + 4 * c4);
             }
-            // D[row = n (first operand's row)][col = m]: a lane holds four consecutive n of one m per register quad
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_lo[a], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo[b], a_hi[a], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_hi[a], acc[a][b], 0, 0, 0);
         }
-        // step t + 1's tile must have landed; the requests of the steps after it may stay in flight (a wave's requests complete in order)
-        if (NS > 2 && t + NS - 1 < nk) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
+    };
+    const int swz = (i >> 2) & 3;
+    for (int ntile = 0; ntile < nl; ++ntile) {
+        if (ntile > 0) {
+            __syncthreads();                                                      // every wave has read its staged results back
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) stage(st, ntile, k0 + (long long)st * G16_BK);
+        if (NS > 2 && nk > 1) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
         __syncthreads();
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-        if (++kin == nk1) {                    // a column tile is complete: out it goes (under the next tile's requests), accumulators cleared
-            store_tile(ntile);
-            if (t + 1 < nk) {
+        int cur = 0, nxt = NS - 1;                                                // buffer of step t, buffer of step t + NS - 1
+        for (int t = 0; t < nk; ++t) {
+            if (t + NS - 1 < nk) stage(nxt, ntile, k0 + (long long)(t + NS - 1) * G16_BK);   // (the buffer step t - 1 read: behind that step's barrier)
+            const unsigned char* sb = smem + cur * STAGE;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                g16h8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+                const int off = (((2 * kb + h) ^ swz) << 4);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ra = (wm * 64 + u * 32 + i) * 64 + off, rb = (wn * 64 + u * 32 + i) * 64 + off;
+                    a_hi[u] = *reinterpret_cast<const g16h8*>(sb + ra);
+                    a_lo[u] = *reinterpret_cast<const g16h8*>(sb + PA + ra);
+                    b_hi[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + rb);
+                    b_lo[u] = *reinterpret_cast<const g16h8*>(sb + 2 * PA + PB + rb);
+                }
+                // D[row = n (first operand's row)][col = m]: a lane holds four consecutive n of one m per register quad
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_lo[a], acc[a][b], 0, 0, 0);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo[b], a_hi[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[b], a_hi[a], acc[a][b], 0, 0, 0);
             }
-            kin = 0; ++ntile;
+            // step t + 1's tile must have landed; the requests of the steps after it may stay in flight (a wave's requests complete in order)
+            if (NS > 2 && t + NS - 1 < nk) dma_wait_le<(NS - 2) * PPW>(); else dma_wait_all();
+            __syncthreads();
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
+        store_tile(ntile);
     }
 }
 
