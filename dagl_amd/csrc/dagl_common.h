@@ -513,6 +513,7 @@ struct WideArgs {
     int32_t* sel; int32_t* eq_before;                          // [R, 4] threshold key + ties to take; [R, 128] ties before each key range
     float* agg; int32_t* deg; float* rowsum;                   // [B*L, 784], [B*L], [B*L] or null
     int b, r0, R;                                              // image, first query and number of queries of the batch
+    int32_t* served;                                           // [R] 1 = the row was done by wide_list_kernel (k <= 1024), or null
 };
 size_t topk_wide_workspace_bytes(int N, int L);
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq /* [B, rows, DS] */, const float* x,

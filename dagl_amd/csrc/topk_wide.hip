@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void wide_select_kernel(WideArgs a) {
     __shared__ WideSelShared shs;
     __shared__ int sh_eq[WIDE_RANGES];
     const int slot = blockIdx.x, tid = threadIdx.x;
+    if (a.served != nullptr && a.served[slot] != 0) return;        // (wide_list_kernel has done this row)
     const size_t ql = (size_t)a.b * a.g.L + a.r0 + slot;
     const float* row = a.scores + (size_t)slot * a.ldn;
     const bool adaptive = a.mode == DAGL_MODE_ADAPTIVE_TOPK;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void wide_attend_kernel(WideArgs a) {
     const bool adaptive = a.mode == DAGL_MODE_ADAPTIVE_TOPK;
     const float4* vmb = reinterpret_cast<const float4*>(a.b2p + (size_t)a.b * a.g.Hp * a.g.Wp * CH);
     for (int slot = blockIdx.y; slot < a.R; slot += gridDim.y) {
+        if (a.served != nullptr && a.served[slot] != 0) continue;  // (block-uniform)
         const size_t ql = (size_t)a.b * a.g.L + a.r0 + slot;
         const float* row = a.scores + (size_t)slot * a.ldn;
         const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void wide_combine_kernel(WideArgs a) {
     __shared__ RowReduceShared sh;
     const int tid = threadIdx.x;
     for (int slot = blockIdx.x; slot < a.R; slot += gridDim.x) {
+        if (a.served != nullptr && a.served[slot] != 0) continue;  // (block-uniform)
         const size_t ql = (size_t)a.b * a.g.L + a.r0 + slot;
         const float* part_row = a.part + (size_t)slot * ROW_CHUNKS * ROW_PART_FLOATS;
         const RowSum row = row_reduce(part_row, a.g.N, sh);
@@ -109,6 +112,255 @@ __global__ __launch_bounds__(256) void wide_combine_kernel(WideArgs a) {
             a.deg[ql] = row.deg;
             if (a.rowsum) a.rowsum[ql] = (float)(row.zs / row.Z);
         }
+    }
+}
+
+// ---- round 5: k of a few hundred -- selection, softmax and weighted sum of a row in ONE block -----------------------------------------
+// The three kernels above read a 256 KiB score row six times to find its k-th largest (4 radix passes + ties), once more to mask it
+// (every one of the N scores walked again to find the k that pass) and hand partial rows through memory to a combine launch:
+// 0.70 + 0.52-0.73 + 0.05 ms per 2048 rows at 256^2, whatever k (profiles/r05_topk_wide.log).  For k <= WL_KMAX a block now
+//   A  samples every s-th score (4096 samples in the LDS) and takes the r-th largest sample, r a little above k / s (+ 3 sigma), as a
+//      LOWER bound t of the k-th largest score -- a bit-wise search over the samples' sort keys;
+//   B  reads the row ONCE: every wave compacts the scores >= t of its eighth of the row, in key order, into its segment of a
+//      candidate list in the LDS (ballot + prefix: no atomics, the list is ordered by key whatever the timing);
+//   C  finds the k-th largest among the candidates exactly (same search), ties to the lower key (the order of the list), and forms the
+//      final list: map offsets + logits;
+//   D  softmax over the list (+ (N - k) e^-M for the masked keys' e^0, dagl.py:259-261; fp64 exp / sums in a fixed order) and the
+//      weighted sum of the value patches: wave w takes entries w, w + 8, .., a lane four float4 columns, sixteen gathers in flight; the
+//      eight waves' partial rows are added in wave order.
+// A row whose sample misleads (fewer than k candidates, or more than a segment holds: flat maps) is left to the kernels above
+// (`served` = 0): same results, old speed.
+constexpr int WL_KMAX = 1024;                        // largest k served from the list
+constexpr int WL_SAMPLES = 4096;
+constexpr int WL_WAVES = 8;                          // 512 threads: the block's phases are chains of memory round trips -- more waves, shorter chains
+constexpr int WL_THREADS = 64 * WL_WAVES;
+constexpr int WL_SEG = 512;                          // candidate slots per wave (an eighth of the row)
+constexpr int WL_PER = WL_SAMPLES / WL_THREADS;      // keys a thread holds in the two selections (8)
+static_assert(WL_WAVES * WL_SEG == WL_SAMPLES, "one register set serves both selections");
+struct WideListShared {
+    // one 32 KiB region, three lives: A the sample keys [4096]; B / C the candidates ckey[8][512] | cscore[8][512]; D the waves' partial rows
+    union {
+        unsigned samp[WL_SAMPLES];
+        struct { int ckey[WL_WAVES][WL_SEG]; float cscore[WL_WAVES][WL_SEG]; } c;
+        float4 part[WL_WAVES][P / 4];
+    } u;
+    int lst_of[WL_KMAX]; float lst_w[WL_KMAX];       // C / D: the selected keys' map offsets (float4 units) and logits -> weights (8 KiB)
+    double dred[WL_THREADS];
+    float fred[WL_WAVES];
+    int ired[WL_WAVES];
+    int wcnt[WL_WAVES], wgt_n[WL_WAVES], weq_n[WL_WAVES];
+};
+
+// r-th largest of the block's sort keys, WL_PER per thread in registers (0 = no key; 0 when there are fewer than r keys): a bit-wise
+// search, block-uniform result
+__device__ __forceinline__ unsigned wl_kth_largest(const unsigned (&key)[WL_PER], int r, int* ired) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    unsigned prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < WL_PER; ++u) cnt += key[u] >= t ? 1 : 0;
+        cnt = wave_sum_i32(cnt);
+        __syncthreads();                                          // (the previous step's sums have been read)
+        if ((tid & 63) == 0) ired[w] = cnt;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int ww = 0; ww < WL_WAVES; ++ww) all += ired[ww];
+        if (all >= r) prefix = t;
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(WL_THREADS) void wide_list_kernel(WideArgs a) {
+    __shared__ WideListShared sh;
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t ql = (size_t)a.b * a.g.L + a.r0 + slot;
+    const float* __restrict__ row = a.scores + (size_t)slot * a.ldn;
+    const bool adaptive = a.mode == DAGL_MODE_ADAPTIVE_TOPK;
+    const float mtq = adaptive ? a.mt[ql] : 0.f, bsq = adaptive ? a.bs[ql] : 0.f;
+    const int N = a.g.N, k = a.k;
+    // ---- A: a lower bound of the k-th largest score from a sample --------------------------------------------------------------------
+    // the sample: whole 128-byte lines (32 scores), one of every `stride` lines -- a score of every 64 bytes would touch EVERY line of
+    // the row and read it a second time; which line of a group of `stride` rotates (5 g mod stride), so that the sample does not sit
+    // on one band of image columns (a key index is a pixel in raster order)
+    const int n_lines = (N + 31) / 32;
+    const int stride = (n_lines * 32 + WL_SAMPLES - 1) / WL_SAMPLES;               // lines per sampled line
+    const int n_groups = (n_lines + stride - 1) / stride;
+    const int ns = n_groups * 32;                                                  // <= WL_SAMPLES
+    unsigned sk[WL_PER];
+#pragma unroll
+    for (int u = 0; u < WL_PER; ++u) {                                             // (independent loads: all in flight)
+        const int e = tid + WL_THREADS * u;
+        const int g = e >> 5;
+        int line = g * stride + (stride > 1 ? (5 * g) % stride : 0);
+        if (line > n_lines - 1) line = n_lines - 1;
+        const int j = line * 32 + (e & 31);
+        sk[u] = (e < ns && j < N) ? wide_key(row[j], adaptive, mtq, bsq) : 0u;
+    }
+    // (neighbouring pixels' scores are correlated: the sample is worth fewer independent draws than it has entries -- a wide margin)
+    int rs = k;
+    if (stride > 1) { const float r = (float)k / (float)stride; rs = (int)(r + 6.0f * sqrtf(r) + 8.0f); }
+    if (rs > ns) rs = ns;
+    unsigned tl = wl_kth_largest(sk, rs, sh.ired);
+    if (tl < 1u) tl = 1u;                                           // (key 0 = "not a candidate")
+    // ---- B: the candidates, per wave eighth, in key order -------------------------------------------------------------------------------
+    {
+        // a lane takes FOUR consecutive scores per load (16 bytes), eight loads in flight per wave (one load per round trip left a
+        // wave's share at hundreds of dependent round trips); positions by a wave scan of the lanes' counts: still key order
+        const int per = ((N + WL_WAVES - 1) / WL_WAVES + 255) / 256 * 256;
+        const int j0 = min(w * per, N), j1 = min(j0 + per, N);
+        const bool vec = (a.ldn % 4 == 0);                          // (16-byte aligned rows)
+        int cw = 0;
+        constexpr int UB = 8;
+        for (int c0 = j0; c0 < j1; c0 += 256 * UB) {
+            float4 v[UB];
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) {
+                const int j = c0 + 256 * ub + 4 * lane;
+                if (vec && j + 3 < j1) v[ub] = *reinterpret_cast<const float4*>(row + j);
+                else v[ub] = make_float4(j < j1 ? row[j] : 0.f, j + 1 < j1 ? row[j + 1] : 0.f, j + 2 < j1 ? row[j + 2] : 0.f, j + 3 < j1 ? row[j + 3] : 0.f);
+            }
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) {
+                const int j = c0 + 256 * ub + 4 * lane;
+                const float sc[4] = {v[ub].x, v[ub].y, v[ub].z, v[ub].w};
+                bool ps[4]; int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ps[q] = j + q < j1 && wide_key(sc[q], adaptive, mtq, bsq) >= tl; cnt += ps[q] ? 1 : 0; }
+                if (!__any(cnt != 0)) continue;                     // (wave-uniform)
+                const int incl = wave_scan_incl_i32(cnt);
+                int pos = cw + incl - cnt;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ps[q]) { if (pos < WL_SEG) { sh.u.c.ckey[w][pos] = j + q; sh.u.c.cscore[w][pos] = sc[q]; } ++pos; }
+                cw += __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        if (lane == 0) sh.wcnt[w] = cw;
+    }
+    __syncthreads();
+    int total = 0; bool fits = true;
+#pragma unroll
+    for (int ww = 0; ww < WL_WAVES; ++ww) { total += sh.wcnt[ww]; fits = fits && sh.wcnt[ww] <= WL_SEG; }
+    // (tl == 1: every candidate of the row is in the list -- fewer than k of them is then the row's true degree)
+    if (!fits || (tl > 1u && total < k)) { if (tid == 0) a.served[slot] = 0; return; }       // block-uniform: left to the three-kernel form
+    // ---- C: the k best of the candidates, ties to the lower key -------------------------------------------------------------------------
+    unsigned ck[WL_PER];
+#pragma unroll
+    for (int u = 0; u < WL_PER; ++u) {                              // thread (w, lane) holds its own wave's segment: positions lane + 64 u
+        const int i = lane + 64 * u;
+        ck[u] = i < sh.wcnt[w] ? wide_key(sh.u.c.cscore[w][i], adaptive, mtq, bsq) : 0u;
+    }
+    const int kk = total < k ? total : k;
+    unsigned T = 0u;
+    if (kk > 0) T = wl_kth_largest(ck, kk, sh.ired);
+    {
+        int ngt = 0, neq = 0;                                       // this wave's segment: keys above / at the threshold
+#pragma unroll
+        for (int u = 0; u < WL_PER; ++u) { ngt += (ck[u] > T) ? 1 : 0; neq += (ck[u] == T && ck[u] != 0u) ? 1 : 0; }
+        ngt = wave_sum_i32(ngt); neq = wave_sum_i32(neq);
+        if (lane == 0) { sh.wgt_n[w] = ngt; sh.weq_n[w] = neq; }
+    }
+    __syncthreads();
+    int gt_all = 0;
+#pragma unroll
+    for (int ww = 0; ww < WL_WAVES; ++ww) gt_all += sh.wgt_n[ww];
+    const int need = kk - gt_all;                                   // of the keys AT the threshold: the first `need` in key order
+    {
+        int eq_before = 0, sel_before = 0;
+        for (int ww = 0; ww < w; ++ww) {
+            const int take = min(max(need - eq_before, 0), sh.weq_n[ww]);
+            sel_before += sh.wgt_n[ww] + take; eq_before += sh.weq_n[ww];
+        }
+        int eq_run = eq_before, pos_run = sel_before;
+#pragma unroll
+        for (int u = 0; u < WL_PER; ++u) {
+            const int i = lane + 64 * u;
+            const unsigned key = ck[u];
+            const bool eq = key == T && key != 0u;
+            const unsigned long long eqb = __ballot(eq);
+            const int rank = eq_run + __popcll(eqb & ((1ull << lane) - 1ull));
+            eq_run += __popcll(eqb);
+            const bool pick = key != 0u && (key > T || (eq && rank < need));
+            const unsigned long long pb = __ballot(pick);
+            const int pos = pos_run + __popcll(pb & ((1ull << lane) - 1ull));
+            pos_run += __popcll(pb);
+            if (pick) {
+                const int j = sh.u.c.ckey[w][i];
+                const int jy = j / a.g.W, jx = j - jy * a.g.W;
+                sh.lst_of[pos] = (jy * a.g.Wp + jx) * (CH / 4);
+                sh.lst_w[pos] = wide_logit(sh.u.c.cscore[w][i], adaptive, mtq, bsq);
+            }
+        }
+    }
+    __syncthreads();                                                // (the candidates are dead from here: their memory holds the partial rows below)
+    const int deg = kk;                                             // (every candidate has a non-zero key: kk of them are picked)
+    // ---- D: softmax over the list, weighted sum ------------------------------------------------------------------------------------------
+    float m = -1.f;
+    for (int e = tid; e < deg; e += WL_THREADS) m = fmaxf(m, sh.lst_w[e]);
+    m = wave_max_f32(m);
+    if (lane == 0) sh.fred[w] = m;
+    __syncthreads();
+    float mf = sh.fred[0];
+#pragma unroll
+    for (int ww = 1; ww < WL_WAVES; ++ww) mf = fmaxf(mf, sh.fred[ww]);
+    double M = (double)mf;
+    if (deg < N) M = fmax(M, 0.0);
+    double zloc = 0.0;
+    for (int e = tid; e < WL_KMAX; e += WL_THREADS) {               // (fixed assignment: thread t sums entries t, t + 512 in that order)
+        if (e < deg) { const double wv = exp((double)sh.lst_w[e] - M); sh.lst_w[e] = (float)wv; zloc += wv; }
+    }
+    sh.dred[tid] = zloc;
+    __syncthreads();
+    for (int st = WL_THREADS / 2; st > 0; st >>= 1) {               // fixed tree: the same sum on every run
+        if (tid < st) sh.dred[tid] += sh.dred[tid + st];
+        __syncthreads();
+    }
+    const double zs = sh.dred[0];
+    const double Z = zs + (double)(N - deg) * exp(-M);
+    const RowCols cols = row_cols(lane);
+    const float4* vmb = reinterpret_cast<const float4*>(a.b2p + (size_t)a.b * a.g.Hp * a.g.Wp * CH);
+    int coff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) coff[u] = cols.kh[u] * a.g.Wp * (CH / 4) + cols.rem[u];
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int GB = 4;                                           // entries in flight per wave (x 4 columns = 16 gathers per lane)
+    for (int e0 = w; e0 < deg; e0 += WL_WAVES * GB) {
+        float4 v[GB][4]; float wv[GB];
+#pragma unroll
+        for (int g2 = 0; g2 < GB; ++g2) {
+            const int e = min(e0 + WL_WAVES * g2, deg - 1);
+            const int of = sh.lst_of[e];
+            wv[g2] = (e0 + WL_WAVES * g2 < deg) ? sh.lst_w[e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[g2][u] = vmb[of + coff[u]];
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < GB; ++g2)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u].x = fmaf(wv[g2], v[g2][u].x, acc[u].x); acc[u].y = fmaf(wv[g2], v[g2][u].y, acc[u].y);
+                acc[u].z = fmaf(wv[g2], v[g2][u].z, acc[u].z); acc[u].w = fmaf(wv[g2], v[g2][u].w, acc[u].w);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (cols.cv[u]) sh.u.part[w][lane + 64 * u] = acc[u];
+    __syncthreads();
+    if (tid < P / 4) {
+        const float inv = (float)(1.0 / Z);
+        float4 t = sh.u.part[0][tid];
+#pragma unroll
+        for (int ww = 1; ww < WL_WAVES; ++ww) { const float4 q = sh.u.part[ww][tid]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }   // wave order
+        reinterpret_cast<float4*>(a.agg)[ql * (P / 4) + tid] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    if (tid == 0) {
+        a.deg[ql] = deg;
+        if (a.rowsum) a.rowsum[ql] = (float)(zs / Z);
+        a.served[slot] = 1;
     }
 }
 
@@ -126,7 +378,7 @@ size_t topk_wide_workspace_bytes(int N, int L) {
     const size_t R = (size_t)topk_wide_rows(N, L);
     const size_t ldn = (size_t)(N + 31) / 32 * 32;
     return align_up(R * ldn * sizeof(float), 256) + align_up(R * ROW_CHUNKS * ROW_PART_FLOATS * sizeof(float), 256) +
-           align_up(R * 4 * sizeof(int32_t), 256) + align_up(R * WIDE_RANGES * sizeof(int32_t), 256);
+           align_up(R * 4 * sizeof(int32_t), 256) + align_up(R * WIDE_RANGES * sizeof(int32_t), 256) + align_up(R * sizeof(int32_t), 256);
 }
 
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq, const float* x, const float* mt,
@@ -140,7 +392,8 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
     a.scores = reinterpret_cast<float*>(p); p += align_up((size_t)Rmax * a.ldn * sizeof(float), 256);
     a.part = reinterpret_cast<float*>(p); p += align_up((size_t)Rmax * ROW_CHUNKS * ROW_PART_FLOATS * sizeof(float), 256);
     a.sel = reinterpret_cast<int32_t*>(p); p += align_up((size_t)Rmax * 4 * sizeof(int32_t), 256);
-    a.eq_before = reinterpret_cast<int32_t*>(p);
+    a.eq_before = reinterpret_cast<int32_t*>(p); p += align_up((size_t)Rmax * WIDE_RANGES * sizeof(int32_t), 256);
+    int32_t* served = reinterpret_cast<int32_t*>(p);
     const int rows_q = feat_rows(g.L), rows_x = feat_rows(g.N);
     for (int b = 0; b < B; ++b)
         for (int r0 = 0; r0 < g.L; r0 += Rmax) {
@@ -156,6 +409,14 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
             gm.alpha = 1.f; gm.beta = 0.f; gm.bias = nullptr; gm.relu = 0; gm.chunk_tiles = 3;
             int rc = launch_gemm32(s, gm);
             if (rc) return rc;
+            // k up to WL_KMAX: one block per row does everything from one read of the row; the rows it leaves alone (and larger k: all)
+            // go through the three kernels behind it
+            a.served = nullptr;
+            if (k <= WL_KMAX) {
+                a.served = served;
+                hipLaunchKernelGGL(wide_list_kernel, dim3(R), dim3(WL_THREADS), 0, s, a);
+                DAGL_LAUNCH_CHECK("wide_list_kernel");
+            }
             hipLaunchKernelGGL(wide_select_kernel, dim3(R), dim3(256), 0, s, a);
             DAGL_LAUNCH_CHECK("wide_select_kernel");
             hipLaunchKernelGGL(wide_attend_kernel, dim3(ROW_CHUNKS, R < 64 ? R : 64), dim3(256), 0, s, a);
