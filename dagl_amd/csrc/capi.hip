@@ -664,7 +664,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         // fixed-k neighbourhoods wider than the lists: scores, k-th largest, mask, softmax and weighted sum row by row
         prof_mark(prof, s, 3); prof_mark(prof, s, 4); prof_mark(prof, s, 5);
         if (heads > 1) { set_error("dagl_ces_stage_forward: k=%d > %d: use the per-head entry point", k, DAGL_MAX_TOPK); return DAGL_ERR_UNSUPPORTED; }
-        if ((rc = launch_topk_wide(s, B, g, mode, p.k, Wq, X, mt, bias, b2p, at<char>(ws, p.o_wide), agg, deg, dbg_rowsum))) return rc;
+        if ((rc = launch_topk_wide(s, B, g, mode, p.k, Wq, X, mt, bias, b2p, at<char>(ws, p.o_wide), agg, deg, dbg_rowsum, rt))) return rc;
         prof_mark(prof, s, 6);
         if (dbg_deg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_deg, deg, BL * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         if (dbg_agg) DAGL_HIP_TRY(hipMemcpyAsync(dbg_agg, agg, BL * P * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -517,7 +517,10 @@ struct WideArgs {
 };
 size_t topk_wide_workspace_bytes(int N, int L);
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq /* [B, rows, DS] */, const float* x,
-                     const float* mt, const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum);
+                     const float* mt, const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum,
+                     RangeTag range = RangeTag());
+// fp32 feature rows [B, rows_in, DS] -> split fp16 rows [B, rows_out, DSH] hi and lo, DN_FS x = hi + lo, columns 196.. zero (dense.hip)
+int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range);
 
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,
@@ -635,6 +638,9 @@ struct Gemm16s {
     const unsigned* scale_word; float alpha0;   // alpha = alpha0 / (fcg_scale_of(*scale_word) fcg_scale_of(*scale_word_b)); a null word = 1
     const unsigned* scale_word_b = nullptr;
     int batch = 1; long long sA = 0, sB = 0, sC = 0;   // batch > 1: operand strides in halfs, output stride in floats (grid.z = batch x slices)
+    int k_valid = 0;                            // > 0: halfs of an operand row that exist inside a slice (multiple of 8, < K): 16-byte pieces from
+                                                // there on are fetched from columns k_valid - 8 .. of the same row instead, which the caller
+                                                // guarantees to be ZERO (feature rows of 216 halfs under a contraction of 224)
     int n_loop = 1;                             // column tiles a block walks one after the other (slices == 1; set by launch_gemm16s): short
                                                 // contractions (d rows of the projections: K = 224 = 7 steps) are one operand pipeline of
                                                 // n_loop x K / 32 steps per block instead of a request latency + 7 steps + 64 KiB of stores

@@ -712,6 +712,13 @@ __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const flo
     reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(vl);
 }
 
+int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range) {
+    const size_t n8 = (size_t)rows_out * (DSH / 8);
+    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n8 + 255) / 256), B), dim3(256), 0, s, rows, rows_in, rows_out, src, hi, lo, range);
+    DAGL_LAUNCH_CHECK("feat_split_kernel");
+    return DAGL_OK;
+}
+
 int dense_splits(int B, const Grid& g) {
     // One block per CU is resident (LDS), so the grid runs in rounds of 256 blocks.  Few query groups: as many key ranges
     // as still fit one round.  More query groups than CUs: the split count that wastes least of the last round

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
             int row = (is_a ? m0 : n0 + nt * BN) + grp * 16 + prow;
             const int lim = (is_a ? g.a_rows : g.b_rows) - 1;
             if (row > lim) row = lim;
-            glds16_asm(reinterpret_cast<const float*>(base + boff + (long long)row * ld + k + 8 * pslot),
+            long long kc = k + 8 * pslot;                                         // (k_valid: the piece past the row's end reads the row's zero columns)
+            if (g.k_valid > 0 && kc - k0 >= g.k_valid) kc = k0 + g.k_valid - 8;
+            glds16_asm(reinterpret_cast<const float*>(base + boff + (long long)row * ld + kc),
                        __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
         }
     };

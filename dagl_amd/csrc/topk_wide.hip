@@ -374,15 +374,18 @@ int topk_wide_rows(int N, int L) {
     const long long lr = (L + 127) / 128 * 128;
     return (int)(c < lr ? c : lr);
 }
+// split-fp16 copy of one image's feature rows (hi or lo): [feat_rows_h(rows) + a tile of slack][DSH] halfs
+static size_t wide_split_bytes(int rows) { return align_up(((size_t)feat_rows_h(rows) + 256) * DSH * sizeof(uint16_t), 256); }
 size_t topk_wide_workspace_bytes(int N, int L) {
     const size_t R = (size_t)topk_wide_rows(N, L);
     const size_t ldn = (size_t)(N + 31) / 32 * 32;
     return align_up(R * ldn * sizeof(float), 256) + align_up(R * ROW_CHUNKS * ROW_PART_FLOATS * sizeof(float), 256) +
-           align_up(R * 4 * sizeof(int32_t), 256) + align_up(R * WIDE_RANGES * sizeof(int32_t), 256) + align_up(R * sizeof(int32_t), 256);
+           align_up(R * 4 * sizeof(int32_t), 256) + align_up(R * WIDE_RANGES * sizeof(int32_t), 256) + align_up(R * sizeof(int32_t), 256) +
+           2 * wide_split_bytes(N) + 2 * wide_split_bytes(L);
 }
 
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq, const float* x, const float* mt,
-                     const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum) {
+                     const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum, RangeTag range) {
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.g = g; a.mode = mode; a.k = k; a.mt = mt; a.bs = bs; a.b2p = b2p; a.agg = agg; a.deg = deg; a.rowsum = rowsum;
@@ -393,12 +396,39 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
     a.part = reinterpret_cast<float*>(p); p += align_up((size_t)Rmax * ROW_CHUNKS * ROW_PART_FLOATS * sizeof(float), 256);
     a.sel = reinterpret_cast<int32_t*>(p); p += align_up((size_t)Rmax * 4 * sizeof(int32_t), 256);
     a.eq_before = reinterpret_cast<int32_t*>(p); p += align_up((size_t)Rmax * WIDE_RANGES * sizeof(int32_t), 256);
-    int32_t* served = reinterpret_cast<int32_t*>(p);
+    int32_t* served = reinterpret_cast<int32_t*>(p); p += align_up((size_t)Rmax * sizeof(int32_t), 256);
+    uint16_t* xs_hi = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.N);
+    uint16_t* xs_lo = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.N);
+    uint16_t* qs_hi = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.L);
+    uint16_t* qs_lo = reinterpret_cast<uint16_t*>(p);
     const int rows_q = feat_rows(g.L), rows_x = feat_rows(g.N);
-    for (int b = 0; b < B; ++b)
+    // scores on the fp16 matrix cores with split operands (round 5; DAGL_WIDE_FP32_SCORES: the fp32 matrix cores as before): the image's
+    // features as fp16 pairs, 64 x = hi + lo (dense.hip's copies: rows of 216 halfs, columns 196.. zero), three products per score
+    // accumulated in fp32 -- >= 21 significant bits, as the projections -- at 0.36 instead of 0.58 ms per 2048 rows
+#ifndef DAGL_WIDE_FP32_SCORES
+    const bool split_scores = g.N >= 2048 && range.word != nullptr;      // (scan = "exact" has no range guard: fp32 products there)
+#else
+    const bool split_scores = false;
+#endif
+    const int rows_xh = feat_rows_h(g.N) + 256, rows_qh = feat_rows_h(g.L) + 256;
+    for (int b = 0; b < B; ++b) {
+        if (split_scores) {
+            int rc = launch_feat_split(s, 1, g.N, rows_x, rows_xh, x + (size_t)b * rows_x * DS, xs_hi, xs_lo, range);
+            if (rc) return rc;
+            if ((rc = launch_feat_split(s, 1, g.L, rows_q, rows_qh, wq + (size_t)b * rows_q * DS, qs_hi, qs_lo, range))) return rc;
+        }
         for (int r0 = 0; r0 < g.L; r0 += Rmax) {
             const int R = (g.L - r0 < Rmax) ? g.L - r0 : Rmax;
             a.b = b; a.r0 = r0; a.R = R;
+            if (split_scores) {
+                Gemm16s gs;
+                gs.M = R; gs.N = g.N; gs.K = 224; gs.k_valid = DSH;
+                gs.a_hi = qs_hi + (size_t)r0 * DSH; gs.a_lo = qs_lo + (size_t)r0 * DSH; gs.lda = DSH; gs.a_rows = rows_qh - r0;
+                gs.b_hi = xs_hi; gs.b_lo = xs_lo; gs.ldb = DSH; gs.b_rows = rows_xh;
+                gs.C = a.scores; gs.ldc = a.ldn; gs.part = nullptr; gs.slices = 1; gs.scale_word = nullptr; gs.alpha0 = 1.0f / (DN_FS * DN_FS);
+                const int rc = launch_gemm16s(s, gs);
+                if (rc) return rc;
+            } else {
             // scores of the batch against all keys of its image: one product [R, 196] x [196, N] on the fp32 matrix cores
             // (chains of 48 products, partial sums added in fp32 -- the form the adaptive mode's flagged rows use)
             Gemm32 gm;
@@ -409,6 +439,7 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
             gm.alpha = 1.f; gm.beta = 0.f; gm.bias = nullptr; gm.relu = 0; gm.chunk_tiles = 3;
             int rc = launch_gemm32(s, gm);
             if (rc) return rc;
+            }
             // k up to WL_KMAX: one block per row does everything from one read of the row; the rows it leaves alone (and larger k: all)
             // go through the three kernels behind it
             a.served = nullptr;
@@ -424,6 +455,7 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
             hipLaunchKernelGGL(wide_combine_kernel, dim3(R < 1024 ? R : 1024), dim3(256), 0, s, a);
             DAGL_LAUNCH_CHECK("wide_combine_kernel");
         }
+    }
     return DAGL_OK;
 }
 
