@@ -147,16 +147,35 @@ struct WideListShared {
     int lst_of[WL_KMAX]; float lst_w[WL_KMAX];       // C / D: the selected keys' map offsets (float4 units) and logits -> weights (8 KiB)
     double dred[WL_THREADS];
     float fred[WL_WAVES];
-    int ired[WL_WAVES];
+    int ired[3 * WL_WAVES];
     int wcnt[WL_WAVES], wgt_n[WL_WAVES], weq_n[WL_WAVES];
 };
 
 // r-th largest of the block's sort keys, WL_PER per thread in registers (0 = no key; 0 when there are fewer than r keys): a bit-wise
-// search, block-uniform result
-__device__ __forceinline__ unsigned wl_kth_largest(const unsigned (&key)[WL_PER], int r, int* ired) {
+// search from the highest bit the keys DIFFER in (scores of a row share sign, exponent and often the leading mantissa bits: ~a dozen
+// steps saved, two block barriers each) down to bit `lo_bit` -- lo_bit > 0 gives a value BELOW the r-th largest with at least r keys
+// above it, which is all the sample's lower bound needs.  Block-uniform result.
+__device__ __forceinline__ unsigned wl_kth_largest(const unsigned (&key)[WL_PER], int r, int* ired, int lo_span = 32) {
     const int tid = threadIdx.x, w = tid >> 6;
-    unsigned prefix = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
+    unsigned kor = 0u, kand = 0xffffffffu; int nz = 0;
+#pragma unroll
+    for (int u = 0; u < WL_PER; ++u) { if (key[u] != 0u) { kor |= key[u]; kand &= key[u]; ++nz; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kor |= __shfl_xor(kor, o); kand &= __shfl_xor(kand, o); }
+    nz = wave_sum_i32(nz);
+    __syncthreads();                                              // (ired's previous use)
+    if ((tid & 63) == 0) { ired[w] = nz; ired[WL_WAVES + w] = (int)kor; ired[2 * WL_WAVES + w] = (int)kand; }
+    __syncthreads();
+    int all_nz = 0;
+#pragma unroll
+    for (int ww = 0; ww < WL_WAVES; ++ww) { all_nz += ired[ww]; kor |= (unsigned)ired[WL_WAVES + ww]; kand &= (unsigned)ired[2 * WL_WAVES + ww]; }
+    if (all_nz < r) return 0u;                                    // block-uniform
+    const unsigned diff = kor ^ kand;
+    if (diff == 0u) return kor;                                   // every key the same value
+    const int top = 31 - __clz((int)diff);                        // highest bit two keys differ in; the bits above it are common
+    unsigned prefix = (top == 31) ? 0u : (kand & ~((2u << top) - 1u));
+    const int lo = (top + 1 - lo_span > 0) ? top + 1 - lo_span : 0;
+    for (int bit = top; bit >= lo; --bit) {
         const unsigned t = prefix | (1u << bit);
         int cnt = 0;
 #pragma unroll
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(WL_THREADS) void wide_list_kernel(WideArgs a) {
     int rs = k;
     if (stride > 1) { const float r = (float)k / (float)stride; rs = (int)(r + 6.0f * sqrtf(r) + 8.0f); }
     if (rs > ns) rs = ns;
-    unsigned tl = wl_kth_largest(sk, rs, sh.ired);
+    unsigned tl = wl_kth_largest(sk, rs, sh.ired, 12);          // (12 bits below the first differing one: a bound 2^-12 of the spread loose)
     if (tl < 1u) tl = 1u;                                           // (key 0 = "not a candidate")
     // ---- B: the candidates, per wave eighth, in key order -------------------------------------------------------------------------------
     {
