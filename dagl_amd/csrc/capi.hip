@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "dagl_common.h"
+#include "thr_bias4.h"
 
 namespace dagl {
 
@@ -422,6 +423,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
 
     // ---- stage 0: layout: zero-bordered NHWC maps, packed fc weights ------------------------------------
     prof_mark(prof, s, 0);
+    ThrHeadSet thr_all = {};
+    bool thr_in_proj = false;
     const int imgs = B / heads;
     // "prepared": the caller vouches that this workspace last served an identical call (same geometry, mode, weights):
     // packed weights, the maps' zero borders and the zero guard rows of the feature matrices are still in place, and
@@ -454,6 +457,13 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         const bool thr_heads = (mode != DAGL_MODE_TOPK);
         const size_t map_f = (size_t)imgs * g.Hp * g.Wp * CH;
         const bool conv_merged = heads > 1 && p.split16;       // a stage's heads: their g / theta convolutions are ONE launch
+        // the thr / bias heads' partial sums are first read by query_thresholds_kernel, behind the projection: on the split-fp16 path their
+        // blocks ride in the projection's launch (round 5; 13 us of every adaptive-mode call as a launch of their own)
+        if (thr_heads) {
+            for (int h2 = 0; h2 < heads; ++h2) { thr_all.x[h2] = fin[h2].x; thr_all.thr_w[h2] = fin[h2].thr_w; thr_all.bias_w[h2] = fin[h2].bias_w; }
+            thr_all.imgs = imgs;
+            thr_in_proj = p.split16 && thr_bias4_ok(g, thr_all, heads);
+        }
         for (int hd = 0; hd < heads; ++hd) {
             const FusedIn& f = fin[hd];
             unsigned char* convw = p.split16 ? at<unsigned char>(ws, p.o_convw) + (size_t)hd * CONV_W16_BYTES : nullptr;
@@ -469,7 +479,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                                    prepared ? reinterpret_cast<uint32_t*>(stats) : nullptr, prepared ? 8 : 0,
                                                    (prepared && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
                                                    (prepared && p.screen) ? B * n_qgroups : 0, rt))) return rc;
-                if (thr_heads) {
+                if (thr_heads && !thr_in_proj) {
                     ThrHeadSet th = {};
                     for (int h2 = 0; h2 < heads; ++h2) { th.x[h2] = fin[h2].x; th.thr_w[h2] = fin[h2].thr_w; th.bias_w[h2] = fin[h2].bias_w; }
                     th.imgs = imgs;
@@ -480,7 +490,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             // writes the hi / lo maps itself and no fp32 copy exists
             if ((rc = launch_prologue(s, imgs, g, f.x, f.g_w, f.g_b, f.th_w, f.th_b, f.thr_w, f.thr_b, f.bias_w, f.bias_b,
                                       p.split16 ? nullptr : b1p + hd * map_f, b2p + hd * map_f,
-                                      thr_heads ? thr_ws + (size_t)hd * imgs * g.L : nullptr,
+                                      (thr_heads && !thr_in_proj) ? thr_ws + (size_t)hd * imgs * g.L : nullptr,
                                       bias_ws + (size_t)hd * imgs * g.L,
                                       p.split16 ? at<uint16_t>(ws, p.o_maphi) + hd * map_f : nullptr,
                                       p.split16 ? at<uint16_t>(ws, p.o_maplo) + hd * map_f : nullptr,
@@ -560,7 +570,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         }
         if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
                                    at<float>(ws, p.o_colpart), wp1h, b1s,
-                                   Wq, Xh, Wqh, heads, rt, q_tiled, split_p))) return rc;
+                                   Wq, Xh, Wqh, heads, rt, q_tiled, split_p,
+                                   thr_in_proj ? &thr_all : nullptr, thr_in_proj ? B : 0, thr_in_proj ? at<float>(ws, p.o_thrpart) : nullptr))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }

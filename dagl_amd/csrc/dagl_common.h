@@ -301,7 +301,9 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      float* colpart, const uint16_t* wp_q, const float* const* bias_q /*[heads]*/, float* feat_q,
                      uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, int heads = 1, RangeTag range = RangeTag(),
                      int q_tiled = 0 /* bf16 query copy in the screen's fragment order (ScreenArgs::q_tiled) */,
-                     const Split16Out* split = nullptr);
+                     const Split16Out* split = nullptr,
+                     const ThrHeadSet* thr_hs = nullptr /* with thr_part: the thr / bias heads' partial sums (thr_bias4.h) as extra blocks of this launch */,
+                     int thr_head_imgs = 0 /* heads x imgs of those heads */, float* thr_part = nullptr);
 int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat /* [B, feat_rows(n), DS] */, float* rows_out /* [B, n, 196] */,
                          RangeTag range);            // dense copy of the feature rows; NaN when the call left the fp16 range
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats

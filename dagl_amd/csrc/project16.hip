@@ -24,8 +24,10 @@
 //                block through a 4-stage LDS ring filled by LDS-DMA; the four 16-byte slots of a 64-byte row are stored at
 //                slot ^ ((row >> 2) & 3), which makes the ds_read_b128 of 32 consecutive rows conflict-free unpadded
 #include <stdlib.h>
+#include <string.h>
 
 #include "dagl_common.h"
+#include "thr_bias4.h"
 
 namespace dagl {
 
@@ -159,6 +161,8 @@ struct Proj16Args {
     float* colpart;                                                 // [B, n_blocks_k, 224] per-block key column sums (or null)
     RangeTag range; int heads;                                      // range guard: the packed weights' flags feed the call's word
     unsigned long long* times;                                      // ablation builds: block phase stamps (debug.hip) or null
+    // the thr / bias heads' blocks (thr_bias4.h) behind the projection's own: n_proj = blocks of the projection, then thr_x x thr_y x TB_GROUPS
+    ThrHeadSet thr_hs; float* thr_part; int n_proj, thr_x, thr_y;
 };
 
 // Block = 4 waves (two blocks per CU, independent barriers).  All operands arrive by LDS-DMA issued from inline asm and are
@@ -831,6 +835,12 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
     // grid that overhangs the resident-block capacity by a few blocks would cost a whole extra round, so the overhang comes last,
     // cut into single-tile blocks (project16_body<1>).
     const int bid = blockIdx.x;
+    if (bid >= pa.n_proj) {                          // (block-uniform) a block of the thr / bias heads: independent of everything this launch computes
+        const int t = bid - pa.n_proj;
+        const int bx = t % pa.thr_x, r2 = t / pa.thr_x;
+        thr_bias4_block(pa.gr, pa.thr_hs, pa.thr_part, bx, r2 % pa.thr_y, r2 / pa.thr_y, smem);
+        return;
+    }
     dbg_stamp(pa.times, bid, 0);
     if (bid == 0 && threadIdx.x < 2 * pa.heads && pa.range.word != nullptr) {        // weights packed from out-of-range values?
         const unsigned short* wpk = pa.wp[threadIdx.x & 1];
@@ -902,8 +912,10 @@ int project16_key_blocks(const Grid& g) { return 2 * ((p16_key_items(g) + P16_UN
 int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint16_t* map_hi, const uint16_t* map_lo,
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
-                     uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled, const Split16Out* split) {
+                     uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled, const Split16Out* split,
+                     const ThrHeadSet* thr_hs, int thr_head_imgs, float* thr_part) {
     Proj16Args pa;
+    static_assert(TB4_LDS_BYTES <= P16_LDS, "the thr / bias blocks live in the projection's LDS");
     for (int w = 0; w < 2; ++w) {
         pa.split_hi[w] = split ? split->hi[w] : nullptr; pa.split_lo[w] = split ? split->lo[w] : nullptr;
         pa.rows_alloc_s[w] = split ? split->rows_alloc[w] : 0;
@@ -939,7 +951,14 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
     int groups = (rem > 0 && rem <= cap / 2) ? (rem + 1) / 2 : 0;        // units whose two blocks overhang the last full round
     if (groups > uk) groups = uk;
     pa.n_split_groups = groups; pa.n_full = total - 2 * groups; pa.batch = B;
-    const dim3 grid(pa.n_full + 2 * P16_NT * groups), block(64 * P16_BW);
+    pa.n_proj = pa.n_full + 2 * P16_NT * groups;
+    pa.thr_part = nullptr; pa.thr_x = pa.thr_y = 1; memset(&pa.thr_hs, 0, sizeof(pa.thr_hs));
+    int n_thr = 0;
+    if (thr_hs != nullptr && thr_part != nullptr && thr_head_imgs > 0) {
+        pa.thr_hs = *thr_hs; pa.thr_part = thr_part; pa.thr_x = thr_bias4_grid_x(g); pa.thr_y = thr_head_imgs;
+        n_thr = pa.thr_x * pa.thr_y * TB_GROUPS;
+    }
+    const dim3 grid(pa.n_proj + n_thr), block(64 * P16_BW);
 #ifdef DAGL_ABLATION      // debug builds only: the variants give wrong results by construction
     if (getenv("DAGL_TIMES_FILE")) pa.times = dbg_times_buffer(grid.x);
     static const int var = getenv("DAGL_P16_VARIANT") ? atoi(getenv("DAGL_P16_VARIANT")) : 0;
