@@ -138,9 +138,8 @@ constexpr int WL_SEG = 512;                          // candidate slots per wave
 constexpr int WL_PER = WL_SAMPLES / WL_THREADS;      // keys a thread holds in the two selections (8)
 static_assert(WL_WAVES * WL_SEG == WL_SAMPLES, "one register set serves both selections");
 struct WideListShared {
-    // one 32 KiB region, three lives: A the sample keys [4096]; B / C the candidates ckey[8][512] | cscore[8][512]; D the waves' partial rows
+    // one 32 KiB region, two lives: B / C the candidates ckey[8][512] | cscore[8][512]; D the waves' partial rows (the sample's keys live in registers)
     union {
-        unsigned samp[WL_SAMPLES];
         struct { int ckey[WL_WAVES][WL_SEG]; float cscore[WL_WAVES][WL_SEG]; } c;
         float4 part[WL_WAVES][P / 4];
     } u;
