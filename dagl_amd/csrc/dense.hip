@@ -291,6 +291,21 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
         dn_glds<4>(xsrc, dst, key_off(0, jy0, jx0), key_off(1, jy0, jx0) - 1024u, key_off(2, jy0, jx0) - 2048u, key_off(3, jy0, jx0) - 3072u);
         dn_glds<3>(xsrc, dst + 4096u, key_off(4, jy0, jx0), key_off(5, jy0, jx0) - 1024u, key_off(6, jy0, jx0) - 2048u, 0);
     };
+#ifdef DAGL_DN_RUNOFF
+    // the producers' key pieces of the tile three ahead: per-lane byte offsets carried from tile to tile (+ 8 pixels' rows per tile; formed
+    // anew where the tile row wraps) -- seven 64-bit multiply-adds, clamps and quarter-rate multiplies per tile otherwise, on the
+    // waves whose chain (key DMA, scores, weights) is what a tile waits for
+    unsigned k_run[kpn];
+    auto key_run_set = [&](int jy0, int jx0) {
+#pragma unroll
+        for (int j = 0; j < kpn; ++j) k_run[j] = key_off(j, jy0, jx0) - 1024u * (unsigned)(j < 4 ? j : j - 4);
+    };
+    auto stage_keys_run = [&](int buf) {
+        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
+        dn_glds<4>(xsrc, dst, k_run[0], k_run[1], k_run[2], k_run[3]);
+        dn_glds<3>(xsrc, dst + 4096u, k_run[4], k_run[5], k_run[6], 0);
+    };
+#endif
     auto stage_values = [&](int jy0, int jx0, int buf) {
         if (producer) return;
         const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
@@ -487,10 +502,17 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     // for 3 000 of matrix work per SIMD, profiles/r04_dense_pc_phases.log).
     if (producer) {
         __builtin_amdgcn_s_setprio(2);
+#ifdef DAGL_DN_RUNOFF
+        key_run_set(y3, x3);
+#endif
         for (int tile = tile0; tile < tile1; ++tile) {
             const int r = tile - tile0;
             DN_PH(0);
+#ifdef DAGL_DN_RUNOFF
+            if (tile + 3 < tile1 && !(a.variant & 4)) stage_keys_run(r % 3);
+#else
             if (tile + 3 < tile1 && !(a.variant & 4)) stage_keys(y3, x3, r % 3);
+#endif
             DN_PH(1);
             if (tile + 1 < tile1) {
                 // One basic block, 14 slots = (k-step, key group): per slot the fragment pair of slot + 2 is requested, the slot's
@@ -557,8 +579,17 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             }
             y0 = y1; x0 = x1; y1 = y2; x1 = x2; y2 = y3; x2 = x3;
             next_tile(y2, x2, y3, x3);
+#ifdef DAGL_DN_RUNOFF
+            if (x3 != 0) {                                 // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < kpn; ++j) k_run[j] += (unsigned)(DN_TW * DSH * 2);
+            } else {
+                key_run_set(y3, x3);
+            }
+#endif
             DN_PH(6);
             dma_wait_all();
+            DN_PH(7);
             __syncthreads();
             DN_PH(5);
         }
@@ -579,6 +610,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             next_tile(y2, x2, y3, x3);
             DN_PH(6);
             dma_wait_all();
+            DN_PH(7);
             __syncthreads();
             DN_PH(5);
         }
@@ -845,7 +877,9 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
             unsigned* h = static_cast<unsigned*>(malloc(n_blocks * 96 * sizeof(unsigned)));
             if (h && hipMemcpy(h, a.phase_out, n_blocks * 96 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
                 if (FILE* f = fopen(getenv("DAGL_TIMES_FILE"), "a")) {
-                    static const char* nm[8] = {"stage", "S", "weights", "p-load", "AV", "wait+barrier", "coords", "-"};
+                    // producers (waves 0-3): 1 = key DMA issue, 6 = scores + weights; multiplying waves: 3 = value DMA issue + weight fragments,
+                    // 4 = A V, 6 = tap 48 + tile coordinates; all: 7 = wait for the wave's own DMA pieces, 5 = barrier
+                    static const char* nm[8] = {"top", "key-dma", "-", "v-dma+p-load", "AV", "barrier", "S+w | tap48", "dma-wait"};
                     for (int grp = 0; grp < 3; ++grp) {               // waves 0-3: producers, 4-11: consumers
                         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
                         for (size_t bl = 0; bl < n_blocks; ++bl)
@@ -853,7 +887,7 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
                                 for (int e = 0; e < 8; ++e) sum[e] += h[(bl * 12 + w) * 8 + e];
                         for (int e = 0; e < 8; ++e) { sum[e] /= (double)(n_blocks * 4); tot += sum[e]; }
                         fprintf(f, "dense_attend phases, waves %d-%d (clocks per wave, %d tiles per block): total %.0f |", 4 * grp, 4 * grp + 3, a.tiles_per_split, tot);
-                        for (int e = 0; e < 7; ++e) fprintf(f, " %s %.0f (%.1f %%)", nm[e], sum[e], 100.0 * sum[e] / tot);
+                        for (int e = 0; e < 8; ++e) fprintf(f, " %s %.0f (%.1f %%)", nm[e], sum[e], 100.0 * sum[e] / tot);
                         fprintf(f, "\n");
                     }
                     fclose(f);
