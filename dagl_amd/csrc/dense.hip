@@ -160,28 +160,41 @@ __device__ __forceinline__ DnFrag dn_vfrag(unsigned va) {
 // caller (64 queries x 16 keys).  Per-query-tile skipping inside here -- uniform branches around groups of three multiplies --
 // skips 5-10 % more granules on synthetic maps and is 2-3 % slower where nothing is zero; compile-time instantiations per
 // (query tile 0 live, query tile 1 live) made the register allocator spill ~290 registers (profiles/r04_ab_dense_variants.log).
-__device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX],
-                                      const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], DnFrag f /* = dn_vfrag(va_kb + vt_off[0]) */) {
-    // the fragment of column tile t + 1 is requested before tile t's multiplies (the first one by the caller, together with the weights)
+__device__ __forceinline__ DnFrag dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb, const unsigned (&vt_off)[DN_CTMAX],
+                                        const dnh8 (&p_hi)[2], const dnh8 (&p_lo)[2], DnFrag f /* = dn_vfrag(va_kb + vt_off[0]) */,
+                                        unsigned va_next) {
+    // The hi half of column tile t + 1's fragment is requested before tile t's multiplies, its lo half after the two multiplies that
+    // use tile t's lo half (into the registers those free: 12 fragment registers live instead of 16 -- the loop sits at the register
+    // cap); before the last tile's multiplies: the first fragment of the NEXT k-block (va_next: this tile's second k-block, or the
+    // next tile's first one), returned to the caller.  The weights' lo halves are used last: they are requested at the top of the
+    // k-block, the hi halves one k-block ahead.
 #pragma unroll
     for (int t = 0; t < DN_CTMAX; ++t) {
-        DnFrag fn = f;
-        if (t + 1 < DN_CTMAX) fn = dn_vfrag(va_kb + vt_off[t + 1]);
+        const unsigned an = t + 1 < DN_CTMAX ? va_kb + vt_off[t + 1] : va_next;
+        DnFrag fn;
+        fn.h0 = dn_tr16(an); fn.h1 = dn_tr16(an + 128);
+#ifdef DAGL_DN_FNFULL
+        fn.l0 = dn_tr16(an + DN_VPART_B); fn.l1 = dn_tr16(an + DN_VPART_B + 128);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
         const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
         const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
-        {
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[0], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[1], acc[1][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[0], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[1], acc[1][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[0], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[1], acc[1][t], 0, 0, 0);
-        }
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[0], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_lo, p_hi[1], acc[1][t], 0, 0, 0);
+#ifndef DAGL_DN_FNFULL
+        __builtin_amdgcn_sched_barrier(0);
+        fn.l0 = dn_tr16(an + DN_VPART_B); fn.l1 = dn_tr16(an + DN_VPART_B + 128);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[0], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_hi[1], acc[1][t], 0, 0, 0);
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[0], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_hi, p_lo[1], acc[1][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         f = fn;
     }
+    return f;
 }
 
 #ifdef DAGL_ABLATION
@@ -195,14 +208,13 @@ __device__ __forceinline__ void dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_kb
 constexpr int DN_THREADS = 768;                    // 12 waves: 4 form scores / weights (one per SIMD), 8 multiply (two per SIMD)
 __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char sm[3 * DN_KTILE_B];     // 84 KiB: key-feature tiles hi | lo, three stages
-    __shared__ __attribute__((aligned(1024))) unsigned char sv[2 * DN_VTILE_B];     // 24 KiB: value regions hi | lo, two stages
-    __shared__ __attribute__((aligned(16))) unsigned char spq[2 * DN_PQ_B];         // 20 KiB: the tiles' weights, two stages
+    __shared__ __attribute__((aligned(1024))) unsigned char sv[3 * DN_VTILE_B];     // 36 KiB: value regions hi | lo, three stages
+    __shared__ __attribute__((aligned(16))) unsigned char spq[3 * DN_PQ_B];         // 30 KiB: the tiles' weights, three stages
     __shared__ double szz[4][64][2];                                                // 4 KiB: the lanes' shares of a query's sums (end of the block)
     __shared__ int sdg[4][64];
     __shared__ float slt[4][64];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
     const int b = blockIdx.y;
     const Grid& g = a.g;
     const int n_qblocks = (g.L + 63) / 64;
@@ -215,6 +227,14 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const int tile0 = split * a.tiles_per_split;
     int tile1 = tile0 + a.tiles_per_split;
     if (tile1 > a.n_tiles) tile1 = a.n_tiles;
+    const int n_t = tile1 - tile0;
+    // first pass: the row's shift from rowmax_exact_kernel's score (dn_shift);
+    // second pass (see dense_combine_kernel): only the blocks of 64 queries flagged by the first one, shifted by their rows' EXACT largest logit
+    if (a.pass == 1 && a.redo_blk[b * n_qblocks + qb] == 0) return;
+    if (a.pass == 0 && split == 0 && tid == 0) {
+        a.redo_blk[b * n_qblocks + qb] = 0;                                              // (set by the first combine, behind this launch)
+        if (blockIdx.x == 0 && b == 0) *a.redo_count = 0;                                // blocks the first combine flags (info->dense_rerun_blocks)
+    }
 
     // ---- roles ------------------------------------------------------------------------------------------------------------------
     // waves 0-3 ("producers", one per SIMD): scores and weights of query group qg = wave (16 queries) against the tile's 32 keys
@@ -223,304 +243,184 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     // waves 4-11 ("consumers", two per SIMD): A V.  lane = (column / query i, key half h) of the 32x32x16 multiply; consumer cw =
     // column tiles [3 cw, 3 cw + 3) of both query tiles; consumers 0-3 also the 49th tap of query group cw; they request the value
     // regions.
+    // The two roles are two code paths from here to the block's last barrier (the same number of barriers on both): everything a
+    // role keeps per lane is formed inside its path, so that nothing of one role holds registers on the other's (both loops run at
+    // the 168-register cap of three waves per SIMD; with shared segments in between, the query fragments of the producers were
+    // kept -- and spilled -- across the multiplying waves' loop).
     const bool producer = wave < 4;
-    const int cw = producer ? 0 : wave - 4;
-    const int qg = producer ? wave : (cw & 3);
-    const int c16 = lane & 15, gk = lane >> 4;
-    const int i = lane & 31, h = lane >> 5;
-    const int ct0 = dn_ct_start(cw);
-
-    const int qs = qb * 64 + 16 * qg + c16;                                        // the query of this lane's scores
-    const int qsc = qs < g.L ? qs : g.L - 1;
-    const size_t qlin = (size_t)b * g.L + qsc;
-    const float mtq = a.mt[qlin], bsq = a.bs[qlin];
-    // first pass: the row's shift from rowmax_exact_kernel's score (dn_shift);
-    // second pass (see dense_combine_kernel): only the blocks of 64 queries flagged by the first one, shifted by their rows' EXACT largest logit
-    if (a.pass == 1 && a.redo_blk[b * n_qblocks + qb] == 0) return;
-    if (a.pass == 0 && split == 0 && tid == 0) {
-        a.redo_blk[b * n_qblocks + qb] = 0;                                              // (set by the first combine, behind this launch)
-        if (blockIdx.x == 0 && b == 0) *a.redo_count = 0;                                // blocks the first combine flags (info->dense_rerun_blocks)
-    }
-    const float m_run = dn_shift(a, qlin);
-
-    // ---- staging plan (per lane, once) ---------------------------------------------------------------------------------------------
-    // keys by the producers: part = wave >> 1 (hi | lo), the part's 14 pieces over its two waves, 7 each, under two M0 set-ups; values by
-    // the consumers: part = cw >> 2, the part's 6 pieces over its four waves as 1 / 1 / 2 / 2.
-    // Position p of a piece: 16-byte slot p of the part's LDS image.
-    const int spart = producer ? (wave >> 1) : (cw >> 2), wl = cw & 3;
-    const int kp0 = 7 * (wave & 1);
-    constexpr int kpn = 7;
-    const int vp0 = wl < 2 ? wl : 2 + 2 * (wl - 2), vpn = wl < 2 ? 1 : 2;
-    unsigned k_c[kpn];                                 // key piece j: bits 0-15 byte offset inside the pixel row's run of keys (+ bias),
-                                                       // bits 16-17 pixel row of the key inside the tile
-#pragma unroll
-    for (int j = 0; j < kpn; ++j) {
-        const int p = (kp0 + j) * 64 + lane;
-        const int row = p / DN_KPITCH, phys = p - row * DN_KPITCH;
-        const int logical = (phys & ~3) | ((phys & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3));
-        k_c[j] = (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096) | ((unsigned)(row >> 3) << 16);
-    }
-    unsigned v_c[2];                                   // value piece j: bits 0-15 byte offset inside the pixel (+ bias), 16-19 region row, 20-23 pixel
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = (vp0 + (j < vpn ? j : 0)) * 64 + lane;
-        int row = p / (2 * DN_VPX); const int c36 = p - row * (2 * DN_VPX);
-        if (row > DN_RH - 1) row = DN_RH - 1;                                    // (slack positions of the last piece: any valid address)
-        int px = c36 >> 1; if (px > DN_RW - 1) px = DN_RW - 1;
-        v_c[j] = (unsigned)(16 * (c36 & 1) + 4096) | ((unsigned)row << 16) | ((unsigned)px << 20);
-    }
     const unsigned lds_sm = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
     const unsigned lds_sv = __builtin_amdgcn_readfirstlane(lds_addr_of(sv));
     const unsigned lds_pq = __builtin_amdgcn_readfirstlane(lds_addr_of(spq));
-    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>((spart ? a.x_lo : a.x_hi) + (size_t)b * a.rows_xh * DSH) - 4096;
-    const unsigned char* vsrc = reinterpret_cast<const unsigned char*>((spart ? a.v_lo : a.v_hi) + (size_t)b * g.Hp * g.Wp * CH) - 4096;
-    auto key_off = [&](int j, int jy0, int jx0) {
-        int jy = jy0 + (int)(k_c[j] >> 16); if (jy > g.H - 1) jy = g.H - 1;      // ragged bottom: a valid row, keys masked below
-        return (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (k_c[j] & 0xffffu);
-    };
-    auto value_off = [&](int j, int jy0, int jx0) {
-        int y = jy0 + (int)((v_c[j] >> 16) & 15u); if (y > g.Hp - 1) y = g.Hp - 1;   // stay inside the padded map
-        int x = jx0 + (int)(v_c[j] >> 20); if (x > g.Wp - 1) x = g.Wp - 1;
-        return (unsigned)(y * g.Wp + x) * 32u + (v_c[j] & 0xffffu);
-    };
-    // (several pieces under one M0 set-up: piece jj of a group carries the immediate offset 1024 jj, which advances the LDS AND the
-    // global address -- its lane offset is taken back by as much; one piece per set-up cost the wave ~200 cycles a piece)
-    auto stage_keys = [&](int jy0, int jx0, int buf) {
-        if (!producer) return;                                                   // wave-uniform
-        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
-        dn_glds<4>(xsrc, dst, key_off(0, jy0, jx0), key_off(1, jy0, jx0) - 1024u, key_off(2, jy0, jx0) - 2048u, key_off(3, jy0, jx0) - 3072u);
-        dn_glds<3>(xsrc, dst + 4096u, key_off(4, jy0, jx0), key_off(5, jy0, jx0) - 1024u, key_off(6, jy0, jx0) - 2048u, 0);
-    };
-#ifdef DAGL_DN_RUNOFF
-    // the producers' key pieces of the tile three ahead: per-lane byte offsets carried from tile to tile (+ 8 pixels' rows per tile; formed
-    // anew where the tile row wraps) -- seven 64-bit multiply-adds, clamps and quarter-rate multiplies per tile otherwise, on the
-    // waves whose chain (key DMA, scores, weights) is what a tile waits for
-    unsigned k_run[kpn];
-    auto key_run_set = [&](int jy0, int jx0) {
-#pragma unroll
-        for (int j = 0; j < kpn; ++j) k_run[j] = key_off(j, jy0, jx0) - 1024u * (unsigned)(j < 4 ? j : j - 4);
-    };
-    auto stage_keys_run = [&](int buf) {
-        const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
-        dn_glds<4>(xsrc, dst, k_run[0], k_run[1], k_run[2], k_run[3]);
-        dn_glds<3>(xsrc, dst + 4096u, k_run[4], k_run[5], k_run[6], 0);
-    };
-#endif
-    auto stage_values = [&](int jy0, int jx0, int buf) {
-        if (producer) return;
-        const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
-        // (one piece per statement here: with several offsets live at once the allocator spilled the consumers' accumulators)
-        dn_glds<1>(vsrc, dst, value_off(0, jy0, jx0), 0, 0, 0);
-        if (vpn > 1) dn_glds<1>(vsrc, dst + 1024u, value_off(1, jy0, jx0), 0, 0, 0);     // wave-uniform
-    };
-
-    // tile coordinates (pixels) of the tiles in flight: c0 = the tile being attended, c1 = the next, c2 = the one after
-    int y0 = (tile0 / a.tiles_per_row) * DN_TH, x0 = (tile0 % a.tiles_per_row) * DN_TW, y1, x1, y2, x2, y3, x3;
+    auto lane_now = [&]() { int l = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(l)); return l; };
     const int xwrap = a.tiles_per_row * DN_TW;
-    auto next_tile = [&](int y, int x, int& yn, int& xn) { xn = x + DN_TW; yn = y; if (xn >= xwrap) { xn = 0; yn = y + DN_TH; } };
-    next_tile(y0, x0, y1, x1);
-    next_tile(y1, x1, y2, x2);
-    next_tile(y2, x2, y3, x3);
-    if (tile0 < tile1) { stage_keys(y0, x0, 0); stage_values(y0, x0, 0); }
-    if (tile0 + 1 < tile1) stage_keys(y1, x1, 1);
-    if (tile0 + 2 < tile1) stage_keys(y2, x2, 2);
+    auto next_tile = [&](int& y, int& x) { x += DN_TW; if (x >= xwrap) { x = 0; y += DN_TH; } };
+    const int ty0 = (tile0 / a.tiles_per_row) * DN_TH, tx0 = (tile0 % a.tiles_per_row) * DN_TW;
 
-    // ---- the query fragments of S: lane (c16, gk) holds features 32 ks + 8 gk .. + 7 of query qs, hi and lo (rows past L are zero
-    // guard rows; halfs 216.. of a row do not exist: zero, and the staged key rows' slots 26 / 27 meet only these zeros) ----------
-    dnh8 qf_hi[DN_KS], qf_lo[DN_KS];
     if (producer) {
-        const uint4* rh = reinterpret_cast<const uint4*>(a.wq_hi + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
-        const uint4* rl = reinterpret_cast<const uint4*>(a.wq_lo + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
+        // ================================================= scores and weights =================================================
+        const int lane = lane_now();
+        const int qg = wave;
+        const int c16 = lane & 15, gk = lane >> 4;
+        const int qs = qb * 64 + 16 * qg + c16;                                    // the query of this lane's scores
+        const int qsc = qs < g.L ? qs : g.L - 1;
+        const size_t qlin = (size_t)b * g.L + qsc;
+        const float mtq = a.mt[qlin], bsq = a.bs[qlin];
+        const float m_run = dn_shift(a, qlin);
+        // ---- the key tiles' LDS-DMA: part = wave >> 1 (hi | lo), the part's 14 pieces of 1 KiB over its two waves, 7 each, under two M0
+        // set-ups (piece jj of a group carries the immediate offset 1024 jj, which advances the LDS AND the global address -- its lane
+        // offset is taken back by as much; one piece per set-up cost the wave ~200 cycles a piece).  Position p of a piece: 16-byte slot
+        // p of the part's LDS image = key row p / 28 of the tile (pixel row row >> 3, pixel row & 7), physical slot p % 28.  The pieces'
+        // per-lane byte offsets are CARRIED from tile to tile (+ 8 pixels per tile) and formed anew only where the tile row wraps
+        // (seven 64-bit multiply-adds, clamps and quarter-rate multiplies per tile otherwise) -- from the lane number again, so that
+        // the plan's constants hold no registers across the loop.
+        const int spart = wave >> 1, kp0 = 7 * (wave & 1);
+        constexpr int kpn = 7;
+        const unsigned char* xsrc = reinterpret_cast<const unsigned char*>((spart ? a.x_lo : a.x_hi) + (size_t)b * a.rows_xh * DSH) - 4096;
+        unsigned k_run[kpn];
+        auto key_run_set = [&](int jy0, int jx0) {
+            const int ln = lane_now();
 #pragma unroll
-        for (int ks = 0; ks < DN_KS; ++ks) {
-            const bool in = 4 * ks + gk < DSH / 8;
-            const int slot = in ? 4 * ks + gk : DSH / 8 - 1;
-            uint4 vh = rh[slot], vl = rl[slot];
-            if (!in) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
-            qf_hi[ks] = __builtin_bit_cast(dnh8, vh);
-            qf_lo[ks] = __builtin_bit_cast(dnh8, vl);
+            for (int j = 0; j < kpn; ++j) {
+                const int p = (kp0 + j) * 64 + ln;
+                const int row = p / DN_KPITCH, phys = p - row * DN_KPITCH;
+                const int logical = (phys & ~3) | ((phys & 3) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3));
+                int jy = jy0 + (row >> 3); if (jy > g.H - 1) jy = g.H - 1;       // ragged bottom: a valid row, keys masked below
+                k_run[j] = (unsigned)(jy * g.W + jx0) * (unsigned)(DSH * 2) + (unsigned)((row & 7) * (DSH * 2) + logical * 16 + 4096) -
+                           1024u * (unsigned)(j < 4 ? j : j - 4);
+            }
+        };
+        auto stage_keys_run = [&](int buf) {
+            const unsigned dst = lds_sm + (unsigned)(buf * DN_KTILE_B + spart * DN_KPART_B + kp0 * 1024);
+            dn_glds<4>(xsrc, dst, k_run[0], k_run[1], k_run[2], k_run[3]);
+            dn_glds<3>(xsrc, dst + 4096u, k_run[4], k_run[5], k_run[6], 0);
+        };
+        int yk = ty0, xk = tx0;                            // the tile of the next key request
+        int yw = ty0, xw = tx0;                            // the tile whose weights are formed next
+        for (int t = 0; t < 3; ++t) {                      // tiles 0-2 -> stages 0-2
+            if (t < n_t) { key_run_set(yk, xk); stage_keys_run(t); }
+            next_tile(yk, xk);
         }
-    }
+        key_run_set(yk, xk);                               // tile 3: requested in interval -1
 
-    f32x16 acc[2][DN_CTMAX];                           // (consumers; cleared in front of their loop)
-    f32x4 acc48;                                       // tap 48 (consumers 0-3): out^T[channel 4 gk + r][query 16 cw + c16]
-    double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
-    float l_top = 0.f;                                 // largest logit among this lane's passing keys (the guard of dense_combine_kernel)
-    int deg = 0;
+        // ---- the query fragments of S: lane (c16, gk) holds features 32 ks + 8 gk .. + 7 of query qs, hi and lo (rows past L are zero
+        // guard rows; halfs 216.. of a row do not exist: zero, and the staged key rows' slots 26 / 27 meet only these zeros) ----------
+        dnh8 qf_hi[DN_KS], qf_lo[DN_KS];
+        {
+            const uint4* rh = reinterpret_cast<const uint4*>(a.wq_hi + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
+            const uint4* rl = reinterpret_cast<const uint4*>(a.wq_lo + ((size_t)b * a.rows_qh + (size_t)qb * 64 + 16 * qg + c16) * DSH);
+#pragma unroll
+            for (int ks = 0; ks < DN_KS; ++ks) {
+                const bool in = 4 * ks + gk < DSH / 8;
+                const int slot = in ? 4 * ks + gk : DSH / 8 - 1;
+                uint4 vh = rh[slot], vl = rl[slot];
+                if (!in) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+                qf_hi[ks] = __builtin_bit_cast(dnh8, vh);
+                qf_lo[ks] = __builtin_bit_cast(dnh8, vl);
+            }
+        }
+        double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
+        float l_top = 0.f;                                 // largest logit among this lane's passing keys (the guard of dense_combine_kernel)
+        int deg = 0;
+        // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row (kg = 1: + 16 rows)
+        const unsigned ka_off = (unsigned)(c16 * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
+        // where this lane's four weights of key group kg go: entry (query tile, key half, query) of the A V lane that multiplies them
+        // (kg = 1: + 16 bytes)
+        const unsigned pw_off = (unsigned)((((qg >> 1) * 64 + (gk >> 1) * 32 + 16 * (qg & 1) + c16) * DN_PQ_ENTRY) + (gk & 1) * 8);
 
-    // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row (kg = 1: + 16 rows)
-    const unsigned ka_off = (unsigned)(c16 * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
-    // where this lane's four weights of key group kg go: entry (query tile, key half, query) of the A V lane that multiplies them
-    // (kg = 1: + 16 bytes)
-    const unsigned pw_off = (unsigned)((((qg >> 1) * 64 + (gk >> 1) * 32 + 16 * (qg & 1) + c16) * DN_PQ_ENTRY) + (gk & 1) * 8);
-    const unsigned pr_off = (unsigned)(lane * DN_PQ_ENTRY);
-    // A V operand A: lane t = lane & 15 of a 16-lane group supplies the 8 bytes (pixel t >> 2, channels 4 (t & 3) ..) of the group's
-    // [4 pixels][16 channels] block; the group = (tap parity, key half h)
-    const bool second = (lane & 16) != 0;
-    const unsigned va_lane = (unsigned)(((c16 >> 2) * 32) + (c16 & 3) * 8 + h * (DN_VPX * 32));
-    // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes 16-31 / 48-63 ("second") take the odd tap
-    unsigned vt_off[DN_CTMAX];
+        // raw scores of the 32 keys staged in sm[kbuf] against this wave's 16 queries: three split products per key group, 42 multiplies
+        struct SAcc { f32x4 hh[2], hl[2], lh[2]; };
+        auto scores = [&](int kbuf, SAcc& sa) {
 #pragma unroll
-    for (int t = 0; t < DN_CTMAX; ++t) {
-        const int tap = 2 * (ct0 + t) + (second ? 1 : 0);
-        const int kh = tap / KS, kw = tap - kh * KS;
-        vt_off[t] = (unsigned)((kh * DN_VPX + kw) * 32) + va_lane;
-    }
-
-    // raw scores of the 32 keys staged in sm[kbuf] against this wave's 16 queries: three split products per key group, 42 multiplies
-    struct SAcc { f32x4 hh[2], hl[2], lh[2]; };
-    auto scores = [&](int kbuf, SAcc& sa) {
+            for (int kg = 0; kg < 2; ++kg) { sa.hh[kg] = f32x4{0.f, 0.f, 0.f, 0.f}; sa.hl[kg] = sa.hh[kg]; sa.lh[kg] = sa.hh[kg]; }
+            const unsigned kb_addr = lds_sm + (unsigned)(kbuf * DN_KTILE_B) + ka_off;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) { sa.hh[kg] = f32x4{0.f, 0.f, 0.f, 0.f}; sa.hl[kg] = sa.hh[kg]; sa.lh[kg] = sa.hh[kg]; }
-        const unsigned kb_addr = lds_sm + (unsigned)(kbuf * DN_KTILE_B) + ka_off;
+            for (int ks = 0; ks < DN_KS; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < DN_KS; ++ks)
+                for (int kg = 0; kg < 2; ++kg) {
+                    const unsigned ad = kb_addr + (unsigned)(kg * 16 * (DN_KPITCH * 16) + 64 * ks);
+                    const dnh8 k_hi = __builtin_bit_cast(dnh8, dn_lds128(ad));
+                    const dnh8 k_lo = __builtin_bit_cast(dnh8, dn_lds128(ad + DN_KPART_B));
+                    sa.hl[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], sa.hl[kg], 0, 0, 0);
+                    sa.hh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], sa.hh[kg], 0, 0, 0);
+                    sa.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], sa.lh[kg], 0, 0, 0);
+                }
+        };
+        // logits, weights and their sums from a tile's raw scores; the split weights go to spq[pbuf]
+        auto weights = [&](int jy0, int jx0, int pbuf, const SAcc& sa) {
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                const unsigned ad = kb_addr + (unsigned)(kg * 16 * (DN_KPITCH * 16) + 64 * ks);
-                const dnh8 k_hi = __builtin_bit_cast(dnh8, dn_lds128(ad));
-                const dnh8 k_lo = __builtin_bit_cast(dnh8, dn_lds128(ad + DN_KPART_B));
-                sa.hl[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_lo[ks], sa.hl[kg], 0, 0, 0);
-                sa.hh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], sa.hh[kg], 0, 0, 0);
-                sa.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], sa.lh[kg], 0, 0, 0);
-            }
-    };
-    // logits, weights and their sums from a tile's raw scores; the split weights go to spq[pbuf]
-    auto weights = [&](int jy0, int jx0, int pbuf, const SAcc& sa) {
+                // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
+                float zt = 0.f, zpt = 0.f;                     // this tile's sums in fp32, one fp64 add per tile
+                int dt = 0;
+                _Float16 hq[4], lq[4];
+                const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
-            float zt = 0.f, zpt = 0.f;                     // this tile's sums in fp32, one fp64 add per tile
-            int dt = 0;
-            _Float16 hq[4], lq[4];
-            const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = (sa.hh[kg][r] + (sa.hl[kg][r] + sa.lh[kg][r])) * (1.0f / (DN_FS * DN_FS));
-                const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
-                bool pass;
-                const float l = dn_logit(sc, mtq, bsq, pass);
-                const float e = __expf(fminf(l - m_run, 0.f));                    // (the bound holds; the clamp is a seat belt)
-                const float p = valid ? e : 0.f;
-                zt += p;
-                pass = pass && valid;
-                l_top = fmaxf(l_top, pass ? l : 0.f);
-                const float pp = pass ? p : 0.f;
-                zpt += pp;
-                dt += pass ? 1 : 0;
-                const float ps = pp * DN_PS;
-                hq[r] = (_Float16)ps;
-                lq[r] = (_Float16)(ps - (float)hq[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = (sa.hh[kg][r] + (sa.hl[kg][r] + sa.lh[kg][r])) * (1.0f / (DN_FS * DN_FS));
+                    const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
+                    bool pass;
+                    const float l = dn_logit(sc, mtq, bsq, pass);
+                    const float e = __expf(fminf(l - m_run, 0.f));                    // (the bound holds; the clamp is a seat belt)
+                    const float p = valid ? e : 0.f;
+                    zt += p;
+                    pass = pass && valid;
+                    l_top = fmaxf(l_top, pass ? l : 0.f);
+                    const float pp = pass ? p : 0.f;
+                    zpt += pp;
+                    dt += pass ? 1 : 0;
+                    const float ps = pp * DN_PS;
+                    hq[r] = (_Float16)ps;
+                    lq[r] = (_Float16)(ps - (float)hq[r]);
+                }
+                z_run += (double)zt; zp_run += (double)zpt; deg += dt;
+                const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
+                unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
+                *reinterpret_cast<dnh4*>(pq) = hv;
+                *reinterpret_cast<dnh4*>(pq + 32) = lv;
             }
-            z_run += (double)zt; zp_run += (double)zpt; deg += dt;
-            const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
-            unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
-            *reinterpret_cast<dnh4*>(pq) = hv;
-            *reinterpret_cast<dnh4*>(pq + 32) = lv;
-        }
-    };
+        };
+        float sc_next[2][4];                               // raw scores of the tile whose weights the next interval forms
+        auto final_scores = [&](const SAcc& sa) {
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) sc_next[kg][rr] = (sa.hh[kg][rr] + (sa.hl[kg][rr] + sa.lh[kg][rr])) * (1.0f / (DN_FS * DN_FS));
+        };
 
-    // the weights of BOTH query tiles for a k-block (lane = query i, keys 16 kb + 8 h ..): hi | lo, and whether any is non-zero:
-    // a granule (32 queries x 16 keys) whose weights are all exactly zero adds exactly nothing and is skipped.  (hi = 0 implies
-    // lo = 0: the split of a number below half the smallest denormal; -0 cannot occur, p >= 0.)
-    struct PFrag { dnu4 h[2], l[2]; };
-    auto load_p = [&](int buf, int kb) {
-        PFrag f;
-        const unsigned pa = lds_pq + (unsigned)(buf * DN_PQ_B + 16 * kb) + pr_off;
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) { f.h[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY)); f.l[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY + 32)); }
-        return f;
-    };
-    auto attend = [&](int buf) {
-        if (a.variant & 1) return;
-        const unsigned vbase = lds_sv + (unsigned)(buf * DN_VTILE_B);
-        PFrag pf = load_p(buf, 0);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            // (the k-block's first value fragment is requested before the weights are looked at: one LDS round trip, not two)
-            const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
-            const DnFrag f0 = dn_vfrag(va_kb + vt_off[0]);
-            dnh8 p_hi[2], p_lo[2];
-            bool nz[2];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                p_hi[qq] = __builtin_bit_cast(dnh8, pf.h[qq]); p_lo[qq] = __builtin_bit_cast(dnh8, pf.l[qq]);
-                nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((pf.h[qq].x | pf.h[qq].y) | (pf.h[qq].z | pf.h[qq].w)) != 0u) != 0ull;
-            }
-            if (kb == 0) pf = load_p(buf, 1);              // the second k-block's weights arrive under the first one's multiplies
-            DN_PH(3);
-            if (nz[0] || nz[1])                            // (wave-uniform)
-                dn_pv(acc, va_kb, vt_off, p_hi, p_lo, f0);
-            DN_PH(4);
+        dma_wait_all();
+        __syncthreads();                                   // barrier 1: tiles 0-2 staged
+        {
+            SAcc s0;
+            if (n_t > 0) { scores(0, s0); weights(yw, xw, 0, s0); }
+            next_tile(yw, xw);
+            if (n_t > 1) { scores(1, s0); final_scores(s0); }
         }
-        if (cw < 4) {
-            // tap 48 = patch position (6, 6): 16 channels x the 16 queries 16 cw .. of the block, K = the tile's 32 keys.  Lane
-            // (c16, gk): operand B = the weights of query c16 for keys 8 gk .. (k-block gk >> 1, key half gk & 1 of the exchange
-            // layout), operand A = channel c16 of the region pixels (row 6 + gk, columns 6 .. 13) through the transposing read
-            const unsigned pe = lds_pq + (unsigned)(buf * DN_PQ_B + (((cw >> 1) * 64 + (gk & 1) * 32 + 16 * (cw & 1) + c16) * DN_PQ_ENTRY) + 16 * (gk >> 1));
-            const dnu4 wh = dn_lds128(pe), wl = dn_lds128(pe + 32);
-            if ((a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull) {
-                const DnFrag f = dn_vfrag(vbase + (unsigned)(((6 + gk) * DN_VPX + 6 + (c16 >> 2)) * 32 + (c16 & 3) * 8));
-                const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
-                const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
-                const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
-                const dnh8 q_hi = __builtin_bit_cast(dnh8, wh), q_lo = __builtin_bit_cast(dnh8, wl);
-                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_lo, acc48, 0, 0, 0);
-                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_lo, q_hi, acc48, 0, 0, 0);
-                acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_hi, acc48, 0, 0, 0);
-            }
-        }
-    };
+        __syncthreads();                                   // barrier 2: weights of tile 0 written, stage 0 of the keys read
 
-    dma_wait_all();
-    __syncthreads();
-    float sc_next[2][4];                                   // (producers) scores of the tile AFTER the one the consumers multiply next
-    auto final_scores = [&](const SAcc& sa) {
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) sc_next[kg][rr] = (sa.hh[kg][rr] + (sa.hl[kg][rr] + sa.lh[kg][rr])) * (1.0f / (DN_FS * DN_FS));
-    };
-    if (producer) {
-        SAcc s0;
-        if (tile0 < tile1) { scores(0, s0); weights(y0, x0, 0, s0); }
-        if (tile0 + 1 < tile1) { scores(1, s0); final_scores(s0); }
-    }
-    __syncthreads();
-
-    // One barrier per tile; between two barriers the two kinds of wave work on different tiles.  With r = tile - tile0: the producers
-    // request the key features of tile r + 3 (-> sm[r % 3]: tile r's were consumed two iterations ago), turn the raw scores of tile
-    // r + 1 (in their registers since the last iteration) into weights (-> spq[(r + 1) & 1]) and form the raw scores of tile r + 2
-    // (sm[(r + 2) % 3]); the consumers request the value region of tile r + 1 (-> sv[(r + 1) & 1]) and multiply tile r (spq[r & 1],
-    // sv[r & 1]).  A multiplying wave issues nothing but fragment reads and multiplies (and 1.5 LDS-DMA pieces): with both kinds of
-    // work in every wave (the first round-4 shape: 8 waves, the two of a SIMD in opposite order) the pipes were 55 % busy.
-    // Two loops, one per role (the same number of barriers in both): the query fragments are live in one, the accumulators in the
-    // other -- in one loop with a branch inside both would hold their registers in every wave.
-    // The producer's multiplies wait for the matrix pipe behind the consumers' (a 32-cycle multiply is not pre-empted: ~50 cycles
-    // per short multiply, 42 of them): its ~250 VALU operations of the weights are issued BETWEEN them -- scores of one tile,
-    // weights of the previous one, no dependence -- instead of after them (scores, then weights: the chain was 5 000 cycles per tile
-    // for 3 000 of matrix work per SIMD, profiles/r04_dense_pc_phases.log).
-    if (producer) {
+        // One barrier per tile; between two barriers the two kinds of wave work on different tiles.  Interval r (r = tile - tile0; the
+        // producers start one interval early, r = -1): the producers request the key features of tile r + 4 (-> sm[(r + 1) % 3], read
+        // last in interval r - 2), turn the raw scores of tile r + 2 (in their registers since the last interval) into weights
+        // (-> spq[(r + 2) % 3]) and form the raw scores of tile r + 3 (sm[r % 3]); the multiplying waves request the value region of
+        // tile r + 2 (-> sv[(r + 2) % 3]), multiply tile r (spq[r % 3], sv[r % 3]) and fetch the first weights / value fragment of tile
+        // r + 1 under its last multiplies (both complete since the barrier that ended interval r - 1).
+        // The producer's multiplies wait for the matrix pipe behind the consumers' (a 32-cycle multiply is not pre-empted: ~50 cycles
+        // per short multiply, 42 of them): its ~250 VALU operations of the weights are issued BETWEEN them -- scores of one tile,
+        // weights of the previous one, no dependence -- instead of after them (scores, then weights: the chain was 5 000 cycles per tile
+        // for 3 000 of matrix work per SIMD, profiles/r04_dense_pc_phases.log).
         __builtin_amdgcn_s_setprio(2);
-#ifdef DAGL_DN_RUNOFF
-        key_run_set(y3, x3);
-#endif
-        for (int tile = tile0; tile < tile1; ++tile) {
-            const int r = tile - tile0;
+        int c3 = 2;                                        // (r + 3) % 3
+        for (int r = -1; r < n_t; ++r) {
+            const int c4 = c3 == 2 ? 0 : c3 + 1, c2 = c4 == 2 ? 0 : c4 + 1;     // (r + 4) % 3, (r + 2) % 3
             DN_PH(0);
-#ifdef DAGL_DN_RUNOFF
-            if (tile + 3 < tile1 && !(a.variant & 4)) stage_keys_run(r % 3);
-#else
-            if (tile + 3 < tile1 && !(a.variant & 4)) stage_keys(y3, x3, r % 3);
-#endif
+            if (r + 4 < n_t && !(a.variant & 4)) stage_keys_run(c4);
             DN_PH(1);
-            if (tile + 1 < tile1) {
+            if (r + 2 < n_t) {
                 // One basic block, 14 slots = (k-step, key group): per slot the fragment pair of slot + 2 is requested, the slot's
-                // three multiplies are issued (tile r + 2; past the last tile: on whatever the stage holds, never used) and one
-                // fourteenth of the weights' VALU work is done (tile r + 1, from the scores formed one iteration ago).  Fences keep
+                // three multiplies are issued (tile r + 3; past the last tile: on whatever the stage holds, never used) and one
+                // fourteenth of the weights' VALU work is done (tile r + 2, from the scores formed one interval ago).  Fences keep
                 // the order: left to the scheduler, every multiply sat behind its own fragment read and a full LDS round trip.
                 constexpr int PF = 2, NSL = 2 * DN_KS;
-                const unsigned kb_addr = lds_sm + (unsigned)(((r + 2) % 3) * DN_KTILE_B) + ka_off;
+                const unsigned kb_addr = lds_sm + (unsigned)(c3 * DN_KTILE_B) + ka_off;
                 dnh8 fh[PF + 1], fl[PF + 1];
                 auto kfrag = [&](int sl) {
                     const unsigned ad = kb_addr + (unsigned)((sl & 1) * 16 * (DN_KPITCH * 16) + 64 * (sl >> 1));
@@ -533,7 +433,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                 dnh4 hq[2], lq[2];
                 float zt[2] = {0.f, 0.f}, zpt[2] = {0.f, 0.f};
                 int dt[2] = {0, 0};
-                const int jy0 = y1, jx0 = x1, pbuf = (r + 1) & 1;
+                const int jy0 = yw, jx0 = xw, pbuf = c2;
 #pragma unroll
                 for (int sl = 0; sl < PF; ++sl) kfrag(sl);
 #pragma unroll
@@ -573,27 +473,148 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                         *reinterpret_cast<dnh4*>(pq) = hq[kg];
                         *reinterpret_cast<dnh4*>(pq + 32) = lq[kg];
                     }
+#ifdef DAGL_DN_PSLEEP
+                    if (sl >= DAGL_DN_PSLEEP_FROM) __builtin_amdgcn_s_sleep(DAGL_DN_PSLEEP);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 final_scores(s_new);
             }
-            y0 = y1; x0 = x1; y1 = y2; x1 = x2; y2 = y3; x2 = x3;
-            next_tile(y2, x2, y3, x3);
-#ifdef DAGL_DN_RUNOFF
-            if (x3 != 0) {                                 // (wave-uniform)
+            next_tile(yw, xw);
+            next_tile(yk, xk);                             // the next interval's key request
+            if (xk != 0) {                                 // (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < kpn; ++j) k_run[j] += (unsigned)(DN_TW * DSH * 2);
             } else {
-                key_run_set(y3, x3);
+                key_run_set(yk, xk);
             }
-#endif
+            c3 = c4;
             DN_PH(6);
             dma_wait_all();
             DN_PH(7);
             __syncthreads();
             DN_PH(5);
         }
+        // the lanes' shares of their queries' sums (read back below, behind the block's last barrier)
+        szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; slt[wave][lane] = l_top;
     } else {
+        // ======================================================== A V ========================================================
+        const int lane = lane_now();
+        const int cw = wave - 4;
+        const int c16 = lane & 15, gk = lane >> 4;
+        const int h = lane >> 5;
+        const int ct0 = dn_ct_start(cw);
+        // ---- the value regions' LDS-DMA: part = cw >> 2, the part's 6 pieces over its four waves as 1 / 1 / 2 / 2; per-lane byte
+        // offsets carried like the producers' (formed anew at a tile-row wrap and at a ragged last tile, whose region is clamped to
+        // the padded map)
+        const int spart = cw >> 2, wl = cw & 3;
+        const int vp0 = wl < 2 ? wl : 2 + 2 * (wl - 2), vpn = wl < 2 ? 1 : 2;
+        const unsigned char* vsrc = reinterpret_cast<const unsigned char*>((spart ? a.v_lo : a.v_hi) + (size_t)b * g.Hp * g.Wp * CH) - 4096;
+        unsigned v_run[2];
+        auto value_run_set = [&](int jy0, int jx0) {
+            const int ln = lane_now();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = (vp0 + (j < vpn ? j : 0)) * 64 + ln;
+                int row = p / (2 * DN_VPX); const int c36 = p - row * (2 * DN_VPX);
+                if (row > DN_RH - 1) row = DN_RH - 1;                            // (slack positions of the last piece: any valid address)
+                int px = c36 >> 1; if (px > DN_RW - 1) px = DN_RW - 1;
+                int y = jy0 + row; if (y > g.Hp - 1) y = g.Hp - 1;               // stay inside the padded map
+                int x = jx0 + px; if (x > g.Wp - 1) x = g.Wp - 1;
+                v_run[j] = (unsigned)(y * g.Wp + x) * 32u + (unsigned)(16 * (c36 & 1) + 4096);
+            }
+        };
+        auto stage_values_run = [&](int buf) {
+            const unsigned dst = lds_sv + (unsigned)(buf * DN_VTILE_B + spart * DN_VPART_B + vp0 * 1024);
+            // (one piece per statement here: with several offsets live at once the allocator spilled the accumulators)
+            dn_glds<1>(vsrc, dst, v_run[0], 0, 0, 0);
+            if (vpn > 1) dn_glds<1>(vsrc, dst + 1024u, v_run[1], 0, 0, 0);       // wave-uniform
+        };
+        int yv = ty0, xv = tx0;                            // the tile of the next value request
+        for (int t = 0; t < 2; ++t) {                      // tiles 0, 1 -> stages 0, 1
+            if (t < n_t) { value_run_set(yv, xv); stage_values_run(t); }
+            next_tile(yv, xv);
+        }
+        value_run_set(yv, xv);                             // tile 2: requested in interval 0
+
+        f32x16 acc[2][DN_CTMAX];
+        f32x4 acc48;                                       // tap 48 (consumers 0-3): out^T[channel 4 gk + r][query 16 cw + c16]
+        const unsigned pr_off = (unsigned)(lane * DN_PQ_ENTRY);
+        // A V operand A: lane t = lane & 15 of a 16-lane group supplies the 8 bytes (pixel t >> 2, channels 4 (t & 3) ..) of the group's
+        // [4 pixels][16 channels] block; the group = (tap parity, key half h)
+        const bool second = (lane & 16) != 0;
+        const unsigned va_lane = (unsigned)(((c16 >> 2) * 32) + (c16 & 3) * 8 + h * (DN_VPX * 32));
+        // column tile ct = taps (2 ct, 2 ct + 1) x 16 channels; lanes 16-31 / 48-63 ("second") take the odd tap
+        unsigned vt_off[DN_CTMAX];
+#pragma unroll
+        for (int t = 0; t < DN_CTMAX; ++t) {
+            const int tap = 2 * (ct0 + t) + (second ? 1 : 0);
+            const int kh = tap / KS, kw = tap - kh * KS;
+            vt_off[t] = (unsigned)((kh * DN_VPX + kw) * 32) + va_lane;
+        }
+        // the weights of BOTH query tiles for a k-block (lane = query i, keys 16 kb + 8 h ..), one half (hi | lo) at a time.  A
+        // granule (32 queries x 16 keys) whose weights are all exactly zero adds exactly nothing and is skipped.  (hi = 0 implies
+        // lo = 0: the split of a number below half the smallest denormal; -0 cannot occur, p >= 0.)
+        struct PHalf { dnu4 q[2]; };
+        auto load_p = [&](int buf, int kb, int lo) {
+            PHalf f;
+            const unsigned pa = lds_pq + (unsigned)(buf * DN_PQ_B + 16 * kb + 32 * lo) + pr_off;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) f.q[qq] = dn_lds128(pa + (unsigned)(qq * 64 * DN_PQ_ENTRY));
+            return f;
+        };
+        // The hi halves of the weights and the first value fragment of the NEXT k-block to multiply are fetched one k-block ahead --
+        // across the tile's barrier too: the producers run two tiles ahead of the multiplies and the value regions are requested two
+        // tiles ahead, so that what tile r + 1 needs was complete at the barrier BEFORE tile r.  (Rounds 4-5: one tile ahead; after
+        // every barrier the multiplying waves first sat through an LDS round trip for their weights while the producers issued their
+        // DMA: ~400 of a tile's ~4300 cycles with no multiply in flight on the SIMD.)  The lo halves (the zero test and a column tile's
+        // first four multiplies need only the hi ones) are requested at the top of their k-block.
+        PHalf ph;
+        DnFrag fv;
+        auto attend = [&](int buf, int nbuf) {
+            if (a.variant & 1) return;
+            const unsigned vbase = lds_sv + (unsigned)(buf * DN_VTILE_B);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const unsigned va_kb = vbase + (unsigned)(2 * kb * DN_VPX * 32);
+                dnh8 p_hi[2], p_lo[2];
+                bool nz[2];
+                const PHalf pl = load_p(buf, kb, 1);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    p_hi[qq] = __builtin_bit_cast(dnh8, ph.q[qq]); p_lo[qq] = __builtin_bit_cast(dnh8, pl.q[qq]);
+                    nz[qq] = (a.variant & 32) || __builtin_amdgcn_ballot_w64(((ph.q[qq].x | ph.q[qq].y) | (ph.q[qq].z | ph.q[qq].w)) != 0u) != 0ull;
+                }
+                const unsigned va_next = (kb == 0 ? va_kb + (unsigned)(2 * DN_VPX * 32) : lds_sv + (unsigned)(nbuf * DN_VTILE_B)) + vt_off[0];
+                ph = kb == 0 ? load_p(buf, 1, 0) : load_p(nbuf, 0, 0);   // arrive under this k-block's multiplies
+                DN_PH(3);
+                if (nz[0] || nz[1])                        // (wave-uniform)
+                    fv = dn_pv(acc, va_kb, vt_off, p_hi, p_lo, fv, va_next);
+                else
+                    fv = dn_vfrag(va_next);
+                DN_PH(4);
+            }
+            if (cw < 4) {
+                // tap 48 = patch position (6, 6): 16 channels x the 16 queries 16 cw .. of the block, K = the tile's 32 keys.  Lane
+                // (c16, gk): operand B = the weights of query c16 for keys 8 gk .. (k-block gk >> 1, key half gk & 1 of the exchange
+                // layout), operand A = channel c16 of the region pixels (row 6 + gk, columns 6 .. 13) through the transposing read
+                const unsigned pe = lds_pq + (unsigned)(buf * DN_PQ_B + (((cw >> 1) * 64 + (gk & 1) * 32 + 16 * (cw & 1) + c16) * DN_PQ_ENTRY) + 16 * (gk >> 1));
+                const dnu4 wh = dn_lds128(pe), wl_ = dn_lds128(pe + 32);
+                if ((a.variant & 32) || __builtin_amdgcn_ballot_w64(((wh.x | wh.y) | (wh.z | wh.w)) != 0u) != 0ull) {
+                    const DnFrag f = dn_vfrag(vbase + (unsigned)(((6 + gk) * DN_VPX + 6 + (c16 >> 2)) * 32 + (c16 & 3) * 8));
+                    const dns8 vh = {f.h0[0], f.h0[1], f.h0[2], f.h0[3], f.h1[0], f.h1[1], f.h1[2], f.h1[3]};
+                    const dns8 vl = {f.l0[0], f.l0[1], f.l0[2], f.l0[3], f.l1[0], f.l1[1], f.l1[2], f.l1[3]};
+                    const dnh8 v_hi = __builtin_bit_cast(dnh8, vh), v_lo = __builtin_bit_cast(dnh8, vl);
+                    const dnh8 q_hi = __builtin_bit_cast(dnh8, wh), q_lo = __builtin_bit_cast(dnh8, wl_);
+                    acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_lo, acc48, 0, 0, 0);
+                    acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_lo, q_hi, acc48, 0, 0, 0);
+                    acc48 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_hi, q_hi, acc48, 0, 0, 0);
+                }
+            }
+        };
+
+        dma_wait_all();
+        __syncthreads();                                   // barrier 1
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
@@ -601,22 +622,48 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[qq][t][r] = 0.f;
         acc48 = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int tile = tile0; tile < tile1; ++tile) {
-            const int cur = (tile - tile0) & 1;
+        __syncthreads();                                   // barrier 2: the weights of tile 0 are written
+        ph = load_p(0, 0, 0);
+        fv = dn_vfrag(lds_sv + vt_off[0]);
+        __syncthreads();                                   // (the producers' interval -1)
+        int c0 = 0;                                        // r % 3
+        for (int r = 0; r < n_t; ++r) {
+            const int c1 = c0 == 2 ? 0 : c0 + 1, c2 = c1 == 2 ? 0 : c1 + 1;
             DN_PH(0);
-            if (tile + 1 < tile1 && !(a.variant & 4)) stage_values(y1, x1, cur ^ 1);
-            attend(cur);
-            y0 = y1; x0 = x1; y1 = y2; x1 = x2; y2 = y3; x2 = x3;
-            next_tile(y2, x2, y3, x3);
+            if (r + 2 < n_t && !(a.variant & 4)) stage_values_run(c2);
+            attend(c0, c1);
+            next_tile(yv, xv);
+            if (xv != 0 && xv + DN_TW <= g.W) {            // (wave-uniform) same tile row, region inside the padded map: 8 pixels on
+                v_run[0] += (unsigned)(DN_TW * 32); v_run[1] += (unsigned)(DN_TW * 32);
+            } else {
+                value_run_set(yv, xv);
+            }
+            c0 = c1;
             DN_PH(6);
             dma_wait_all();
             DN_PH(7);
             __syncthreads();
             DN_PH(5);
         }
+        // ---- this wave's column tiles of both query tiles ----
+        {
+            const int ln = lane_now();
+            const int i_ = ln & 31, h_ = ln >> 5, c16_ = ln & 15, gk_ = ln >> 4;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q2 = qb * 64 + qq * 32 + i_;
+                if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h_, ct0);
+            }
+            const int qs_ = qb * 64 + 16 * cw + c16_;
+            if (cw < 4 && qs_ < g.L) {                     // tap 48: columns 768 + 4 gk .. of query qb 64 + 16 cw + c16
+                constexpr float inv = 1.0f / (DN_PS * DN_VS);
+                *reinterpret_cast<float4*>(a.part_acc + (((size_t)split * a.B + b) * g.L + qs_) * P + 768 + 4 * gk_) =
+                    make_float4(acc48[0] * inv, acc48[1] * inv, acc48[2] * inv, acc48[3] * inv);
+            }
+        }
     }
 #ifdef DAGL_ABLATION
-    if (clocks && lane == 0) {
+    if (clocks && (threadIdx.x & 63u) == 0) {
         unsigned* po = a.phase_out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 12 + wave) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) po[e] = ph[e];
@@ -624,7 +671,6 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 #endif
 
     // ---- partial results of this key range ------------------------------------------------------------------------------------------
-    if (producer) { szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; slt[wave][lane] = l_top; }
     __syncthreads();
     if (tid < 64) {
         // query tid of the block: its scores lived in producer wave tid / 16, lanes c16 + 16 gk; summed in a fixed order
@@ -639,18 +685,6 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             const size_t ql = (size_t)b * g.L + q;
             a.part_m[orow] = dn_shift(a, ql);
             a.part_z[3 * orow] = z; a.part_z[3 * orow + 1] = zp; a.part_z[3 * orow + 2] = (double)lt; a.part_deg[orow] = d;
-        }
-    }
-    if (!producer) {
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {                   // this wave's column tiles of both query tiles
-            const int q2 = qb * 64 + qq * 32 + i;
-            if (q2 < g.L) dn_store(acc[qq], a.part_acc + (((size_t)split * a.B + b) * g.L + q2) * P, h, ct0);
-        }
-        if (cw < 4 && qs < g.L) {                          // tap 48: columns 768 + 4 gk .. of query qs (= qb 64 + 16 cw + c16 for these waves)
-            constexpr float inv = 1.0f / (DN_PS * DN_VS);
-            *reinterpret_cast<float4*>(a.part_acc + (((size_t)split * a.B + b) * g.L + qs) * P + 768 + 4 * gk) =
-                make_float4(acc48[0] * inv, acc48[1] * inv, acc48[2] * inv, acc48[3] * inv);
         }
     }
 }
