@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: dense regime -- kernel stats and SQ counters of dense_attend_kernel (release build), then the ablation
 # ladder (DAGL_DENSE_VARIANT: 1 no A V, 2 no S, 4 no staging, 16 constant weights, 32 no zero-granule skip).
-#   tools/dense_study.sh <tag> "<kinds>" "<variants>"
+#   tools/dense_study.sh <tag> "<kinds>" "<variants>" ("none": no ablation build)
 set -u
 TAG=$1; KINDS=${2:-"real synth"}; VARS=${3:-"0 1 2 3 4 32"}
 cd $GRAFT_REPO_ROOT
@@ -45,7 +45,7 @@ json.dump(res, open(f"{out}/pmc_{kind}.json", "w"), indent=1)
 PY
 done
 cd $GRAFT_REPO_ROOT
-if [ -n "$VARS" ]; then
+if [ -n "$VARS" ] && [ "$VARS" != "none" ]; then
   DAGL_EXTRA_FLAGS=-DDAGL_ABLATION python -m dagl_amd.build --force > /dev/null 2>&1
   for kind in $KINDS; do
     for v in $VARS; do
