@@ -44,6 +44,7 @@
 //
 // Matrix time per (64 query, 32 key) tile: 8 x 21 + 12 multiplies of 16 cycles + 288 of 32 cycles.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dagl_common.h"
 
@@ -53,6 +54,7 @@ typedef _Float16 dnh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 dnh4 __attribute__((ext_vector_type(4)));
 typedef short dns4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short dns8 __attribute__((ext_vector_type(8)));
+typedef float dnf2 __attribute__((ext_vector_type(2)));
 
 constexpr int DN_KS = 7;                              // k-steps of 32 features (224 >= 196; a feature row holds 216 halfs)
 constexpr int DN_KPITCH = 4 * DN_KS;                  // 16-byte slots per staged key row
@@ -200,7 +202,7 @@ __device__ __forceinline__ DnFrag dn_pv(f32x16 (&acc)[2][DN_CTMAX], unsigned va_
 #ifdef DAGL_ABLATION
 // phase clocks (DAGL_DENSE_VARIANT & 64): every wave sums shader-clock deltas per phase (s_memtime also waits for the wave's
 // outstanding LDS operations: ~10 % perturbation)
-#define DN_PH(i) do { if (clocks) { const unsigned long long n_ = __builtin_readcyclecounter(); ph[i] += (unsigned)(n_ - t_last); t_last = n_; } } while (0)
+#define DN_PH(i) do { if (clocks) { const unsigned long long n_ = __builtin_readcyclecounter(); phc[i] += (unsigned)(n_ - t_last); t_last = n_; } } while (0)
 #else
 #define DN_PH(i) do { } while (0)
 #endif
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     const int n_qblocks = (g.L + 63) / 64;
     const int qb = blockIdx.x % n_qblocks, split = blockIdx.x / n_qblocks;
 #ifdef DAGL_ABLATION
-    unsigned ph[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned phc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     const bool clocks = (a.variant & 64) && a.phase_out != nullptr;
     unsigned long long t_last = clocks ? __builtin_readcyclecounter() : 0ull;
 #endif
@@ -318,9 +320,16 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                 qf_lo[ks] = __builtin_bit_cast(dnh8, vl);
             }
         }
-        double z_run = 0.0, zp_run = 0.0;                  // sum over this lane's keys / its passing keys of e^(l - m_run)
-        float l_top = 0.f;                                 // largest logit among this lane's passing keys (the guard of dense_combine_kernel)
-        int deg = 0;
+        // Per lane: the sum of 2^15 e^(l - m_run) over its PASSING keys, their number, the number of positions outside the map it met, and
+        // its largest score.  Everything else the block reports follows from these at the end: a masked key weighs e^(0 - m_run) whatever its
+        // score, so the sum over ALL keys is the passing keys' sum + (valid keys - degree) e^(-m_run); l = 10 S m(S) grows with S on the
+        // passing side of a row (m = S - c > 0; below S = 0 it is negative and never the maximum), so the row's largest logit is the
+        // logit of its largest score.  (Round 4-5 carried both sums, the degree and the running maximum of the logits per key: ~24 VALU
+        // operations a key, 190 a tile, on waves that share their SIMD's issue port with two multiplying waves -- taken out, a call on
+        // trained features went from 1.59 to 1.34 ms: profiles/r05_dense_ablation_weights.log.  Now ~13 a key, most of them packed.)
+        double zp_run = 0.0;
+        float s_top = -1e30f;
+        int deg = 0, n_inv = 0;
         // S operand A: key row 16 kg + c16 of the tile, slot (4 ks + gk) with the low bits swizzled by the row (kg = 1: + 16 rows)
         const unsigned ka_off = (unsigned)(c16 * (DN_KPITCH * 16) + ((gk ^ ((0x1320 >> (4 * (c16 >> 2))) & 3)) * 16));
         // where this lane's four weights of key group kg go: entry (query tile, key half, query) of the A V lane that multiplies them
@@ -345,53 +354,92 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                     sa.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], sa.lh[kg], 0, 0, 0);
                 }
         };
-        // logits, weights and their sums from a tile's raw scores; the split weights go to spq[pbuf]
-        auto weights = [&](int jy0, int jx0, int pbuf, const SAcc& sa) {
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                // register r holds key 16 kg + 4 gk + r of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + r)
-                float zt = 0.f, zpt = 0.f;                     // this tile's sums in fp32, one fp64 add per tile
-                int dt = 0;
-                _Float16 hq[4], lq[4];
-                const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sc = (sa.hh[kg][r] + (sa.hl[kg][r] + sa.lh[kg][r])) * (1.0f / (DN_FS * DN_FS));
-                    const bool valid = rowv && (jx0 + 4 * (gk & 1) + r < g.W);
-                    bool pass;
-                    const float l = dn_logit(sc, mtq, bsq, pass);
-                    const float e = __expf(fminf(l - m_run, 0.f));                    // (the bound holds; the clamp is a seat belt)
-                    const float p = valid ? e : 0.f;
-                    zt += p;
-                    pass = pass && valid;
-                    l_top = fmaxf(l_top, pass ? l : 0.f);
-                    const float pp = pass ? p : 0.f;
-                    zpt += pp;
-                    dt += pass ? 1 : 0;
-                    const float ps = pp * DN_PS;
-                    hq[r] = (_Float16)ps;
-                    lq[r] = (_Float16)(ps - (float)hq[r]);
-                }
-                z_run += (double)zt; zp_run += (double)zpt; deg += dt;
-                const dnh4 hv = {hq[0], hq[1], hq[2], hq[3]}, lv = {lq[0], lq[1], lq[2], lq[3]};
-                unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
-                *reinterpret_cast<dnh4*>(pq) = hv;
-                *reinterpret_cast<dnh4*>(pq + 32) = lv;
-            }
-        };
-        float sc_next[2][4];                               // raw scores of the tile whose weights the next interval forms
+        dnf2 sc_next[2][2];                                // scores of the tile whose weights the next interval forms: [key group][pair]
         auto final_scores = [&](const SAcc& sa) {
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) sc_next[kg][rr] = (sa.hh[kg][rr] + (sa.hl[kg][rr] + sa.lh[kg][rr])) * (1.0f / (DN_FS * DN_FS));
+                for (int pr = 0; pr < 2; ++pr) {
+                    const dnf2 hh = {sa.hh[kg][2 * pr], sa.hh[kg][2 * pr + 1]}, hl = {sa.hl[kg][2 * pr], sa.hl[kg][2 * pr + 1]},
+                               lh = {sa.lh[kg][2 * pr], sa.lh[kg][2 * pr + 1]};
+                    sc_next[kg][pr] = (hh + (hl + lh)) * (1.0f / (DN_FS * DN_FS));
+                }
+        };
+        // Weights of two neighbouring keys (registers 2 pr, 2 pr + 1 of key group kg = keys 16 kg + 4 gk + 2 pr .. of the tile = pixel
+        // (row 2 kg + (gk >> 1), columns 4 (gk & 1) + 2 pr ..)): logits in the reference's fp32 expression order (dagl.py:256-259),
+        // 2^15 e^(l - m_run) through one v_exp_f32 (the scale is an addend of its argument), split hi + lo.  A masked key's weight is
+        // exactly zero (its logit is replaced by -1e30 in front of the exponential); positions outside the map (ragged last tiles,
+        // wave-uniform test) get a score of -1e30, which masks them, and are counted.
+        constexpr float DN_LOG2E = 1.4426950408889634f;
+        // (RG: a std::bool_constant -- the tile has positions outside the map.  Two instantiations of the tile's code instead of a
+        // test inside it: a branch in the fenced block splits it into basic blocks, the fences stop ordering anything and the compiler
+        // sinks all of the weights' arithmetic into one burst in front of the store.)
+        auto weight_pair_a = [&](auto RG, int kg, int pr, int jy0, int jx0, dnf2& zpv, int& dt, dnf2& ps) {
+            dnf2 sc = sc_next[kg][pr];
+            if constexpr (decltype(RG)::value) {
+                const bool rowv = jy0 + 2 * kg + (gk >> 1) < g.H;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool valid = rowv && (jx0 + 4 * (gk & 1) + 2 * pr + u < g.W);
+                    sc[u] = valid ? sc[u] : -1e30f;
+                    n_inv += valid ? 0 : 1;
+                }
+            }
+            const dnf2 m = (sc - mtq) + bsq;                   // same expression order as dagl.py:256
+            const bool p0 = m[0] > 0.f, p1 = m[1] > 0.f;
+            const dnf2 l = (sc * m) * SOFTMAX_SCALE;
+            dnf2 d;
+            d[0] = fminf((p0 ? l[0] : -1e30f) - m_run, 0.f);   // (the bound holds; the clamp is a seat belt)
+            d[1] = fminf((p1 ? l[1] : -1e30f) - m_run, 0.f);
+            const dnf2 x = d * DN_LOG2E + 15.0f;
+#ifdef DAGL_ABLATION
+            if (a.variant & 128) { ps = x * 1e-3f; } else      // (ablation: no transcendental)
+#endif
+            { ps[0] = __builtin_amdgcn_exp2f(x[0]); ps[1] = __builtin_amdgcn_exp2f(x[1]); }
+            dt += (p0 ? 1 : 0) + (p1 ? 1 : 0);
+            s_top = fmaxf(s_top, fmaxf(sc[0], sc[1]));
+        };
+        auto weight_pair_b = [&](int pr, const dnf2& ps, dnf2& zpv, dnh4& hq, dnh4& lq) {
+            zpv += ps;
+#ifdef DAGL_ABLATION
+            if (a.variant & 256) { hq[2 * pr] = (_Float16)0.004f; hq[2 * pr + 1] = (_Float16)0.003f; lq[2 * pr] = (_Float16)1e-5f; lq[2 * pr + 1] = (_Float16)1e-5f; return; }   // (ablation: no split)
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const _Float16 hp = (_Float16)ps[u];
+                hq[2 * pr + u] = hp;
+                lq[2 * pr + u] = (_Float16)(ps[u] - (float)hp);
+            }
+        };
+        auto weight_store = [&](int kg, int pbuf, const dnf2& zpv, int dt, const dnh4& hq, const dnh4& lq) {
+            zp_run += (double)(zpv[0] + zpv[1]); deg += dt;    // (fp32 per tile and key group, one fp64 add each)
+            unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
+            *reinterpret_cast<dnh4*>(pq) = hq;
+            *reinterpret_cast<dnh4*>(pq + 32) = lq;
+        };
+        auto tile_ragged = [&](int jy0, int jx0) { return jy0 + DN_TH > g.H || jx0 + DN_TW > g.W; };
+        // (prologue) the weights of a tile from sc_next, all at once
+        auto weights = [&](int jy0, int jx0, int pbuf) {
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                dnf2 zpv = {0.f, 0.f};
+                int dt = 0;
+                dnh4 hq, lq;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    dnf2 ps;
+                    weight_pair_a(std::true_type{}, kg, pr, jy0, jx0, zpv, dt, ps);      // (prologue: always with the test)
+                    weight_pair_b(pr, ps, zpv, hq, lq);
+                }
+                weight_store(kg, pbuf, zpv, dt, hq, lq);
+            }
         };
 
         dma_wait_all();
         __syncthreads();                                   // barrier 1: tiles 0-2 staged
         {
             SAcc s0;
-            if (n_t > 0) { scores(0, s0); weights(yw, xw, 0, s0); }
+            if (n_t > 0) { scores(0, s0); final_scores(s0); weights(yw, xw, 0); }
             next_tile(yw, xw);
             if (n_t > 1) { scores(1, s0); final_scores(s0); }
         }
@@ -414,7 +462,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             DN_PH(0);
             if (r + 4 < n_t && !(a.variant & 4)) stage_keys_run(c4);
             DN_PH(1);
-            if (r + 2 < n_t) {
+            auto tile_block = [&](auto RG) {
                 // One basic block, 14 slots = (k-step, key group): per slot the fragment pair of slot + 2 is requested, the slot's
                 // three multiplies are issued (tile r + 3; past the last tile: on whatever the stage holds, never used) and one
                 // fourteenth of the weights' VALU work is done (tile r + 2, from the scores formed one interval ago).  Fences keep
@@ -431,7 +479,8 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg) { s_new.hh[kg] = f32x4{0.f, 0.f, 0.f, 0.f}; s_new.hl[kg] = s_new.hh[kg]; s_new.lh[kg] = s_new.hh[kg]; }
                 dnh4 hq[2], lq[2];
-                float zt[2] = {0.f, 0.f}, zpt[2] = {0.f, 0.f};
+                dnf2 zpv[2] = {{0.f, 0.f}, {0.f, 0.f}};
+                dnf2 ps_t = {0.f, 0.f};
                 int dt[2] = {0, 0};
                 const int jy0 = yw, jx0 = xw, pbuf = c2;
 #pragma unroll
@@ -447,31 +496,30 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                         s_new.hh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, qf_hi[ks], s_new.hh[kg], 0, 0, 0);
                         s_new.lh[kg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, qf_hi[ks], s_new.lh[kg], 0, 0, 0);
                     }
-                    if (sl < 8) {
-                        // register rr of key group kg holds key 16 kg + 4 gk + rr of the tile = pixel (row 2 kg + (gk >> 1), column 4 (gk & 1) + rr)
+#ifdef DAGL_ABLATION
+                    if ((a.variant & 16) && sl < 8) {          // (ablation: no weights' arithmetic -- what its VALU operations cost the SIMD)
                         const int kg = sl >> 2, rr = sl & 3;
-                        const float sc = sc_next[kg][rr];
-                        const bool valid = (jy0 + 2 * kg + (gk >> 1) < g.H) && (jx0 + 4 * (gk & 1) + rr < g.W);
-                        bool pass;
-                        const float l = dn_logit(sc, mtq, bsq, pass);
-                        const float e = __expf(fminf(l - m_run, 0.f));            // (the bound holds; the clamp is a seat belt)
-                        const float p = valid ? e : 0.f;
-                        zt[kg] += p;
-                        pass = pass && valid;
-                        l_top = fmaxf(l_top, pass ? l : 0.f);
-                        const float pp = pass ? p : 0.f;
-                        zpt[kg] += pp;
-                        dt[kg] += pass ? 1 : 0;
-                        const float ps = pp * DN_PS;
-                        const _Float16 hp = (_Float16)ps;
-                        hq[kg][rr] = hp;
-                        lq[kg][rr] = (_Float16)(ps - (float)hp);
+                        hq[kg][rr] = (_Float16)(0.001f * (float)(sl + 1)); lq[kg][rr] = (_Float16)1e-5f;
+                        zpv[kg] = dnf2{1.f, 1.f}; dt[kg] = 1; s_top = 1e30f;
+                    } else
+#endif
+                    if (sl < 8) {                              // slots 2 j, 2 j + 1: one pair of keys (logits + exponentials | sums + split)
+                        const int kg = sl >> 2, pr = (sl >> 1) & 1;
+                        if (!(sl & 1)) weight_pair_a(RG, kg, pr, jy0, jx0, zpv[kg], dt[kg], ps_t);
+                        else weight_pair_b(pr, ps_t, zpv[kg], hq[kg], lq[kg]);
                     } else if (sl < 10) {
                         const int kg = sl - 8;
-                        z_run += (double)zt[kg]; zp_run += (double)zpt[kg]; deg += dt[kg];     // (fp32 per tile and key group, one fp64 add each)
-                        unsigned char* pq = spq + pbuf * DN_PQ_B + pw_off + kg * 16;
-                        *reinterpret_cast<dnh4*>(pq) = hq[kg];
-                        *reinterpret_cast<dnh4*>(pq + 32) = lq[kg];
+#ifdef DAGL_ABLATION
+                        if (a.variant & 8) {                   // (ablation: all of the arithmetic, but constant weights handed over -- the multiplies' data, not the VALU work)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                zpv[kg][0] += (float)hq[kg][rr] + (float)lq[kg][rr];
+                                hq[kg][rr] = (_Float16)(0.001f * (float)(4 * kg + rr + 1)); lq[kg][rr] = (_Float16)1e-5f;
+                            }
+                            s_top = 1e30f;
+                        }
+#endif
+                        weight_store(kg, pbuf, zpv[kg], dt[kg], hq[kg], lq[kg]);
                     }
 #ifdef DAGL_DN_PSLEEP
                     if (sl >= DAGL_DN_PSLEEP_FROM) __builtin_amdgcn_s_sleep(DAGL_DN_PSLEEP);
@@ -479,6 +527,16 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 final_scores(s_new);
+            };
+            if (r + 2 < n_t) {
+                if (!tile_ragged(yw, xw)) {
+                    tile_block(std::false_type{});
+                } else {                                   // (rare: a tile with positions outside the map -- the two phases one after the other)
+                    weights(yw, xw, c2);
+                    SAcc s_new;
+                    scores(c3, s_new);
+                    final_scores(s_new);
+                }
             }
             next_tile(yw, xw);
             next_tile(yk, xk);                             // the next interval's key request
@@ -496,7 +554,15 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
             DN_PH(5);
         }
         // the lanes' shares of their queries' sums (read back below, behind the block's last barrier)
-        szz[wave][lane][0] = z_run; szz[wave][lane][1] = zp_run; sdg[wave][lane] = deg; slt[wave][lane] = l_top;
+        {
+            constexpr double inv_ps = 1.0 / (double)DN_PS;
+            const float e0 = __builtin_amdgcn_exp2f(fminf(0.f - m_run, 0.f) * DN_LOG2E + 15.0f);     // 2^15 e^(0 - m_run): a masked key's weight
+            const double z_run = zp_run + (double)(8 * n_t - n_inv - deg) * (double)e0;
+            bool ps_;
+            const float lt = dn_logit(s_top, mtq, bsq, ps_);
+            szz[wave][lane][0] = z_run * inv_ps; szz[wave][lane][1] = zp_run * inv_ps; sdg[wave][lane] = deg;
+            slt[wave][lane] = ps_ ? fmaxf(lt, 0.f) : 0.f;
+        }
     } else {
         // ======================================================== A V ========================================================
         const int lane = lane_now();
@@ -666,7 +732,7 @@ __global__ __launch_bounds__(DN_THREADS) void dense_attend_kernel(DenseArgs a) {
     if (clocks && (threadIdx.x & 63u) == 0) {
         unsigned* po = a.phase_out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 12 + wave) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) po[e] = ph[e];
+        for (int e = 0; e < 8; ++e) po[e] = phc[e];
     }
 #endif
 
