@@ -8,16 +8,18 @@
 //   block = 64 queries x 12 waves (three per SIMD), key tiles of 32 keys = an 8 x 4 pixel block, ONE barrier per tile, two kinds of
 //   wave that work on different tiles between two barriers:
 //   producers (waves 0-3, one per SIMD, s_setprio 2): query group qg = wave (16 queries, fragments in registers)
-//     S(t+2)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo; three products): the COMPLETE scores of 16 queries x
+//     S(t+3)  v_mfma_f32_16x16x32_f16 on split features (64 x = hi + lo; three products): the COMPLETE scores of 16 queries x
 //             32 keys (42 multiplies), nothing about S is exchanged between waves.  A lane ends up with 2 x 4 consecutive keys of
 //             one query;
-//     w(t+1)  logits in the reference's fp32 expression order, p = e^(l - M') with M' the row's largest logit, known
+//     w(t+2)  logits in the reference's fp32 expression order, p = e^(l - M') with M' the row's largest logit, known
 //             before the pass (rowmax_exact_kernel: a top-1 screen + exact rescoring; the softmax is shift invariant, nothing is ever rescaled),
 //             split 2^15 p = hi + lo and handed to the consumers through the LDS in the K-layout of the next MFMA (the only
-//             exchange of the tile).  The ~250 VALU operations of w(t+1) are issued BETWEEN the multiplies of S(t+2) (fenced
-//             slots: fragment reads two slots ahead, three multiplies, a fourteenth of the weights): a short multiply waits ~50
-//             cycles for the pipe behind the consumers' long ones, and scores-then-weights was a 5 000-cycle chain per tile;
-//     the key tiles' LDS-DMA requests (7 pieces per producer under two M0 set-ups), three tiles ahead.
+//             exchange of the tile).  The VALU operations of w(t+2) (~13 a key since round 5, packed fp32) are issued BETWEEN the
+//             multiplies of S(t+3) (fenced slots: fragment reads two slots ahead, three multiplies, a share of the weights): a
+//             short multiply waits ~50 cycles for the pipe behind the consumers' long ones, and scores-then-weights was a
+//             5 000-cycle chain per tile;
+//     the key tiles' LDS-DMA requests (7 pieces per producer under two M0 set-ups), four tiles ahead, per-lane offsets carried
+//     from tile to tile.
 //   consumers (waves 4-11, two per SIMD):
 //     A V(t)  v_mfma_f32_32x32x16_f16, out^T[col][q] += V[key][col] p[q][key], three split products, every consumer three of the 24
 //             32-column tiles (two taps x 16 channels) for BOTH query tiles.  The value operand: 8 consecutive keys of one column =
@@ -27,8 +29,11 @@
 //             tap's kw shift is a whole-pixel (32-byte) address offset, no funnel shifts.
 //     The 49th tap (16 columns) goes through v_mfma_f32_16x16x32_f16 (16 channels x 16 queries, K = the tile's 32 keys), one
 //     query group of 16 per consumer 0-3.
-//   Two loops, one per role, with the same barriers: the query fragments are live in one, the 100 accumulator registers in the
-//   other (168 registers per wave at three waves per SIMD).
+//   Two role PATHS with the same number of barriers (round 5): from the role test to the block's last barrier the roles share no
+//   code and everything a role keeps per lane is formed inside its path -- 165 registers, no spill (with shared segments between
+//   two role loops: 168 with 26 spilled, the producers' query fragments held across the multiplying waves' loop).  Weights and
+//   value regions are three stages deep: the producers run two tiles ahead, a multiplying wave fetches the next tile's first
+//   weights and value fragment under its last multiplies (across the barrier).
 //   The first round-4 shape had both kinds of work in every wave (8 waves, the two of a SIMD in opposite order): the pipes were
 //   55 % busy -- every wave spent half its time in code that does not multiply.  This one: 63 % (trained features, 1.38 -> 1.28 ms),
 //   synthetic map 0.71 -> 0.62 ms, leaf-tile batch 0.69 -> 0.65 ms (profiles/r04_pmc_dense_*.json, r04_ab_dense_roles.log).
@@ -37,7 +42,7 @@
 //   the weight fragments: bit-identical results).  On synthetic N(0,1) maps at default init ~60-80 % of the granules are zero
 //   (profiles/r04_dense_zero_granules.log); with the trained checkpoint's features (logits of 5-70) none are -- that regime runs
 //   every multiply.
-//   Staging: key features hi | lo (3 x 28 KiB), value region (2 x 12 KiB), weights (2 x 10 KiB); key rows at a 28-slot pitch with
+//   Staging: key features hi | lo (3 x 28 KiB), value region (3 x 12 KiB), weights (3 x 10 KiB); key rows at a 28-slot pitch with
 //   the low slot bits XORed by a function of the row so that the S fragments' ds_read_b128 are conflict-free for the 16x16x32
 //   operand pattern.
 //   key range split over `splits` blocks per 64 queries; dense_combine_kernel merges the partial sums and rows.
