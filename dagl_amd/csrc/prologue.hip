@@ -203,9 +203,11 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                                                           float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
                                                           int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
-                                                          RangeTag range) {
+                                                          RangeTag range, unsigned long long* times) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB];           // 110 KiB
     const int tid = threadIdx.x;
+    const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // (phase stamps of ablation builds)
+    dbg_stamp(times, blin, 0);
     float amax = 0.f;                                      // largest |pre-scaled operand| this thread splits (range guard)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {      // per-call counters / flags of the later stages
         for (int t = tid; t < clear_a_words; t += 256) clear_a[t] = 0u;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         wl2[kb] = *reinterpret_cast<const h16x8*>(wbase + kb * 2048 + wlo);
     }
 
+    dbg_stamp(times, blin, 1);
     // rows y+2 and y+3 are both in flight: a row's loads are issued two iterations before its conversion (the matrix
     // part of an iteration is ~0.5 us, a memory round trip under load 2 us), register sets A / B alternate
     if (y0 + 2 < y1 + 1) load_row(y0 + 2, st0, sh0);
@@ -377,8 +380,10 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         do_row(y, st0, sh0, st1, sh1);
         if (y + 1 < y1) do_row(y + 1, st1, sh1, st0, sh0);
     }
+    dbg_stamp(times, blin, 2);
     // (a NaN / inf input compares false / true here and is flagged as well: !(amax < limit))
     if (range.word != nullptr && !(amax < RANGE_LIMIT)) *range.word = range.tag;
+    dbg_stamp(times, blin, 3);
 }
 
 // thr / bias heads (two 7x7 stride-4 convolutions 64 -> 1 over the SAME-padded input, dagl.py:212-215).
@@ -492,9 +497,16 @@ int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, 
     if (chunks < 1) chunks = 1;
     const int rows_per_block = (g.H + chunks - 1) / chunks;
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
+    unsigned long long* times = nullptr;
+#ifdef DAGL_ABLATION
+    if (getenv("DAGL_TIMES_FILE")) times = dbg_times_buffer((size_t)strips * chunks * B);
+#endif
     hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
-                       b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
+                       b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
     DAGL_LAUNCH_CHECK("conv_pair16_kernel");
+#ifdef DAGL_ABLATION
+    if (times) dbg_times_dump(s, "conv_pair16_kernel", times, (size_t)strips * chunks * B);
+#endif
     return DAGL_OK;
 }
 
@@ -535,9 +547,16 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
         if (conv_w16 == nullptr) { set_error("launch_prologue: the split-fp16 convolutions need their packed weights"); return DAGL_ERR_INVALID; }
         ConvHeadSet hs = {};
         hs.x[0] = x; hs.w[0] = conv_w16; hs.gb[0] = g_b; hs.tb[0] = th_b; hs.imgs = B;
+        unsigned long long* times = nullptr;
+#ifdef DAGL_ABLATION
+        if (getenv("DAGL_TIMES_FILE")) times = dbg_times_buffer((size_t)strips * chunks * B);
+#endif
         hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
-                           b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range);
+                           b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
+#ifdef DAGL_ABLATION
+        if (times) dbg_times_dump(s, "conv_pair16_kernel", times, (size_t)strips * chunks * B);
+#endif
     } else {
         hipLaunchKernelGGL(conv_pair_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, x, g_w,
                            g_b, th_w, th_b, b1p, b2p, b1_hi, b1_lo);
