@@ -171,3 +171,34 @@ def test_topk_calls_without_the_redo_launch_are_never_wrong():
     # a matter of its last bit -- the fp64 oracle is held to 1e-3 here, the bit-equality with the module that always queues the pass
     # is the assertion that matters)
     assert normwise(y.cpu().numpy(), oracle.float().numpy()) <= 1e-3
+
+
+@pytest.mark.parametrize("H,W,fseed", [(512, 512, 7), (200, 304, 8), (301, 203, 9)])
+def test_dense_regime_on_larger_and_ragged_maps_against_oracle_rows(H, W, fseed):
+    """The rebuilt dense kernel (round 5, second half: two role paths, three-stage rings, sequential path for tiles with positions
+    outside the map) beyond the sizes the whole-map oracle reaches: 48 sampled queries against ALL keys of a 512 x 512 map (262 144
+    keys, 16 key ranges per query block... one per block here) and of two maps whose width / height are not multiples of the 8 x 4
+    key tile -- degree, softmax mass and aggregated patches of the library's debug outputs, and the module's output equal to it."""
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_rows_oracle
+    params = {n: torch.from_numpy(a) for n, a in make_ce_params(2024, variant="default", sparse_gain=2.0).items()}
+    x = torch.from_numpy(make_features(fseed, 1, 64, H, W))
+    ce = _module(params)
+    with torch.no_grad():
+        first = ce(x.to(_dev()))
+        info = dict(ce.last_info)
+        second = ce(x.to(_dev()))
+    assert info["path"] == 4 and not info["range_fallback"], info
+    assert torch.equal(first, second)
+    out, dbg = _debug_dense(ce, x.to(_dev()))
+    assert dbg["path"] == 4
+    assert normwise(out.cpu().numpy(), first.cpu().numpy()) <= 3e-4      # (two prologues: see the 256^2 test above)
+    L = dbg["deg"].numel()
+    rows = torch.linspace(0, L - 1, 48).long()
+    want = ce_rows_oracle(x, params, rows, mode="adaptive", dtype=torch.float64)
+    d_deg = np.abs(dbg["deg"].cpu().numpy().reshape(-1)[rows.numpy()].astype(np.int64) - want["deg"].numpy().astype(np.int64))
+    e_sum = normwise(dbg["rowsum"].cpu().numpy().reshape(-1)[rows.numpy()], want["rowsum"].numpy())
+    e_agg = normwise(_agg_ckk(dbg["agg"].cpu()[0][rows]).numpy(), want["agg"].numpy())
+    print(f"[parity] dense {H}x{W}: re-run blocks {info['dense_rerun_blocks']}, |d degree| <= {d_deg.max()}, rowsum {e_sum:.2e}, agg {e_agg:.2e}")
+    assert d_deg.max() <= 3 * max(1, (H * W) // 65536), d_deg
+    assert e_sum <= TOL_OUT and e_agg <= TOL_OUT
