@@ -643,6 +643,7 @@ struct Gemm16s {
     int k_valid = 0;                            // > 0: halfs of an operand row that exist inside a slice (multiple of 8, < K): 16-byte pieces from
                                                 // there on are fetched from columns k_valid - 8 .. of the same row instead, which the caller
                                                 // guarantees to be ZERO (feature rows of 216 halfs under a contraction of 224)
+    int nt_store = 0;                           // results as streaming stores (set by launch_gemm16s for results beyond the caches)
     int n_loop = 1;                             // column tiles a block walks one after the other (slices == 1; set by launch_gemm16s): short
                                                 // contractions (d rows of the projections: K = 224 = 7 steps) are one operand pipeline of
                                                 // n_loop x K / 32 steps per block instead of a request latency + 7 steps + 64 KiB of stores

@@ -291,7 +291,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
 #else
                 if (m < g.M && n < g.N)                                           // (N is a multiple of 4: whole quads)
 #endif
-                    *reinterpret_cast<float4*>(out + (long long)m * ldo + n) = *reinterpret_cast<const float4*>(stg + row * SPITCH + 4 * c4);
+                    {
+                        // results larger than the caches (the top-k modes' score rows beyond 64 neighbours: 537 MB per 2048 queries; d rows of the
+                        // projections' backward: 411 MB) leave as streaming stores: they are read back from HBM whatever happens, and as ordinary
+                        // stores they push the operands' tiles out of the L2 on their way (k = 100: 1.41 -> 1.29 ms, profiles/r05_topk_wide.log)
+                        typedef float g16f4 __attribute__((ext_vector_type(4)));
+                        const g16f4 v = *reinterpret_cast<const g16f4*>(stg + row * SPITCH + 4 * c4);
+                        g16f4* dstp = reinterpret_cast<g16f4*>(out + (long long)m * ldo + n);
+                        // (inline assembly: as two IR stores the compiler folds the branches into ONE ordinary store and the hint is gone)
+                        if (g.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dstp), "v"(v) : "memory");
+                        else *dstp = v;
+                    }
             }
         }
     };
@@ -374,13 +384,14 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
     // backward's batched products (K >= 512, M >= 1024): 114.5 -> 113.0 ms per adaptive-mode step, 47.6 -> 47.1 top-k; the 128 x 128
     // kernel with three stages (one block per CU instead of two): 123.6.  d rows (K = 224: seven steps per block): 128 x 128.
     const bool small_m = g.M <= 256 && g.slices > 1;
+    Gemm16s gl = g;
+    gl.nt_store = (size_t)nb * (size_t)(g.slices > 1 ? g.slices : 1) * (size_t)g.M * (size_t)g.N * sizeof(float) >= ((size_t)64 << 20);
     if (small_m || (g.K >= 512 && g.M >= 1024)) {
         dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
-        hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, gl);
     } else {
         // short contraction, many column tiles (d rows of the patch projections: K = 224, N = 784): a block walks ALL column tiles of
         // its row tile -- one pipeline of 49 steps instead of seven blocks of 7 (each: request latency, 7 steps, 64 KiB of stores)
-        Gemm16s gl = g;
         const int nt = (g.N + 127) / 128;
         gl.n_loop = (g.slices == 1 && g.K <= 256 && nt > 1 && nt <= 8 && (long long)((g.M + 127) / 128) * nb >= 512) ? nt : 1;
 #ifdef DAGL_G16_NLOOP_256
