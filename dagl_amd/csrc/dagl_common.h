@@ -516,6 +516,8 @@ struct WideArgs {
     float* agg; int32_t* deg; float* rowsum;                   // [B*L, 784], [B*L], [B*L] or null
     int b, r0, R;                                              // image, first query and number of queries of the batch
     int32_t* served;                                           // [R] 1 = the row was done by wide_list_kernel (k <= 1024), or null
+    const float* wq; const float* x; int rows_q, rows_x;       // fp32 feature rows [B, rows, DS] (wide_list_kernel: exact scores of the selected keys of rows
+                                                               // with logits beyond WL_RESCORE_LOGIT), or null
 };
 size_t topk_wide_workspace_bytes(int N, int L);
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq /* [B, rows, DS] */, const float* x,

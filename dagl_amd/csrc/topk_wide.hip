@@ -137,6 +137,7 @@ constexpr int WL_THREADS = 64 * WL_WAVES;
 constexpr int WL_SEG = 512;                          // candidate slots per wave (an eighth of the row)
 constexpr int WL_PER = WL_SAMPLES / WL_THREADS;      // keys a thread holds in the two selections (8)
 static_assert(WL_WAVES * WL_SEG == WL_SAMPLES, "one register set serves both selections");
+constexpr float WL_RESCORE_LOGIT = 2.0e4f;            // rows whose largest logit exceeds this get their selected keys' scores again, exactly
 struct WideListShared {
     // one 32 KiB region, two lives: B / C the candidates ckey[8][512] | cscore[8][512]; D the waves' partial rows (the sample's keys live in registers)
     union {
@@ -326,6 +327,38 @@ __global__ __launch_bounds__(WL_THREADS) void wide_list_kernel(WideArgs a) {
     float mf = sh.fred[0];
 #pragma unroll
     for (int ww = 1; ww < WL_WAVES; ++ww) mf = fmaxf(mf, sh.fred[ww]);
+    if (a.x != nullptr && mf > WL_RESCORE_LOGIT) {                  // (block-uniform)
+        // Rows with logits of tens of thousands: the scores came from split-fp16 products (2^-22 relative: a logit of 1e5 is off by
+        // 0.02, tools/scale_sweep.py at x 30 inputs: 1.1e-3 against the fp64 oracle where fp32 scores gave 1.6e-4) -- the selected keys
+        // are scored again from the fp32 feature rows, accumulated in fp64.  A thread per key, its row read serially: a path for inputs
+        // far outside anything trained features produce (logits 5-70), never taken otherwise.
+        float* qrow = reinterpret_cast<float*>(&sh.u.part[0][0]);      // (dead until the partial rows below)
+        const float* qsrc = a.wq + ((size_t)a.b * a.rows_q + a.r0 + slot) * DS;
+        for (int c = tid; c < D; c += WL_THREADS) qrow[c] = qsrc[c];
+        __syncthreads();
+        float m2 = -1.f;
+        for (int e = tid; e < deg; e += WL_THREADS) {
+            const int po = sh.lst_of[e] / (CH / 4);
+            const int jy = po / a.g.Wp, jx = po - jy * a.g.Wp;
+            const float* xr = a.x + ((size_t)a.b * a.rows_x + (size_t)jy * a.g.W + jx) * DS;
+            double acc = 0.0;
+            for (int c = 0; c < D; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+                acc += (double)qrow[c] * (double)v.x + (double)qrow[c + 1] * (double)v.y + (double)qrow[c + 2] * (double)v.z + (double)qrow[c + 3] * (double)v.w;
+            }
+            const float lg = wide_logit((float)acc, adaptive, mtq, bsq);
+            sh.lst_w[e] = lg;
+            m2 = fmaxf(m2, lg);
+        }
+        m2 = wave_max_f32(m2);
+        __syncthreads();                                            // (fred has been read by every thread)
+        if (lane == 0) sh.fred[w] = m2;
+        __syncthreads();
+        mf = sh.fred[0];
+#pragma unroll
+        for (int ww = 1; ww < WL_WAVES; ++ww) mf = fmaxf(mf, sh.fred[ww]);
+        __syncthreads();                                            // (qrow is dead: the partial rows may be written)
+    }
     double M = (double)mf;
     if (deg < N) M = fmax(M, 0.0);
     double zloc = 0.0;
@@ -409,6 +442,7 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.g = g; a.mode = mode; a.k = k; a.mt = mt; a.bs = bs; a.b2p = b2p; a.agg = agg; a.deg = deg; a.rowsum = rowsum;
+    a.wq = wq; a.x = x; a.rows_q = feat_rows(g.L); a.rows_x = feat_rows(g.N);
     const int Rmax = topk_wide_rows(g.N, g.L);
     a.ldn = (g.N + 31) / 32 * 32;
     char* p = static_cast<char*>(ws);
