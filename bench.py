@@ -62,9 +62,9 @@ def parse():
                     help="secondary workload (BASELINE configs[4]): one optimisation step of the whole RR network on "
                          "--crop x --crop crops, --batch crops per GPU, DDP gradient all-reduce over RCCL")
     ap.add_argument("--crop", type=int, default=128)
-    ap.add_argument("--topk-redo", choices=["auto", "always"], default="auto",
-                    help="CE.topk_redo: 'auto' (module default) drops the fp32 redo launch once a poll found the workspace without redo work; "
-                         "'always' queues it in every call (A/B)")
+    ap.add_argument("--topk-redo", choices=["auto", "always"], default="always",
+                    help="CE.topk_redo: 'always' (module default, what the benchmark times) queues the fp32 redo launch in every call; "
+                         "'auto' (opt-in, A/B) drops it once a poll found the workspace without redo work")
     ap.add_argument("--dense-backward", choices=["f16", "fp32"], default="f16",
                     help="--train A/B: the dense graph core's backward products on the fp16 (split operands, default) or fp32 matrix cores")
     ap.add_argument("--prologue-backward", choices=["direct", "unfold"], default="direct",

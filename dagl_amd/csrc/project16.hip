@@ -655,6 +655,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
     for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
     P16_WAIT2(PD - 1);
     __syncthreads();
+    dbg_stamp(pa.times, blockIdx.x, 1);
 
     auto compute = [&](int step) {
         const int kh = step / KS, kw = step - kh * KS;
@@ -702,6 +703,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
     compute(P16_STEPS - 1);
     __syncthreads();
 #undef P16_WAIT2
+    dbg_stamp(pa.times, blockIdx.x, 2);
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i]: this block's columns [c0, c0 + cw) of the rows ----
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;

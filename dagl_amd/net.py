@@ -288,17 +288,66 @@ def chop_forward_batched(model, x: torch.Tensor, min_size: int = 10000, shave_si
         # share a shape); per leaf this is exactly test_x8's stack and mean
         res = forward_x8(model, batch) if ensemble else model(batch)
         outs.extend(res.split(x.shape[0], dim=0))
+    return stitch_leaves(x, outs, min_size, shave_size_max, shave_scale)
+
+
+def stitch_leaves(x: torch.Tensor, outs, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4) -> torch.Tensor:
+    """Put the leaf outputs ``outs`` (the order of ``chop_leaf_boxes`` = the order ``chop_forward`` visits them) back together:
+    the reference's recursion (DN_Gray/model/__init__.py:216-231) bottom-up, inner quadrants of every 4-way split."""
     it = iter(outs)
 
-    def stitch_tree(h, w, like):
+    def stitch_tree(h, w):
         corners, stitch, area = tile_boxes(h, w, shave_scale, shave_size_max)
         if area < min_size:
             o = [next(it) for _ in range(4)]
         else:
-            o = [stitch_tree(y1 - y0, x1 - x0, like) for (y0, y1, x0, x1) in corners]
-        return _stitch(like.new_empty(like.shape[0], like.shape[1], h, w), o, stitch)
+            o = [stitch_tree(y1 - y0, x1 - x0) for (y0, y1, x0, x1) in corners]
+        return _stitch(o[0].new_empty(o[0].shape[0], o[0].shape[1], h, w), o, stitch)
 
-    return stitch_tree(x.shape[2], x.shape[3], x)
+    return stitch_tree(x.shape[2], x.shape[3])
+
+
+def chop_forward_sharded(model, x: torch.Tensor, dist=None, min_size: int = 10000, shave_size_max: int = 24, shave_scale: int = 4,
+                         max_batch: int = 64, ensemble: bool = False):
+    """Tile-level multi-GPU inference: the reference hands ``min(n_GPUs, 4)`` leaf tiles per call to ``nn.DataParallel``
+    (DN_Gray/model/__init__.py:181, 203-209); here -- one process per GPU, SURVEY.md section 8(e) "tiles/8 leaf tiles at inference"
+    -- the leaf tiles of ``chop_leaf_boxes`` are dealt to the ranks as contiguous slices (``shard.shard_range``), every rank runs
+    its slice in batches of up to ``max_batch``, ONE ``all_gather`` (RCCL on GPUs, any backend of the process group) brings the
+    leaf outputs to every rank, and every rank stitches the full image (``stitch_leaves``).  ``x`` is the same full image on
+    every rank.  Without an initialised process group (or at world size 1) this is ``chop_forward_batched``.  Tiles are independent:
+    no halo, no exchange besides the gather."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return chop_forward_batched(model, x, min_size, shave_size_max, shave_scale, max_batch, ensemble)
+    from .shard import shard_range
+    rank, world = dist.get_rank(), dist.get_world_size()
+    boxes = chop_leaf_boxes(x.shape[2], x.shape[3], min_size, shave_size_max, shave_scale)
+    shapes = {(y1 - y0, x1 - x0) for (y0, y1, x0, x1) in boxes}
+    if len(shapes) != 1:
+        # ragged leaves (odd sizes) cannot share one gather buffer: every rank runs the sequential driver (same result everywhere)
+        return chop_forward(model, x, min_size, shave_size_max, shave_scale, ensemble)
+    lo, hi = shard_range(len(boxes), rank, world)
+    mine = []
+    for i in range(lo, hi, max_batch):
+        batch = torch.cat([x[:, :, y0:y1, x0:x1] for (y0, y1, x0, x1) in boxes[i:min(i + max_batch, hi)]], dim=0).contiguous()
+        res = forward_x8(model, batch) if ensemble else model(batch)
+        mine.extend(res.split(x.shape[0], dim=0))
+    # fixed-size slices (they differ by at most one leaf): pad, gather once, trim
+    per = -(-len(boxes) // world)
+    if mine:
+        like = mine[0]
+    else:                                                  # more ranks than leaves: the output shape of a leaf from one probe call
+        (y0, y1, x0, x1) = boxes[0]
+        like = model(x[:, :, y0:y1, x0:x1].contiguous())
+    buf = like.new_zeros((per,) + tuple(like.shape))
+    for j, o in enumerate(mine):
+        buf[j] = o
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    outs = []
+    for r in range(world):
+        l, h = shard_range(len(boxes), r, world)
+        outs.extend(gathered[r][j] for j in range(h - l))
+    return stitch_leaves(x, outs, min_size, shave_size_max, shave_scale)
 
 
 # The 8 symmetries of the square in the order the reference enumerates them (``augment_img`` modes 0..7,

@@ -65,3 +65,61 @@ def test_world2_gloo_sharded_forward(B):
     for rank, same, t in res:
         assert same, f"rank {rank}: gathered output differs from the unsharded forward"
         assert t == 2.0                                   # max over ranks of (1.0, 2.0)
+
+
+def _chop_worker(rank, world, port, shape, ensemble, q):
+    import torch.distributed as dist
+    from dagl_amd.net import chop_forward, chop_forward_sharded, chop_leaf_boxes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        x = torch.randn(*shape)                           # the same full image on every rank
+        mod = torch.nn.Sequential(torch.nn.Conv2d(shape[1], 4, 3, padding=1), torch.nn.PReLU(),
+                                  torch.nn.Conv2d(4, shape[1], 3, padding=1))     # a cheap seeded conv as the network
+        calls = []
+        fn = lambda t: (calls.append(t.shape[0]), mod(t))[1]
+        with torch.no_grad():
+            want = chop_forward(mod, x, ensemble=ensemble)                        # the reference tiling, leaf by leaf
+            got = chop_forward_sharded(fn, x, dist, max_batch=1, ensemble=ensemble)    # leaf by leaf, as the reference calls the net
+            ran = sum(calls) // (8 if ensemble else 1)
+            got5 = chop_forward_sharded(mod, x, dist, max_batch=5, ensemble=ensemble)  # batches of leaves: oneDNN may pick another
+                                                                                       # algorithm per batch size -> last-bit differences
+        n_leaves = len(chop_leaf_boxes(shape[2], shape[3]))
+        q.put((rank, bool(torch.equal(got, want)) and bool(torch.allclose(got5, want, atol=1e-6, rtol=1e-6)), ran, n_leaves))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,ensemble", [(2, (1, 2, 256, 256), False), (3, (2, 1, 200, 184), False), (2, (1, 1, 136, 136), True)])
+def test_gloo_sharded_tiler_equals_forward_chop_bit_for_bit(world, shape, ensemble):
+    """Tile-level multi-GPU inference (DN_Gray/model/__init__.py:181,195-214): leaves dealt to the ranks, one
+    all_gather, every rank stitches -- the same bits as the sequential reference tiling on a cheap conv, and every rank ran only
+    its share of the leaves."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chop_worker, args=(r, world, port, shape, ensemble, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_leaves = res[0][3]
+    assert sum(r[2] for r in res) == n_leaves * shape[0]                         # the leaves were dealt out, nobody ran them all
+    for rank, same, ran, _ in res:
+        assert same, f"rank {rank}: stitched output differs from chop_forward"
+        assert ran <= (-(-n_leaves // world)) * shape[0]
+
+
+def test_sharded_tiler_without_a_process_group_is_the_batched_driver():
+    from dagl_amd.net import chop_forward, chop_forward_batched, chop_forward_sharded
+    torch.manual_seed(1)
+    x = torch.randn(1, 1, 144, 160)
+    mod = torch.nn.Conv2d(1, 1, 3, padding=1)
+    with torch.no_grad():
+        got = chop_forward_sharded(mod, x)
+        assert torch.equal(got, chop_forward_batched(mod, x))
+        assert torch.allclose(got, chop_forward(mod, x), atol=1e-6, rtol=1e-6)

@@ -60,11 +60,14 @@ def main():
                        "--steps 20 --warmup 5); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts 128-B "
                        "requests at 64 B (MI355X_MICROARCH.md, HBM section); gather_rows_kernel's launches rotate over 4 row sets "
                        "(833 MiB, past the 256 MiB Infinity Cache)"}
+    split = {}
     for k in fetch:
         sk = short(k)
         if sk and "FETCH_SIZE" in fetch[k]:
             w = write.get(k, {}).get("WRITE_SIZE", 0.0)
             traffic[sk] = (2.0 * fetch[k]["FETCH_SIZE"] + w) * 1024.0
+            split[sk] = {"fetch_bytes": 2.0 * fetch[k]["FETCH_SIZE"] * 1024.0, "write_bytes": w * 1024.0}
+    traffic["split"] = split       # (round 6) reads and writes apart: fetch = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     durations = {}
     f = find(os.path.join(src, "stats"), "*kernel_stats.csv")
