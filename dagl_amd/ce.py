@@ -202,14 +202,15 @@ class CE(nn.Module):
         self.topk_threshold = "auto"
         # Top-k modes behind the screen: "always" (default) = every call queues the fp32 redo pass for query groups whose candidate slots
         # overflowed (a launch that finds nothing on a warm workspace: 4.7 us under rocprofv3, which serialises dispatches); "auto" =
-        # once a poll of the workspace (every 64th call, as for the range word) has found the last call without redo work, identical
+        # once three polls of the workspace in a row (every 64th call, as for the range word) have found the last call without redo work, identical
         # calls (same shape, weights, workspace) go without the launch (DAGL_FLAG_NO_REDO) and the workspace is polled every 32nd call;
         # a call that flags a group after all returns NaN -- never wrong numbers --, the next poll reports it and the module queues
         # the pass again from then on.  Not under HIP-graph capture (a replayed graph is never polled).  Measured on the headline
         # (profiles/r05_ab_topk_redo_launch.log, same box, interleaved): 0.2250 ms with "auto" against 0.2254 with "always" -- in the
         # un-profiled stream the empty launch runs under its neighbours' dispatch and the polls cost what is left; hence not the default.
         self.topk_redo = "always"
-        self._redo_skip = False        # the last poll found no redo work
+        self._redo_skip = False        # the last three polls found no redo work
+        self._redo_clean_polls = 0
         self._redo_banned = False      # a no-redo call went unserved once: never again on this module
         self._served_streak = 0
         self._served_streaks = {}      # the same for adaptive_sync = "auto"
@@ -249,9 +250,12 @@ class CE(nn.Module):
                 import warnings
                 warnings.warn("dagl_amd.CE: a top-k call that went without the fp32 redo pass (topk_redo = 'auto') met query groups whose "
                               "candidate slots overflowed: its output is NaN-filled; this module queues the pass again from now on")
-                self._redo_banned, self._redo_skip = True, False
+                self._redo_banned, self._redo_skip, self._redo_clean_polls = True, False, 0
             else:
-                self._redo_skip = not (bad & 4) and not self._redo_banned
+                # three polls in a row without redo work (not one: inputs that overflow the candidate slots now and then would hand
+                # out NaN-filled calls until the next poll)
+                self._redo_clean_polls = 0 if (bad & 4) else self._redo_clean_polls + 1
+                self._redo_skip = self._redo_clean_polls >= 3 and not self._redo_banned
         if bad & 2:
             import warnings
             warnings.warn("dagl_amd.CE: an adaptive call that did not wait for its verdict met neighbourhoods the in-stream kernels "
@@ -540,7 +544,7 @@ class CE(nn.Module):
         no_redo = (topk_screen and self.topk_redo == "auto" and self._redo_skip and not self._redo_banned and key == self._pack_key
                    and not torch.cuda.is_current_stream_capturing())
         if key != self._pack_key:
-            self._redo_skip = False                # another shape / weights / workspace: what the last poll saw no longer applies
+            self._redo_skip, self._redo_clean_polls = False, 0     # another shape / weights / workspace: what the polls saw no longer applies
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),

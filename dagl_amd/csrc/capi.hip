@@ -31,7 +31,11 @@ __global__ void retag_kernel(int32_t* word, int32_t* veto, int32_t tag) {
 // two shapes forgot "tight" on every call and paid sampled pass + policy kernel + tight re-run each time.  The learnt word now
 // survives as long as the workspace still carries the cookie of this very geometry (a fresh or re-used buffer does not).
 __global__ void policy_init_kernel(int64_t* stats, int64_t cookie, int32_t start_tight) {
-    if (stats[12] != cookie) { stats[9] = start_tight; stats[12] = cookie; stats[13] = 0; }     // ([13]: sticky "a DAGL_FLAG_NO_REDO call went unserved")
+    if (stats[12] != cookie) { stats[9] = start_tight; stats[12] = cookie; }
+    // [13]: sticky "a DAGL_FLAG_NO_REDO call went unserved" -- only prepared (weights-packed) calls set or report it, and this kernel runs
+    // on the non-prepared ones: cleared every time, so that a workspace handed on by torch's caching allocator, or shared by modules of
+    // one shape (the cookie hashes the geometry, not the owner), cannot pass a stale bit to CE.range_ok()
+    stats[13] = 0;
     stats[10] = 0;
 }
 

@@ -795,7 +795,10 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
     if (a.pass == 0 && lane == 0) {
         a.m_exact[ql] = ltop;                                                      // (>= 0: masked keys have l = 0, and so has an empty row)
         // (an empty row too: its masked keys' e^(0 - M) must not vanish either)
-        if (M - ltop > DN_SHIFT_SLACK && atomicExch(&a.redo_blk[bq * n_qblocks + qin / 64], 1) == 0) atomicAdd(a.redo_count, 1);
+        // ... and a shift BELOW the kernel's own largest logit (the row kernel's score further from the split-fp16 one than its 6e-6
+        // inflation at logits of 1e4-1e5, or the true arg-max missing from its candidates): the producers clamp l - M' at 0, the top
+        // weights would silently read 1 instead of e^(ltop - M) -- the same second pass, whose shifts are the recorded maxima, repairs it
+        if ((M - ltop > DN_SHIFT_SLACK || ltop - M > 2e-5f) && atomicExch(&a.redo_blk[bq * n_qblocks + qin / 64], 1) == 0) atomicAdd(a.redo_count, 1);
     }
     const float invz = (float)(1.0 / z);
     float4 acc[4];

@@ -377,6 +377,9 @@ __global__ void gemm16s_reduce_kernel(size_t n4, int slices, const float4* __res
 
 int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
     const int nb = g.batch > 1 ? g.batch : 1;
+    // (k_valid: rows shorter than the contraction -- the pieces past a row's end re-read its LAST eight columns, which the caller keeps zero)
+    DAGL_REQUIRE(g.k_valid == 0 || (g.k_valid >= 8 && g.k_valid % 8 == 0 && g.k_valid < g.K),
+                 "gemm16s: k_valid = %d must be a multiple of 8 in [8, K = %d)", g.k_valid, g.K);
     // tile shape by measurement (tools/time_fc_grad.py, n = 131 072): the weight gradient (one 196-row M tile, long K) is
     // faster on 256 x 128 tiles / 8 waves / one block per CU (0.55 against 0.59 ms with its producers), d rows (K = 224:
     // seven steps per block) on 128 x 128 / 4 waves / two blocks per CU (0.42 against 0.49 ms)

@@ -918,6 +918,7 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      const ThrHeadSet* thr_hs, int thr_head_imgs, float* thr_part) {
     Proj16Args pa;
     static_assert(TB4_LDS_BYTES <= P16_LDS, "the thr / bias blocks live in the projection's LDS");
+    static_assert(P16_BW == 4, "thr_bias4_block (thr_bias4.h) is written for blocks of exactly 256 threads: tid + 256 j strides, part[4][..]");
     for (int w = 0; w < 2; ++w) {
         pa.split_hi[w] = split ? split->hi[w] : nullptr; pa.split_lo[w] = split ? split->lo[w] : nullptr;
         pa.rows_alloc_s[w] = split ? split->rows_alloc[w] : 0;
