@@ -589,6 +589,9 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
             for (int r = 0; r < 16; ++r) hh[it][n][r] = 0.f;
 
     auto issue_w = [&](int t) {                        // the group's rows of tap t's weight slice -> ring stage t % RING
+#if defined(DAGL_P16_HALFW)
+        if (t & 1) return;               // (timing experiment, wrong results: half of the weight LDS-DMA)
+#endif
         const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE2_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
 #pragma unroll
@@ -619,6 +622,9 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
     auto issue_row = [&](int r) {                      // keys: kernel row r of both items (44 pixels, hi | lo) -> row buffer r & 1
 #pragma unroll
         for (int it = 0; it < PW; ++it) {
+#if defined(DAGL_P16_HALFROWS)
+            if (it > 0) break;           // (timing experiment, wrong results: half of the key-row LDS-DMA -- what a block shared by both tile groups would issue)
+#endif
             const unsigned dst = lds0 + P16_OFF_A2 + (wave * PW + it) * (2 * P16_AROW) + (r & 1) * P16_AROW;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // pieces: hi px 0-31, hi px 32-43 (24 lanes), lo px 0-31, lo px 32-43
@@ -890,6 +896,12 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
         project16_body<1, true, VAR>(pa, smem, tile, 2 * (pa.units_k - pa.n_split_groups + grp) + half, pa.batch - 1);
     }
     dbg_stamp(pa.times, bid, 3);
+#if defined(DAGL_ABLATION) && defined(DAGL_P16_HWID)
+    // (experiment: which CU ran the block -- HW_ID (cu [11:8], sh [12], se [15:13]) | XCC_ID << 16 in place of the prologue stamp)
+    if (pa.times != nullptr && threadIdx.x == 0)
+        pa.times[(size_t)bid * 4 + 1] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) |
+                                        ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 16);
+#endif
 }
 
 // colsum[b][col] = sum over key blocks of colpart[b][blk][col]: one wave per column, lane-strided partial sums

@@ -331,7 +331,10 @@ def test_config5_whole_network_gradients_match_oracle_autograd(mode, k):
             # (everything else still sees the flip at second order -- the activations behind that head move a little, and with them
             # the gradient that reaches its siblings: 2.1e-3 on one sibling's bias in the committed draw, 3e-4 typical)
             assert e <= (5e-2 if loose else 3e-3), (name, e, "touched by a near-tie head" if loose else "")
-            if not loose and name in e32:
+            # (per tensor against the reference's own fp32 distance: only meaningful when no head sits on a tie -- a neighbour that the
+            # HIP scores and the fp64 oracle resolve differently moves that head's output, and through the activations behind it EVERY
+            # gradient of the network at the 1e-3 level, while the fp32 oracle, resolving the tie as fp64 does, stays at 1e-6)
+            if not near_tie and name in e32:
                 assert e <= 3.0 * (e32[name] + floor32), (name, e, e32[name], floor32)
         assert float(np.median(errs)) <= 1e-3, float(np.median(errs))
     else:
