@@ -236,9 +236,10 @@ class CE(nn.Module):
         return bool(bad & 8)
 
     def range_ok(self) -> bool:
-        """False when the last inference call on this module met operands outside the split-fp16 range (|activation| >=
-        3750; include/dagl_ce.h): that call's output is NaN-filled.  Switches the module to ``scan = "exact"`` (the fp32
-        path, no range limit) in that case.  One host synchronisation."""
+        """False when an inference call on this module since the last poll met operands the split-fp16 kernels do not hold
+        (include/dagl_ce.h "Range": since round 6 that is a non-finite input or |g(x)| >= 1.5e7 -- the input itself has no limit
+        and the key / query map two tiers --, or dense-regime features >= 937): that call's output is NaN-filled.  Switches the
+        module to ``scan = "exact"`` (the fp32 path, no range limit) in that case.  One host synchronisation."""
         self._calls_since_range_check = 0
         if self.scan == "exact" or self._last_call is None:
             return True
@@ -545,6 +546,14 @@ class CE(nn.Module):
                    and not torch.cuda.is_current_stream_capturing())
         if key != self._pack_key:
             self._redo_skip, self._redo_clean_polls = False, 0     # another shape / weights / workspace: what the polls saw no longer applies
+            if self.scan != "exact" and key[6] != (self._pack_key[6] if self._pack_key else None) and not torch.cuda.is_current_stream_capturing():
+                # new weights are about to be packed as fp16 pairs (256 w_conv, 1024 w_fc): beyond |w_conv| < 234 / |w_fc| < 58 -- never
+                # seen on a trained DAGL -- the module takes the fp32 path from its first call (one synchronisation per weight set; the
+                # activations have no such limit since round 6: include/dagl_ce.h)
+                wmax = torch.stack([params[n].abs().max() for n in ("g.weight", "theta.weight", "fc1.0.weight", "fc2.0.weight")]).tolist()
+                if not (wmax[0] < 230.0 and wmax[1] < 230.0 and wmax[2] < 57.0 and wmax[3] < 57.0):
+                    self._note_range_violation("weights beyond the split-fp16 range (|w_conv| < 234, |w_fc| < 58)")
+                    return self._forward_infer(b, k_eff)
         out, info = ops.ce_forward_fused(b.contiguous(), params, mode=self.select_mode, k=k_eff,
                                          workspace=self._ws, profile=self.profile,
                                          exact_scan=(self.scan == "exact"), weights_packed=(key == self._pack_key),

@@ -133,7 +133,7 @@ struct Plan {
     // byte offsets into the workspace
     size_t o_b1p, o_b2p, o_wp1, o_wp2, o_x, o_wq, o_xh, o_wqh, o_colsum, o_mt, o_cnt, o_segcnt, o_segoff, o_rowoff,
         o_deg, o_stats, o_lidx, o_lval, o_cidx, o_cval, o_nbidx, o_nbwgt, o_nbcnt, o_agg, o_gmax, o_theta, o_smax, o_traw, o_scand, o_spill, o_spillcnt,
-        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
+        o_scandv, o_ssegcnt, o_redo, o_ovflist, o_heavy, o_ovfq, o_ovfscores, o_ovfpart, o_thr, o_bias, o_thrpart, o_maphi, o_maplo, o_maphi2, o_maplo2, o_b1amax, o_wp1h, o_wp2h, o_convw, o_colpart, o_end;
 };
 
 static bool g_N_small(int H, int W);
@@ -283,10 +283,15 @@ static int make_plan(int B, int H, int W, int mode_flags, int k, Plan& p, bool c
     p.o_thr = carve(off, BL * sizeof(float));
     p.o_bias = carve(off, BL * sizeof(float));
     p.o_thrpart = carve(off, 8 * BL * sizeof(float));                       // prologue: partial thr/bias sums of 4 channel groups
-    p.o_maphi = p.o_maplo = p.o_wp1h = p.o_wp2h = p.o_convw = p.o_colpart = 0;
+    p.o_maphi = p.o_maplo = p.o_maphi2 = p.o_maplo2 = p.o_b1amax = p.o_wp1h = p.o_wp2h = p.o_convw = p.o_colpart = 0;
     if (!exact) {
         p.o_maphi = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
         p.o_maplo = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
+        // the coarse tier of the key / query map and the conv blocks' |b1| slots (B1Tiers, dagl_common.h): written by conv_pair16_kernel,
+        // read by project16_kernel, so that activations beyond the fine tier's |b1| < 3750 are served by the same launches
+        p.o_maphi2 = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
+        p.o_maplo2 = carve(off, (size_t)B * g.Hp * g.Wp * CH * sizeof(uint16_t));
+        p.o_b1amax = carve(off, (size_t)conv16_blocks_per_head(g, 1, B) * sizeof(float));
         p.o_wp1h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));          // up to 4 heads (stage entry point)
         p.o_wp2h = carve(off, 4 * P16_PACKED_HALFS * sizeof(uint16_t));
         p.o_convw = carve(off, 4 * CONV_W16_BYTES);                                       // packed g / theta weights per head
@@ -468,8 +473,15 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
             thr_all.imgs = imgs;
             thr_in_proj = p.split16 && thr_bias4_ok(g, thr_all, heads);
         }
+        // the map's two tiers (B1Tiers): all heads of the call share the slot array, [head][blocks of that head]
+        B1Tiers tiers_all;
+        if (p.split16) {
+            tiers_all.hi2 = at<uint16_t>(ws, p.o_maphi2); tiers_all.lo2 = at<uint16_t>(ws, p.o_maplo2);
+            tiers_all.amax = at<float>(ws, p.o_b1amax); tiers_all.slots = conv16_blocks_per_head(g, heads, imgs);
+        }
         for (int hd = 0; hd < heads; ++hd) {
             const FusedIn& f = fin[hd];
+            B1Tiers tiers_hd;
             unsigned char* convw = p.split16 ? at<unsigned char>(ws, p.o_convw) + (size_t)hd * CONV_W16_BYTES : nullptr;
             if (convw && !(mode_flags & DAGL_FLAG_WEIGHTS_PACKED) && (rc = launch_pack_conv_weight16(s, f.g_w, f.th_w, convw))) return rc;
             if (conv_merged && hd == heads - 1) {
@@ -479,6 +491,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                     hs.gb[h2] = fin[h2].g_b; hs.tb[h2] = fin[h2].th_b;
                 }
                 hs.imgs = imgs;
+                hs.tiers = tiers_all;
                 if ((rc = launch_conv_pair16_heads(s, heads, imgs, g, hs, b2p, at<uint16_t>(ws, p.o_maphi), at<uint16_t>(ws, p.o_maplo),
                                                    prepared ? reinterpret_cast<uint32_t*>(stats) : nullptr, prepared ? 8 : 0,
                                                    (prepared && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
@@ -503,7 +516,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                       (prepared && hd == 0) ? reinterpret_cast<uint32_t*>(stats) : nullptr,
                                       (prepared && hd == 0) ? 8 : 0,
                                       (prepared && hd == 0 && p.screen) ? reinterpret_cast<uint32_t*>(at<int32_t>(ws, p.o_redo)) : nullptr,
-                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt, convw, conv_merged))) return rc;
+                                      (prepared && hd == 0 && p.screen) ? B * n_qgroups : 0, rt, convw, conv_merged,
+                                      p.split16 ? &(tiers_hd = B1Tiers{tiers_all.hi2 + hd * map_f, tiers_all.lo2 + hd * map_f, tiers_all.amax, tiers_all.slots}) : nullptr))) return rc;
         }
         thr = thr_ws; bias = bias_ws;
     } else {
@@ -567,6 +581,11 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if (mode != DAGL_MODE_TOPK)
             if ((rc = launch_colsum_rows(s, B, g.N, core->x_rows, colsum))) return rc;
     } else if (p.split16) {
+        B1Tiers tiers_fused;               // (the fused entry points: conv_pair16_kernel wrote both tiers; dagl_ce_forward's split_map_kernel only the fine one)
+        if (fin) {
+            tiers_fused.hi2 = at<uint16_t>(ws, p.o_maphi2); tiers_fused.lo2 = at<uint16_t>(ws, p.o_maplo2);
+            tiers_fused.amax = at<float>(ws, p.o_b1amax); tiers_fused.slots = conv16_blocks_per_head(g, heads, B / heads);
+        }
         const float* b1s[4]; const float* b2s[4];
         for (int hd = 0; hd < 4; ++hd) {
             b1s[hd] = (fin && hd < heads) ? fin[hd].fc1_b : fc1_b;
@@ -575,7 +594,8 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
         if ((rc = launch_project16(s, B, g, 3, map_hi, map_lo, wp2h, b2s, X, (mode == DAGL_MODE_TOPK) ? nullptr : colsum,
                                    at<float>(ws, p.o_colpart), wp1h, b1s,
                                    Wq, Xh, Wqh, heads, rt, q_tiled, split_p,
-                                   thr_in_proj ? &thr_all : nullptr, thr_in_proj ? B : 0, thr_in_proj ? at<float>(ws, p.o_thrpart) : nullptr))) return rc;
+                                   thr_in_proj ? &thr_all : nullptr, thr_in_proj ? B : 0, thr_in_proj ? at<float>(ws, p.o_thrpart) : nullptr,
+                                   fin ? &tiers_fused : nullptr))) return rc;
     } else {
         if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
     }

@@ -198,7 +198,8 @@ int hip_fail(hipError_t e, const char* what);
     } while (0)
 
 // Range guard of the split-fp16 kernels (prologue.hip, project16.hip, dense.hip): operands are pre-scaled by powers of two
-// and split into two fp16 numbers, which holds for |16 x|, |16 b1|, |256 w_conv|, |1024 w_fc|, |64 feature| < 65504.  A kernel
+// and split into two fp16 numbers, which holds for |256 w_conv|, |1024 w_fc|, |64 feature| < 65504 and -- on the entry points that
+// do not carry the map's two tiers (B1Tiers below; round 6) -- |16 x|, |16 b1| < 65504.  A kernel
 // that meets a larger value stores the call's tag into the workspace's range word; the last kernel of the call (fold) then
 // writes NaN instead of numbers computed from inf / NaN halves, and the host side re-runs the call on the fp32 path where
 // it reads statistics back anyway (adaptive modes) or on request (dagl_ce_range_check).
@@ -264,7 +265,24 @@ int launch_zero_borders(hipStream_t s, int B, int H, int W, float* m1, float* m2
 int launch_pad_nhwc(hipStream_t s, int B, int H, int W, const float* src, float* dst);
 int launch_pack_fc_weight(hipStream_t s, const float* w, float* wp);
 // g / theta convolutions of up to four heads (a CES stage) in one launch: per-head input, packed weights, biases
-struct ConvHeadSet { const float* x[4]; const unsigned char* w[4]; const float* gb[4]; const float* tb[4]; int imgs; };
+// (round 6) the split-fp16 range of the activations is per call, not fixed:
+//   * the INPUT x is split with a power-of-two scale of the block's own (a convolution is linear: the block scales its result back):
+//     a block whose rows leave |16 x| < 60000 runs its strip a second time with 2^e, e from the largest |x| it met -- free for inputs
+//     in range, twice the (latency-bound) strip otherwise;
+//   * the key / query map b1 = g(x) needs ONE scale per head (a patch projection sums 49 pixels of the map in one accumulator) that is
+//     only known once every block has finished: the kernel writes TWO tiers, 16 b1 = hi + lo (|b1| < 3750) and 2^-8 b1 = hi2 + lo2
+//     (|b1| < 1.5e7), and each block its largest |b1| into a slot; project16_kernel reduces its head's slots (a wave each: no atomics,
+//     nothing to clear, valid under HIP-graph replay) and multiplies the tier that holds the map.  Beyond 1.5e7 -- x of ~1e6 with
+//     default-like weights; the reference's own fp32 logits 10 S m ~ b1^4 overflow at b1 ~ 2e8 -- and for non-finite input the range
+//     word is set as before (NaN-filled output + sticky report).
+constexpr float B1_FINE_SCALE = 16.0f, B1_COARSE_SCALE = 1.0f / 256.0f;
+struct B1Tiers {
+    uint16_t* hi2 = nullptr; uint16_t* lo2 = nullptr;      // coarse tier maps, same geometry as the fine ones
+    float* amax = nullptr;                                  // [heads][slots]: largest |b1| of every wave of every conv block (inf for non-finite values)
+    int slots = 0;                                          // 4 x conv blocks per head
+};
+struct ConvHeadSet { const float* x[4]; const unsigned char* w[4]; const float* gb[4]; const float* tb[4]; int imgs; B1Tiers tiers; };
+int conv16_blocks_per_head(const Grid& g, int heads, int imgs);     // 4 x (grid of conv_pair16_kernel / heads): the slots of B1Tiers::amax per head
 struct ThrHeadSet { const float* x[4]; const float* thr_w[4]; const float* bias_w[4]; int imgs; };     // thr / bias heads likewise
 int launch_thr_bias_heads(hipStream_t s, int heads, int imgs, const Grid& g, const ThrHeadSet& hs,
                           float* thr_part /* per head [4][imgs][L][2] partial sums */);
@@ -281,7 +299,8 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     uint32_t* clear_a = nullptr, int clear_a_words = 0, uint32_t* clear_b = nullptr, int clear_b_words = 0
                     /* two small per-call regions (counters, flags) cleared by the first block of the conv kernel */,
                     RangeTag range = RangeTag(), const unsigned char* conv_w16 = nullptr /* packed g / theta weights (split-fp16 path) */,
-                    bool skip_conv = false /* the g / theta convolutions of all heads were one launch_conv_pair16_heads */);
+                    bool skip_conv = false /* the g / theta convolutions of all heads were one launch_conv_pair16_heads */,
+                    const B1Tiers* tiers = nullptr /* split-fp16 path: the coarse tier maps + the blocks' |b1| slots (see B1Tiers) */);
 constexpr size_t CONV_W16_BYTES = (18 + 2) * 16 * 128 + 256;   // packed conv weights of one head + range flag
 int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w, unsigned char* img);
 int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint16_t* m2);
@@ -303,7 +322,8 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      int q_tiled = 0 /* bf16 query copy in the screen's fragment order (ScreenArgs::q_tiled) */,
                      const Split16Out* split = nullptr,
                      const ThrHeadSet* thr_hs = nullptr /* with thr_part: the thr / bias heads' partial sums (thr_bias4.h) as extra blocks of this launch */,
-                     int thr_head_imgs = 0 /* heads x imgs of those heads */, float* thr_part = nullptr);
+                     int thr_head_imgs = 0 /* heads x imgs of those heads */, float* thr_part = nullptr,
+                     const B1Tiers* tiers = nullptr /* the map's coarse tier + the conv blocks' |b1| slots: the kernel picks the tier per head */);
 int launch_feat_rows_out(hipStream_t s, int B, int n, const float* feat /* [B, feat_rows(n), DS] */, float* rows_out /* [B, n, 196] */,
                          RangeTag range);            // dense copy of the feature rows; NaN when the call left the fp16 range
 int project16_key_blocks(const Grid& g);     // key blocks of project16: colpart is [B, key blocks, 224] floats

@@ -137,7 +137,9 @@ __device__ __forceinline__ void p16_split_pair(float a, float b, unsigned& hi, u
 
 struct Proj16Args {
     Grid gr;
-    const unsigned short* map_hi; const unsigned short* map_lo;     // [B,Hp,Wp,16] fp16
+    const unsigned short* map_hi; const unsigned short* map_lo;     // [B,Hp,Wp,16] fp16: 16 b1 = hi + lo
+    const unsigned short* map_hi2; const unsigned short* map_lo2;   // the coarse tier 2^-8 b1 = hi + lo, or null (B1Tiers, dagl_common.h)
+    const float* b1_amax; int amax_slots;                           // [heads][slots] largest |b1| of the conv blocks, or null: fine tier
     const unsigned short* wp[2];                                    // packed weights: [0] keys (fc2), [1] queries (fc1);
                                                                     // head h at + h * P16_PACKED_HALFS
     const float* bias[2][4];                                        // fc bias per head
@@ -186,6 +188,40 @@ static_assert(P16_BW * 2 * P16_AROW <= P16_QRING * P16_BW * 2048, "key row rings
 static_assert(P16_BLOCKS_PER_CU * P16_LDS <= 160 * 1024, "resident blocks per CU");
 
 
+// Which tier of the key / query map holds this head's values (B1Tiers, dagl_common.h).  Every wave reduces its head's slots itself, but
+// not before it needs to: the slots are REQUESTED first thing (inline asm: up to four 16-byte loads per lane = 1024 slots, the oldest
+// entries of the wave's memory queue, so the counted wait in front of the block's first barrier covers them), the block starts on the
+// fine tier like every call up to round 5, and the verdict is formed behind that barrier -- no round trip in front of the first
+// LDS-DMA.  A head on the coarse tier (|b1| >= 3750) requests its first patch rows / taps again from there: one round trip, once.
+typedef float p16f4 __attribute__((ext_vector_type(4)));
+struct P16Tier { const unsigned short* hi; const unsigned short* lo; float unscale; };
+struct P16TierReq { p16f4 v[4]; };
+__device__ __forceinline__ void p16_tier_request(const Proj16Args& pa, int head, int lane, P16TierReq& rq) {
+    if (pa.b1_amax == nullptr) return;
+    const float* sl = pa.b1_amax + (size_t)head * pa.amax_slots;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int base = 4 * (lane + 64 * j);
+        if (base > pa.amax_slots - 4) base = pa.amax_slots - 4;          // (slots: a multiple of 4; a slot read twice changes no maximum)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq.v[j]) : "v"(sl + base) : "memory");
+    }
+}
+// (call it behind a wait that covers the requests -- dma_wait_le of the block's prologue -- and a barrier; block-uniform result)
+__device__ __forceinline__ bool p16_tier_is_coarse(const Proj16Args& pa, int head, int lane, P16TierReq& rq) {
+    if (pa.b1_amax == nullptr) return false;
+    asm volatile("" : "+v"(rq.v[0]), "+v"(rq.v[1]), "+v"(rq.v[2]), "+v"(rq.v[3]));      // (ordered behind the wait: both are volatile)
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(fmaxf(m, fmaxf(rq.v[j][0], rq.v[j][1])), fmaxf(rq.v[j][2], rq.v[j][3]));
+    if (pa.amax_slots > 1024) {                                  // (huge batches: the rest in the ordinary way)
+        const float* sl = pa.b1_amax + (size_t)head * pa.amax_slots;
+        for (int i = 1024 + lane; i < pa.amax_slots; i += 64) m = fmaxf(m, sl[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return !(m * B1_FINE_SCALE < RANGE_LIMIT);
+}
+
 template <int NT, bool KEYS, int VAR>
 __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned char* smem, int n0, int blk, int b) {
     const int tid = threadIdx.x;
@@ -195,6 +231,9 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     const Grid& gr = pa.gr;
     constexpr int which = KEYS ? 0 : 1;
     const int head = b / pa.imgs_per_head;
+    P16TierReq tier_rq;
+    p16_tier_request(pa, head, lane, tier_rq);
+    P16Tier tier = {pa.map_hi, pa.map_lo, 1.0f / (P16_A_SCALE * P16_W_SCALE)};
     const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)head * P16_PACKED_HALFS + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
@@ -260,7 +299,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         else if (gx >= row_len) gx = row_len - 1;
         const int py = QS * qy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
         const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
-        ahi = pa.map_hi + aoff; alo = pa.map_lo + aoff;
+        ahi = tier.hi + aoff; alo = tier.lo + aoff;
     }
     auto issue_row = [&](int r) {                      // keys: kernel row r of the item (44 pixels, hi | lo) -> row buffer r & 1
         if (VAR == 6) return;                          // positions 0 .. nA+5: map row gy + r from pixel gx0; from nA+6 on: row gy+1+r from pixel 0
@@ -272,7 +311,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
             if (p >= nA + 6) { row += 1; px = p - (nA + 6); }
             if (px > gr.Wp - 1) px = gr.Wp - 1;                                   // stay inside the map
             if (row > gr.Hp - 1) row = gr.Hp - 1;
-            const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
+            const unsigned short* src = ((j < 2) ? tier.hi : tier.lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
             const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
             if ((j & 1) == 0 || lane < 2 * (P16_APX - 32)) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
         }
@@ -312,6 +351,12 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         issue_row(0); issue_wrow(0); issue_wrow(1);
         if (four) dma_wait_le<4>(); else dma_wait_le<3>();             // row 0 and weight row 0 landed
         __syncthreads();
+        if (p16_tier_is_coarse(pa, head, lane, tier_rq)) {             // (block-uniform) the map lives in the coarse tier: row 0 again
+            tier.hi = pa.map_hi2; tier.lo = pa.map_lo2; tier.unscale = 1.0f / (B1_COARSE_SCALE * P16_W_SCALE);
+            issue_row(0);
+            dma_wait_le<0>();
+            __syncthreads();
+        }
         for (int kh = 0; kh < KS; ++kh) {
             if (kh + 1 < KS) issue_row(kh + 1);
             if (kh + 2 < KS) issue_wrow(kh + 2);
@@ -339,6 +384,23 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
     for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
     P16_WAIT(PD - 1);
     __syncthreads();
+    if (p16_tier_is_coarse(pa, head, lane, tier_rq)) {                 // (block-uniform) the map lives in the coarse tier
+        tier.hi = pa.map_hi2; tier.lo = pa.map_lo2; tier.unscale = 1.0f / (B1_COARSE_SCALE * P16_W_SCALE);
+        if (!KEYS) {
+            int qy = gy, gx = gx0 + i;
+            if (lin) { int q = base_row + i; if (q > gr.L - 1) q = gr.L - 1; qy = q / row_len; gx = q - qy * row_len; }
+            else if (gx >= row_len) gx = row_len - 1;
+            const int py = QS * qy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
+            const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
+            ahi = tier.hi + aoff; alo = tier.lo + aoff;
+#pragma unroll
+            for (int t = 0; t < PD; ++t) issue_q(t);
+        } else {
+            issue_row(0);
+        }
+        dma_wait_le<0>();
+        __syncthreads();
+    }
     dbg_stamp(pa.times, blockIdx.x, 1);
 
     if (VAR == 9) { if (hh[0][0] != 0.f) pa.feat[which][0] = 1.f; return; }
@@ -418,7 +480,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
                     const int r = 8 * pass + r8;
                     const int rl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;              // row inside the pass: 0..15
                     const int rr = rl + 16 * pass;
-                    float v = hh[n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
+                    float v = hh[n][r] * tier.unscale + bv;
                     v = v > 0.f ? v : 0.f;
                     if (col >= D) v = 0.f;
                     if (col < DS) stg[rl * DS + col] = v;
@@ -474,7 +536,7 @@ __device__ __forceinline__ void project16_body(const Proj16Args& pa, unsigned ch
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
             const bool ok = wave_valid && (rr < lim);
-            float v = hh[n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
+            float v = hh[n][r] * tier.unscale + bv;
             v = v > 0.f ? v : 0.f;
             if (col >= D) v = 0.f;
             if (VAR == 1 && v != 12345.678f) continue;
@@ -549,6 +611,9 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
     constexpr int which = KEYS ? 0 : 1;
     constexpr int PW = P16_PW;
     const int head = b / pa.imgs_per_head;
+    P16TierReq tier_rq;
+    p16_tier_request(pa, head, lane, tier_rq);
+    P16Tier tier = {pa.map_hi, pa.map_lo, 1.0f / (P16_A_SCALE * P16_W_SCALE)};
     const unsigned short* __restrict__ wp = pa.wp[which] + (size_t)head * P16_PACKED_HALFS + (size_t)n0 * 32 * P16_ROWH;
     const int n_items = pa.n_items[which];
     const int segs_per_row = pa.segs[which];
@@ -616,7 +681,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
             else if (gx >= row_len) gx = row_len - 1;
             const int py = QS * qy - gr.pt + PADPIX, px = QS * gx - gr.pl + PADPIX;
             const size_t aoff = (((size_t)b * gr.Hp + py) * gr.Wp + px) * CH + 8 * h;
-            ahi[it] = pa.map_hi + aoff; alo[it] = pa.map_lo + aoff;
+            ahi[it] = tier.hi + aoff; alo[it] = tier.lo + aoff;
         }
     }
     auto issue_row = [&](int r) {                      // keys: kernel row r of both items (44 pixels, hi | lo) -> row buffer r & 1
@@ -633,7 +698,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
                 if (p >= nA[it] + 6) { row += 1; px = p - (nA[it] + 6); }
                 if (px > gr.Wp - 1) px = gr.Wp - 1;                                   // stay inside the map
                 if (row > gr.Hp - 1) row = gr.Hp - 1;
-                const unsigned short* src = ((j < 2) ? pa.map_hi : pa.map_lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
+                const unsigned short* src = ((j < 2) ? tier.hi : tier.lo) + krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
                 const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
                 if ((j & 1) == 0 || lane < 2 * (P16_APX - 32)) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
             }
@@ -661,6 +726,22 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
     for (int t = 0; t < PD; ++t) { issue_w(t); if (!KEYS) issue_q(t); }
     P16_WAIT2(PD - 1);
     __syncthreads();
+    if (p16_tier_is_coarse(pa, head, lane, tier_rq)) {                 // (block-uniform) the map lives in the coarse tier
+        tier.hi = pa.map_hi2; tier.lo = pa.map_lo2; tier.unscale = 1.0f / (B1_COARSE_SCALE * P16_W_SCALE);
+        if (!KEYS) {
+#pragma unroll
+            for (int it = 0; it < PW; ++it) {
+                const size_t d = ahi[it] - pa.map_hi;                  // this lane's patch corner, same offset in the other tier
+                ahi[it] = tier.hi + d; alo[it] = tier.lo + d;
+            }
+#pragma unroll
+            for (int t = 0; t < PD; ++t) issue_q(t);
+        } else {
+            issue_row(0);
+        }
+        dma_wait_le<0>();
+        __syncthreads();
+    }
     dbg_stamp(pa.times, blockIdx.x, 1);
 
     auto compute = [&](int step) {
@@ -736,7 +817,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
                     const int r = 8 * pass + r8;
                     const int rl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;              // row inside the pass: 0..15
                     const int rr = rl + 16 * pass;
-                    float v = hh[it][n][r] * (1.0f / (P16_A_SCALE * P16_W_SCALE)) + bv;
+                    float v = hh[it][n][r] * tier.unscale + bv;
                     v = v > 0.f ? v : 0.f;
                     if (col >= D) v = 0.f;
                     stg[rl * SEG + n * 32 + i] = v;
@@ -927,8 +1008,10 @@ int launch_project16(hipStream_t s, int B, const Grid& g, int which, const uint1
                      const uint16_t* wp_keys, const float* const* bias_keys, float* feat_keys, double* colsum, float* colpart,
                      const uint16_t* wp_q, const float* const* bias_q, float* feat_q, uint16_t* feat_keys_bf16,
                      uint16_t* feat_q_bf16, int heads, RangeTag range, int q_tiled, const Split16Out* split,
-                     const ThrHeadSet* thr_hs, int thr_head_imgs, float* thr_part) {
+                     const ThrHeadSet* thr_hs, int thr_head_imgs, float* thr_part, const B1Tiers* tiers) {
     Proj16Args pa;
+    pa.map_hi2 = tiers ? tiers->hi2 : nullptr; pa.map_lo2 = tiers ? tiers->lo2 : nullptr;
+    pa.b1_amax = (tiers && tiers->hi2) ? tiers->amax : nullptr; pa.amax_slots = tiers ? tiers->slots : 0;
     static_assert(TB4_LDS_BYTES <= P16_LDS, "the thr / bias blocks live in the projection's LDS");
     static_assert(P16_BW == 4, "thr_bias4_block (thr_bias4.h) is written for blocks of exactly 256 threads: tid + 256 j strides, part[4][..]");
     for (int w = 0; w < 2; ++w) {

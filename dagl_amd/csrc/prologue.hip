@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
                                                           int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
                                                           RangeTag range, unsigned long long* times) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB];           // 110 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C16_WOFF + C16_WB + 16];      // 110 KiB (+ the out-of-range flag)
+    int* const oor = reinterpret_cast<int*>(smem + C16_WOFF + C16_WB);      // "some input value of the strip left the scale's range"
     const int tid = threadIdx.x;
     const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // (phase stamps of ablation builds)
     dbg_stamp(times, blin, 0);
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         for (int t = tid; t < clear_a_words; t += 256) clear_a[t] = 0u;
         for (int t = tid; t < clear_b_words; t += 256) clear_b[t] = 0u;
     }
+    if (tid == 0) *oor = 0;                               // (read after the strip's barriers)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 15, kg = lane >> 4;
@@ -249,6 +251,9 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         for (int c = 0; c < 16; ++c) st[c] = oka ? raw[c] : 0.f;
         sh = okc ? rh : 0.f;
     };
+    float xs = C16_XS;                                     // the block's input scale (see B1Tiers, dagl_common.h): 16, or 2^e on the second attempt
+    float amax_x = 0.f;                                    // largest |x| this thread staged (unscaled; inf stays, a NaN is skipped here and
+                                                           // shows up in the outputs it poisons: b1_bits below)
     auto store_row = [&](int yy, const float* st, float sh) {
         unsigned char* row = smem + ((yy + 1) & (PRO_ROWS - 1)) * C16_ROWB;
         unsigned char* px = row + lane * C16_PXB;
@@ -256,9 +261,9 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             _Float16 h, l;
-            c16_split(st[c] * C16_XS, h, l); hi0[c] = h; lo0[c] = l;
-            c16_split(st[c + 8] * C16_XS, h, l); hi1[c] = h; lo1[c] = l;
-            amax = fmaxf(amax, fmaxf(fabsf(st[c]), fabsf(st[c + 8])) * C16_XS);
+            c16_split(st[c] * xs, h, l); hi0[c] = h; lo0[c] = l;
+            c16_split(st[c + 8] * xs, h, l); hi1[c] = h; lo1[c] = l;
+            amax_x = fmaxf(amax_x, fmaxf(fabsf(st[c]), fabsf(st[c + 8])));
         }
         *reinterpret_cast<h16x8*>(px + 32 * wave) = hi0;
         *reinterpret_cast<h16x8*>(px + 32 * wave + 16) = hi1;
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         *reinterpret_cast<h16x8*>(px + 128 + 32 * wave + 16) = lo1;
         if (tid < 128) {
             _Float16 h, l;
-            c16_split(sh * C16_XS, h, l);
+            c16_split(sh * xs, h, l);
+            amax_x = fmaxf(amax_x, fabsf(sh));
             *reinterpret_cast<_Float16*>(row + hpx * C16_PXB + 2 * hch) = h;
             *reinterpret_cast<_Float16*>(row + hpx * C16_PXB + 128 + 2 * hch) = l;
         }
@@ -274,10 +280,17 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
 
     // prologue: the three first rows and the weights are requested together (one memory round trip), then converted
     float st0[16], st1[16], st2[16], sh0, sh1, sh2;
+    unsigned b1_bits = 0u;                                 // largest |b1| this thread wrote, as bits (B1Tiers::amax): inf and NaN rank above
+                                                           // every finite value, so one integer maximum carries all three
+    const bool tiers = hs.tiers.amax != nullptr;           // (else: the fixed scales and the range word, as up to round 5)
+    unsigned short* __restrict__ b1hi2 = hs.tiers.hi2;
+    unsigned short* __restrict__ b1lo2 = hs.tiers.lo2;
+    bool first = true;
+    auto run_strip = [&]() {
     load_row(y0 - 1, st0, sh0);
     load_row(y0, st1, sh1);
     load_row(y0 + 1, st2, sh2);
-    {
+    if (first) {
         // the packed weight image: 40 KiB = 10 x 16 B per thread, straight into LDS
         uint4 wv[10];
 #pragma unroll
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
     const unsigned char* wbase = smem + C16_WOFF + i * 128;
     const int whi = (kg ^ ((i >> 1) & 7)) << 4, wlo = ((4 + kg) ^ ((i >> 1) & 7)) << 4;
     const int pxo = (16 * wave + i) * C16_PXB + kg * 16;                        // B: col = pixel 16 wave + i (+ dx)
-    constexpr float inv = 1.0f / (C16_XS * C16_WS);
+    const float inv = 1.0f / (xs * C16_WS);                 // (powers of two: exact)
     // the A fragments (weights) of all 20 K-blocks stay in registers (160 VGPRs; one wave per SIMD anyway): a row then
     // needs only its 36 pixel fragments from LDS, all requested up front
     h16x8 wh[20], wl2[20];
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         wh[kb] = *reinterpret_cast<const h16x8*>(wbase + kb * 2048 + whi);
         wl2[kb] = *reinterpret_cast<const h16x8*>(wbase + kb * 2048 + wlo);
     }
+    b1_bits = 0u;
 
     dbg_stamp(times, blin, 1);
     // rows y+2 and y+3 are both in flight: a row's loads are issued two iterations before its conversion (the matrix
@@ -357,33 +371,90 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         const int xx = x0 + 16 * wave + i;
         if (xx < W) {
             const size_t o = (((size_t)b * Hp + y + PADPIX) * Wp + xx + PADPIX) * CH + 4 * kg;
-            h16x4 vh, vl;
+            h16x4 vh, vl, vh2, vl2;
             float4 v2;
             float* v2p = &v2.x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v1 = ag[r] * inv + bg[r];
                 _Float16 h, l;
-                c16_split(v1 * 16.0f, h, l);                     // P16_A_SCALE (project16.hip)
-                amax = fmaxf(amax, fabsf(v1) * 16.0f);
+                c16_split(v1 * B1_FINE_SCALE, h, l);             // P16_A_SCALE (project16.hip)
                 vh[r] = h; vl[r] = l;
+                c16_split(v1 * B1_COARSE_SCALE, h, l);           // the coarse tier (B1Tiers)
+                vh2[r] = h; vl2[r] = l;
+                b1_bits = max(b1_bits, __float_as_uint(v1) & 0x7fffffffu);
                 v2p[r] = at[r] * inv + bt[r];
             }
             *reinterpret_cast<h16x4*>(b1hi + o) = vh;
             *reinterpret_cast<h16x4*>(b1lo + o) = vl;
+            if (tiers) {
+                *reinterpret_cast<h16x4*>(b1hi2 + o) = vh2;
+                *reinterpret_cast<h16x4*>(b1lo2 + o) = vl2;
+            }
             *reinterpret_cast<float4*>(b2p + o) = v2;
         }
         if (y + 1 < y1) store_row(y + 2, stc, shc);              // overwrites row y-2's slot: not read any more
+        if (y + 1 >= y1 && !(amax_x * xs < RANGE_LIMIT)) *oor = 1;   // (the strip's last row: amax_x is final, its barrier publishes the flag)
         __syncthreads();
     };
     for (int y = y0; y < y1; y += 2) {
         do_row(y, st0, sh0, st1, sh1);
         if (y + 1 < y1) do_row(y + 1, st1, sh1, st0, sh0);
     }
+    };
+    run_strip();
+    // Did every input value of the strip fit |16 x| < 60000?  (block-uniform: the flag was written before the strip's last barrier)
+    if (tiers && *oor != 0) {
+        // second attempt (a second copy of the strip's code, not a loop around it: with a back edge the optimizer keeps every address of
+        // the strip live across the body -- 512 registers, 60 spilled): the strip again with a scale of its own.  Block maximum of |x|
+        // through the LDS (the pixel ring is dead: every wave is past its last row's barrier), 2^e = the largest power of two with
+        // 2^e max|x| < 32768; inf in the input: the scale does not matter, the outputs are NaN / inf, which the slots and the range
+        // word below report
+        float m = amax_x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();                                       // (the ring is about to be restaged)
+        int e = 0;
+        if (m <= 3.0e38f) { (void)frexpf(m, &e); e = 15 - e; }  // m = f 2^e', f in [0.5, 1)  ->  2^(15 - e') m < 32768
+        e = e < -120 ? -120 : (e > 4 ? 4 : e);
+        xs = ldexpf(1.0f, e);
+        first = false;
+        run_strip();
+    }
     dbg_stamp(times, blin, 2);
-    // (a NaN / inf input compares false / true here and is flagged as well: !(amax < limit))
-    if (range.word != nullptr && !(amax < RANGE_LIMIT)) *range.word = range.tag;
+    if (tiers) {
+        // the wave's largest |b1| -> its slot (project16_kernel picks the tier from its head's slots); inf / NaN: +inf
+        unsigned mb = b1_bits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+        if (lane == 0) {
+            const float m = mb >= 0x7f800000u ? __builtin_inff() : __uint_as_float(mb);
+            const int img = b - head * hs.imgs;
+            hs.tiers.amax[(size_t)head * hs.tiers.slots + (((size_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave] = m;
+            // beyond the coarse tier, non-finite values (or weights packed from out-of-range values): the call's range word, as before
+            if (range.word != nullptr && (!(m * B1_COARSE_SCALE < RANGE_LIMIT) || !(amax < RANGE_LIMIT))) *range.word = range.tag;
+        }
+    } else {
+        // (a NaN / inf input compares false / true here and is flagged as well: !(amax < limit))
+        if (range.word != nullptr && (!(amax < RANGE_LIMIT) || !(amax_x * xs < RANGE_LIMIT) || !((float)(b1_bits >= 0x7f800000u ? __builtin_inff() : __uint_as_float(b1_bits)) * B1_FINE_SCALE < RANGE_LIMIT)))
+            *range.word = range.tag;
+    }
     dbg_stamp(times, blin, 3);
+}
+
+int conv16_blocks_per_head(const Grid& g, int heads, int imgs) {
+    const int B = heads * imgs;
+    const int strips = (g.W + PRO_TW - 1) / PRO_TW;
+    int chunks = (256 + strips * B - 1) / (strips * B);
+    if (chunks > (g.H + 1) / 2) chunks = (g.H + 1) / 2;
+    if (chunks < 1) chunks = 1;
+    const int rows_per_block = (g.H + chunks - 1) / chunks;
+    chunks = (g.H + rows_per_block - 1) / rows_per_block;
+    return strips * chunks * imgs * 4;                      // (a slot per wave of every block)
 }
 
 // thr / bias heads (two 7x7 stride-4 convolutions 64 -> 1 over the SAME-padded input, dagl.py:212-215).
@@ -527,11 +598,12 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
                     const float* bias_w, const float* bias_b, float* b1p, float* b2p, float* thr, float* bias,
                     uint16_t* b1_hi, uint16_t* b1_lo, float* thr_part, bool borders_zero, bool defer_thr_reduce, uint32_t* clear_a,
                     int clear_a_words, uint32_t* clear_b, int clear_b_words, RangeTag range, const unsigned char* conv_w16,
-                    bool skip_conv) {
+                    bool skip_conv, const B1Tiers* tiers) {
     int rcz;
     if (!borders_zero) {
         if ((rcz = launch_zero_borders(s, B, g.H, g.W, b1p ? b1p : b2p, b2p))) return rcz;
         if (b1_hi != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, b1_hi, b1_lo))) return rcz;
+        if (b1_hi != nullptr && tiers != nullptr && tiers->hi2 != nullptr && (rcz = launch_zero_borders16(s, B, g.H, g.W, tiers->hi2, tiers->lo2))) return rcz;
     }
     const int strips = (g.W + PRO_TW - 1) / PRO_TW;
     // one block per CU over the whole launch (1 block/CU resident: 332 registers), at least 2 rows per block
@@ -547,6 +619,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
         if (conv_w16 == nullptr) { set_error("launch_prologue: the split-fp16 convolutions need their packed weights"); return DAGL_ERR_INVALID; }
         ConvHeadSet hs = {};
         hs.x[0] = x; hs.w[0] = conv_w16; hs.gb[0] = g_b; hs.tb[0] = th_b; hs.imgs = B;
+        if (tiers != nullptr) hs.tiers = *tiers;
         unsigned long long* times = nullptr;
 #ifdef DAGL_ABLATION
         if (getenv("DAGL_TIMES_FILE")) times = dbg_times_buffer((size_t)strips * chunks * B);

@@ -76,6 +76,15 @@ class CES(nn.Module):
             wsb = ws.peek(x.device)
             key = (tuple(x.shape), heads[0].select_mode, k_eff, tuple(hd._pack_epoch for hd in heads),
                    tuple((t.data_ptr(), t._version) for t in fcs), wsb.data_ptr() if wsb is not None else 0)
+            if key != self._pack_key[s] and (self._pack_key[s] is None or key[4] != self._pack_key[s][4]) \
+                    and not torch.cuda.is_current_stream_capturing():
+                # new weights are about to be packed as fp16 pairs: beyond |w_conv| < 234 / |w_fc| < 58 (never seen on a trained DAGL) the
+                # heads take the fp32 path -- which takes them off the fused launch set -- before their first call (CE._forward_infer)
+                wmax = torch.stack([t.abs().max() for t in fcs]).view(4, 4).max(dim=0).values.tolist()
+                if not (wmax[0] < 57.0 and wmax[1] < 57.0 and wmax[2] < 230.0 and wmax[3] < 230.0):
+                    for hd in heads:
+                        hd._note_range_violation("weights beyond the split-fp16 range (|w_conv| < 234, |w_fc| < 58)")
+                    return self._stage(s, x)
             # the top-k threshold policy ("auto") lives in the stage workspace and is read by the kernels themselves (CE.topk_threshold)
             thr = heads[0].topk_threshold
             out, info = ops.ces_stage_forward(x.contiguous(), prm, mix.weight.detach().contiguous(),

@@ -135,14 +135,21 @@ typedef struct dagl_ce_info {
                                  5 = dense formulation under autograd (dagl_ce_core_dense_forward),
                                  6 = top-k modes with min(k, N) > DAGL_MAX_TOPK: row-wise dense form (no lists) */
     int32_t range_fallback;   /* 1 = an operand left the range of the split-fp16 kernels (|activation| >= 3750, see
-                                 below) and the call was re-run on the fp32 path (DAGL_FLAG_EXACT_SCAN)  */
+                                 below: weights, dense-regime features, |b1| >= 1.5e7, non-finite input) and the call was re-run on the fp32 path */
     int32_t dense_rerun_blocks; /* path 4 / 5: blocks of 64 queries the streamed dense formulation ran a second time (rows whose
                                  exact maximum the top-1 screen could not serve: flat maps); 0 otherwise (ABI 404; was `reserved`) */
 } dagl_ce_info;
 
-/* Range of the default (split-fp16) path: |x|, |b1| < 3750, |w_conv| < 234, |w_fc| < 58, |features| < 937 in the dense
- * regime.  A call that meets a larger (or non-finite) operand never returns numbers computed from it: its output is
- * NaN-filled by the last kernel, and
+/* Range of the default (split-fp16) path.
+ * Activations (round 6): the fused entry points (dagl_ce_forward_fused, dagl_ces_stage_forward) have NO fixed limit on the input
+ * and serve |b1| = |g(x)| < 1.5e7 with the same launches -- the prologue splits x with a power-of-two scale of each block's own
+ * and writes the key / query map in two tiers (16 b1 and 2^-8 b1 as fp16 pairs), the projection multiplies the tier that holds the
+ * head's values (csrc/dagl_common.h B1Tiers): finite in, finite out, on the first call, without a host round trip, under HIP-graph
+ * replay.  (The reference's own fp32 logits 10 S m ~ b1^4 overflow at b1 ~ 2e8.)  dagl_ce_forward (maps computed by the caller)
+ * and the training entry points keep the fine tier: |b1| < 3750.  Still fixed: |w_conv| < 234, |w_fc| < 58 (checked when the
+ * weights are packed; dagl_amd.CE moves a module with larger weights to DAGL_FLAG_EXACT_SCAN before its first call) and
+ * |features| < 937 in the dense regime.  A call that meets an operand beyond these (or a non-finite one) never returns numbers
+ * computed from it: its output is NaN-filled by the last kernel, and
  *   - the adaptive modes, which read statistics back anyway, notice and re-run the call on the fp32 path at once
  *     (info->range_fallback = 1; the result is the exact scan's);
  *   - the top-k modes have no host round trip: dagl_ce_range_check(workspace) tells (one synchronisation) whether ANY

@@ -124,7 +124,7 @@ def test_unserved_no_wait_call_is_nan_filled_and_reported():
 
 def test_one_out_of_range_replay_does_not_poison_the_later_ones():
     """A captured call carries its range-guard tag as a kernel argument: every replay has the same one.  A replay that leaves the
-    split-fp16 range (|activation| >= 3750) is NaN-filled and leaves the tag in the sticky word; before round 4's last fix every LATER
+    split-fp16 range (since round 6: a non-finite input; |activation| >= 3750 up to round 5) is NaN-filled and leaves the tag in the sticky word; before round 4's last fix every LATER
     replay found its own tag there and was NaN-filled too.  Now the first launch of a captured call re-labels the word ("an earlier
     call", still non-zero): the next replay is served, the poll still reports the violation."""
     import warnings
@@ -150,7 +150,11 @@ def test_one_out_of_range_replay_does_not_poison_the_later_ones():
             out_static = ce(x_static)
         graph.replay(); torch.cuda.synchronize()
         assert torch.equal(out_static, want)
-        x_static.copy_(good * 3.0e4)                         # far outside the range of the split-fp16 kernels
+        x_static.copy_(good * 3.0e4)                         # far outside the fine tier: served by the same captured launches (round 6)
+        graph.replay(); torch.cuda.synchronize()
+        assert torch.isfinite(out_static).all()
+        x_static.copy_(good)
+        x_static[1, 7, 20, 21] = float("inf")                # what the guard is left with: a non-finite input
         graph.replay(); torch.cuda.synchronize()
         assert torch.isnan(out_static).all()                 # never numbers computed from inf halves
         x_static.copy_(good)

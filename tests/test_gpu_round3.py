@@ -330,7 +330,8 @@ def test_range_word_is_sticky_until_read():
     x = torch.from_numpy(make_features(77, 1, 64, 64, 64)).to(DEV)
     with torch.no_grad():
         assert torch.isfinite(ce(x)).all()
-        assert torch.isnan(ce(x * 3.0e3)).all()                      # leaves the split-fp16 range: NaN, never wrong numbers
+        assert torch.isfinite(ce(x * 3.0e3)).all()                   # beyond the fine tier: served (round 6)
+        assert torch.isnan(ce(x * 1.0e8)).all()                      # |g(x)| >= 1.5e7 leaves the coarse tier too: NaN, never wrong numbers
         for _ in range(3):
             assert torch.isfinite(ce(x)).all()                       # later calls are fine again ...
         with warnings.catch_warnings(record=True):
@@ -351,7 +352,7 @@ def test_fused_stage_polls_its_range_word():
         warnings.simplefilter("always")
         ces._stage(1, x)
         ces._fused_calls[1] = 63                                     # the next fused call is the polling one
-        bad = ces._stage(1, x * 1.0e4)                               # |x| ~ 4e4: outside the range
+        bad = ces._stage(1, x * 1.0e8)                               # |g(x)| ~ 1e8: beyond both tiers of the map (round 6: 1e4 is served)
         assert all(hd.scan == "exact" for hd in heads[:4])           # stage 1's heads left the fused path ...
         assert torch.isfinite(bad).all()                             # ... and the call was redone per head on the fp32 path
 
