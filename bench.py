@@ -214,7 +214,11 @@ def dense_roofline(stage_ms, B, L, N, info, source):
             "executed_frac": executed / (stage_ms * 1e-3) / 1e12 / PEAK_BF16_MATRIX_TFLOPS if stage_ms > 0 else 0.0,
             "executed_note": "upper figure: exact-zero weight granules (64 queries x 16 keys) are skipped, so fewer multiplies than "
                              "this run on maps whose logits reach hundreds (synthetic N(0,1) features); none are on trained features",
-            "traffic": None, "flop_per_launch": flops, "ms_per_launch": stage_ms,
+            "traffic": committed_traffic("dense:dense_attend_kernel") if (B, L, N) == (1, 4096, 65536) else None,
+            "traffic_note": "HBM-side bytes per dense_attend_kernel launch from the committed rocprofv3 --pmc passes of `bench.py --mode "
+                            "adaptive --variant default` (profiles/rNN_traffic.json, key dense:dense_attend_kernel; mean over the call's "
+                            "two launches, of which the gated second one moves nothing): not measured in this run",
+            "flop_per_launch": flops, "ms_per_launch": stage_ms,
             "launches_per_call": 1 if rerun == 0 else 2, "dense_rerun_blocks": rerun,
             "launches_note": "dense_attend_kernel launches of a call that do work (the second, gated pass exits at once unless the "
                              "first flagged blocks of 64 queries: rows the top-1 screen could not give an exact shift)",
@@ -226,6 +230,7 @@ def extra_configs(dev):
     --prewarm --, 3 warm-ups + 10 timed steps) inside the one driver-timed command, so that their numbers are measured by
     the driver's run as well."""
     from dagl_amd import ops
+    from dagl_amd._lib import STAGE_NAMES
     from dagl_amd.ce import CE
     from dagl_amd.synth import make_ce_params, make_features
 
@@ -265,6 +270,35 @@ def extra_configs(dev):
             out[name] = {"what": what, "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": size * size, "batch": nb,
                          "selection_path": info.get("path"), "max_degree": info.get("max_degree"),
                          "mean_degree": (info.get("total_edges", -1) / L) if info.get("total_edges", -1) >= 0 else None}
+            if info.get("path") == 3 and size >= 512:
+                # configs[2] / configs[3]: the same accounting as the headline -- the dominant kernel (the bf16 filter pass over all L N
+                # scores) event-bracketed on the launch stream in 10 more calls, then the nine-boundary stage profile of 5 calls
+                pr = ops.StageProfile(10)
+                pr.select_stage("select")
+                ce.profile = pr
+                for _ in range(10):
+                    ce(x)
+                torch.cuda.synchronize()
+                s_ms = [c[4] for c in pr.read()]
+                pr.select_stage(-1)
+                pr.reset()
+                for _ in range(5):
+                    ce(x)
+                torch.cuda.synchronize()
+                ce.profile = None
+                st = pr.read()
+                sel = sum(s_ms) / max(len(s_ms), 1)
+                flop = 2.0 * L * (size * size) * D_FEAT
+                ach = flop / (sel * 1e-3) / 1e12 if sel > 0 else 0.0
+                out[name]["roofline"] = {"bound": "mfma", "kernel": "screen_ring_kernel<1> (bf16 v_mfma_f32_32x32x16_bf16, full L*N candidate filter)",
+                                         "achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MATRIX_TFLOPS,
+                                         "traffic": None, "flop_per_launch": flop, "ms_per_launch": sel,
+                                         "timing": "mean of 10 calls, two hipEvents around the stage 'select' on the launch stream"}
+                if st:
+                    mean = [sum(c[i] for c in st) / len(st) for i in range(8)]
+                    out[name]["stage_ms"] = {STAGE_NAMES[i]: float(mean[i]) for i in range(8)}
+                    out[name]["stage_ms_note"] = "separate instrumented pass (nine event records per call); stage 'select' there includes the records' stream time"
+                del pr
             if info.get("path") == 4:              # dense regime: its dominant kernel's roofline, event-bracketed in 10 more calls
                 pr = ops.StageProfile(10)
                 pr.select_stage("gather")
@@ -529,7 +563,10 @@ def gemm_roofline(dev, B, crop):
                                       "operands, gemm16s_kernel v_mfma_f32_32x32x16_f16 + its operand producers)" % (n, n),
             "achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MATRIX_TFLOPS,
             "executed_frac": 3.0 * ach / PEAK_BF16_MATRIX_TFLOPS, "fp32_matrix_peak_equivalent": ach / PEAK_F32_MATRIX_TFLOPS,
-            "flop_per_launch": flop, "ms_per_launch": g_ms, "traffic": None,
+            "flop_per_launch": flop, "ms_per_launch": g_ms, "traffic": committed_traffic("train:gemm16s_kernel"),
+            "traffic_note": "HBM-side bytes of ONE gemm16s_kernel launch (the larger of the call's two products) from the committed "
+                            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --train` (profiles/rNN_traffic.json, key "
+                            "train:gemm16s_kernel); not measured in this run",
             "note": "algorithmic FLOP of both products / time of the whole call (producers included); x3 = executed fp16 products "
                     "against the 2.5 PF fp16 peak; the same FLOP against the 157.3 TF fp32 matrix peak in fp32_matrix_peak_equivalent",
             "calls_per_step": "12 heads x (fc2 on the key rows; fc1 on the query rows is 1/16 of it)"}

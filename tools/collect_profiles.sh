@@ -5,7 +5,7 @@
 #   3. --pmc SQ_* counters                           MFMA utilisation / wait breakdown of the matrix-core kernels
 # tools/summarize_profiles.py turns the CSVs into the small JSON / CSV files kept under profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -22,5 +22,15 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/md8 -o 
 # first step -- is two thirds of the traced time and the CSV does not show the steady-state step)
 MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 12 --warmup 4 > $OUT/train.log 2>&1
 MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_adaptive -o k -- python $GRAFT_REPO_ROOT/bench.py --train --mode adaptive --steps 8 --warmup 3 > $OUT/train_adaptive.log 2>&1
+# (round 6) BASELINE configs[2] / configs[3]: kernel by kernel
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c512 -o k -- python $GRAFT_REPO_ROOT/tools/prof_case.py topk default 2.0 2024 100 512 8 60 > $OUT/c512.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c1024 -o k -- python $GRAFT_REPO_ROOT/tools/prof_case.py adaptive_topk sparse 1.7 2024 100 1024 16 12 > $OUT/c1024.log 2>&1
+# (round 6) HBM-side traffic of the dense regime's and the training path's kernels: FETCH_SIZE / WRITE_SIZE, separate passes
+DENSE="python $GRAFT_REPO_ROOT/bench.py --mode adaptive --variant default --steps 10 --warmup 3 --no-cpu-baseline --no-quality --no-extra"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/dense_fetch -o k -- $DENSE > $OUT/dense_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/dense_write -o k -- $DENSE > $OUT/dense_write.log 2>&1
+TRAIN="python $GRAFT_REPO_ROOT/bench.py --train --mode topk --steps 6 --warmup 3"
+MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/train_fetch -o k -- $TRAIN > $OUT/train_fetch.log 2>&1
+MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/train_write -o k -- $TRAIN > $OUT/train_write.log 2>&1
 python $GRAFT_REPO_ROOT/tools/summarize_profiles.py $OUT $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary $TAG
 ls $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary

@@ -51,7 +51,7 @@ def main():
     src, dst, tag = sys.argv[1:4]
     os.makedirs(dst, exist_ok=True)
     for sub, name in (("stats", "topk8_256"), ("dense", "dense_256"), ("md8", "adaptive_mean_degree_8_256"), ("train", "train"),
-                      ("train_adaptive", "train_adaptive")):
+                      ("train_adaptive", "train_adaptive"), ("c512", "topk8_512"), ("c1024", "adaptive_topk16_1024")):
         f = find(os.path.join(src, sub), "*kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"))
@@ -68,6 +68,19 @@ def main():
             traffic[sk] = (2.0 * fetch[k]["FETCH_SIZE"] + w) * 1024.0
             split[sk] = {"fetch_bytes": 2.0 * fetch[k]["FETCH_SIZE"] * 1024.0, "write_bytes": w * 1024.0}
     traffic["split"] = split       # (round 6) reads and writes apart: fetch = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB
+    # (round 6) the dense regime's and the training path's kernels from their own passes (same corrections; keys carry the regime)
+    for regime, keys in (("dense", ("dense_attend_kernel", "project16_kernel", "screen_ring_kernel<1>")), ("train", ("gemm16s_kernel", "gemm32_kernel"))):
+        fe, wr = counters(os.path.join(src, regime + "_fetch")), counters(os.path.join(src, regime + "_write"))
+        for k in fe:
+            sk = short(k)
+            if sk in keys and "FETCH_SIZE" in fe[k]:
+                w = wr.get(k, {}).get("WRITE_SIZE", 0.0)
+                key = f"{regime}:{sk}"
+                if key in split:        # several template instances of one kernel: keep the larger (the dominant launch shape)
+                    if 2.0 * fe[k]["FETCH_SIZE"] * 1024.0 + w * 1024.0 <= traffic[key]:
+                        continue
+                traffic[key] = (2.0 * fe[k]["FETCH_SIZE"] + w) * 1024.0
+                split[key] = {"fetch_bytes": 2.0 * fe[k]["FETCH_SIZE"] * 1024.0, "write_bytes": w * 1024.0, "kernel": k[:120]}
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     durations = {}
     f = find(os.path.join(src, "stats"), "*kernel_stats.csv")
