@@ -544,7 +544,8 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
                      const float* mt, const float* bs, const float* b2p, void* ws, float* agg, int32_t* deg, float* rowsum,
                      RangeTag range = RangeTag());
 // fp32 feature rows [B, rows_in, DS] -> split fp16 rows [B, rows_out, DSH] hi and lo, DN_FS x = hi + lo, columns 196.. zero (dense.hip)
-int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range);
+int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range,
+                      const unsigned* scale_word = nullptr /* the tensor's largest magnitude (launch_absmax): its power-of-two scale instead of DN_FS */);
 
 
 int launch_row_degree(hipStream_t s, int n_rows, int splits2, const int32_t* seg_cnt, int32_t* seg_rel,

@@ -831,17 +831,21 @@ __global__ __launch_bounds__(256) void dense_combine_kernel(DenseArgs a, float* 
 }
 
 // fp32 feature rows [B, rows_in, 204] -> split fp16 rows [B, rows_out, 216] hi and lo, 64 x = hi + lo (pad columns zero)
+// (scale_word: the bits of the tensor's largest magnitude -- launch_absmax -- instead of the fixed DN_FS: s = fcg_scale_of(*word) brings it
+// into [2^13, 2^14), the consumer divides by s; top-k beyond 64, round 6: no fixed range of the features there)
 __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const float* __restrict__ src,
-                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, RangeTag range) {
+                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, RangeTag range,
+                                  const unsigned* __restrict__ scale_word) {
     const int b = blockIdx.y;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)rows_out * (DSH / 8)) return;
     const int r = (int)(t / (DSH / 8)), c8 = (int)(t % (DSH / 8));
     unsigned short vh[8], vl[8];
+    const float fs = scale_word != nullptr ? fcg_scale_of(*scale_word) : DN_FS;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int c = 8 * c8 + u;
-        const float v = (r < rows && c < D) ? src[((size_t)b * rows_in + r) * DS + c] * DN_FS : 0.f;
+        const float v = (r < rows && c < D) ? src[((size_t)b * rows_in + r) * DS + c] * fs : 0.f;
         if (range.word != nullptr && !(fabsf(v) < RANGE_LIMIT)) *range.word = range.tag;
         const _Float16 h = (_Float16)v;
         vh[u] = __builtin_bit_cast(unsigned short, h);
@@ -852,9 +856,10 @@ __global__ void feat_split_kernel(int rows, int rows_in, int rows_out, const flo
     reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(vl);
 }
 
-int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range) {
+int launch_feat_split(hipStream_t s, int B, int rows, int rows_in, int rows_out, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range,
+                      const unsigned* scale_word) {
     const size_t n8 = (size_t)rows_out * (DSH / 8);
-    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n8 + 255) / 256), B), dim3(256), 0, s, rows, rows_in, rows_out, src, hi, lo, range);
+    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n8 + 255) / 256), B), dim3(256), 0, s, rows, rows_in, rows_out, src, hi, lo, range, scale_word);
     DAGL_LAUNCH_CHECK("feat_split_kernel");
     return DAGL_OK;
 }
@@ -961,9 +966,9 @@ int launch_dense_attend(hipStream_t s, int B, const Grid& g, const float* wq, co
     {
         const size_t nx = (size_t)a.rows_xh * (DSH / 8), nq8 = (size_t)a.rows_qh * (DSH / 8);
         if (!features_split) {
-        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl, range);
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nx + 255) / 256), B), dim3(256), 0, s, g.N, a.rows_x, a.rows_xh, x, xh, xl, range, (const unsigned*)nullptr);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
-        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql, range);
+        hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((nq8 + 255) / 256), B), dim3(256), 0, s, g.L, a.rows_q, a.rows_qh, wq, qh, ql, range, (const unsigned*)nullptr);
         DAGL_LAUNCH_CHECK("feat_split_kernel");
         }
         int rc = launch_split_map(s, (size_t)B * g.Hp * g.Wp * CH, b2p, vh, vl, range);     // 16 v = hi + lo, borders stay zero

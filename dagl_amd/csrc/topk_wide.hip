@@ -434,7 +434,7 @@ size_t topk_wide_workspace_bytes(int N, int L) {
     const size_t ldn = (size_t)(N + 31) / 32 * 32;
     return align_up(R * ldn * sizeof(float), 256) + align_up(R * ROW_CHUNKS * ROW_PART_FLOATS * sizeof(float), 256) +
            align_up(R * 4 * sizeof(int32_t), 256) + align_up(R * WIDE_RANGES * sizeof(int32_t), 256) + align_up(R * sizeof(int32_t), 256) +
-           2 * wide_split_bytes(N) + 2 * wide_split_bytes(L);
+           2 * wide_split_bytes(N) + 2 * wide_split_bytes(L) + 256;
 }
 
 int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const float* wq, const float* x, const float* mt,
@@ -454,7 +454,8 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
     uint16_t* xs_hi = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.N);
     uint16_t* xs_lo = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.N);
     uint16_t* qs_hi = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.L);
-    uint16_t* qs_lo = reinterpret_cast<uint16_t*>(p);
+    uint16_t* qs_lo = reinterpret_cast<uint16_t*>(p); p += wide_split_bytes(g.L);
+    unsigned* amax_words = reinterpret_cast<unsigned*>(p);              // [0] keys, [1] queries: bits of the image's largest feature
     const int rows_q = feat_rows(g.L), rows_x = feat_rows(g.N);
     // scores on the fp16 matrix cores with split operands (round 5; DAGL_WIDE_FP32_SCORES: the fp32 matrix cores as before): the image's
     // features as fp16 pairs, 64 x = hi + lo (dense.hip's copies: rows of 216 halfs, columns 196.. zero), three products per score
@@ -467,9 +468,15 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
     const int rows_xh = feat_rows_h(g.N) + 256, rows_qh = feat_rows_h(g.L) + 256;
     for (int b = 0; b < B; ++b) {
         if (split_scores) {
-            int rc = launch_feat_split(s, 1, g.N, rows_x, rows_xh, x + (size_t)b * rows_x * DS, xs_hi, xs_lo, range);
+            // (round 6) the features' split takes its power of two from the image's largest feature -- two small passes (53 + 3 MB at
+            // 256^2: ~12 us of a 1.3 ms call) -- instead of the fixed 64: finite features of any size are served (a non-finite one still
+            // sets the range word: the scale of an inf / NaN maximum is 1 and the split flags the value)
+            DAGL_HIP_TRY(hipMemsetAsync(amax_words, 0, 2 * sizeof(unsigned), s));
+            int rc = launch_absmax(s, (size_t)g.N * DS, x + (size_t)b * rows_x * DS, amax_words);
             if (rc) return rc;
-            if ((rc = launch_feat_split(s, 1, g.L, rows_q, rows_qh, wq + (size_t)b * rows_q * DS, qs_hi, qs_lo, range))) return rc;
+            if ((rc = launch_absmax(s, (size_t)g.L * DS, wq + (size_t)b * rows_q * DS, amax_words + 1))) return rc;
+            if ((rc = launch_feat_split(s, 1, g.N, rows_x, rows_xh, x + (size_t)b * rows_x * DS, xs_hi, xs_lo, range, amax_words))) return rc;
+            if ((rc = launch_feat_split(s, 1, g.L, rows_q, rows_qh, wq + (size_t)b * rows_q * DS, qs_hi, qs_lo, range, amax_words + 1))) return rc;
         }
         for (int r0 = 0; r0 < g.L; r0 += Rmax) {
             const int R = (g.L - r0 < Rmax) ? g.L - r0 : Rmax;
@@ -479,7 +486,7 @@ int launch_topk_wide(hipStream_t s, int B, const Grid& g, int mode, int k, const
                 gs.M = R; gs.N = g.N; gs.K = 224; gs.k_valid = DSH;
                 gs.a_hi = qs_hi + (size_t)r0 * DSH; gs.a_lo = qs_lo + (size_t)r0 * DSH; gs.lda = DSH; gs.a_rows = rows_qh - r0;
                 gs.b_hi = xs_hi; gs.b_lo = xs_lo; gs.ldb = DSH; gs.b_rows = rows_xh;
-                gs.C = a.scores; gs.ldc = a.ldn; gs.part = nullptr; gs.slices = 1; gs.scale_word = nullptr; gs.alpha0 = 1.0f / (DN_FS * DN_FS);
+                gs.C = a.scores; gs.ldc = a.ldn; gs.part = nullptr; gs.slices = 1; gs.scale_word = amax_words + 1; gs.scale_word_b = amax_words; gs.alpha0 = 1.0f;
                 const int rc = launch_gemm16s(s, gs);
                 if (rc) return rc;
             } else {

@@ -119,3 +119,20 @@ def test_nonfinite_input_is_nan_filled_and_reported():
         with warnings.catch_warnings(record=True):
             warnings.simplefilter("always")
             assert not ce.range_ok()
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0e3])
+def test_topk_beyond_64_neighbours_has_no_fixed_feature_range(scale):
+    """k = 100 (row-wise dense form, csrc/topk_wide.hip): the split-fp16 scores take their power of two from the image's largest
+    feature since round 6 -- an input x 3e3 (features ~1e3 x the fixed scale's limit of 937) is served on the first call."""
+    from oracle.ce_oracle import ce_forward_oracle
+    ce, params, x = _setup("topk", 100, "default", 2.0, scale, hw=(48, 56))
+    with torch.no_grad():
+        out = ce(x.to("cuda:0")).cpu()
+        assert ce.scan == "screened"
+    assert torch.isfinite(out).all()
+    want = ce_forward_oracle(x, params, mode="topk", k=100, dtype=torch.float64).float()
+    e_ref32 = normwise(ce_forward_oracle(x, params, mode="topk", k=100).numpy(), want.numpy())
+    e = normwise(out.numpy(), want.numpy())
+    print(f"[range] top-k 100 x{scale:g}: e_hip {e:.2e} e_ref32 {e_ref32:.2e} path {ce.last_info and ce.last_info.get('path')}")
+    assert e <= max(1e-4, 2.0 * e_ref32 + 1e-5), (e, e_ref32)
