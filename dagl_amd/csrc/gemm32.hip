@@ -108,22 +108,26 @@ struct TileLoader {
 };
 
 // CHUNK: chunked accumulation compiled in (a second set of 64 accumulator registers; without it a third block fits a CU)
-template <bool AKC, bool BKC, bool CHUNK>
-__global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
+// MLOOP: the launch's y extent is shorter than the row tiles and a block walks them (device-side row limit; its own instance: a loop
+// around the tile keeps addresses live across it and spills ~50 registers, which the straight-line instances must not pay)
+template <bool AKC, bool BKC, bool CHUNK, bool MLOOP = false>
+__global__ __launch_bounds__(256, MLOOP ? 2 : (CHUNK ? 3 : 4)) void gemm32_kernel(Gemm32 g, int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][G_BK][G_BM + G_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][G_BK][G_BN + G_PAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+    const int n0 = blockIdx.x * G_BN;
     const long long bz = blockIdx.z;
     if (g.m_limit != nullptr) {                     // row count known on the device only: blocks past it have nothing to do
         int ml = *g.m_limit;
         if (ml <= g.m_limit_floor || ml > g.m_limit_ceil) ml = 0;
-        if (m0 >= ml) return;
         if (ml < g.M) g.M = ml;
     }
-
+    // the grid's y extent may be SHORTER than the row tiles (launch_gemm32 with a device-side row limit: a product that usually has no
+    // or few rows -- the adaptive mode's flagged queries -- used to launch 8192 blocks that looked at the limit and left: 4.9 us);
+    // a block walks its row tiles
+    for (int m0 = blockIdx.y * G_BM; m0 < g.M; m0 += gridDim.y * G_BM) {
     TileLoader<AKC> la{g.A + bz * g.sA, g.lda, g.M, g.K, m0, vecA != 0, {}};
     TileLoader<BKC> lb{g.B + bz * g.sB, g.ldb, g.N, g.K, n0, vecB != 0, {}};
 
@@ -220,6 +224,9 @@ __global__ __launch_bounds__(256, CHUNK ? 3 : 4) void gemm32_kernel(Gemm32 g, in
                 *c = v;
             }
         }
+    if (!MLOOP) break;
+    __syncthreads();                               // (the tile buffers are about to be restaged)
+    }
 }
 
 // C = epilogue(sum over slices, in slice order): the second half of a split-K product
@@ -269,10 +276,14 @@ int launch_gemm32(hipStream_t s, const Gemm32& g_in) {
     }
     const int vecA = ((uintptr_t)g.A % 16 == 0) && (g.lda % 4 == 0) && (g.sA % 4 == 0);
     const int vecB = ((uintptr_t)g.B % 16 == 0) && (g.ldb % 4 == 0) && (g.sB % 4 == 0);
-    const dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM, g.batch), block(256);
+    int tiles_m = (g.M + G_BM - 1) / G_BM;
+    const bool mloop = g.m_limit != nullptr && tiles_m > 2 && g.a_kc && g.b_kc && g.chunk_tiles > 0;   // (the flagged rows' score product)
+    if (mloop) tiles_m = 2;                                        // blocks walk their row tiles: gemm32_kernel<.., MLOOP>
+    const dim3 grid((g.N + G_BN - 1) / G_BN, tiles_m, g.batch), block(256);
 #define G32_LAUNCH(A_, B_) do { if (g.chunk_tiles > 0) hipLaunchKernelGGL((gemm32_kernel<A_, B_, true>), grid, block, 0, s, g, vecA, vecB); \
                                 else hipLaunchKernelGGL((gemm32_kernel<A_, B_, false>), grid, block, 0, s, g, vecA, vecB); } while (0)
-    if (g.a_kc && g.b_kc) G32_LAUNCH(true, true);
+    if (mloop) hipLaunchKernelGGL((gemm32_kernel<true, true, true, true>), grid, block, 0, s, g, vecA, vecB);
+    else if (g.a_kc && g.b_kc) G32_LAUNCH(true, true);
     else if (g.a_kc && !g.b_kc) G32_LAUNCH(true, false);
     else if (!g.a_kc && g.b_kc) G32_LAUNCH(false, true);
     else G32_LAUNCH(false, false);
