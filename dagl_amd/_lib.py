@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 404          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 405          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -80,6 +80,9 @@ SIGNATURES = {
     "dagl_selftest_wave_ops": (_i, [_vp, _vp]),
     "dagl_fc_grad16_scratch_bytes": (_sz, [_i, _i, _i]),
     "dagl_fc_grad16": (_i, [_vp] + [_i] * 8 + [_vp] * 8 + [_sz]),
+    "dagl_fc_grad16_dmap_ok": (_i, [_i, _i]),
+    "dagl_fc_grad16_dmap_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dagl_fc_grad16_dmap": (_i, [_vp] + [_i] * 8 + [_vp] * 8 + [_sz]),
     "dagl_unfold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),
     "dagl_fold_patches": (_i, [_vp] + [_i] * 10 + [_vp, _vp]),
     "dagl_copy4": (_i, [_vp, _i, _i, _i, _i, _vp] + [C.c_longlong] * 4 + [_vp] + [C.c_longlong] * 4),

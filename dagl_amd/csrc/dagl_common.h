@@ -667,6 +667,17 @@ struct Gemm16s {
                                                 // there on are fetched from columns k_valid - 8 .. of the same row instead, which the caller
                                                 // guarantees to be ZERO (feature rows of 216 halfs under a contraction of 224)
     int nt_store = 0;                           // results as streaming stores (set by launch_gemm16s for results beyond the caches)
+    // (round 6) d rows of the stride-1 patch projection folded on the way out (gemm16s.hip fold_tile): with the weight's columns laid out
+    // [kh][kw 8 (7 + a zero pad)][c 16], column tile kh of a row tile of 128 consecutive patches is one kernel ROW of their patches: the block
+    // adds it over kw in the LDS (fixed order) and writes [tile][kh][rows of the tile][seg + 6][16] partial rows instead of 128 x 112 results
+    // -- 61 MB instead of 411 MB at n = 131 072 --, which fcg_fold_kh_kernel adds over kh.  fold_seg = patches of an image row a tile
+    // holds (min(ow, 128)), fold_rows = image rows per tile (128 / fold_seg)
+    float* fold_part = nullptr; int fold_seg = 0, fold_rows = 0;
+    // (round 6) the weight gradient's second operand straight from SHIFTED PLANES of the map instead of the transposed patch rows
+    // (fcg_shift_planes_kernel: planes[kw][c][b Hp + y][x] = 16 map[b, y, x + kw, c], x < W = 2^im_logw; 61 MB instead of 470 MB at
+    // [8, 128, 128]): row n = (kh, kw, c) of B, contraction index k = patch (b, py, px) -> planes[kw][c][b Hp + py + kh][px].  A slice
+    // (K patches) must be whole image rows of ONE image: the block derives (b, py) of its first patch once, no per-lane division
+    int b_implicit = 0, im_logw = 0, im_H = 0, im_Hp = 0; long long im_plane = 0;       // im_plane = B Hp W halfs per (kw, c) plane
     int n_loop = 1;                             // column tiles a block walks one after the other (slices == 1; set by launch_gemm16s): short
                                                 // contractions (d rows of the projections: K = 224 = 7 steps) are one operand pipeline of
                                                 // n_loop x K / 32 steps per block instead of a request latency + 7 steps + 64 KiB of stores

@@ -31,6 +31,11 @@ constexpr int G16_BK = 32;                             // K step: rows of 64 byt
 constexpr int FCG_O = 196, FCG_OP = 224, FCG_OM = 256; // outputs, padded to the K step / to the M tile
 constexpr int FCG_P = 784, FCG_PP = 896;               // patch length, padded to the N tile (7 x 128)
 constexpr float FCG_XS = 16.0f, FCG_WS = 1024.0f;      // activation / weight pre-scaling (project16.hip)
+#ifdef DAGL_FCG_NO_IMPLICIT                            // (A/B builds: the transposed patch rows as up to round 5)
+constexpr bool FCG_NO_IMPLICIT = true;
+#else
+constexpr bool FCG_NO_IMPLICIT = false;
+#endif
 
 // largest |x| of a tensor -> *word (bits of a non-negative float: integer max = float max, order-independent)
 __global__ __launch_bounds__(256) void fcg_absmax_kernel(size_t n4, const float4* __restrict__ x, unsigned* __restrict__ word) {
@@ -127,11 +132,16 @@ __global__ __launch_bounds__(256) void fcg_split_rows_kernel(size_t n, size_t n_
 
 // d Z [n, 196] fp32 -> transposed hi / lo [256][n_pad] halfs (rows 196.. and columns n.. zero).  Block = 128 rows x 32
 // columns of d Z: coalesced 128-byte row reads, transposed in LDS, 256-byte runs written.
+// (round 6) khi / klo non-null: the row-major copy [n_pad][224] of fcg_split_rows_kernel from the same read of d Z (both products of a
+// call want it: one pass over the 103 MB instead of two)
 __global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size_t n_pad, const float* __restrict__ dz,
                                                                   const unsigned* __restrict__ max_word,
-                                                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+                                                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                                  unsigned short* __restrict__ khi, unsigned short* __restrict__ klo) {
     __shared__ __attribute__((aligned(16))) unsigned short th[32][128 + 8];
     __shared__ __attribute__((aligned(16))) unsigned short tl[32][128 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short rh[128][32 + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short rl[128][32 + 8];
     const size_t r0 = (size_t)blockIdx.x * 128;
     const int c0 = blockIdx.y * 32;
     const float s = fcg_scale_of(*max_word);
@@ -145,8 +155,17 @@ __global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size
     for (int u = 0; u < 16; ++u) {
         const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
         g16_split(v[u] * s, th[c][r], tl[c][r]);
+        if (khi != nullptr) { rh[r][c] = th[c][r]; rl[r][c] = tl[c][r]; }
     }
     __syncthreads();
+    if (khi != nullptr && c0 < FCG_OP) {
+        for (int e = threadIdx.x; e < 128 * 4; e += 256) {                    // (row, octet of columns)
+            const int r = e >> 2, c8 = e & 3;
+            const size_t o = ((r0 + r) * FCG_OP + c0) / 8 + c8;
+            reinterpret_cast<uint4*>(khi)[o] = *reinterpret_cast<const uint4*>(&rh[r][8 * c8]);
+            reinterpret_cast<uint4*>(klo)[o] = *reinterpret_cast<const uint4*>(&rl[r][8 * c8]);
+        }
+    }
     for (int e = threadIdx.x; e < 32 * 16; e += 256) {                        // (column, octet of rows)
         const int c = e >> 4, r8 = e & 15;
         const size_t o = ((size_t)(c0 + c) * n_pad + r0) / 8 + r8;
@@ -189,12 +208,75 @@ __global__ __launch_bounds__(256) void fcg_unfold_transpose_kernel(int Hp, int W
 }
 
 // W [196][784] -> transposed hi / lo [896][224] halfs, 1024 w = hi + lo, pads zero
-__global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+// (fold_layout: row kk = kh * 128 + kw * 16 + c, kw = 7 a zero pad -- every 128-row tile one kernel row: Gemm16s::fold_part)
+__global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                            int fold_layout) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= FCG_PP * FCG_OP) return;
     const int kk = t / FCG_OP, o = t - kk * FCG_OP;
-    const float v = (kk < FCG_P && o < FCG_O) ? w[(size_t)o * FCG_P + kk] * FCG_WS : 0.f;
+    int src = kk;
+    if (fold_layout) {
+        const int kh = kk >> 7, kw = (kk >> 4) & 7, c = kk & 15;
+        src = (kw < KS) ? (kh * KS + kw) * CH + c : FCG_P;
+    }
+    const float v = (src < FCG_P && o < FCG_O) ? w[(size_t)o * FCG_P + src] * FCG_WS : 0.f;
     g16_split(v, hi[t], lo[t]);
+}
+
+// d map[b, y, x, :] = sum over kh (then the row segments that cover x) of the partial rows gemm16s_kernel's fold_tile wrote; thread = one
+// float4 of a map pixel.  Stride-1 patches: patch (py, px) covers map rows oy + py + kh, columns ox + px + kw.
+__global__ __launch_bounds__(256) void fcg_fold_kh_kernel(int Hp, int Wp, int oy, int ox, int oh, int ow, int seg, int rows_per_tile,
+                                                          const float4* __restrict__ part, float4* __restrict__ dmap) {
+    const int b = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Hp * Wp * 4) return;
+    const int pix = (int)(t >> 2), c4 = (int)(t & 3);
+    const int y = pix / Wp, x = pix - y * Wp;
+    const int tx = x - ox;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int segw = seg + KS - 1;
+    if (tx >= 0 && tx < ow + KS - 1) {
+        for (int kh = 0; kh < KS; ++kh) {
+            const int ty = y - oy - kh;
+            if (ty < 0 || ty >= oh) continue;
+            const size_t p0 = ((size_t)b * oh + ty) * ow;                   // first patch of that image row
+            for (int s0 = 0; s0 < ow; s0 += seg) {
+                const int xs = tx - s0;
+                if (xs < 0 || xs >= segw) continue;
+                const size_t tile = (p0 + s0) >> 7;
+                const int ry = (int)(((p0 + s0) & 127) / seg);
+                const float4 v = part[((((tile * KS + kh) * rows_per_tile + ry) * segw + xs) << 2) + c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    dmap[((size_t)b * Hp * Wp + pix) * 4 + c4] = acc;
+}
+
+// planes[kw][c][b Hp + y][x] = 16 map[b, y, x + kw, c] as fp16 hi / lo, x < W (Gemm16s::b_implicit).  Block = one row (b, y) of the map in
+// the LDS (Wp pixels x 16 channels); thread = (plane (kw, c), octet of x): 16-byte stores, runs of 2 W bytes per plane
+__global__ __launch_bounds__(256) void fcg_shift_planes_kernel(int Hp, int Wp, int W, long long plane, const float* __restrict__ map,
+                                                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    extern __shared__ float row_s[];                                             // [Wp][16 + 1]
+    const int by = blockIdx.x;                                                   // b Hp + y
+    const float4* src = reinterpret_cast<const float4*>(map + (size_t)by * Wp * CH);
+    for (int e = threadIdx.x; e < Wp * 4; e += 256) {
+        const float4 v = src[e];
+        float* d = row_s + (e >> 2) * 17 + 4 * (e & 3);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int octs = W / 8;
+    for (int e = threadIdx.x; e < KS * CH * octs; e += 256) {
+        const int pl = e / octs, o8 = e - pl * octs;                            // plane = kw * 16 + c
+        const int kw = pl >> 4, c = pl & 15;
+        unsigned short vh[8], vl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g16_split(row_s[(8 * o8 + u + kw) * 17 + c] * FCG_XS, vh[u], vl[u]);
+        const size_t o = ((size_t)pl * plane + (size_t)by * W) / 8 + o8;
+        reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(vh);
+        reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(vl);
+    }
 }
 
 // C[m][n] = sum_k A[m][k] B[n][k]; block = (64 WM) x (64 WN) outputs by WM x WN waves of 64 x 64, grid.z = K slices.
@@ -202,7 +284,7 @@ __global__ void fcg_weight_transpose_kernel(const float* __restrict__ w, unsigne
 // fp16 GEMM): 256 x 128 tiles fetch 3/4 of the bytes per product of 128 x 128 ones.
 // NS = stages of the operand ring: 2 = the tile of step t + 1 is requested at the start of step t and awaited at its end (a step is
 // ~0.7 us of multiplies per SIMD: less than the request's latency); 3 = two steps ahead, awaited with a counted vmcnt.
-template <int WM, int WN, int NS = 2>
+template <int WM, int WN, int NS = 2, bool IMPL = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) void gemm16s_kernel(Gemm16s g) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
     constexpr int PA = BM * 64, PB = BN * 64;                                     // bytes of one part (hi or lo) of an operand tile
@@ -230,6 +312,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     const int wm = wave / WN, wn = wave % WN;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
+    // (IMPL) first patch of the slice -> its row in the planes: b Hp + py  (one scalar division per block)
+    int im_row0 = 0;
+    if (IMPL) {
+        const long long r0 = k0 >> g.im_logw;                                      // image row index b H + py of the slice's first patch
+        const int ib = (int)(r0 / g.im_H);
+        im_row0 = ib * g.im_Hp + (int)(r0 - (long long)ib * g.im_H);
+    }
     // LDS-DMA: a piece = 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 holds logical slot (l & 3) ^ ((row >> 2) & 3)
     const int prow = lane >> 2, pslot = (lane & 3) ^ ((prow >> 2) & 3);
     auto stage = [&](int buf, int nt, long long k) {        // operand tiles of column tile nt of this block, contraction offset k
@@ -249,8 +338,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
             if (row > lim) row = lim;
             long long kc = k + 8 * pslot;                                         // (k_valid: the piece past the row's end reads the row's zero columns)
             if (g.k_valid > 0 && kc - k0 >= g.k_valid) kc = k0 + g.k_valid - 8;
-            glds16_asm(reinterpret_cast<const float*>(base + boff + (long long)row * ld + kc),
-                       __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
+            const unsigned short* src = base + boff + (long long)row * ld + kc;
+            if (IMPL && !is_a) {
+                // B row n = (kh, kw, c), contraction index = patch (b, py, px): the shifted plane (kw, c), map row b Hp + py + kh, column px
+                const int tap = row >> 4, c = row & 15;
+                const int kh = (tap * 37) >> 8, kw = tap - KS * kh;                // (tap / 7 for tap < 49 .. 55)
+                const int kl = (int)(kc - k0);                                     // inside the slice: whole image rows of image im_b
+                const int px = kl & ((1 << g.im_logw) - 1), dy = kl >> g.im_logw;
+                src = base + (long long)(kw * CH + c) * g.im_plane + ((long long)(im_row0 + dy + kh) << g.im_logw) + px;
+            }
+            glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
         }
     };
     f32x16 acc[2][2];
@@ -274,6 +371,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     // step's barrier: two passes of 32 rows, 8.5 KiB per wave) and leaves as whole 256-byte row segments, four rows per instruction.
     constexpr int SPITCH = 68;                                                    // floats per staged row (64 + 4: rows 8 apart share a bank)
     static_assert(NW * 32 * SPITCH * 4 <= NS * STAGE, "the result staging must fit the operand ring");
+    static_assert(BM != 128 || BN != 128 || 128 * 116 * 4 <= NS * STAGE, "the fold's staged tile must fit the operand ring");
     auto store_tile = [&](int nt) {
         float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SPITCH);       // 32 rows x 64 columns at a time (the wave's upper / lower half)
         const int nw = n0 + nt * BN + wn * 64;
@@ -310,6 +408,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
                         else *dstp = v;
                     }
             }
+        }
+    };
+    // (Gemm16s::fold_part) column tile nt = kernel row kh of the block's 128 patches: the tile through the LDS (112 real columns at a pitch of
+    // 116 floats: 58 KiB of the dead operand ring), then every thread adds its outputs over kw in a fixed order
+    constexpr int FPITCH = 116;
+    auto fold_tile = [&](int nt) {
+        float* T = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = wn * 64 + b * 32 + 8 * q + 4 * h;
+                    if (col < KS * CH)
+                        *reinterpret_cast<float4*>(T + (wm * 64 + a * 32 + i) * FPITCH + col) =
+                            make_float4(acc[a][b][4 * q] * alpha, acc[a][b][4 * q + 1] * alpha, acc[a][b][4 * q + 2] * alpha,
+                                        acc[a][b][4 * q + 3] * alpha);
+                }
+        __syncthreads();
+        const int segw = g.fold_seg + KS - 1;
+        const int items = g.fold_rows * segw * 4;
+        float4* dst = reinterpret_cast<float4*>(g.fold_part) + ((size_t)by * KS + (bx * nl + nt)) * (size_t)items;     // (column tile = kernel row kh)
+        for (int e = tid; e < items; e += 64 * NW) {
+            const int c4 = e & 3, rx = e >> 2;
+            const int ry = rx / segw, xs = rx - ry * segw;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int px = xs - kw;
+                if (px >= 0 && px < g.fold_seg) {
+                    const float4 v = *reinterpret_cast<const float4*>(T + (ry * g.fold_seg + px) * FPITCH + kw * CH + 4 * c4);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+            }
+            dst[e] = sum;
         }
     };
     const int swz = (i >> 2) & 3;
@@ -364,7 +498,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
             cur = (cur + 1 == NS) ? 0 : cur + 1;
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
-        store_tile(ntile);
+        if (BM == 128 && BN == 128 && g.fold_part != nullptr) fold_tile(ntile);
+        else store_tile(ntile);
     }
 }
 
@@ -396,9 +531,10 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
     const bool small_m = g.M <= 256 && g.slices > 1;
     Gemm16s gl = g;
     gl.nt_store = (size_t)nb * (size_t)(g.slices > 1 ? g.slices : 1) * (size_t)g.M * (size_t)g.N * sizeof(float) >= ((size_t)64 << 20);
-    if (small_m || (g.K >= 512 && g.M >= 1024)) {
+    if (!g.fold_part && (small_m || (g.K >= 512 && g.M >= 1024))) {
         dim3 grid((g.N + 127) / 128, (g.M + 255) / 256, g.slices * nb);
-        hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, gl);
+        if (g.b_implicit) hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3, true>), grid, dim3(512), 0, s, gl);
+        else hipLaunchKernelGGL((gemm16s_kernel<4, 2, 3>), grid, dim3(512), 0, s, gl);
     } else {
         // short contraction, many column tiles (d rows of the patch projections: K = 224, N = 784): a block walks ALL column tiles of
         // its row tile -- one pipeline of 49 steps instead of seven blocks of 7 (each: request latency, 7 steps, 64 KiB of stores)
@@ -429,15 +565,36 @@ int launch_gemm16s(hipStream_t s, const Gemm16s& g) {
 struct FcgPlan {
     size_t n, n_pad;                  // patches of the batch, rounded up to the K granule of the weight gradient
     int slices; size_t k_slice;       // split-K of d W
-    size_t o_word, o_zk_hi, o_zk_lo, o_zt_hi, o_zt_lo, o_rt_hi, o_rt_lo, o_wt_hi, o_wt_lo, o_part, o_dz, o_csum, o_end;
+    size_t o_word, o_zk_hi, o_zk_lo, o_zt_hi, o_zt_lo, o_rt_hi, o_rt_lo, o_wt_hi, o_wt_lo, o_part, o_dz, o_csum, o_fold, o_end;
+    int fold_seg, fold_rows;          // > 0: d rows can be folded on the way out (fcg_fold_ok)
+    int im_rps;                       // > 0: the weight gradient reads shifted planes of the map (Gemm16s::b_implicit): image rows per K slice
     int stat_blocks;
 };
 
 static size_t fcg_carve(size_t& off, size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; }
 
-static FcgPlan fcg_plan(size_t n) {
+// d rows folded inside the product (Gemm16s::fold_part): stride-1 patches whose row tiles of 128 hold whole image rows or one 128-patch
+// segment of a row
+static bool fcg_fold_ok(int stride, int ow) { return stride == 1 && ow >= 16 && ((ow % 128) == 0 || (128 % ow) == 0); }
+
+// The weight gradient from shifted planes (Gemm16s::b_implicit): stride-1 patches from the map's corner, rows a power of two >= 32 patches
+// wide, and a divisor of the image height as the rows of a K slice (a slice = whole rows of one image)
+static int fcg_implicit_rows(int B, int stride, int oy, int ox, int oh, int ow, int Hp, int Wp) {
+    if (stride != 1 || oy != 0 || ox != 0 || ow < 32 || (ow & (ow - 1)) != 0 || Hp != oh + KS - 1 || Wp != ow + KS - 1) return 0;
+    if (((size_t)B * oh * ow) % 128 != 0) return 0;
+    const double want = (double)B * oh / 36.0;                 // ~36 slices x 7 column tiles fill the chip with one block per CU
+    int best = 0;
+    for (int r = 1; r <= oh; ++r)
+        if (oh % r == 0 && (long long)r * ow >= 256 && (best == 0 || (r <= want * 1.5 && r > best))) best = r;
+    return best;
+}
+
+static FcgPlan fcg_plan(size_t n, int ow_fold = 0, int im_rps = 0, int im_ow = 0) {
     FcgPlan p;
     p.n = n;
+    p.im_rps = im_rps;
+    p.fold_seg = ow_fold > 0 ? (ow_fold < 128 ? ow_fold : 128) : 0;
+    p.fold_rows = p.fold_seg > 0 ? 128 / p.fold_seg : 0;
     // d W has 1 x 7 output tiles of 256 x 128: K slices fill the chip (one block per CU: 7 x 36 = 252 blocks), each a multiple
     // of the 32-deep K step
     int slices = 36;
@@ -446,6 +603,7 @@ static FcgPlan fcg_plan(size_t n) {
     if (ks < 256) { ks = 256; }
     slices = (int)((n + ks - 1) / ks);
     if (slices < 1) slices = 1;
+    if (im_rps > 0) { ks = (size_t)im_rps * im_ow; slices = (int)(n / ks); }      // (whole image rows: n = slices * ks exactly)
     p.slices = slices; p.k_slice = ks; p.n_pad = (size_t)slices * ks;
     if (p.n_pad % 128) p.n_pad = (p.n_pad + 127) / 128 * 128;          // (the transposing producers work in tiles of 128 patches)
     size_t off = 0;
@@ -458,6 +616,9 @@ static FcgPlan fcg_plan(size_t n) {
     p.o_dz = fcg_carve(off, n * FCG_O * sizeof(float));
     p.stat_blocks = (int)((n + FCG_SROWS - 1) / FCG_SROWS);
     p.o_csum = fcg_carve(off, (size_t)p.stat_blocks * FCG_O * sizeof(double));
+    p.o_fold = off;
+    if (p.fold_seg > 0)       // [row tiles][7 kh][rows of a tile][seg + 6][16] partial rows
+        p.o_fold = fcg_carve(off, (p.n_pad / 128) * KS * (size_t)p.fold_rows * (p.fold_seg + KS - 1) * CH * sizeof(float));
     p.o_end = off;
     return p;
 }
@@ -470,20 +631,39 @@ extern "C" {
 
 size_t dagl_fc_grad16_scratch_bytes(int B, int oh, int ow) {
     if (B < 1 || oh < 1 || ow < 1) return 0;
-    return fcg_plan((size_t)B * oh * ow).o_end;
+    // (the larger of the two layouts the call may choose: K slices of whole image rows -- shifted planes -- or of ~n / 36 patches)
+    const size_t a = fcg_plan((size_t)B * oh * ow).o_end;
+    const int rps = fcg_implicit_rows(B, 1, 0, 0, oh, ow, oh + KS - 1, ow + KS - 1);
+    const size_t b = rps ? fcg_plan((size_t)B * oh * ow, 0, rps, ow).o_end : 0;
+    return a > b ? a : b;
 }
 
-int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
-                   const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, void* scratch,
-                   size_t scratch_bytes) {
+// (ABI 405) the same call with the gradient of the MAP as its output instead of the patch rows' (dagl_fc_grad16 + dagl_fold_patches in one):
+// stride-1 projections whose rows are 16 / 32 / 64 or a multiple of 128 patches wide fold the rows inside the product
+// (Gemm16s::fold_part: [n, 784] rows -- 411 MB at n = 131 072 -- are never written); dagl_fc_grad16_dmap_ok tells whether a geometry qualifies
+int dagl_fc_grad16_dmap_ok(int stride, int ow) { return fcg_fold_ok(stride, ow) ? 1 : 0; }
+size_t dagl_fc_grad16_dmap_scratch_bytes(int B, int oh, int ow) {
+    if (B < 1 || oh < 1 || ow < 1 || !fcg_fold_ok(1, ow)) return 0;
+    const size_t a = fcg_plan((size_t)B * oh * ow, ow).o_end;
+    const int rps = fcg_implicit_rows(B, 1, 0, 0, oh, ow, oh + KS - 1, ow + KS - 1);
+    const size_t b = rps ? fcg_plan((size_t)B * oh * ow, ow, rps, ow).o_end : 0;
+    return a > b ? a : b;
+}
+
+static int fc_grad16_impl(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
+                          const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, float* d_map,
+                          void* scratch, size_t scratch_bytes) {
     DAGL_REQUIRE(B >= 1 && Hp >= 1 && Wp >= 1 && stride >= 1 && oy >= 0 && ox >= 0 && oh >= 1 && ow >= 1 &&
-                 oy + (oh - 1) * stride + KS <= Hp && ox + (ow - 1) * stride + KS <= Wp && dy && scratch && (d_w || d_rows || d_b),
+                 oy + (oh - 1) * stride + KS <= Hp && ox + (ow - 1) * stride + KS <= Wp && dy && scratch && (d_w || d_rows || d_b || d_map),
                  "dagl_fc_grad16: bad argument");
-    DAGL_REQUIRE((!d_w || map_nhwc) && (!d_rows || w_rows), "dagl_fc_grad16: d_w needs the map, d_rows the weight");
+    DAGL_REQUIRE((!d_w || map_nhwc) && ((!d_rows && !d_map) || w_rows), "dagl_fc_grad16: d_w needs the map, d_rows / d_map the weight");
+    DAGL_REQUIRE(!(d_rows && d_map), "dagl_fc_grad16: d_rows or d_map, not both");
+    DAGL_REQUIRE(!d_map || fcg_fold_ok(stride, ow), "dagl_fc_grad16_dmap: stride %d, %d patches per row: not a geometry the product can fold", stride, ow);
     DAGL_REQUIRE(((uintptr_t)scratch % 256) == 0, "dagl_fc_grad16: scratch must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * oh * ow;
-    const FcgPlan p = fcg_plan(n);
+    const int im_rps = (d_w && !FCG_NO_IMPLICIT) ? fcg_implicit_rows(B, stride, oy, ox, oh, ow, Hp, Wp) : 0;
+    const FcgPlan p = fcg_plan(n, d_map ? ow : 0, im_rps, ow);
     DAGL_REQUIRE(scratch_bytes >= p.o_end, "dagl_fc_grad16: scratch %zu B, need %zu B", scratch_bytes, p.o_end);
     char* ws = static_cast<char*>(scratch);
     unsigned* word = reinterpret_cast<unsigned*>(ws + p.o_word);
@@ -498,29 +678,58 @@ int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int 
         DAGL_LAUNCH_CHECK("fcg_relu_stats_kernel");
         if (d_b) { const int rc = launch_col_sum_final(s, p.stat_blocks, FCG_O, csum, d_b); if (rc) return rc; }
     }
-    if (d_rows) {
+    const bool merged_split = (d_rows || d_map) && d_w;          // one pass over d Z writes both of its split copies
+    if (merged_split) {
+        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, dz,
+                           word, H(p.o_zt_hi), H(p.o_zt_lo), H(p.o_zk_hi), H(p.o_zk_lo));
+        DAGL_LAUNCH_CHECK("fcg_split_transpose_kernel");
+    }
+    if (d_rows || d_map) {
         const size_t items = p.n_pad * (FCG_OP / 8);
+        if (!merged_split) {
         hipLaunchKernelGGL(fcg_split_rows_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, n, p.n_pad, dz, word,
                            H(p.o_zk_hi), H(p.o_zk_lo));
         DAGL_LAUNCH_CHECK("fcg_split_rows_kernel");
+        }
         hipLaunchKernelGGL(fcg_weight_transpose_kernel, dim3((FCG_PP * FCG_OP + 255) / 256), dim3(256), 0, s, w_rows, H(p.o_wt_hi),
-                           H(p.o_wt_lo));
+                           H(p.o_wt_lo), d_map ? 1 : 0);
         DAGL_LAUNCH_CHECK("fcg_weight_transpose_kernel");
         Gemm16s g;
-        g.M = (int)n; g.N = FCG_P; g.K = FCG_OP;
+        g.M = (int)n; g.N = d_map ? FCG_PP : FCG_P; g.K = FCG_OP;
         g.a_hi = H(p.o_zk_hi); g.a_lo = H(p.o_zk_lo); g.lda = FCG_OP; g.a_rows = (int)p.n_pad;
         g.b_hi = H(p.o_wt_hi); g.b_lo = H(p.o_wt_lo); g.ldb = FCG_OP; g.b_rows = FCG_PP;
-        g.C = d_rows; g.ldc = FCG_P; g.part = nullptr; g.slices = 1; g.scale_word = word; g.alpha0 = 1.0f / FCG_WS;
+        g.C = d_map ? reinterpret_cast<float*>(ws + p.o_fold) : d_rows;
+        g.ldc = FCG_P; g.part = nullptr; g.slices = 1; g.scale_word = word; g.alpha0 = 1.0f / FCG_WS;
+        if (d_map) { g.fold_part = reinterpret_cast<float*>(ws + p.o_fold); g.fold_seg = p.fold_seg; g.fold_rows = p.fold_rows; }
         const int rc = launch_gemm16s(s, g);
         if (rc) return rc;
+        if (d_map) {
+            const size_t nt = (size_t)Hp * Wp * 4;
+            hipLaunchKernelGGL(fcg_fold_kh_kernel, dim3((unsigned)((nt + 255) / 256), B), dim3(256), 0, s, Hp, Wp, oy, ox, oh, ow, p.fold_seg,
+                               p.fold_rows, reinterpret_cast<const float4*>(ws + p.o_fold), reinterpret_cast<float4*>(d_map));
+            DAGL_LAUNCH_CHECK("fcg_fold_kh_kernel");
+        }
     }
     if (d_w) {
+        if (!merged_split) {
         hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, dz,
-                           word, H(p.o_zt_hi), H(p.o_zt_lo));
+                           word, H(p.o_zt_hi), H(p.o_zt_lo), (unsigned short*)nullptr, (unsigned short*)nullptr);
         DAGL_LAUNCH_CHECK("fcg_split_transpose_kernel");
+        }
+        int logw = 0;
+        while ((1 << logw) < ow) ++logw;
+        const long long plane = (long long)B * Hp * ow;
+        if (p.im_rps > 0) {
+            // (round 6) no transposed patch rows (470 MB at [8, 128, 128]): seven shifted copies of the map's planes (61 MB), which the
+            // product addresses by (kw, c, row + kh, px)
+            hipLaunchKernelGGL(fcg_shift_planes_kernel, dim3((unsigned)(B * Hp)), dim3(256), (size_t)Wp * 17 * sizeof(float), s, Hp, Wp, ow, plane,
+                               map_nhwc, H(p.o_rt_hi), H(p.o_rt_lo));
+            DAGL_LAUNCH_CHECK("fcg_shift_planes_kernel");
+        } else {
         hipLaunchKernelGGL(fcg_unfold_transpose_kernel, dim3((unsigned)(p.n_pad / 128), KS * KS), dim3(256), 0, s, Hp, Wp, stride, oy,
                            ox, oh, ow, n, p.n_pad, map_nhwc, H(p.o_rt_hi), H(p.o_rt_lo));
         DAGL_LAUNCH_CHECK("fcg_unfold_transpose_kernel");
+        }
         // (rows 784..895 of the last N tile do not exist: its loads are clamped to row 783, their products are never stored)
         Gemm16s g;
         g.M = FCG_O; g.N = FCG_P; g.K = (int)p.k_slice;
@@ -528,10 +737,23 @@ int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int 
         g.b_hi = H(p.o_rt_hi); g.b_lo = H(p.o_rt_lo); g.ldb = (long long)p.n_pad; g.b_rows = FCG_P;
         g.C = d_w; g.ldc = FCG_P; g.part = reinterpret_cast<float*>(ws + p.o_part); g.slices = p.slices; g.scale_word = word;
         g.alpha0 = 1.0f / FCG_XS;
+        if (p.im_rps > 0) { g.b_implicit = 1; g.im_logw = logw; g.im_H = oh; g.im_Hp = Hp; g.im_plane = plane; }
         const int rc = launch_gemm16s(s, g);
         if (rc) return rc;
     }
     return DAGL_OK;
+}
+
+int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
+                   const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, void* scratch,
+                   size_t scratch_bytes) {
+    return fc_grad16_impl(stream, B, Hp, Wp, stride, oy, ox, oh, ow, map_nhwc, w_rows, y, dy, d_w, d_b, d_rows, nullptr, scratch, scratch_bytes);
+}
+
+int dagl_fc_grad16_dmap(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
+                        const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_map, void* scratch,
+                        size_t scratch_bytes) {
+    return fc_grad16_impl(stream, B, Hp, Wp, stride, oy, ox, oh, ow, map_nhwc, w_rows, y, dy, d_w, d_b, nullptr, d_map, scratch, scratch_bytes);
 }
 
 }  // extern "C"

@@ -62,6 +62,7 @@ def to_padded_nhwc(x, H, W, from_rows=False):
 
 FAST_FC_FORWARD = True          # forward of the two patch projections on the split-fp16 inference kernels (tests flip it)
 FAST_FC_BACKWARD = True         # their two gradient products on the split-fp16 GEMM (gemm16s.hip; tests flip it)
+FOLD_IN_PRODUCT = True          # ... with d rows of the stride-1 projection folded inside the product (dagl_fc_grad16_dmap; tests flip it)
 
 
 def _fc_grid(k, C, O, relu, stride, oy, ox, oh, ow, H, W):
@@ -129,11 +130,22 @@ def _patch_linear_backward(pmap, weight, y, geom, d_y, need_map, need_w, need_b,
         d_w = d_b = d_map = None
         if fast and (need_w or need_map):
             # one call: ReLU backward, the split's scale and d bias in one pass over d y, then the two split-fp16 products
+            d_w = torch.empty(O, K, device=pmap.device, dtype=torch.float32) if need_w else None
+            d_b = torch.empty(O, device=pmap.device, dtype=torch.float32) if need_b else None
+            if need_map and FOLD_IN_PRODUCT and lib.dagl_fc_grad16_dmap_ok(stride, ow):
+                # round 6: the key projection (stride 1) folds d rows inside the product -- the [n, 784] rows (411 MB at n = 131 072) are
+                # neither written nor read back (dagl_fc_grad16_dmap, gemm16s.hip fold_tile)
+                need = lib.dagl_fc_grad16_dmap_scratch_bytes(B, oh, ow)
+                scratch = torch.empty(need + 256, device=pmap.device, dtype=torch.uint8)
+                base = (scratch.data_ptr() + 255) // 256 * 256
+                d_map = torch.empty_like(pmap)
+                check(lib.dagl_fc_grad16_dmap(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pmap.data_ptr(), weight.data_ptr(),
+                                              y.data_ptr() if relu else None, dz.data_ptr(), d_w.data_ptr() if need_w else None,
+                                              d_b.data_ptr() if need_b else None, d_map.data_ptr(), base, need), "dagl_fc_grad16_dmap")
+                return d_map, d_w, d_b
             need = lib.dagl_fc_grad16_scratch_bytes(B, oh, ow)
             scratch = torch.empty(need + 256, device=pmap.device, dtype=torch.uint8)
             base = (scratch.data_ptr() + 255) // 256 * 256
-            d_w = torch.empty(O, K, device=pmap.device, dtype=torch.float32) if need_w else None
-            d_b = torch.empty(O, device=pmap.device, dtype=torch.float32) if need_b else None
             d_rows = torch.empty(n, K, device=pmap.device, dtype=torch.float32) if need_map else None
             check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, stride, oy, ox, oh, ow, pmap.data_ptr(), weight.data_ptr(),
                                      y.data_ptr() if relu else None, dz.data_ptr(), d_w.data_ptr() if need_w else None,

@@ -167,9 +167,9 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
 /* ABI version of THIS header: bumped whenever a struct or a signature declared here changes (round 3: dagl_ce_info is 40
  * bytes, dagl_ce_prologue takes `scratch`, dagl_ce_core_dense_forward takes `flags`, k <= 64; round 4: DAGL_FLAG_SAMPLED_TOPK,
  * the workspace layout carries the top-k policy words; 403: dagl_ce_core_wide_forward / _backward; 404:
- * dagl_ce_info.dense_rerun_blocks in the place of `reserved`).  A caller compares
+ * dagl_ce_info.dense_rerun_blocks in the place of `reserved`; 405: dagl_fc_grad16_dmap).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 404
+#define DAGL_ABI_VERSION 405
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
@@ -399,6 +399,16 @@ size_t dagl_fc_grad16_scratch_bytes(int B, int oh, int ow);
 int dagl_fc_grad16(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
                    const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_rows, void* scratch,
                    size_t scratch_bytes);
+/* (ABI 405) The same with the gradient of the MAP as its output: d_map [B,Hp,Wp,16] = fold(d_rows) as dagl_fold_patches computes it
+ * (autograd through `fc(unfold(map))`, dagl.py:240-249), the rows folded inside the product -- over kw in the block's LDS, over kh by a
+ * light second kernel, every sum in a fixed order -- so that the [n, 784] fp32 rows (411 MB at n = 131 072) are neither written nor read
+ * back.  Geometries: dagl_fc_grad16_dmap_ok(stride, ow) (stride 1 and 16 / 32 / 64 or a multiple of 128 patches per row); others:
+ * dagl_fc_grad16 + dagl_fold_patches.                                                                                          */
+int    dagl_fc_grad16_dmap_ok(int stride, int ow);
+size_t dagl_fc_grad16_dmap_scratch_bytes(int B, int oh, int ow);
+int dagl_fc_grad16_dmap(void* stream, int B, int Hp, int Wp, int stride, int oy, int ox, int oh, int ow, const float* map_nhwc,
+                        const float* w_rows, const float* y, const float* dy, float* d_w, float* d_b, float* d_map, void* scratch,
+                        size_t scratch_bytes);
 
 /* Backward of the first two convolutions of the block (g 3x3 and theta 1x1, 64 -> 16: dagl.py:208-209 under loss.backward(),
  * DN_Gray/trainer.py:48-57) straight on the maps -- no patch rows (conv_grad.hip): tap-wise products on the fp32 matrix cores,

@@ -140,6 +140,57 @@ def test_fc_grad16_matches_fp64(B, H, W, stride, scale):
     assert e_w <= 5e-6 and e_r <= 5e-6
 
 
+@pytest.mark.parametrize("B,H,W,scale", [(8, 128, 128, 1e-4), (3, 40, 64, 1.0), (2, 24, 32, 1.0), (1, 16, 256, 1e3), (5, 33, 16, 1.0)])
+def test_fc_grad16_dmap_folds_the_rows_inside_the_product(B, H, W, scale):
+    """``dagl_fc_grad16_dmap`` (round 6): d map = fold(d Z W) of the stride-1 projection with the [n, 784] rows folded inside the product
+    (over kw in the block's LDS, over kh by a second kernel) -- against fp64, against ``dagl_fc_grad16`` + ``dagl_fold_patches``, bit-equal
+    across calls; widths of 16 / 32 / 64 patches (several image rows per row tile), 128 and 256 (two segments per row), the BASELINE
+    config-5 size; a width the product cannot fold says so."""
+    from dagl_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    Hp, Wp = H + 6, W + 6
+    pmap = torch.zeros(B, Hp, Wp, 16)
+    pmap[:, 3:3 + H, 3:3 + W] = torch.randn(B, H, W, 16, generator=g)
+    n = B * H * W
+    w = (torch.rand(196, 784, generator=g) - 0.5) * 0.07
+    dy = torch.randn(n, 196, generator=g) * scale * torch.rand(n, 1, generator=g) ** 4
+    y = torch.randn(n, 196, generator=g)
+    dz = dy * (y > 0)
+    assert lib.dagl_fc_grad16_dmap_ok(1, W) == 1 and lib.dagl_fc_grad16_dmap_ok(1, 72) == 0 and lib.dagl_fc_grad16_dmap_ok(4, W) == 0
+    pm, wd, dyd, yd = pmap.to(dev), w.to(dev), dy.to(dev), y.to(dev)
+    need = lib.dagl_fc_grad16_dmap_scratch_bytes(B, H, W)
+    scratch = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    outs = []
+    for rep in range(2):
+        d_w = torch.empty(196, 784, device=dev); d_b = torch.empty(196, device=dev); d_map = torch.full((B, Hp, Wp, 16), float("nan"), device=dev)
+        _lib.check(lib.dagl_fc_grad16_dmap(ops._stream(), B, Hp, Wp, 1, 0, 0, H, W, pm.data_ptr(), wd.data_ptr(), yd.data_ptr(), dyd.data_ptr(),
+                                           d_w.data_ptr(), d_b.data_ptr(), d_map.data_ptr(), base, need), "dagl_fc_grad16_dmap")
+        outs.append((d_map.cpu(), d_w.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the unfused pair on the library
+    need2 = lib.dagl_fc_grad16_scratch_bytes(B, H, W)
+    scratch2 = torch.empty(need2 + 256, device=dev, dtype=torch.uint8)
+    base2 = (scratch2.data_ptr() + 255) // 256 * 256
+    d_rows = torch.empty(n, 784, device=dev); d_w2 = torch.empty(196, 784, device=dev); d_map2 = torch.empty(B, Hp, Wp, 16, device=dev)
+    _lib.check(lib.dagl_fc_grad16(ops._stream(), B, Hp, Wp, 1, 0, 0, H, W, pm.data_ptr(), wd.data_ptr(), yd.data_ptr(), dyd.data_ptr(),
+                                  d_w2.data_ptr(), None, d_rows.data_ptr(), base2, need2), "dagl_fc_grad16")
+    _lib.check(lib.dagl_fold_patches(ops._stream(), B, Hp, Wp, 16, 7, 1, 0, 0, H, W, d_rows.data_ptr(), d_map2.data_ptr()), "dagl_fold_patches")
+    assert torch.equal(outs[0][1], d_w2.cpu())                                   # (d W does not know about the fold)
+    # fp64: d map = fold(d z W)
+    rows64 = (dz.double() @ w.double()).view(B, H, W, 7, 7, 16)
+    want = torch.zeros(B, Hp, Wp, 16, dtype=torch.float64)
+    for kh in range(7):
+        for kw in range(7):
+            want[:, kh:kh + H, kw:kw + W, :] += rows64[:, :, :, kh, kw, :]
+    e = normwise(outs[0][0].numpy(), want.numpy())
+    e2 = normwise(d_map2.cpu().numpy(), want.numpy())
+    print(f"[parity] fc_grad16_dmap B={B} {H}x{W} |dz|~{scale:g}: folded in the product {e:.2e}, rows + fold {e2:.2e} (normwise vs fp64)")
+    assert torch.isfinite(outs[0][0]).all() and e <= 5e-6
+
+
 def test_projection_backward_fast_path_equals_the_fp32_gemm_path():
     """CE's fc2 layer under autograd: gradients through the split-fp16 gradient GEMM against the fp32 matrix-core GEMM path."""
     from dagl_amd import train_ops as T
