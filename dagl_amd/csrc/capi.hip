@@ -418,7 +418,9 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // range guard of the split-fp16 kernels (dagl_common.h RangeTag); the fp32 path and the training entry point have no
     // such range
     RangeTag rt;
-    if (p.split16 || core) {        // (training entry points: the streamed dense core splits the features into fp16 halves too, and
+    // (round 6: the fp32 path too -- it has no range, but a NaN feature must not become a 0 behind its ReLU, nor an inf-poisoned key drop out
+    // of the selection: dagl.py:207-275 returns NaN for a non-finite input, and so does every path here; project.hip sets the word)
+    {                               // (training entry points: the streamed dense core splits the features into fp16 halves too, and
                                     //  non-finite feature rows -- a poisoned projection upstream -- must not vanish in the selection)
         rt.word = reinterpret_cast<int32_t*>(stats + 4); rt.done = reinterpret_cast<int32_t*>(stats + 5); rt.tag = next_call_tag();
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -597,7 +599,7 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
                                    thr_in_proj ? &thr_all : nullptr, thr_in_proj ? B : 0, thr_in_proj ? at<float>(ws, p.o_thrpart) : nullptr,
                                    fin ? &tiers_fused : nullptr))) return rc;
     } else {
-        if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh))) return rc;
+        if ((rc = launch_project(s, B, g, 3, b1p, wp2, fc2_b, X, colsum, wp1, fc1_b, Wq, Xh, Wqh, rt))) return rc;
     }
 
     // ---- stage 2: adaptive thresholds ----------------------------------------------------------------------
@@ -638,6 +640,10 @@ static int ce_forward_impl(hipStream_t s, int B, int H, int W, const float* b1, 
     // re-run on the fp32 path right here (same arguments, DAGL_FLAG_EXACT_SCAN); without a read-back (top-k modes) the
     // poisoned output and dagl_ce_range_check report it
     auto rerun_exact = [&]() -> int {
+        if (mode_flags & DAGL_FLAG_EXACT_SCAN) {      // already the fp32 path: the word was set by a NON-FINITE feature (round 6), the output is
+            if (info) info->range_fallback = 1;       // NaN-filled as the reference's would be; nothing to re-run
+            return DAGL_OK;
+        }
         if (heads > 1) {            // stage entry point: no fp32 form of the four-head launch set; hand the call back (per-head path)
             if (info) { info->required_bytes = -1; info->range_fallback = 1; }
             set_error("dagl_ces_stage_forward: an operand left the split-fp16 range: use the per-head entry point");

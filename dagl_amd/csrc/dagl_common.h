@@ -307,7 +307,8 @@ int launch_zero_borders16(hipStream_t s, int B, int H, int W, uint16_t* m1, uint
 int launch_project(hipStream_t s, int B, const Grid& g, int which /* bit0 keys, bit1 queries */, const float* map,
                    const float* wp_keys, const float* bias_keys, float* feat_keys, double* colsum,
                    const float* wp_q, const float* bias_q, float* feat_q,
-                   uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr);
+                   uint16_t* feat_keys_bf16 = nullptr, uint16_t* feat_q_bf16 = nullptr,
+                   RangeTag range = RangeTag() /* set by a non-finite feature: the call's output is NaN-filled, as the reference's is */);
 // fp16 split-operand projection (project16.hip)
 int launch_split_map(hipStream_t s, size_t n_floats, const float* src, uint16_t* hi, uint16_t* lo, RangeTag range = RangeTag());
 int launch_pack_fc_weight16(hipStream_t s, const float* w, uint16_t* wp, bool rows_order = false /* [196][tap][c] instead of [196][c][tap] */);

@@ -57,6 +57,9 @@ struct ProjArgs {
     int segs[2];                 // work items per grid row
     int n_blocks_q;              // blocks [0, n_blocks_q) project queries, the rest keys
     double* colsum;              // [B, DS] key column sums (may be null)
+    RangeTag range;              // a non-finite feature (NaN / inf input upstream) sets the call's word: the fp32 path has no RANGE, but the
+                                 // ReLU below would turn a NaN into 0 and the selection drop an inf-poisoned key -- finite output from a
+                                 // non-finite input, where dagl.py:207-275 returns NaN
 };
 
 // One launch covers both projections: the few query blocks (stride-4 grid, fc1) are dispatched first and
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjArgs pa) {
                 const int rr = 4 * g + r;
                 const bool ok = wave_valid && (gx0 + 16 * m + rr < row_len);
                 float v = tot[m][n][r] + bv;
+                if (pa.range.word != nullptr && !(fabsf(v) <= 3.4e38f)) *pa.range.word = pa.range.tag;
                 v = v > 0.f ? v : 0.f;
                 if (col >= D) v = 0.f;
                 if (ok && col < DS) fb[(size_t)(grid_row_base + rr) * DS + col] = v;
@@ -210,8 +214,9 @@ __global__ __launch_bounds__(256, 2) void project_kernel(ProjArgs pa) {
 // which: bit 0 = keys, bit 1 = queries
 int launch_project(hipStream_t s, int B, const Grid& g, int which, const float* map, const float* wp_keys,
                    const float* bias_keys, float* feat_keys, double* colsum, const float* wp_q,
-                   const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16) {
+                   const float* bias_q, float* feat_q, uint16_t* feat_keys_bf16, uint16_t* feat_q_bf16, RangeTag range) {
     ProjArgs pa;
+    pa.range = range;
     pa.feat_h[0] = feat_keys_bf16; pa.feat_h[1] = feat_q_bf16;
     pa.rows_alloc_h[0] = feat_rows_h(g.N); pa.rows_alloc_h[1] = feat_rows_h(g.L);
     pa.gr = g; pa.map = map;
