@@ -777,20 +777,121 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
 #pragma unroll
             for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[it], w_hi[n], hh[it][n], 0, 0, 0);
     };
+#ifndef DAGL_P16_PIPE
+#if defined(DAGL_ABLATION) && defined(DAGL_P16_PHASES)
+    // (experiment) where a wave's loop time goes: shader clocks of (0) the requests, (1) fragment reads + multiplies issued, (2) the counted
+    // wait for tap t + 1's pieces, (3) the barrier; wave 0's sums replace the block's four stamps
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    unsigned long long pt = __builtin_amdgcn_s_memtime();
+#define P16_PH(k) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); ph[k] += t1_ - pt; pt = t1_; } while (0)
+#else
+#define P16_PH(k) do { } while (0)
+#endif
     for (int step = 0; step < P16_STEPS - PD; ++step) {
         if (KEYS && (step % KS) == 0 && step / KS + 1 < KS) issue_row(step / KS + 1);     // one kernel row ahead
         issue_w(step + PD);
         if (!KEYS) issue_q(step + PD);
+        P16_PH(0);
         compute(step);
+        __builtin_amdgcn_sched_barrier(0);
+        P16_PH(1);
         P16_WAIT2(PD - 1);
+        P16_PH(2);
         __syncthreads();
+        P16_PH(3);
     }
+#if defined(DAGL_ABLATION) && defined(DAGL_P16_PHASES)
+    if (pa.times != nullptr && threadIdx.x == 0) {
+        pa.times[(size_t)blockIdx.x * 4 + 0] = ph[0]; pa.times[(size_t)blockIdx.x * 4 + 1] = ph[1];
+        pa.times[(size_t)blockIdx.x * 4 + 2] = ph[2]; pa.times[(size_t)blockIdx.x * 4 + 3] = ph[3];
+    }
+#endif
+#undef P16_PH
     if (PD == 3) { compute(P16_STEPS - 3); P16_WAIT2(1); __syncthreads(); }
     compute(P16_STEPS - 2); P16_WAIT2(0); __syncthreads();
     compute(P16_STEPS - 1);
     __syncthreads();
+#else
+    // (experiment, round 6) the fragments of tap t + 1 are read right behind tap t's barrier -- which is what makes them readable -- and
+    // under tap t's second and third multiply groups; tap t + 1 starts its first group from registers.  Two fragment sets, taps in pairs.
+    (void)compute;
+    struct Frag { f16x8 fa_hi[PW], fa_lo[PW], w_hi[NT], w_lo[NT]; };
+    auto load = [&](int step, Frag& f) {
+        const int kh = step / KS, kw = step - kh * KS;
+#pragma unroll
+        for (int it = 0; it < PW; ++it) {
+            const unsigned char* sa;
+            int lo_off;
+            if (KEYS) { sa = smem + P16_OFF_A2 + (wave * PW + it) * (2 * P16_AROW) + (kh & 1) * P16_AROW + (off_i[it] + kw) * 32 + 16 * h; lo_off = P16_APART; }
+            else { sa = smem + P16_OFF_A2 + (step % P16_QRING) * (P16_BW * PW * 2048) + (wave * PW + it) * 2048 + lane * 16; lo_off = 1024; }
+            f.fa_hi[it] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa));
+            f.fa_lo[it] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sa + lo_off));
+        }
+        const unsigned char* sb = smem + (step % P16_RING) * P16_STAGE2_B;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f.w_lo[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_lo));
+            f.w_hi[n] = __builtin_bit_cast(f16x8, *reinterpret_cast<const s16x8*>(sb + n * 32 * P16_ROWH * 2 + boff_hi));
+        }
+    };
+    auto g1 = [&](const Frag& f) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.fa_hi[it], f.w_lo[n], hh[it][n], 0, 0, 0);
+    };
+    auto g23 = [&](const Frag& f) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.fa_lo[it], f.w_hi[n], hh[it][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int it = 0; it < PW; ++it) hh[it][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.fa_hi[it], f.w_hi[n], hh[it][n], 0, 0, 0);
+    };
+    // one tap: WAITP = taps whose requests may stay in flight behind it (-1: the last tap, nothing to wait for)
+#define P16_TAP(STEP, CUR, NXT, ISSUE, WAITP)                                                                              \
+    do {                                                                                                                   \
+        if (ISSUE) {                                                                                                       \
+            if (KEYS && ((STEP) % KS) == 0 && (STEP) / KS + 1 < KS) issue_row((STEP) / KS + 1);                            \
+            issue_w((STEP) + PD);                                                                                          \
+            if (!KEYS) issue_q((STEP) + PD);                                                                               \
+        }                                                                                                                  \
+        g1(CUR);                                                                                                           \
+        if ((WAITP) >= 0) {                                                                                                \
+            if ((WAITP) == 2) P16_WAIT2(2); else if ((WAITP) == 1) P16_WAIT2(1); else P16_WAIT2(0);                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* this wave's reads of the stage about to be refilled */ \
+            __syncthreads();                                                                                               \
+            load((STEP) + 1, NXT);                                                                                         \
+        }                                                                                                                  \
+        g23(CUR);                                                                                                          \
+        if ((WAITP) >= 0) {          /* one fragment read behind every multiply (left alone, hipcc reads a fragment right before its use) */ \
+            _Pragma("unroll") for (int pin_ = 0; pin_ < 2 * PW + 2 * NT; ++pin_) {                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
+            }                                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT * PW - (2 * PW + 2 * NT), 0);                               \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+    Frag fA, fB;
+    load(0, fA);
+    static_assert(P16_STEPS == 49 && (PD == 2 || PD == 3), "the tap pairs below are written for 49 taps");
+    for (int step = 0; step < 46; step += 2) {                 // taps 0 .. 45: steady for both prefetch distances
+        P16_TAP(step, fA, fB, true, PD - 1);
+        P16_TAP(step + 1, fB, fA, true, PD - 1);
+    }
+    if (PD == 2) P16_TAP(46, fA, fB, true, 1); else P16_TAP(46, fA, fB, false, 1);
+    P16_TAP(47, fB, fA, false, 0);
+    P16_TAP(48, fA, fB, false, -1);
+    __syncthreads();
+#undef P16_TAP
+#endif
 #undef P16_WAIT2
+#if !defined(DAGL_P16_PHASES)
     dbg_stamp(pa.times, blockIdx.x, 2);
+#endif
 
     // ---- epilogue: D[row = patch (r&3)+8(r>>2)+4h][col = output (n0+n)*32 + i]: this block's columns [c0, c0 + cw) of the rows ----
     float* fb = pa.feat[which] + (size_t)b * pa.rows_alloc[which] * DS;
@@ -976,7 +1077,9 @@ __global__ __launch_bounds__(64 * P16_BW, P16_BLOCKS_PER_CU) void project16_kern
         const int half = rest / P16_NT, tile = rest - half * P16_NT;
         project16_body<1, true, VAR>(pa, smem, tile, 2 * (pa.units_k - pa.n_split_groups + grp) + half, pa.batch - 1);
     }
+#if !defined(DAGL_P16_PHASES)
     dbg_stamp(pa.times, bid, 3);
+#endif
 #if defined(DAGL_ABLATION) && defined(DAGL_P16_HWID)
     // (experiment: which CU ran the block -- HW_ID (cu [11:8], sh [12], se [15:13]) | XCC_ID << 16 in place of the prologue stamp)
     if (pa.times != nullptr && threadIdx.x == 0)
