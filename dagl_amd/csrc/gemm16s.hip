@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void fcg_split_rows_kernel(size_t n, size_t n_
 // columns of d Z: coalesced 128-byte row reads, transposed in LDS, 256-byte runs written.
 // (round 6) khi / klo non-null: the row-major copy [n_pad][224] of fcg_split_rows_kernel from the same read of d Z (both products of a
 // call want it: one pass over the 103 MB instead of two)
-__global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size_t n_pad, const float* __restrict__ dz,
+// (zt_ld: row stride of the transposed copy, n_pad + 64 halfs -- with n_pad a power of two (131 072 at [8, 128, 128]) the 16 rows of every
+// LDS-DMA piece of the weight gradient's first operand sat on one memory channel: dense_train.hip's lesson of round 4)
+__global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size_t n_pad, size_t zt_ld, const float* __restrict__ dz,
                                                                   const unsigned* __restrict__ max_word,
                                                                   unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                                   unsigned short* __restrict__ khi, unsigned short* __restrict__ klo) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void fcg_split_transpose_kernel(size_t n, size
     }
     for (int e = threadIdx.x; e < 32 * 16; e += 256) {                        // (column, octet of rows)
         const int c = e >> 4, r8 = e & 15;
-        const size_t o = ((size_t)(c0 + c) * n_pad + r0) / 8 + r8;
+        const size_t o = ((size_t)(c0 + c) * zt_ld + r0) / 8 + r8;
         reinterpret_cast<uint4*>(hi)[o] = *reinterpret_cast<const uint4*>(&th[c][8 * r8]);
         reinterpret_cast<uint4*>(lo)[o] = *reinterpret_cast<const uint4*>(&tl[c][8 * r8]);
     }
@@ -609,7 +611,7 @@ static FcgPlan fcg_plan(size_t n, int ow_fold = 0, int im_rps = 0, int im_ow = 0
     size_t off = 0;
     p.o_word = fcg_carve(off, 256);
     p.o_zk_hi = fcg_carve(off, p.n_pad * FCG_OP * 2); p.o_zk_lo = fcg_carve(off, p.n_pad * FCG_OP * 2);
-    p.o_zt_hi = fcg_carve(off, (size_t)FCG_OM * p.n_pad * 2); p.o_zt_lo = fcg_carve(off, (size_t)FCG_OM * p.n_pad * 2);
+    p.o_zt_hi = fcg_carve(off, (size_t)FCG_OM * (p.n_pad + 64) * 2); p.o_zt_lo = fcg_carve(off, (size_t)FCG_OM * (p.n_pad + 64) * 2);
     p.o_rt_hi = fcg_carve(off, (size_t)FCG_P * p.n_pad * 2); p.o_rt_lo = fcg_carve(off, (size_t)FCG_P * p.n_pad * 2);
     p.o_wt_hi = fcg_carve(off, (size_t)FCG_PP * FCG_OP * 2); p.o_wt_lo = fcg_carve(off, (size_t)FCG_PP * FCG_OP * 2);
     p.o_part = fcg_carve(off, (size_t)slices * FCG_O * FCG_P * sizeof(float));
@@ -680,7 +682,7 @@ static int fc_grad16_impl(void* stream, int B, int Hp, int Wp, int stride, int o
     }
     const bool merged_split = (d_rows || d_map) && d_w;          // one pass over d Z writes both of its split copies
     if (merged_split) {
-        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, dz,
+        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, p.n_pad + 64, dz,
                            word, H(p.o_zt_hi), H(p.o_zt_lo), H(p.o_zk_hi), H(p.o_zk_lo));
         DAGL_LAUNCH_CHECK("fcg_split_transpose_kernel");
     }
@@ -712,7 +714,7 @@ static int fc_grad16_impl(void* stream, int B, int Hp, int Wp, int stride, int o
     }
     if (d_w) {
         if (!merged_split) {
-        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, dz,
+        hipLaunchKernelGGL(fcg_split_transpose_kernel, dim3((unsigned)(p.n_pad / 128), FCG_OM / 32), dim3(256), 0, s, n, p.n_pad, p.n_pad + 64, dz,
                            word, H(p.o_zt_hi), H(p.o_zt_lo), (unsigned short*)nullptr, (unsigned short*)nullptr);
         DAGL_LAUNCH_CHECK("fcg_split_transpose_kernel");
         }
@@ -733,7 +735,7 @@ static int fc_grad16_impl(void* stream, int B, int Hp, int Wp, int stride, int o
         // (rows 784..895 of the last N tile do not exist: its loads are clamped to row 783, their products are never stored)
         Gemm16s g;
         g.M = FCG_O; g.N = FCG_P; g.K = (int)p.k_slice;
-        g.a_hi = H(p.o_zt_hi); g.a_lo = H(p.o_zt_lo); g.lda = (long long)p.n_pad; g.a_rows = FCG_OM;
+        g.a_hi = H(p.o_zt_hi); g.a_lo = H(p.o_zt_lo); g.lda = (long long)p.n_pad + 64; g.a_rows = FCG_OM;
         g.b_hi = H(p.o_rt_hi); g.b_lo = H(p.o_rt_lo); g.ldb = (long long)p.n_pad; g.b_rows = FCG_P;
         g.C = d_w; g.ldc = FCG_P; g.part = reinterpret_cast<float*>(ws + p.o_part); g.slices = p.slices; g.scale_word = word;
         g.alpha0 = 1.0f / FCG_XS;

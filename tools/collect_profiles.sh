@@ -34,3 +34,5 @@ MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --ou
 MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/train_write -o k -- $TRAIN > $OUT/train_write.log 2>&1
 python $GRAFT_REPO_ROOT/tools/summarize_profiles.py $OUT $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary $TAG
 ls $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_summary
+# gpurun merges at most 64 MiB back: the raw traces (kernel traces of ~2000-launch runs) go, the summaries stay
+rm -rf $OUT
