@@ -657,6 +657,9 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
 #if defined(DAGL_P16_HALFW)
         if (t & 1) return;               // (timing experiment, wrong results: half of the weight LDS-DMA)
 #endif
+#if defined(DAGL_P16_NOW)
+        return;                          // (timing experiment, wrong results: no weight LDS-DMA at all)
+#endif
         const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE2_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
 #pragma unroll
