@@ -107,6 +107,8 @@ SIGNATURES = {
     "dagl_ces_stage_forward": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(CeWeights), _vp, _vp, _i, _i, _vp, _vp, _sz,
                                     C.POINTER(CeInfo), _vp]),
     "dagl_ce_prologue": (_i, [_vp, _i, _i, _i] + [_vp] * 14),
+    "dagl_ce_prologue16_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dagl_ce_prologue16": (_i, [_vp, _i, _i, _i] + [_vp] * 14 + [_sz]),
     "dagl_pad_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_pack_fc_weight": (_i, [_vp, _vp, _vp]),
     "dagl_project_patches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -380,9 +380,9 @@ class CE(nn.Module):
             b = F.pad(b, (0, 0, 0, 0, 0, padc))
             convs = tuple(SimpleNamespace(weight=F.pad(m.weight, (0, 0, 0, 0, 0, padc)), bias=m.bias) for m in convs)
         if self.select_mode != "topk":                 # (the fixed-k variant has no threshold heads)
-            b1p, b2p, thr, bias = T.prologue_convs(b, *convs)
+            b1p, b2p, thr, bias = T.prologue_convs(b, *convs, fast=self.scan != "exact")
         else:
-            b1p, b2p = T.prologue_convs(b, convs[0], convs[1])
+            b1p, b2p = T.prologue_convs(b, convs[0], convs[1], fast=self.scan != "exact")
         b2 = b2p[:, T.PAD:T.PAD + H, T.PAD:T.PAD + W, :].permute(0, 3, 1, 2)                  # NCHW view of the value map
         # dagl.py:216-249  patches of b1 (stride 4 SAME / stride 1) through fc1 / fc2 + ReLU
         wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, self.stride_1,

@@ -1396,6 +1396,43 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x, const fl
                            thr, bias, nullptr, nullptr, scratch);
 }
 
+// (ABI 405) the same four convolutions with g / theta on the fp16 matrix cores (split operands, conv_pair16_kernel: a third of the fp32
+// kernel's time) and the key / query map out in fp32 -- the differentiable path's forward.  The input is split with a power-of-two scale
+// of each block's own (a second run of the strip when its rows leave |16 x| < 60000): no range on x; |w_conv| < 234 as everywhere.
+size_t dagl_ce_prologue16_scratch_bytes(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return 0;
+    const Grid g = make_grid(H, W);
+    size_t off = 0;
+    carve(off, CONV_W16_BYTES);
+    carve(off, (size_t)conv16_blocks_per_head(g, 1, B) * sizeof(float));
+    carve(off, 8 * (size_t)B * g.L * sizeof(float));
+    return off;
+}
+
+int dagl_ce_prologue16(void* stream, int B, int H, int W, const float* x, const float* g_w, const float* g_b,
+                       const float* theta_w, const float* theta_b, const float* thr_w, const float* thr_b,
+                       const float* bias_w, const float* bias_b, float* b1_nhwc, float* b2_nhwc, float* thr, float* bias,
+                       void* scratch, size_t scratch_bytes) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && x && g_w && g_b && theta_w && theta_b && b1_nhwc && b2_nhwc && scratch,
+                 "dagl_ce_prologue16: bad argument");
+    if (thr || bias)
+        DAGL_REQUIRE(thr && bias && thr_w && thr_b && bias_w && bias_b, "dagl_ce_prologue16: thr/bias heads incomplete");
+    DAGL_REQUIRE(scratch_bytes >= dagl_ce_prologue16_scratch_bytes(B, H, W) && ((uintptr_t)scratch % 256) == 0,
+                 "dagl_ce_prologue16: scratch %zu B (256-byte aligned), need %zu B", scratch_bytes, dagl_ce_prologue16_scratch_bytes(B, H, W));
+    hipStream_t s = (hipStream_t)stream;
+    const Grid g = make_grid(H, W);
+    size_t off = 0;
+    unsigned char* convw = at<unsigned char>(scratch, carve(off, CONV_W16_BYTES));
+    B1Tiers tiers;                                   // (slots only: the fp32 map has no tiers; they switch the per-block input scale on)
+    tiers.slots = conv16_blocks_per_head(g, 1, B);
+    tiers.amax = at<float>(scratch, carve(off, (size_t)tiers.slots * sizeof(float)));
+    float* thr_part = at<float>(scratch, carve(off, 8 * (size_t)B * g.L * sizeof(float)));
+    int rc;
+    if ((rc = launch_pack_conv_weight16(s, g_w, theta_w, convw))) return rc;
+    return launch_prologue(s, B, g, x, g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, b1_nhwc, b2_nhwc,
+                           thr, bias, nullptr, nullptr, thr_part, false, false, nullptr, 0, nullptr, 0, RangeTag(), convw, false, &tiers);
+}
+
 // ---- the 7x7x16 -> 196 patch Linear (+ReLU) of the differentiable path's FORWARD on the inference kernels: split the map,
 // pack the weight, project (split-fp16 matrix cores, no unfolded rows), copy the feature rows out densely ---------------
 static void pp16_carve(int B, const Grid& g, int n, size_t& o_hi, size_t& o_lo, size_t& o_wp, size_t& o_feat, size_t& o_range,

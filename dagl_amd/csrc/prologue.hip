@@ -199,8 +199,10 @@ int launch_pack_conv_weight16(hipStream_t s, const float* g_w, const float* th_w
 
 // (hs: per-head input, packed weights and biases; batch index b = head * hs.imgs + image -- a CES stage's four heads are
 // one launch: 256 blocks of 16 rows instead of four launches of 256 blocks of 4 rows, each of which loads the 40 KiB of weights)
+// (b1p: optional fp32 copy of the key / query map -- the differentiable path's forward, round 6: the map as autograd's tensor; b1hi / b1lo
+// may then be null)
 __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows_per_block, ConvHeadSet hs,
-                                                          float* __restrict__ b2p, unsigned short* __restrict__ b1hi,
+                                                          float* __restrict__ b2p, float* __restrict__ b1p, unsigned short* __restrict__ b1hi,
                                                           unsigned short* __restrict__ b1lo, uint32_t* __restrict__ clear_a,
                                                           int clear_a_words, uint32_t* __restrict__ clear_b, int clear_b_words,
                                                           RangeTag range, unsigned long long* times) {
@@ -372,11 +374,13 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
         if (xx < W) {
             const size_t o = (((size_t)b * Hp + y + PADPIX) * Wp + xx + PADPIX) * CH + 4 * kg;
             h16x4 vh, vl, vh2, vl2;
-            float4 v2;
+            float4 v2, v1q;
             float* v2p = &v2.x;
+            float* v1p = &v1q.x;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v1 = ag[r] * inv + bg[r];
+                v1p[r] = v1;
                 _Float16 h, l;
                 c16_split(v1 * B1_FINE_SCALE, h, l);             // P16_A_SCALE (project16.hip)
                 vh[r] = h; vl[r] = l;
@@ -385,9 +389,12 @@ __global__ __launch_bounds__(256) void conv_pair16_kernel(int H, int W, int rows
                 b1_bits = max(b1_bits, __float_as_uint(v1) & 0x7fffffffu);
                 v2p[r] = at[r] * inv + bt[r];
             }
-            *reinterpret_cast<h16x4*>(b1hi + o) = vh;
-            *reinterpret_cast<h16x4*>(b1lo + o) = vl;
-            if (tiers) {
+            if (b1hi != nullptr) {
+                *reinterpret_cast<h16x4*>(b1hi + o) = vh;
+                *reinterpret_cast<h16x4*>(b1lo + o) = vl;
+            }
+            if (b1p != nullptr) *reinterpret_cast<float4*>(b1p + o) = v1q;
+            if (tiers && b1hi2 != nullptr) {
                 *reinterpret_cast<h16x4*>(b1hi2 + o) = vh2;
                 *reinterpret_cast<h16x4*>(b1lo2 + o) = vl2;
             }
@@ -573,7 +580,7 @@ int launch_conv_pair16_heads(hipStream_t s, int heads, int imgs, const Grid& g, 
     if (getenv("DAGL_TIMES_FILE")) times = dbg_times_buffer((size_t)strips * chunks * B);
 #endif
     hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
-                       b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
+                       b2p, (float*)nullptr, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
     DAGL_LAUNCH_CHECK("conv_pair16_kernel");
 #ifdef DAGL_ABLATION
     if (times) dbg_times_dump(s, "conv_pair16_kernel", times, (size_t)strips * chunks * B);
@@ -615,7 +622,8 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
     chunks = (g.H + rows_per_block - 1) / rows_per_block;
     if (skip_conv) {
         // (the caller ran launch_conv_pair16_heads for all its heads)
-    } else if (b1p == nullptr && b1_hi != nullptr) {
+    } else if ((b1p == nullptr && b1_hi != nullptr) || (b1p != nullptr && conv_w16 != nullptr)) {
+        // (split-fp16 convolutions; with b1p: the differentiable path's forward -- an fp32 map out, the fp16 pairs optional)
         if (conv_w16 == nullptr) { set_error("launch_prologue: the split-fp16 convolutions need their packed weights"); return DAGL_ERR_INVALID; }
         ConvHeadSet hs = {};
         hs.x[0] = x; hs.w[0] = conv_w16; hs.gb[0] = g_b; hs.tb[0] = th_b; hs.imgs = B;
@@ -625,7 +633,7 @@ int launch_prologue(hipStream_t s, int B, const Grid& g, const float* x, const f
         if (getenv("DAGL_TIMES_FILE")) times = dbg_times_buffer((size_t)strips * chunks * B);
 #endif
         hipLaunchKernelGGL(conv_pair16_kernel, dim3(strips, chunks, B), dim3(256), 0, s, g.H, g.W, rows_per_block, hs,
-                           b2p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
+                           b2p, b1p, b1_hi, b1_lo, clear_a, clear_a_words, clear_b, clear_b_words, range, times);
         DAGL_LAUNCH_CHECK("conv_pair16_kernel");
 #ifdef DAGL_ABLATION
         if (times) dbg_times_dump(s, "conv_pair16_kernel", times, (size_t)strips * chunks * B);

@@ -310,7 +310,7 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
 
 
 @_on_device
-def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None):
+def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None, fast=False):
     """The four prologue convolutions (dagl.py:208-215) -> (b1_nhwc, b2_nhwc, thr, bias); heads optional."""
     for n, t in (("x", x), ("g_w", g_w), ("g_b", g_b), ("theta_w", theta_w), ("theta_b", theta_b)):
         _need(t, n)
@@ -326,8 +326,18 @@ def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=No
     if heads:
         for n, t in (("thr_w", thr_w), ("thr_b", thr_b), ("bias_w", bias_w), ("bias_b", bias_b)):
             _need(t, n)
-    scratch = torch.empty(8 * B * Lh * Lw, device=x.device, dtype=torch.float32) if heads else None
     p = lambda t: t.data_ptr() if t is not None else None
+    if fast:
+        # g / theta on the fp16 matrix cores with split operands (conv_pair16_kernel, the inference path's kernel, fp32 map out)
+        lib = _lib.load()
+        need = lib.dagl_ce_prologue16_scratch_bytes(B, H, W)
+        scratch = torch.empty(need + 256, device=x.device, dtype=torch.uint8)
+        base = (scratch.data_ptr() + 255) // 256 * 256
+        check(lib.dagl_ce_prologue16(_stream(), B, H, W, x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(), theta_w.data_ptr(), theta_b.data_ptr(),
+                                     p(thr_w), p(thr_b), p(bias_w), p(bias_b), b1p.data_ptr(), b2p.data_ptr(), p(thr), p(bias), base, need),
+              "dagl_ce_prologue16")
+        return b1p, b2p, thr, bias
+    scratch = torch.empty(8 * B * Lh * Lw, device=x.device, dtype=torch.float32) if heads else None
     check(_lib.load().dagl_ce_prologue(_stream(), B, H, W, x.data_ptr(), g_w.data_ptr(), g_b.data_ptr(),
                                        theta_w.data_ptr(), theta_b.data_ptr(), p(thr_w), p(thr_b), p(bias_w), p(bias_b),
                                        b1p.data_ptr(), b2p.data_ptr(), p(thr), p(bias), p(scratch)), "dagl_ce_prologue")

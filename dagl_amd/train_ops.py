@@ -62,6 +62,7 @@ def to_padded_nhwc(x, H, W, from_rows=False):
 
 FAST_FC_FORWARD = True          # forward of the two patch projections on the split-fp16 inference kernels (tests flip it)
 FAST_FC_BACKWARD = True         # their two gradient products on the split-fp16 GEMM (gemm16s.hip; tests flip it)
+FAST_PROLOGUE_FORWARD = True    # g / theta of the differentiable path's forward on the fp16 matrix cores (dagl_ce_prologue16; tests flip it)
 FOLD_IN_PRODUCT = True          # ... with d rows of the stride-1 projection folded inside the product (dagl_fc_grad16_dmap; tests flip it)
 
 
@@ -192,13 +193,14 @@ class _PrologueConvs(torch.autograd.Function):
     unfold / GEMM / fold one, layer by layer."""
 
     @staticmethod
-    def forward(ctx, x, g_w, g_b, th_w, th_b, thr_w, thr_b, bias_w, bias_b):
+    def forward(ctx, x, g_w, g_b, th_w, th_b, thr_w, thr_b, bias_w, bias_b, fast=True):
         x = x.contiguous()
         heads = thr_w is not None
         c = lambda t: t.contiguous() if t is not None else None
         with torch.cuda.device(x.device):
             if x.shape[1] == 64:
-                b1p, b2p, thr, bias = ops.ce_prologue(x, c(g_w), c(g_b), c(th_w), c(th_b), c(thr_w), c(thr_b), c(bias_w), c(bias_b))
+                b1p, b2p, thr, bias = ops.ce_prologue(x, c(g_w), c(g_b), c(th_w), c(th_b), c(thr_w), c(thr_b), c(bias_w), c(bias_b),
+                                                      fast=bool(fast) and FAST_PROLOGUE_FORWARD and x.dtype == torch.float32)
             else:
                 b1p, b2p, thr, bias = prologue_forward_any_width(x, g_w, g_b, th_w, th_b, thr_w, thr_b, bias_w, bias_b)
         ctx.heads = heads
@@ -294,7 +296,7 @@ class _PrologueConvs(torch.autograd.Function):
                 _copy4(d_xp.view(-1)[inner64:], (B, C, H, W), (Hp * Wp * C, 1, Wp * C, C), d_x, (C * H * W, H * W, W, 1))
             if d_x_direct is not None:
                 d_x = d_x_direct if d_x is None else d_x_direct.add_(d_x)
-        return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b)
+        return (d_x, grads["g"][0], grads["g"][1], grads["theta"][0], grads["theta"][1], d_thr_w, d_thr_b, d_bias_w, d_bias_b, None)
 
 
 class _PReLU1(torch.autograd.Function):
@@ -379,12 +381,13 @@ def prologue_forward_any_width(x, g_w, g_b, th_w, th_b, thr_w=None, thr_b=None, 
     return maps[0], maps[1], thr, bias
 
 
-def prologue_convs(x, g, theta, thr_conv=None, bias_conv=None):
-    """(b1p, b2p[, thr, bias]) of the block input: zero-bordered NHWC maps [B,H+6,W+6,16] and per-query thr / bias [B,L]."""
+def prologue_convs(x, g, theta, thr_conv=None, bias_conv=None, fast=True):
+    """(b1p, b2p[, thr, bias]) of the block input: zero-bordered NHWC maps [B,H+6,W+6,16] and per-query thr / bias [B,L].
+    ``fast=False`` (modules moved to ``scan="exact"``): g / theta on the fp32 matrix cores instead of the split-fp16 ones."""
     if thr_conv is None:
-        return _PrologueConvs.apply(x, g.weight, g.bias, theta.weight, theta.bias, None, None, None, None)
+        return _PrologueConvs.apply(x, g.weight, g.bias, theta.weight, theta.bias, None, None, None, None, fast)
     return _PrologueConvs.apply(x, g.weight, g.bias, theta.weight, theta.bias, thr_conv.weight, thr_conv.bias,
-                                bias_conv.weight, bias_conv.bias)
+                                bias_conv.weight, bias_conv.bias, fast)
 
 
 def patch_linear(pmap, weight, bias, k, stride, oy, ox, oh, ow, relu=False, allow_fast=True):

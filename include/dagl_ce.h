@@ -433,6 +433,15 @@ int dagl_ce_prologue(void* stream, int B, int H, int W, const float* x,
                      const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
                      float* b1_nhwc, float* b2_nhwc, float* thr, float* bias, float* scratch);
 
+/* (ABI 405) The same with g / theta on the fp16 matrix cores (split operands: >= 21 significant bits, a third of the fp32 kernel's time):
+ * the differentiable path's forward.  No range on x (per-block power-of-two input scale); |w_conv| < 234.  `scratch`: 256-byte aligned,
+ * dagl_ce_prologue16_scratch_bytes(B, H, W) bytes (packed weights, per-block statistics, the heads' partial sums).                  */
+size_t dagl_ce_prologue16_scratch_bytes(int B, int H, int W);
+int dagl_ce_prologue16(void* stream, int B, int H, int W, const float* x,
+                       const float* g_w, const float* g_b, const float* theta_w, const float* theta_b,
+                       const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
+                       float* b1_nhwc, float* b2_nhwc, float* thr, float* bias, void* scratch, size_t scratch_bytes);
+
 /* NCHW [B,16,H,W] -> zero-bordered NHWC [B,H+6,W+6,16]  (patch unfold without materialising
  * patches: replaces same_padding/extract_image_patches, dagl.py:123-169, for all three uses).    */
 int dagl_pad_nhwc(void* stream, int B, int H, int W, const float* src_nchw, float* dst_nhwc);

@@ -322,3 +322,26 @@ def test_prologue_backward_direct_and_unfold_routes_agree():
                 T._FORCE_UNFOLD_BACKWARD = False
         for a, b in zip(res[(heads, False)], res[(heads, True)]):
             assert normwise(a.numpy(), b.numpy()) <= 2e-6
+
+
+def test_prologue16_matches_the_fp32_prologue_forward_and_backward():
+    """dagl_ce_prologue16 (round 6: g / theta of the differentiable path's forward on the fp16 matrix cores, fp32 map out) against the fp32
+    prologue: maps, thr / bias and the gradients through them; an input x 3e3 (beyond the fixed split's range) is served."""
+    from dagl_amd import train_ops as T
+    from dagl_amd.ce import CE
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    ce = CE(in_channels=64).to(dev)
+    for scale in (1.0, 3.0e3):
+        x = (torch.randn(2, 64, 40, 44, generator=torch.Generator().manual_seed(7)) * scale).to(dev)
+        res = {}
+        for fast in (True, False):
+            xx = x.clone().requires_grad_(True)
+            b1p, b2p, thr, bias = T.prologue_convs(xx, ce.g, ce.theta, ce.thr_conv, ce.bias_conv, fast=fast)
+            gsel = torch.Generator().manual_seed(9)
+            loss = (b1p * torch.randn(b1p.shape, generator=gsel).to(dev)).sum() + (b2p ** 2).sum() * 1e-3 + thr.sum() + (bias ** 2).sum()
+            grads = torch.autograd.grad(loss, [xx, ce.g.weight, ce.theta.weight, ce.thr_conv.weight])
+            res[fast] = [t.detach().cpu() for t in (b1p, b2p, thr, bias, *grads)]
+        for a, c in zip(res[True], res[False]):
+            assert torch.isfinite(a).all()
+            assert normwise(a.numpy(), c.numpy()) <= 2e-6, normwise(a.numpy(), c.numpy())
