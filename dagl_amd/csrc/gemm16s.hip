@@ -582,7 +582,7 @@ static bool fcg_fold_ok(int stride, int ow) { return stride == 1 && ow >= 16 && 
 // The weight gradient from shifted planes (Gemm16s::b_implicit): stride-1 patches from the map's corner, rows a power of two >= 32 patches
 // wide, and a divisor of the image height as the rows of a K slice (a slice = whole rows of one image)
 static int fcg_implicit_rows(int B, int stride, int oy, int ox, int oh, int ow, int Hp, int Wp) {
-    if (stride != 1 || oy != 0 || ox != 0 || ow < 32 || (ow & (ow - 1)) != 0 || Hp != oh + KS - 1 || Wp != ow + KS - 1) return 0;
+    if (stride != 1 || oy != 0 || ox != 0 || ow < 32 || ow > 512 || (ow & (ow - 1)) != 0 || Hp != oh + KS - 1 || Wp != ow + KS - 1) return 0;   // (<= 512: fcg_shift_planes_kernel keeps a map row in 64 KiB of LDS)
     if (((size_t)B * oh * ow) % 128 != 0) return 0;
     const double want = (double)B * oh / 36.0;                 // ~36 slices x 7 column tiles fill the chip with one block per CU
     int best = 0;
