@@ -136,3 +136,31 @@ def test_topk_beyond_64_neighbours_has_no_fixed_feature_range(scale):
     e = normwise(out.numpy(), want.numpy())
     print(f"[range] top-k 100 x{scale:g}: e_hip {e:.2e} e_ref32 {e_ref32:.2e} path {ce.last_info and ce.last_info.get('path')}")
     assert e <= max(1e-4, 2.0 * e_ref32 + 1e-5), (e, e_ref32)
+
+
+def test_random_shapes_and_input_scales_first_call():
+    """Twelve seeded (batch, H, W, k, scale) draws -- ragged widths (partial 64-pixel strips of the prologue, rows that are no multiple
+    of 32 in the projection), batches, scales from 1e-3 to 1e5 -- each on a cold module's first call against the fp64 oracle."""
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params, make_features
+    from oracle.ce_oracle import ce_forward_oracle
+    rng = np.random.default_rng(606)
+    worst = 0.0
+    for case in range(12):
+        B = int(rng.integers(1, 4)); H = int(rng.integers(24, 90)); W = int(rng.integers(24, 90))
+        k = int(rng.choice([4, 8, 16])); scale = float(rng.choice([1e-3, 1.0, 1e2, 3e3, 1e5]))
+        params = {n: torch.from_numpy(a) for n, a in make_ce_params(100 + case, variant="default").items()}
+        x = torch.from_numpy(make_features(200 + case, B, 64, H, W)) * scale
+        ce = CE(in_channels=64)
+        ce.load_state_dict(params, strict=True)
+        ce.select_mode, ce.select_k = "topk", k
+        ce = ce.to("cuda:0").eval()
+        with torch.no_grad():
+            out = ce(x.to("cuda:0")).cpu()
+        assert torch.isfinite(out).all(), (case, B, H, W, k, scale)
+        want = ce_forward_oracle(x, params, mode="topk", k=k, dtype=torch.float64).float()
+        e_ref32 = normwise(ce_forward_oracle(x, params, mode="topk", k=k).numpy(), want.numpy())
+        e = normwise(out.numpy(), want.numpy())
+        worst = max(worst, e)
+        assert e <= max(1e-4, 2.0 * e_ref32 + 1e-5), (case, B, H, W, k, scale, e, e_ref32)
+    print(f"[range] 12 random (batch, H, W, k, scale) draws, first calls: worst {worst:.2e} of the fp64 oracle")
