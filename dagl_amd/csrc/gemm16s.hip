@@ -21,6 +21,8 @@
 //     projection's weight layout), v_mfma_f32_32x32x16_f16, the operands swapped so that a lane ends up with four
 //     consecutive columns of one output row (16-byte stores); split-K with a fixed-order reduce for the weight gradient.
 // Everything is summed in a fixed order: bit-reproducible.  Range: |16 x| (the forward's own limit) and |1024 w| < 65504.
+#include <stdlib.h>
+
 #include "dagl_common.h"
 
 namespace dagl {
@@ -588,6 +590,9 @@ static int fcg_implicit_rows(int B, int stride, int oy, int ox, int oh, int ow, 
     int best = 0;
     for (int r = 1; r <= oh; ++r)
         if (oh % r == 0 && (long long)r * ow >= 256 && (best == 0 || (r <= want * 1.5 && r > best))) best = r;
+#ifdef DAGL_ABLATION                   // (debug builds: DAGL_FCG_RPS = image rows per K slice of the weight gradient)
+    { static const int e = [] { const char* v = getenv("DAGL_FCG_RPS"); return v ? atoi(v) : 0; }(); if (e > 0 && oh % e == 0 && (long long)e * ow >= 256) best = e; }
+#endif
     return best;
 }
 
