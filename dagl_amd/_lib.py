@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdagl_ce.so")
 MODE_ADAPTIVE, MODE_TOPK, MODE_ADAPTIVE_TOPK = 0, 1, 2
 MODES = {"adaptive": MODE_ADAPTIVE, "topk": MODE_TOPK, "adaptive_topk": MODE_ADAPTIVE_TOPK}
 MAX_TOPK = 64
-ABI_VERSION = 405          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
+ABI_VERSION = 406          # include/dagl_ce.h DAGL_ABI_VERSION this binding was written against
 FAST_CAP = 64
 P = 784
 D = 196
@@ -120,6 +120,8 @@ SIGNATURES = {
     "dagl_unfold_values": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_fold_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "dagl_scores_dense": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "dagl_ce_generic_workspace_bytes": (_sz, [_i] * 8),
+    "dagl_ce_generic_forward": (_i, [_vp] + [_i] * 8 + [C.c_float, _i, _i] + [_vp] * 16 + [_sz]),
 }
 
 _lib = None

@@ -142,10 +142,15 @@ class CE(nn.Module):
     def __init__(self, ksize=7, stride_1=4, stride_2=1, softmax_scale=10, shape=64, p_len=64, in_channels=64,
                  inter_channels=16, use_multiple_size=False, use_topk=False, add_SE=False, num_edge=50):
         super().__init__()
-        if (ksize, stride_1, stride_2, inter_channels) != (7, 4, 1, 16):
-            raise DaglError(
-                "dagl_amd.CE implements the patch geometry the reference ships and never overrides "
-                "(ksize=7, stride_1=4, stride_2=1, inter_channels=16; dagl.py:175-176)")
+        # Patch geometry (dagl.py:175-176).  The reference's own builders never override it (dagl.py:94-109) and every tuned kernel has
+        # (7, 4, 1, 16) compiled in; any other geometry runs the reference's dense formulation with the geometry as run-time arguments
+        # (dagl_ce_generic_forward, csrc/generic.hip: fp32 matrix cores, inference only).
+        self._generic = (int(ksize), int(stride_1), int(stride_2), int(inter_channels)) != (7, 4, 1, 16)
+        if self._generic:
+            if not (1 <= int(ksize) <= 31 and int(stride_1) >= 1 and int(stride_2) >= 1):
+                raise DaglError(f"CE: ksize={ksize} (1..31), stride_1={stride_1}, stride_2={stride_2} (>= 1)")
+            if int(inter_channels) < 4 or int(inter_channels) % 4:
+                raise DaglError(f"CE: inter_channels={inter_channels} must be a multiple of 4 (16-byte pixels of the NHWC maps)")
         if not float(softmax_scale) > 0.0:
             raise DaglError(f"CE: softmax_scale={softmax_scale} must be positive")
         self.ksize, self.shape, self.p_len = ksize, shape, p_len
@@ -467,6 +472,13 @@ class CE(nn.Module):
         # RR / CES the block's input then "requires grad" although nobody will ask for one.  Such a call keeps its place in
         # the autograd graph (_EvalLazyGrad): should a backward arrive after all, it recomputes the block on the
         # differentiable path then -- same gradients, paid only when used.
+        if self._generic:
+            if torch.is_grad_enabled() and self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
+                raise DaglError("CE: the differentiable path implements the shipped patch geometry (7, 4, 1, 16) only; a module with "
+                                f"(ksize, stride_1, stride_2, inter_channels) = ({self.ksize}, {self.stride_1}, {self.stride_2}, "
+                                f"{self.inter_channels}) serves eval() / torch.no_grad() calls")
+            out = self._forward_infer_generic(b, k_eff)
+            return out if in_dtype == torch.float32 else out.to(in_dtype)
         if torch.is_grad_enabled():
             if self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
                 out = self._forward_train(b.contiguous())
@@ -477,6 +489,32 @@ class CE(nn.Module):
                 return out if in_dtype == torch.float32 else out.to(in_dtype)
         out = self._forward_infer(b, k_eff)
         return out if in_dtype == torch.float32 else out.to(in_dtype)
+
+    def _forward_infer_generic(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
+        """A module built with non-default ``ksize / stride_1 / stride_2 / inter_channels`` (dagl.py:175-176): the whole method through
+        ``dagl_ce_generic_forward`` (csrc/generic.hip).  ``softmax_scale`` goes to the kernel as it is (no scaled parameter copies);
+        an input width that is not a multiple of 4 gets zero channels (and zero weight columns), which change nothing."""
+        p = {}
+        for n, t in self.named_parameters():
+            if n.startswith("W."):
+                continue
+            t = t.detach()
+            if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                raise DaglError(f"CE: parameter {n} has dtype {t.dtype}; fp32, fp16 or bf16 expected")
+            p[n] = t.float().contiguous()
+        padc = (-self.in_channels) % 4
+        if padc:
+            b = F.pad(b, (0, 0, 0, 0, 0, padc))
+            for n in ("g.weight", "theta.weight", "thr_conv.weight", "bias_conv.weight"):
+                p[n] = F.pad(p[n], (0, 0, 0, 0, 0, padc)).contiguous()
+        with torch.no_grad():
+            out, deg = ops.ce_forward_generic(b.contiguous(), p, self.ksize, self.stride_1, self.stride_2, self.inter_channels,
+                                              mode=self.select_mode, k=k_eff, softmax_scale=float(self.softmax_scale),
+                                              workspace=self._ws, want_degree=True)
+        self._last_call = None
+        self._pack_key = None                      # the shared workspace holds another layout now
+        self.last_info = dict(path=7, degree=deg)  # (device tensor [B,L]: reading it is the caller's synchronisation)
+        return out
 
     def _forward_infer_any_width(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
         """``CE(in_channels = n_feats)`` for n_feats != 64 (CES builds every head that way, dagl.py:94-109; ``--n_feats``,

@@ -1542,4 +1542,28 @@ int dagl_scores_dense(void* stream, int B, int L, int N, const float* wq, const 
     return launch_scores_dense((hipStream_t)stream, B, L, N, wq, x, sc);
 }
 
+// (ABI 406) any patch geometry: csrc/generic.hip
+size_t dagl_ce_generic_workspace_bytes(int B, int Cin, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels) {
+    if (B < 1 || Cin < 4 || H < 1 || W < 1 || ksize < 1 || ksize > 31 || stride_1 < 1 || stride_2 < 1 || inter_channels < 4) return 0;
+    return dagl::ce_generic_workspace_bytes(B, Cin, H, W, ksize, stride_1, stride_2, inter_channels);
+}
+
+int dagl_ce_generic_forward(void* stream, int B, int Cin, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                            float softmax_scale, int mode, int k, const float* x, const float* g_w, const float* g_b,
+                            const float* theta_w, const float* theta_b, const float* thr_w, const float* thr_b, const float* bias_w,
+                            const float* bias_b, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                            float* out, int32_t* degree, void* workspace, size_t workspace_bytes) {
+    int rc = dagl::ce_generic_check(B, Cin, H, W, ksize, stride_1, stride_2, inter_channels, mode, k);
+    if (rc) return rc;
+    DAGL_REQUIRE(softmax_scale > 0.f, "dagl_ce_generic_forward: softmax_scale must be positive");
+    DAGL_REQUIRE(x && g_w && g_b && theta_w && theta_b && fc1_w && fc1_b && fc2_w && fc2_b && out && workspace,
+                 "dagl_ce_generic_forward: null pointer");
+    if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr_w && thr_b && bias_w && bias_b, "dagl_ce_generic_forward: thr / bias heads missing");
+    const size_t need = dagl::ce_generic_workspace_bytes(B, Cin, H, W, ksize, stride_1, stride_2, inter_channels);
+    if (workspace_bytes < need) { dagl::set_error("dagl_ce_generic_forward: workspace %zu bytes, %zu needed", workspace_bytes, need); return DAGL_ERR_WORKSPACE; }
+    if ((rc = check_device())) return rc;
+    return dagl::launch_ce_generic((hipStream_t)stream, B, Cin, H, W, ksize, stride_1, stride_2, inter_channels, softmax_scale, mode, k, x,
+                                   g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, fc1_w, fc1_b, fc2_w, fc2_b, out, degree, workspace);
+}
+
 }  // extern "C"

@@ -690,6 +690,13 @@ int launch_unfold_dout(hipStream_t s, int B, const Grid& g, const float* dout, f
 int launch_dxbar(hipStream_t s, int B, int L, const float* wq_rows, const float* dmu, float* dxbar);
 // dense neighbourhoods under autograd (dense_train.hip): the dense formulation chunked over queries
 size_t dense_train_workspace_bytes(int B, const Grid& g, bool backward);
+// any patch geometry (generic.hip; ABI 406)
+size_t ce_generic_workspace_bytes(int B, int Cin, int H, int W, int ks, int s1, int s2, int C);
+int ce_generic_check(int B, int Cin, int H, int W, int ks, int s1, int s2, int C, int mode, int k);
+int launch_ce_generic(hipStream_t s, int B, int Cin, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                      const float* x, const float* g_w, const float* g_b, const float* th_w, const float* th_b, const float* thr_w,
+                      const float* thr_b, const float* bias_w, const float* bias_b, const float* fc1_w, const float* fc1_b,
+                      const float* fc2_w, const float* fc2_b, float* out, int32_t* degree, void* workspace);
 int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                const float* thr, const float* bias, float* out, float* lse /*[B,L,2]*/, float* mu /*[B,L]*/,
                                void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */,

@@ -1,0 +1,377 @@
+// CE.forward for ANY patch geometry -- ksize, stride_1, stride_2 and inter_channels are constructor arguments of the reference
+// block (DN_Gray/model/dagl.py:175-176) that its own builders never override (dagl.py:94-109), so every tuned kernel of this
+// library has (7, 4, 1, 16) compiled in.  This file is the run-time-geometry route behind the same module: the reference's dense
+// formulation (dagl.py:207-275) stage by stage on the fp32 matrix cores, nothing O(L N) beyond one chunk of score rows:
+//
+//   dagl.py:208-215   g (3x3) + theta (1x1 = centre tap) as ONE 2c-output product over the 3x3 patches of the zero-bordered NHWC
+//                     input; thr / bias as one 2-output product over the stride_1 SAME ksize x ksize patches
+//   dagl.py:216-243   unfold_patches_kernel (train_ops.hip) on the maps, any window / stride / channel count (multiple of 4)
+//   dagl.py:248-249   rows x fc^T + bias, ReLU (gemm32.hip; Linear weights re-ordered once from Unfold's (c,kh,kw) to (kh,kw,c))
+//   dagl.py:250       S chunk = Wq chunk x X^T (gemm32.hip), rows of at most 256 MiB at a time
+//   dagl.py:256-261   gen_row_softmax_kernel: one block per query row -- row mean (fp64 sum), mask, softmax over ALL keys with the
+//                     masked keys' e^0 in the denominator, not renormalised; the fixed-k variant's k best by radix selection
+//                     (wide_select.h, ties to the lower key index), GReccR2b_3mh_1-checkpoint.py:242-250
+//   dagl.py:263-264   A chunk x value rows (gemm32.hip)
+//   dagl.py:265-272   gen_fold_normalize_kernel: fold with padding = the stride_2 SAME grid's left pad and stride_1 (the reference
+//                     folds query patches cut with the stride_1 SAME pad back with the stride_2 pad: reproduced), overlap count
+//                     with its zero guard, NCHW out
+//
+// Correct and on the device, not tuned: the default geometry never comes here (dagl_amd/ce.py routes it to the tuned kernels).
+#include "dagl_common.h"
+#include "wide_select.h"
+
+namespace dagl {
+
+int launch_unfold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
+                          const float* map, float* rows);
+
+namespace {
+
+struct GenGeom {
+    int B, Cin, H, W, ks, s1, s2, C;
+    int PG, Hp, Wp;                 // border of the NHWC maps, padded extent
+    int Lh, Lw, L, t1, l1;          // query grid (stride_1 SAME) and its top / left pad
+    int Nh, Nw, N, t2, l2;          // key / value grid (stride_2 SAME)
+    int P, D;                       // patch length ks*ks*C, feature length P / 4
+    int fold_pad, fold_h, fold_w;   // F.fold's padding (dagl.py:243: paddings[0] = left pad of the stride_2 grid) and block grid
+    long long ldn; int Lc;          // score-row stride (N rounded up to 4) and rows per chunk
+};
+
+inline void same_pad_1d(int n, int k, int stride, int& out, int& lead) {
+    out = (n + stride - 1) / stride;
+    int p = (out - 1) * stride + k - n; if (p < 0) p = 0;
+    lead = p / 2;                                   // dagl.py:131-136: the odd unit goes to the bottom / right
+}
+
+inline GenGeom gen_geom(int B, int Cin, int H, int W, int ks, int s1, int s2, int C) {
+    GenGeom g{};
+    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.ks = ks; g.s1 = s1; g.s2 = s2; g.C = C;
+    g.PG = ks > 2 ? ks - 1 : 1;
+    g.Hp = H + 2 * g.PG; g.Wp = W + 2 * g.PG;
+    same_pad_1d(H, ks, s1, g.Lh, g.t1); same_pad_1d(W, ks, s1, g.Lw, g.l1);
+    same_pad_1d(H, ks, s2, g.Nh, g.t2); same_pad_1d(W, ks, s2, g.Nw, g.l2);
+    g.L = g.Lh * g.Lw; g.N = g.Nh * g.Nw;
+    g.P = ks * ks * C; g.D = g.P / 4;
+    g.fold_pad = g.l2;                              // dagl.py:243 takes paddings[0] (the LEFT pad) for both axes
+    g.fold_h = (H + 2 * g.fold_pad - ks) / s1 + 1;
+    g.fold_w = (W + 2 * g.fold_pad - ks) / s1 + 1;
+    g.ldn = ((long long)g.N + 3) / 4 * 4;
+    long long lc = (64ll << 20) / g.ldn;            // 256 MiB of score rows
+    if (lc < 1) lc = 1;
+    if (lc > g.L) lc = g.L;
+    g.Lc = (int)lc;
+    return g;
+}
+
+struct GenPlan {
+    size_t o_xp, o_wgt, o_bgt, o_wtb, o_btb, o_fc1, o_fc2, o_rows, o_y, o_b1p, o_b2p, o_tb, o_wq, o_x, o_s, o_agg, o_end;
+};
+inline GenPlan gen_plan(const GenGeom& g) {
+    GenPlan p{};
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t B = g.B, HW = (size_t)g.H * g.W, pix = (size_t)g.Hp * g.Wp;
+    p.o_xp = carve(B * pix * g.Cin * 4);
+    p.o_wgt = carve((size_t)2 * g.C * 9 * g.Cin * 4);
+    p.o_bgt = carve((size_t)2 * g.C * 4);
+    p.o_wtb = carve((size_t)2 * g.ks * g.ks * g.Cin * 4);
+    p.o_btb = carve(8);
+    p.o_fc1 = carve((size_t)g.D * g.P * 4);
+    p.o_fc2 = carve((size_t)g.D * g.P * 4);
+    // one row buffer serves every unfold in turn: 3x3 input patches, thr / bias patches, query / key / value patches
+    size_t rows = B * HW * 9 * g.Cin;
+    const size_t r_tb = B * g.L * (size_t)g.ks * g.ks * g.Cin, r_q = B * g.L * (size_t)g.P, r_k = B * g.N * (size_t)g.P;
+    if (r_tb > rows) rows = r_tb;
+    if (r_q > rows) rows = r_q;
+    if (r_k > rows) rows = r_k;
+    p.o_rows = carve(rows * 4);
+    p.o_y = carve(B * HW * 2 * g.C * 4);
+    p.o_b1p = carve(B * pix * g.C * 4);
+    p.o_b2p = carve(B * pix * g.C * 4);
+    p.o_tb = carve(B * g.L * 2 * 4);
+    p.o_wq = carve(B * g.L * (size_t)g.D * 4);
+    p.o_x = carve(B * g.N * (size_t)g.D * 4);
+    p.o_s = carve((size_t)g.Lc * g.ldn * 4);
+    p.o_agg = carve(B * g.L * (size_t)g.P * 4);
+    p.o_end = off;
+    return p;
+}
+
+// NCHW [B,C,H,W] -> zero-bordered NHWC [B,H+2pg,W+2pg,C]; thread = one float4 of a padded pixel (border pixels get zeros)
+__global__ __launch_bounds__(256) void gen_pad_nhwc_kernel(int C, int H, int W, int pg, const float* __restrict__ src,
+                                                           float* __restrict__ dst) {
+    const int b = blockIdx.y, c4n = C / 4, Hp = H + 2 * pg, Wp = W + 2 * pg;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Hp * Wp * c4n) return;
+    const int pix = (int)(t / c4n), c4 = (int)(t - (size_t)pix * c4n);
+    const int y = pix / Wp - pg, x = pix % Wp - pg;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float* s = src + (((size_t)b * C + 4 * c4) * H + y) * W + x;
+        const size_t hw = (size_t)H * W;
+        v = make_float4(s[0], s[hw], s[2 * hw], s[3 * hw]);
+    }
+    reinterpret_cast<float4*>(dst + ((size_t)b * Hp * Wp + pix) * C)[c4] = v;
+}
+
+// weight [O, Cw, k, k] (conv weights; Linear weights over Unfold's (c,kh,kw) patch order, dagl.py:196-203) -> rows
+// dst[o * ld + off + (kh*k + kw) * Cw + c]: the element order of unfold_patches_kernel
+__global__ void gen_weight_rows_kernel(int O, int Cw, int k, const float* __restrict__ src, float* __restrict__ dst, long long ld,
+                                       long long off) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)Cw * k * k;
+    if (t >= (size_t)O * per) return;
+    const int o = (int)(t / per); const int e = (int)(t - (size_t)o * per);
+    const int tap = e / Cw, c = e - tap * Cw;
+    dst[(size_t)o * ld + off + e] = src[((size_t)o * Cw + c) * (k * k) + tap];
+}
+
+// y [B*H*W, 2c] (g | theta) -> the two zero-bordered NHWC maps (their borders were zeroed by a memset)
+__global__ __launch_bounds__(256) void gen_split_maps_kernel(int C, int H, int W, int pg, const float* __restrict__ y,
+                                                             float* __restrict__ b1p, float* __restrict__ b2p) {
+    const int b = blockIdx.y, c4n = C / 4, Wp = W + 2 * pg, Hp = H + 2 * pg;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)H * W * 2 * c4n) return;
+    const int pix = (int)(t / (2 * c4n)), e = (int)(t - (size_t)pix * (2 * c4n));
+    const int yy = pix / W, xx = pix - yy * W;
+    const float4 v = reinterpret_cast<const float4*>(y + ((size_t)b * H * W + pix) * (2 * C))[e];
+    float* m = e < c4n ? b1p : b2p;
+    reinterpret_cast<float4*>(m + (((size_t)b * Hp + yy + pg) * Wp + xx + pg) * C)[e < c4n ? e : e - c4n] = v;
+}
+
+__device__ __forceinline__ double gen_block_sum(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ __forceinline__ float gen_block_max(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// MODE 0 adaptive (dagl.py:256-261), 1 the k best (0/1 mask), 2 both.  (T, jt, tie): wide_radix_select's k-th sort key, the last
+// key index taken at that key when the k-th place is tied (ties go to the lower index)
+template <int MODE>
+__device__ __forceinline__ float gen_logit(float s, int j, float mtq, float bsq, float scale, unsigned T, int jt, bool& pass) {
+    float m = 1.f;
+    if (MODE != 1) { m = (s - mtq) + bsq; pass = m > 0.f; }          // expression order of dagl.py:256
+    if (MODE != 0) {
+        const unsigned key = wide_key(s, MODE == 2, mtq, bsq);
+        pass = key != 0u && (key > T || (key == T && j <= jt));
+    }
+    return pass ? __fmul_rn(__fmul_rn(s, m), scale) : 0.f;            // (S m) softmax_scale, dagl.py:259-260
+}
+
+// one block per query row of the chunk: S row -> A row in place
+template <int MODE>
+__global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long ldn, int L, int l0, int b, int k, float scale,
+                                                              float* __restrict__ sbuf, const float* __restrict__ tb,
+                                                              int32_t* __restrict__ deg) {
+    __shared__ double shd[4];
+    __shared__ float shf[4];
+    __shared__ WideSelShared shs;
+    __shared__ int sh_cnt[4];
+    __shared__ int sh_jt;
+    const int lr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t ql = (size_t)b * L + l0 + lr;
+    float* row = sbuf + (size_t)lr * ldn;
+    float mtq = 0.f, bsq = 0.f;
+    if (MODE != 1) {
+        double sm = 0.0;
+        for (int j = tid; j < N; j += 256) sm += (double)row[j];
+        const float mean = (float)(gen_block_sum(sm, shd) / (double)N);           // yi.mean(dim=1), dagl.py:256
+        mtq = __fmul_rn(mean, tb[2 * ql]); bsq = tb[2 * ql + 1];
+    }
+    unsigned T = 0u; int jt = 0x7fffffff;
+    if (MODE != 0) {
+        unsigned need, bin_count;
+        wide_radix_select(row, N, k, MODE == 2, mtq, bsq, shs, T, need, bin_count);
+        if (need < bin_count) {                                    // block-uniform: a tie at the k-th place, the `need` lowest key indices win
+            int run = 0;
+            for (int j0 = 0; j0 < N; j0 += 256) {
+                const int j = j0 + tid;
+                const bool eq = j < N && wide_key(row[j], MODE == 2, mtq, bsq) == T;
+                const unsigned long long eqb = __ballot(eq);
+                if (lane == 0) sh_cnt[w] = __popcll(eqb);
+                __syncthreads();
+                int before = run;
+                for (int u = 0; u < w; ++u) before += sh_cnt[u];
+                const int rank = before + __popcll(eqb & ((1ull << lane) - 1ull));
+                if (eq && rank == (int)need - 1) sh_jt = j;
+                run += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+                __syncthreads();
+                if (run >= (int)need) break;
+            }
+            jt = sh_jt;
+        }
+    }
+    float mx = 0.f; int cnt = 0;                                   // a masked key's logit is 0 (dagl.py:259: yi * mask)
+    bool any_masked = false;
+    for (int j = tid; j < N; j += 256) {
+        bool pass;
+        const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
+        cnt += pass ? 1 : 0;
+        any_masked |= !pass;
+        mx = (j == tid && !any_masked) ? l : fmaxf(mx, l);         // (first element seeds the maximum; masked ones contribute their 0)
+    }
+    if (tid >= N) mx = -__builtin_inff();
+    const float M = gen_block_max(mx, shf);
+    double z = 0.0;
+    for (int j = tid; j < N; j += 256) {
+        bool pass;
+        const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
+        z += (double)expf(l - M);
+    }
+    const float invz = (float)(1.0 / gen_block_sum(z, shd));
+    for (int j = tid; j < N; j += 256) {
+        bool pass;
+        const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
+        row[j] = pass ? expf(l - M) * invz : 0.f;                  // softmax * mask_b, dagl.py:260-261
+    }
+    for (int j = N + tid; j < ldn; j += 256) row[j] = 0.f;
+    const double Cn = gen_block_sum((double)cnt, shd);
+    if (tid == 0 && deg != nullptr) deg[ql] = (int32_t)Cn;
+}
+
+// out[b,c,y,x] = sum over the fold's blocks covering (y,x) of agg[b, block, (kh,kw,c)] / max(count, 1 if 0)   (dagl.py:265-272)
+__global__ __launch_bounds__(256) void gen_fold_normalize_kernel(int C, int H, int W, int ks, int s1, int pad, int fh, int fw,
+                                                                 const float* __restrict__ agg, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)C * H * W) return;
+    const int x = (int)(t % W); const int y = (int)((t / W) % H); const int c = (int)(t / ((size_t)W * H));
+    const size_t P_ = (size_t)ks * ks * C;
+    float acc = 0.f; int cnt = 0;
+    for (int kh = 0; kh < ks; ++kh) {
+        const int ty = y + pad - kh;
+        if (ty < 0 || ty % s1 != 0 || ty / s1 >= fh) continue;
+        for (int kw = 0; kw < ks; ++kw) {
+            const int tx = x + pad - kw;
+            if (tx < 0 || tx % s1 != 0 || tx / s1 >= fw) continue;
+            acc += agg[((size_t)b * fh * fw + (size_t)(ty / s1) * fw + tx / s1) * P_ + (size_t)(kh * ks + kw) * C + c];
+            ++cnt;
+        }
+    }
+    out[(size_t)b * C * H * W + t] = acc / (float)(cnt == 0 ? 1 : cnt);             // out_mask += (out_mask == 0), dagl.py:271
+}
+
+Gemm32 gen_gemm(int M, int N, int K, const float* A, long long lda, const float* Bm, long long ldb, int b_kc, float* Cm, long long ldc,
+                const float* bias, int relu) {
+    Gemm32 g;
+    g.M = M; g.N = N; g.K = K; g.batch = 1;
+    g.A = A; g.lda = lda; g.sA = 0; g.a_kc = 1;
+    g.B = Bm; g.ldb = ldb; g.sB = 0; g.b_kc = b_kc;
+    g.C = Cm; g.ldc = ldc; g.sC = 0;
+    g.alpha = 1.f; g.beta = 0.f; g.bias = bias; g.relu = relu;
+    g.chunk_tiles = 7;                              // partial sums of 112 products added in fp32: shorter rounding chains
+    return g;
+}
+
+inline dim3 gen_grid(size_t n, int B) { return dim3((unsigned)((n + 255) / 256), (unsigned)B); }
+
+}  // namespace
+
+size_t ce_generic_workspace_bytes(int B, int Cin, int H, int W, int ks, int s1, int s2, int C) {
+    return gen_plan(gen_geom(B, Cin, H, W, ks, s1, s2, C)).o_end + 256;
+}
+
+int ce_generic_check(int B, int Cin, int H, int W, int ks, int s1, int s2, int C, int mode, int k) {
+    DAGL_REQUIRE(B >= 1 && H >= 1 && W >= 1, "dagl_ce_generic_forward: bad shape");
+    DAGL_REQUIRE(ks >= 1 && ks <= 31 && s1 >= 1 && s2 >= 1, "dagl_ce_generic_forward: ksize in 1..31, strides >= 1");
+    DAGL_REQUIRE(Cin >= 4 && Cin % 4 == 0 && C >= 4 && C % 4 == 0,
+                 "dagl_ce_generic_forward: in_channels and inter_channels must be multiples of 4 (16-byte pixels of the NHWC maps)");
+    DAGL_REQUIRE(mode == DAGL_MODE_ADAPTIVE || mode == DAGL_MODE_TOPK || mode == DAGL_MODE_ADAPTIVE_TOPK, "dagl_ce_generic_forward: bad mode");
+    DAGL_REQUIRE(mode == DAGL_MODE_ADAPTIVE || k >= 1, "dagl_ce_generic_forward: k >= 1 in the top-k modes");
+    const GenGeom g = gen_geom(B, Cin, H, W, ks, s1, s2, C);
+    // F.fold (dagl.py:267) raises when its block grid does not hold exactly the L query patches
+    DAGL_REQUIRE(g.fold_h >= 1 && g.fold_w >= 1 && (long long)g.fold_h * g.fold_w == (long long)g.L,
+                 "dagl_ce_generic_forward: fold(kernel %d, padding %d, stride %d) of a %dx%d map has %dx%d blocks, the query grid %dx%d "
+                 "(the reference's F.fold raises on this geometry too)", ks, g.fold_pad, s1, H, W, g.fold_h, g.fold_w, g.Lh, g.Lw);
+    return DAGL_OK;
+}
+
+int launch_ce_generic(hipStream_t s, int B, int Cin, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                      const float* x, const float* g_w, const float* g_b, const float* th_w, const float* th_b, const float* thr_w,
+                      const float* thr_b, const float* bias_w, const float* bias_b, const float* fc1_w, const float* fc1_b,
+                      const float* fc2_w, const float* fc2_b, float* out, int32_t* degree, void* workspace) {
+    const GenGeom g = gen_geom(B, Cin, H, W, ks, s1, s2, C);
+    const GenPlan p = gen_plan(g);
+    char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) / 256 * 256);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    const size_t HW = (size_t)H * W;
+    const bool heads = mode != DAGL_MODE_TOPK;
+
+    // ---- weights in the unfold's element order ------------------------------------------------------------------------------
+    const long long kg = 9ll * Cin;
+    DAGL_HIP_TRY(hipMemsetAsync(F(p.o_wgt), 0, (size_t)2 * C * kg * 4, s));
+    hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)(((size_t)C * kg + 255) / 256)), dim3(256), 0, s, C, Cin, 3, g_w, F(p.o_wgt), kg, 0ll);
+    hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)(((size_t)C * Cin + 255) / 256)), dim3(256), 0, s, C, Cin, 1, th_w,
+                       F(p.o_wgt) + (size_t)C * kg, kg, 4ll * Cin);                       // theta = the centre tap
+    DAGL_HIP_TRY(hipMemcpyAsync(F(p.o_bgt), g_b, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    DAGL_HIP_TRY(hipMemcpyAsync(F(p.o_bgt) + C, th_b, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)(((size_t)g.D * g.P + 255) / 256)), dim3(256), 0, s, g.D, C, ks, fc1_w, F(p.o_fc1), (long long)g.P, 0ll);
+    hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)(((size_t)g.D * g.P + 255) / 256)), dim3(256), 0, s, g.D, C, ks, fc2_w, F(p.o_fc2), (long long)g.P, 0ll);
+    const long long ktb = (long long)ks * ks * Cin;
+    if (heads) {
+        hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)((ktb + 255) / 256)), dim3(256), 0, s, 1, Cin, ks, thr_w, F(p.o_wtb), ktb, 0ll);
+        hipLaunchKernelGGL(gen_weight_rows_kernel, dim3((unsigned)((ktb + 255) / 256)), dim3(256), 0, s, 1, Cin, ks, bias_w, F(p.o_wtb) + ktb, ktb, 0ll);
+        DAGL_HIP_TRY(hipMemcpyAsync(F(p.o_btb), thr_b, 4, hipMemcpyDeviceToDevice, s));
+        DAGL_HIP_TRY(hipMemcpyAsync(F(p.o_btb) + 1, bias_b, 4, hipMemcpyDeviceToDevice, s));
+    }
+    DAGL_LAUNCH_CHECK("gen_weight_rows_kernel");
+
+    // ---- prologue convolutions, dagl.py:208-215 -----------------------------------------------------------------------------
+    hipLaunchKernelGGL(gen_pad_nhwc_kernel, gen_grid((size_t)g.Hp * g.Wp * (Cin / 4), B), dim3(256), 0, s, Cin, H, W, g.PG, x, F(p.o_xp));
+    DAGL_LAUNCH_CHECK("gen_pad_nhwc_kernel");
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, Cin, 3, 1, g.PG - 1, g.PG - 1, H, W, F(p.o_xp), F(p.o_rows)))) return rc;
+    if ((rc = launch_gemm32(s, gen_gemm((int)(B * HW), 2 * C, (int)kg, F(p.o_rows), kg, F(p.o_wgt), kg, 1, F(p.o_y), 2 * C, F(p.o_bgt), 0)))) return rc;
+    DAGL_HIP_TRY(hipMemsetAsync(F(p.o_b1p), 0, (size_t)B * g.Hp * g.Wp * C * 4, s));
+    DAGL_HIP_TRY(hipMemsetAsync(F(p.o_b2p), 0, (size_t)B * g.Hp * g.Wp * C * 4, s));
+    hipLaunchKernelGGL(gen_split_maps_kernel, gen_grid(HW * 2 * (C / 4), B), dim3(256), 0, s, C, H, W, g.PG, F(p.o_y), F(p.o_b1p), F(p.o_b2p));
+    DAGL_LAUNCH_CHECK("gen_split_maps_kernel");
+    if (heads) {
+        if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, Cin, ks, s1, g.PG - g.t1, g.PG - g.l1, g.Lh, g.Lw, F(p.o_xp), F(p.o_rows)))) return rc;
+        if ((rc = launch_gemm32(s, gen_gemm(B * g.L, 2, (int)ktb, F(p.o_rows), ktb, F(p.o_wtb), ktb, 1, F(p.o_tb), 2, F(p.o_btb), 0)))) return rc;
+    }
+
+    // ---- patch features, dagl.py:216-249 ------------------------------------------------------------------------------------
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s1, g.PG - g.t1, g.PG - g.l1, g.Lh, g.Lw, F(p.o_b1p), F(p.o_rows)))) return rc;
+    if ((rc = launch_gemm32(s, gen_gemm(B * g.L, g.D, g.P, F(p.o_rows), g.P, F(p.o_fc1), g.P, 1, F(p.o_wq), g.D, fc1_b, 1)))) return rc;
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, F(p.o_b1p), F(p.o_rows)))) return rc;
+    if ((rc = launch_gemm32(s, gen_gemm(B * g.N, g.D, g.P, F(p.o_rows), g.P, F(p.o_fc2), g.P, 1, F(p.o_x), g.D, fc2_b, 1)))) return rc;
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, F(p.o_b2p), F(p.o_rows)))) return rc;   // value rows
+
+    // ---- graph core, dagl.py:250-264, a chunk of query rows at a time -------------------------------------------------------
+    const int kk = k < g.N ? k : g.N;                                      // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
+    for (int b = 0; b < B; ++b) {
+        const float* Xb = F(p.o_x) + (size_t)b * g.N * g.D;
+        const float* Vb = F(p.o_rows) + (size_t)b * g.N * g.P;
+        for (int l0 = 0; l0 < g.L; l0 += g.Lc) {
+            const int lc = (g.L - l0 < g.Lc) ? g.L - l0 : g.Lc;
+            const float* Wqc = F(p.o_wq) + ((size_t)b * g.L + l0) * g.D;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.D, Wqc, g.D, Xb, g.D, 1, F(p.o_s), g.ldn, nullptr, 0)))) return rc;
+#define GEN_ROWS(M_) hipLaunchKernelGGL((gen_row_softmax_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, F(p.o_s), F(p.o_tb), degree)
+            if (mode == DAGL_MODE_ADAPTIVE) GEN_ROWS(0); else if (mode == DAGL_MODE_TOPK) GEN_ROWS(1); else GEN_ROWS(2);
+#undef GEN_ROWS
+            DAGL_LAUNCH_CHECK("gen_row_softmax_kernel");
+            Gemm32 av = gen_gemm(lc, g.P, g.N, F(p.o_s), g.ldn, Vb, g.P, 0, F(p.o_agg) + ((size_t)b * g.L + l0) * g.P, g.P, nullptr, 0);
+            if ((rc = launch_gemm32(s, av))) return rc;
+        }
+    }
+
+    // ---- fold + overlap count, dagl.py:265-272 ------------------------------------------------------------------------------
+    hipLaunchKernelGGL(gen_fold_normalize_kernel, gen_grid((size_t)C * HW, B), dim3(256), 0, s, C, H, W, ks, s1, g.fold_pad, g.fold_h, g.fold_w,
+                       F(p.o_agg), out);
+    DAGL_LAUNCH_CHECK("gen_fold_normalize_kernel");
+    return DAGL_OK;
+}
+
+}  // namespace dagl

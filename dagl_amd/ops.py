@@ -310,6 +310,46 @@ def ce_forward(b1, b2, thr, bias, fc1_w, fc1_b, fc2_w, fc2_b, mode: str = "adapt
 
 
 @_on_device
+def ce_forward_generic(x, params: dict, ksize: int, stride_1: int, stride_2: int, inter_channels: int, mode: str = "adaptive",
+                       k: int = 0, softmax_scale: float = 10.0, workspace: "Workspace | None" = None, want_degree: bool = False):
+    """``CE.forward`` for ANY patch geometry (``dagl_ce_generic_forward``, csrc/generic.hip; dagl.py:175-176 makes ksize, stride_1,
+    stride_2 and inter_channels constructor arguments): x [B,Cin,H,W] fp32 -> [B,inter_channels,H,W].  ``params`` = the block's
+    state_dict tensors under their own names (fp32, on the device); Cin and inter_channels multiples of 4."""
+    lib = _lib.load()
+    if mode not in MODES:
+        raise DaglError(f"unknown mode {mode!r}")
+    _need(x, "x")
+    B, Cin, H, W = x.shape
+    c, ks = int(inter_channels), int(ksize)
+    P_, heads = ks * ks * c, mode != "topk"
+    want = {"g.weight": (c, Cin, 3, 3), "g.bias": (c,), "theta.weight": (c, Cin, 1, 1), "theta.bias": (c,),
+            "fc1.0.weight": (P_ // 4, P_), "fc1.0.bias": (P_ // 4,), "fc2.0.weight": (P_ // 4, P_), "fc2.0.bias": (P_ // 4,)}
+    if heads:
+        want.update({"thr_conv.weight": (1, Cin, ks, ks), "thr_conv.bias": (1,), "bias_conv.weight": (1, Cin, ks, ks), "bias_conv.bias": (1,)})
+    for n, shp in want.items():
+        _need(params[n], n)
+        if tuple(params[n].shape) != shp:
+            raise DaglError(f"ce_forward_generic: {n} is {tuple(params[n].shape)}, expected {shp}")
+    need = lib.dagl_ce_generic_workspace_bytes(B, Cin, H, W, ks, int(stride_1), int(stride_2), c)
+    if need == 0:
+        raise DaglError(f"ce_forward_generic: unsupported shape / geometry B={B} Cin={Cin} H={H} W={W} ksize={ks} "
+                        f"strides=({stride_1},{stride_2}) inter_channels={c}")
+    ws = workspace if workspace is not None else Workspace()
+    buf = ws.get(need, x.device)
+    out = torch.empty(B, c, H, W, device=x.device, dtype=torch.float32)
+    L = (-(-H // int(stride_1))) * (-(-W // int(stride_1)))
+    deg = torch.empty(B, L, device=x.device, dtype=torch.int32) if want_degree else None
+    ptr = lambda n: params[n].data_ptr() if n in want else None
+    check(lib.dagl_ce_generic_forward(_stream(), B, Cin, H, W, ks, int(stride_1), int(stride_2), c, float(softmax_scale), MODES[mode], int(k),
+                                      x.data_ptr(), ptr("g.weight"), ptr("g.bias"), ptr("theta.weight"), ptr("theta.bias"),
+                                      ptr("thr_conv.weight"), ptr("thr_conv.bias"), ptr("bias_conv.weight"), ptr("bias_conv.bias"),
+                                      ptr("fc1.0.weight"), ptr("fc1.0.bias"), ptr("fc2.0.weight"), ptr("fc2.0.bias"),
+                                      out.data_ptr(), deg.data_ptr() if deg is not None else None, buf.data_ptr(), buf.numel()),
+          "dagl_ce_generic_forward")
+    return (out, deg) if want_degree else out
+
+
+@_on_device
 def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None, fast=False):
     """The four prologue convolutions (dagl.py:208-215) -> (b1_nhwc, b2_nhwc, thr, bias); heads optional."""
     for n, t in (("x", x), ("g_w", g_w), ("g_b", g_b), ("theta_w", theta_w), ("theta_b", theta_b)):

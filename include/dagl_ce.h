@@ -169,7 +169,7 @@ int dagl_ce_range_check(void* stream, int B, int H, int W, int mode, int k, void
  * the workspace layout carries the top-k policy words; 403: dagl_ce_core_wide_forward / _backward; 404:
  * dagl_ce_info.dense_rerun_blocks in the place of `reserved`; 405: dagl_fc_grad16_dmap).  A caller compares
  * dagl_version() with the DAGL_ABI_VERSION it was built against and refuses a mismatch (dagl_amd/_lib.py does).           */
-#define DAGL_ABI_VERSION 405
+#define DAGL_ABI_VERSION 406
 int         dagl_version(void);                 /* DAGL_ABI_VERSION of the library = 10000*major + 100*minor + patch */
 const char* dagl_last_error(void);              /* thread-local, never NULL                         */
 int         dagl_device_check(void);            /* OK iff the current HIP device is gfx950          */
@@ -496,6 +496,25 @@ int dagl_fold_normalize(void* stream, int B, int H, int W, const float* agg, flo
 
 /* Dense score matrix S = Wq . X^T for tests (dagl.py:250): s [B,L,N].                            */
 int dagl_scores_dense(void* stream, int B, int L, int N, const float* wq, const float* x, float* s);
+
+/* (ABI 406) CE.forward for ANY patch geometry.  ksize, stride_1, stride_2 and inter_channels are constructor arguments of the
+ * reference block (DN_Gray/model/dagl.py:175-176; its own builders, dagl.py:94-109, never override them, so every tuned kernel has
+ * (7, 4, 1, 16) compiled in).  This entry runs the reference's dense formulation, dagl.py:207-275, with the geometry as run-time
+ * arguments -- unfold + fp32 matrix-core products, one chunk of score rows (<= 256 MiB) at a time, row-wise mask / softmax, fold
+ * with the reference's padding rule (dagl.py:243: the stride_2 SAME grid's left pad) -- csrc/generic.hip.  Replaces the Python
+ * call self.cX_Y(x) of a CE built with non-default arguments (dagl.py:114-118).
+ *   x [B,Cin,H,W] fp32 NCHW;  g_w [c,Cin,3,3], theta_w [c,Cin,1,1], thr_w / bias_w [1,Cin,ksize,ksize] (may be NULL in
+ *   DAGL_MODE_TOPK), fc1_w / fc2_w [P/4, P] over Unfold's (c,kh,kw) patch order with P = ksize^2 c -- the state_dict's own
+ *   layouts, nothing pre-packed;  out [B,c,H,W];  degree [B*L] int32 or NULL (neighbours per query);  Cin and c multiples of 4.
+ *   softmax_scale: dagl.py:175 (10 by default), any positive value.  k: the fixed-k modes' num_edge (min(k, N) keys are kept).
+ * A geometry whose F.fold block grid does not hold exactly the L query patches raises in the reference; here DAGL_ERR_INVALID.  */
+size_t dagl_ce_generic_workspace_bytes(int B, int Cin, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels);
+int dagl_ce_generic_forward(void* stream, int B, int Cin, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                            float softmax_scale, int mode, int k, const float* x,
+                            const float* g_w, const float* g_b, const float* theta_w, const float* theta_b,
+                            const float* thr_w, const float* thr_b, const float* bias_w, const float* bias_b,
+                            const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                            float* out, int32_t* degree, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,8 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
                       mode: str = "adaptive", k: Optional[int] = None,
                       dtype: torch.dtype = torch.float32,
                       zero_guard: bool = True,
-                      stages: bool = False, softmax_scale: float = 10.0):
+                      stages: bool = False, softmax_scale: float = 10.0,
+                      ksize: int = KSIZE, stride_q: int = STRIDE_Q, stride_kv: int = STRIDE_KV):
     """Dense restatement of ``CE.forward``.
 
     x       [B, C, H, W]
@@ -85,6 +86,8 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     zero_guard  DN_Gray's ``out_mask += (out_mask==0)`` (dagl.py:271); a
             numerical no-op because the count is never 0
     stages  also return the per-sample intermediates
+    ksize, stride_q, stride_kv   the ctor's ksize / stride_1 / stride_2 (dagl.py:175;
+            inter_channels is read off the weights); defaults = what ships
 
     Returns out ``[B, c, H, W]`` (and a dict of stage tensors when asked).
     """
@@ -99,17 +102,20 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     # prologue, dagl.py:208-215
     b1 = F.conv2d(x, P["g.weight"], P["g.bias"], padding=1)           # keys + queries
     b2 = F.conv2d(x, P["theta.weight"], P["theta.bias"])              # values
-    xq, _ = same_pad(x, KSIZE, STRIDE_Q)
-    thr = F.conv2d(xq, P["thr_conv.weight"], P["thr_conv.bias"], stride=STRIDE_Q).reshape(B, -1)
-    bias = F.conv2d(xq, P["bias_conv.weight"], P["bias_conv.bias"], stride=STRIDE_Q).reshape(B, -1)
+    xq, _ = same_pad(x, ksize, stride_q)
+    if mode == "topk" and "thr_conv.weight" not in P:                 # (the fixed-k variant has no threshold heads)
+        thr = bias = torch.zeros(B, (-(-H // stride_q)) * (-(-W // stride_q)), dtype=dtype)
+    else:
+        thr = F.conv2d(xq, P["thr_conv.weight"], P["thr_conv.bias"], stride=stride_q).reshape(B, -1)
+        bias = F.conv2d(xq, P["bias_conv.weight"], P["bias_conv.bias"], stride=stride_q).reshape(B, -1)
 
     # patch extraction, dagl.py:216-240
-    q_rows = patch_rows(b1, KSIZE, STRIDE_Q)    # [B, L, 784]
-    v_rows = patch_rows(b2, KSIZE, STRIDE_KV)   # [B, N, 784]
-    k_rows = patch_rows(b1, KSIZE, STRIDE_KV)   # [B, N, 784]
-    fold_pad = same_pad(b1[:1, :1], KSIZE, STRIDE_KV)[1][0]           # dagl.py:243 -> 3
+    q_rows = patch_rows(b1, ksize, stride_q)    # [B, L, 784]
+    v_rows = patch_rows(b2, ksize, stride_kv)   # [B, N, 784]
+    k_rows = patch_rows(b1, ksize, stride_kv)   # [B, N, 784]
+    fold_pad = same_pad(b1[:1, :1], ksize, stride_kv)[1][0]           # dagl.py:243 -> 3 (paddings[0]: the LEFT pad, for both axes)
 
-    cnt = overlap_count(H, W, dtype, pad=fold_pad)
+    cnt = overlap_count(H, W, dtype, ksize=ksize, stride=stride_q, pad=fold_pad)
     if zero_guard:
         cnt = cnt + (cnt == 0).to(dtype)                              # dagl.py:271
 
@@ -118,7 +124,7 @@ def ce_forward_oracle(x: torch.Tensor, params: Dict[str, torch.Tensor], *,
     for n in range(B):                                                # dagl.py:245
         Wq = F.relu(F.linear(q_rows[n], P["fc1.0.weight"], P["fc1.0.bias"]))  # [L,196] :248
         X = F.relu(F.linear(k_rows[n], P["fc2.0.weight"], P["fc2.0.bias"]))   # [N,196] :249
-        z, c = _graph_core(Wq, X, thr[n], bias[n], v_rows[n], mode, k, H, W, fold_pad, softmax_scale)
+        z, c = _graph_core(Wq, X, thr[n], bias[n], v_rows[n], mode, k, H, W, fold_pad, softmax_scale, ksize, stride_q)
         outs.append(z / cnt)                                                   # :272
         if stages:
             st["Wq"].append(Wq); st["X"].append(X)
@@ -139,7 +145,7 @@ def _k_best(S: torch.Tensor, kk: int) -> torch.Tensor:
     return torch.sort(S, dim=1, descending=True, stable=True).indices[:, :kk]
 
 
-def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax_scale=SOFTMAX_SCALE):
+def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax_scale=SOFTMAX_SCALE, ksize=KSIZE, stride_q=STRIDE_Q):
     """One sample of dagl.py:250-267 from its feature rows: similarity, mask, edge softmax, aggregate, fold
     (not yet divided by the overlap count).  Returns (folded [1,c,H,W], dict of intermediates)."""
     dtype = Wq.dtype
@@ -163,8 +169,8 @@ def _graph_core(Wq, X, thr_n, bias_n, v_rows_n, mode, k, H, W, fold_pad, softmax
     agg = A @ v_rows_n                                                         # [L,784] :263-264
     z = None
     if fold_pad is not None:                          # (None: a sample of the queries, nothing to fold)
-        z = F.fold(agg.t().unsqueeze(0), (H, W), (KSIZE, KSIZE),
-                   padding=fold_pad, stride=STRIDE_Q)                          # :265-267
+        z = F.fold(agg.t().unsqueeze(0), (H, W), (ksize, ksize),
+                   padding=fold_pad, stride=stride_q)                          # :265-267
     return z, dict(S=S, T=T, deg=mb.sum(dim=1), rowsum=A.sum(dim=1), agg=agg, mask_b=mb)
 
 

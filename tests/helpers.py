@@ -15,10 +15,16 @@ def load_golden(path):
     return meta, {k: z[k] for k in ("out", "deg", "rowsum", "agg_sub")}
 
 
+def load_geometry_golden(path):
+    z = np.load(path, allow_pickle=False)
+    return json.loads(str(z["meta"])), {k: z[k] for k in ("out", "deg")}
+
+
 def case_inputs(meta):
     """Regenerate (x, params) of a golden case from its seed (numpy PCG64)."""
     from dagl_amd.synth import make_ce_params, make_features
-    p = make_ce_params(meta["seed"], in_channels=meta["C"], variant=meta["variant"], sparse_gain=meta["sparse_gain"])
+    p = make_ce_params(meta["seed"], in_channels=meta["C"], inter_channels=meta.get("inter_channels", 16), ksize=meta.get("ksize", 7),
+                       variant=meta["variant"], sparse_gain=meta["sparse_gain"])
     x = make_features(meta["seed"], meta["B"], meta["C"], meta["H"], meta["W"])
     return torch.from_numpy(x), {n: torch.from_numpy(a) for n, a in p.items()}
 
