@@ -329,12 +329,35 @@ def extra_configs(dev):
                                           "ms_per_step": ms, "patches_per_s": 4 * 4096 / (ms * 1e-3), "L": 4096, "N": 65536}
         del heads, prm, x, ws
         torch.cuda.empty_cache()
+    out["128x128_geometry_k5_s2_generic"] = generic_geometry_extra(dev)
     out["256x256_set12_features"] = real_features_extra(dev)
     out["train_rr_topk8_128x128_b8"] = train_extra(dev)
     out["train_rr_adaptive_128x128_b8"] = train_extra(dev, steps=4, warmup=2, mode="adaptive")
     # the reference trainer's own default shape: DN_Gray --patch_size 64 --batch_size 32 (option.py:42,88), shipped adaptive semantics
     out["train_rr_adaptive_64x64_b32_gray"] = train_extra(dev, B=32, crop=64, colors=1, steps=4, warmup=2, mode="adaptive")
     return out
+
+
+def generic_geometry_extra(dev):
+    """A head built with a NON-default patch geometry -- CE(ksize=5, stride_1=2, stride_2=1): ctor arguments of the reference block
+    (dagl.py:175-176) that none of the tuned kernels holds -- through ``dagl_ce_generic_forward`` (csrc/generic.hip: the reference's dense
+    formulation, unfold + fp32 matrix cores, score rows a chunk at a time).  [1,64,128,128]: L = 4096 queries, N = 16384 keys, P = 400."""
+    from dagl_amd.ce import CE
+    from dagl_amd.synth import make_ce_params, make_features
+    prm = {n: torch.from_numpy(a) for n, a in make_ce_params(2024, ksize=5, variant="sparse", sparse_gain=1.6).items()}
+    ce = CE(ksize=5, stride_1=2, stride_2=1)
+    ce.load_state_dict(prm, strict=True)
+    ce = ce.to(dev).eval()
+    x = torch.from_numpy(make_features(100, 1, 64, 128, 128)).to(dev)
+    with torch.no_grad():
+        ms = _time_steps(lambda: ce(x), 10, 3, EXTRA_PREWARM_S)
+        deg = ce.last_info["degree"].float()
+    L, N, P_, D_ = 4096, 16384, 400, 100
+    flop = 2.0 * L * N * (D_ + P_) + 2.0 * (L + N) * P_ * D_
+    return {"what": "CE(ksize=5, stride_1=2, stride_2=1) on [1,64,128,128], shipped adaptive semantics: the run-time-geometry route "
+                    "(dagl_ce_generic_forward; fp32 matrix cores, not tuned)", "ms_per_step": ms, "patches_per_s": L / (ms * 1e-3), "L": L, "N": N,
+            "mean_degree": float(deg.mean()), "max_degree": int(deg.max()),
+            "fp32_tflops": flop / (ms * 1e-3) / 1e12, "flop_note": "scores + A V + the two projections, 2 L N (D + P) + 2 (L + N) P D"}
 
 
 def real_features_extra(dev):

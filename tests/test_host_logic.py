@@ -51,8 +51,9 @@ def test_module_surface_matches_reference_block():
 def test_module_rejects_cpu_and_foreign_hyperparameters():
     from dagl_amd._lib import DaglError
     from dagl_amd.ce import CE
-    with pytest.raises(DaglError):
-        CE(ksize=5)
+    assert CE(ksize=5)._generic                              # (any patch geometry since round 6: tests/test_geometry_oracle.py)
+    with pytest.raises(DaglError, match="inter_channels"):
+        CE(inter_channels=10)
     with pytest.raises(DaglError, match="softmax_scale"):
         CE(softmax_scale=0)
     # softmax_scale is served by scaling fc1 (and the bias head) on the module side: c^2 = scale / 10, c = scale / 10 in top-k mode
