@@ -122,6 +122,10 @@ SIGNATURES = {
     "dagl_scores_dense": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "dagl_ce_generic_workspace_bytes": (_sz, [_i] * 8),
     "dagl_ce_generic_forward": (_i, [_vp] + [_i] * 8 + [C.c_float, _i, _i] + [_vp] * 16 + [_sz]),
+    "dagl_ce_generic_border": (_i, [_i]),
+    "dagl_ce_generic_core_workspace_bytes": (_sz, [_i] * 8),
+    "dagl_ce_generic_core_forward": (_i, [_vp] + [_i] * 7 + [C.c_float, _i, _i] + [_vp] * 8 + [_sz]),
+    "dagl_ce_generic_core_backward": (_i, [_vp] + [_i] * 7 + [C.c_float, _i, _i] + [_vp] * 12 + [_sz]),
 }
 
 _lib = None

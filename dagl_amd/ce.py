@@ -86,6 +86,31 @@ class _GraphCoreDense(torch.autograd.Function):
         return d_wq, d_x, d_b2, d_thr.view(ctx.thr_shape), d_bias.view(ctx.thr_shape), None, None, None, None, None
 
 
+class _GraphCoreGeneric(torch.autograd.Function):
+    """dagl.py:250-272 under autograd for a module built with a non-default patch geometry (``dagl_ce_generic_core_forward`` /
+    ``_backward``, csrc/generic.hip): the dense formulation on the fp32 matrix cores, S and A recomputed chunk by chunk in the backward."""
+
+    @staticmethod
+    def forward(ctx, wq_rows, x_rows, b2p, thr, bias, geom, mode, k, scale, ws_f, ws_b):
+        H, W, ks, s1, s2 = geom
+        heads = mode != "topk"
+        wq_rows, x_rows, b2p = wq_rows.contiguous(), x_rows.contiguous(), b2p.contiguous()
+        thr_c, bias_c = (thr.contiguous(), bias.contiguous()) if heads else (None, None)
+        out = ops.ce_generic_core_forward(wq_rows, x_rows, b2p, thr_c, bias_c, H, W, ks, s1, s2, mode=mode, k=k, softmax_scale=scale, workspace=ws_f)
+        ctx.geom, ctx.mode, ctx.k, ctx.scale, ctx.ws_b, ctx.heads = geom, mode, k, scale, ws_b, heads
+        ctx.save_for_backward(*([wq_rows, x_rows, b2p] + ([thr_c, bias_c] if heads else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        wq_rows, x_rows, b2p, *tb = ctx.saved_tensors
+        thr, bias = tb if ctx.heads else (None, None)
+        H, W, ks, s1, s2 = ctx.geom
+        d_wq, d_x, d_b2p, d_thr, d_bias = ops.ce_generic_core_backward(d_out.contiguous().float(), wq_rows, x_rows, b2p, thr, bias, H, W, ks, s1, s2,
+                                                                       mode=ctx.mode, k=ctx.k, softmax_scale=ctx.scale, workspace=ctx.ws_b)
+        return d_wq, d_x, d_b2p, d_thr, d_bias, None, None, None, None, None, None
+
+
 class _GraphCoreWide(torch.autograd.Function):
     """dagl.py:250-272 in the top-k modes when min(k, N) exceeds the lists' width (the fixed-k variant takes any num_edge,
     GReccR2b_3mh_1-checkpoint.py:242-250; CA_model-checkpoint.py:134-143 uses 500): the dense formulation with the row-wise
@@ -473,11 +498,10 @@ class CE(nn.Module):
         # the autograd graph (_EvalLazyGrad): should a backward arrive after all, it recomputes the block on the
         # differentiable path then -- same gradients, paid only when used.
         if self._generic:
-            if torch.is_grad_enabled() and self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
-                raise DaglError("CE: the differentiable path implements the shipped patch geometry (7, 4, 1, 16) only; a module with "
-                                f"(ksize, stride_1, stride_2, inter_channels) = ({self.ksize}, {self.stride_1}, {self.stride_2}, "
-                                f"{self.inter_channels}) serves eval() / torch.no_grad() calls")
-            out = self._forward_infer_generic(b, k_eff)
+            if torch.is_grad_enabled() and (b.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+                out = self._forward_train_generic(b.contiguous(), k_eff)
+            else:
+                out = self._forward_infer_generic(b, k_eff)
             return out if in_dtype == torch.float32 else out.to(in_dtype)
         if torch.is_grad_enabled():
             if self.training and (b.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -515,6 +539,45 @@ class CE(nn.Module):
         self._pack_key = None                      # the shared workspace holds another layout now
         self.last_info = dict(path=7, degree=deg)  # (device tensor [B,L]: reading it is the caller's synchronisation)
         return out
+
+    def _forward_train_generic(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
+        """Differentiable route of a module with a non-default patch geometry: every convolution / Linear-over-patches as unfold + fp32
+        matrix-core product with explicit adjoints (train_ops.patch_linear: any window, stride, channel count), the graph core as
+        ``_GraphCoreGeneric``.  Layout plumbing (NCHW -> zero-bordered NHWC) is torch's: autograd carries it."""
+        from . import train_ops as T
+        if any(p.dtype != torch.float32 for p in self.parameters()):
+            raise DaglError("CE: the differentiable path needs fp32 parameters")
+        from ._lib import load
+        B, Cin, H, W = b.shape
+        ks, s1, s2, c = int(self.ksize), int(self.stride_1), int(self.stride_2), int(self.inter_channels)
+        pg = load().dagl_ce_generic_border(ks)
+        t1, l1 = same_pad_amounts(H, ks, s1)[0], same_pad_amounts(W, ks, s1)[0]
+        t2, l2 = same_pad_amounts(H, ks, s2)[0], same_pad_amounts(W, ks, s2)[0]
+        Lh, Lw, Nh, Nw = -(-H // s1), -(-W // s1), -(-H // s2), -(-W // s2)
+        padc = (-Cin) % 4                             # float4 channel groups: zero channels, zero weight columns
+        def wrows(m):
+            w = F.pad(m.weight, (0, 0, 0, 0, 0, padc)) if padc else m.weight
+            return T.conv_weight_rows(w)
+        def nhwc_bordered(t_nchw):                    # [B,C,H,W] -> zero-bordered NHWC (border pg)
+            return F.pad(t_nchw.permute(0, 2, 3, 1), (0, 0, pg, pg, pg, pg)).contiguous()
+        xp = nhwc_bordered(F.pad(b, (0, 0, 0, 0, 0, padc)) if padc else b)
+        heads = self.select_mode != "topk"
+        b1 = T.patch_linear(xp, wrows(self.g), self.g.bias, 3, 1, pg - 1, pg - 1, H, W, allow_fast=False)             # [B, H*W, c]   dagl.py:208
+        b2 = T.patch_linear(xp, wrows(self.theta), self.theta.bias, 1, 1, pg, pg, H, W, allow_fast=False)               # dagl.py:209
+        thr = bias = None
+        if heads:                                                                                                        # dagl.py:213-215
+            thr = T.patch_linear(xp, wrows(self.thr_conv), self.thr_conv.bias, ks, s1, pg - t1, pg - l1, Lh, Lw, allow_fast=False).reshape(B, -1)
+            bias = T.patch_linear(xp, wrows(self.bias_conv), self.bias_conv.bias, ks, s1, pg - t1, pg - l1, Lh, Lw, allow_fast=False).reshape(B, -1)
+        b1p = F.pad(b1.view(B, H, W, c), (0, 0, pg, pg, pg, pg)).contiguous()
+        b2p = F.pad(b2.view(B, H, W, c), (0, 0, pg, pg, pg, pg)).contiguous()
+        wq_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc1[0].weight, c, ks), self.fc1[0].bias, ks, s1, pg - t1, pg - l1, Lh, Lw,
+                                 relu=True, allow_fast=False)                                                          # dagl.py:248
+        x_rows = T.patch_linear(b1p, T.fc_weight_rows(self.fc2[0].weight, c, ks), self.fc2[0].bias, ks, s2, pg - t2, pg - l2, Nh, Nw,
+                                relu=True, allow_fast=False)                                                           # dagl.py:249
+        self._last_call = None
+        self._pack_key = None
+        return _GraphCoreGeneric.apply(wq_rows, x_rows, b2p, thr, bias, (H, W, ks, s1, s2), self.select_mode, k_eff,
+                                       float(self.softmax_scale), self._ws, self._ws_bwd)
 
     def _forward_infer_any_width(self, b: torch.Tensor, k_eff: int) -> torch.Tensor:
         """``CE(in_channels = n_feats)`` for n_feats != 64 (CES builds every head that way, dagl.py:94-109; ``--n_feats``,

@@ -1566,4 +1566,41 @@ int dagl_ce_generic_forward(void* stream, int B, int Cin, int H, int W, int ksiz
                                    g_w, g_b, theta_w, theta_b, thr_w, thr_b, bias_w, bias_b, fc1_w, fc1_b, fc2_w, fc2_b, out, degree, workspace);
 }
 
+int dagl_ce_generic_border(int ksize) { return dagl::ce_generic_border(ksize); }
+
+size_t dagl_ce_generic_core_workspace_bytes(int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels, int backward) {
+    if (B < 1 || H < 1 || W < 1 || ksize < 1 || ksize > 31 || stride_1 < 1 || stride_2 < 1 || inter_channels < 4) return 0;
+    return dagl::ce_generic_core_workspace_bytes(B, H, W, ksize, stride_1, stride_2, inter_channels, backward);
+}
+
+int dagl_ce_generic_core_forward(void* stream, int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                                 float softmax_scale, int mode, int k, const float* wq_rows, const float* x_rows, const float* b2p,
+                                 const float* thr, const float* bias, float* out, int32_t* degree, void* workspace, size_t workspace_bytes) {
+    int rc = dagl::ce_generic_check(B, 4, H, W, ksize, stride_1, stride_2, inter_channels, mode, k);
+    if (rc) return rc;
+    DAGL_REQUIRE(softmax_scale > 0.f && wq_rows && x_rows && b2p && out && workspace, "dagl_ce_generic_core_forward: bad argument");
+    if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias, "dagl_ce_generic_core_forward: thr / bias missing");
+    const size_t need = dagl::ce_generic_core_workspace_bytes(B, H, W, ksize, stride_1, stride_2, inter_channels, 0);
+    if (workspace_bytes < need) { dagl::set_error("dagl_ce_generic_core_forward: workspace %zu bytes, %zu needed", workspace_bytes, need); return DAGL_ERR_WORKSPACE; }
+    if ((rc = check_device())) return rc;
+    return dagl::launch_ce_generic_core_forward((hipStream_t)stream, B, H, W, ksize, stride_1, stride_2, inter_channels, softmax_scale, mode, k,
+                                                wq_rows, x_rows, b2p, thr, bias, out, degree, workspace);
+}
+
+int dagl_ce_generic_core_backward(void* stream, int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                                  float softmax_scale, int mode, int k, const float* wq_rows, const float* x_rows, const float* b2p,
+                                  const float* thr, const float* bias, const float* d_out, float* d_wq, float* d_x, float* d_b2p,
+                                  float* d_thr, float* d_bias, void* workspace, size_t workspace_bytes) {
+    int rc = dagl::ce_generic_check(B, 4, H, W, ksize, stride_1, stride_2, inter_channels, mode, k);
+    if (rc) return rc;
+    DAGL_REQUIRE(softmax_scale > 0.f && wq_rows && x_rows && b2p && d_out && d_wq && d_x && d_b2p && workspace,
+                 "dagl_ce_generic_core_backward: bad argument");
+    if (mode != DAGL_MODE_TOPK) DAGL_REQUIRE(thr && bias && d_thr && d_bias, "dagl_ce_generic_core_backward: thr / bias (and their gradients) missing");
+    const size_t need = dagl::ce_generic_core_workspace_bytes(B, H, W, ksize, stride_1, stride_2, inter_channels, 1);
+    if (workspace_bytes < need) { dagl::set_error("dagl_ce_generic_core_backward: workspace %zu bytes, %zu needed", workspace_bytes, need); return DAGL_ERR_WORKSPACE; }
+    if ((rc = check_device())) return rc;
+    return dagl::launch_ce_generic_core_backward((hipStream_t)stream, B, H, W, ksize, stride_1, stride_2, inter_channels, softmax_scale, mode, k,
+                                                 wq_rows, x_rows, b2p, thr, bias, d_out, d_wq, d_x, d_b2p, d_thr, d_bias, workspace);
+}
+
 }  // extern "C"

@@ -697,6 +697,14 @@ int launch_ce_generic(hipStream_t s, int B, int Cin, int H, int W, int ks, int s
                       const float* x, const float* g_w, const float* g_b, const float* th_w, const float* th_b, const float* thr_w,
                       const float* thr_b, const float* bias_w, const float* bias_b, const float* fc1_w, const float* fc1_b,
                       const float* fc2_w, const float* fc2_b, float* out, int32_t* degree, void* workspace);
+size_t ce_generic_core_workspace_bytes(int B, int H, int W, int ks, int s1, int s2, int C, int backward);
+int ce_generic_border(int ks);
+int launch_ce_generic_core_forward(hipStream_t s, int B, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                                   const float* wq, const float* x, const float* b2p, const float* thr, const float* bias, float* out,
+                                   int32_t* degree, void* workspace);
+int launch_ce_generic_core_backward(hipStream_t s, int B, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                                    const float* wq, const float* x, const float* b2p, const float* thr, const float* bias, const float* d_out,
+                                    float* d_wq, float* d_x, float* d_b2p, float* d_thr, float* d_bias, void* workspace);
 int launch_dense_train_forward(hipStream_t s, int B, const Grid& g, const float* wq_rows, const float* x_rows, const float* b2,
                                const float* thr, const float* bias, float* out, float* lse /*[B,L,2]*/, float* mu /*[B,L]*/,
                                void* ws, size_t ws_bytes, int64_t* stats_dev /* [2]: edges, max degree */,

@@ -170,10 +170,11 @@ __device__ __forceinline__ float gen_logit(float s, int j, float mtq, float bsq,
 }
 
 // one block per query row of the chunk: S row -> A row in place
+// (abuf != sbuf: the differentiable path keeps S for its backward)
 template <int MODE>
 __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long ldn, int L, int l0, int b, int k, float scale,
-                                                              float* __restrict__ sbuf, const float* __restrict__ tb,
-                                                              int32_t* __restrict__ deg) {
+                                                              const float* sbuf, float* abuf, const float* __restrict__ thr,
+                                                              const float* __restrict__ bias, int tstride, int32_t* __restrict__ deg) {
     __shared__ double shd[4];
     __shared__ float shf[4];
     __shared__ WideSelShared shs;
@@ -181,13 +182,14 @@ __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long l
     __shared__ int sh_jt;
     const int lr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t ql = (size_t)b * L + l0 + lr;
-    float* row = sbuf + (size_t)lr * ldn;
+    const float* row = sbuf + (size_t)lr * ldn;
+    float* arow = abuf + (size_t)lr * ldn;
     float mtq = 0.f, bsq = 0.f;
     if (MODE != 1) {
         double sm = 0.0;
         for (int j = tid; j < N; j += 256) sm += (double)row[j];
         const float mean = (float)(gen_block_sum(sm, shd) / (double)N);           // yi.mean(dim=1), dagl.py:256
-        mtq = __fmul_rn(mean, tb[2 * ql]); bsq = tb[2 * ql + 1];
+        mtq = __fmul_rn(mean, thr[ql * tstride]); bsq = bias[ql * tstride];
     }
     unsigned T = 0u; int jt = 0x7fffffff;
     if (MODE != 0) {
@@ -233,9 +235,9 @@ __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long l
     for (int j = tid; j < N; j += 256) {
         bool pass;
         const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
-        row[j] = pass ? expf(l - M) * invz : 0.f;                  // softmax * mask_b, dagl.py:260-261
+        arow[j] = pass ? expf(l - M) * invz : 0.f;                 // softmax * mask_b, dagl.py:260-261
     }
-    for (int j = N + tid; j < ldn; j += 256) row[j] = 0.f;
+    for (int j = N + tid; j < ldn; j += 256) arow[j] = 0.f;
     const double Cn = gen_block_sum((double)cnt, shd);
     if (tid == 0 && deg != nullptr) deg[ql] = (int32_t)Cn;
 }
@@ -275,6 +277,145 @@ Gemm32 gen_gemm(int M, int N, int K, const float* A, long long lda, const float*
 }
 
 inline dim3 gen_grid(size_t n, int B) { return dim3((unsigned)((n + 255) / 256), (unsigned)B); }
+
+// ---- the differentiable form (autograd through dagl.py:250-272 for a module built with a non-default geometry) ------------------
+// d agg[b, block (py,px), (kh,kw,c)] = d out[b, c, py*s1 - pad + kh, px*s1 - pad + kw] / count   (adjoint of gen_fold_normalize_kernel)
+__global__ __launch_bounds__(256) void gen_unfold_out_kernel(int C, int H, int W, int ks, int s1, int pad, int fh, int fw,
+                                                             const float* __restrict__ dout, float* __restrict__ dagg) {
+    const int b = blockIdx.y;
+    const size_t P_ = (size_t)ks * ks * C;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)fh * fw * P_) return;
+    const int blk = (int)(t / P_); const int e = (int)(t - (size_t)blk * P_);
+    const int tap = e / C, c = e - tap * C, kh = tap / ks, kw = tap - kh * ks;
+    const int py = blk / fw, px = blk - py * fw;
+    const int y = py * s1 - pad + kh, x = px * s1 - pad + kw;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        int cnt = 0;                                                            // how many blocks cover (y, x): as the forward counts them
+        for (int a = 0; a < ks; ++a) {
+            const int ty = y + pad - a;
+            if (ty < 0 || ty % s1 != 0 || ty / s1 >= fh) continue;
+            for (int q = 0; q < ks; ++q) {
+                const int tx = x + pad - q;
+                if (tx < 0 || tx % s1 != 0 || tx / s1 >= fw) continue;
+                ++cnt;
+            }
+        }
+        v = dout[(((size_t)b * C + c) * H + y) * W + x] / (float)(cnt == 0 ? 1 : cnt);
+    }
+    dagg[(size_t)b * fh * fw * P_ + t] = v;
+}
+
+// one block per query row of the chunk: sbuf = S row, abuf = A row, dabuf = d A row  ->  dabuf = d S row (without the row-mean term),
+// d bias[q] = t = sum_j d l_j scale S_j,  d thr[q] = -t mean,  rcoef[q] = -t thr / N (the row-mean term: d S_j += rcoef for EVERY key j,
+// applied as two rank-1 updates of d Wq / d X).  l_j = scale S_j m_j with m_j = S_j - mean thr + bias on the passing keys (a 0/1 mask
+// in the fixed-k mode: MODE 1), y_j = mask_j e^{l_j} / Z  =>  d l_j = y_j (d y_j - sum_i y_i d y_i); a key passes iff its weight is
+// not zero (a passing key whose weight underflowed has no gradient either way).
+template <int MODE>
+__global__ __launch_bounds__(256) void gen_row_backward_kernel(int N, long long ldn, int L, int l0, int b, float scale,
+                                                               const float* __restrict__ sbuf, const float* __restrict__ abuf, float* __restrict__ dabuf,
+                                                               const float* __restrict__ thr, const float* __restrict__ bias,
+                                                               float* __restrict__ d_thr, float* __restrict__ d_bias, float* __restrict__ rcoef) {
+    __shared__ double shd[4];
+    const int lr = blockIdx.x, tid = threadIdx.x;
+    const size_t ql = (size_t)b * L + l0 + lr;
+    const float* srow = sbuf + (size_t)lr * ldn;
+    const float* arow = abuf + (size_t)lr * ldn;
+    float* drow = dabuf + (size_t)lr * ldn;
+    float mean = 0.f, mtq = 0.f, bsq = 0.f;
+    if (MODE != 1) {
+        double sm = 0.0;
+        for (int j = tid; j < N; j += 256) sm += (double)srow[j];
+        mean = (float)(gen_block_sum(sm, shd) / (double)N);
+        mtq = __fmul_rn(mean, thr[ql]); bsq = bias[ql];
+    }
+    double cs = 0.0;
+    for (int j = tid; j < N; j += 256) cs += (double)arow[j] * (double)drow[j];
+    const float c = (float)gen_block_sum(cs, shd);
+    double ts = 0.0;
+    for (int j = tid; j < N; j += 256) {
+        const float a = arow[j], sj = srow[j];
+        float ds = 0.f;
+        if (a != 0.f) {
+            const float dl = a * (drow[j] - c);
+            if (MODE == 1) ds = dl * scale;
+            else {
+                const float m = (sj - mtq) + bsq;
+                ds = dl * scale * (m + sj);
+                ts += (double)(dl * scale) * (double)sj;
+            }
+        }
+        drow[j] = ds;
+    }
+    for (int j = N + tid; j < ldn; j += 256) drow[j] = 0.f;
+    if (MODE != 1) {
+        const double t = gen_block_sum(ts, shd);
+        if (tid == 0) {
+            d_bias[ql] = (float)t;
+            d_thr[ql] = (float)(-t * (double)mean);
+            rcoef[ql] = (float)(-t * (double)thr[ql] / (double)N);
+        }
+    }
+}
+
+__global__ void gen_fill_kernel(size_t n, float v, float* __restrict__ dst) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = v;
+}
+// out[r, c] += (rowcoef ? rowcoef[r] : 1) * vec[c]
+__global__ void gen_rank1_add_kernel(size_t rows, int cols, const float* __restrict__ rowcoef, const float* __restrict__ vec, float* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const size_t r = t / cols; const int c = (int)(t - r * cols);
+    out[t] += (rowcoef ? rowcoef[r] : 1.f) * vec[c];
+}
+
+struct GenCorePlan { size_t o_vrows, o_dvrows, o_s, o_a, o_da, o_agg, o_rc, o_ones, o_vec, o_end; };
+inline GenCorePlan gen_core_plan(const GenGeom& g, bool backward) {
+    GenCorePlan p{};
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t B = g.B;
+    p.o_vrows = carve(B * g.N * (size_t)g.P * 4);
+    p.o_dvrows = backward ? carve(B * g.N * (size_t)g.P * 4) : 0;
+    p.o_s = carve((size_t)g.Lc * g.ldn * 4);
+    p.o_a = backward ? carve((size_t)g.Lc * g.ldn * 4) : 0;
+    p.o_da = backward ? carve((size_t)g.Lc * g.ldn * 4) : 0;
+    p.o_agg = carve(B * g.L * (size_t)g.P * 4);
+    p.o_rc = backward ? carve(B * g.L * 4) : 0;
+    p.o_ones = backward ? carve((size_t)(g.N > g.L ? g.N : g.L) * 4) : 0;
+    p.o_vec = backward ? carve((size_t)g.D * 4 * 2) : 0;
+    p.o_end = off;
+    return p;
+}
+
+// dagl.py:250-272 from the feature rows: a chunk of query rows at a time -- S chunk, row-wise mask / softmax, A chunk x value rows --,
+// then fold + overlap count.  vrows [B,N,P] = the value patches (unfold of the zero-bordered value map).
+int gen_core_forward(hipStream_t s, const GenGeom& g, float scale, int mode, int k, const float* wq, const float* x, const float* vrows,
+                     const float* thr, const float* bias, int tstride, float* sbuf, float* agg, float* out, int32_t* degree) {
+    int rc;
+    const int kk = k < g.N ? k : g.N;                                      // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
+    for (int b = 0; b < g.B; ++b) {
+        const float* Xb = x + (size_t)b * g.N * g.D;
+        const float* Vb = vrows + (size_t)b * g.N * g.P;
+        for (int l0 = 0; l0 < g.L; l0 += g.Lc) {
+            const int lc = (g.L - l0 < g.Lc) ? g.L - l0 : g.Lc;
+            const float* Wqc = wq + ((size_t)b * g.L + l0) * g.D;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.D, Wqc, g.D, Xb, g.D, 1, sbuf, g.ldn, nullptr, 0)))) return rc;
+#define GEN_ROWS(M_) hipLaunchKernelGGL((gen_row_softmax_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, sbuf, sbuf, thr, bias, tstride, degree)
+            if (mode == DAGL_MODE_ADAPTIVE) GEN_ROWS(0); else if (mode == DAGL_MODE_TOPK) GEN_ROWS(1); else GEN_ROWS(2);
+#undef GEN_ROWS
+            DAGL_LAUNCH_CHECK("gen_row_softmax_kernel");
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.P, g.N, sbuf, g.ldn, Vb, g.P, 0, agg + ((size_t)b * g.L + l0) * g.P, g.P, nullptr, 0)))) return rc;
+        }
+    }
+    // fold + overlap count, dagl.py:265-272
+    hipLaunchKernelGGL(gen_fold_normalize_kernel, gen_grid((size_t)g.C * g.H * g.W, g.B), dim3(256), 0, s, g.C, g.H, g.W, g.ks, g.s1, g.fold_pad,
+                       g.fold_h, g.fold_w, agg, out);
+    DAGL_LAUNCH_CHECK("gen_fold_normalize_kernel");
+    return DAGL_OK;
+}
 
 }  // namespace
 
@@ -349,29 +490,97 @@ int launch_ce_generic(hipStream_t s, int B, int Cin, int H, int W, int ks, int s
     if ((rc = launch_gemm32(s, gen_gemm(B * g.N, g.D, g.P, F(p.o_rows), g.P, F(p.o_fc2), g.P, 1, F(p.o_x), g.D, fc2_b, 1)))) return rc;
     if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, F(p.o_b2p), F(p.o_rows)))) return rc;   // value rows
 
-    // ---- graph core, dagl.py:250-264, a chunk of query rows at a time -------------------------------------------------------
-    const int kk = k < g.N ? k : g.N;                                      // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
+    return gen_core_forward(s, g, scale, mode, k, F(p.o_wq), F(p.o_x), F(p.o_rows), F(p.o_tb), F(p.o_tb) + 1, 2, F(p.o_s), F(p.o_agg), out, degree);
+}
+
+size_t ce_generic_core_workspace_bytes(int B, int H, int W, int ks, int s1, int s2, int C, int backward) {
+    return gen_core_plan(gen_geom(B, 4, H, W, ks, s1, s2, C), backward != 0).o_end + 256;
+}
+int ce_generic_border(int ks) { return ks > 2 ? ks - 1 : 1; }
+
+// forward of the differentiable core: the feature rows and the zero-bordered NHWC value map (border = ce_generic_border(ks)) given
+int launch_ce_generic_core_forward(hipStream_t s, int B, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                                   const float* wq, const float* x, const float* b2p, const float* thr, const float* bias, float* out,
+                                   int32_t* degree, void* workspace) {
+    const GenGeom g = gen_geom(B, 4, H, W, ks, s1, s2, C);
+    const GenCorePlan p = gen_core_plan(g, false);
+    char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) / 256 * 256);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, b2p, F(p.o_vrows)))) return rc;
+    return gen_core_forward(s, g, scale, mode, k, wq, x, F(p.o_vrows), thr, bias, 1, F(p.o_s), F(p.o_agg), out, degree);
+}
+
+int launch_fold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow, const float* drows,
+                        float* dmap);
+
+// backward: S and A are recomputed chunk by chunk (nothing O(L N) is kept between the passes)
+int launch_ce_generic_core_backward(hipStream_t s, int B, int H, int W, int ks, int s1, int s2, int C, float scale, int mode, int k,
+                                    const float* wq, const float* x, const float* b2p, const float* thr, const float* bias, const float* d_out,
+                                    float* d_wq, float* d_x, float* d_b2p, float* d_thr, float* d_bias, void* workspace) {
+    const GenGeom g = gen_geom(B, 4, H, W, ks, s1, s2, C);
+    const GenCorePlan p = gen_core_plan(g, true);
+    char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) / 256 * 256);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    const bool heads = mode != DAGL_MODE_TOPK;
+    const int kk = k < g.N ? k : g.N;
+    if ((rc = launch_unfold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, b2p, F(p.o_vrows)))) return rc;
+    hipLaunchKernelGGL(gen_unfold_out_kernel, gen_grid((size_t)g.L * g.P, B), dim3(256), 0, s, C, H, W, ks, s1, g.fold_pad, g.fold_h, g.fold_w,
+                       d_out, F(p.o_agg));
+    DAGL_LAUNCH_CHECK("gen_unfold_out_kernel");
+    const size_t n_ones = (size_t)(g.N > g.L ? g.N : g.L);
+    hipLaunchKernelGGL(gen_fill_kernel, dim3((unsigned)((n_ones + 255) / 256)), dim3(256), 0, s, n_ones, 1.0f, F(p.o_ones));
+    DAGL_LAUNCH_CHECK("gen_fill_kernel");
     for (int b = 0; b < B; ++b) {
-        const float* Xb = F(p.o_x) + (size_t)b * g.N * g.D;
-        const float* Vb = F(p.o_rows) + (size_t)b * g.N * g.P;
+        const float* Xb = x + (size_t)b * g.N * g.D;
+        const float* Vb = F(p.o_vrows) + (size_t)b * g.N * g.P;
+        float* dVb = F(p.o_dvrows) + (size_t)b * g.N * g.P;
+        float* dXb = d_x + (size_t)b * g.N * g.D;
         for (int l0 = 0; l0 < g.L; l0 += g.Lc) {
             const int lc = (g.L - l0 < g.Lc) ? g.L - l0 : g.Lc;
-            const float* Wqc = F(p.o_wq) + ((size_t)b * g.L + l0) * g.D;
-            if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.D, Wqc, g.D, Xb, g.D, 1, F(p.o_s), g.ldn, nullptr, 0)))) return rc;
-#define GEN_ROWS(M_) hipLaunchKernelGGL((gen_row_softmax_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, F(p.o_s), F(p.o_tb), degree)
-            if (mode == DAGL_MODE_ADAPTIVE) GEN_ROWS(0); else if (mode == DAGL_MODE_TOPK) GEN_ROWS(1); else GEN_ROWS(2);
+            const float* Wqc = wq + ((size_t)b * g.L + l0) * g.D;
+            const float* dAggc = F(p.o_agg) + ((size_t)b * g.L + l0) * g.P;
+            const float beta = l0 == 0 ? 0.f : 1.f;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.D, Wqc, g.D, Xb, g.D, 1, F(p.o_s), g.ldn, nullptr, 0)))) return rc;          // S
+#define GEN_ROWS(M_) hipLaunchKernelGGL((gen_row_softmax_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, F(p.o_s), F(p.o_a), thr, bias, 1, (int32_t*)nullptr)
+            if (mode == DAGL_MODE_ADAPTIVE) GEN_ROWS(0); else if (mode == DAGL_MODE_TOPK) GEN_ROWS(1); else GEN_ROWS(2);                 // A
 #undef GEN_ROWS
             DAGL_LAUNCH_CHECK("gen_row_softmax_kernel");
-            Gemm32 av = gen_gemm(lc, g.P, g.N, F(p.o_s), g.ldn, Vb, g.P, 0, F(p.o_agg) + ((size_t)b * g.L + l0) * g.P, g.P, nullptr, 0);
-            if ((rc = launch_gemm32(s, av))) return rc;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.P, dAggc, g.P, Vb, g.P, 1, F(p.o_da), g.ldn, nullptr, 0)))) return rc;       // d A = d agg V^T
+            {                                                                                                                            // d V (+)= A^T d agg
+                Gemm32 q = gen_gemm(g.N, g.P, lc, F(p.o_a), g.ldn, dAggc, g.P, 0, dVb, g.P, nullptr, 0);
+                q.a_kc = 0; q.beta = beta;
+                if ((rc = launch_gemm32(s, q))) return rc;
+            }
+            float* rc_q = F(p.o_rc) + (size_t)b * g.L;
+#define GEN_BWD(M_) hipLaunchKernelGGL((gen_row_backward_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, scale, F(p.o_s), F(p.o_a), F(p.o_da), \
+                                       thr, bias, d_thr, d_bias, F(p.o_rc))
+            if (heads) GEN_BWD(0); else GEN_BWD(1);                                                                                     // d S
+#undef GEN_BWD
+            DAGL_LAUNCH_CHECK("gen_row_backward_kernel");
+            (void)rc_q;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.D, g.N, F(p.o_da), g.ldn, Xb, g.D, 0, d_wq + ((size_t)b * g.L + l0) * g.D, g.D, nullptr, 0)))) return rc;   // d Wq = d S X
+            {                                                                                                                            // d X (+)= d S^T Wq
+                Gemm32 q = gen_gemm(g.N, g.D, lc, F(p.o_da), g.ldn, Wqc, g.D, 0, dXb, g.D, nullptr, 0);
+                q.a_kc = 0; q.beta = beta;
+                if ((rc = launch_gemm32(s, q))) return rc;
+            }
+        }
+        if (heads) {
+            // the row-mean term of dagl.py:256: d S_lj += rcoef_l for every key j  =>  d Wq_l += rcoef_l sum_j X_j,  d X_j += sum_l rcoef_l Wq_l
+            float* colsum = F(p.o_vec); float* u = F(p.o_vec) + g.D;
+            if ((rc = launch_gemm32(s, gen_gemm(1, g.D, g.N, F(p.o_ones), g.N, Xb, g.D, 0, colsum, g.D, nullptr, 0)))) return rc;
+            if ((rc = launch_gemm32(s, gen_gemm(1, g.D, g.L, F(p.o_rc) + (size_t)b * g.L, g.L, wq + (size_t)b * g.L * g.D, g.D, 0, u, g.D, nullptr, 0)))) return rc;
+            hipLaunchKernelGGL(gen_rank1_add_kernel, dim3((unsigned)(((size_t)g.L * g.D + 255) / 256)), dim3(256), 0, s, (size_t)g.L, g.D,
+                               F(p.o_rc) + (size_t)b * g.L, colsum, d_wq + (size_t)b * g.L * g.D);
+            hipLaunchKernelGGL(gen_rank1_add_kernel, dim3((unsigned)(((size_t)g.N * g.D + 255) / 256)), dim3(256), 0, s, (size_t)g.N, g.D,
+                               (const float*)nullptr, u, dXb);
+            DAGL_LAUNCH_CHECK("gen_rank1_add_kernel");
         }
     }
-
-    // ---- fold + overlap count, dagl.py:265-272 ------------------------------------------------------------------------------
-    hipLaunchKernelGGL(gen_fold_normalize_kernel, gen_grid((size_t)C * HW, B), dim3(256), 0, s, C, H, W, ks, s1, g.fold_pad, g.fold_h, g.fold_w,
-                       F(p.o_agg), out);
-    DAGL_LAUNCH_CHECK("gen_fold_normalize_kernel");
-    return DAGL_OK;
+    // d value map = fold(d value rows)
+    return launch_fold_patches(s, B, g.Hp, g.Wp, C, ks, s2, g.PG - g.t2, g.PG - g.l2, g.Nh, g.Nw, F(p.o_dvrows), d_b2p);
 }
 
 }  // namespace dagl

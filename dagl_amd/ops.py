@@ -349,6 +349,65 @@ def ce_forward_generic(x, params: dict, ksize: int, stride_1: int, stride_2: int
     return (out, deg) if want_degree else out
 
 
+def _generic_geom(H, W, ksize, stride_1, stride_2):
+    lib = _lib.load()
+    pg = lib.dagl_ce_generic_border(int(ksize))
+    L = (-(-H // int(stride_1))) * (-(-W // int(stride_1)))
+    N = (-(-H // int(stride_2))) * (-(-W // int(stride_2)))
+    return pg, L, N
+
+
+@_on_device
+def ce_generic_core_forward(wq_rows, x_rows, b2p, thr, bias, H: int, W: int, ksize: int, stride_1: int, stride_2: int, mode: str = "adaptive",
+                            k: int = 0, softmax_scale: float = 10.0, workspace: "Workspace | None" = None, want_degree: bool = False):
+    """dagl.py:250-272 from the feature rows for any patch geometry (``dagl_ce_generic_core_forward``): wq_rows [B,L,D], x_rows [B,N,D],
+    b2p the zero-bordered NHWC value map [B,H+2pg,W+2pg,c] (pg = ``dagl_ce_generic_border(ksize)``), thr / bias [B,L] -> [B,c,H,W]."""
+    lib = _lib.load()
+    for n, t in (("wq_rows", wq_rows), ("x_rows", x_rows), ("b2p", b2p)):
+        _need(t, n)
+    B, c = b2p.shape[0], b2p.shape[3]
+    pg, L, N = _generic_geom(H, W, ksize, stride_1, stride_2)
+    D_ = ksize * ksize * c // 4
+    if tuple(b2p.shape) != (B, H + 2 * pg, W + 2 * pg, c) or tuple(wq_rows.shape) != (B, L, D_) or tuple(x_rows.shape) != (B, N, D_):
+        raise DaglError(f"ce_generic_core_forward: shapes {tuple(wq_rows.shape)}, {tuple(x_rows.shape)}, {tuple(b2p.shape)} do not fit "
+                        f"L={L} N={N} D={D_} border={pg}")
+    heads = mode != "topk"
+    if heads:
+        _need(thr, "thr"); _need(bias, "bias")
+    need = lib.dagl_ce_generic_core_workspace_bytes(B, H, W, int(ksize), int(stride_1), int(stride_2), c, 0)
+    ws = workspace if workspace is not None else Workspace()
+    buf = ws.get(need, b2p.device)
+    out = torch.empty(B, c, H, W, device=b2p.device, dtype=torch.float32)
+    deg = torch.empty(B, L, device=b2p.device, dtype=torch.int32) if want_degree else None
+    check(lib.dagl_ce_generic_core_forward(_stream(), B, H, W, int(ksize), int(stride_1), int(stride_2), c, float(softmax_scale), MODES[mode], int(k),
+                                           wq_rows.data_ptr(), x_rows.data_ptr(), b2p.data_ptr(), thr.data_ptr() if heads else None,
+                                           bias.data_ptr() if heads else None, out.data_ptr(), deg.data_ptr() if deg is not None else None,
+                                           buf.data_ptr(), buf.numel()), "dagl_ce_generic_core_forward")
+    return (out, deg) if want_degree else out
+
+
+@_on_device
+def ce_generic_core_backward(d_out, wq_rows, x_rows, b2p, thr, bias, H: int, W: int, ksize: int, stride_1: int, stride_2: int,
+                             mode: str = "adaptive", k: int = 0, softmax_scale: float = 10.0, workspace: "Workspace | None" = None):
+    """Gradients of ``ce_generic_core_forward`` w.r.t. (wq_rows, x_rows, b2p, thr, bias) (``dagl_ce_generic_core_backward``)."""
+    lib = _lib.load()
+    _need(d_out, "d_out")
+    B, c = b2p.shape[0], b2p.shape[3]
+    heads = mode != "topk"
+    need = lib.dagl_ce_generic_core_workspace_bytes(B, H, W, int(ksize), int(stride_1), int(stride_2), c, 1)
+    ws = workspace if workspace is not None else Workspace()
+    buf = ws.get(need, b2p.device)
+    d_wq, d_x, d_b2p = torch.empty_like(wq_rows), torch.empty_like(x_rows), torch.empty_like(b2p)
+    d_thr = torch.empty_like(thr) if heads else None
+    d_bias = torch.empty_like(bias) if heads else None
+    check(lib.dagl_ce_generic_core_backward(_stream(), B, H, W, int(ksize), int(stride_1), int(stride_2), c, float(softmax_scale), MODES[mode], int(k),
+                                            wq_rows.data_ptr(), x_rows.data_ptr(), b2p.data_ptr(), thr.data_ptr() if heads else None,
+                                            bias.data_ptr() if heads else None, d_out.data_ptr(), d_wq.data_ptr(), d_x.data_ptr(), d_b2p.data_ptr(),
+                                            d_thr.data_ptr() if heads else None, d_bias.data_ptr() if heads else None, buf.data_ptr(), buf.numel()),
+          "dagl_ce_generic_core_backward")
+    return d_wq, d_x, d_b2p, d_thr, d_bias
+
+
 @_on_device
 def ce_prologue(x, g_w, g_b, theta_w, theta_b, thr_w=None, thr_b=None, bias_w=None, bias_b=None, fast=False):
     """The four prologue convolutions (dagl.py:208-215) -> (b1_nhwc, b2_nhwc, thr, bias); heads optional."""

@@ -516,6 +516,22 @@ int dagl_ce_generic_forward(void* stream, int B, int Cin, int H, int W, int ksiz
                             const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                             float* out, int32_t* degree, void* workspace, size_t workspace_bytes);
 
+/* (ABI 406) The differentiable graph core, dagl.py:250-272, for any patch geometry (autograd through a CE built with non-default
+ * arguments; the convolutions and patch projections around it are dagl_unfold_patches + dagl_gemm_f32 with their adjoints):
+ *   wq_rows [B,L,P/4], x_rows [B,N,P/4] the feature rows (relu(fc(patches)), dagl.py:248-249);  b2p the value map, zero-bordered NHWC
+ *   [B, H+2*border, W+2*border, c] with border = dagl_ce_generic_border(ksize);  thr / bias [B,L] (NULL in DAGL_MODE_TOPK);
+ *   out / d_out [B,c,H,W].  The backward recomputes S and A chunk by chunk; it writes d_wq, d_x, d_b2p (every element) and, in the
+ *   adaptive modes, d_thr / d_bias.  Workspace: dagl_ce_generic_core_workspace_bytes(..., backward).                                 */
+int    dagl_ce_generic_border(int ksize);
+size_t dagl_ce_generic_core_workspace_bytes(int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels, int backward);
+int dagl_ce_generic_core_forward(void* stream, int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                                 float softmax_scale, int mode, int k, const float* wq_rows, const float* x_rows, const float* b2p,
+                                 const float* thr, const float* bias, float* out, int32_t* degree, void* workspace, size_t workspace_bytes);
+int dagl_ce_generic_core_backward(void* stream, int B, int H, int W, int ksize, int stride_1, int stride_2, int inter_channels,
+                                  float softmax_scale, int mode, int k, const float* wq_rows, const float* x_rows, const float* b2p,
+                                  const float* thr, const float* bias, const float* d_out, float* d_wq, float* d_x, float* d_b2p,
+                                  float* d_thr, float* d_bias, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ def pytest_configure(config):
 def golden_cases():
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*.npz")))
-    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol", "quality_", "geom_"))      # CE block cases only
+    return [f for f in files if not os.path.basename(f).startswith(("set12", "grad_", "ces_stage", "x8_protocol", "quality_", "geom_", "geomgrad_"))      # CE block cases only
             and "_scale" not in os.path.basename(f)]                        # (softmax_scale != 10: scale_cases())
 
 

@@ -55,3 +55,42 @@ def test_recorded_geometry_on_which_the_reference_raises():
     with open(os.path.join(REPO, "tests", "golden", "geom_raises.json")) as f:
         cases = json.load(f)
     assert cases and all(c["error"] == "RuntimeError" for c in cases)
+
+
+# ---- gradients: the oracle's autograd against the reference's own, for non-default geometries -----------------------------------------
+import glob  # noqa: E402
+
+from tests.helpers import GOLDEN_DIR  # noqa: E402
+
+GEOM_GRAD_CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "geomgrad_*.npz")))
+
+
+def geom_grad_inputs(meta):
+    from dagl_amd.synth import make_ce_params, make_features
+    p = make_ce_params(meta["seed"], in_channels=meta["C"], inter_channels=meta["inter_channels"], ksize=meta["ksize"],
+                       variant=meta["variant"], sparse_gain=meta["sparse_gain"])
+    x = torch.from_numpy(make_features(meta["seed"], meta["B"], meta["C"], meta["H"], meta["W"]))
+    G = np.random.Generator(np.random.PCG64(meta["seed"] + 1000)).standard_normal(
+        (meta["B"], meta["inter_channels"], meta["H"], meta["W"])).astype(np.float32)
+    return x, {n: torch.from_numpy(a) for n, a in p.items()}, torch.from_numpy(G)
+
+
+def geom_oracle_grads(meta, dtype):
+    x, params, G = geom_grad_inputs(meta)
+    x = x.to(dtype).requires_grad_(True)
+    P = {n: t.to(dtype).requires_grad_(True) for n, t in params.items()}
+    out = ce_forward_oracle(x, P, mode=meta["mode"], k=meta["k"] or None, dtype=dtype, softmax_scale=float(meta["softmax_scale"]),
+                            ksize=meta["ksize"], stride_q=meta["stride_1"], stride_kv=meta["stride_2"])
+    (out * G.to(dtype)).sum().backward()
+    grads = {"d_x": x.grad}
+    grads.update({"d_" + n: t.grad for n, t in P.items() if t.grad is not None})
+    return out.detach(), grads
+
+
+@pytest.mark.parametrize("path", GEOM_GRAD_CASES, ids=[os.path.basename(p)[9:-4] for p in GEOM_GRAD_CASES])
+def test_oracle_autograd_matches_reference_gradients_geometry(path):
+    from tests.test_oracle_grad import compare_grads, load_grad_case
+    meta, want = load_grad_case(path)
+    out, grads = geom_oracle_grads(meta, torch.float32)
+    assert normwise(out.numpy(), want["out"]) <= 1e-4
+    compare_grads(grads, want, meta["fc_step"], 5e-4)

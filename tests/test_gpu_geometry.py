@@ -109,7 +109,7 @@ def test_geometry_on_which_the_reference_raises_is_refused():
 
 
 def test_generic_module_contract():
-    """Half-precision I/O, an input width that is not a multiple of 4, train() mode refused with a message, workspace check of the C ABI."""
+    """Half-precision I/O, an input width that is not a multiple of 4, train() mode, workspace check of the C ABI."""
     from dagl_amd import _lib
     from dagl_amd._lib import DaglError
     from dagl_amd.synth import make_ce_params, make_features
@@ -130,9 +130,9 @@ def test_generic_module_contract():
     want_h = ce_forward_oracle(xh.float().cpu(), params, dtype=torch.float64, ksize=5, stride_q=3, stride_kv=1)
     assert normwise(oh.float().cpu().numpy(), want_h.numpy()) <= 2e-3           # (fp16 output rounding)
     ce.train()
-    with pytest.raises(DaglError, match="differentiable path"):
-        ce(x.cuda())
-    with torch.no_grad():                                                        # train() without autograd: served
+    o2 = ce(x.cuda())                                                            # train() under autograd: the differentiable route
+    assert o2.requires_grad and normwise(o2.detach().cpu().numpy(), want.numpy()) <= 1e-4
+    with torch.no_grad():                                                        # train() without autograd: the inference route
         assert torch.equal(ce(x.cuda()), out)
     lib = _lib.load()
     need = lib.dagl_ce_generic_workspace_bytes(1, 24, 24, 27, 5, 3, 1, 8)
@@ -145,3 +145,68 @@ def test_generic_module_contract():
         "g.weight", "g.bias", "theta.weight", "theta.bias", "thr_conv.weight", "thr_conv.bias", "bias_conv.weight", "bias_conv.bias",
         "fc1.0.weight", "fc1.0.bias", "fc2.0.weight", "fc2.0.bias")], o.data_ptr(), None, buf.data_ptr(), buf.numel())
     assert rc == _lib.ERR_WORKSPACE and b"workspace" in lib.dagl_last_error()
+
+
+# ---- autograd through a module with a non-default geometry (dagl_ce_generic_core_forward / _backward) -------------------------------
+from tests.test_geometry_oracle import GEOM_GRAD_CASES, geom_grad_inputs, geom_oracle_grads  # noqa: E402
+
+
+def _hip_geom_grads(meta):
+    x, params, G = geom_grad_inputs(meta)
+    ce = _module(meta, params, meta["mode"], meta["k"], meta["softmax_scale"]).train()
+    xg = x.cuda().requires_grad_(True)
+    out = ce(xg)
+    (out * G.cuda()).sum().backward()
+    grads = {"d_x": xg.grad}
+    grads.update({"d_" + n: p.grad for n, p in ce.named_parameters() if p.grad is not None})
+    return ce, out.detach(), grads
+
+
+@pytest.mark.parametrize("path", GEOM_GRAD_CASES, ids=[os.path.basename(p)[9:-4] for p in GEOM_GRAD_CASES])
+def test_generic_geometry_gradients_match_reference_autograd(path):
+    from tests.test_oracle_grad import compare_grads, load_grad_case
+    meta, want = load_grad_case(path)
+    ce, out, grads = _hip_geom_grads(meta)
+    assert normwise(out.cpu().numpy(), want["out"]) <= 1e-4
+    assert "d_W.weight" not in grads
+    compare_grads(grads, want, meta["fc_step"], 5e-4)
+    if meta["mode"] == "topk":
+        assert "d_thr_conv.weight" not in grads
+    # ... and as close to the fp64 oracle's autograd as the reference's own fp32 gradients are
+    _, g64 = geom_oracle_grads(meta, torch.float64)
+    for name, w in g64.items():
+        w = w.numpy()
+        e_hip = normwise(grads[name].cpu().numpy(), w)
+        if name in ("d_fc1.0.weight", "d_fc2.0.weight"):
+            w = w.reshape(-1)[::meta["fc_step"]]
+        e_ref = normwise(want[name], w)
+        assert e_hip <= 3 * e_ref + 1e-4, (name, e_hip, e_ref)
+
+
+def test_generic_geometry_training_forward_equals_inference_and_eval_input_gradients():
+    from tests.test_oracle_grad import load_grad_case
+    meta, _ = load_grad_case([p for p in GEOM_GRAD_CASES if "k5s3_sparse_b2" in p][0])
+    x, params, G = geom_grad_inputs(meta)
+    for mode, k in (("adaptive", 0), ("topk", 5), ("adaptive_topk", 9)):
+        ce = _module(meta, params, mode, k, meta["softmax_scale"])
+        xd = x.cuda()
+        with torch.no_grad():
+            ref = ce(xd)
+        ce.train()
+        out = ce(xd.clone().requires_grad_(True))
+        assert out.requires_grad and normwise(out.detach().cpu().numpy(), ref.cpu().numpy()) <= 2e-5, mode
+        # an eval() module whose INPUT requires a gradient (the reference's test loop runs with autograd on): same input gradient
+        ce.eval()
+        xa, xb = xd.clone().requires_grad_(True), xd.clone().requires_grad_(True)
+        (ce(xa) * G.cuda()).sum().backward()
+        ce.train()
+        (ce(xb) * G.cuda()).sum().backward()
+        assert torch.equal(xa.grad, xb.grad), mode
+    m2 = dict(meta, mode="adaptive_topk", k=9)
+    _, g64 = geom_oracle_grads(m2, torch.float64)
+    ce = _module(meta, params, "adaptive_topk", 9, meta["softmax_scale"]).train()
+    xg = x.cuda().requires_grad_(True)
+    (ce(xg) * G.cuda()).sum().backward()
+    got = {"d_x": xg.grad, **{"d_" + n: p.grad for n, p in ce.named_parameters() if p.grad is not None}}
+    for name, w in g64.items():
+        assert normwise(got[name].cpu().numpy(), w.numpy()) <= 5e-4, name
