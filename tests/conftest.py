@@ -22,7 +22,7 @@ def golden_cases():
 def scale_cases():
     """Goldens minted with a softmax_scale other than the default 10 (meta["softmax_scale"])."""
     import glob
-    return [f for f in sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*_scale*.npz"))) if not os.path.basename(f).startswith("geom_")]
+    return [f for f in sorted(glob.glob(os.path.join(REPO, "tests", "golden", "*_scale*.npz"))) if not os.path.basename(f).startswith(("geom_", "geomgrad_"))]
 
 
 def geometry_cases():
