@@ -55,6 +55,9 @@ ORACLE_CASES = [
     (11, 4, 1, 8, 16, 1, 36, 40, "default", 2.0, "topk", 20, 7),
     (4, 4, 1, 16, 64, 1, 32, 48, "sparse", 1.5, "adaptive", 0, 10),        # even window: SAME pad (1, 2)
     (5, 3, 1, 16, 64, 3, 27, 33, "default", 2.0, "adaptive", 0, 2.5),
+    (3, 4, 1, 16, 64, 1, 32, 40, "sparse", 1.3, "adaptive", 0, 10),         # stride_1 > ksize: pixels no query window covers (zero guard, dagl.py:271)
+    (1, 1, 1, 16, 64, 1, 24, 20, "sparse", 1.2, "adaptive", 0, 10),         # 1 x 1 patches: P = c, D = c / 4
+    (7, 4, 2, 16, 64, 1, 64, 72, "default", 2.0, "topk", 40, 10),           # keys on a stride-2 grid
 ]
 
 
