@@ -214,16 +214,13 @@ __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long l
             jt = sh_jt;
         }
     }
-    float mx = 0.f; int cnt = 0;                                   // a masked key's logit is 0 (dagl.py:259: yi * mask)
-    bool any_masked = false;
+    float mx = -__builtin_inff(); int cnt = 0;                     // the softmax runs over ALL keys: a masked key's logit is 0 (dagl.py:259: yi * mask)
     for (int j = tid; j < N; j += 256) {
         bool pass;
         const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
         cnt += pass ? 1 : 0;
-        any_masked |= !pass;
-        mx = (j == tid && !any_masked) ? l : fmaxf(mx, l);         // (first element seeds the maximum; masked ones contribute their 0)
+        mx = fmaxf(mx, l);
     }
-    if (tid >= N) mx = -__builtin_inff();
     const float M = gen_block_max(mx, shf);
     double z = 0.0;
     for (int j = tid; j < N; j += 256) {
