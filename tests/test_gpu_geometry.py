@@ -50,7 +50,7 @@ def test_generic_geometry_matches_reference_goldens(path):
 # (ksize, stride_1, stride_2, inter_channels, Cin, B, H, W, variant, gain, mode, k, scale)
 ORACLE_CASES = [
     (5, 2, 1, 16, 64, 1, 64, 64, "sparse", 1.6, "adaptive", 0, 10),
-    (3, 1, 1, 4, 4, 1, 96, 96, "sparse", 1.4, "adaptive", 0, 10),         # L = N = 9216: two chunks of score rows
+    (3, 1, 1, 4, 4, 2, 96, 96, "sparse", 1.4, "adaptive", 0, 10),         # two images, L = N = 9216 each: two chunks of score rows per image
     (7, 4, 1, 16, 64, 2, 40, 44, "sparse", 1.6, "adaptive_topk", 12, 10),  # (default geometry through the generic entry point: see below)
     (11, 4, 1, 8, 16, 1, 36, 40, "default", 2.0, "topk", 20, 7),
     (4, 4, 1, 16, 64, 1, 32, 48, "sparse", 1.5, "adaptive", 0, 10),        # even window: SAME pad (1, 2)
