@@ -11,7 +11,8 @@
 //   dagl.py:256-261   gen_row_softmax_kernel: one block per query row -- row mean (fp64 sum), mask, softmax over ALL keys with the
 //                     masked keys' e^0 in the denominator, not renormalised; the fixed-k variant's k best by radix selection
 //                     (wide_select.h, ties to the lower key index), GReccR2b_3mh_1-checkpoint.py:242-250
-//   dagl.py:263-264   A chunk x value rows (gemm32.hip)
+//   dagl.py:263-264   A chunk x value rows (gemm32.hip); fixed-k modes with k <= 64: the row kernel writes (key, weight) lists in key order
+//                     (ballot compaction, no atomics) and the sum is a gather over k value rows (gather_rows_kernel, aggregate.hip)
 //   dagl.py:265-272   gen_fold_normalize_kernel: fold with padding = the stride_2 SAME grid's left pad and stride_1 (the reference
 //                     folds query patches cut with the stride_1 SAME pad back with the stride_2 pad: reproduced), overlap count
 //                     with its zero guard, NCHW out
@@ -24,6 +25,7 @@ namespace dagl {
 
 int launch_unfold_patches(hipStream_t s, int B, int Hp, int Wp, int C, int k, int stride, int oy, int ox, int oh, int ow,
                           const float* map, float* rows);
+int launch_gather_fixed(hipStream_t s, int L, int k, int P_, const int32_t* idx, const float* wgt, const float* values, float* out);
 
 namespace {
 
@@ -63,6 +65,7 @@ inline GenGeom gen_geom(int B, int Cin, int H, int W, int ks, int s1, int s2, in
     return g;
 }
 
+constexpr int GEN_LIST_CAP_WORDS = 64;              // = GEN_LIST_MAX: (key, weight) list slots per row behind a chunk's score rows
 struct GenPlan {
     size_t o_xp, o_wgt, o_bgt, o_wtb, o_btb, o_fc1, o_fc2, o_rows, o_y, o_b1p, o_b2p, o_tb, o_wq, o_x, o_s, o_agg, o_end;
 };
@@ -91,7 +94,7 @@ inline GenPlan gen_plan(const GenGeom& g) {
     p.o_tb = carve(B * g.L * 2 * 4);
     p.o_wq = carve(B * g.L * (size_t)g.D * 4);
     p.o_x = carve(B * g.N * (size_t)g.D * 4);
-    p.o_s = carve((size_t)g.Lc * g.ldn * 4);
+    p.o_s = carve((size_t)g.Lc * (g.ldn + 2 * GEN_LIST_CAP_WORDS) * 4);
     p.o_agg = carve(B * g.L * (size_t)g.P * 4);
     p.o_end = off;
     return p;
@@ -171,10 +174,14 @@ __device__ __forceinline__ float gen_logit(float s, int j, float mtq, float bsq,
 
 // one block per query row of the chunk: S row -> A row in place
 // (abuf != sbuf: the differentiable path keeps S for its backward)
-template <int MODE>
+// LIST (fixed-k modes, k <= GEN_LIST_MAX): instead of the A row, the row's neighbours as a list of k (key, weight) pairs in key order,
+// empty slots = -1 -- the weighted sum of dagl.py:263-264 is then a gather over k value rows (gather_rows_kernel), not an [Lc,N] x [N,P] product
+constexpr int GEN_LIST_MAX = GEN_LIST_CAP_WORDS;
+template <int MODE, bool LIST = false>
 __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long ldn, int L, int l0, int b, int k, float scale,
                                                               const float* sbuf, float* abuf, const float* __restrict__ thr,
-                                                              const float* __restrict__ bias, int tstride, int32_t* __restrict__ deg) {
+                                                              const float* __restrict__ bias, int tstride, int32_t* __restrict__ deg,
+                                                              int32_t* __restrict__ nb_idx = nullptr, float* __restrict__ nb_wgt = nullptr) {
     __shared__ double shd[4];
     __shared__ float shf[4];
     __shared__ WideSelShared shs;
@@ -229,12 +236,36 @@ __global__ __launch_bounds__(256) void gen_row_softmax_kernel(int N, long long l
         z += (double)expf(l - M);
     }
     const float invz = (float)(1.0 / gen_block_sum(z, shd));
-    for (int j = tid; j < N; j += 256) {
-        bool pass;
-        const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
-        arow[j] = pass ? expf(l - M) * invz : 0.f;                 // softmax * mask_b, dagl.py:260-261
+    if (LIST) {
+        // ordered compaction of the (at most k) passing keys: positions by ballot + wave offsets, no atomics -- the list (and with it the
+        // gather's summation order) is the same on every run
+        int32_t* li = nb_idx + (size_t)lr * k;
+        float* lw = nb_wgt + (size_t)lr * k;
+        int run = 0;
+        for (int j0 = 0; j0 < N; j0 += 256) {
+            const int j = j0 + tid;
+            bool pass = false; float l = 0.f;
+            if (j < N) l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
+            const unsigned long long pb = __ballot(pass);
+            if (lane == 0) sh_cnt[w] = __popcll(pb);
+            __syncthreads();
+            int pos = run;
+            for (int u = 0; u < w; ++u) pos += sh_cnt[u];
+            pos += __popcll(pb & ((1ull << lane) - 1ull));
+            if (pass && pos < k) { li[pos] = j; lw[pos] = expf(l - M) * invz; }
+            run += sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+            __syncthreads();
+            if (run >= k) break;                                    // (block-uniform; at most k keys pass in the fixed-k modes)
+        }
+        for (int e = run + tid; e < k; e += 256) { li[e] = -1; lw[e] = 0.f; }
+    } else {
+        for (int j = tid; j < N; j += 256) {
+            bool pass;
+            const float l = gen_logit<MODE>(row[j], j, mtq, bsq, scale, T, jt, pass);
+            arow[j] = pass ? expf(l - M) * invz : 0.f;             // softmax * mask_b, dagl.py:260-261
+        }
+        for (int j = N + tid; j < ldn; j += 256) arow[j] = 0.f;
     }
-    for (int j = N + tid; j < ldn; j += 256) arow[j] = 0.f;
     const double Cn = gen_block_sum((double)cnt, shd);
     if (tid == 0 && deg != nullptr) deg[ql] = (int32_t)Cn;
 }
@@ -376,7 +407,7 @@ inline GenCorePlan gen_core_plan(const GenGeom& g, bool backward) {
     const size_t B = g.B;
     p.o_vrows = carve(B * g.N * (size_t)g.P * 4);
     p.o_dvrows = backward ? carve(B * g.N * (size_t)g.P * 4) : 0;
-    p.o_s = carve((size_t)g.Lc * g.ldn * 4);
+    p.o_s = carve((size_t)g.Lc * (g.ldn + 2 * GEN_LIST_CAP_WORDS) * 4);
     p.o_a = backward ? carve((size_t)g.Lc * g.ldn * 4) : 0;
     p.o_da = backward ? carve((size_t)g.Lc * g.ldn * 4) : 0;
     p.o_agg = carve(B * g.L * (size_t)g.P * 4);
@@ -393,6 +424,10 @@ int gen_core_forward(hipStream_t s, const GenGeom& g, float scale, int mode, int
                      const float* thr, const float* bias, int tstride, float* sbuf, float* agg, float* out, int32_t* degree) {
     int rc;
     const int kk = k < g.N ? k : g.N;                                      // top_k = min(num_edge, N), GReccR2b_3mh_1-checkpoint.py:243
+    // the lists live in the tail of the score chunk's buffer (gen_geom sizes a chunk so that Lc rows of scores AND of lists fit)
+    const bool lists = mode != DAGL_MODE_ADAPTIVE && kk <= GEN_LIST_MAX;
+    int32_t* nb_idx = reinterpret_cast<int32_t*>(sbuf + (size_t)g.Lc * g.ldn);
+    float* nb_wgt = reinterpret_cast<float*>(nb_idx + (size_t)g.Lc * GEN_LIST_MAX);
     for (int b = 0; b < g.B; ++b) {
         const float* Xb = x + (size_t)b * g.N * g.D;
         const float* Vb = vrows + (size_t)b * g.N * g.P;
@@ -400,11 +435,24 @@ int gen_core_forward(hipStream_t s, const GenGeom& g, float scale, int mode, int
             const int lc = (g.L - l0 < g.Lc) ? g.L - l0 : g.Lc;
             const float* Wqc = wq + ((size_t)b * g.L + l0) * g.D;
             if ((rc = launch_gemm32(s, gen_gemm(lc, g.N, g.D, Wqc, g.D, Xb, g.D, 1, sbuf, g.ldn, nullptr, 0)))) return rc;
+            float* aggc = agg + ((size_t)b * g.L + l0) * g.P;
+            if (lists) {
+                // fixed-k modes with short lists: (key, weight) lists out of the row kernel, then a gather over k value rows
+                if (mode == DAGL_MODE_TOPK)
+                    hipLaunchKernelGGL((gen_row_softmax_kernel<1, true>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, sbuf, sbuf, thr, bias,
+                                       tstride, degree, nb_idx, nb_wgt);
+                else
+                    hipLaunchKernelGGL((gen_row_softmax_kernel<2, true>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, sbuf, sbuf, thr, bias,
+                                       tstride, degree, nb_idx, nb_wgt);
+                DAGL_LAUNCH_CHECK("gen_row_softmax_kernel");
+                if ((rc = launch_gather_fixed(s, lc, kk, g.P, nb_idx, nb_wgt, Vb, aggc))) return rc;
+                continue;
+            }
 #define GEN_ROWS(M_) hipLaunchKernelGGL((gen_row_softmax_kernel<M_>), dim3(lc), dim3(256), 0, s, g.N, g.ldn, g.L, l0, b, kk, scale, sbuf, sbuf, thr, bias, tstride, degree)
             if (mode == DAGL_MODE_ADAPTIVE) GEN_ROWS(0); else if (mode == DAGL_MODE_TOPK) GEN_ROWS(1); else GEN_ROWS(2);
 #undef GEN_ROWS
             DAGL_LAUNCH_CHECK("gen_row_softmax_kernel");
-            if ((rc = launch_gemm32(s, gen_gemm(lc, g.P, g.N, sbuf, g.ldn, Vb, g.P, 0, agg + ((size_t)b * g.L + l0) * g.P, g.P, nullptr, 0)))) return rc;
+            if ((rc = launch_gemm32(s, gen_gemm(lc, g.P, g.N, sbuf, g.ldn, Vb, g.P, 0, aggc, g.P, nullptr, 0)))) return rc;
         }
     }
     // fold + overlap count, dagl.py:265-272
