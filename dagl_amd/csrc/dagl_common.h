@@ -39,6 +39,54 @@ __device__ __forceinline__ void glds16_asm(const float* gsrc, unsigned lds_byte_
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// two ADJACENT 1-KiB pieces under ONE M0 value (the second through the instruction's immediate offset, which advances the global
+// and the LDS address alike): a wave that changes M0 between two requests waits for the first to leave the issue stage
+__device__ __forceinline__ void glds16x2_asm(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+// N pieces whose LDS destinations are 1 KiB apart under ONE M0 value, each with a global address of its own: piece j goes out with the
+// immediate offset 1024 j -- which the hardware adds to the LDS AND the global address -- and the lane's address minus 1024 j.  What it
+// buys: a wave that changes M0 between two requests waits for the first to leave the issue stage (~240-280 cycles a piece,
+// profiles/r03_screen_ring_phases.log, r06_project16_anatomy.log); four requests behind one M0 value issue back to back.
+__device__ __forceinline__ void glds16x4_any_asm(const void* s0, const void* s1, const void* s2, const void* s3, unsigned lds_byte_addr) {
+    unsigned keep;
+    const char* a1 = static_cast<const char*>(s1) - 1024;
+    const char* a2 = static_cast<const char*>(s2) - 2048;
+    const char* a3 = static_cast<const char*>(s3) - 3072;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\tglobal_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(s0), "v"(a1), "v"(a2), "v"(a3), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void glds16x2_any_asm(const void* s0, const void* s1, unsigned lds_byte_addr) {
+    unsigned keep;
+    const char* a1 = static_cast<const char*>(s1) - 1024;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(s0), "v"(a1), "s"(lds_byte_addr)
+                 : "memory");
+}
+// two pieces under one M0 value at LDS offsets OFF0 / OFF1 (< 4096) from the M0 base
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void glds16x2_off_asm(const void* s0, const void* s1, unsigned lds_byte_addr) {
+    static_assert(OFF0 >= 0 && OFF0 < 4096 && OFF1 >= 0 && OFF1 < 4096, "13-bit immediate offset");
+    unsigned keep;
+    const char* a0 = static_cast<const char*>(s0) - OFF0;
+    const char* a1 = static_cast<const char*>(s1) - OFF1;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%4\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:%5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(a0), "v"(a1), "s"(lds_byte_addr), "n"(OFF0), "n"(OFF1)
+                 : "memory");
+}
 // A whole 27-KiB key tile of the screen (27 pieces of 1 KiB) requested by ONE wave in one statement: wave-uniform source
 // base in SGPRs + a 32-bit lane offset, four pieces per M0 value through the instruction's immediate offset (it advances the
 // global AND the LDS address), M0 saved / restored once.  The per-piece form above costs the issuing wave ~280 cycles a piece

@@ -325,11 +325,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
     }
     // LDS-DMA: a piece = 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 holds logical slot (l & 3) ^ ((row >> 2) & 3)
     const int prow = lane >> 2, pslot = (lane & 3) ^ ((prow >> 2) & 3);
-    auto stage = [&](int buf, int nt, long long k) {        // operand tiles of column tile nt of this block, contraction offset k
-        const unsigned dst = lds0 + (unsigned)buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < PIECES / NW; ++j) {
-            const int p = wave * (PIECES / NW) + j;                               // A hi | A lo | B hi | B lo, 16-row groups
+    auto piece_src = [&](int p, int nt, long long k) -> const unsigned short* {
+            // A hi | A lo | B hi | B lo, 16-row groups
             const bool is_a = p < 2 * (BM / 16);
             const int q = is_a ? p : p - 2 * (BM / 16);
             const int per = is_a ? BM / 16 : BN / 16;
@@ -351,8 +348,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NS == 2) ? 2 : 1) vo
                 const int px = kl & ((1 << g.im_logw) - 1), dy = kl >> g.im_logw;
                 src = base + (long long)(kw * CH + c) * g.im_plane + ((long long)(im_row0 + dy + kh) << g.im_logw) + px;
             }
-            glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024));
+            return src;
+    };
+    auto stage = [&](int buf, int nt, long long k) {        // operand tiles of column tile nt of this block, contraction offset k
+        const unsigned dst = lds0 + (unsigned)buf * STAGE;
+        const int p0 = wave * PPW;                            // a wave's pieces are consecutive: 1 KiB apart in the LDS
+#if defined(DAGL_G16_M0_PER_PIECE)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            glds16_asm(reinterpret_cast<const float*>(piece_src(p0 + j, nt, k)), __builtin_amdgcn_readfirstlane(dst + (unsigned)(p0 + j) * 1024));
+#else
+        // four requests per M0 value (glds16x4_any_asm): with one M0 value per piece the requests were what a step waited for
+#pragma unroll
+        for (int j = 0; j + 4 <= PPW; j += 4)
+            glds16x4_any_asm(piece_src(p0 + j, nt, k), piece_src(p0 + j + 1, nt, k), piece_src(p0 + j + 2, nt, k), piece_src(p0 + j + 3, nt, k),
+                             __builtin_amdgcn_readfirstlane(dst + (unsigned)(p0 + j) * 1024));
+        if (PPW % 4 >= 2) {
+            constexpr int j = PPW / 4 * 4;
+            glds16x2_any_asm(piece_src(p0 + j, nt, k), piece_src(p0 + j + 1, nt, k), __builtin_amdgcn_readfirstlane(dst + (unsigned)(p0 + j) * 1024));
         }
+        if (PPW % 2 == 1) {
+            constexpr int j = PPW - 1;
+            glds16_asm(reinterpret_cast<const float*>(piece_src(p0 + j, nt, k)), __builtin_amdgcn_readfirstlane(dst + (unsigned)(p0 + j) * 1024));
+        }
+#endif
     };
     f32x16 acc[2][2];
 #pragma unroll

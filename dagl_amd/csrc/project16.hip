@@ -662,6 +662,23 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
 #endif
         const unsigned st = lds0 + (unsigned)(t % P16_RING) * P16_STAGE2_B;
         const unsigned short* wsrc = wp + (size_t)t * P16_SLICE_H;
+#if !defined(DAGL_P16_M0_PER_PIECE)
+        // a wave's pieces are ADJACENT, so that two of them go out under one M0 value (glds16x2_asm); same pieces per wave as below
+        if (PBASE == 2 && (PIECES % P16_BW) == 0) {
+            const int p = 2 * wave;
+            glds16x2_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+        } else if (PBASE == 1) {
+            const int nx = PIECES % P16_BW;                                   // waves carrying two pieces
+            if (extra) {
+                const int p = 2 * wave;
+                glds16x2_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+            } else {
+                const int p = nx + wave;
+                glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int j = 0; j < PBASE; ++j) {
             const int p = wave + P16_BW * j;
@@ -670,6 +687,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
         if (extra) {
             const int p = wave + P16_BW * PBASE;
             glds16_asm(reinterpret_cast<const float*>(wsrc + (size_t)p * 512 + lane * 8), __builtin_amdgcn_readfirstlane(st + p * 1024));
+        }
         }
     };
     // ---- patch operand plumbing (per item) ---------------------------------------------------------------------------------------
@@ -694,6 +712,21 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
             if (it > 0) break;           // (timing experiment, wrong results: half of the key-row LDS-DMA -- what a block shared by both tile groups would issue)
 #endif
             const unsigned dst = lds0 + P16_OFF_A2 + (wave * PW + it) * (2 * P16_AROW) + (r & 1) * P16_AROW;
+#if !defined(DAGL_P16_M0_PER_PIECE)
+            // pieces: hi px 0-31, hi px 32-43 (24 lanes), lo px 0-31, lo px 32-43 -- the two whole ones and the two partial ones each under ONE
+            // M0 value (glds16x2_off_asm; hi and lo of a pixel sit at the same offset of their maps)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int p = half * 32 + (lane >> 1);
+                int row = gy[it] + r, px = gx0[it] + p;
+                if (p >= nA[it] + 6) { row += 1; px = p - (nA[it] + 6); }
+                if (px > gr.Wp - 1) px = gr.Wp - 1;                                   // stay inside the map
+                if (row > gr.Hp - 1) row = gr.Hp - 1;
+                const size_t o = krow0 + ((size_t)row * gr.Wp + px) * CH + 8 * (lane & 1);
+                if (half == 0) glds16x2_off_asm<0, P16_APART>(tier.hi + o, tier.lo + o, __builtin_amdgcn_readfirstlane(dst));
+                else if (lane < 2 * (P16_APX - 32)) glds16x2_off_asm<1024, P16_APART + 1024>(tier.hi + o, tier.lo + o, __builtin_amdgcn_readfirstlane(dst));
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // pieces: hi px 0-31, hi px 32-43 (24 lanes), lo px 0-31, lo px 32-43
                 const int p = (j & 1) * 32 + (lane >> 1);
@@ -705,6 +738,7 @@ __device__ __forceinline__ void project16_body2(const Proj16Args& pa, unsigned c
                 const unsigned d = dst + (j >> 1) * P16_APART + (j & 1) * 1024;
                 if ((j & 1) == 0 || lane < 2 * (P16_APX - 32)) glds16_asm(reinterpret_cast<const float*>(src), __builtin_amdgcn_readfirstlane(d));
             }
+#endif
         }
     };
     auto issue_q = [&](int t) {                        // queries: the 16 B of tap t this lane will read back, both items
