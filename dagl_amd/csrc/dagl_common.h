@@ -108,6 +108,27 @@ __device__ __forceinline__ void glds_tile27_asm(const void* src_uniform, unsigne
 #undef DAGL_G4
 #undef DAGL_ADV
 }
+// the same tile with EIGHT pieces per M0 value: immediate offsets -4096 .. +3072 around an M0 base four pieces in (the 13-bit offset is
+// signed for the LDS address as for the global one: 27 pieces under 4 M0 values instead of 7; the filter pass -0.4 us, r06_ab_m0_pairs.log)
+__device__ __forceinline__ void glds_tile27_x8_asm(const void* src_uniform, unsigned lane_byte_off, unsigned lds_byte_addr) {
+    unsigned keep;
+    lane_byte_off += 4096u;
+#define DAGL_G8 "global_load_lds_dwordx4 %1, %2 offset:-4096\n\tglobal_load_lds_dwordx4 %1, %2 offset:-3072\n\t" \
+                "global_load_lds_dwordx4 %1, %2 offset:-2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:-1024\n\t" \
+                "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t" \
+                "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+#define DAGL_ADV8 "v_add_u32 %1, 0x2000, %1\n\ts_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, 0x1000\n\ts_nop 4\n\t"
+                 DAGL_G8 DAGL_ADV8 DAGL_G8 DAGL_ADV8 DAGL_G8 DAGL_ADV8
+                 "global_load_lds_dwordx4 %1, %2 offset:-4096\n\tglobal_load_lds_dwordx4 %1, %2 offset:-3072\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(lane_byte_off)
+                 : "s"(src_uniform), "s"(lds_byte_addr)
+                 : "memory");
+#undef DAGL_G8
+#undef DAGL_ADV8
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // counted form: returns once at most N of this wave's vector-memory operations are outstanding (loads land in issue order, so
 // everything but the N youngest has arrived)

@@ -439,8 +439,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void screen_ring_kernel(ScreenArgs a
                     const unsigned long long sa = (unsigned long long)(uintptr_t)(xb + (size_t)(step0 + T * stride) * STEP_ELEMS);
                     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa);
                     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32));
+#if !defined(DAGL_TILE27_X4)
+                    glds_tile27_x8_asm(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)lane * 16u,
+                                       __builtin_amdgcn_readfirstlane(dst));
+#else
                     glds_tile27_asm(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)lane * 16u,
                                     __builtin_amdgcn_readfirstlane(dst));
+#endif
                 }
                 pend_tile = T;
             }
